@@ -1,0 +1,191 @@
+/*
+ * marius_hip.h — C-ABI of libmarius_hip.so: the MI355X (gfx950) kernels behind Marius's link-prediction
+ * training hot path.  Plain pointers and sizes only; no torch types.  All device pointers are HBM addresses
+ * on the current HIP device; `stream` is a hipStream_t (NULL = default stream).  Every entry point returns
+ * MARIUS_OK (0) or an error code; marius_hip_last_error() gives the message.  Nothing here allocates or frees
+ * device memory and nothing synchronises the device: calls only enqueue work on `stream`.
+ *
+ * The reference (marius-team/marius) has NO FFI boundary for this path: its operator API is C++ classes over
+ * torch::Tensor.  Each entry point below names the reference function(s) it replaces (paths relative to
+ * /root/reference/src/cpp); the C++ host classes in marius_amd/csrc/host keep the reference's class/method
+ * names and call these.  INTEGRATION.md shows the binding a reference maintainer would add.
+ */
+#ifndef MARIUS_HIP_H
+#define MARIUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* marius_stream_t; /* hipStream_t */
+
+enum { MARIUS_OK = 0, MARIUS_ERR_INVALID = 1, MARIUS_ERR_HIP = 2, MARIUS_ERR_UNSUPPORTED = 3 };
+
+/* RelationOperator subclasses: include/nn/decoders/edge/relation_operators.h:11-43 */
+enum { MARIUS_OP_HADAMARD = 0, MARIUS_OP_COMPLEX_HADAMARD = 1, MARIUS_OP_TRANSLATION = 2, MARIUS_OP_NOOP = 3 };
+/* Comparator subclasses: include/nn/decoders/edge/comparators.h:13-35 */
+enum { MARIUS_CMP_DOT = 0, MARIUS_CMP_L2 = 1, MARIUS_CMP_COSINE = 2 };
+/* LossReduction: include/configuration/options.h */
+enum { MARIUS_REDUCE_SUM = 0, MARIUS_REDUCE_MEAN = 1 };
+
+int marius_hip_abi_version(void);
+const char* marius_hip_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------ storage */
+
+/* out[i, 0:d] = table[ids[i], 0:d]            replaces InMemory::indexRead  src/storage/storage.cpp:606-649
+ *                                             (PartitionBuffer::indexRead    src/storage/buffer.cpp:441-455)   */
+int marius_gather_rows(const float* table, int64_t table_ld, const int64_t* ids, int64_t n, int32_t d,
+                       float* out, int64_t out_ld, marius_stream_t stream);
+
+/* both node tables with one id list (embeddings + Adagrad state): DataLoader::loadGPUParameters
+ * src/data/dataloader.cpp:529-548 */
+int marius_gather_rows2(const float* table_a, const float* table_b, int64_t table_ld, const int64_t* ids, int64_t n,
+                        int32_t d, float* out_a, float* out_b, int64_t out_ld, marius_stream_t stream);
+
+/* table[ids[i], 0:d] += delta[i, 0:d]; ids UNIQUE (reference contract)   replaces InMemory::indexAdd
+ * src/storage/storage.cpp:651-673 (PartitionBuffer::indexAdd src/storage/buffer.cpp:460-480). No atomics. */
+int marius_scatter_add_rows(float* table, int64_t table_ld, const int64_t* ids, int64_t n, int32_t d,
+                            const float* delta, int64_t delta_ld, marius_stream_t stream);
+
+/* ds = g*g; state += ds; dw = -lr * g / (sqrt(state) + eps)     replaces Batch::accumulateGradients
+ * src/data/batch.cpp:62-79 (eps = 1e-10 there). n = number of floats. */
+int marius_adagrad_rule(const float* grad, float* state, float* dw, float* ds, int64_t n, float lr, float eps,
+                        marius_stream_t stream);
+
+/* dense AdagradOptimizer::step  src/nn/optim.cpp:114-145:  sum += g*g; w -= lr * g / (sqrt(sum) + eps) */
+int marius_dense_adagrad_step(float* param, float* state_sum, const float* grad, int64_t n, float lr, float eps,
+                              float weight_decay, marius_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ sampling */
+
+/* ATen CPU generator stream (at::mt19937 as used by torch::randint / torch::randperm on CPU tensors).
+ * state = 624 words + [624] = index of next word (624 => twist first).  Host helpers are plain C. */
+#define MARIUS_MT_STATE_WORDS 625
+void marius_mt19937_seed_host(uint32_t* state_host, uint64_t seed);            /* torch::manual_seed, src/marius.cpp:47 */
+void marius_mt19937_fill_host(uint32_t* state_host, uint32_t* out, int64_t n); /* n raw 32-bit draws */
+/* torch::randperm(n) on the CPU generator: DataLoader::setActiveEdges src/data/dataloader.cpp:176-182 */
+int marius_mt19937_randperm_host(uint32_t* state_host, int64_t* out, int64_t n);
+
+/* n raw tempered 32-bit draws from a DEVICE-resident state (advances it).  One workgroup; stream-ordered. */
+int marius_mt19937_fill(uint32_t* state_dev, uint32_t* out_dev, int64_t n, marius_stream_t stream);
+
+/* number of raw 32-bit words one getNegatives() call consumes */
+int64_t marius_negatives_raw_words(int64_t num_nodes, int64_t B, int32_t num_chunks, int32_t num_negatives,
+                                   int32_t num_deg);
+
+/* raw words -> negative ids.   replaces CorruptNodeNegativeSampler::getNegatives src/data/samplers/negative.cpp:328-366
+ * and batch_sample :7-19.  Per chunk: (N - num_deg) uniform ids `draw % num_nodes` (drawn first), then num_deg edge
+ * positions `draw % B`; row layout cat({deg, uniform}).  range >= 2^28 consumes two words per draw (ATen).
+ * edges: [B, edge_cols] int64; inverse != 0 -> column 0 (src) else last column (dst).
+ * out_ids [C, N] int64; deg_pos [C, num_deg] int64 (sampled edge positions; may be NULL when num_deg == 0). */
+int marius_sample_negatives(const uint32_t* raw, const int64_t* edges, int64_t B, int32_t edge_cols, int32_t inverse,
+                            int64_t num_nodes, int32_t num_chunks, int32_t num_negatives, int32_t num_deg,
+                            int64_t* out_ids, int64_t* deg_pos, marius_stream_t stream);
+
+/* out[i, :] = edges[perm[start + i], :] cast to int64      replaces active_edges_ index_select + RandomEdgeSampler::getEdges
+ * src/data/dataloader.cpp:180-182, src/data/samplers/edge.cpp:12-14.  edges_in is int32 or int64 ([E, cols]). */
+int marius_select_edges(const void* edges_in, int32_t in_is_int64, int32_t cols, const int64_t* perm, int64_t start,
+                        int64_t B, int64_t* out, marius_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ unique map */
+
+size_t marius_sort_unique_workspace_bytes(int64_t n);
+/* replaces map_tensors src/common/util.cpp:180-205 (_unique2 sorted + inverse).
+ * ids[n] int64 (>= 0) -> uniq[<=n] ascending, inverse[n] (index into uniq per input position),
+ * perm[n] (input position of the k-th smallest id; stable), seg_offsets[<=n+1] (run starts in sorted order),
+ * *num_unique_dev (device int64).  key_bits = number of significant id bits (<= 63). */
+int marius_sort_unique(const int64_t* ids, int64_t n, int32_t key_bits, int64_t* uniq, int64_t* inverse, int32_t* perm,
+                       int32_t* seg_offsets, int64_t* num_unique_dev, void* workspace, size_t workspace_bytes,
+                       marius_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ decoder */
+
+/* Descriptor of one CORRUPT_NODE link-prediction batch in batch-local ids (after map_tensors):
+ * everything Model::forward_lp / train_batch (src/nn/model.cpp:252-333) reads. */
+typedef struct marius_lp_desc {
+    int32_t relop;        /* MARIUS_OP_*  */
+    int32_t cmp;          /* MARIUS_CMP_* */
+    int32_t d;            /* embedding dim */
+    int32_t edge_cols;    /* 3 = (src, rel, dst), 2 = (src, dst) */
+    int64_t B;            /* positives */
+    int32_t C;            /* num_chunks */
+    int32_t N;            /* negatives per chunk */
+    int32_t use_inverse;  /* decoder->use_inverse_relations_ (needs edge_cols == 3) */
+    int32_t reduction;    /* MARIUS_REDUCE_* */
+    const float* emb;     /* [U, emb_ld] batch node embeddings (Batch::node_embeddings_) */
+    int64_t emb_ld;
+    int64_t U;            /* rows in emb (upper bound is fine; only used for validation) */
+    const int64_t* edges; /* [B, edge_cols] batch-local (Batch::edges_) */
+    const int64_t* dst_neg; /* [C, N] batch-local (Batch::dst_neg_indices_mapping_) */
+    const int64_t* src_neg; /* [C, N] or NULL (Batch::src_neg_indices_mapping_) */
+    const float* rel;     /* [R, rel_ld] relation_embeddings (EdgeDecoder::relations_) or NULL */
+    const float* inv_rel; /* [R, rel_ld] inverse_relation_embeddings or NULL */
+    int64_t rel_ld;
+    int64_t R;
+    const int64_t* dst_filter; /* [n_dst_filter, 2] (edge, negative column) -> score -1e9, or NULL */
+    int64_t n_dst_filter;
+    const int64_t* src_filter;
+    int64_t n_src_filter;
+} marius_lp_desc;
+
+/* Workspace layout (all offsets in BYTES from the workspace base; dir 0 = (src,rel)->dst "rhs", dir 1 = inverse "lhs").
+ * Bp = C * ceil(B / C) (pad_and_reshape, comparators.cpp:7-20); n_ld = N rounded up to 4. */
+typedef struct marius_lp_layout {
+    int64_t Bp, n_ld, d_ld;
+    size_t total_bytes;
+    size_t adj[2];    /* [Bp, d_ld]  op(src, rel) rows (zero rows for i >= B)                                   */
+    size_t pos[2];    /* [Bp]        positive scores (zero padded)  -> forward_lp pos / inv_pos                  */
+    size_t neg[2];    /* [Bp, n_ld]  negative scores                -> forward_lp neg / inv_neg                  */
+    size_t lse[2];    /* [Bp]        log(e^pos + sum_j e^neg)                                                    */
+    size_t rowloss[2];/* [Bp]        per-row loss                                                                */
+    size_t loss;      /* [4] floats: total, dir0, dir1, unused                                                   */
+    size_t dadj[2];   /* [Bp, d_ld]  dL/d adj (negative part)                                                    */
+    size_t gocc;      /* [2B + 2CN, d] occurrence gradients in map_tensors order (src, dst, src_neg, dst_neg)    */
+    size_t grel[2];   /* [B, d]      per-edge relation gradients (dir 0 -> relations_, dir 1 -> inverse)         */
+    size_t aux;       /* scratch (row norms etc.)                                                                */
+} marius_lp_layout;
+
+int marius_lp_plan(const marius_lp_desc* desc, marius_lp_layout* layout);
+
+/* forward_lp: encoder pass-through + node_corrupt_forward (src/nn/decoders/edge/decoder_methods.cpp:57-114:
+ * select_relations, apply_relation, compute_scores for both directions, pos padding) + apply_score_filter
+ * (src/data/samplers/negative.cpp:306-311).  Fills adj/pos/neg. */
+int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_layout* layout, void* workspace, marius_stream_t stream);
+
+/* SoftmaxCrossEntropy (src/nn/loss.cpp:50-67) of both directions, summed (model.cpp:309-312). Fills lse/rowloss/loss. */
+int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout* layout, void* workspace, marius_stream_t stream);
+
+/* loss.backward() (model.cpp:324) restricted to this graph: fills gocc (per-occurrence node gradients) and grel. */
+int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_layout* layout, void* workspace, marius_stream_t stream);
+
+/* ranks = (neg >= pos[:,None]).sum(1) + 1   replaces LinkPredictionReporter::computeRanks src/reporting/reporting.cpp:55-57 */
+int marius_compute_ranks(const float* pos, const float* neg, int64_t rows, int32_t N, int64_t neg_ld, int64_t* ranks,
+                         marius_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ gradient reduce */
+
+/* Segmented row sum in sorted-id order (autograd's index_select backward = index_add_, src/nn/model.cpp:324), no atomics:
+ *   out[r(u), 0:d] = sum_{k in [seg_offsets[u], seg_offsets[u+1])} rows[perm[k], 0:d],  r(u) = out_rows ? out_rows[u] : u
+ * perm / inverse / seg_offsets come from marius_sort_unique over the n occurrence ids (n = rows in `rows`).
+ * With out_rows = the unique relation ids this builds the dense relation gradient (rows not hit stay untouched).
+ * carry: scratch of marius_segment_carry_bytes(n, d) bytes. */
+size_t marius_segment_carry_bytes(int64_t n, int32_t d);
+int marius_segment_sum_rows(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
+                            const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* out_rows, float* out,
+                            int64_t out_ld, void* carry, marius_stream_t stream);
+
+/* Fused tail of the step: segmented sum + Batch::accumulateGradients (src/data/batch.cpp:62-79) + both indexAdd calls of
+ * DataLoader::updateEmbeddings (src/data/dataloader.cpp:550-564):
+ *   g = sum rows; ds = g*g; s = state[id] + ds; table[id] += -lr*(g/(sqrt(s)+eps)); state[id] = s   (uniq_ids ascending, unique) */
+int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
+                                   const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* uniq_ids, float* table,
+                                   float* state, int64_t table_ld, float lr, float eps, void* carry, marius_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARIUS_HIP_H */

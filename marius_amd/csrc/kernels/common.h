@@ -1,0 +1,57 @@
+// Shared helpers for the gfx950 kernels of libmarius_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "marius_hip.h"
+
+namespace marius {
+
+void set_last_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error("%s: %s", what, hipGetErrorString(e));
+        return MARIUS_ERR_HIP;
+    }
+    return MARIUS_OK;
+}
+
+#define MARIUS_REQUIRE(cond, ...)             \
+    do {                                      \
+        if (!(cond)) {                        \
+            marius::set_last_error(__VA_ARGS__); \
+            return MARIUS_ERR_INVALID;        \
+        }                                     \
+    } while (0)
+
+inline hipStream_t as_stream(marius_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// vector width usable for rows of `d` floats starting at multiples of `ld` floats from a 16-B aligned base
+inline int row_vec_width(const void* base, int64_t ld, int d) {
+    uintptr_t p = reinterpret_cast<uintptr_t>(base);
+    if ((d % 4 == 0) && (ld % 4 == 0) && (p % 16 == 0)) return 4;
+    if ((d % 2 == 0) && (ld % 2 == 0) && (p % 8 == 0)) return 2;
+    return 1;
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace marius

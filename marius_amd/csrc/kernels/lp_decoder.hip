@@ -1,0 +1,897 @@
+// CORRUPT_NODE link-prediction decoder: forward scores, SoftmaxCE, hand-derived backward.  gfx950 only.
+//
+// Reference path replaced (src/cpp/src): nn/decoders/edge/decoder_methods.cpp:57-114 (node_corrupt_forward),
+// relation_operators.cpp:7-47, comparators.cpp:7-73, data/samplers/negative.cpp:306-311 (apply_score_filter),
+// nn/loss.cpp:50-67 (SoftmaxCrossEntropy), and the autograd backward of all of these (nn/model.cpp:324).
+//
+// Work split per batch (dir 0 = (src,rel)->dst with dst negatives, dir 1 = (dst,inv_rel)->src with src negatives):
+//   prep      adj = op(e, r) rows [Bp, d] (zero rows for the pad_and_reshape padding), pos = cmp(adj, other)      HBM-bound
+//   scores    S_c = adj_c [Bc x d] . Neg_c^T [d x N] per (chunk, dir): batched NT contraction, FP32 MFMA 32x32x2   MFMA-bound
+//   filter    S[e][k] = -1e9                                                                                       tiny
+//   lse       per-row logsumexp over {pos, S row}, row loss                                                        HBM-bound (reads S once)
+//   grad_adj  dAdj_c [Bc x d] = V_c [Bc x N] . Neg_c [N x d],  V = dL/dS (exp(S - lse), L2: -q/S), made on the fly MFMA-bound
+//   grad_neg  dNeg_c [N x d]  = V_c^T [N x Bc] . adj_c [Bc x d]                                                     MFMA-bound
+//   edge_bwd  positive-score gradient + relation-operator backward -> per-occurrence node grads, per-edge rel grads HBM-bound
+// The negative rows are gathered by batch-local index straight into LDS (the "LDS-staged transpose": fragments are
+// read from LDS in MFMA operand order, no transposed copy ever exists in HBM).  No atomics anywhere: every output
+// element has exactly one owner workgroup.
+#include "lp_common.h"
+
+namespace marius {
+
+// =========================================================================================== prep
+struct PrepArgs {
+    const float* emb;
+    int64_t emb_ld;
+    const int64_t* edges;
+    const float* rel[2];
+    int64_t rel_ld;
+    float* adj;  // [ndir][Bp, d_ld]
+    float* pos;  // [ndir][Bp]
+    float* x2;   // [ndir][Bp] (L2) or null
+    LpDims D;
+};
+
+__device__ __forceinline__ float relop_fwd(int relop, const float* e, const float* r, int c, int d) {
+#pragma clang fp contract(off)
+    switch (relop) {
+        case MARIUS_OP_HADAMARD: return e[c] * r[c];
+        case MARIUS_OP_TRANSLATION: return e[c] + r[c];
+        case MARIUS_OP_COMPLEX_HADAMARD: {
+            const int h = d / 2;
+            if (c < h) return (e[c] * r[c]) - (e[c + h] * r[c + h]);
+            return (e[c - h] * r[c]) + (e[c] * r[c - h]);
+        }
+        default: return e[c];
+    }
+}
+
+// one wave per (row, dir); lanes stride over d
+__global__ __launch_bounds__(256) void lp_prep_kernel(PrepArgs a) {
+#pragma clang fp contract(off)
+    const LpDims& D = a.D;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t total = D.Bp * D.ndir;
+    if (wave >= total) return;
+    const int dir = (int)(wave / D.Bp);
+    const int64_t i = wave - (int64_t)dir * D.Bp;
+    float* adj = a.adj + ((int64_t)dir * D.Bp + i) * D.d_ld;
+    if (i >= D.B) {  // pad_and_reshape zero rows; F.pad zero positives
+        for (int c = lane; c < D.d_ld; c += 64) adj[c] = 0.f;
+        if (lane == 0) {
+            a.pos[(int64_t)dir * D.Bp + i] = 0.f;
+            if (a.x2) a.x2[(int64_t)dir * D.Bp + i] = 0.f;
+        }
+        return;
+    }
+    const int64_t* ed = a.edges + i * D.edge_cols;
+    const int64_t s = ed[0], t = ed[D.edge_cols - 1];
+    const float* e = a.emb + (dir == 0 ? s : t) * a.emb_ld;
+    const float* o = a.emb + (dir == 0 ? t : s) * a.emb_ld;
+    const bool has_rel = (D.edge_cols == 3) && (a.rel[dir] != nullptr);
+    const float* r = has_rel ? a.rel[dir] + ed[1] * a.rel_ld : nullptr;
+    float acc = 0.f, nrm = 0.f;
+    for (int c = lane; c < D.d_ld; c += 64) {
+        float v = 0.f;
+        if (c < D.d) {
+            v = has_rel ? relop_fwd(D.relop, e, r, c, D.d) : e[c];
+            const float ov = o[c];
+            if (D.cmp == MARIUS_CMP_L2) {
+                const float df = (v - ov) + 1e-6f;  // pairwise_distance: ||x1 - x2 + eps||
+                acc += df * df;
+                nrm += v * v;
+            } else {
+                acc += v * ov;
+            }
+        }
+        adj[c] = v;
+    }
+    acc = wave_sum(acc);
+    if (D.cmp == MARIUS_CMP_L2) {
+        nrm = wave_sum(nrm);
+        acc = sqrtf(acc);
+    }
+    if (lane == 0) {
+        a.pos[(int64_t)dir * D.Bp + i] = acc;
+        if (a.x2) a.x2[(int64_t)dir * D.Bp + i] = nrm;
+    }
+}
+
+// L2 only: y2[dir][c*N + j] = ||neg row||^2
+__global__ __launch_bounds__(256) void lp_negnorm_kernel(const float* emb, int64_t emb_ld, const int64_t* neg0, const int64_t* neg1,
+                                                         int64_t CN, int d, int ndir, float* y2) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave >= CN * ndir) return;
+    const int dir = (int)(wave / CN);
+    const int64_t j = wave - dir * CN;
+    const float* row = emb + (dir == 0 ? neg0 : neg1)[j] * emb_ld;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += row[c] * row[c];
+    s = wave_sum(s);
+    if (lane == 0) y2[wave] = s;
+}
+
+// =========================================================================================== scores (F)
+struct ScoreArgs {
+    const float* adj;  // [ndir][Bp, d_ld]
+    const float* emb;
+    int64_t emb_ld;
+    int emb_vec;
+    const int64_t* negmap[2];  // [C, N] batch-local
+    float* S;                  // [ndir][Bp, n_ld]
+    const float* x2;           // L2
+    const float* y2;           // L2
+    int KC, KS, nkc, dk;
+    LpDims D;
+};
+
+constexpr int F_TM = 128, F_TN = 128;
+
+template <bool L2>
+__global__ __launch_bounds__(256) void lp_scores_kernel(ScoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LpDims& D = a.D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int dir = blockIdx.z / D.C, c = blockIdx.z - dir * D.C;
+    const int m0 = blockIdx.y * F_TM, n0 = blockIdx.x * F_TN;
+    const int KS = a.KS;
+    float* As = smem;
+    float* Bs = smem + F_TM * KS;
+    const float* adj = a.adj + ((int64_t)dir * D.Bp + (int64_t)c * D.Bc) * D.d_ld;
+    const int64_t* negmap = a.negmap[dir] + (int64_t)c * D.N;
+
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int piece = tid & 15, rbase = tid >> 4;  // 16 threads per row, 16 rows per pass
+    // negative row pointers for the 8 rows this thread stages
+    const float* nrow[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int n = n0 + rbase + 16 * it;
+        nrow[it] = (n < D.N) ? a.emb + negmap[n] * a.emb_ld : nullptr;
+    }
+
+    for (int kc = 0; kc < a.nkc; ++kc) {
+        const int k0 = kc * a.KC;
+        const int kcur = min(a.KC, a.dk - k0);
+        if (4 * piece < kcur) {
+            const int k = k0 + 4 * piece;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = rbase + 16 * it;
+                const int m = m0 + row;
+                float4 va = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < D.Bc) va = *reinterpret_cast<const float4*>(adj + (int64_t)m * D.d_ld + k);
+                float4 vb = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (nrow[it]) vb = load_row4(nrow[it], k, D.d, a.emb_vec);
+                float* pa = As + row * KS + 4 * piece;
+                float* pb = Bs + row * KS + 4 * piece;
+                *reinterpret_cast<float2*>(pa) = make_float2(va.x, va.y);
+                *reinterpret_cast<float2*>(pa + 2) = make_float2(va.z, va.w);
+                *reinterpret_cast<float2*>(pb) = make_float2(vb.x, vb.y);
+                *reinterpret_cast<float2*>(pb + 2) = make_float2(vb.z, vb.w);
+            }
+        }
+        __syncthreads();
+        const float* ap = As + (wm * 64 + l31) * KS + 2 * h;
+        const float* bp = Bs + (wn * 64 + l31) * KS + 2 * h;
+        const int nq = kcur >> 2;
+        for (int q = 0; q < nq; ++q) {
+            const float2 a0 = *reinterpret_cast<const float2*>(ap + 4 * q);
+            const float2 a1 = *reinterpret_cast<const float2*>(ap + 32 * KS + 4 * q);
+            const float2 b0 = *reinterpret_cast<const float2*>(bp + 4 * q);
+            const float2 b1 = *reinterpret_cast<const float2*>(bp + 32 * KS + 4 * q);
+            acc[0][0] = mfma32(a0.x, b0.x, acc[0][0]);
+            acc[0][1] = mfma32(a0.x, b1.x, acc[0][1]);
+            acc[1][0] = mfma32(a1.x, b0.x, acc[1][0]);
+            acc[1][1] = mfma32(a1.x, b1.x, acc[1][1]);
+            acc[0][0] = mfma32(a0.y, b0.y, acc[0][0]);
+            acc[0][1] = mfma32(a0.y, b1.y, acc[0][1]);
+            acc[1][0] = mfma32(a1.y, b0.y, acc[1][0]);
+            acc[1][1] = mfma32(a1.y, b1.y, acc[1][1]);
+        }
+        __syncthreads();
+    }
+
+    float* S = a.S + ((int64_t)dir * D.Bp + (int64_t)c * D.Bc) * D.n_ld;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int n = n0 + wn * 64 + tn * 32 + l31;
+            float yy = 0.f;
+            if (L2 && n < D.N) yy = a.y2[(int64_t)dir * D.C * D.N + (int64_t)c * D.N + n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + tm * 32 + acc_row(r, h);
+                if (m < D.Bc && n < D.N) {
+                    float v = acc[tm][tn][r];
+                    if (L2) {
+#pragma clang fp contract(off)
+                        const float xx = a.x2[(int64_t)dir * D.Bp + (int64_t)c * D.Bc + m];
+                        const float t = (xx + yy) - 2.f * v;  // comparators.cpp:37 x2 + y2 - 2*xy
+                        v = sqrtf(fmaxf(t, 1e-8f));
+                    }
+                    S[(int64_t)m * D.n_ld + n] = v;
+                }
+            }
+        }
+}
+
+// =========================================================================================== filter / lse / loss
+__global__ __launch_bounds__(256) void lp_filter_kernel(float* S, int64_t n_ld, int64_t Bp, int N, const int64_t* filt, int64_t nf) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nf; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = filt[2 * t], k = filt[2 * t + 1];
+        if (e >= 0 && e < Bp && k >= 0 && k < N) S[e * n_ld + k] = -1e9f;
+    }
+}
+
+// one wave per (row, dir): lse = log(e^pos + sum_j e^S_j); rowloss = lse - pos
+__global__ __launch_bounds__(256) void lp_lse_kernel(const float* __restrict__ S, int64_t n_ld, const float* __restrict__ pos,
+                                                     int64_t rows, int N, float* __restrict__ lse, float* __restrict__ rowloss) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* s = S + row * n_ld;
+    const float p = pos[row];
+    float m = p;
+    const int n4 = N >> 2;
+    for (int c = lane; c < n4; c += 64) {
+        const float4 v = reinterpret_cast<const float4*>(s)[c];
+        m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    for (int c = (n4 << 2) + lane; c < N; c += 64) m = fmaxf(m, s[c]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int c = lane; c < n4; c += 64) {
+        const float4 v = reinterpret_cast<const float4*>(s)[c];
+        sum += (__expf(v.x - m) + __expf(v.y - m)) + (__expf(v.z - m) + __expf(v.w - m));
+    }
+    for (int c = (n4 << 2) + lane; c < N; c += 64) sum += __expf(s[c] - m);
+    sum = wave_sum(sum);
+    if (lane == 0) {
+        sum += __expf(p - m);
+        const float l = m + __logf(sum);
+        lse[row] = l;
+        rowloss[row] = l - p;
+    }
+}
+
+// deterministic sum of rowloss per dir -> loss[1 + dir]; loss[0] = total (lhs + rhs, model.cpp:309-312)
+__global__ __launch_bounds__(1024) void lp_loss_reduce_kernel(const float* rowloss, int64_t Bp, int ndir, float scale, float* loss) {
+    __shared__ float red[1024];
+    float tot = 0.f;
+    for (int dir = 0; dir < ndir; ++dir) {
+        float s = 0.f;
+        for (int64_t i = threadIdx.x; i < Bp; i += 1024) s += rowloss[(int64_t)dir * Bp + i];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            loss[1 + dir] = red[0] * scale;
+            tot += red[0] * scale;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        loss[0] = tot;
+        if (ndir == 1) loss[2] = 0.f;
+        loss[3] = 0.f;
+    }
+}
+
+// =========================================================================================== backward contractions
+struct GradArgs {
+    const float* S;
+    const float* lse;  // [ndir][Bp]
+    const float* adj;  // [ndir][Bp, d_ld]
+    const float* emb;
+    int64_t emb_ld;
+    int emb_vec;
+    const int64_t* negmap[2];
+    float* dadj;            // [ndir][Bp, d_ld]
+    float* gocc;            // [L, d_ld]
+    int64_t negocc_off[2];  // first gocc row of dir's negatives
+    int ncols;              // useful columns per n-block (128, or 127 when the ones column is appended for L2)
+    LpDims D;
+};
+
+constexpr int G_TM = 64, G_TN = 128, G_KC = 64;
+constexpr int G_KSA = G_KC + 2;   // [m][k] layout, b64 fragment reads: stride/2 odd
+constexpr int G_TMS = G_TM + 4;   // [k][m] layout
+constexpr int G_TNS = G_TN + 4;   // [k][n] layout
+
+template <bool L2>
+__device__ __forceinline__ float dscore(float s, float lse, float gscale) {
+    // dL/dS (Dot) or dL/d(x.y) (L2: S = sqrt(max(t,1e-8)), t = x2 + y2 - 2 x.y  =>  -q / S, zero where clamped)
+    if (L2) {
+        const float q = gscale * __expf(s - lse);
+        return (s > 1.0000001e-4f) ? (-q / s) : 0.f;
+    }
+    return gscale * __expf(s - lse);
+}
+
+// dAdj_c[m, n] = sum_j V[m, j] * Neg_c[j, n]     (M = rows of the chunk, K = negatives, N = embedding columns)
+template <bool L2>
+__global__ __launch_bounds__(256) void lp_grad_adj_kernel(GradArgs a) {
+    __shared__ __attribute__((aligned(16))) float Qs[G_TM * G_KSA];
+    __shared__ __attribute__((aligned(16))) float Bs[G_KC * G_TNS];
+    __shared__ float rsum[G_TM];
+    const LpDims& D = a.D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int dir = blockIdx.z / D.C, c = blockIdx.z - dir * D.C;
+    const int m0 = blockIdx.y * G_TM, n0 = blockIdx.x * a.ncols;
+    const int64_t rowbase = (int64_t)dir * D.Bp + (int64_t)c * D.Bc;
+    const float* S = a.S + rowbase * D.n_ld;
+    const int64_t* negmap = a.negmap[dir] + (int64_t)c * D.N;
+
+    v16f acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // staging roles
+    const int qpiece = tid & 15, qrow = tid >> 4;   // Q: 16 threads x float4 = 64 k per row, 16 rows per pass, 4 passes
+    const int bpiece = tid & 31, brow = tid >> 5;   // B: 32 threads x float4 = 128 n per row, 8 rows per pass, 8 passes
+    float lse_r[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int m = m0 + qrow + 16 * it;
+        lse_r[it] = (m < D.Bc) ? a.lse[rowbase + m] : 0.f;
+    }
+
+    for (int j0 = 0; j0 < D.N; j0 += G_KC) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = qrow + 16 * it;
+            const int m = m0 + row;
+            const int j = j0 + 4 * qpiece;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < D.Bc && j < D.N) {
+                const float4 s = *reinterpret_cast<const float4*>(S + (int64_t)m * D.n_ld + j);
+                v.x = dscore<L2>(s.x, lse_r[it], D.gscale);
+                if (j + 1 < D.N) v.y = dscore<L2>(s.y, lse_r[it], D.gscale);
+                if (j + 2 < D.N) v.z = dscore<L2>(s.z, lse_r[it], D.gscale);
+                if (j + 3 < D.N) v.w = dscore<L2>(s.w, lse_r[it], D.gscale);
+            }
+            float* p = Qs + row * G_KSA + 4 * qpiece;
+            *reinterpret_cast<float2*>(p) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2*>(p + 2) = make_float2(v.z, v.w);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = brow + 8 * it;
+            const int j = j0 + row;
+            const int nl = 4 * bpiece;  // local column
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < D.N) {
+                const float* nr = a.emb + negmap[j] * a.emb_ld;
+                if (nl < a.ncols) {
+                    const int lim = min(D.d, n0 + a.ncols);
+                    v = load_row4(nr, n0 + nl, lim, (n0 & 3) ? 1 : a.emb_vec);
+                }
+                if (L2 && nl == G_TN - 4) v.w = 1.f;  // ones column -> row sums of V
+            }
+            *reinterpret_cast<float4*>(Bs + row * G_TNS + nl) = v;
+        }
+        __syncthreads();
+        const float* ap = Qs + (wm * 32 + l31) * G_KSA + 2 * h;
+        const float* bp = Bs + (2 * h) * G_TNS + wn * 64 + l31;
+#pragma unroll 4
+        for (int q = 0; q < G_KC / 4; ++q) {
+            const float2 av = *reinterpret_cast<const float2*>(ap + 4 * q);
+            const float b00 = bp[(4 * q) * G_TNS], b01 = bp[(4 * q) * G_TNS + 32];
+            const float b10 = bp[(4 * q + 1) * G_TNS], b11 = bp[(4 * q + 1) * G_TNS + 32];
+            acc[0] = mfma32(av.x, b00, acc[0]);
+            acc[1] = mfma32(av.x, b01, acc[1]);
+            acc[0] = mfma32(av.y, b10, acc[0]);
+            acc[1] = mfma32(av.y, b11, acc[1]);
+        }
+        __syncthreads();
+    }
+
+    if (L2) {  // local column 127 holds sum_j V[m, j]
+        if (wn == 1 && l31 == 31) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rsum[wm * 32 + acc_row(r, h)] = acc[1][r];
+        }
+        __syncthreads();
+    }
+    float* out = a.dadj + rowbase * D.d_ld;
+    const float* adj = a.adj + rowbase * D.d_ld;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int nl = wn * 64 + tn * 32 + l31;
+        const int n = n0 + nl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ml = wm * 32 + acc_row(r, h);
+            const int m = m0 + ml;
+            if (m < D.Bc && nl < a.ncols && n < D.d) {
+                float v = acc[tn][r];
+                if (L2) v -= adj[(int64_t)m * D.d_ld + n] * rsum[ml];  // + a_i * sum_j (q/S)
+                out[(int64_t)m * D.d_ld + n] = v;
+            }
+        }
+    }
+}
+
+// dNeg_c[m, n] = sum_i V[i, m] * adj_c[i, n]     (M = negatives of the chunk, K = rows of the chunk, N = embedding columns)
+template <bool L2>
+__global__ __launch_bounds__(256) void lp_grad_neg_kernel(GradArgs a) {
+    __shared__ __attribute__((aligned(16))) float Qs[G_KC * G_TMS];
+    __shared__ __attribute__((aligned(16))) float Bs[G_KC * G_TNS];
+    __shared__ float csum[G_TM];
+    const LpDims& D = a.D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int dir = blockIdx.z / D.C, c = blockIdx.z - dir * D.C;
+    const int m0 = blockIdx.y * G_TM, n0 = blockIdx.x * a.ncols;
+    const int64_t rowbase = (int64_t)dir * D.Bp + (int64_t)c * D.Bc;
+    const float* S = a.S + rowbase * D.n_ld;
+    const float* adj = a.adj + rowbase * D.d_ld;
+    const float* lse = a.lse + rowbase;
+
+    v16f acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int qpiece = tid & 15, qrow = tid >> 4;  // Q: row = k (= i), 16 threads x float4 = 64 m (= j)
+    const int bpiece = tid & 31, brow = tid >> 5;
+
+    for (int i0 = 0; i0 < D.Bc; i0 += G_KC) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = qrow + 16 * it;
+            const int i = i0 + row;
+            const int j = m0 + 4 * qpiece;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < D.Bc && j < D.N) {
+                const float l = lse[i];
+                const float4 s = *reinterpret_cast<const float4*>(S + (int64_t)i * D.n_ld + j);
+                v.x = dscore<L2>(s.x, l, D.gscale);
+                if (j + 1 < D.N) v.y = dscore<L2>(s.y, l, D.gscale);
+                if (j + 2 < D.N) v.z = dscore<L2>(s.z, l, D.gscale);
+                if (j + 3 < D.N) v.w = dscore<L2>(s.w, l, D.gscale);
+            }
+            *reinterpret_cast<float4*>(Qs + row * G_TMS + 4 * qpiece) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = brow + 8 * it;
+            const int i = i0 + row;
+            const int nl = 4 * bpiece;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < D.Bc) {
+                if (nl < a.ncols) {
+                    const int lim = min(D.d, n0 + a.ncols);
+                    v = load_row4(adj + (int64_t)i * D.d_ld, n0 + nl, lim, (n0 & 3) ? 1 : 4);
+                }
+                if (L2 && nl == G_TN - 4) v.w = 1.f;
+            }
+            *reinterpret_cast<float4*>(Bs + row * G_TNS + nl) = v;
+        }
+        __syncthreads();
+        const float* ap = Qs + (2 * h) * G_TMS + wm * 32 + l31;
+        const float* bp = Bs + (2 * h) * G_TNS + wn * 64 + l31;
+#pragma unroll 4
+        for (int q = 0; q < G_KC / 4; ++q) {
+            const float a0 = ap[(4 * q) * G_TMS], a1 = ap[(4 * q + 1) * G_TMS];
+            const float b00 = bp[(4 * q) * G_TNS], b01 = bp[(4 * q) * G_TNS + 32];
+            const float b10 = bp[(4 * q + 1) * G_TNS], b11 = bp[(4 * q + 1) * G_TNS + 32];
+            acc[0] = mfma32(a0, b00, acc[0]);
+            acc[1] = mfma32(a0, b01, acc[1]);
+            acc[0] = mfma32(a1, b10, acc[0]);
+            acc[1] = mfma32(a1, b11, acc[1]);
+        }
+        __syncthreads();
+    }
+
+    if (L2) {
+        if (wn == 1 && l31 == 31) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) csum[wm * 32 + acc_row(r, h)] = acc[1][r];
+        }
+        __syncthreads();
+    }
+    const int64_t* negmap = a.negmap[dir] + (int64_t)c * D.N;
+    float* out = a.gocc + (a.negocc_off[dir] + (int64_t)c * D.N) * D.d_ld;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int nl = wn * 64 + tn * 32 + l31;
+        const int n = n0 + nl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ml = wm * 32 + acc_row(r, h);
+            const int m = m0 + ml;
+            if (m < D.N && nl < a.ncols && n < D.d) {
+                float v = acc[tn][r];
+                if (L2) v -= a.emb[negmap[m] * a.emb_ld + n] * csum[ml];
+                out[(int64_t)m * D.d_ld + n] = v;
+            }
+        }
+    }
+}
+
+// =========================================================================================== edge backward
+struct EdgeBwdArgs {
+    const float* emb;
+    int64_t emb_ld;
+    const int64_t* edges;
+    const float* rel[2];
+    int64_t rel_ld;
+    const float* adj;
+    const float* pos;
+    const float* lse;
+    const float* dadj;
+    float* gocc;     // rows [0,B) = src occurrences, [B,2B) = dst occurrences
+    float* grel[2];  // [B, d_ld]
+    LpDims D;
+};
+
+// gradient wrt (e, r) of a = op(e, r) given g = dL/da, for column c (complex: c < h handles the pair (c, c + h))
+// one wave per edge; handles both directions so every gocc element is written exactly once.
+__global__ __launch_bounds__(256) void lp_edge_bwd_kernel(EdgeBwdArgs a) {
+    const LpDims& D = a.D;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= D.B) return;
+    const int64_t* ed = a.edges + i * D.edge_cols;
+    const int64_t s = ed[0], t = ed[D.edge_cols - 1];
+    const float* es = a.emb + s * a.emb_ld;
+    const float* et = a.emb + t * a.emb_ld;
+    float* gs = a.gocc + i * D.d_ld;
+    float* gt = a.gocc + (D.B + i) * D.d_ld;
+    const bool cplx = (D.relop == MARIUS_OP_COMPLEX_HADAMARD);
+    const int h = D.d / 2;
+    const int span = cplx ? h : D.d;  // complex: each lane-iteration handles columns c and c + h
+
+    float coef[2], posv[2];
+    for (int dir = 0; dir < D.ndir; ++dir) {
+        const float p = a.pos[(int64_t)dir * D.Bp + i];
+        const float l = a.lse[(int64_t)dir * D.Bp + i];
+        coef[dir] = (__expf(p - l) - 1.f) * D.gscale;  // dL/dpos
+        posv[dir] = p;
+    }
+
+    for (int c = lane; c < span; c += 64) {
+        float out_s[2] = {0.f, 0.f}, out_t[2] = {0.f, 0.f};  // [0]: column c, [1]: column c + h (complex)
+        for (int dir = 0; dir < D.ndir; ++dir) {
+            const float* e = dir == 0 ? es : et;   // operand that went through the relation operator
+            const float* o = dir == 0 ? et : es;   // the other endpoint
+            const bool has_rel = (D.edge_cols == 3) && (a.rel[dir] != nullptr);
+            const float* r = has_rel ? a.rel[dir] + ed[1] * a.rel_ld : nullptr;
+            const int64_t rowoff = ((int64_t)dir * D.Bp + i) * D.d_ld;
+            const int ncol = cplx ? 2 : 1;
+            float ga[2], go[2];
+            for (int u = 0; u < ncol; ++u) {
+                const int cc = c + u * h;
+                const float av = a.adj[rowoff + cc];
+                const float ov = o[cc];
+                float g = a.dadj[rowoff + cc];
+                if (D.cmp == MARIUS_CMP_L2) {
+                    const float df = (av - ov) + 1e-6f;
+                    const float w = (posv[dir] > 0.f) ? coef[dir] * df / posv[dir] : 0.f;
+                    g += w;
+                    go[u] = -w;
+                } else {
+                    g += coef[dir] * ov;
+                    go[u] = coef[dir] * av;
+                }
+                ga[u] = g;
+            }
+            float ge[2] = {ga[0], ga[1]}, gr[2] = {0.f, 0.f};
+            if (has_rel) {
+                if (D.relop == MARIUS_OP_HADAMARD) {
+                    ge[0] = ga[0] * r[c];
+                    gr[0] = ga[0] * e[c];
+                } else if (D.relop == MARIUS_OP_TRANSLATION) {
+                    gr[0] = ga[0];
+                } else if (cplx) {
+                    const float er = e[c], ei = e[c + h], rr = r[c], ri = r[c + h];
+                    ge[0] = ga[0] * rr + ga[1] * ri;
+                    ge[1] = -ga[0] * ri + ga[1] * rr;
+                    gr[0] = ga[0] * er + ga[1] * ei;
+                    gr[1] = -ga[0] * ei + ga[1] * er;
+                }
+                for (int u = 0; u < ncol; ++u) a.grel[dir][i * D.d_ld + c + u * h] = gr[u];
+            }
+            for (int u = 0; u < ncol; ++u) {
+                if (dir == 0) {
+                    out_s[u] += ge[u];
+                    out_t[u] += go[u];
+                } else {
+                    out_t[u] += ge[u];
+                    out_s[u] += go[u];
+                }
+            }
+        }
+        const int ncol = cplx ? 2 : 1;
+        for (int u = 0; u < ncol; ++u) {
+            gs[c + u * h] = out_s[u];
+            gt[c + u * h] = out_t[u];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lp_zero_rows_kernel(float* p, int64_t n) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) p[t] = 0.f;
+}
+
+// =========================================================================================== ranks
+__global__ __launch_bounds__(256) void lp_ranks_kernel(const float* __restrict__ pos, const float* __restrict__ neg, int64_t rows,
+                                                       int N, int64_t neg_ld, int64_t* __restrict__ ranks) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float p = pos[row];
+    const float* s = neg + row * neg_ld;
+    int cnt = 0;
+    for (int c = lane; c < N; c += 64) cnt += (s[c] >= p) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) ranks[row] = (int64_t)cnt + 1;
+}
+
+// =========================================================================================== host side
+static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+static int fill_dims(const marius_lp_desc* d, LpDims& D) {
+    MARIUS_REQUIRE(d, "lp: null descriptor");
+    MARIUS_REQUIRE(d->d > 0 && d->B > 0 && d->C > 0 && d->N > 0, "lp: bad sizes d=%d B=%ld C=%d N=%d", d->d, (long)d->B, d->C, d->N);
+    MARIUS_REQUIRE(d->edge_cols == 2 || d->edge_cols == 3, "lp: Edge list must be a 3 or 2 column tensor");
+    MARIUS_REQUIRE(d->cmp >= 0 && d->cmp <= 2 && d->relop >= 0 && d->relop <= 3, "lp: bad relop/cmp");
+    MARIUS_REQUIRE(!(d->relop == MARIUS_OP_COMPLEX_HADAMARD && (d->d & 1)), "lp: ComplEx needs an even embedding dim");
+    MARIUS_REQUIRE(!(d->use_inverse && (d->edge_cols != 3 || !d->inv_rel)), "lp: inverse relations need 3-column edges and inv_rel");
+    MARIUS_REQUIRE(!(d->use_inverse && !d->src_neg), "lp: inverse direction needs src negatives");
+    D.B = d->B;
+    D.C = d->C;
+    D.N = d->N;
+    D.d = d->d;
+    // comparators.cpp:9: (int)ceil((float)num_pos / num_chunks)
+    D.Bc = (int)ceilf((float)d->B / (float)d->C);
+    D.Bp = (int64_t)D.Bc * D.C;
+    D.ndir = d->use_inverse ? 2 : 1;
+    D.edge_cols = d->edge_cols;
+    D.relop = d->relop;
+    D.cmp = (d->cmp == MARIUS_CMP_COSINE) ? MARIUS_CMP_DOT : d->cmp;  // CosineCompare scores un-normalised tensors (comparators.cpp:43-60)
+    D.n_ld = (d->N + 3) / 4 * 4;
+    D.d_ld = (d->d + 3) / 4 * 4;
+    D.gscale = (d->reduction == MARIUS_REDUCE_MEAN) ? 1.f / (float)D.Bp : 1.f;
+    MARIUS_REQUIRE((int64_t)D.Bc * (D.C - 1) < d->B, "lp: num_chunks too large for batch (empty chunk)");
+    return MARIUS_OK;
+}
+
+static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layout* L) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align256(bytes);
+        return o;
+    };
+    L->Bp = D.Bp;
+    L->n_ld = D.n_ld;
+    L->d_ld = D.d_ld;
+    const size_t rows = (size_t)D.Bp;
+    for (int dir = 0; dir < 2; ++dir) L->adj[dir] = L->pos[dir] = L->neg[dir] = L->lse[dir] = L->rowloss[dir] = L->dadj[dir] = L->grel[dir] = 0;
+    // per-dir arrays are contiguous [ndir][...] so kernels can index by dir
+    size_t base = take(rows * D.d_ld * 4 * D.ndir);
+    for (int dir = 0; dir < D.ndir; ++dir) L->adj[dir] = base + (size_t)dir * rows * D.d_ld * 4;
+    base = take(rows * 4 * D.ndir);
+    for (int dir = 0; dir < D.ndir; ++dir) L->pos[dir] = base + (size_t)dir * rows * 4;
+    base = take(rows * D.n_ld * 4 * D.ndir);
+    for (int dir = 0; dir < D.ndir; ++dir) L->neg[dir] = base + (size_t)dir * rows * D.n_ld * 4;
+    base = take(rows * 4 * D.ndir);
+    for (int dir = 0; dir < D.ndir; ++dir) L->lse[dir] = base + (size_t)dir * rows * 4;
+    base = take(rows * 4 * D.ndir);
+    for (int dir = 0; dir < D.ndir; ++dir) L->rowloss[dir] = base + (size_t)dir * rows * 4;
+    L->loss = take(16);
+    base = take(rows * D.d_ld * 4 * D.ndir);
+    for (int dir = 0; dir < D.ndir; ++dir) L->dadj[dir] = base + (size_t)dir * rows * D.d_ld * 4;
+    const size_t nocc = (size_t)2 * D.B + (size_t)(d->src_neg ? 2 : 1) * D.C * D.N;
+    L->gocc = take(nocc * D.d_ld * 4);
+    base = take((size_t)D.B * D.d_ld * 4 * D.ndir);
+    for (int dir = 0; dir < D.ndir; ++dir) L->grel[dir] = base + (size_t)dir * D.B * D.d_ld * 4;
+    L->aux = take((rows + (size_t)D.C * D.N) * 4 * D.ndir);
+    L->total_bytes = off;
+    return MARIUS_OK;
+}
+
+}  // namespace marius
+
+using namespace marius;
+
+extern "C" int marius_lp_plan(const marius_lp_desc* desc, marius_lp_layout* layout) {
+    LpDims D;
+    int rc = fill_dims(desc, D);
+    if (rc) return rc;
+    MARIUS_REQUIRE(layout, "lp_plan: null layout");
+    return make_layout(desc, D, layout);
+}
+
+extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_layout* L, void* workspace, marius_stream_t stream) {
+    LpDims D;
+    int rc = fill_dims(desc, D);
+    if (rc) return rc;
+    MARIUS_REQUIRE(L && workspace && desc->emb && desc->edges && desc->dst_neg, "lp_forward: null pointer");
+    MARIUS_REQUIRE(desc->emb_ld >= desc->d, "lp_forward: emb_ld < d");
+    MARIUS_REQUIRE(desc->edge_cols == 2 || desc->rel, "lp_forward: relations missing for 3-column edges");
+    hipStream_t st = as_stream(stream);
+    char* ws = (char*)workspace;
+    const bool l2 = (D.cmp == MARIUS_CMP_L2);
+    float* x2 = l2 ? (float*)(ws + L->aux) : nullptr;
+    float* y2 = l2 ? x2 + (size_t)D.Bp * D.ndir : nullptr;
+
+    PrepArgs pa;
+    pa.emb = desc->emb;
+    pa.emb_ld = desc->emb_ld;
+    pa.edges = desc->edges;
+    pa.rel[0] = desc->rel;
+    pa.rel[1] = desc->inv_rel;
+    pa.rel_ld = desc->rel_ld;
+    pa.adj = (float*)(ws + L->adj[0]);
+    pa.pos = (float*)(ws + L->pos[0]);
+    pa.x2 = x2;
+    pa.D = D;
+    lp_prep_kernel<<<dim3((unsigned)cdiv(D.Bp * D.ndir, 4)), dim3(256), 0, st>>>(pa);
+    rc = check_launch("lp_prep");
+    if (rc) return rc;
+    if (l2) {
+        const int64_t CN = (int64_t)D.C * D.N;
+        lp_negnorm_kernel<<<dim3((unsigned)cdiv(CN * D.ndir, 4)), dim3(256), 0, st>>>(desc->emb, desc->emb_ld, desc->dst_neg,
+                                                                                     desc->src_neg, CN, D.d, D.ndir, y2);
+        rc = check_launch("lp_negnorm");
+        if (rc) return rc;
+    }
+
+    ScoreArgs sa;
+    sa.adj = pa.adj;
+    sa.emb = desc->emb;
+    sa.emb_ld = desc->emb_ld;
+    sa.emb_vec = row_vec_width(desc->emb, desc->emb_ld, 4);
+    sa.negmap[0] = desc->dst_neg;
+    sa.negmap[1] = desc->src_neg;
+    sa.S = (float*)(ws + L->neg[0]);
+    sa.x2 = x2;
+    sa.y2 = y2;
+    sa.dk = (int)D.d_ld;
+    sa.nkc = (sa.dk + 55) / 56;  // KC <= 56 keeps (128 + 128) * KS * 4 B under the 64 KiB dynamic-LDS default
+    sa.KC = ((sa.dk + sa.nkc - 1) / sa.nkc + 3) / 4 * 4;
+    sa.KS = ((sa.KC / 2) & 1) ? sa.KC : sa.KC + 2;  // stride/2 odd -> conflict-free ds_read_b64 across 32 rows
+    sa.D = D;
+    dim3 grid((unsigned)cdiv(D.N, F_TN), (unsigned)cdiv(D.Bc, F_TM), (unsigned)(D.C * D.ndir));
+    size_t lds = (size_t)(F_TM + F_TN) * sa.KS * sizeof(float);
+    if (l2)
+        lp_scores_kernel<true><<<grid, dim3(256), lds, st>>>(sa);
+    else
+        lp_scores_kernel<false><<<grid, dim3(256), lds, st>>>(sa);
+    rc = check_launch("lp_scores");
+    if (rc) return rc;
+
+    const int64_t* filt[2] = {desc->dst_filter, desc->src_filter};
+    const int64_t nfilt[2] = {desc->n_dst_filter, desc->n_src_filter};
+    for (int dir = 0; dir < D.ndir; ++dir) {
+        if (filt[dir] && nfilt[dir] > 0) {
+            int64_t blocks = cdiv(nfilt[dir], 256);
+            if (blocks > 1024) blocks = 1024;
+            lp_filter_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((float*)(ws + L->neg[dir]), D.n_ld, D.Bp, D.N, filt[dir],
+                                                                          nfilt[dir]);
+            rc = check_launch("lp_filter");
+            if (rc) return rc;
+        }
+    }
+    return MARIUS_OK;
+}
+
+extern "C" int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout* L, void* workspace, marius_stream_t stream) {
+    LpDims D;
+    int rc = fill_dims(desc, D);
+    if (rc) return rc;
+    MARIUS_REQUIRE(L && workspace, "lp_loss: null pointer");
+    hipStream_t st = as_stream(stream);
+    char* ws = (char*)workspace;
+    const int64_t rows = D.Bp * D.ndir;
+    lp_lse_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>((const float*)(ws + L->neg[0]), D.n_ld,
+                                                                      (const float*)(ws + L->pos[0]), rows, D.N,
+                                                                      (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]));
+    rc = check_launch("lp_lse");
+    if (rc) return rc;
+    lp_loss_reduce_kernel<<<dim3(1), dim3(1024), 0, st>>>((const float*)(ws + L->rowloss[0]), D.Bp, D.ndir, D.gscale,
+                                                         (float*)(ws + L->loss));
+    return check_launch("lp_loss_reduce");
+}
+
+extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_layout* L, void* workspace, marius_stream_t stream) {
+    LpDims D;
+    int rc = fill_dims(desc, D);
+    if (rc) return rc;
+    MARIUS_REQUIRE(L && workspace, "lp_backward: null pointer");
+    hipStream_t st = as_stream(stream);
+    char* ws = (char*)workspace;
+    const bool l2 = (D.cmp == MARIUS_CMP_L2);
+    const int64_t CN = (int64_t)D.C * D.N;
+
+    GradArgs ga;
+    ga.S = (const float*)(ws + L->neg[0]);
+    ga.lse = (const float*)(ws + L->lse[0]);
+    ga.adj = (const float*)(ws + L->adj[0]);
+    ga.emb = desc->emb;
+    ga.emb_ld = desc->emb_ld;
+    ga.emb_vec = row_vec_width(desc->emb, desc->emb_ld, 4);
+    ga.negmap[0] = desc->dst_neg;
+    ga.negmap[1] = desc->src_neg;
+    ga.dadj = (float*)(ws + L->dadj[0]);
+    ga.gocc = (float*)(ws + L->gocc);
+    const bool has_src_neg = desc->src_neg != nullptr;
+    ga.negocc_off[0] = 2 * D.B + (has_src_neg ? CN : 0);  // dst negatives come last in map_tensors order
+    ga.negocc_off[1] = 2 * D.B;                            // src negatives
+    ga.ncols = l2 ? G_TN - 1 : G_TN;
+    ga.D = D;
+    const unsigned nblk = (unsigned)cdiv(D.d, ga.ncols);
+    dim3 ga_grid(nblk, (unsigned)cdiv(D.Bc, G_TM), (unsigned)(D.C * D.ndir));
+    dim3 gn_grid(nblk, (unsigned)cdiv(D.N, G_TM), (unsigned)(D.C * D.ndir));
+    if (l2) {
+        lp_grad_adj_kernel<true><<<ga_grid, dim3(256), 0, st>>>(ga);
+        lp_grad_neg_kernel<true><<<gn_grid, dim3(256), 0, st>>>(ga);
+    } else {
+        lp_grad_adj_kernel<false><<<ga_grid, dim3(256), 0, st>>>(ga);
+        lp_grad_neg_kernel<false><<<gn_grid, dim3(256), 0, st>>>(ga);
+    }
+    rc = check_launch("lp_grad");
+    if (rc) return rc;
+    if (has_src_neg && D.ndir == 1) {  // src negatives take part in the unique map but receive no gradient
+        const int64_t n = CN * D.d_ld;
+        int64_t blocks = cdiv(n, 256);
+        if (blocks > 4096) blocks = 4096;
+        lp_zero_rows_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(ga.gocc + 2 * D.B * D.d_ld, n);
+        rc = check_launch("lp_zero_rows");
+        if (rc) return rc;
+    }
+
+    EdgeBwdArgs ea;
+    ea.emb = desc->emb;
+    ea.emb_ld = desc->emb_ld;
+    ea.edges = desc->edges;
+    ea.rel[0] = desc->rel;
+    ea.rel[1] = desc->inv_rel;
+    ea.rel_ld = desc->rel_ld;
+    ea.adj = ga.adj;
+    ea.pos = (const float*)(ws + L->pos[0]);
+    ea.lse = ga.lse;
+    ea.dadj = ga.dadj;
+    ea.gocc = ga.gocc;
+    ea.grel[0] = (float*)(ws + L->grel[0]);
+    ea.grel[1] = D.ndir == 2 ? (float*)(ws + L->grel[1]) : nullptr;
+    ea.D = D;
+    lp_edge_bwd_kernel<<<dim3((unsigned)cdiv(D.B, 4)), dim3(256), 0, st>>>(ea);
+    return check_launch("lp_edge_bwd");
+}
+
+extern "C" int marius_compute_ranks(const float* pos, const float* neg, int64_t rows, int32_t N, int64_t neg_ld, int64_t* ranks,
+                                    marius_stream_t stream) {
+    MARIUS_REQUIRE(rows >= 0 && N >= 0 && neg_ld >= N, "compute_ranks: bad sizes");
+    if (rows == 0) return MARIUS_OK;
+    MARIUS_REQUIRE(pos && neg && ranks, "compute_ranks: null pointer");
+    lp_ranks_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, as_stream(stream)>>>(pos, neg, rows, N, neg_ld, ranks);
+    return check_launch("compute_ranks");
+}

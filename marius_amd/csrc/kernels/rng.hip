@@ -1,0 +1,209 @@
+// ATen-CPU-generator-compatible sampling on the device.
+//
+// The reference draws negatives with torch::randint on the CPU generator (at::mt19937); "bit-exact sampled ids"
+// therefore means reproducing that MT19937 stream.  mt19937_fill_kernel advances a DEVICE-resident 624-word state
+// and emits raw tempered words; sample_negatives_kernel maps them to ids exactly as ATen's
+// uniform_int_from_to_distribution does (draw % range, two words per draw when range >= 2^28).
+//
+// MT19937 regeneration is a 3-phase recurrence (new[i] needs new[i-227]); one 256-thread workgroup keeps both
+// state generations in LDS and pays 3 barriers per 624 words (~45 us for the 100k words of a Freebase86m batch).
+// The kernel is stream-ordered and touches one CU, so the trainer runs it on a side stream one batch ahead.
+#include "common.h"
+
+namespace marius {
+
+constexpr int MT_N = 624;
+constexpr int MT_M = 397;
+
+__device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+__global__ __launch_bounds__(256) void mt19937_fill_kernel(uint32_t* __restrict__ state, uint32_t* __restrict__ out,
+                                                           int64_t n) {
+    __shared__ uint32_t buf[2][MT_N];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < MT_N; i += 256) buf[0][i] = state[i];
+    int idx = (int)state[MT_N];
+    int cur = 0;
+    __syncthreads();
+    int64_t produced = 0;
+    while (produced < n) {
+        if (idx >= MT_N) {
+            uint32_t* o = buf[cur];
+            uint32_t* w = buf[cur ^ 1];
+            // phase A: i in [0, 227): new[i] = old[i+397] ^ f(old[i], old[i+1])
+            if (tid < MT_N - MT_M) w[tid] = mt_mix(o[tid], o[tid + 1], o[tid + MT_M]);
+            __syncthreads();
+            // phase B: i in [227, 454): new[i] = new[i-227] ^ f(old[i], old[i+1])
+            if (tid < MT_N - MT_M) {
+                int i = tid + (MT_N - MT_M);
+                w[i] = mt_mix(o[i], o[i + 1], w[i - (MT_N - MT_M)]);
+            }
+            __syncthreads();
+            // phase C: i in [454, 624): new[i] = new[i-227] ^ f(old[i], i == 623 ? new[0] : old[i+1])
+            if (tid < MT_N - 2 * (MT_N - MT_M)) {
+                int i = tid + 2 * (MT_N - MT_M);
+                uint32_t nxt = (i == MT_N - 1) ? w[0] : o[i + 1];
+                w[i] = mt_mix(o[i], nxt, w[i - (MT_N - MT_M)]);
+            }
+            __syncthreads();
+            cur ^= 1;
+            idx = 0;
+        }
+        int64_t left = n - produced;
+        int take = MT_N - idx;
+        if ((int64_t)take > left) take = (int)left;
+        const uint32_t* s = buf[cur];
+        for (int i = tid; i < take; i += 256) out[produced + i] = mt_temper(s[idx + i]);
+        idx += take;
+        produced += take;
+        // the next twist writes buf[cur^1] only, and reads buf[cur]: no hazard with the tempering reads above
+    }
+    __syncthreads();
+    for (int i = tid; i < MT_N; i += 256) state[i] = buf[cur][i];
+    if (tid == 0) state[MT_N] = (uint32_t)idx;
+}
+
+__global__ __launch_bounds__(256) void sample_negatives_kernel(const uint32_t* __restrict__ raw,
+                                                               const int64_t* __restrict__ edges, uint64_t B, int edge_cols,
+                                                               int col, uint64_t num_nodes, int C, int N, int n_deg,
+                                                               int w_uni, int w_deg, int64_t* __restrict__ out_ids,
+                                                               int64_t* __restrict__ deg_pos) {
+    const int64_t total = (int64_t)C * N;
+    const int n_uni = N - n_deg;
+    const int64_t words_per_chunk = (int64_t)n_uni * w_uni + (int64_t)n_deg * w_deg;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t / N);
+        const int k = (int)(t - (int64_t)c * N);
+        const uint32_t* r = raw + c * words_per_chunk;
+        int64_t id;
+        if (k >= n_deg) {  // uniform part, drawn first
+            const uint32_t* p = r + (int64_t)(k - n_deg) * w_uni;
+            uint64_t v = (w_uni == 2) ? (((uint64_t)p[0] << 32) | (uint64_t)p[1]) : (uint64_t)p[0];
+            id = (int64_t)(v % num_nodes);
+        } else {  // degree-based part: edge position drawn after the uniform ids of this chunk
+            const uint32_t* p = r + (int64_t)n_uni * w_uni + (int64_t)k * w_deg;
+            uint64_t v = (w_deg == 2) ? (((uint64_t)p[0] << 32) | (uint64_t)p[1]) : (uint64_t)p[0];
+            int64_t pos = (int64_t)(v % B);
+            deg_pos[(int64_t)c * n_deg + k] = pos;
+            id = edges[pos * edge_cols + col];
+        }
+        out_ids[t] = id;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void select_edges_kernel(const T* __restrict__ in, int cols, const int64_t* __restrict__ perm,
+                                                           int64_t start, int64_t B, int64_t* __restrict__ out) {
+    const int64_t total = B * cols;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = t / cols;
+        int c = (int)(t - i * cols);
+        int64_t src = perm ? perm[start + i] : (start + i);
+        out[t] = (int64_t)in[src * cols + c];
+    }
+}
+
+// ---- host-side generator (same stream; used for the per-epoch randperm, which is a serial swap chain) ----
+static void host_twist(uint32_t* p) {
+    for (int i = 0; i < MT_N; i++) {
+        uint32_t y = (p[i] & 0x80000000u) | (p[(i + 1) % MT_N] & 0x7fffffffu);
+        p[i] = p[(i + MT_M) % MT_N] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+}
+static inline uint32_t host_next(uint32_t* st) {
+    if (st[MT_N] >= (uint32_t)MT_N) {
+        host_twist(st);
+        st[MT_N] = 0;
+    }
+    uint32_t y = st[st[MT_N]++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+}  // namespace marius
+
+using namespace marius;
+
+extern "C" void marius_mt19937_seed_host(uint32_t* st, uint64_t seed) {
+    st[0] = (uint32_t)(seed & 0xffffffffu);
+    for (int j = 1; j < MT_N; j++) st[j] = 1812433253u * (st[j - 1] ^ (st[j - 1] >> 30)) + (uint32_t)j;
+    st[MT_N] = MT_N;
+}
+
+extern "C" void marius_mt19937_fill_host(uint32_t* st, uint32_t* out, int64_t n) {
+    for (int64_t i = 0; i < n; i++) out[i] = host_next(st);
+}
+
+extern "C" int marius_mt19937_randperm_host(uint32_t* st, int64_t* out, int64_t n) {
+    MARIUS_REQUIRE(n >= 0 && (n == 0 || out), "randperm: bad arguments");
+    // ATen switches to 64-bit draws for n >= 2^32 / 20; that path is not reproduced here.
+    MARIUS_REQUIRE((uint64_t)n < (0xffffffffull / 20ull), "randperm: n=%ld needs ATen's 64-bit path (unsupported)", (long)n);
+    for (int64_t i = 0; i < n; i++) out[i] = i;
+    for (int64_t i = 0; i < n - 1; i++) {
+        int64_t z = (int64_t)((uint64_t)host_next(st) % (uint64_t)(n - i));
+        int64_t sav = out[i];
+        out[i] = out[z + i];
+        out[z + i] = sav;
+    }
+    return MARIUS_OK;
+}
+
+extern "C" int marius_mt19937_fill(uint32_t* state_dev, uint32_t* out_dev, int64_t n, marius_stream_t stream) {
+    MARIUS_REQUIRE(state_dev && n >= 0 && (n == 0 || out_dev), "mt19937_fill: bad arguments");
+    if (n == 0) return MARIUS_OK;
+    mt19937_fill_kernel<<<dim3(1), dim3(256), 0, as_stream(stream)>>>(state_dev, out_dev, n);
+    return check_launch("mt19937_fill");
+}
+
+static inline int draw_words(uint64_t range) { return range >= (1ull << 28) ? 2 : 1; }
+
+extern "C" int64_t marius_negatives_raw_words(int64_t num_nodes, int64_t B, int32_t C, int32_t N, int32_t n_deg) {
+    int64_t n_uni = N - n_deg;
+    return (int64_t)C * (n_uni * draw_words((uint64_t)num_nodes) + (int64_t)n_deg * draw_words((uint64_t)B));
+}
+
+extern "C" int marius_sample_negatives(const uint32_t* raw, const int64_t* edges, int64_t B, int32_t edge_cols,
+                                       int32_t inverse, int64_t num_nodes, int32_t C, int32_t N, int32_t n_deg,
+                                       int64_t* out_ids, int64_t* deg_pos, marius_stream_t stream) {
+    MARIUS_REQUIRE(raw && out_ids && C > 0 && N > 0 && n_deg >= 0 && n_deg <= N && num_nodes > 0,
+                   "sample_negatives: bad arguments");
+    MARIUS_REQUIRE(n_deg == 0 || (edges && deg_pos && B > 0 && (edge_cols == 2 || edge_cols == 3)),
+                   "sample_negatives: degree sampling needs edges/deg_pos");
+    int64_t total = (int64_t)C * N;
+    int64_t blocks = cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    int col = inverse ? 0 : (edge_cols - 1);
+    sample_negatives_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(
+        raw, edges, (uint64_t)B, edge_cols, col, (uint64_t)num_nodes, C, N, n_deg, draw_words((uint64_t)num_nodes),
+        draw_words((uint64_t)(B > 0 ? B : 1)), out_ids, deg_pos);
+    return check_launch("sample_negatives");
+}
+
+extern "C" int marius_select_edges(const void* edges_in, int32_t in_is_int64, int32_t cols, const int64_t* perm,
+                                   int64_t start, int64_t B, int64_t* out, marius_stream_t stream) {
+    MARIUS_REQUIRE(B >= 0 && (cols == 2 || cols == 3) && start >= 0, "select_edges: bad arguments");
+    if (B == 0) return MARIUS_OK;
+    MARIUS_REQUIRE(edges_in && out, "select_edges: null pointer");
+    int64_t blocks = cdiv(B * cols, 256);
+    if (blocks > 4096) blocks = 4096;
+    if (in_is_int64)
+        select_edges_kernel<int64_t><<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(
+            (const int64_t*)edges_in, cols, perm, start, B, out);
+    else
+        select_edges_kernel<int32_t><<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(
+            (const int32_t*)edges_in, cols, perm, start, B, out);
+    return check_launch("select_edges");
+}

@@ -1,0 +1,280 @@
+// Atomic-free segmented row reduction in sorted-id order, optionally fused with the sparse Adagrad update.
+//
+// Replaces autograd's index_select backward (index_add_ with atomics on the device, nn/model.cpp:324) and, in the
+// fused form, Batch::accumulateGradients (data/batch.cpp:62-79) + the two Storage::indexAdd calls of
+// DataLoader::updateEmbeddings (data/dataloader.cpp:550-564).
+//
+// Input: rows[n, ld] (one gradient row per occurrence), perm/seg_offsets from marius_sort_unique (stable sort, so the
+// summation order inside a segment is the input order => bit-reproducible).  The sorted positions are cut into
+// chunks of SEG_R; one wave owns one chunk, so work is balanced regardless of how skewed the segment lengths are
+// (a Zipf hub node or relation can own thousands of rows).  A segment fully inside a chunk is finished by that wave;
+// a segment that crosses chunk boundaries leaves per-chunk partials in `carry` and is finished by the wave of the
+// chunk where it starts (second launch).  Every output row has exactly one writer: no atomics.
+#include "common.h"
+
+namespace marius {
+
+constexpr int SEG_R = 32;      // sorted positions per wave
+constexpr int SEG_BATCH = 8;   // row loads in flight per lane
+
+struct SegArgs {
+    const float* rows;
+    int64_t rows_ld;
+    const int32_t* perm;
+    const int64_t* inverse;  // unique index of each input position
+    const int32_t* seg_offsets;
+    int64_t n;
+    int d;
+    float* carry;  // [nchunks][2][dpad]
+    int dpad;
+};
+
+struct ApplySum {
+    float* out;
+    int64_t out_ld;
+    const int64_t* out_rows;  // optional row indirection
+    template <int VEC>
+    __device__ __forceinline__ void operator()(int u, int col, const float (&g)[VEC]) const {
+        const int64_t r = out_rows ? out_rows[u] : (int64_t)u;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) out[r * out_ld + col + e] = g[e];
+    }
+};
+
+struct ApplyAdagrad {
+    const int64_t* uniq;
+    float* table;
+    float* state;
+    int64_t ld;
+    float lr, eps;
+    template <int VEC>
+    __device__ __forceinline__ void operator()(int u, int col, const float (&g)[VEC]) const {
+#pragma clang fp contract(off)
+        const int64_t r = uniq[u];
+        float* w = table + r * ld + col;
+        float* s = state + r * ld + col;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float ds = g[e] * g[e];
+            const float sn = s[e] + ds;
+            const float dw = -lr * (g[e] / (sqrtf(sn) + eps));
+            s[e] = sn;
+            w[e] = w[e] + dw;
+        }
+    }
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else if constexpr (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x; v[1] = t.y;
+    } else {
+        v[0] = *p;
+    }
+}
+
+// phase 1: one wave per chunk
+template <int VEC, int NIT, class Apply>
+__global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply) {
+    const int lane = threadIdx.x & 63;
+    const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t k0 = chunk * SEG_R;
+    if (k0 >= a.n) return;
+    const int cnt = (int)min((int64_t)SEG_R, a.n - k0);
+    const int64_t k1 = k0 + cnt;
+    int p = -1, u = -1;
+    if (lane < cnt) {
+        p = a.perm[k0 + lane];
+        u = (int)a.inverse[p];
+    }
+    const int u_first = __shfl(u, 0, 64);
+    float acc[NIT][VEC];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[it][e] = 0.f;
+    int cur = u_first;
+
+    auto flush = [&](int useg) {
+        const int s0 = a.seg_offsets[useg], s1 = a.seg_offsets[useg + 1];
+        const bool complete = (s0 >= k0) && (s1 <= k1);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (lane + it * 64) * VEC;
+            if (col < a.d) {
+                if (complete) {
+                    apply.template operator()<VEC>(useg, col, acc[it]);
+                } else {
+                    float* c = a.carry + ((chunk * 2) + (useg == u_first ? 0 : 1)) * a.dpad + col;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) c[e] = acc[it][e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[it][e] = 0.f;
+        }
+    };
+
+    for (int b0 = 0; b0 < cnt; b0 += SEG_BATCH) {
+        float v[SEG_BATCH][NIT][VEC];
+        int ub[SEG_BATCH];
+#pragma unroll
+        for (int j = 0; j < SEG_BATCH; ++j) {
+            const int r = b0 + j;
+            const int pr = __shfl(p, r < cnt ? r : 0, 64);
+            ub[j] = (r < cnt) ? __shfl(u, r, 64) : -1;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int col = (lane + it * 64) * VEC;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[j][it][e] = 0.f;
+                if (r < cnt && col < a.d) load_vec<VEC>(a.rows + (int64_t)pr * a.rows_ld + col, v[j][it]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SEG_BATCH; ++j) {
+            if (ub[j] < 0) break;
+            if (ub[j] != cur) {
+                flush(cur);
+                cur = ub[j];
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[it][e] += v[j][it][e];
+        }
+    }
+    flush(cur);
+}
+
+// phase 2: the chunk in which a boundary-crossing segment STARTS finishes it from the carries
+template <int VEC, int NIT, class Apply>
+__global__ __launch_bounds__(256) void seg_fixup_kernel(SegArgs a, Apply apply) {
+    const int lane = threadIdx.x & 63;
+    const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t k0 = chunk * SEG_R;
+    if (k0 >= a.n) return;
+    const int64_t k1 = min(k0 + SEG_R, a.n);
+    const int u_first = (int)a.inverse[a.perm[k0]];
+    const int u_last = (int)a.inverse[a.perm[k1 - 1]];
+    const int64_t s0 = a.seg_offsets[u_last], s1 = a.seg_offsets[u_last + 1];
+    if (!(s0 >= k0 && s1 > k1)) return;  // not the owner of a crossing segment
+    const int64_t last_chunk = (s1 - 1) / SEG_R;
+    float acc[NIT][VEC];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = (lane + it * 64) * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[it][e] = 0.f;
+        if (col < a.d) load_vec<VEC>(a.carry + ((chunk * 2) + (u_last == u_first ? 0 : 1)) * a.dpad + col, acc[it]);
+    }
+    for (int64_t ch = chunk + 1; ch <= last_chunk; ++ch) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int col = (lane + it * 64) * VEC;
+            if (col < a.d) {
+                float t[VEC];
+                load_vec<VEC>(a.carry + (ch * 2) * a.dpad + col, t);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[it][e] += t[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = (lane + it * 64) * VEC;
+        if (col < a.d) apply.template operator()<VEC>(u_last, col, acc[it]);
+    }
+}
+
+static inline int dpad_of(int d) { return (d + 3) / 4 * 4; }
+
+template <class Apply>
+static int launch_seg(const SegArgs& a, const Apply& apply, int vec, hipStream_t st) {
+    const int64_t nchunks = cdiv(a.n, SEG_R);
+    dim3 grid((unsigned)cdiv(nchunks, 4)), block(256);
+    const int per = cdiv(a.d, 64 * vec);  // column iterations per lane
+#define SEG_LAUNCH(V, N)                                             \
+    do {                                                             \
+        seg_reduce_kernel<V, N, Apply><<<grid, block, 0, st>>>(a, apply); \
+        seg_fixup_kernel<V, N, Apply><<<grid, block, 0, st>>>(a, apply);  \
+    } while (0)
+    if (vec == 4) {
+        if (per <= 1) SEG_LAUNCH(4, 1);
+        else if (per <= 2) SEG_LAUNCH(4, 2);
+        else { set_last_error("segment reduce: d=%d too large", a.d); return MARIUS_ERR_UNSUPPORTED; }
+    } else if (vec == 2) {
+        if (per <= 1) SEG_LAUNCH(2, 1);
+        else if (per <= 2) SEG_LAUNCH(2, 2);
+        else if (per <= 4) SEG_LAUNCH(2, 4);
+        else { set_last_error("segment reduce: d=%d too large", a.d); return MARIUS_ERR_UNSUPPORTED; }
+    } else {
+        if (per <= 1) SEG_LAUNCH(1, 1);
+        else if (per <= 2) SEG_LAUNCH(1, 2);
+        else if (per <= 4) SEG_LAUNCH(1, 4);
+        else if (per <= 8) SEG_LAUNCH(1, 8);
+        else { set_last_error("segment reduce: d=%d too large", a.d); return MARIUS_ERR_UNSUPPORTED; }
+    }
+#undef SEG_LAUNCH
+    return check_launch("segment_reduce");
+}
+
+static int fill_args(SegArgs& a, const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
+                     const int32_t* seg_offsets, int64_t n, int d, void* carry) {
+    MARIUS_REQUIRE(n >= 0 && d > 0 && d <= 512 && rows_ld >= d, "segment reduce: bad sizes n=%ld d=%d", (long)n, d);
+    MARIUS_REQUIRE(n == 0 || (rows && perm && inverse && seg_offsets && carry), "segment reduce: null pointer");
+    a.rows = rows;
+    a.rows_ld = rows_ld;
+    a.perm = perm;
+    a.inverse = inverse;
+    a.seg_offsets = seg_offsets;
+    a.n = n;
+    a.d = d;
+    a.carry = (float*)carry;
+    a.dpad = dpad_of(d);
+    return MARIUS_OK;
+}
+
+}  // namespace marius
+
+using namespace marius;
+
+extern "C" size_t marius_segment_carry_bytes(int64_t n, int32_t d) {
+    return (size_t)cdiv(n > 0 ? n : 1, SEG_R) * 2 * dpad_of(d) * sizeof(float) + 256;
+}
+
+extern "C" int marius_segment_sum_rows(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
+                                       const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* out_rows, float* out,
+                                       int64_t out_ld, void* carry, marius_stream_t stream) {
+    SegArgs a;
+    int rc = fill_args(a, rows, rows_ld, perm, inverse, seg_offsets, n, d, carry);
+    if (rc) return rc;
+    if (n == 0) return MARIUS_OK;
+    MARIUS_REQUIRE(out && out_ld >= d, "segment_sum_rows: bad output");
+    int vec = row_vec_width(rows, rows_ld, d);
+    int v2 = row_vec_width(out, out_ld, d);
+    vec = vec < v2 ? vec : v2;
+    ApplySum ap{out, out_ld, out_rows};
+    return launch_seg(a, ap, vec, as_stream(stream));
+}
+
+extern "C" int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
+                                              const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* uniq_ids,
+                                              float* table, float* state, int64_t table_ld, float lr, float eps, void* carry,
+                                              marius_stream_t stream) {
+    SegArgs a;
+    int rc = fill_args(a, rows, rows_ld, perm, inverse, seg_offsets, n, d, carry);
+    if (rc) return rc;
+    if (n == 0) return MARIUS_OK;
+    MARIUS_REQUIRE(uniq_ids && table && state && table_ld >= d, "segment_adagrad_scatter: bad table arguments");
+    int vec = row_vec_width(rows, rows_ld, d);
+    int v2 = row_vec_width(table, table_ld, d), v3 = row_vec_width(state, table_ld, d);
+    vec = vec < v2 ? vec : v2;
+    vec = vec < v3 ? vec : v3;
+    ApplyAdagrad ap{uniq_ids, table, state, table_ld, lr, eps};
+    return launch_seg(a, ap, vec, as_stream(stream));
+}

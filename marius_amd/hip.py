@@ -1,0 +1,347 @@
+"""ctypes binding of libmarius_hip.so (include/marius_hip.h).  Fails loudly when the library is missing:
+there is NO CPU fallback anywhere in the product path.
+
+The helpers take torch tensors only to obtain device pointers / the current HIP stream; the C-ABI itself sees plain
+pointers and sizes.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmarius_hip.so")
+
+OP_HADAMARD, OP_COMPLEX_HADAMARD, OP_TRANSLATION, OP_NOOP = 0, 1, 2, 3
+CMP_DOT, CMP_L2, CMP_COSINE = 0, 1, 2
+REDUCE_SUM, REDUCE_MEAN = 0, 1
+MT_STATE_WORDS = 625
+
+
+class MariusHipError(RuntimeError):
+    pass
+
+
+class LpDesc(C.Structure):
+    _fields_ = [
+        ("relop", C.c_int32), ("cmp", C.c_int32), ("d", C.c_int32), ("edge_cols", C.c_int32),
+        ("B", C.c_int64), ("C", C.c_int32), ("N", C.c_int32), ("use_inverse", C.c_int32), ("reduction", C.c_int32),
+        ("emb", C.c_void_p), ("emb_ld", C.c_int64), ("U", C.c_int64),
+        ("edges", C.c_void_p), ("dst_neg", C.c_void_p), ("src_neg", C.c_void_p),
+        ("rel", C.c_void_p), ("inv_rel", C.c_void_p), ("rel_ld", C.c_int64), ("R", C.c_int64),
+        ("dst_filter", C.c_void_p), ("n_dst_filter", C.c_int64), ("src_filter", C.c_void_p), ("n_src_filter", C.c_int64),
+    ]
+
+
+class LpLayout(C.Structure):
+    _fields_ = [
+        ("Bp", C.c_int64), ("n_ld", C.c_int64), ("d_ld", C.c_int64), ("total_bytes", C.c_size_t),
+        ("adj", C.c_size_t * 2), ("pos", C.c_size_t * 2), ("neg", C.c_size_t * 2), ("lse", C.c_size_t * 2),
+        ("rowloss", C.c_size_t * 2), ("loss", C.c_size_t), ("dadj", C.c_size_t * 2), ("gocc", C.c_size_t),
+        ("grel", C.c_size_t * 2), ("aux", C.c_size_t),
+    ]
+
+
+_i32, _i64, _f32, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/marius_hip.h one to one
+SIGNATURES = {
+    "marius_hip_abi_version": (C.c_int, []),
+    "marius_hip_last_error": (C.c_char_p, []),
+    "marius_gather_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "marius_gather_rows2": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp]),
+    "marius_scatter_add_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "marius_adagrad_rule": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp]),
+    "marius_dense_adagrad_step": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp]),
+    "marius_mt19937_seed_host": (None, [_vp, C.c_uint64]),
+    "marius_mt19937_fill_host": (None, [_vp, _vp, _i64]),
+    "marius_mt19937_randperm_host": (C.c_int, [_vp, _vp, _i64]),
+    "marius_mt19937_fill": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "marius_negatives_raw_words": (_i64, [_i64, _i64, _i32, _i32, _i32]),
+    "marius_sample_negatives": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "marius_select_edges": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _i64, _vp, _vp]),
+    "marius_sort_unique_workspace_bytes": (_sz, [_i64]),
+    "marius_sort_unique": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "marius_lp_plan": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout)]),
+    "marius_lp_forward": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),
+    "marius_lp_loss": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),
+    "marius_lp_backward": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),
+    "marius_compute_ranks": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp]),
+    "marius_segment_carry_bytes": (_sz, [_i64, _i32]),
+    "marius_segment_sum_rows": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "marius_segment_adagrad_scatter": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libmarius_hip.so; raise (never fall back) if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MariusHipError(
+                "libmarius_hip.so not found at %s — build it with `python -m marius_amd.build`; there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().marius_hip_last_error().decode()
+        raise MariusHipError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise MariusHipError("device tensor required (no CPU fallback)")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ thin wrappers
+def gather_rows(table, ids, out=None):
+    _dev(table)
+    n, d = ids.numel(), table.size(1)
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=table.device)
+    check(lib().marius_gather_rows(ptr(table), table.stride(0), ptr(ids), n, d, ptr(out), out.stride(0), stream_ptr()), "gather_rows")
+    return out
+
+
+def gather_rows2(table_a, table_b, ids, out_a=None, out_b=None):
+    _dev(table_a)
+    n, d = ids.numel(), table_a.size(1)
+    if out_a is None:
+        out_a = torch.empty((n, d), dtype=torch.float32, device=table_a.device)
+        out_b = torch.empty((n, d), dtype=torch.float32, device=table_a.device)
+    assert table_a.stride(0) == table_b.stride(0) and out_a.stride(0) == out_b.stride(0)
+    check(lib().marius_gather_rows2(ptr(table_a), ptr(table_b), table_a.stride(0), ptr(ids), n, d, ptr(out_a), ptr(out_b),
+                                    out_a.stride(0), stream_ptr()), "gather_rows2")
+    return out_a, out_b
+
+
+def scatter_add_rows(table, ids, delta):
+    _dev(table)
+    check(lib().marius_scatter_add_rows(ptr(table), table.stride(0), ptr(ids), ids.numel(), table.size(1), ptr(delta), delta.stride(0),
+                                        stream_ptr()), "scatter_add_rows")
+
+
+def adagrad_rule(grad, state, lr, eps=1e-10):
+    _dev(grad)
+    dw, ds = torch.empty_like(grad), torch.empty_like(grad)
+    check(lib().marius_adagrad_rule(ptr(grad), ptr(state), ptr(dw), ptr(ds), grad.numel(), lr, eps, stream_ptr()), "adagrad_rule")
+    return dw, ds
+
+
+def dense_adagrad_step(param, state_sum, grad, lr, eps=1e-10, weight_decay=0.0):
+    _dev(param)
+    check(lib().marius_dense_adagrad_step(ptr(param), ptr(state_sum), ptr(grad), param.numel(), lr, eps, weight_decay, stream_ptr()),
+          "dense_adagrad_step")
+
+
+class Generator:
+    """ATen-CPU-compatible MT19937 stream that can live on the host or the device."""
+
+    def __init__(self, seed, device=None):
+        self.host = torch.zeros(MT_STATE_WORDS, dtype=torch.int32)
+        lib().marius_mt19937_seed_host(ptr(self.host), seed)
+        self.dev = None
+        self.device = device
+
+    def to_device(self, device=None):
+        self.device = device or self.device
+        self.dev = self.host.to(self.device)
+        return self
+
+    def to_host(self):
+        if self.dev is not None:
+            self.host = self.dev.cpu()
+            self.dev = None
+        return self
+
+    def randperm_host(self, n):
+        self.to_host()
+        out = torch.empty(n, dtype=torch.int64)
+        check(lib().marius_mt19937_randperm_host(ptr(self.host), ptr(out), n), "randperm")
+        return out
+
+    def fill_host(self, n):
+        self.to_host()
+        out = torch.empty(n, dtype=torch.int32)
+        lib().marius_mt19937_fill_host(ptr(self.host), ptr(out), n)
+        return out
+
+    def fill_device(self, n, out=None):
+        if self.dev is None:
+            self.to_device()
+        if out is None:
+            out = torch.empty(n, dtype=torch.int32, device=self.dev.device)
+        check(lib().marius_mt19937_fill(ptr(self.dev), ptr(out), n, stream_ptr()), "mt19937_fill")
+        return out
+
+
+def negatives_raw_words(num_nodes, B, C_, N, n_deg):
+    return lib().marius_negatives_raw_words(num_nodes, B, C_, N, n_deg)
+
+
+def sample_negatives(raw, edges, num_nodes, num_chunks, num_negatives, degree_fraction, inverse):
+    """CorruptNodeNegativeSampler::getNegatives on the device. Returns (ids [C,N], deg_pos [C,n_deg] or None)."""
+    _dev(raw)
+    n_deg = int(num_negatives * degree_fraction)
+    out = torch.empty((num_chunks, num_negatives), dtype=torch.int64, device=raw.device)
+    deg = torch.empty((num_chunks, n_deg), dtype=torch.int64, device=raw.device) if n_deg > 0 else None
+    B = edges.size(0)
+    check(lib().marius_sample_negatives(ptr(raw), ptr(edges), B, edges.size(1), 1 if inverse else 0, num_nodes, num_chunks, num_negatives,
+                                        n_deg, ptr(out), ptr(deg), stream_ptr()), "sample_negatives")
+    return out, deg
+
+
+def select_edges(edges_all, perm, start, B):
+    _dev(edges_all)
+    out = torch.empty((B, edges_all.size(1)), dtype=torch.int64, device=edges_all.device)
+    check(lib().marius_select_edges(ptr(edges_all), 1 if edges_all.dtype == torch.int64 else 0, edges_all.size(1), ptr(perm), start, B,
+                                    ptr(out), stream_ptr()), "select_edges")
+    return out
+
+
+class UniqueMap:
+    """Device buffers + workspace for marius_sort_unique over up to `capacity` ids."""
+
+    def __init__(self, capacity, device):
+        self.cap = capacity
+        self.uniq = torch.empty(capacity, dtype=torch.int64, device=device)
+        self.inverse = torch.empty(capacity, dtype=torch.int64, device=device)
+        self.perm = torch.empty(capacity, dtype=torch.int32, device=device)
+        self.seg = torch.empty(capacity + 1, dtype=torch.int32, device=device)
+        self.count = torch.zeros(1, dtype=torch.int64, device=device)
+        self.ws_bytes = lib().marius_sort_unique_workspace_bytes(capacity)
+        if self.ws_bytes == 0:
+            raise MariusHipError("sort_unique workspace query failed")
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+
+    def run(self, ids, key_bits=63):
+        n = ids.numel()
+        assert n <= self.cap
+        check(lib().marius_sort_unique(ptr(ids), n, key_bits, ptr(self.uniq), ptr(self.inverse), ptr(self.perm), ptr(self.seg),
+                                       ptr(self.count), ptr(self.ws), self.ws_bytes, stream_ptr()), "sort_unique")
+        return self
+
+
+class LpWorkspace:
+    """marius_lp_desc + layout + workspace for one batch shape."""
+
+    def __init__(self, relop, cmp, d, B, C_, N, use_inverse, reduction, edge_cols, has_src_neg, device):
+        self.desc = LpDesc()
+        self.desc.relop, self.desc.cmp, self.desc.d, self.desc.edge_cols = relop, cmp, d, edge_cols
+        self.desc.B, self.desc.C, self.desc.N = B, C_, N
+        self.desc.use_inverse, self.desc.reduction = int(use_inverse), reduction
+        # plan needs src_neg / inv_rel presence for validation: use dummy non-null markers
+        self.desc.src_neg = C.c_void_p(1) if has_src_neg else None
+        self.desc.inv_rel = C.c_void_p(1) if use_inverse else None
+        self.layout = LpLayout()
+        check(lib().marius_lp_plan(C.byref(self.desc), C.byref(self.layout)), "lp_plan")
+        self.ws = torch.empty(self.layout.total_bytes, dtype=torch.uint8, device=device)
+        self.device = device
+        self._keep = None
+
+    def bind(self, emb, edges, dst_neg, src_neg, rel, inv_rel, dst_filter=None, src_filter=None):
+        d = self.desc
+        d.emb, d.emb_ld, d.U = emb.data_ptr(), emb.stride(0), emb.size(0)
+        d.edges, d.dst_neg = edges.data_ptr(), dst_neg.data_ptr()
+        d.src_neg = src_neg.data_ptr() if src_neg is not None else None
+        d.rel = rel.data_ptr() if rel is not None else None
+        d.inv_rel = inv_rel.data_ptr() if inv_rel is not None else None
+        d.rel_ld = rel.stride(0) if rel is not None else 0
+        d.R = rel.size(0) if rel is not None else 0
+        d.dst_filter = dst_filter.data_ptr() if dst_filter is not None and dst_filter.numel() else None
+        d.n_dst_filter = dst_filter.size(0) if dst_filter is not None else 0
+        d.src_filter = src_filter.data_ptr() if src_filter is not None and src_filter.numel() else None
+        d.n_src_filter = src_filter.size(0) if src_filter is not None else 0
+        self._keep = (emb, edges, dst_neg, src_neg, rel, inv_rel, dst_filter, src_filter)
+        return self
+
+    def forward(self):
+        check(lib().marius_lp_forward(C.byref(self.desc), C.byref(self.layout), ptr(self.ws), stream_ptr()), "lp_forward")
+
+    def loss(self):
+        check(lib().marius_lp_loss(C.byref(self.desc), C.byref(self.layout), ptr(self.ws), stream_ptr()), "lp_loss")
+
+    def backward(self):
+        check(lib().marius_lp_backward(C.byref(self.desc), C.byref(self.layout), ptr(self.ws), stream_ptr()), "lp_backward")
+
+    # typed views into the workspace
+    def _view(self, off, shape):
+        n = 1
+        for s in shape:
+            n *= s
+        return self.ws[off:off + 4 * n].view(torch.float32).view(*shape)
+
+    def pos(self, dir_):
+        return self._view(self.layout.pos[dir_], (self.layout.Bp,))
+
+    def neg(self, dir_):
+        return self._view(self.layout.neg[dir_], (self.layout.Bp, self.layout.n_ld))[:, : self.desc.N]
+
+    def lse(self, dir_):
+        return self._view(self.layout.lse[dir_], (self.layout.Bp,))
+
+    def loss_values(self):
+        return self._view(self.layout.loss, (4,))
+
+    def adj(self, dir_):
+        return self._view(self.layout.adj[dir_], (self.layout.Bp, self.layout.d_ld))[:, : self.desc.d]
+
+    def dadj(self, dir_):
+        return self._view(self.layout.dadj[dir_], (self.layout.Bp, self.layout.d_ld))[:, : self.desc.d]
+
+    def num_occ(self):
+        return 2 * self.desc.B + (2 if self.desc.src_neg else 1) * self.desc.C * self.desc.N
+
+    def gocc(self):
+        return self._view(self.layout.gocc, (self.num_occ(), self.layout.d_ld))
+
+    def grel(self, dir_):
+        return self._view(self.layout.grel[dir_], (self.desc.B, self.layout.d_ld))
+
+
+def compute_ranks(pos, neg):
+    _dev(pos)
+    ranks = torch.empty(pos.numel(), dtype=torch.int64, device=pos.device)
+    check(lib().marius_compute_ranks(ptr(pos), ptr(neg), pos.numel(), neg.size(1), neg.stride(0), ptr(ranks), stream_ptr()), "compute_ranks")
+    return ranks
+
+
+def segment_carry(n, d, device):
+    return torch.empty(lib().marius_segment_carry_bytes(n, d), dtype=torch.uint8, device=device)
+
+
+def segment_sum_rows(rows, um, n, d, out, out_rows=None, carry=None):
+    _dev(rows)
+    if carry is None:
+        carry = segment_carry(n, d, rows.device)
+    check(lib().marius_segment_sum_rows(ptr(rows), rows.stride(0), ptr(um.perm), ptr(um.inverse), ptr(um.seg), n, d, ptr(out_rows), ptr(out),
+                                        out.stride(0), ptr(carry), stream_ptr()), "segment_sum_rows")
+    return out
+
+
+def segment_adagrad_scatter(rows, um, n, d, table, state, lr, eps=1e-10, carry=None):
+    _dev(rows)
+    if carry is None:
+        carry = segment_carry(n, d, rows.device)
+    check(lib().marius_segment_adagrad_scatter(ptr(rows), rows.stride(0), ptr(um.perm), ptr(um.inverse), ptr(um.seg), n, d, ptr(um.uniq),
+                                               ptr(table), ptr(state), table.stride(0), lr, eps, ptr(carry), stream_ptr()),
+          "segment_adagrad_scatter")

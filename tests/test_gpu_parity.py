@@ -1,0 +1,331 @@
+"""GPU parity tests: HIP path (through the C-ABI of libmarius_hip.so) vs the oracle on the same seeded inputs.
+
+Bars: bit-exact for ids / indices / copies; floats within rtol 1e-4 (north_star: "within 1e-4 relative on float
+scores"), with an absolute floor of 1e-4 x the tensor's max magnitude for entries that cancel to ~0.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lp_oracle as O
+from oracle.mt_oracle import OracleGenerator
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def assert_close(got, want, what, rtol=RTOL):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    atol = rtol * max(want.abs().max().item(), 1e-30)
+    err = (got - want).abs()
+    ok = err <= atol + rtol * want.abs()
+    assert bool(ok.all()), "%s: max abs err %.3e (atol %.3e), worst rel %.3e" % (
+        what, err.max().item(), atol, (err / want.abs().clamp_min(1e-30)).max().item())
+
+
+@pytest.fixture(scope="module")
+def H():
+    from marius_amd import hip
+
+    hip.lib()
+    return hip
+
+
+# ------------------------------------------------------------------------------------------------ storage rows
+@pytest.mark.parametrize("d", [2, 50, 100, 128, 400])
+def test_gather_scatter_rows(H, dev, d):
+    g = torch.Generator().manual_seed(d)
+    num_nodes, n = 5000, 1777
+    table = torch.randn(num_nodes, d, generator=g)
+    state = torch.rand(num_nodes, d, generator=g)
+    ids = torch.randperm(num_nodes, generator=g)[:n].sort().values
+    t_d, s_d, ids_d = table.to(dev), state.to(dev), ids.to(dev)
+    out = H.gather_rows(t_d, ids_d)
+    assert torch.equal(out.cpu(), O.index_read(table, ids))  # bit exact copy
+    a, b = H.gather_rows2(t_d, s_d, ids_d)
+    assert torch.equal(a.cpu(), table[ids]) and torch.equal(b.cpu(), state[ids])
+    delta = torch.randn(n, d, generator=g)
+    H.scatter_add_rows(t_d, ids_d, delta.to(dev))
+    ref = table.clone()
+    O.index_add(ref, ids, delta)
+    assert torch.equal(t_d.cpu(), ref)  # unique ids: one add per element, bit exact
+
+
+def test_gather_empty_and_errors(H, dev):
+    table = torch.randn(10, 8, device=dev)
+    ids = torch.empty(0, dtype=torch.int64, device=dev)
+    assert H.gather_rows(table, ids).shape == (0, 8)
+    with pytest.raises(H.MariusHipError):
+        H.check(H.lib().marius_gather_rows(H.ptr(table), 4, H.ptr(ids), 1, 8, H.ptr(table), 8, None), "bad ld")
+
+
+def test_adagrad_rule_bit_exact(H, dev):
+    g = torch.Generator().manual_seed(3)
+    grad = torch.randn(1234, 100, generator=g)
+    state = torch.rand(1234, 100, generator=g)
+    st = state.clone()
+    dw_ref, ds_ref = O.accumulate_gradients(grad, st, 0.1)
+    st_d = state.to(dev)
+    dw, ds = H.adagrad_rule(grad.to(dev), st_d, 0.1)
+    assert torch.equal(ds.cpu(), ds_ref)
+    assert torch.equal(st_d.cpu(), st)
+    assert_close(dw, dw_ref, "dw", rtol=1e-6)
+
+
+def test_dense_adagrad_step(H, dev):
+    g = torch.Generator().manual_seed(4)
+    w, gr, ssum = torch.randn(237, 100, generator=g), torch.randn(237, 100, generator=g), torch.rand(237, 100, generator=g)
+    w_d, s_d = w.to(dev), ssum.to(dev)
+    H.dense_adagrad_step(w_d, s_d, gr.to(dev), 0.1)
+    O.dense_adagrad_step(w, gr, ssum, 0.1)
+    assert_close(s_d, ssum, "sum", rtol=1e-6)
+    assert_close(w_d, w, "w", rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ sampler
+@pytest.mark.parametrize("n", [1, 623, 624, 625, 5000, 100000])
+def test_mt19937_device_stream_bit_exact(H, dev, n):
+    gen = H.Generator(42, dev)
+    raw = gen.fill_device(n)
+    want = OracleGenerator(42).raw(n)
+    assert np.array_equal(raw.cpu().numpy().view(np.uint32), want)
+    # stream continues correctly across calls and across host <-> device hand-over
+    raw2 = gen.fill_device(700)
+    og = OracleGenerator(42)
+    og.raw(n)
+    assert np.array_equal(raw2.cpu().numpy().view(np.uint32), og.raw(700))
+    perm = gen.randperm_host(50)
+    assert np.array_equal(perm.numpy(), og.randperm(50))
+
+
+@pytest.mark.parametrize("B,C,N,f,num_nodes", [(6, 1, 5, 0.0, 6), (6, 3, 5, 0.5, 6), (1000, 10, 500, 0.0, 14541),
+                                               (1000, 10, 500, 0.5, 14541), (5000, 50, 1000, 0.0, 86054151),
+                                               (64, 2, 16, 0.25, 2 ** 28 + 5)])
+def test_negative_sampler_bit_exact(H, dev, B, C, N, f, num_nodes):
+    seed = 1234 + B
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(B)
+    edges = torch.stack([torch.randint(num_nodes, (B,), generator=g), torch.randint(7, (B,), generator=g),
+                         torch.randint(num_nodes, (B,), generator=g)], 1)
+    og = OracleGenerator(seed)
+    gen = H.Generator(seed, dev)
+    edges_d = edges.to(dev)
+    n_deg = int(N * f)
+    for inverse in (True, False):  # DataLoader::negativeSample order: src negatives first (dataloader.cpp:498-503)
+        want_ids, want_deg = og.get_negatives(edges.numpy(), num_nodes, C, N, f, inverse)
+        words = H.negatives_raw_words(num_nodes, B, C, N, n_deg)
+        raw = gen.fill_device(words)
+        ids, deg = H.sample_negatives(raw, edges_d, num_nodes, C, N, f, inverse)
+        assert np.array_equal(ids.cpu().numpy(), want_ids)
+        if n_deg:
+            assert np.array_equal(deg.cpu().numpy(), want_deg)
+        # and the oracle itself is the torch stream (same generator calls as negative.cpp:340-357)
+        if num_nodes < 2 ** 28 or True:
+            chunks = []
+            for _ in range(C):
+                uni = torch.randint(num_nodes, (N - n_deg,))
+                if f > 0:
+                    pos = torch.randint(0, B, (n_deg,))
+                    uni = torch.cat([edges[pos, 0 if inverse else 2], uni])
+                chunks.append(uni)
+            assert np.array_equal(torch.stack(chunks).numpy(), want_ids)
+
+
+def test_select_edges(H, dev):
+    g = torch.Generator().manual_seed(9)
+    E = 5000
+    edges32 = torch.randint(0, 1000, (E, 3), generator=g, dtype=torch.int32)
+    gen = H.Generator(7, dev)
+    perm = gen.randperm_host(E)
+    torch.manual_seed(7)
+    assert torch.equal(perm, torch.randperm(E))
+    out = H.select_edges(edges32.to(dev), perm.to(dev), 1000, 777)
+    assert torch.equal(out.cpu(), edges32[perm[1000:1777]].to(torch.int64))
+
+
+# ------------------------------------------------------------------------------------------------ unique map
+@pytest.mark.parametrize("n,hi", [(1, 5), (12, 6), (12000, 14541), (200000, 86054151), (200000, 300)])
+def test_sort_unique_matches_map_tensors(H, dev, n, hi):
+    g = torch.Generator().manual_seed(n + hi)
+    parts = [torch.randint(hi, (n // 4 + 1,), generator=g) for _ in range(4)]
+    uniq_ref, mapped_ref = O.map_tensors(parts)
+    ids = torch.cat(parts).to(dev)
+    um = H.UniqueMap(ids.numel(), dev).run(ids, key_bits=max(1, math.ceil(math.log2(hi + 1))))
+    U = int(um.count.item())
+    assert U == uniq_ref.numel()
+    assert torch.equal(um.uniq[:U].cpu(), uniq_ref)
+    assert torch.equal(um.inverse[: ids.numel()].cpu(), torch.cat(mapped_ref))
+    seg = um.seg[: U + 1].cpu()
+    perm = um.perm[: ids.numel()].cpu().long()
+    assert seg[0] == 0 and seg[U] == ids.numel()
+    sorted_ids = ids.cpu()[perm]
+    assert torch.equal(sorted_ids, torch.sort(ids.cpu(), stable=True).values)
+    assert torch.equal(perm, torch.sort(ids.cpu(), stable=True).indices)  # stable order
+
+
+def test_sort_unique_empty(H, dev):
+    um = H.UniqueMap(8, dev)
+    um.run(torch.empty(0, dtype=torch.int64, device=dev))
+    assert int(um.count.item()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ decoder fwd / loss / bwd
+DEC = {"DISTMULT": (0, 0), "COMPLEX": (1, 0), "TRANSE": (2, 1)}
+
+
+def make_batch(decoder, B, C, N, d, U, R, seed, zipf=False):
+    g = torch.Generator().manual_seed(seed)
+    emb = torch.randn(U, d, generator=g) * 0.5
+    state = torch.rand(U, d, generator=g)
+    if zipf:  # heavy duplicates: hub nodes / hub relations
+        src = (torch.rand(B, generator=g) ** 4 * U).long().clamp_(0, U - 1)
+        rel = (torch.rand(B, generator=g) ** 4 * R).long().clamp_(0, R - 1)
+    else:
+        src = torch.randint(U, (B,), generator=g)
+        rel = torch.randint(R, (B,), generator=g)
+    dst = torch.randint(U, (B,), generator=g)
+    edges = torch.stack([src, rel, dst], 1)
+    dst_neg = torch.randint(U, (C, N), generator=g)
+    src_neg = torch.randint(U, (C, N), generator=g)
+    relations = O.init_relations(decoder, R, d) + 0.3 * torch.randn(R, d, generator=g)
+    inv_relations = O.init_relations(decoder, R, d) + 0.3 * torch.randn(R, d, generator=g)
+    return emb, state, edges, dst_neg, src_neg, relations, inv_relations
+
+
+def run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, reduction, dst_filter=None, src_filter=None):
+    relop, cmp = DEC[decoder]
+    B, (C, N), d = edges.size(0), dst_neg.shape, emb.size(1)
+    W = H.LpWorkspace(relop, cmp, d, B, C, N, use_inverse, H.REDUCE_SUM if reduction == "sum" else H.REDUCE_MEAN, edges.size(1), True, dev)
+    t = lambda x: None if x is None else x.to(dev)
+    W.bind(t(emb), t(edges), t(dst_neg), t(src_neg), t(rel), t(inv) if use_inverse else None, t(dst_filter), t(src_filter))
+    W.forward()
+    W.loss()
+    W.backward()
+    torch.cuda.synchronize()
+    return W
+
+
+@pytest.mark.parametrize("decoder", ["DISTMULT", "COMPLEX", "TRANSE"])
+@pytest.mark.parametrize("use_inverse", [True, False])
+@pytest.mark.parametrize("B,C,N,d", [(6, 3, 5, 2), (100, 10, 50, 50), (1000, 10, 500, 100), (250, 7, 130, 100), (300, 4, 260, 200)])
+@pytest.mark.parametrize("reduction", ["sum"])
+def test_lp_forward_loss_backward(H, dev, decoder, use_inverse, B, C, N, d, reduction):
+    U, R = max(40, B), 11
+    emb, state, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=B + d, zipf=(B == 250))
+    want = O.train_batch(decoder, emb, state, edges, dst_neg, src_neg, rel, inv if use_inverse else None, reduction=reduction)
+    W = run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, reduction)
+    Bp = W.layout.Bp
+    assert Bp == want["pos"].numel()
+    assert_close(W.pos(0), want["pos"], "pos")
+    assert_close(W.neg(0), want["neg"], "neg")
+    if use_inverse:
+        assert_close(W.pos(1), want["inv_pos"], "inv_pos")
+        assert_close(W.neg(1), want["inv_neg"], "inv_neg")
+    assert_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss")
+    # node gradient: segment-sum of the occurrence gradients in map order == autograd's index_add
+    L = W.num_occ()
+    occ_ids = torch.cat([edges[:, 0], edges[:, 2], src_neg.flatten(), dst_neg.flatten()])
+    gocc = W.gocc()[:, :d].cpu()
+    node_grad = torch.zeros(U, d, dtype=torch.float64).index_add_(0, occ_ids, gocc.double())
+    assert_close(node_grad.float(), want["node_grad"], "node_grad")
+    rel_grad = torch.zeros(R, d, dtype=torch.float64).index_add_(0, edges[:, 1], W.grel(0)[:, :d].cpu().double())
+    assert_close(rel_grad.float(), want["rel_grad"], "rel_grad")
+    if use_inverse:
+        inv_grad = torch.zeros(R, d, dtype=torch.float64).index_add_(0, edges[:, 1], W.grel(1)[:, :d].cpu().double())
+        assert_close(inv_grad.float(), want["inv_rel_grad"], "inv_rel_grad")
+
+
+@pytest.mark.parametrize("decoder", ["DISTMULT", "TRANSE"])
+def test_lp_mean_reduction_and_filter(H, dev, decoder):
+    B, C, N, d, U, R = 96, 4, 40, 20, 60, 5
+    emb, state, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=77)
+    g = torch.Generator().manual_seed(5)
+    dst_filter = torch.stack([torch.randint(B, (30,), generator=g), torch.randint(N, (30,), generator=g)], 1)
+    src_filter = torch.stack([torch.randint(B, (17,), generator=g), torch.randint(N, (17,), generator=g)], 1)
+    want = O.train_batch(decoder, emb, state, edges, dst_neg, src_neg, rel, inv, dst_filter=dst_filter, src_filter=src_filter, reduction="mean")
+    W = run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, "mean", dst_filter, src_filter)
+    assert_close(W.neg(0), want["neg"], "neg filtered")
+    assert_close(W.neg(1), want["inv_neg"], "inv_neg filtered")
+    assert_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss")
+    occ_ids = torch.cat([edges[:, 0], edges[:, 2], src_neg.flatten(), dst_neg.flatten()])
+    node_grad = torch.zeros(U, d, dtype=torch.float64).index_add_(0, occ_ids, W.gocc()[:, :d].cpu().double())
+    assert_close(node_grad.float(), want["node_grad"], "node_grad")
+
+
+def test_lp_two_column_edges(H, dev):
+    """num_relations == 1: edges [B,2], no relation operator, single direction (decoder_methods.cpp:98-101)."""
+    B, C, N, d, U = 64, 4, 24, 16, 50
+    g = torch.Generator().manual_seed(2)
+    emb = torch.randn(U, d, generator=g)
+    edges = torch.stack([torch.randint(U, (B,), generator=g), torch.randint(U, (B,), generator=g)], 1)
+    dst_neg, src_neg = torch.randint(U, (C, N), generator=g), torch.randint(U, (C, N), generator=g)
+    want = O.train_batch("DISTMULT", emb, torch.zeros(U, d), edges, dst_neg, src_neg, None, None)
+    W = H.LpWorkspace(0, 0, d, B, C, N, False, H.REDUCE_SUM, 2, True, dev)
+    W.bind(emb.to(dev), edges.to(dev), dst_neg.to(dev), src_neg.to(dev), None, None)
+    W.forward(); W.loss(); W.backward()
+    assert_close(W.pos(0), want["pos"], "pos")
+    assert_close(W.neg(0), want["neg"], "neg")
+    occ_ids = torch.cat([edges[:, 0], edges[:, 1], src_neg.flatten(), dst_neg.flatten()])
+    node_grad = torch.zeros(U, d, dtype=torch.float64).index_add_(0, occ_ids, W.gocc()[:, :d].cpu().double())
+    assert_close(node_grad.float(), want["node_grad"], "node_grad")
+
+
+def test_lp_bad_edge_columns_raises(H, dev):
+    with pytest.raises(H.MariusHipError, match="3 or 2 column"):
+        H.LpWorkspace(0, 0, 8, 4, 1, 4, False, 0, 4, True, dev)
+
+
+def test_compute_ranks(H, dev):
+    g = torch.Generator().manual_seed(8)
+    pos, neg = torch.randn(500, generator=g), torch.randn(500, 333, generator=g)
+    neg[5, 7] = pos[5]  # tie counts as >=
+    got = H.compute_ranks(pos.to(dev), neg.to(dev))
+    assert torch.equal(got.cpu(), O.compute_ranks(pos, neg))
+
+
+# ------------------------------------------------------------------------------------------------ gradient reduce + fused update
+@pytest.mark.parametrize("n,U,d", [(1, 1, 4), (1000, 900, 100), (5000, 37, 50), (20000, 19000, 100), (4096, 3, 7), (3000, 2500, 400)])
+def test_segment_sum_rows(H, dev, n, U, d):
+    g = torch.Generator().manual_seed(n + U)
+    ids = torch.randint(U, (n,), generator=g)
+    rows = torch.randn(n, d, generator=g)
+    um = H.UniqueMap(n, dev).run(ids.to(dev), key_bits=32)
+    nu = int(um.count.item())
+    out = torch.zeros(nu, d, device=dev)
+    H.segment_sum_rows(rows.to(dev), um, n, d, out)
+    uniq, inv = torch.unique(ids, return_inverse=True)
+    want = torch.zeros(nu, d, dtype=torch.float64).index_add_(0, inv, rows.double())
+    assert_close(out, want.float(), "segment sum", rtol=2e-6 * max(1, n // max(nu, 1)) ** 0.5 + 1e-6)
+    # indexed variant (dense relation gradient)
+    dense = torch.zeros(U, d, device=dev)
+    H.segment_sum_rows(rows.to(dev), um, n, d, dense, out_rows=um.uniq)
+    want_dense = torch.zeros(U, d, dtype=torch.float64).index_add_(0, ids, rows.double())
+    assert_close(dense, want_dense.float(), "segment sum indexed", rtol=1e-5)
+    # reproducible: same bits on a second run
+    out2 = torch.zeros(nu, d, device=dev)
+    H.segment_sum_rows(rows.to(dev), um, n, d, out2)
+    assert torch.equal(out, out2)
+
+
+def test_segment_adagrad_scatter_matches_reference_update(H, dev):
+    g = torch.Generator().manual_seed(11)
+    num_nodes, n, d = 3000, 8000, 100
+    ids = (torch.rand(n, generator=g) ** 3 * num_nodes).long()
+    rows = torch.randn(n, d, generator=g) * 0.1
+    table, state = torch.randn(num_nodes, d, generator=g), torch.rand(num_nodes, d, generator=g)
+    um = H.UniqueMap(n, dev).run(ids.to(dev), key_bits=16)
+    t_d, s_d = table.to(dev), state.to(dev)
+    H.segment_adagrad_scatter(rows.to(dev), um, n, d, t_d, s_d, lr=0.1)
+    # reference sequence: grad = index_add; accumulateGradients on the gathered copies; indexAdd x2
+    uniq, inv = torch.unique(ids, return_inverse=True)
+    grad = torch.zeros(uniq.numel(), d).index_add_(0, inv, rows)
+    st = O.index_read(state, uniq)
+    dw, ds = O.accumulate_gradients(grad, st, 0.1)
+    O.index_add(table, uniq, dw)
+    O.index_add(state, uniq, ds)
+    assert_close(t_d, table, "table after update", rtol=1e-5)
+    assert_close(s_d, state, "state after update", rtol=1e-5)
