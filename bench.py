@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py — edges/sec scored (pos+neg) for Marius's link-prediction training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload freebase86m|fb15k237] [--num-nodes N] [--edge-dist zipf|uniform]
+
+A "step" is one pass of the whole hot path over one batch of synthetic Freebase86m-shaped input already resident in HBM:
+edge slice -> MT19937 negative sampling -> sort/unique map -> row gather -> ComplEx scores (FP32 MFMA) -> SoftmaxCE ->
+hand-derived backward -> dense Adagrad on the relation tables -> segmented-sum + sparse Adagrad scatter into the node table.
+Prints ONE JSON line (rank 0).  The CPU baseline leg runs the oracle (a port of the reference's CPU path) on a bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # cfg2 (the configuration BASELINE.json's metric is quoted on)
+    "freebase86m": dict(decoder="COMPLEX", num_nodes=86054151, num_relations=14824, d=100, B=50000, C=50, N=1000, num_edges=10_000_000),
+    # cfg1 shape (reference's CPU-runnable case), for quick runs
+    "fb15k237": dict(decoder="DISTMULT", num_nodes=14541, num_relations=237, d=100, B=1000, C=10, N=500, num_edges=272115),
+}
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32x32x2_f32)
+
+
+def synth_edges(num_nodes, num_relations, E, dist, device, seed=1):
+    g = torch.Generator(device=device).manual_seed(seed)
+    if dist == "zipf":  # P(k) ~ 1/k via inverse CDF k = n^u, then an affine permutation of the ids
+        def zipf(n, count, a, c):
+            u = torch.rand(count, generator=g, device=device, dtype=torch.float64)
+            k = torch.exp(u * math.log(n)).long().clamp_(1, n) - 1
+            return (k * a + c) % n
+        src = zipf(num_nodes, E, 48271, 11)
+        dst = zipf(num_nodes, E, 69621, 7)
+        rel = zipf(num_relations, E, 1, 0)
+    else:
+        src = torch.randint(num_nodes, (E,), generator=g, device=device)
+        dst = torch.randint(num_nodes, (E,), generator=g, device=device)
+        rel = torch.randint(num_relations, (E,), generator=g, device=device)
+    return torch.stack([src, rel, dst], 1).to(torch.int32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="freebase86m", choices=sorted(WORKLOADS))
+    ap.add_argument("--num-nodes", type=int, default=0, help="override the node count (smaller table for quick tests)")
+    ap.add_argument("--edge-dist", default="zipf", choices=["zipf", "uniform"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    assert a.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
+
+    from marius_amd import hip as H
+    from marius_amd.lp_step import DeviceLinkPredictionStep
+
+    H.lib()
+    cfg = dict(WORKLOADS[a.workload])
+    if a.num_nodes:
+        cfg["num_nodes"] = a.num_nodes
+    num_nodes, R, d, B, C, N = cfg["num_nodes"], cfg["num_relations"], cfg["d"], cfg["B"], cfg["C"], cfg["N"]
+
+    if world > 1:
+        from marius_amd.sharded import run_sharded_bench
+        return run_sharded_bench(a, cfg, rank, world, dev)
+
+    # ---- synthetic inputs, resident in HBM before the timed region
+    limit = math.sqrt(6.0 / (num_nodes + d))  # glorot_uniform over the full table shape (initialization.cpp:26-41)
+    table = torch.empty((num_nodes, d), dtype=torch.float32, device=dev).uniform_(-limit, limit, generator=torch.Generator(device=dev).manual_seed(0))
+    state = torch.zeros((num_nodes, d), dtype=torch.float32, device=dev)
+    edges_all = synth_edges(num_nodes, R, cfg["num_edges"], a.edge_dist, dev)
+    stepper = DeviceLinkPredictionStep(cfg["decoder"], num_nodes, R, d, B, C, N, seed=42, device=dev, node_table=table, node_state=state)
+    perm = stepper.gen.randperm_host(edges_all.size(0)).to(dev)  # setActiveEdges: randperm on the same generator stream
+    nbatches = edges_all.size(0) // B
+
+    def run(k0, k):
+        for s in range(k0, k0 + k):
+            edges = H.select_edges(edges_all, perm, (s % nbatches) * B, B)
+            stepper.step(edges)
+
+    run(0, a.warmup)
+    torch.cuda.synchronize()
+    H.profile_reset()
+    H.profile_enable(True)
+    t0 = time.perf_counter()
+    run(a.warmup, a.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    H.profile_enable(False)
+    prof = H.profile_read()
+
+    ms_per_step = dt / a.steps * 1e3
+    pos_eps = B * a.steps / dt
+    scored_eps = pos_eps * (2 + 2 * N)
+    U = int(stepper.um.count.item())
+    loss = float(stepper.W.loss_values()[0].item())
+
+    # ---- roofline of the kernels, from HIP events recorded on the launch stream inside the timed region
+    Bp = stepper.W.layout.Bp
+    contraction_flops = 2.0 * Bp * N * d * 2  # one [Bc x d] x [d x N] contraction per chunk, both directions
+    L = stepper.L
+    alg = {  # algorithmic work per launch
+        "lp_scores": ("mfma", contraction_flops),
+        "lp_grad_adj": ("mfma", contraction_flops),
+        "lp_grad_neg": ("mfma", contraction_flops),
+        "gather_rows": ("hbm", U * d * 4.0 * 2 + U * 8.0),                    # read rows + write batch copy + ids
+        "segment_adagrad_scatter": ("hbm", L * d * 4.0 + U * d * 4.0 * 4),    # occurrence grads + r/w of w and s
+        "lp_lse": ("hbm", 2.0 * Bp * N * 4.0),
+        "lp_prep": ("hbm", 2.0 * Bp * d * 4.0 * 4),
+        "lp_edge_bwd": ("hbm", 2.0 * B * d * 4.0 * 6),
+        "sort_unique": ("hbm", L * (8.0 + 4.0) * 2 * 4),
+        "mt19937_fill": ("hbm", 2.0 * C * N * 4.0 * 2),
+    }
+    kernels = {}
+    for name, (ms, cnt) in prof.items():
+        if cnt == 0 or name not in alg:
+            continue
+        bound, work = alg[name]
+        avg_ms = ms / cnt
+        if bound == "mfma":
+            ach, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
+        else:
+            ach, peak, unit = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        kernels[name] = {"bound": bound, "avg_ms": round(avg_ms, 4), "launches": cnt, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                         "frac": round(ach / peak, 4)}
+    dom = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
+    roofline = None
+    if dom:
+        k = kernels[dom]
+        roofline = {"kernel": dom, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"], "frac": k["frac"],
+                    "traffic": None, "avg_ms": k["avg_ms"]}
+
+    # ---- CPU baseline: the oracle (port of the reference's CPU path) on a bounded sample, host cores of this box
+    cpu = None
+    if not a.no_cpu_baseline:
+        from oracle.cpu_step import time_cpu_baseline
+        proxy = min(num_nodes, 10_000_000)
+        e_cpu = edges_all[: B * 16].cpu().long()
+        v, steps, threads = time_cpu_baseline(cfg["decoder"], proxy, num_nodes, R, d, B, C, N, e_cpu, max_seconds=a.cpu_seconds)
+        cpu = {"value": round(v * (2 + 2 * N), 1), "unit": "scored edges/s", "positive_edges_per_s": round(v, 1), "cores": threads, "kind": "port",
+               "sample": "%d full steps (B=%d) of the same workload on a %d-row proxy table, oracle/cpu_step.py, torch CPU ops" % (steps, B, proxy)}
+
+    out = {
+        "metric": "edges/sec scored (pos+neg)", "value": round(scored_eps, 1), "unit": "scored edges/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s %s d=%d in-memory, B=%d C=%d N=%d inverse_edges, SoftmaxCE SUM, Adagrad lr 0.1, %s edges" % (
+            a.workload, cfg["decoder"], d, B, C, N, a.edge_dist), "num_nodes": num_nodes, "num_relations": R, "num_edges": cfg["num_edges"],
+            "parallelism": "single GPU"},
+        "positive_edges_per_s": round(pos_eps, 1), "unique_rows_last_batch": U, "loss_last_batch": loss,
+        "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

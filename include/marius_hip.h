@@ -34,6 +34,14 @@ enum { MARIUS_REDUCE_SUM = 0, MARIUS_REDUCE_MEAN = 1 };
 int marius_hip_abi_version(void);
 const char* marius_hip_last_error(void);
 
+/* Optional HIP-event profiler (bench.py's roofline): when enabled, the library records hipEvents on the launch stream
+ * around its main kernels; marius_profile_read waits for them and returns the accumulated kernel time. */
+int marius_profile_enable(int on);
+int marius_profile_reset(void);
+int marius_profile_kernel_count(void);
+const char* marius_profile_kernel_name(int id);
+int marius_profile_read(int id, double* total_ms, int64_t* launches);
+
 /* ------------------------------------------------------------------------------------------------ storage */
 
 /* out[i, 0:d] = table[ids[i], 0:d]            replaces InMemory::indexRead  src/storage/storage.cpp:606-649
@@ -86,10 +94,25 @@ int marius_sample_negatives(const uint32_t* raw, const int64_t* edges, int64_t B
                             int64_t num_nodes, int32_t num_chunks, int32_t num_negatives, int32_t num_deg,
                             int64_t* out_ids, int64_t* deg_pos, marius_stream_t stream);
 
+/* deg_negative_local_filter  src/data/samplers/negative.cpp:21-39 (LocalFilterMode::DEG, training):
+ * out [C * num_deg, 2] int64, row (c * num_deg + k) = (e, k) if e = deg_pos[c][k] lies in chunk c (e / ceil(B / C) == c), else (-1, -1).
+ * Rows with -1 are ignored by marius_lp_forward's filter; dropping them yields the reference's tensor in its order. */
+int marius_deg_filter(const int64_t* deg_pos, int32_t num_chunks, int32_t num_deg, int64_t B, int64_t* out, marius_stream_t stream);
+
 /* out[i, :] = edges[perm[start + i], :] cast to int64      replaces active_edges_ index_select + RandomEdgeSampler::getEdges
  * src/data/dataloader.cpp:180-182, src/data/samplers/edge.cpp:12-14.  edges_in is int32 or int64 ([E, cols]). */
 int marius_select_edges(const void* edges_in, int32_t in_is_int64, int32_t cols, const int64_t* perm, int64_t start,
                         int64_t B, int64_t* out, marius_stream_t stream);
+
+/* all_ids = cat({src, dst, src_neg.flatten(), dst_neg.flatten()})   DataLoader::edgeSample src/data/dataloader.cpp:400-409
+ * (src_neg / dst_neg may be NULL).  out has 2B + (#neg tensors) * CN entries. */
+int marius_assemble_ids(const int64_t* edges, int64_t B, int32_t edge_cols, const int64_t* src_neg, const int64_t* dst_neg,
+                        int64_t CN, int64_t* out, marius_stream_t stream);
+
+/* batch->edges_ = stack({src_mapping, rel, dst_mapping}) with the inverse of marius_sort_unique over all_ids
+ * src/data/dataloader.cpp:460-466.  (The negative mappings are the views inverse[2B ..] — no kernel needed.) */
+int marius_remap_edges(const int64_t* edges, const int64_t* inverse, int64_t B, int32_t edge_cols, int64_t* out,
+                       marius_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ unique map */
 
@@ -97,7 +120,7 @@ size_t marius_sort_unique_workspace_bytes(int64_t n);
 /* replaces map_tensors src/common/util.cpp:180-205 (_unique2 sorted + inverse).
  * ids[n] int64 (>= 0) -> uniq[<=n] ascending, inverse[n] (index into uniq per input position),
  * perm[n] (input position of the k-th smallest id; stable), seg_offsets[<=n+1] (run starts in sorted order),
- * *num_unique_dev (device int64).  key_bits = number of significant id bits (<= 63). */
+ * *num_unique_dev (device int64).  uniq[U..n) is zero-filled.  key_bits = number of significant id bits (<= 63). */
 int marius_sort_unique(const int64_t* ids, int64_t n, int32_t key_bits, int64_t* uniq, int64_t* inverse, int32_t* perm,
                        int32_t* seg_offsets, int64_t* num_unique_dev, void* workspace, size_t workspace_bytes,
                        marius_stream_t stream);

@@ -33,6 +33,23 @@ inline hipStream_t as_stream(marius_stream_t s) { return reinterpret_cast<hipStr
 
 constexpr int WAVE = 64;
 
+// optional HIP-event profiler (see error.hip): PROF_SCOPE(id, stream) { launch; }
+enum ProfId { PROF_LP_SCORES = 0, PROF_LP_GRAD_ADJ, PROF_LP_GRAD_NEG, PROF_LP_PREP, PROF_LP_LSE, PROF_LP_EDGE_BWD, PROF_GATHER,
+              PROF_SEG_ADAGRAD, PROF_SORT_UNIQUE, PROF_MT_FILL, PROF_COUNT };
+struct ProfMark {
+    int id;
+    hipEvent_t a, b;
+};
+bool prof_enabled();
+void prof_begin(int id, hipStream_t st, ProfMark& m);
+void prof_end(hipStream_t st, ProfMark& m);
+struct ProfScope {
+    ProfMark m;
+    hipStream_t st;
+    ProfScope(int id, hipStream_t s) : st(s) { prof_begin(id, s, m); }
+    ~ProfScope() { prof_end(st, m); }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

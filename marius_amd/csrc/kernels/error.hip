@@ -1,4 +1,7 @@
-// Error string + ABI version for libmarius_hip.so.
+// Error string, ABI version and the optional per-kernel HIP-event profiler of libmarius_hip.so.
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace marius {
@@ -9,7 +12,81 @@ void set_last_error(const char* fmt, ...) {
     vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
     va_end(ap);
 }
+
+// ---- HIP-event profiler: events are recorded on the launch stream around selected kernels (bench.py roofline) ----
+static const char* kProfNames[PROF_COUNT] = {"lp_scores", "lp_grad_adj", "lp_grad_neg", "lp_prep", "lp_lse", "lp_edge_bwd",
+                                             "gather_rows", "segment_adagrad_scatter", "sort_unique", "mt19937_fill"};
+static int g_prof_on = 0;
+static std::mutex g_prof_mu;
+struct ProfRec {
+    int id;
+    hipEvent_t a, b;
+};
+static std::vector<ProfRec> g_prof_pending;
+static double g_prof_ms[PROF_COUNT];
+static long g_prof_cnt[PROF_COUNT];
+
+bool prof_enabled() { return g_prof_on != 0; }
+
+void prof_begin(int id, hipStream_t st, ProfMark& m) {
+    m.id = -1;
+    if (!g_prof_on) return;
+    if (hipEventCreate(&m.a) != hipSuccess || hipEventCreate(&m.b) != hipSuccess) return;
+    m.id = id;
+    hipEventRecord(m.a, st);
+}
+void prof_end(hipStream_t st, ProfMark& m) {
+    if (m.id < 0) return;
+    hipEventRecord(m.b, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_pending.push_back({m.id, m.a, m.b});
+}
 }  // namespace marius
+
+using namespace marius;
 
 extern "C" int marius_hip_abi_version(void) { return 1; }
 extern "C" const char* marius_hip_last_error(void) { return marius::g_last_error; }
+
+extern "C" int marius_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on;
+    return MARIUS_OK;
+}
+
+extern "C" int marius_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof_pending) {
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    g_prof_pending.clear();
+    for (int i = 0; i < PROF_COUNT; ++i) {
+        g_prof_ms[i] = 0;
+        g_prof_cnt[i] = 0;
+    }
+    return MARIUS_OK;
+}
+
+extern "C" int marius_profile_kernel_count(void) { return PROF_COUNT; }
+extern "C" const char* marius_profile_kernel_name(int id) { return (id >= 0 && id < PROF_COUNT) ? kProfNames[id] : ""; }
+
+// Waits for the recorded events, folds them into the per-kernel totals and returns total ms / launches of kernel `id`.
+extern "C" int marius_profile_read(int id, double* total_ms, int64_t* launches) {
+    MARIUS_REQUIRE(id >= 0 && id < PROF_COUNT && total_ms && launches, "profile_read: bad arguments");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof_pending) {
+        hipEventSynchronize(r.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            g_prof_ms[r.id] += ms;
+            g_prof_cnt[r.id] += 1;
+        }
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    g_prof_pending.clear();
+    *total_ms = g_prof_ms[id];
+    *launches = g_prof_cnt[id];
+    return MARIUS_OK;
+}

@@ -753,7 +753,10 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     pa.pos = (float*)(ws + L->pos[0]);
     pa.x2 = x2;
     pa.D = D;
-    lp_prep_kernel<<<dim3((unsigned)cdiv(D.Bp * D.ndir, 4)), dim3(256), 0, st>>>(pa);
+    {
+        ProfScope ps(PROF_LP_PREP, st);
+        lp_prep_kernel<<<dim3((unsigned)cdiv(D.Bp * D.ndir, 4)), dim3(256), 0, st>>>(pa);
+    }
     rc = check_launch("lp_prep");
     if (rc) return rc;
     if (l2) {
@@ -781,10 +784,13 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     sa.D = D;
     dim3 grid((unsigned)cdiv(D.N, F_TN), (unsigned)cdiv(D.Bc, F_TM), (unsigned)(D.C * D.ndir));
     size_t lds = (size_t)(F_TM + F_TN) * sa.KS * sizeof(float);
-    if (l2)
-        lp_scores_kernel<true><<<grid, dim3(256), lds, st>>>(sa);
-    else
-        lp_scores_kernel<false><<<grid, dim3(256), lds, st>>>(sa);
+    {
+        ProfScope ps(PROF_LP_SCORES, st);
+        if (l2)
+            lp_scores_kernel<true><<<grid, dim3(256), lds, st>>>(sa);
+        else
+            lp_scores_kernel<false><<<grid, dim3(256), lds, st>>>(sa);
+    }
     rc = check_launch("lp_scores");
     if (rc) return rc;
 
@@ -811,9 +817,12 @@ extern "C" int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout
     hipStream_t st = as_stream(stream);
     char* ws = (char*)workspace;
     const int64_t rows = D.Bp * D.ndir;
-    lp_lse_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>((const float*)(ws + L->neg[0]), D.n_ld,
-                                                                      (const float*)(ws + L->pos[0]), rows, D.N,
-                                                                      (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]));
+    {
+        ProfScope ps(PROF_LP_LSE, st);
+        lp_lse_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>((const float*)(ws + L->neg[0]), D.n_ld,
+                                                                          (const float*)(ws + L->pos[0]), rows, D.N,
+                                                                          (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]));
+    }
     rc = check_launch("lp_lse");
     if (rc) return rc;
     lp_loss_reduce_kernel<<<dim3(1), dim3(1024), 0, st>>>((const float*)(ws + L->rowloss[0]), D.Bp, D.ndir, D.gscale,
@@ -850,12 +859,19 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     const unsigned nblk = (unsigned)cdiv(D.d, ga.ncols);
     dim3 ga_grid(nblk, (unsigned)cdiv(D.Bc, G_TM), (unsigned)(D.C * D.ndir));
     dim3 gn_grid(nblk, (unsigned)cdiv(D.N, G_TM), (unsigned)(D.C * D.ndir));
-    if (l2) {
-        lp_grad_adj_kernel<true><<<ga_grid, dim3(256), 0, st>>>(ga);
-        lp_grad_neg_kernel<true><<<gn_grid, dim3(256), 0, st>>>(ga);
-    } else {
-        lp_grad_adj_kernel<false><<<ga_grid, dim3(256), 0, st>>>(ga);
-        lp_grad_neg_kernel<false><<<gn_grid, dim3(256), 0, st>>>(ga);
+    {
+        ProfScope ps(PROF_LP_GRAD_ADJ, st);
+        if (l2)
+            lp_grad_adj_kernel<true><<<ga_grid, dim3(256), 0, st>>>(ga);
+        else
+            lp_grad_adj_kernel<false><<<ga_grid, dim3(256), 0, st>>>(ga);
+    }
+    {
+        ProfScope ps(PROF_LP_GRAD_NEG, st);
+        if (l2)
+            lp_grad_neg_kernel<true><<<gn_grid, dim3(256), 0, st>>>(ga);
+        else
+            lp_grad_neg_kernel<false><<<gn_grid, dim3(256), 0, st>>>(ga);
     }
     rc = check_launch("lp_grad");
     if (rc) return rc;
@@ -883,7 +899,10 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     ea.grel[0] = (float*)(ws + L->grel[0]);
     ea.grel[1] = D.ndir == 2 ? (float*)(ws + L->grel[1]) : nullptr;
     ea.D = D;
-    lp_edge_bwd_kernel<<<dim3((unsigned)cdiv(D.B, 4)), dim3(256), 0, st>>>(ea);
+    {
+        ProfScope ps(PROF_LP_EDGE_BWD, st);
+        lp_edge_bwd_kernel<<<dim3((unsigned)cdiv(D.B, 4)), dim3(256), 0, st>>>(ea);
+    }
     return check_launch("lp_edge_bwd");
 }
 

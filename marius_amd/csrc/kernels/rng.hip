@@ -113,6 +113,46 @@ __global__ __launch_bounds__(256) void select_edges_kernel(const T* __restrict__
     }
 }
 
+// all_ids = cat(src, dst, src_neg.flat, dst_neg.flat)   (DataLoader::edgeSample, dataloader.cpp:400-409)
+__global__ __launch_bounds__(256) void assemble_ids_kernel(const int64_t* __restrict__ edges, int64_t B, int cols,
+                                                           const int64_t* __restrict__ src_neg, const int64_t* __restrict__ dst_neg,
+                                                           int64_t CN, int64_t* __restrict__ out) {
+    const int64_t nsrc = src_neg ? CN : 0;
+    const int64_t total = 2 * B + nsrc + (dst_neg ? CN : 0);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t v;
+        if (t < B) v = edges[t * cols];
+        else if (t < 2 * B) v = edges[(t - B) * cols + cols - 1];
+        else if (t < 2 * B + nsrc) v = src_neg[t - 2 * B];
+        else v = dst_neg[t - 2 * B - nsrc];
+        out[t] = v;
+    }
+}
+
+// edges_ = stack({src_mapping, rel, dst_mapping})   (dataloader.cpp:460-466)
+__global__ __launch_bounds__(256) void remap_edges_kernel(const int64_t* __restrict__ edges, const int64_t* __restrict__ inverse,
+                                                          int64_t B, int cols, int64_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        out[i * cols] = inverse[i];
+        if (cols == 3) out[i * cols + 1] = edges[i * cols + 1];
+        out[i * cols + cols - 1] = inverse[B + i];
+    }
+}
+
+// deg_negative_local_filter (negative.cpp:21-39), uncompacted: row (c*n_deg + k) = (e, k) when the sampled edge position
+// e = deg_pos[c][k] lies in chunk c, else (-1, -1) (ignored by the score filter; compaction keeps the reference's order).
+__global__ __launch_bounds__(256) void deg_filter_kernel(const int64_t* __restrict__ deg_pos, int C, int n_deg, int64_t chunk_size,
+                                                         int64_t* __restrict__ out) {
+    const int64_t total = (int64_t)C * n_deg;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = t / n_deg, k = t - c * n_deg;
+        const int64_t e = deg_pos[t];
+        const bool hit = (e / chunk_size) == c;
+        out[2 * t] = hit ? e : -1;
+        out[2 * t + 1] = hit ? k : -1;
+    }
+}
+
 // ---- host-side generator (same stream; used for the per-epoch randperm, which is a serial swap chain) ----
 static void host_twist(uint32_t* p) {
     for (int i = 0; i < MT_N; i++) {
@@ -164,6 +204,7 @@ extern "C" int marius_mt19937_randperm_host(uint32_t* st, int64_t* out, int64_t 
 extern "C" int marius_mt19937_fill(uint32_t* state_dev, uint32_t* out_dev, int64_t n, marius_stream_t stream) {
     MARIUS_REQUIRE(state_dev && n >= 0 && (n == 0 || out_dev), "mt19937_fill: bad arguments");
     if (n == 0) return MARIUS_OK;
+    ProfScope ps(PROF_MT_FILL, as_stream(stream));
     mt19937_fill_kernel<<<dim3(1), dim3(256), 0, as_stream(stream)>>>(state_dev, out_dev, n);
     return check_launch("mt19937_fill");
 }
@@ -206,4 +247,34 @@ extern "C" int marius_select_edges(const void* edges_in, int32_t in_is_int64, in
         select_edges_kernel<int32_t><<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(
             (const int32_t*)edges_in, cols, perm, start, B, out);
     return check_launch("select_edges");
+}
+
+extern "C" int marius_assemble_ids(const int64_t* edges, int64_t B, int32_t cols, const int64_t* src_neg, const int64_t* dst_neg,
+                                   int64_t CN, int64_t* out, marius_stream_t stream) {
+    MARIUS_REQUIRE(edges && out && B > 0 && (cols == 2 || cols == 3) && CN >= 0, "assemble_ids: bad arguments");
+    int64_t total = 2 * B + (src_neg ? CN : 0) + (dst_neg ? CN : 0);
+    int64_t blocks = cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    assemble_ids_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(edges, B, cols, src_neg, dst_neg, CN, out);
+    return check_launch("assemble_ids");
+}
+
+extern "C" int marius_remap_edges(const int64_t* edges, const int64_t* inverse, int64_t B, int32_t cols, int64_t* out,
+                                  marius_stream_t stream) {
+    MARIUS_REQUIRE(edges && inverse && out && B > 0 && (cols == 2 || cols == 3), "remap_edges: bad arguments");
+    int64_t blocks = cdiv(B, 256);
+    if (blocks > 4096) blocks = 4096;
+    remap_edges_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(edges, inverse, B, cols, out);
+    return check_launch("remap_edges");
+}
+
+extern "C" int marius_deg_filter(const int64_t* deg_pos, int32_t C, int32_t n_deg, int64_t B, int64_t* out, marius_stream_t stream) {
+    MARIUS_REQUIRE(C > 0 && n_deg >= 0 && B > 0, "deg_filter: bad arguments");
+    if (n_deg == 0) return MARIUS_OK;
+    MARIUS_REQUIRE(deg_pos && out, "deg_filter: null pointer");
+    const int64_t chunk_size = (B + C - 1) / C;  // ceil((double)B / C), negative.cpp:28
+    int64_t blocks = cdiv((int64_t)C * n_deg, 256);
+    if (blocks > 1024) blocks = 1024;
+    deg_filter_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(deg_pos, C, n_deg, chunk_size, out);
+    return check_launch("deg_filter");
 }

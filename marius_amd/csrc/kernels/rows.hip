@@ -148,6 +148,7 @@ static int launch_gather(const float* ta, const float* tb, int64_t table_ld, con
     int rpb;
     row_geometry(vpr, block, rpb);
     dim3 grid((unsigned)cdiv(n, rpb));
+    ProfScope ps(PROF_GATHER, st);
     if (vec == 4)
         gather_rows_kernel<4, NT><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld);
     else if (vec == 2)

@@ -276,5 +276,6 @@ extern "C" int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld
     vec = vec < v2 ? vec : v2;
     vec = vec < v3 ? vec : v3;
     ApplyAdagrad ap{uniq_ids, table, state, table_ld, lr, eps};
+    ProfScope ps(PROF_SEG_ADAGRAD, as_stream(stream));
     return launch_seg(a, ap, vec, as_stream(stream));
 }

@@ -95,6 +95,12 @@ extern "C" int marius_sort_unique(const int64_t* ids, int64_t n, int32_t key_bit
         return MARIUS_ERR_HIP;
     }
     MARIUS_REQUIRE(workspace_bytes >= p.total, "sort_unique: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+    ProfScope ps(PROF_SORT_UNIQUE, st);
+    // uniq[U..n) reads as id 0 so that capacity-sized gathers downstream stay in bounds without a host sync on U
+    if (hipMemsetAsync(uniq, 0, (size_t)n * sizeof(int64_t), st) != hipSuccess) {
+        set_last_error("sort_unique: memset failed");
+        return MARIUS_ERR_HIP;
+    }
     char* ws = (char*)workspace;
     uint64_t* keys = (uint64_t*)(ws + p.keys_off);
     int32_t* flags = (int32_t*)(ws + p.scan_off);

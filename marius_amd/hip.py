@@ -59,7 +59,15 @@ SIGNATURES = {
     "marius_mt19937_fill": (C.c_int, [_vp, _vp, _i64, _vp]),
     "marius_negatives_raw_words": (_i64, [_i64, _i64, _i32, _i32, _i32]),
     "marius_sample_negatives": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "marius_deg_filter": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp]),
     "marius_select_edges": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _i64, _vp, _vp]),
+    "marius_assemble_ids": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "marius_remap_edges": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "marius_profile_enable": (C.c_int, [C.c_int]),
+    "marius_profile_reset": (C.c_int, []),
+    "marius_profile_kernel_count": (C.c_int, []),
+    "marius_profile_kernel_name": (C.c_char_p, [C.c_int]),
+    "marius_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "marius_sort_unique_workspace_bytes": (_sz, [_i64]),
     "marius_sort_unique": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "marius_lp_plan": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout)]),
@@ -210,6 +218,14 @@ def sample_negatives(raw, edges, num_nodes, num_chunks, num_negatives, degree_fr
     return out, deg
 
 
+def deg_filter(deg_pos, B):
+    """Uncompacted DEG local filter [C*n_deg, 2]; rows of -1 are non-hits."""
+    C_, n_deg = deg_pos.shape
+    out = torch.empty((C_ * n_deg, 2), dtype=torch.int64, device=deg_pos.device)
+    check(lib().marius_deg_filter(ptr(deg_pos), C_, n_deg, B, ptr(out), stream_ptr()), "deg_filter")
+    return out
+
+
 def select_edges(edges_all, perm, start, B):
     _dev(edges_all)
     out = torch.empty((B, edges_all.size(1)), dtype=torch.int64, device=edges_all.device)
@@ -345,3 +361,21 @@ def segment_adagrad_scatter(rows, um, n, d, table, state, lr, eps=1e-10, carry=N
     check(lib().marius_segment_adagrad_scatter(ptr(rows), rows.stride(0), ptr(um.perm), ptr(um.inverse), ptr(um.seg), n, d, ptr(um.uniq),
                                                ptr(table), ptr(state), table.stride(0), lr, eps, ptr(carry), stream_ptr()),
           "segment_adagrad_scatter")
+
+
+def profile_enable(on=True):
+    lib().marius_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    lib().marius_profile_reset()
+
+
+def profile_read():
+    """{kernel name: (total_ms, launches)} measured with HIP events on the launch stream."""
+    out = {}
+    for i in range(lib().marius_profile_kernel_count()):
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        check(lib().marius_profile_read(i, C.byref(ms), C.byref(cnt)), "profile_read")
+        out[lib().marius_profile_kernel_name(i).decode()] = (ms.value, cnt.value)
+    return out

@@ -329,3 +329,44 @@ def test_segment_adagrad_scatter_matches_reference_update(H, dev):
     O.index_add(state, uniq, ds)
     assert_close(t_d, table, "table after update", rtol=1e-5)
     assert_close(s_d, state, "state after update", rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ whole steps vs the CPU path
+@pytest.mark.parametrize("decoder,f", [("COMPLEX", 0.0), ("DISTMULT", 0.5), ("TRANSE", 0.0)])
+def test_train_steps_match_cpu_reference_path(H, dev, decoder, f):
+    """3 synchronous steps: sampled ids bit-exact (same generator stream), unique map bit-exact, loss/tables within tolerance."""
+    from marius_amd.lp_step import DeviceLinkPredictionStep
+    from oracle.cpu_step import CpuLinkPredictionStep
+
+    num_nodes, R, d, B, C, N, E, seed = 5000, 13, 20, 200, 4, 50, 2000, 99
+    g = torch.Generator().manual_seed(1)
+    table = (torch.rand(num_nodes, d, generator=g) - 0.5) * 0.6
+    state = torch.zeros(num_nodes, d)
+    edges_all = torch.stack([torch.randint(num_nodes, (E,), generator=g), torch.randint(R, (E,), generator=g),
+                             torch.randint(num_nodes, (E,), generator=g)], 1)
+    cpu = CpuLinkPredictionStep(decoder, table.clone(), state.clone(), R, B, C, N, degree_fraction=f)
+    t_d, s_d = table.to(dev), state.to(dev)
+    hipstep = DeviceLinkPredictionStep(decoder, num_nodes, R, d, B, C, N, degree_fraction=f, seed=seed, device=dev, node_table=t_d, node_state=s_d)
+    torch.manual_seed(seed)
+    perm_ref = torch.randperm(E)                       # setActiveEdges draws first (dataloader.cpp:180)
+    perm = hipstep.gen.randperm_host(E)
+    assert torch.equal(perm, perm_ref)
+    e32 = edges_all.to(torch.int32).to(dev)
+    for s in range(3):
+        batch = edges_all[perm_ref[s * B:(s + 1) * B]]
+        want = cpu.step(batch)
+        edges = H.select_edges(e32, perm.to(dev), s * B, B)
+        assert torch.equal(edges.cpu(), batch)
+        W = hipstep.step(edges)
+        assert torch.equal(hipstep.last["src_neg"].cpu(), want["src_neg"])   # bit-exact sampled node indices
+        assert torch.equal(hipstep.last["dst_neg"].cpu(), want["dst_neg"])
+        U = int(hipstep.um.count.item())
+        assert torch.equal(hipstep.um.uniq[:U].cpu(), want["uniq"])
+        assert_close(W.pos(0), want["pos"], "pos step %d" % s)
+        assert_close(W.neg(0), want["neg"], "neg step %d" % s)
+        assert_close(W.neg(1), want["inv_neg"], "inv_neg step %d" % s)
+        assert_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss step %d" % s)
+    assert_close(t_d, cpu.table, "node table after 3 steps", rtol=2e-4)
+    assert_close(s_d, cpu.state, "adagrad state after 3 steps", rtol=2e-4)
+    assert_close(hipstep.rel, cpu.rel, "relations after 3 steps", rtol=2e-4)
+    assert_close(hipstep.inv_rel, cpu.inv_rel, "inverse relations after 3 steps", rtol=2e-4)
