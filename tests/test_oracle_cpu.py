@@ -1,0 +1,244 @@
+"""CPU tests: pin the oracle against (1) the reference's own known answers, (2) golden vectors produced by the REFERENCE's
+comparators/relation operators (oracle/_ref), (3) the torch RNG stream; plus host-side product logic that needs no GPU."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lp_oracle as O
+from oracle.mt_oracle import OracleGenerator
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(HERE, "golden")
+
+
+@pytest.fixture(scope="module")
+def known():
+    with open(os.path.join(GOLD, "ref_known_answers.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def refgold():
+    return np.load(os.path.join(GOLD, "ref_scores_golden.npz"))
+
+
+# ------------------------------------------------------------------------------------------------ reference known answers
+def test_distmult_known_scores(known):
+    k = known["distmult_forward"]
+    emb, edges = torch.tensor(k["node_embeddings"]), torch.tensor(k["batch_edges"])
+    rel = O.init_relations("DISTMULT", k["num_relations"], k["embedding_dim"])
+    pos, inv = O.only_pos_forward("DISTMULT", edges, emb, rel, None)
+    assert torch.equal(pos, torch.tensor(k["expected_scores"]))  # test_nn.py:158 uses torch.eq
+    assert inv is None
+
+
+def test_accumulate_gradients_known(known):
+    k = known["accumulate_gradients"]
+    grad, state = torch.tensor(k["grad"]), torch.tensor(k["state"])
+    dw, ds = O.accumulate_gradients(grad, state, k["learning_rate"])
+    assert torch.equal(ds, torch.tensor(k["expected_state_update"]))
+    assert torch.equal(ds, grad.pow(2))
+    assert torch.equal(dw, -1.0 * (grad / (ds.sqrt().add_(1e-10))))  # test_data.py:46-47
+
+
+def test_train_batch_known_shapes(known):
+    k = known["distmult_forward"]
+    emb, edges = torch.tensor(k["node_embeddings"]), torch.tensor(k["batch_edges"])
+    dst_neg = torch.tensor(known["train_batch_shapes"]["dst_neg_indices_mapping"])
+    rel = O.init_relations("DISTMULT", 2, 2)
+    out = O.train_batch("DISTMULT", emb, torch.zeros_like(emb), edges, dst_neg, None, rel, None)
+    assert out["neg"].shape == (3, 2) and out["node_grad"].shape == emb.shape and out["inv_neg"] is None
+
+
+# ------------------------------------------------------------------------------------------------ golden vectors from the reference code
+OPS = {"hadamard": "hadamard", "complex_hadamard": "complex_hadamard", "translation": "translation"}
+
+
+@pytest.mark.parametrize("name", sorted(OPS))
+def test_relation_operators_match_reference(refgold, name):
+    e, r = torch.from_numpy(refgold["op_in_e"]), torch.from_numpy(refgold["op_in_r"])
+    assert torch.equal(O.REL_OPS[name](e, r), torch.from_numpy(refgold["op_" + name]))
+
+
+@pytest.mark.parametrize("name", ["dot", "l2", "cosine"])
+def test_comparators_match_reference(refgold, name):
+    e, o = torch.from_numpy(refgold["op_in_e"]), torch.from_numpy(refgold["cmp_in_o"])
+    assert torch.equal(O.COMPARATORS[name](e, o), torch.from_numpy(refgold["cmp_same_" + name]))
+    for B in (12, 10):  # 10: B % C != 0 -> zero padded last chunk
+        src, negs = torch.from_numpy(refgold["neg_in_src_%d" % B]), torch.from_numpy(refgold["neg_in_negs_%d" % B])
+        got = O.COMPARATORS[name](src, negs)
+        want = torch.from_numpy(refgold["cmp_neg_%s_%d" % (name, B)])
+        assert got.shape == want.shape
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dec", ["DISTMULT", "COMPLEX", "TRANSE"])
+def test_score_forward_backward_matches_reference(refgold, dec):
+    g = lambda k: torch.from_numpy(refgold["fb_%s_%s" % (dec, k)])
+    src, rel, dst, negs = [g(k).clone().requires_grad_(True) for k in ("src", "rel", "dst", "negs")]
+    op, cmp = O.REL_OPS[O.DECODERS[dec][0]], O.COMPARATORS[O.DECODERS[dec][1]]
+    adj = op(src, rel)
+    pos, neg = cmp(adj, dst), cmp(adj, negs)
+    loss = O.softmax_cross_entropy(pos, neg, "sum")
+    loss.backward()
+    tol = dict(rtol=1e-5, atol=1e-6)
+    assert torch.allclose(pos, g("pos"), **tol) and torch.allclose(neg, g("neg"), **tol)
+    assert torch.allclose(loss.reshape(1), g("loss"), **tol)
+    for t, k in ((src, "g_src"), (rel, "g_rel"), (dst, "g_dst"), (negs, "g_negs")):
+        assert torch.allclose(t.grad, g(k), **tol), k
+
+
+def test_oracle_vs_live_reference_build():
+    """When oracle/_ref/libmarius_ref.so is present (built from /root/reference), compare on fresh random inputs."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libmarius_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not built")
+    L = C.CDLL(so)
+    fp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rs = np.random.RandomState(5)
+    B, Cc, N, d = 21, 4, 9, 14
+    src, negs = rs.randn(B, d).astype(np.float32), rs.randn(Cc, N, d).astype(np.float32)
+    Bp = Cc * math.ceil(B / Cc)
+    for cmp, name in [(0, "dot"), (1, "l2")]:
+        res = np.zeros((Bp, N), np.float32)
+        assert L.ref_compare_neg(cmp, fp(src), fp(negs), C.c_int64(B), C.c_int64(Cc), C.c_int64(N), C.c_int64(d), fp(res)) == 0
+        got = O.COMPARATORS[name](torch.from_numpy(src), torch.from_numpy(negs))
+        assert torch.allclose(got, torch.from_numpy(res), rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ decoder quirks the reference has
+def test_pad_and_reshape_zero_rows_enter_loss():
+    """comparators.cpp:7-20 + decoder_methods.cpp:103-111: B % C != 0 pads rows with zeros; they add log(1+N) each."""
+    emb = torch.randn(30, 6)
+    edges = torch.stack([torch.randint(30, (10,)), torch.zeros(10, dtype=torch.int64), torch.randint(30, (10,))], 1)
+    dst_neg = torch.randint(30, (4, 5))
+    rel = O.init_relations("DISTMULT", 1, 6)
+    pos, neg, _, _ = O.node_corrupt_forward("DISTMULT", edges, emb, dst_neg, None, rel, None)
+    assert pos.shape == (12,) and neg.shape == (12, 5)
+    assert torch.equal(pos[10:], torch.zeros(2)) and torch.equal(neg[10:], torch.zeros(2, 5))
+    full = O.softmax_cross_entropy(pos, neg)
+    part = O.softmax_cross_entropy(pos[:10], neg[:10])
+    assert torch.allclose(full - part, torch.tensor(2 * math.log(6.0)), atol=1e-5)
+
+
+def test_transe_scores_are_positive_distances():
+    emb = torch.randn(20, 8)
+    edges = torch.stack([torch.randint(20, (6,)), torch.zeros(6, dtype=torch.int64), torch.randint(20, (6,))], 1)
+    pos, neg, _, _ = O.node_corrupt_forward("TRANSE", edges, emb, torch.randint(20, (2, 4)), None, O.init_relations("TRANSE", 1, 8), None)
+    assert (pos >= 0).all() and (neg > 0).all()
+
+
+def test_edge_column_validation():
+    with pytest.raises(RuntimeError, match="3 or 2 column"):
+        O.only_pos_forward("DISTMULT", torch.zeros(3, 4, dtype=torch.int64), torch.randn(4, 2), None, None)
+
+
+def test_deg_filter_entries_are_own_chunk():
+    """test/cpp/unit/data/samplers/test_negative.cpp property: every DEG filter entry points at a positive of its own chunk."""
+    B, Cc, n_deg = 12, 3, 5
+    g = torch.Generator().manual_seed(0)
+    deg = torch.randint(B, (Cc, n_deg), generator=g)
+    edges = torch.zeros(B, 3, dtype=torch.int64)
+    f = O.deg_negative_local_filter(deg, edges)
+    chunk = math.ceil(B / Cc)
+    for e, k in f.tolist():
+        c = e // chunk
+        assert deg[c, k] == e
+    assert f.size(0) == int((deg // chunk == torch.arange(Cc).view(-1, 1)).sum())
+
+
+# ------------------------------------------------------------------------------------------------ RNG stream
+@pytest.fixture(scope="module")
+def rnggold():
+    with open(os.path.join(GOLD, "rng_golden.json")) as f:
+        return json.load(f)
+
+
+def test_c_oracle_rng_matches_golden_and_torch(rnggold):
+    for case in rnggold["cases"]:
+        if case["kind"] == "randint":
+            got = OracleGenerator(case["seed"]).randint(case["high"], case["n"])
+            assert got.tolist() == case["values"]
+            torch.manual_seed(case["seed"])
+            assert torch.randint(case["high"], (case["n"],)).tolist() == case["values"]  # this torch == golden torch
+        elif case["kind"] == "randperm":
+            og = OracleGenerator(case["seed"])
+            assert og.randperm(case["n"]).tolist() == case["values"]
+            assert og.randint(1000, 5).tolist() == case["next_randint_1000"]
+        else:
+            og = OracleGenerator(case["seed"])
+            edges = np.array(case["edges"], dtype=np.int64)
+            for call in case["calls"]:
+                ids, deg = og.get_negatives(edges, case["num_nodes"], case["C"], case["N"], case["degree_fraction"], call["inverse"])
+                assert ids.tolist() == call["ids"]
+                if call["deg_pos"]:
+                    assert deg.tolist() == call["deg_pos"]
+
+
+# ------------------------------------------------------------------------------------------------ product: C-ABI library + host logic (no GPU)
+def _declared_symbols():
+    import re
+
+    txt = open(os.path.join(ROOT, "include", "marius_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(marius_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from marius_amd import hip
+
+    L = hip.lib()  # loads libmarius_hip.so and binds argtypes for every entry of SIGNATURES
+    decl = _declared_symbols()
+    assert len(decl) >= 25
+    for name in decl:
+        assert hasattr(L, name), "libmarius_hip.so does not export %s" % name
+    assert sorted(hip.SIGNATURES) == decl, set(hip.SIGNATURES) ^ set(decl)
+    assert L.marius_hip_abi_version() == 1
+
+
+def test_host_generator_matches_golden(rnggold):
+    """Host half of the product sampler (seed / raw words / randperm are plain C, no device needed)."""
+    from marius_amd import hip
+
+    for case in rnggold["cases"]:
+        if case["kind"] == "randperm":
+            g = hip.Generator(case["seed"])
+            assert g.randperm_host(case["n"]).tolist() == case["values"]
+            raw = g.fill_host(5).numpy().view(np.uint32)
+            assert (raw % 1000).tolist() == case["next_randint_1000"]
+        elif case["kind"] == "randint" and case["high"] < 2 ** 28:
+            raw = hip.Generator(case["seed"]).fill_host(case["n"]).numpy().view(np.uint32).astype(np.uint64)
+            assert (raw % case["high"]).tolist() == case["values"]
+    assert hip.negatives_raw_words(86054151, 50000, 50, 1000, 0) == 50000
+    assert hip.negatives_raw_words(2 ** 28, 50000, 2, 10, 4) == 2 * (6 * 2 + 4)
+
+
+def test_product_path_has_no_cpu_fallback():
+    from marius_amd import hip
+
+    with pytest.raises(hip.MariusHipError):
+        hip.gather_rows(torch.zeros(4, 4), torch.zeros(2, dtype=torch.int64))
+
+
+def test_lp_plan_validation_and_layout():
+    from marius_amd import hip
+
+    d = hip.LpDesc()
+    d.relop, d.cmp, d.d, d.edge_cols, d.B, d.C, d.N, d.use_inverse, d.reduction = 1, 0, 100, 3, 1000, 10, 500, 1, 0
+    d.src_neg, d.inv_rel = C.c_void_p(1), C.c_void_p(1)
+    lay = hip.LpLayout()
+    assert hip.lib().marius_lp_plan(C.byref(d), C.byref(lay)) == 0
+    assert lay.Bp == 1000 and lay.n_ld == 500 and lay.d_ld == 100 and lay.total_bytes > 2 * 1000 * 500 * 4
+    d.B = 1005  # ceil(1005/10) = 101 -> Bp = 1010 (pad_and_reshape)
+    assert hip.lib().marius_lp_plan(C.byref(d), C.byref(lay)) == 0 and lay.Bp == 1010
+    d.edge_cols = 4
+    assert hip.lib().marius_lp_plan(C.byref(d), C.byref(lay)) == hip.lib().marius_hip_abi_version() * 1  # MARIUS_ERR_INVALID
+    assert b"3 or 2 column" in hip.lib().marius_hip_last_error()
+    d.edge_cols, d.d = 3, 7  # ComplEx needs even d
+    assert hip.lib().marius_lp_plan(C.byref(d), C.byref(lay)) != 0
