@@ -81,7 +81,12 @@ def main():
         cfg["num_nodes"] = a.num_nodes
     num_nodes, R, d, B, C, N = cfg["num_nodes"], cfg["num_relations"], cfg["d"], cfg["B"], cfg["C"], cfg["N"]
 
-    if world > 1:
+    if world > 1 or os.environ.get("MARIUS_FORCE_SHARDED") == "1":
+        if world == 1:  # exercise the N>1 code path on a single GPU (tests / profiling)
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         from marius_amd.sharded import run_sharded_bench
         return run_sharded_bench(a, cfg, rank, world, dev)
 

@@ -125,6 +125,12 @@ int marius_sort_unique(const int64_t* ids, int64_t n, int32_t key_bits, int64_t*
                        int32_t* seg_offsets, int64_t* num_unique_dev, void* workspace, size_t workspace_bytes,
                        marius_stream_t stream);
 
+/* Sharded node table (partition axis of src/storage/storage.cpp:75 / buffer.cpp:340-356: shard q owns ids
+ * [q * shard_rows, (q+1) * shard_rows)):  out[q] = first position in the ascending list uniq[0..*num_unique_dev) with
+ * id >= q * shard_rows, q = 0..num_shards (out[num_shards] = U).  These are the all-to-all split points. */
+int marius_owner_offsets(const int64_t* uniq, const int64_t* num_unique_dev, int64_t shard_rows, int32_t num_shards, int64_t* out,
+                         marius_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------ decoder */
 
 /* Descriptor of one CORRUPT_NODE link-prediction batch in batch-local ids (after map_tensors):

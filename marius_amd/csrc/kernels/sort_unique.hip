@@ -44,6 +44,21 @@ __global__ void zero_count_kernel(int64_t* num_unique, int32_t* seg_offsets) {
     seg_offsets[0] = 0;
 }
 
+// first position in uniq[0..U) whose id >= q * shard_rows, for q = 0..P  (owner bucket boundaries of a sorted id list)
+__global__ void owner_offsets_kernel(const int64_t* __restrict__ uniq, const int64_t* __restrict__ num_unique, int64_t shard_rows,
+                                     int P, int64_t* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > P) return;
+    const int64_t U = *num_unique;
+    const int64_t key = (int64_t)q * shard_rows;
+    int64_t lo = 0, hi = U;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (uniq[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    out[q] = (q == P) ? U : lo;
+}
+
 struct SortPlan {
     size_t keys_off, scan_off, temp_off, temp_bytes, total;
 };
@@ -125,4 +140,12 @@ extern "C" int marius_sort_unique(const int64_t* ids, int64_t n, int32_t key_bit
     emit_unique_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const int64_t*)keys, scan, perm, n, uniq, inverse,
                                                                     seg_offsets, num_unique_dev);
     return check_launch("sort_unique");
+}
+
+extern "C" int marius_owner_offsets(const int64_t* uniq, const int64_t* num_unique_dev, int64_t shard_rows, int32_t num_shards,
+                                    int64_t* out, marius_stream_t stream) {
+    MARIUS_REQUIRE(uniq && num_unique_dev && out && shard_rows > 0 && num_shards > 0, "owner_offsets: bad arguments");
+    owner_offsets_kernel<<<dim3((unsigned)cdiv(num_shards + 1, 64)), dim3(64), 0, as_stream(stream)>>>(uniq, num_unique_dev, shard_rows,
+                                                                                                    num_shards, out);
+    return check_launch("owner_offsets");
 }

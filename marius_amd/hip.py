@@ -70,6 +70,7 @@ SIGNATURES = {
     "marius_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "marius_sort_unique_workspace_bytes": (_sz, [_i64]),
     "marius_sort_unique": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "marius_owner_offsets": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "marius_lp_plan": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout)]),
     "marius_lp_forward": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),
     "marius_lp_loss": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),
@@ -255,6 +256,13 @@ class UniqueMap:
         check(lib().marius_sort_unique(ptr(ids), n, key_bits, ptr(self.uniq), ptr(self.inverse), ptr(self.perm), ptr(self.seg),
                                        ptr(self.count), ptr(self.ws), self.ws_bytes, stream_ptr()), "sort_unique")
         return self
+
+
+def owner_offsets(um, shard_rows, num_shards):
+    """Split points of um.uniq[:U] by owning shard; returned on the HOST (one small D2H sync: all-to-all needs host sizes)."""
+    out = torch.empty(num_shards + 1, dtype=torch.int64, device=um.uniq.device)
+    check(lib().marius_owner_offsets(ptr(um.uniq), ptr(um.count), shard_rows, num_shards, ptr(out), stream_ptr()), "owner_offsets")
+    return out.cpu()
 
 
 class LpWorkspace:

@@ -1,0 +1,206 @@
+"""Node-embedding table sharded across the GPUs of one node, one process per GPU, RCCL over xGMI.
+
+Partition axis = Marius's own: shard p of P owns the contiguous id range [p*S, min((p+1)*S, num_nodes)), S = ceil(num_nodes / P)
+(reference src/cpp/src/storage/storage.cpp:75, storage/buffer.cpp:340-356,
+src/python/tools/preprocess/converters/partitioners/torch_partitioner.py:13-16).  The reference never shards a DEVICE_MEMORY table
+(storage.cpp:567-569 keeps it on one device; its multi-GPU mode replicates the dense model and all-reduces relation gradients,
+nn/model.cpp:136-159) — this exchange is new design along that axis.
+
+One synchronous data-parallel step on every rank (each rank trains its own batch):
+  1. getBatch locally: edge slice, negatives (generator seeded random_seed + rank), sort/unique  -> ascending unique ids.
+     Ascending order == grouped by owner, so the all-to-all split points are P+1 lower bounds (marius_owner_offsets).
+  2. all-to-all(v) of the id lists, owners gather the requested rows from their shard, all-to-all(v) of the rows back.
+  3. forward / loss / backward locally; per-unique-row gradient by atomic-free segmented sum.
+  4. all-to-all(v) of the row gradients to the owners; the owner sort/uniques everything it received (a row may be requested
+     by several ranks), sums per row and applies sparse Adagrad once:  exactly the single-GPU update for the union batch.
+  5. relation-table gradients are all-reduced (sum) and every replica takes the same dense Adagrad step (model.cpp:136-159).
+Only the exchange lives here; every local operation goes through a backend (HIP kernels in production, the oracle in the
+CPU gloo tests) so the N>1 plumbing is testable without a GPU while the product path still has no CPU fallback.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(num_nodes, world):
+    return (num_nodes + world - 1) // world
+
+
+def shard_range(num_nodes, rank, world):
+    S = shard_rows(num_nodes, world)
+    lo = min(rank * S, num_nodes)
+    return lo, min(lo + S, num_nodes)
+
+
+def exchange_splits(send_offsets, group=None):
+    """send_offsets: host int64 [P+1] split points of this rank's sorted unique ids. Returns (send_counts, recv_counts) lists."""
+    send = (send_offsets[1:] - send_offsets[:-1]).to(torch.int64)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    s = send.to(dev)
+    r = torch.empty_like(s)
+    dist.all_to_all_single(r, s, group=group)
+    return send.tolist(), r.cpu().tolist()
+
+
+def a2a_rows(buf, send_counts, recv_counts, group=None):
+    """all-to-all(v) along dim 0 of a [n, ...] tensor."""
+    out = buf.new_empty((sum(recv_counts),) + tuple(buf.shape[1:]))
+    dist.all_to_all_single(out, buf.contiguous(), recv_counts, send_counts, group=group)
+    return out
+
+
+def sharded_step(backend, edges, rank, world, num_nodes, group=None):
+    """One synchronous step. `backend` provides the local operations (see HipBackend below)."""
+    S = shard_rows(num_nodes, world)
+    lo, _ = shard_range(num_nodes, rank, world)
+    ctx = backend.get_batch(edges)                              # sample + unique
+    offs = backend.owner_offsets(ctx, S, world)                 # host [P+1] (the one host sync of the step)
+    uniq = backend.unique_ids(ctx)                              # [U] ascending global ids (exact size)
+    send_counts, recv_counts = exchange_splits(offs, group)
+    req_ids = a2a_rows(uniq, send_counts, recv_counts, group)   # ids other ranks (and this one) need from my shard
+    rows = backend.gather_local(req_ids - lo)                   # [sum(recv), d]
+    emb = a2a_rows(rows, recv_counts, send_counts, group)       # my batch's rows, in unique-id order
+    grad, rel_grads, loss = backend.compute(ctx, emb)           # grad [U, d]
+    recv_grad = a2a_rows(grad, send_counts, recv_counts, group)
+    backend.apply_local(req_ids - lo, recv_grad)                # dedupe across senders + Adagrad + scatter on my shard
+    for g in rel_grads:
+        if g is not None:
+            dist.all_reduce(g, group=group)
+    backend.dense_step(rel_grads)
+    return loss
+
+
+class HipBackend:
+    """Local operations on the MI355X through the C-ABI (no CPU fallback)."""
+
+    def __init__(self, stepper, shard_table, shard_state):
+        from . import hip as H
+
+        self.H, self.s = H, stepper
+        self.table, self.state = shard_table, shard_state
+        self.um_recv = None
+        self.carry_recv = None
+
+    def get_batch(self, edges):
+        s, H = self.s, self.H
+        B, CN = s.B, s.C * s.N
+        src_neg, dst_neg, sdeg, ddeg = s.sample(edges)
+        ctx = {"edges": edges, "src_neg": src_neg, "dst_neg": dst_neg, "filters": (None, None)}
+        if s.n_deg > 0:
+            ctx["filters"] = (H.deg_filter(ddeg, B), H.deg_filter(sdeg, B))
+        st = H.stream_ptr()
+        H.check(H.lib().marius_assemble_ids(H.ptr(edges), B, s.edge_cols, H.ptr(src_neg), H.ptr(dst_neg), CN, H.ptr(s.all_ids), st), "assemble")
+        s.um.run(s.all_ids, s.key_bits)
+        H.check(H.lib().marius_remap_edges(H.ptr(edges), H.ptr(s.um.inverse), B, s.edge_cols, H.ptr(s.edges_local), st), "remap")
+        return ctx
+
+    def owner_offsets(self, ctx, S, world):
+        offs = self.H.owner_offsets(self.s.um, S, world)  # host copy: the one sync per step
+        ctx["U"] = int(offs[-1])
+        return offs
+
+    def unique_ids(self, ctx):
+        if "U" not in ctx:
+            ctx["U"] = int(self.s.um.count.item())
+        return self.s.um.uniq[: ctx["U"]]
+
+    def gather_local(self, local_ids):
+        return self.H.gather_rows(self.table, local_ids)
+
+    def compute(self, ctx, emb):
+        s, H = self.s, self.H
+        B, CN, d = s.B, s.C * s.N, s.d
+        W = s.W
+        src_map = s.um.inverse[2 * B: 2 * B + CN]
+        dst_map = s.um.inverse[2 * B + CN: 2 * B + 2 * CN]
+        W.bind(emb, s.edges_local, dst_map, src_map, s.rel, s.inv_rel, ctx["filters"][0], ctx["filters"][1])
+        W.forward()
+        W.loss()
+        W.backward()
+        grad = torch.empty((ctx["U"], d), dtype=torch.float32, device=emb.device)
+        H.segment_sum_rows(W.gocc(), s.um, s.L, d, grad, carry=s.carry)
+        s.rel_ids.copy_(ctx["edges"][:, 1])
+        s.um_rel.run(s.rel_ids, s.rel_bits)
+        s.rel_grad.zero_()
+        H.segment_sum_rows(W.grel(0), s.um_rel, B, d, s.rel_grad, out_rows=s.um_rel.uniq, carry=s.carry_rel)
+        inv = None
+        if s.inverse:
+            s.inv_rel_grad.zero_()
+            H.segment_sum_rows(W.grel(1), s.um_rel, B, d, s.inv_rel_grad, out_rows=s.um_rel.uniq, carry=s.carry_rel)
+            inv = s.inv_rel_grad
+        return grad, [s.rel_grad, inv], W.loss_values()[0]
+
+    def apply_local(self, local_ids, grads):
+        H, s = self.H, self.s
+        n = local_ids.numel()
+        if n == 0:
+            return
+        if self.um_recv is None or self.um_recv.cap < n:
+            cap = max(n, int(1.5 * s.L))
+            self.um_recv = H.UniqueMap(cap, local_ids.device)
+            self.carry_recv = H.segment_carry(cap, s.d, local_ids.device)
+        bits = max(1, math.ceil(math.log2(self.table.size(0) + 1)))
+        self.um_recv.run(local_ids.contiguous(), bits)
+        H.segment_adagrad_scatter(grads, self.um_recv, n, s.d, self.table, self.state, s.sparse_lr, carry=self.carry_recv)
+
+    def dense_step(self, rel_grads):
+        s, H = self.s, self.H
+        H.dense_adagrad_step(s.rel, s.rel_sum, rel_grads[0], s.dense_lr)
+        if rel_grads[1] is not None:
+            H.dense_adagrad_step(s.inv_rel, s.inv_rel_sum, rel_grads[1], s.dense_lr)
+
+
+def run_sharded_bench(a, cfg, rank, world, dev):
+    """bench.py body for N > 1: weak scaling (every rank trains its own B-edge batches against the sharded table)."""
+    import json
+    import time
+
+    from . import hip as H
+    from .lp_step import DeviceLinkPredictionStep
+
+    sys_path_fix = None  # noqa: F841
+    num_nodes, R, d, B, C, N = cfg["num_nodes"], cfg["num_relations"], cfg["d"], cfg["B"], cfg["C"], cfg["N"]
+    lo, hi = shard_range(num_nodes, rank, world)
+    limit = math.sqrt(6.0 / (num_nodes + d))
+    table = torch.empty((hi - lo, d), dtype=torch.float32, device=dev).uniform_(-limit, limit, generator=torch.Generator(device=dev).manual_seed(rank))
+    state = torch.zeros((hi - lo, d), dtype=torch.float32, device=dev)
+    import bench as bench_mod
+
+    edges_all = bench_mod.synth_edges(num_nodes, R, cfg["num_edges"], a.edge_dist, dev, seed=1 + rank)
+    stepper = DeviceLinkPredictionStep(cfg["decoder"], num_nodes, R, d, B, C, N, seed=42 + rank, device=dev, node_table=None, node_state=None)
+    backend = HipBackend(stepper, table, state)
+    perm = stepper.gen.randperm_host(edges_all.size(0)).to(dev)
+    nb = edges_all.size(0) // B
+
+    def run(k0, k):
+        for s in range(k0, k0 + k):
+            edges = H.select_edges(edges_all, perm, (s % nb) * B, B)
+            sharded_step(backend, edges, rank, world, num_nodes)
+
+    run(0, a.warmup)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(a.warmup, a.steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    if rank == 0:
+        pos_eps = B * a.steps * world / dt
+        out = {
+            "metric": "edges/sec scored (pos+neg)", "value": round(pos_eps * (2 + 2 * N), 1), "unit": "scored edges/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s %s d=%d, node table sharded by contiguous id range over %d GPUs, B=%d per GPU, C=%d N=%d, %s edges" % (
+                a.workload, cfg["decoder"], d, world, B, C, N, a.edge_dist), "num_nodes": num_nodes, "num_relations": R,
+                "parallelism": "dp%d + sharded node table, RCCL all-to-all(v) row fetch / gradient return" % world},
+            "positive_edges_per_s": round(pos_eps, 1), "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(out))
+    dist.destroy_process_group()

@@ -370,3 +370,39 @@ def test_train_steps_match_cpu_reference_path(H, dev, decoder, f):
     assert_close(s_d, cpu.state, "adagrad state after 3 steps", rtol=2e-4)
     assert_close(hipstep.rel, cpu.rel, "relations after 3 steps", rtol=2e-4)
     assert_close(hipstep.inv_rel, cpu.inv_rel, "inverse relations after 3 steps", rtol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------ sharded exchange (world 1 on the GPU)
+def test_sharded_hip_backend_equals_single_gpu_step(H, dev):
+    """The N>1 code path (owner split points, all-to-all(v) over RCCL, owner-side dedupe + Adagrad) run with world_size 1 must
+    reproduce the fused single-GPU step."""
+    import os
+
+    import torch.distributed as dist
+
+    from marius_amd.lp_step import DeviceLinkPredictionStep
+    from marius_amd.sharded import HipBackend, sharded_step
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    num_nodes, R, d, B, C, N, E, seed = 3000, 9, 100, 200, 4, 60, 1200, 21
+    g = torch.Generator().manual_seed(2)
+    table = (torch.rand(num_nodes, d, generator=g) - 0.5) * 0.5
+    edges_all = torch.stack([torch.randint(num_nodes, (E,), generator=g), torch.randint(R, (E,), generator=g),
+                             torch.randint(num_nodes, (E,), generator=g)], 1).to(dev)
+    ta, sa = table.to(dev), torch.zeros(num_nodes, d, device=dev)
+    tb, sb = table.to(dev), torch.zeros(num_nodes, d, device=dev)
+    fused = DeviceLinkPredictionStep("COMPLEX", num_nodes, R, d, B, C, N, seed=seed, device=dev, node_table=ta, node_state=sa)
+    split = DeviceLinkPredictionStep("COMPLEX", num_nodes, R, d, B, C, N, seed=seed, device=dev)
+    be = HipBackend(split, tb, sb)
+    for s in range(3):
+        batch = edges_all[s * B:(s + 1) * B].contiguous()
+        W = fused.step(batch)
+        loss = sharded_step(be, batch, 0, 1, num_nodes)
+        assert_close(loss.reshape(1), W.loss_values()[0:1], "loss", rtol=1e-6)
+    assert_close(tb, ta, "table", rtol=1e-6)
+    assert_close(sb, sa, "state", rtol=1e-6)
+    assert_close(split.rel, fused.rel, "rel", rtol=1e-6)
+    dist.destroy_process_group()

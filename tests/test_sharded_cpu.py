@@ -1,0 +1,161 @@
+"""N>1 path on CPU: world_size-2 gloo run of marius_amd.sharded.sharded_step with the ORACLE as the local backend
+(tests may use the oracle; the product backend is HIP-only) vs a single-process simulation of the same synchronous
+union-batch update."""
+import os
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import lp_oracle as O
+from oracle.cpu_step import CpuLinkPredictionStep
+
+CFG = dict(decoder="COMPLEX", num_nodes=1001, R=5, d=8, B=24, C=3, N=10, steps=3, seed=17, lr=0.1)
+
+
+class OracleBackend:
+    def __init__(self, cfg, rank, table, state):
+        self.c, self.rank = cfg, rank
+        self.table, self.state = table, state
+        self.step = CpuLinkPredictionStep(cfg["decoder"], table, state, cfg["R"], cfg["B"], cfg["C"], cfg["N"])
+        self.step.num_nodes = cfg["num_nodes"]
+
+    def get_batch(self, edges):
+        src_neg, sf = self.step.get_negatives(edges, True)
+        dst_neg, df = self.step.get_negatives(edges, False)
+        uniq, mapped = O.map_tensors([edges[:, 0], edges[:, -1], src_neg.flatten(), dst_neg.flatten()])
+        el = torch.stack([mapped[0], edges[:, 1], mapped[1]]).transpose(0, 1)
+        return {"uniq": uniq, "edges_local": el, "src_map": mapped[2].reshape(src_neg.shape), "dst_map": mapped[3].reshape(dst_neg.shape)}
+
+    def unique_ids(self, ctx):
+        return ctx["uniq"]
+
+    def owner_offsets(self, ctx, S, world):
+        bounds = torch.arange(world + 1, dtype=torch.int64) * S
+        offs = torch.searchsorted(ctx["uniq"], bounds)
+        offs[-1] = ctx["uniq"].numel()
+        return offs
+
+    def gather_local(self, local_ids):
+        return O.index_read(self.table, local_ids)
+
+    def compute(self, ctx, emb):
+        s = self.step
+        out = O.train_batch(s.decoder, emb, torch.zeros_like(emb), ctx["edges_local"], ctx["dst_map"], ctx["src_map"], s.rel, s.inv_rel)
+        return out["node_grad"], [out["rel_grad"], out["inv_rel_grad"]], out["loss"]
+
+    def apply_local(self, local_ids, grads):
+        uniq, inv = torch.unique(local_ids, return_inverse=True)
+        g = torch.zeros(uniq.numel(), grads.size(1)).index_add_(0, inv, grads)
+        st = O.index_read(self.state, uniq)
+        dw, ds = O.accumulate_gradients(g, st, self.c["lr"])
+        O.index_add(self.table, uniq, dw)
+        O.index_add(self.state, uniq, ds)
+
+    def dense_step(self, rel_grads):
+        s = self.step
+        O.dense_adagrad_step(s.rel, rel_grads[0], s.rel_sum, self.c["lr"])
+        O.dense_adagrad_step(s.inv_rel, rel_grads[1], s.inv_rel_sum, self.c["lr"])
+
+
+def make_inputs(cfg):
+    g = torch.Generator().manual_seed(3)
+    table = (torch.rand(cfg["num_nodes"], cfg["d"], generator=g) - 0.5) * 0.8
+    edges = [torch.stack([torch.randint(cfg["num_nodes"], (cfg["B"] * cfg["steps"],), generator=g),
+                          torch.randint(cfg["R"], (cfg["B"] * cfg["steps"],), generator=g),
+                          torch.randint(cfg["num_nodes"], (cfg["B"] * cfg["steps"],), generator=g)], 1) for _ in range(2)]
+    return table, edges
+
+
+def worker(rank, world, port, outdir):
+    from marius_amd.sharded import shard_range, sharded_step
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = CFG
+    table, edges = make_inputs(cfg)
+    lo, hi = shard_range(cfg["num_nodes"], rank, world)
+    shard, state = table[lo:hi].clone(), torch.zeros(hi - lo, cfg["d"])
+    be = OracleBackend(cfg, rank, shard, state)
+    torch.manual_seed(cfg["seed"] + rank)
+    losses = []
+    for s in range(cfg["steps"]):
+        batch = edges[rank][s * cfg["B"]:(s + 1) * cfg["B"]]
+        losses.append(float(sharded_step(be, batch, rank, world, cfg["num_nodes"])))
+    torch.save({"shard": shard, "state": state, "rel": be.step.rel, "inv_rel": be.step.inv_rel, "losses": losses}, os.path.join(outdir, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def simulate(cfg, world=2):
+    """Single process: every 'rank' gathers from the same table state, gradients are summed per node over all ranks'
+    batches, Adagrad is applied once; relation gradients are summed (all-reduce) before the dense step."""
+    table, edges = make_inputs(cfg)
+    state = torch.zeros_like(table)
+    steppers, gens = [], []
+    for r in range(world):
+        st = CpuLinkPredictionStep(cfg["decoder"], table, state, cfg["R"], cfg["B"], cfg["C"], cfg["N"])
+        st.num_nodes = cfg["num_nodes"]
+        steppers.append(st)
+    rel, inv = steppers[0].rel, steppers[0].inv_rel
+    rel_sum, inv_sum = torch.zeros_like(rel), torch.zeros_like(inv)
+    rng_states = []
+    for r in range(world):
+        torch.manual_seed(cfg["seed"] + r)
+        rng_states.append(torch.get_rng_state())
+    losses = [[] for _ in range(world)]
+    for s in range(cfg["steps"]):
+        all_ids, all_g, rg, ig = [], [], torch.zeros_like(rel), torch.zeros_like(inv)
+        for r in range(world):
+            torch.set_rng_state(rng_states[r])
+            batch = edges[r][s * cfg["B"]:(s + 1) * cfg["B"]]
+            st = steppers[r]
+            src_neg, _ = st.get_negatives(batch, True)
+            dst_neg, _ = st.get_negatives(batch, False)
+            rng_states[r] = torch.get_rng_state()
+            uniq, mapped = O.map_tensors([batch[:, 0], batch[:, -1], src_neg.flatten(), dst_neg.flatten()])
+            el = torch.stack([mapped[0], batch[:, 1], mapped[1]]).transpose(0, 1)
+            emb = O.index_read(table, uniq)
+            out = O.train_batch(cfg["decoder"], emb, torch.zeros_like(emb), el, mapped[3].reshape(dst_neg.shape), mapped[2].reshape(src_neg.shape), rel, inv)
+            all_ids.append(uniq)
+            all_g.append(out["node_grad"])
+            rg += out["rel_grad"]
+            ig += out["inv_rel_grad"]
+            losses[r].append(float(out["loss"]))
+        ids, g = torch.cat(all_ids), torch.cat(all_g)
+        uniq, invx = torch.unique(ids, return_inverse=True)
+        gs = torch.zeros(uniq.numel(), g.size(1)).index_add_(0, invx, g)
+        stt = O.index_read(state, uniq)
+        dw, ds = O.accumulate_gradients(gs, stt, cfg["lr"])
+        O.index_add(table, uniq, dw)
+        O.index_add(state, uniq, ds)
+        O.dense_adagrad_step(rel, rg, rel_sum, cfg["lr"])
+        O.dense_adagrad_step(inv, ig, inv_sum, cfg["lr"])
+    return table, state, rel, inv, losses
+
+
+def test_sharded_step_world2_gloo_matches_union_batch_update():
+    from marius_amd.sharded import shard_range
+
+    world, port = 2, 29000 + os.getpid() % 2000
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(worker, args=(world, port, outdir), nprocs=world, join=True)
+        res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(world)]
+    table, state, rel, inv, losses = simulate(CFG, world)
+    for r in range(world):
+        lo, hi = shard_range(CFG["num_nodes"], r, world)
+        assert torch.allclose(res[r]["shard"], table[lo:hi], rtol=1e-5, atol=1e-6), "shard %d" % r
+        assert torch.allclose(res[r]["state"], state[lo:hi], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(res[r]["rel"], rel, rtol=1e-5, atol=1e-6) and torch.allclose(res[r]["inv_rel"], inv, rtol=1e-5, atol=1e-6)
+        assert res[r]["losses"] == pytest.approx(losses[r], rel=1e-5)
+    # replicas of the relation tables stay identical
+    assert torch.equal(res[0]["rel"], res[1]["rel"])
+
+
+def test_shard_ranges_follow_marius_partition_rule():
+    from marius_amd.sharded import shard_range, shard_rows
+
+    assert shard_rows(86054151, 8) == 10756769  # ceil(num_nodes / num_partitions), storage.cpp:75
+    assert shard_range(86054151, 7, 8) == (75297383, 86054151)
+    assert shard_range(10, 3, 4) == (9, 10) and shard_range(8, 3, 3) == (8, 8)
