@@ -97,6 +97,7 @@ def main():
     edges_all = synth_edges(num_nodes, R, cfg["num_edges"], a.edge_dist, dev)
     stepper = DeviceLinkPredictionStep(cfg["decoder"], num_nodes, R, d, B, C, N, seed=42, device=dev, node_table=table, node_state=state)
     perm = stepper.gen.randperm_host(edges_all.size(0)).to(dev)  # setActiveEdges: randperm on the same generator stream
+    stepper.gen.to_device(dev)
     nbatches = edges_all.size(0) // B
 
     def run(k0, k):

@@ -43,4 +43,55 @@ struct LpDims {
     float gscale;  // 1 (SUM) or 1/Bp (MEAN)
 };
 
+// ---- MFMA contraction kernels: argument blocks and tile constants (shared by lp_decoder.hip and lp_fast.hip)
+struct ScoreArgs {
+    const float* adj;  // [ndir][Bp, d_ld]
+    const float* emb;
+    int64_t emb_ld;
+    int emb_vec;
+    const int64_t* negmap[2];  // [C, N] batch-local
+    float* S;                  // [ndir][Bp, n_ld]
+    const float* x2;           // L2
+    const float* y2;           // L2
+    int KC, KS, nkc, dk;
+    LpDims D;
+};
+
+constexpr int F_TM = 128, F_TN = 128;
+
+struct GradArgs {
+    const float* S;
+    const float* lse;  // [ndir][Bp]
+    const float* adj;  // [ndir][Bp, d_ld]
+    const float* emb;
+    int64_t emb_ld;
+    int emb_vec;
+    const int64_t* negmap[2];
+    float* dadj;            // [ndir][Bp, d_ld]
+    float* gocc;            // [L, d_ld]
+    int64_t negocc_off[2];  // first gocc row of dir's negatives
+    int ncols;              // useful columns per n-block (128, or 127 when the ones column is appended for L2)
+    LpDims D;
+};
+
+constexpr int G_TM = 64, G_TN = 128, G_KC = 64;
+constexpr int G_KSA = G_KC + 2;   // [m][k] layout, b64 fragment reads: stride/2 odd
+constexpr int G_TMS = G_TM + 4;   // [k][m] layout
+constexpr int G_TNS = G_TN + 4;   // [k][n] layout
+
+template <bool L2>
+__device__ __forceinline__ float dscore(float s, float lse, float gscale) {
+    // dL/dS (Dot) or dL/d(x.y) (L2: S = sqrt(max(t,1e-8)), t = x2 + y2 - 2 x.y  =>  -q / S, zero where clamped)
+    if (L2) {
+        const float q = gscale * __expf(s - lse);
+        return (s > 1.0000001e-4f) ? (-q / s) : 0.f;
+    }
+    return gscale * __expf(s - lse);
+}
+
+// fast variants (lp_fast.hip): require d % 4 == 0 and 16-B aligned embedding rows; return false if not applicable
+bool launch_scores_fast(const ScoreArgs& a, bool l2, hipStream_t st);
+bool launch_grad_adj_fast(const GradArgs& a, bool l2, hipStream_t st);
+bool launch_grad_neg_fast(const GradArgs& a, bool l2, hipStream_t st);
+
 }  // namespace marius

@@ -15,6 +15,8 @@
 // The negative rows are gathered by batch-local index straight into LDS (the "LDS-staged transpose": fragments are
 // read from LDS in MFMA operand order, no transposed copy ever exists in HBM).  No atomics anywhere: every output
 // element has exactly one owner workgroup.
+#include <cstdlib>
+
 #include "lp_common.h"
 
 namespace marius {
@@ -115,20 +117,6 @@ __global__ __launch_bounds__(256) void lp_negnorm_kernel(const float* emb, int64
 }
 
 // =========================================================================================== scores (F)
-struct ScoreArgs {
-    const float* adj;  // [ndir][Bp, d_ld]
-    const float* emb;
-    int64_t emb_ld;
-    int emb_vec;
-    const int64_t* negmap[2];  // [C, N] batch-local
-    float* S;                  // [ndir][Bp, n_ld]
-    const float* x2;           // L2
-    const float* y2;           // L2
-    int KC, KS, nkc, dk;
-    LpDims D;
-};
-
-constexpr int F_TM = 128, F_TN = 128;
 
 template <bool L2>
 __global__ __launch_bounds__(256) void lp_scores_kernel(ScoreArgs a) {
@@ -268,63 +256,36 @@ __global__ __launch_bounds__(256) void lp_lse_kernel(const float* __restrict__ S
     }
 }
 
-// deterministic sum of rowloss per dir -> loss[1 + dir]; loss[0] = total (lhs + rhs, model.cpp:309-312)
-__global__ __launch_bounds__(1024) void lp_loss_reduce_kernel(const float* rowloss, int64_t Bp, int ndir, float scale, float* loss) {
+// deterministic sum of rowloss: one block per direction -> loss[1 + dir]; lp_loss_total_kernel then writes loss[0] = lhs + rhs
+// (model.cpp:309-312)
+__global__ __launch_bounds__(1024) void lp_loss_reduce_kernel(const float* rowloss, int64_t Bp, float scale, float* loss) {
     __shared__ float red[1024];
-    float tot = 0.f;
-    for (int dir = 0; dir < ndir; ++dir) {
-        float s = 0.f;
-        for (int64_t i = threadIdx.x; i < Bp; i += 1024) s += rowloss[(int64_t)dir * Bp + i];
-        red[threadIdx.x] = s;
-        __syncthreads();
-        for (int o = 512; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            loss[1 + dir] = red[0] * scale;
-            tot += red[0] * scale;
-        }
+    const int dir = blockIdx.x;
+    const float* r = rowloss + (int64_t)dir * Bp;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t i = threadIdx.x;
+    for (; i + 3 * 1024 < Bp; i += 4 * 1024) {
+        s0 += r[i];
+        s1 += r[i + 1024];
+        s2 += r[i + 2048];
+        s3 += r[i + 3072];
+    }
+    for (; i < Bp; i += 1024) s0 += r[i];
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        loss[0] = tot;
-        if (ndir == 1) loss[2] = 0.f;
-        loss[3] = 0.f;
-    }
+    if (threadIdx.x == 0) loss[1 + dir] = red[0] * scale;
+}
+__global__ void lp_loss_total_kernel(int ndir, float* loss) {
+    if (ndir == 1) loss[2] = 0.f;
+    loss[0] = loss[1] + (ndir == 2 ? loss[2] : 0.f);
+    loss[3] = 0.f;
 }
 
 // =========================================================================================== backward contractions
-struct GradArgs {
-    const float* S;
-    const float* lse;  // [ndir][Bp]
-    const float* adj;  // [ndir][Bp, d_ld]
-    const float* emb;
-    int64_t emb_ld;
-    int emb_vec;
-    const int64_t* negmap[2];
-    float* dadj;            // [ndir][Bp, d_ld]
-    float* gocc;            // [L, d_ld]
-    int64_t negocc_off[2];  // first gocc row of dir's negatives
-    int ncols;              // useful columns per n-block (128, or 127 when the ones column is appended for L2)
-    LpDims D;
-};
-
-constexpr int G_TM = 64, G_TN = 128, G_KC = 64;
-constexpr int G_KSA = G_KC + 2;   // [m][k] layout, b64 fragment reads: stride/2 odd
-constexpr int G_TMS = G_TM + 4;   // [k][m] layout
-constexpr int G_TNS = G_TN + 4;   // [k][n] layout
-
-template <bool L2>
-__device__ __forceinline__ float dscore(float s, float lse, float gscale) {
-    // dL/dS (Dot) or dL/d(x.y) (L2: S = sqrt(max(t,1e-8)), t = x2 + y2 - 2 x.y  =>  -q / S, zero where clamped)
-    if (L2) {
-        const float q = gscale * __expf(s - lse);
-        return (s > 1.0000001e-4f) ? (-q / s) : 0.f;
-    }
-    return gscale * __expf(s - lse);
-}
-
 // dAdj_c[m, n] = sum_j V[m, j] * Neg_c[j, n]     (M = rows of the chunk, K = negatives, N = embedding columns)
 template <bool L2>
 __global__ __launch_bounds__(256) void lp_grad_adj_kernel(GradArgs a) {
@@ -656,6 +617,12 @@ __global__ __launch_bounds__(256) void lp_ranks_kernel(const float* __restrict__
 // =========================================================================================== host side
 static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
+// MARIUS_NO_FAST=1 forces the generic contraction kernels (A/B runs, tests of both code paths)
+static bool use_fast() {
+    const char* e = getenv("MARIUS_NO_FAST");
+    return !(e && e[0] == '1');
+}
+
 static int fill_dims(const marius_lp_desc* d, LpDims& D) {
     MARIUS_REQUIRE(d, "lp: null descriptor");
     MARIUS_REQUIRE(d->d > 0 && d->B > 0 && d->C > 0 && d->N > 0, "lp: bad sizes d=%d B=%ld C=%d N=%d", d->d, (long)d->B, d->C, d->N);
@@ -786,10 +753,12 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     size_t lds = (size_t)(F_TM + F_TN) * sa.KS * sizeof(float);
     {
         ProfScope ps(PROF_LP_SCORES, st);
-        if (l2)
-            lp_scores_kernel<true><<<grid, dim3(256), lds, st>>>(sa);
-        else
-            lp_scores_kernel<false><<<grid, dim3(256), lds, st>>>(sa);
+        if (!use_fast() || !launch_scores_fast(sa, l2, st)) {
+            if (l2)
+                lp_scores_kernel<true><<<grid, dim3(256), lds, st>>>(sa);
+            else
+                lp_scores_kernel<false><<<grid, dim3(256), lds, st>>>(sa);
+        }
     }
     rc = check_launch("lp_scores");
     if (rc) return rc;
@@ -825,8 +794,8 @@ extern "C" int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout
     }
     rc = check_launch("lp_lse");
     if (rc) return rc;
-    lp_loss_reduce_kernel<<<dim3(1), dim3(1024), 0, st>>>((const float*)(ws + L->rowloss[0]), D.Bp, D.ndir, D.gscale,
-                                                         (float*)(ws + L->loss));
+    lp_loss_reduce_kernel<<<dim3(D.ndir), dim3(1024), 0, st>>>((const float*)(ws + L->rowloss[0]), D.Bp, D.gscale, (float*)(ws + L->loss));
+    lp_loss_total_kernel<<<dim3(1), dim3(1), 0, st>>>(D.ndir, (float*)(ws + L->loss));
     return check_launch("lp_loss_reduce");
 }
 
@@ -861,17 +830,21 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     dim3 gn_grid(nblk, (unsigned)cdiv(D.N, G_TM), (unsigned)(D.C * D.ndir));
     {
         ProfScope ps(PROF_LP_GRAD_ADJ, st);
-        if (l2)
-            lp_grad_adj_kernel<true><<<ga_grid, dim3(256), 0, st>>>(ga);
-        else
-            lp_grad_adj_kernel<false><<<ga_grid, dim3(256), 0, st>>>(ga);
+        if (!use_fast() || !launch_grad_adj_fast(ga, l2, st)) {
+            if (l2)
+                lp_grad_adj_kernel<true><<<ga_grid, dim3(256), 0, st>>>(ga);
+            else
+                lp_grad_adj_kernel<false><<<ga_grid, dim3(256), 0, st>>>(ga);
+        }
     }
     {
         ProfScope ps(PROF_LP_GRAD_NEG, st);
-        if (l2)
-            lp_grad_neg_kernel<true><<<gn_grid, dim3(256), 0, st>>>(ga);
-        else
-            lp_grad_neg_kernel<false><<<gn_grid, dim3(256), 0, st>>>(ga);
+        if (!use_fast() || !launch_grad_neg_fast(ga, l2, st)) {
+            if (l2)
+                lp_grad_neg_kernel<true><<<gn_grid, dim3(256), 0, st>>>(ga);
+            else
+                lp_grad_neg_kernel<false><<<gn_grid, dim3(256), 0, st>>>(ga);
+        }
     }
     rc = check_launch("lp_grad");
     if (rc) return rc;

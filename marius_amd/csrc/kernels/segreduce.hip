@@ -86,10 +86,13 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply)
     if (k0 >= a.n) return;
     const int cnt = (int)min((int64_t)SEG_R, a.n - k0);
     const int64_t k1 = k0 + cnt;
-    int p = -1, u = -1;
+    // lane r < cnt owns sorted position k0 + r: its occurrence row, its segment, and whether that segment lies inside the chunk
+    int p = 0, u = -1, complete = 0;
     if (lane < cnt) {
         p = a.perm[k0 + lane];
         u = (int)a.inverse[p];
+        const int s0 = a.seg_offsets[u], s1 = a.seg_offsets[u + 1];
+        complete = (s0 >= k0) && (s1 <= k1);
     }
     const int u_first = __shfl(u, 0, 64);
     float acc[NIT][VEC];
@@ -97,16 +100,14 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply)
     for (int it = 0; it < NIT; ++it)
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[it][e] = 0.f;
-    int cur = u_first;
+    int cur = u_first, cur_complete = __shfl(complete, 0, 64);
 
-    auto flush = [&](int useg) {
-        const int s0 = a.seg_offsets[useg], s1 = a.seg_offsets[useg + 1];
-        const bool complete = (s0 >= k0) && (s1 <= k1);
+    auto flush = [&](int useg, int is_complete) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int col = (lane + it * 64) * VEC;
             if (col < a.d) {
-                if (complete) {
+                if (is_complete) {
                     apply.template operator()<VEC>(useg, col, acc[it]);
                 } else {
                     float* c = a.carry + ((chunk * 2) + (useg == u_first ? 0 : 1)) * a.dpad + col;
@@ -121,12 +122,14 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply)
 
     for (int b0 = 0; b0 < cnt; b0 += SEG_BATCH) {
         float v[SEG_BATCH][NIT][VEC];
-        int ub[SEG_BATCH];
+        int ub[SEG_BATCH], cb[SEG_BATCH];
 #pragma unroll
         for (int j = 0; j < SEG_BATCH; ++j) {
             const int r = b0 + j;
-            const int pr = __shfl(p, r < cnt ? r : 0, 64);
-            ub[j] = (r < cnt) ? __shfl(u, r, 64) : -1;
+            const int rr = r < cnt ? r : 0;
+            const int pr = __shfl(p, rr, 64);
+            ub[j] = (r < cnt) ? __shfl(u, rr, 64) : -1;
+            cb[j] = __shfl(complete, rr, 64);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int col = (lane + it * 64) * VEC;
@@ -139,8 +142,9 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply)
         for (int j = 0; j < SEG_BATCH; ++j) {
             if (ub[j] < 0) break;
             if (ub[j] != cur) {
-                flush(cur);
+                flush(cur, cur_complete);
                 cur = ub[j];
+                cur_complete = cb[j];
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply)
                 for (int e = 0; e < VEC; ++e) acc[it][e] += v[j][it][e];
         }
     }
-    flush(cur);
+    flush(cur, cur_complete);
 }
 
 // phase 2: the chunk in which a boundary-crossing segment STARTS finishes it from the carries
@@ -192,6 +196,54 @@ __global__ __launch_bounds__(256) void seg_fixup_kernel(SegArgs a, Apply apply) 
 }
 
 static inline int dpad_of(int d) { return (d + 3) / 4 * 4; }
+
+// Row-parallel sparse Adagrad over the per-unique-row gradients g[U, dpad] (U = inverse[perm[n-1]] + 1 read on the device):
+//   ds = g*g; s = state[id] + ds; table[id] += -lr * (g / (sqrt(s) + eps)); state[id] = s        (batch.cpp:67-69 op order)
+template <int VEC>
+__global__ __launch_bounds__(256) void adagrad_unique_rows_kernel(const float* __restrict__ g, int64_t g_ld, const int32_t* __restrict__ perm,
+                                                                  const int64_t* __restrict__ inverse, int64_t n, const int64_t* __restrict__ uniq,
+                                                                  float* __restrict__ table, float* __restrict__ state, int64_t ld, int vpr,
+                                                                  float lr, float eps) {
+#pragma clang fp contract(off)
+    const int64_t U = inverse[perm[n - 1]] + 1;
+    const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
+    constexpr int UNR = 4;
+    int64_t rows[UNR], ids[UNR];
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+        rows[k] = ((int64_t)blockIdx.x * UNR + k) * TY + ty;
+        ids[k] = rows[k] < U ? uniq[rows[k]] : -1;
+    }
+    for (int c = tx; c < vpr; c += TX) {
+        float gv[UNR][VEC], wv[UNR][VEC], sv[UNR][VEC];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            if (ids[k] >= 0) {
+                load_vec<VEC>(g + rows[k] * g_ld + c * VEC, gv[k]);
+                load_vec<VEC>(table + ids[k] * ld + c * VEC, wv[k]);
+                load_vec<VEC>(state + ids[k] * ld + c * VEC, sv[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            if (ids[k] >= 0) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float ds = gv[k][e] * gv[k][e];
+                    const float sn = sv[k][e] + ds;
+                    const float dw = -lr * (gv[k][e] / (sqrtf(sn) + eps));
+                    sv[k][e] = sn;
+                    wv[k][e] = wv[k][e] + dw;
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    state[ids[k] * ld + c * VEC + e] = sv[k][e];
+                    table[ids[k] * ld + c * VEC + e] = wv[k][e];
+                }
+            }
+        }
+    }
+}
 
 template <class Apply>
 static int launch_seg(const SegArgs& a, const Apply& apply, int vec, hipStream_t st) {
@@ -243,8 +295,11 @@ static int fill_args(SegArgs& a, const float* rows, int64_t rows_ld, const int32
 
 using namespace marius;
 
+static inline size_t carry_only_bytes(int64_t n, int d) { return ((size_t)cdiv(n > 0 ? n : 1, SEG_R) * 2 * dpad_of(d) * sizeof(float) + 255) / 256 * 256; }
+
 extern "C" size_t marius_segment_carry_bytes(int64_t n, int32_t d) {
-    return (size_t)cdiv(n > 0 ? n : 1, SEG_R) * 2 * dpad_of(d) * sizeof(float) + 256;
+    // chunk carries + (for the fused Adagrad form) the per-unique-row gradient scratch [n, dpad]
+    return carry_only_bytes(n, d) + (size_t)(n > 0 ? n : 1) * dpad_of(d) * sizeof(float) + 256;
 }
 
 extern "C" int marius_segment_sum_rows(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
@@ -275,7 +330,26 @@ extern "C" int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld
     int v2 = row_vec_width(table, table_ld, d), v3 = row_vec_width(state, table_ld, d);
     vec = vec < v2 ? vec : v2;
     vec = vec < v3 ? vec : v3;
-    ApplyAdagrad ap{uniq_ids, table, state, table_ld, lr, eps};
-    ProfScope ps(PROF_SEG_ADAGRAD, as_stream(stream));
-    return launch_seg(a, ap, vec, as_stream(stream));
+    hipStream_t st = as_stream(stream);
+    ProfScope ps(PROF_SEG_ADAGRAD, st);
+    // (1) per-unique-row gradient sums into scratch (stores only: nothing in the reduction waits on the tables)
+    float* gsum = (float*)((char*)carry + carry_only_bytes(n, d));
+    const int64_t g_ld = dpad_of(d);
+    int vsum = row_vec_width(rows, rows_ld, d);
+    ApplySum ap{gsum, g_ld, nullptr};
+    rc = launch_seg(a, ap, vsum, st);
+    if (rc) return rc;
+    // (2) row-parallel Adagrad + scatter (ids ascending and unique: race-free, fully pipelined loads)
+    const int vpr = d / vec;
+    int tx = 1;
+    while (tx < vpr && tx < 64) tx <<= 1;
+    const int ty = 256 / tx;
+    dim3 block(tx, ty, 1), grid((unsigned)cdiv(n, (int64_t)ty * 4));
+    if (vec == 4)
+        adagrad_unique_rows_kernel<4><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps);
+    else if (vec == 2)
+        adagrad_unique_rows_kernel<2><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps);
+    else
+        adagrad_unique_rows_kernel<1><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps);
+    return check_launch("segment_adagrad_scatter");
 }

@@ -46,7 +46,14 @@ class DeviceLinkPredictionStep:
         CN = self.C * self.N
         self.L = 2 * self.B + 2 * CN
         self.words = H.negatives_raw_words(num_nodes, self.B, self.C, self.N, self.n_deg)
-        self.raw = torch.empty(2 * self.words, dtype=torch.int32, device=self.dev)
+        # raw MT19937 words for one step (src negatives then dst negatives), double buffered: the single-workgroup generator
+        # kernel runs on a side stream one step ahead of the consumer (same stream of numbers, just produced early)
+        self.raw_bufs = [torch.empty(2 * self.words, dtype=torch.int32, device=self.dev) for _ in range(2)]
+        self.side = torch.cuda.Stream(device=self.dev)
+        self.ev_ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.ev_free = [torch.cuda.Event(), torch.cuda.Event()]
+        self.step_idx = 0
+        self.prefetched = -1
         self.all_ids = torch.empty(self.L, dtype=torch.int64, device=self.dev)
         self.um = H.UniqueMap(self.L, self.dev)
         self.um_rel = H.UniqueMap(self.B, self.dev)
@@ -64,10 +71,29 @@ class DeviceLinkPredictionStep:
     # ---- getBatch: dataloader.cpp:360-471
     def sample(self, edges):
         """edges [B, cols] int64 global ids on device. Returns (src_neg, dst_neg, src_deg_pos, dst_deg_pos)."""
-        self.gen.fill_device(2 * self.words, out=self.raw)
-        src_neg, sdeg = H.sample_negatives(self.raw[: self.words], edges, self.num_nodes, self.C, self.N, self.f, True)
-        dst_neg, ddeg = H.sample_negatives(self.raw[self.words:], edges, self.num_nodes, self.C, self.N, self.f, False)
+        slot = self.step_idx & 1
+        main = torch.cuda.current_stream()
+        if self.prefetched < self.step_idx:
+            self._prefetch_raw(self.step_idx, main)
+        main.wait_event(self.ev_ready[slot])
+        raw = self.raw_bufs[slot]
+        src_neg, sdeg = H.sample_negatives(raw[: self.words], edges, self.num_nodes, self.C, self.N, self.f, True)
+        dst_neg, ddeg = H.sample_negatives(raw[self.words:], edges, self.num_nodes, self.C, self.N, self.f, False)
+        self.ev_free[slot].record(main)
+        self.step_idx += 1
+        self._prefetch_raw(self.step_idx, main)
         return src_neg, dst_neg, sdeg, ddeg
+
+    def _prefetch_raw(self, idx, main):
+        slot = idx & 1
+        with torch.cuda.stream(self.side):
+            if idx >= 2:
+                self.side.wait_event(self.ev_free[slot])
+            else:
+                self.side.wait_stream(main)
+            self.gen.fill_device(2 * self.words, out=self.raw_bufs[slot])
+            self.ev_ready[slot].record(self.side)
+        self.prefetched = idx
 
     def step(self, edges, dst_filter=None, src_filter=None):
         B, CN, d = self.B, self.C * self.N, self.d

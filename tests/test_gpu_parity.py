@@ -239,6 +239,21 @@ def test_lp_forward_loss_backward(H, dev, decoder, use_inverse, B, C, N, d, redu
         assert_close(inv_grad.float(), want["inv_rel_grad"], "inv_rel_grad")
 
 
+@pytest.mark.parametrize("decoder", ["DISTMULT", "COMPLEX", "TRANSE"])
+def test_lp_generic_kernels_also_match(H, dev, decoder, monkeypatch):
+    """MARIUS_NO_FAST=1 forces the generic contraction kernels at a shape the fast ones normally take."""
+    monkeypatch.setenv("MARIUS_NO_FAST", "1")
+    B, C, N, d, U, R = 300, 4, 200, 100, 400, 7
+    emb, state, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=31)
+    want = O.train_batch(decoder, emb, state, edges, dst_neg, src_neg, rel, inv)
+    W = run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, "sum")
+    assert_close(W.neg(0), want["neg"], "neg")
+    assert_close(W.neg(1), want["inv_neg"], "inv_neg")
+    occ_ids = torch.cat([edges[:, 0], edges[:, 2], src_neg.flatten(), dst_neg.flatten()])
+    node_grad = torch.zeros(U, d, dtype=torch.float64).index_add_(0, occ_ids, W.gocc()[:, :d].cpu().double())
+    assert_close(node_grad.float(), want["node_grad"], "node_grad")
+
+
 @pytest.mark.parametrize("decoder", ["DISTMULT", "TRANSE"])
 def test_lp_mean_reduction_and_filter(H, dev, decoder):
     B, C, N, d, U, R = 96, 4, 40, 20, 60, 5
