@@ -54,6 +54,7 @@ struct ScoreArgs {
     const float* x2;           // L2
     const float* y2;           // L2
     int KC, KS, nkc, dk;
+    int ablate;  // debug only (MARIUS_ABLATE): 1 = skip S stores, 2 = skip MFMAs, 4 = skip negative-tile staging
     LpDims D;
 };
 
@@ -71,6 +72,7 @@ struct GradArgs {
     float* gocc;            // [L, d_ld]
     int64_t negocc_off[2];  // first gocc row of dir's negatives
     int ncols;              // useful columns per n-block (128, or 127 when the ones column is appended for L2)
+    int ablate;             // debug only (MARIUS_ABLATE): 2 = skip MFMAs, 4 = skip V staging, 8 = skip B staging, 16 = skip exp
     LpDims D;
 };
 
@@ -93,5 +95,9 @@ __device__ __forceinline__ float dscore(float s, float lse, float gscale) {
 bool launch_scores_fast(const ScoreArgs& a, bool l2, hipStream_t st);
 bool launch_grad_adj_fast(const GradArgs& a, bool l2, hipStream_t st);
 bool launch_grad_neg_fast(const GradArgs& a, bool l2, hipStream_t st);
+// resident-operand / 16x16x4 variants (lp_res.hip): additionally d <= 128 for the score kernel
+bool launch_scores_res(const ScoreArgs& a, bool l2, hipStream_t st);
+bool launch_scores_pp(const ScoreArgs& a, bool l2, hipStream_t st);  // ping-pong persistent variant (level 3)
+bool launch_grad16(const GradArgs& a, bool l2, int which, hipStream_t st);  // which: 0 both (one launch), 1 dAdj, 2 dNeg
 
 }  // namespace marius

@@ -617,10 +617,19 @@ __global__ __launch_bounds__(256) void lp_ranks_kernel(const float* __restrict__
 // =========================================================================================== host side
 static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
-// MARIUS_NO_FAST=1 forces the generic contraction kernels (A/B runs, tests of both code paths)
-static bool use_fast() {
+// Contraction kernel family: 3 = ping-pong persistent scores (experimental, MARIUS_KERNELS=pp; measured slower than 2),
+// 2 = resident-operand scores + merged 16x16x4 grads (lp_res.hip, default),
+// 1 = fast (lp_fast.hip), 0 = generic.
+// MARIUS_KERNELS=generic|fast|res (or MARIUS_NO_FAST=1) selects a lower level for A/B runs and for tests of every code path;
+// a level that does not apply to the shape falls through to the next lower one.
+static int kernel_level() {
     const char* e = getenv("MARIUS_NO_FAST");
-    return !(e && e[0] == '1');
+    if (e && e[0] == '1') return 0;
+    const char* k = getenv("MARIUS_KERNELS");
+    if (k && k[0] == 'g') return 0;
+    if (k && k[0] == 'f') return 1;
+    if (k && k[0] == 'p') return 3;
+    return 2;
 }
 
 static int fill_dims(const marius_lp_desc* d, LpDims& D) {
@@ -749,11 +758,13 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     sa.KC = ((sa.dk + sa.nkc - 1) / sa.nkc + 3) / 4 * 4;
     sa.KS = ((sa.KC / 2) & 1) ? sa.KC : sa.KC + 2;  // stride/2 odd -> conflict-free ds_read_b64 across 32 rows
     sa.D = D;
+    { const char* ab = getenv("MARIUS_ABLATE"); sa.ablate = ab ? atoi(ab) : 0; }
     dim3 grid((unsigned)cdiv(D.N, F_TN), (unsigned)cdiv(D.Bc, F_TM), (unsigned)(D.C * D.ndir));
     size_t lds = (size_t)(F_TM + F_TN) * sa.KS * sizeof(float);
     {
         ProfScope ps(PROF_LP_SCORES, st);
-        if (!use_fast() || !launch_scores_fast(sa, l2, st)) {
+        const int lvl = kernel_level();
+        if (!((lvl >= 3 && launch_scores_pp(sa, l2, st)) || (lvl >= 2 && launch_scores_res(sa, l2, st)) || (lvl >= 1 && launch_scores_fast(sa, l2, st)))) {
             if (l2)
                 lp_scores_kernel<true><<<grid, dim3(256), lds, st>>>(sa);
             else
@@ -825,25 +836,38 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     ga.negocc_off[1] = 2 * D.B;                            // src negatives
     ga.ncols = l2 ? G_TN - 1 : G_TN;
     ga.D = D;
+    { const char* ab = getenv("MARIUS_ABLATE"); ga.ablate = ab ? atoi(ab) : 0; }
     const unsigned nblk = (unsigned)cdiv(D.d, ga.ncols);
     dim3 ga_grid(nblk, (unsigned)cdiv(D.Bc, G_TM), (unsigned)(D.C * D.ndir));
     dim3 gn_grid(nblk, (unsigned)cdiv(D.N, G_TM), (unsigned)(D.C * D.ndir));
     {
-        ProfScope ps(PROF_LP_GRAD_ADJ, st);
-        if (!use_fast() || !launch_grad_adj_fast(ga, l2, st)) {
-            if (l2)
-                lp_grad_adj_kernel<true><<<ga_grid, dim3(256), 0, st>>>(ga);
-            else
-                lp_grad_adj_kernel<false><<<ga_grid, dim3(256), 0, st>>>(ga);
+        const int lvl = kernel_level();
+        const char* sp = getenv("MARIUS_GRAD_SPLIT");  // 1 = separate launches for dAdj / dNeg (per-kernel timing)
+        const bool split = sp && sp[0] == '1';
+        bool done = false;
+        if (lvl >= 2 && !split) {
+            ProfScope ps(PROF_LP_GRAD_ADJ, st);  // merged launch is accounted under lp_grad_adj (both contractions)
+            done = launch_grad16(ga, l2, 0, st);
         }
-    }
-    {
-        ProfScope ps(PROF_LP_GRAD_NEG, st);
-        if (!use_fast() || !launch_grad_neg_fast(ga, l2, st)) {
-            if (l2)
-                lp_grad_neg_kernel<true><<<gn_grid, dim3(256), 0, st>>>(ga);
-            else
-                lp_grad_neg_kernel<false><<<gn_grid, dim3(256), 0, st>>>(ga);
+        if (!done) {
+            {
+                ProfScope ps(PROF_LP_GRAD_ADJ, st);
+                if (!((lvl >= 2 && launch_grad16(ga, l2, 1, st)) || (lvl >= 1 && launch_grad_adj_fast(ga, l2, st)))) {
+                    if (l2)
+                        lp_grad_adj_kernel<true><<<ga_grid, dim3(256), 0, st>>>(ga);
+                    else
+                        lp_grad_adj_kernel<false><<<ga_grid, dim3(256), 0, st>>>(ga);
+                }
+            }
+            {
+                ProfScope ps(PROF_LP_GRAD_NEG, st);
+                if (!((lvl >= 2 && launch_grad16(ga, l2, 2, st)) || (lvl >= 1 && launch_grad_neg_fast(ga, l2, st)))) {
+                    if (l2)
+                        lp_grad_neg_kernel<true><<<gn_grid, dim3(256), 0, st>>>(ga);
+                    else
+                        lp_grad_neg_kernel<false><<<gn_grid, dim3(256), 0, st>>>(ga);
+                }
+            }
         }
     }
     rc = check_launch("lp_grad");

@@ -240,9 +240,10 @@ def test_lp_forward_loss_backward(H, dev, decoder, use_inverse, B, C, N, d, redu
 
 
 @pytest.mark.parametrize("decoder", ["DISTMULT", "COMPLEX", "TRANSE"])
-def test_lp_generic_kernels_also_match(H, dev, decoder, monkeypatch):
-    """MARIUS_NO_FAST=1 forces the generic contraction kernels at a shape the fast ones normally take."""
-    monkeypatch.setenv("MARIUS_NO_FAST", "1")
+@pytest.mark.parametrize("level", ["generic", "fast", "pp"])
+def test_lp_lower_kernel_levels_also_match(H, dev, decoder, level, monkeypatch):
+    """MARIUS_KERNELS forces the generic / fast contraction kernels at a shape the resident ones normally take."""
+    monkeypatch.setenv("MARIUS_KERNELS", level)
     B, C, N, d, U, R = 300, 4, 200, 100, 400, 7
     emb, state, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=31)
     want = O.train_batch(decoder, emb, state, edges, dst_neg, src_neg, rel, inv)
