@@ -191,6 +191,11 @@ int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout* layout, v
 /* loss.backward() (model.cpp:324) restricted to this graph: fills gocc (per-occurrence node gradients) and grel. */
 int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_layout* layout, void* workspace, marius_stream_t stream);
 
+/* SoftmaxCrossEntropy::operator() on materialised scores  src/nn/loss.cpp:50-67 (API-level; the training path uses marius_lp_loss).
+ * lse[rows], rowloss[rows], loss[4] are outputs (loss[0] = reduced loss).  neg_ld must be a multiple of 4. */
+int marius_softmax_ce(const float* pos, const float* neg, int64_t rows, int32_t N, int64_t neg_ld, int32_t reduction, float* lse,
+                      float* rowloss, float* loss, marius_stream_t stream);
+
 /* ranks = (neg >= pos[:,None]).sum(1) + 1   replaces LinkPredictionReporter::computeRanks src/reporting/reporting.cpp:55-57 */
 int marius_compute_ranks(const float* pos, const float* neg, int64_t rows, int32_t N, int64_t neg_ld, int64_t* ranks,
                          marius_stream_t stream);

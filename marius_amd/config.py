@@ -1,0 +1,98 @@
+"""YAML configuration surface of `marius_train` for the link-prediction path.
+
+Same keys and defaults as the reference's OmegaConf schema (src/python/tools/configuration/marius_config.py; defaults cited in
+SURVEY.md §5.6) for everything the hot path reads; keys that configure subsystems outside the path (GNN layers, partition
+buffer, async pipeline) are accepted and ignored with a warning.  Dataset statistics come from <dataset_dir>/dataset.yaml
+(marius_config.py:470-493), model_dir defaults to <dataset_dir>/model_<i> (:47-56,562-565).
+"""
+import copy
+import os
+import random
+import warnings
+
+import yaml
+
+DEFAULTS = {
+    "model": {
+        "random_seed": None,  # random if absent (marius_config.py:354-356)
+        "learning_task": "LINK_PREDICTION",
+        "encoder": {"layers": [[{"type": "EMBEDDING", "output_dim": 50}]]},
+        "decoder": {"type": "DISTMULT", "options": {"inverse_edges": True, "edge_decoder_method": "CORRUPT_NODE"}},
+        "loss": {"type": "SOFTMAX_CE", "options": {"reduction": "SUM"}},
+        "dense_optimizer": {"type": "ADAGRAD", "options": {"learning_rate": 0.1}},
+        "sparse_optimizer": {"type": "ADAGRAD", "options": {"learning_rate": 0.1}},
+    },
+    "storage": {
+        "device_type": "cpu",
+        "dataset": {"dataset_dir": None, "num_relations": 1},
+        "edges": {"type": "DEVICE_MEMORY", "options": {"dtype": "int"}},
+        "embeddings": {"type": "DEVICE_MEMORY", "options": {"dtype": "float"}},
+        "save_model": True, "shuffle_input": True, "full_graph_evaluation": True, "model_dir": None,
+    },
+    "training": {
+        "batch_size": 1000,
+        "negative_sampling": {"num_chunks": 1, "negatives_per_positive": 1000, "degree_fraction": 0.0, "filtered": False, "local_filter_mode": "DEG"},
+        "num_epochs": 10, "pipeline": {"sync": True}, "epochs_per_shuffle": 1, "logs_per_epoch": 10,
+    },
+    "evaluation": {
+        "batch_size": 1000,
+        "negative_sampling": {"num_chunks": 1, "negatives_per_positive": 1000, "degree_fraction": 0.0, "filtered": False, "local_filter_mode": "DEG"},
+        "pipeline": {"sync": True}, "epochs_per_eval": 1,
+    },
+}
+
+
+def _merge(base, over, path=""):
+    out = copy.deepcopy(base)
+    for k, v in (over or {}).items():
+        if isinstance(v, dict) and isinstance(out.get(k), dict):
+            out[k] = _merge(out[k], v, path + k + ".")
+        else:
+            out[k] = v
+    return out
+
+
+def load_config(path):
+    """Returns the full configuration dict (defaults merged, dataset stats filled in)."""
+    with open(path) as f:
+        user = yaml.safe_load(f)
+    cfg = _merge(DEFAULTS, user)
+    base = os.path.dirname(os.path.abspath(path))
+    ds = cfg["storage"]["dataset"]
+    if not ds.get("dataset_dir"):
+        raise ValueError("storage.dataset.dataset_dir is required")
+    ddir = ds["dataset_dir"]
+    if not os.path.isabs(ddir):
+        ddir = os.path.normpath(os.path.join(base, ddir)) if not os.path.isdir(ddir) else os.path.abspath(ddir)
+    ds["dataset_dir"] = ddir
+    stats = os.path.join(ddir, "dataset.yaml")
+    if os.path.exists(stats):
+        with open(stats) as f:
+            for k, v in (yaml.safe_load(f) or {}).items():
+                if k != "dataset_dir":
+                    ds[k] = v
+    for k in ("num_nodes", "num_train"):
+        if k not in ds:
+            raise ValueError("dataset statistic %s missing (expected in %s)" % (k, stats))
+    if cfg["model"]["random_seed"] is None:
+        cfg["model"]["random_seed"] = random.randint(0, 2 ** 31 - 1)
+    if cfg["model"]["learning_task"] != "LINK_PREDICTION":
+        raise NotImplementedError("only LINK_PREDICTION is in scope (SURVEY.md §8)")
+    layers = cfg["model"]["encoder"]["layers"]
+    if len(layers) != 1 or len(layers[0]) != 1 or layers[0][0]["type"] != "EMBEDDING":
+        raise NotImplementedError("only the embedding-only encoder is on the link-prediction hot path")
+    if cfg["training"]["negative_sampling"]["filtered"] or cfg["evaluation"]["negative_sampling"]["filtered"]:
+        # config.cpp:365-376: filtered forces num_chunks=1, negatives=-1 (all nodes)
+        warnings.warn("filtered negative sampling: evaluation scores against all nodes; the global true-edge filter is a 'next' row")
+    if not cfg["training"]["pipeline"].get("sync", True):
+        warnings.warn("async pipeline is out of scope; running the synchronous trainer")
+    if cfg["storage"]["model_dir"] is None:
+        i = 0
+        while os.path.exists(os.path.join(ddir, "model_%d" % i)):
+            i += 1
+        cfg["storage"]["model_dir"] = os.path.join(ddir, "model_%d" % i)
+    return cfg
+
+
+def embedding_dim(cfg):
+    return int(cfg["model"]["encoder"]["layers"][0][0]["output_dim"])

@@ -1,0 +1,195 @@
+// pybind11 module `_marius_host`: the C++ host classes (marius_host.h) for Python drivers / tests.
+// Mirrors the parts of the reference's python_bindings (src/cpp/python_bindings) that sit on the link-prediction path.
+#include <torch/extension.h>
+
+#include "marius_host.h"
+
+namespace py = pybind11;
+using namespace marius_amd;
+
+PYBIND11_MODULE(_marius_host, m) {
+    m.doc() = "MI355X-native host layer of the Marius link-prediction hot path (C++ on libtorch, kernels via libmarius_hip.so)";
+    py::register_exception<MariusRuntimeException>(m, "MariusRuntimeException");
+
+    py::enum_<LossReduction>(m, "LossReduction").value("MEAN", LossReduction::MEAN).value("SUM", LossReduction::SUM);
+    py::enum_<EdgeDecoderMethod>(m, "EdgeDecoderMethod")
+        .value("ONLY_POS", EdgeDecoderMethod::ONLY_POS)
+        .value("POS_AND_NEG", EdgeDecoderMethod::POS_AND_NEG)
+        .value("CORRUPT_NODE", EdgeDecoderMethod::CORRUPT_NODE)
+        .value("CORRUPT_REL", EdgeDecoderMethod::CORRUPT_REL);
+    py::enum_<LocalFilterMode>(m, "LocalFilterMode").value("ALL", LocalFilterMode::ALL).value("DEG", LocalFilterMode::DEG);
+    py::enum_<DecoderType>(m, "DecoderType").value("DISTMULT", DecoderType::DISTMULT).value("TRANSE", DecoderType::TRANSE).value("COMPLEX", DecoderType::COMPLEX);
+
+    py::class_<MariusGenerator, std::shared_ptr<MariusGenerator>>(m, "MariusGenerator")
+        .def(py::init<uint64_t>(), py::arg("seed"))
+        .def("randperm", &MariusGenerator::randperm)
+        .def("raw_words", [](MariusGenerator& g, int64_t n, torch::Device d) { return g.raw_words(n, d); })
+        .def("to_host", &MariusGenerator::to_host)
+        .def_readwrite("state_host", &MariusGenerator::state_host_);
+
+    py::class_<InMemory, std::shared_ptr<InMemory>>(m, "InMemory")
+        .def(py::init<torch::Tensor>(), py::arg("data"))
+        .def(py::init([](std::string filename, int64_t dim0, int64_t dim1, py::object dtype, torch::Device device) {
+                 return std::make_shared<InMemory>(filename, dim0, dim1, torch::python::detail::py_object_to_dtype(dtype), device);
+             }),
+             py::arg("filename"), py::arg("dim0_size"), py::arg("dim1_size"), py::arg("dtype"), py::arg("device"))
+        .def("indexRead", &InMemory::indexRead)
+        .def("indexAdd", &InMemory::indexAdd)
+        .def("range", &InMemory::range)
+        .def("indexPut", &InMemory::indexPut)
+        .def("rangePut", &InMemory::rangePut)
+        .def("load", &InMemory::load)
+        .def("write", &InMemory::write)
+        .def("unload", &InMemory::unload, py::arg("perform_write") = false)
+        .def_readwrite("data", &InMemory::data_)
+        .def_readwrite("dim0_size", &InMemory::dim0_size_)
+        .def_readwrite("dim1_size", &InMemory::dim1_size_)
+        .def_readwrite("filename", &InMemory::filename_);
+
+    py::class_<MariusGraph, std::shared_ptr<MariusGraph>>(m, "MariusGraph")
+        .def(py::init([](int64_t n) {
+                 auto g = std::make_shared<MariusGraph>();
+                 g->num_nodes_in_memory_ = n;
+                 return g;
+             }),
+             py::arg("num_nodes_in_memory"))
+        .def_readwrite("num_nodes_in_memory", &MariusGraph::num_nodes_in_memory_);
+
+    py::class_<CorruptNodeNegativeSampler, std::shared_ptr<CorruptNodeNegativeSampler>>(m, "CorruptNodeNegativeSampler")
+        .def(py::init<int, int, float, bool, LocalFilterMode, std::shared_ptr<MariusGenerator>>(), py::arg("num_chunks") = 1, py::arg("num_negatives") = 500,
+             py::arg("degree_fraction") = 0.0f, py::arg("filtered") = false, py::arg("local_filter_mode") = LocalFilterMode::DEG,
+             py::arg("generator") = nullptr)
+        .def("getNegatives", &CorruptNodeNegativeSampler::getNegatives, py::arg("graph"), py::arg("edges"), py::arg("inverse") = false)
+        .def_readwrite("num_chunks", &CorruptNodeNegativeSampler::num_chunks_)
+        .def_readwrite("num_negatives", &CorruptNodeNegativeSampler::num_negatives_)
+        .def_readwrite("degree_fraction", &CorruptNodeNegativeSampler::degree_fraction_)
+        .def_readwrite("generator", &CorruptNodeNegativeSampler::generator_);
+
+    py::class_<Batch, std::shared_ptr<Batch>>(m, "Batch")
+        .def(py::init<bool>(), py::arg("train"))
+        .def_readwrite("train", &Batch::train_)
+        .def_readwrite("batch_id", &Batch::batch_id_)
+        .def_readwrite("edges", &Batch::edges_)
+        .def_readwrite("unique_node_indices", &Batch::unique_node_indices_)
+        .def_readwrite("node_embeddings", &Batch::node_embeddings_)
+        .def_readwrite("node_embeddings_state", &Batch::node_embeddings_state_)
+        .def_readwrite("node_embeddings_grad", &Batch::node_embeddings_grad_)
+        .def_readwrite("node_gradients", &Batch::node_gradients_)
+        .def_readwrite("node_state_update", &Batch::node_state_update_)
+        .def_readwrite("src_neg_indices", &Batch::src_neg_indices_)
+        .def_readwrite("dst_neg_indices", &Batch::dst_neg_indices_)
+        .def_readwrite("src_neg_indices_mapping", &Batch::src_neg_indices_mapping_)
+        .def_readwrite("dst_neg_indices_mapping", &Batch::dst_neg_indices_mapping_)
+        .def_readwrite("src_neg_filter", &Batch::src_neg_filter_)
+        .def_readwrite("dst_neg_filter", &Batch::dst_neg_filter_)
+        .def_readwrite("occ_perm", &Batch::occ_perm_)
+        .def_readwrite("occ_inverse", &Batch::occ_inverse_)
+        .def_readwrite("occ_seg_offsets", &Batch::occ_seg_offsets_)
+        .def("accumulateGradients", &Batch::accumulateGradients, py::arg("learning_rate"))
+        .def("clear", &Batch::clear);
+
+    py::class_<RelationOperator, std::shared_ptr<RelationOperator>>(m, "RelationOperator")
+        .def("__call__", [](RelationOperator& op, torch::Tensor e, torch::Tensor r) { return op(e, r); });
+    py::class_<HadamardOperator, RelationOperator, std::shared_ptr<HadamardOperator>>(m, "HadamardOperator").def(py::init<>());
+    py::class_<ComplexHadamardOperator, RelationOperator, std::shared_ptr<ComplexHadamardOperator>>(m, "ComplexHadamardOperator").def(py::init<>());
+    py::class_<TranslationOperator, RelationOperator, std::shared_ptr<TranslationOperator>>(m, "TranslationOperator").def(py::init<>());
+    py::class_<Comparator, std::shared_ptr<Comparator>>(m, "Comparator").def("__call__", [](Comparator& c, torch::Tensor s, torch::Tensor d) { return c(s, d); });
+    py::class_<DotCompare, Comparator, std::shared_ptr<DotCompare>>(m, "DotCompare").def(py::init<>());
+    py::class_<L2Compare, Comparator, std::shared_ptr<L2Compare>>(m, "L2Compare").def(py::init<>());
+    py::class_<CosineCompare, Comparator, std::shared_ptr<CosineCompare>>(m, "CosineCompare").def(py::init<>());
+
+    py::class_<EdgeDecoder, std::shared_ptr<EdgeDecoder>>(m, "EdgeDecoder")
+        .def_readwrite("relations", &EdgeDecoder::relations_)
+        .def_readwrite("inverse_relations", &EdgeDecoder::inverse_relations_)
+        .def_readwrite("comparator", &EdgeDecoder::comparator_)
+        .def_readwrite("relation_operator", &EdgeDecoder::relation_operator_)
+        .def_readwrite("use_inverse_relations", &EdgeDecoder::use_inverse_relations_)
+        .def_readwrite("decoder_method", &EdgeDecoder::decoder_method_)
+        .def_readonly("num_relations", &EdgeDecoder::num_relations_)
+        .def_readonly("embedding_size", &EdgeDecoder::embedding_size_)
+        .def("apply_relation", &EdgeDecoder::apply_relation)
+        .def("compute_scores", &EdgeDecoder::compute_scores)
+        .def("select_relations", &EdgeDecoder::select_relations, py::arg("indices"), py::arg("inverse") = false)
+        .def("reset", &EdgeDecoder::reset);
+    auto dec_init = [](auto tag) {
+        using T = decltype(tag);
+        return py::init([](int num_relations, int embedding_dim, torch::Device device, bool use_inverse_relations, EdgeDecoderMethod method) {
+            return std::make_shared<T>(num_relations, embedding_dim, torch::TensorOptions().dtype(torch::kFloat32).device(device), use_inverse_relations, method);
+        });
+    };
+    (void)dec_init;
+#define MARIUS_DECODER(NAME)                                                                                                                       \
+    py::class_<NAME, EdgeDecoder, std::shared_ptr<NAME>>(m, #NAME)                                                                                 \
+        .def(py::init([](int num_relations, int embedding_dim, torch::Device device, bool use_inverse_relations, EdgeDecoderMethod method) {       \
+                 return std::make_shared<NAME>(num_relations, embedding_dim, torch::TensorOptions().dtype(torch::kFloat32).device(device),        \
+                                               use_inverse_relations, method);                                                                     \
+             }),                                                                                                                                   \
+             py::arg("num_relations"), py::arg("embedding_dim"), py::arg("device"), py::arg("use_inverse_relations") = true,                       \
+             py::arg("decoder_method") = EdgeDecoderMethod::CORRUPT_NODE)
+    MARIUS_DECODER(DistMult);
+    MARIUS_DECODER(ComplEx);
+    MARIUS_DECODER(TransE);
+#undef MARIUS_DECODER
+
+    m.def("only_pos_forward", &only_pos_forward, py::arg("decoder"), py::arg("edges"), py::arg("node_embeddings"));
+    m.def("node_corrupt_forward",
+          [](std::shared_ptr<EdgeDecoder> dec, torch::Tensor edges, torch::Tensor emb, torch::Tensor dst_negs, std::optional<torch::Tensor> src_negs) {
+              return node_corrupt_forward(dec, edges, emb, dst_negs, src_negs.has_value() ? *src_negs : torch::Tensor(), nullptr);
+          },
+          py::arg("decoder"), py::arg("positive_edges"), py::arg("node_embeddings"), py::arg("dst_negs"), py::arg("src_negs") = py::none());
+
+    py::class_<LossFunction, std::shared_ptr<LossFunction>>(m, "LossFunction")
+        .def("__call__", [](LossFunction& l, torch::Tensor a, torch::Tensor b, bool scores) { return l(a, b, scores); }, py::arg("y_pred"),
+             py::arg("targets"), py::arg("scores") = true);
+    py::class_<SoftmaxCrossEntropy, LossFunction, std::shared_ptr<SoftmaxCrossEntropy>>(m, "SoftmaxCrossEntropy")
+        .def(py::init([](std::string reduction) {
+                 return std::make_shared<SoftmaxCrossEntropy>(reduction == "mean" || reduction == "MEAN" ? LossReduction::MEAN : LossReduction::SUM);
+             }),
+             py::arg("reduction") = "sum");
+
+    py::class_<LinkPredictionReporter, std::shared_ptr<LinkPredictionReporter>>(m, "LinkPredictionReporter")
+        .def(py::init<>())
+        .def("computeRanks", &LinkPredictionReporter::computeRanks)
+        .def("addResult", &LinkPredictionReporter::addResult)
+        .def("clear", &LinkPredictionReporter::clear)
+        .def("report", &LinkPredictionReporter::report);
+
+    py::class_<Model, std::shared_ptr<Model>>(m, "Model")
+        .def(py::init<std::shared_ptr<EdgeDecoder>, std::shared_ptr<LossFunction>, std::shared_ptr<LinkPredictionReporter>, torch::Device>(),
+             py::arg("decoder"), py::arg("loss"), py::arg("reporter"), py::arg("device"))
+        .def("forward_lp", &Model::forward_lp, py::arg("batch"), py::arg("train") = true)
+        .def("train_batch", &Model::train_batch, py::arg("batch"), py::arg("call_step") = true)
+        .def("evaluate_batch", &Model::evaluate_batch)
+        .def("setup_optimizers", &Model::setup_optimizers, py::arg("dense_lr"))
+        .def("step", &Model::step)
+        .def("clear_grad", &Model::clear_grad)
+        .def_readwrite("sparse_lr", &Model::sparse_lr_)
+        .def_readwrite("decoder", &Model::decoder_)
+        .def_readwrite("reporter", &Model::reporter_)
+        .def_readonly("loss", &Model::loss_)
+        .def_readonly("relations_grad", &Model::relations_grad_)
+        .def_readonly("inverse_relations_grad", &Model::inverse_relations_grad_);
+
+    py::class_<DataLoader, std::shared_ptr<DataLoader>>(m, "DataLoader")
+        .def(py::init<std::shared_ptr<InMemory>, std::shared_ptr<InMemory>, std::shared_ptr<InMemory>, std::shared_ptr<CorruptNodeNegativeSampler>,
+                      std::shared_ptr<MariusGenerator>, int64_t, bool>(),
+             py::arg("edges"), py::arg("node_embeddings"), py::arg("node_embeddings_state"), py::arg("negative_sampler"), py::arg("generator"),
+             py::arg("batch_size"), py::arg("train") = true)
+        .def("initializeBatches", &DataLoader::initializeBatches, py::arg("shuffle") = true)
+        .def("hasNextBatch", &DataLoader::hasNextBatch)
+        .def("getBatch", &DataLoader::getBatch, py::arg("exact_unique") = true)
+        .def("loadGPUParameters", &DataLoader::loadGPUParameters)
+        .def("updateEmbeddings", &DataLoader::updateEmbeddings, py::arg("batch"), py::arg("gpu") = true)
+        .def("getNumEdges", &DataLoader::getNumEdges)
+        .def_readonly("active_perm", &DataLoader::active_perm_);
+
+    py::class_<SynchronousTrainer, std::shared_ptr<SynchronousTrainer>>(m, "SynchronousTrainer")
+        .def(py::init<std::shared_ptr<DataLoader>, std::shared_ptr<Model>>())
+        .def("train", &SynchronousTrainer::train, py::arg("num_epochs") = 1, py::call_guard<py::gil_scoped_release>())
+        .def_readwrite("fused_update", &SynchronousTrainer::fused_update_)
+        .def_readonly("last_epoch_seconds", &SynchronousTrainer::last_epoch_seconds_)
+        .def_readonly("last_edges_per_second", &SynchronousTrainer::last_edges_per_second_);
+    py::class_<SynchronousEvaluator, std::shared_ptr<SynchronousEvaluator>>(m, "SynchronousEvaluator")
+        .def(py::init<std::shared_ptr<DataLoader>, std::shared_ptr<Model>>())
+        .def("evaluate", &SynchronousEvaluator::evaluate);
+}

@@ -1,0 +1,684 @@
+// Implementation of the host layer (see marius_host.h).  Every device operation is a call into libmarius_hip.so.
+#include "marius_host.h"
+
+#include <c10/hip/HIPStream.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+
+namespace marius_amd {
+
+// ------------------------------------------------------------------------------------------------ helpers
+std::string TensorSizeMismatchException::describe(const Tensor& t, const std::string& msg) {
+    std::stringstream ss;
+    ss << "Tensor size mismatch. Size: " << (t.defined() ? t.sizes() : at::IntArrayRef{}) << " " << msg;
+    return ss.str();
+}
+
+void mcheck(int rc) {
+    if (rc != MARIUS_OK) throw MariusRuntimeException(std::string("libmarius_hip: ") + marius_hip_last_error());
+}
+
+marius_stream_t cur_stream() { return (marius_stream_t)c10::hip::getCurrentHIPStream().stream(); }
+
+void require_device(const Tensor& t, const char* what) {
+    if (!t.defined()) throw UndefinedTensorException();
+    if (!t.is_cuda()) throw MariusRuntimeException(std::string(what) + ": tensor must live on the MI355X (no CPU fallback)");
+}
+
+static inline float* fp(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+static inline int64_t* ip(const Tensor& t) { return t.defined() ? t.data_ptr<int64_t>() : nullptr; }
+static inline int key_bits_for(int64_t n) {
+    int b = 1;
+    while ((1ll << b) <= n && b < 63) ++b;
+    return b;
+}
+static torch::TensorOptions i64(torch::Device d) { return torch::TensorOptions().dtype(torch::kInt64).device(d); }
+static torch::TensorOptions i32(torch::Device d) { return torch::TensorOptions().dtype(torch::kInt32).device(d); }
+static torch::TensorOptions f32(torch::Device d) { return torch::TensorOptions().dtype(torch::kFloat32).device(d); }
+
+// ------------------------------------------------------------------------------------------------ generator
+MariusGenerator::MariusGenerator(uint64_t seed) {
+    state_host_ = torch::zeros({MARIUS_MT_STATE_WORDS}, torch::kInt32);
+    marius_mt19937_seed_host((uint32_t*)state_host_.data_ptr<int32_t>(), seed);
+}
+void MariusGenerator::to_host() {
+    if (state_dev_.defined()) {
+        state_host_ = state_dev_.cpu();
+        state_dev_ = Tensor();
+    }
+}
+void MariusGenerator::to_device(torch::Device dev) {
+    if (!state_dev_.defined()) state_dev_ = state_host_.to(dev);
+}
+Tensor MariusGenerator::randperm(int64_t n) {
+    to_host();
+    Tensor out = torch::empty({n}, torch::kInt64);
+    mcheck(marius_mt19937_randperm_host((uint32_t*)state_host_.data_ptr<int32_t>(), out.data_ptr<int64_t>(), n));
+    return out;
+}
+Tensor MariusGenerator::raw_words(int64_t n, torch::Device dev) {
+    to_device(dev);
+    Tensor out = torch::empty({n}, i32(dev));
+    mcheck(marius_mt19937_fill((uint32_t*)state_dev_.data_ptr<int32_t>(), (uint32_t*)out.data_ptr<int32_t>(), n, cur_stream()));
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------ storage
+InMemory::InMemory(std::string filename, int64_t dim0_size, int64_t dim1_size, torch::Dtype dtype, torch::Device device) {
+    filename_ = std::move(filename);
+    dim0_size_ = dim0_size;
+    dim1_size_ = dim1_size;
+    dtype_ = dtype;
+    device_ = device;
+}
+InMemory::InMemory(Tensor data) {
+    require_device(data, "InMemory");
+    data_ = data;
+    dim0_size_ = data.size(0);
+    dim1_size_ = data.dim() > 1 ? data.size(1) : 1;
+    dtype_ = data.scalar_type();
+    device_ = data.device();
+    loaded_ = true;
+}
+void InMemory::load() {  // storage.cpp:547-573: pread the raw row-major file, then .to(device)
+    if (loaded_) return;
+    Tensor host = torch::empty({dim0_size_, dim1_size_}, torch::TensorOptions().dtype(dtype_));
+    std::ifstream f(filename_, std::ios::binary);
+    if (!f) throw std::runtime_error("");  // storage.cpp:179-201 behaviour: bare runtime_error after logging
+    f.read(reinterpret_cast<char*>(host.data_ptr()), (std::streamsize)host.nbytes());
+    if (!f) throw std::runtime_error("");
+    data_ = host.to(device_);
+    loaded_ = true;
+}
+void InMemory::write() {
+    if (!loaded_ || filename_.empty()) return;
+    Tensor host = data_.cpu().contiguous();
+    std::ofstream f(filename_, std::ios::binary | std::ios::trunc);
+    if (!f) throw std::runtime_error("");
+    f.write(reinterpret_cast<const char*>(host.data_ptr()), (std::streamsize)host.nbytes());
+}
+void InMemory::unload(bool perform_write) {
+    if (perform_write) write();
+    data_ = Tensor();
+    loaded_ = false;
+}
+Tensor InMemory::indexRead(Tensor indices) {  // storage.cpp:606-649
+    if (indices.sizes().size() != 1) throw std::runtime_error("");
+    require_device(data_, "indexRead");
+    require_device(indices, "indexRead");
+    if (dtype_ != torch::kFloat32) return data_.index_select(0, indices);  // edge lists: not on the float path
+    Tensor out = torch::empty({indices.size(0), dim1_size_}, data_.options());
+    mcheck(marius_gather_rows(fp(data_), data_.stride(0), ip(indices), indices.size(0), (int32_t)dim1_size_, fp(out), out.stride(0), cur_stream()));
+    return out;
+}
+void InMemory::indexAdd(Tensor indices, Tensor values) {  // storage.cpp:651-673 (ids unique)
+    if (!values.defined() || indices.sizes().size() != 1 || values.size(0) != indices.size(0) || data_.dim() != values.dim())
+        throw std::runtime_error("");
+    require_device(data_, "indexAdd");
+    mcheck(marius_scatter_add_rows(fp(data_), data_.stride(0), ip(indices), indices.size(0), (int32_t)dim1_size_, fp(values), values.stride(0),
+                                   cur_stream()));
+}
+Tensor InMemory::range(int64_t offset, int64_t n) {
+    if (!data_.defined()) throw std::runtime_error("");
+    return data_.narrow(0, offset, n);
+}
+void InMemory::indexPut(Tensor indices, Tensor values) { data_.index_copy_(0, indices, values); }
+void InMemory::rangePut(int64_t offset, Tensor values) { data_.narrow(0, offset, values.size(0)).copy_(values); }
+
+// ------------------------------------------------------------------------------------------------ negative sampler
+CorruptNodeNegativeSampler::CorruptNodeNegativeSampler(int num_chunks, int num_negatives, float degree_fraction, bool filtered,
+                                                       LocalFilterMode local_filter_mode, shared_ptr<MariusGenerator> generator)
+    : num_chunks_(num_chunks), num_negatives_(num_negatives), degree_fraction_(degree_fraction), filtered_(filtered),
+      local_filter_mode_(local_filter_mode), generator_(generator) {
+    if (filtered_) {  // negative.cpp:321-325
+        num_chunks_ = 1;
+        num_negatives_ = -1;
+        degree_fraction_ = 0.0;
+    }
+    if (!generator_) generator_ = std::make_shared<MariusGenerator>(0);
+}
+
+std::tuple<Tensor, Tensor> CorruptNodeNegativeSampler::getNegatives(shared_ptr<MariusGraph> graph, Tensor edges, bool inverse) {
+    require_device(edges, "getNegatives");
+    auto dev = edges.device();
+    const int64_t num_nodes = graph->num_nodes_in_memory_;
+    if (num_negatives_ == -1) {  // filtered evaluation: all nodes (negative.cpp:354-356); global filter construction is the "next" row
+        Tensor ids = torch::arange(num_nodes, i64(dev)).unsqueeze(0);
+        return std::forward_as_tuple(ids, torch::empty({0, 2}, i64(dev)));
+    }
+    const int n_deg = (int)(num_negatives_ * degree_fraction_);
+    const int64_t B = edges.size(0);
+    const int64_t words = marius_negatives_raw_words(num_nodes, B, num_chunks_, num_negatives_, n_deg);
+    Tensor raw = generator_->raw_words(words, dev);
+    Tensor ids = torch::empty({num_chunks_, num_negatives_}, i64(dev));
+    Tensor deg = n_deg > 0 ? torch::empty({num_chunks_, n_deg}, i64(dev)) : Tensor();
+    mcheck(marius_sample_negatives((const uint32_t*)raw.data_ptr<int32_t>(), ip(edges), B, (int32_t)edges.size(1), inverse ? 1 : 0, num_nodes,
+                                   num_chunks_, num_negatives_, n_deg, ip(ids), ip(deg), cur_stream()));
+    Tensor filter = torch::empty({0, 2}, i64(dev));
+    if (n_deg > 0 && local_filter_mode_ == LocalFilterMode::DEG) {
+        filter = torch::empty({(int64_t)num_chunks_ * n_deg, 2}, i64(dev));
+        mcheck(marius_deg_filter(ip(deg), num_chunks_, n_deg, B, ip(filter), cur_stream()));
+        if (compact_filter_) filter = filter.index({filter.select(1, 0) >= 0});  // the reference's tensor, in its nonzero() order
+    } else if (n_deg > 0) {
+        throw MariusRuntimeException("Local filtering against all edges in the batch not yet supported on GPU.");  // negative.cpp:301
+    }
+    return std::forward_as_tuple(ids, filter);
+}
+
+// ------------------------------------------------------------------------------------------------ batch
+void Batch::accumulateGradients(float learning_rate) {
+    if (node_embeddings_.defined()) {
+        if (!node_embeddings_grad_.defined()) throw UndefinedTensorException();
+        node_gradients_ = torch::empty_like(node_embeddings_grad_);
+        node_state_update_ = torch::empty_like(node_embeddings_grad_);
+        mcheck(marius_adagrad_rule(fp(node_embeddings_grad_), fp(node_embeddings_state_), fp(node_gradients_), fp(node_state_update_),
+                                   node_embeddings_grad_.numel(), learning_rate, 1e-10f, cur_stream()));
+    }
+    node_embeddings_state_ = Tensor();
+}
+void Batch::clear() {
+    unique_node_indices_ = node_embeddings_ = node_embeddings_grad_ = node_gradients_ = node_state_update_ = node_embeddings_state_ = Tensor();
+    edges_ = src_neg_indices_ = dst_neg_indices_ = src_neg_indices_mapping_ = dst_neg_indices_mapping_ = Tensor();
+    src_neg_filter_ = dst_neg_filter_ = occ_perm_ = occ_inverse_ = occ_seg_offsets_ = num_unique_dev_ = Tensor();
+}
+
+// ------------------------------------------------------------------------------------------------ LP context / fused decoder calls
+Tensor LpContext::view(size_t off, std::vector<int64_t> shape, std::vector<int64_t> strides) const {
+    int64_t n = 1;
+    if (strides.empty()) {
+        for (auto s : shape) n *= s;
+        return workspace.narrow(0, (int64_t)off, n * 4).view(torch::kFloat32).view(shape);
+    }
+    int64_t span = 1;
+    for (size_t i = 0; i < shape.size(); ++i) span += (shape[i] - 1) * strides[i];
+    return workspace.narrow(0, (int64_t)off, span * 4).view(torch::kFloat32).as_strided(shape, strides);
+}
+
+static void lp_setup(LpContext& ctx, shared_ptr<EdgeDecoder> dec, const Tensor& edges, const Tensor& emb, const Tensor& dst_negs, const Tensor& src_negs,
+                     const Tensor& dst_filter, const Tensor& src_filter, LossReduction reduction) {
+    require_device(emb, "forward_lp");
+    require_device(edges, "forward_lp");
+    if (edges.dim() != 2 || (edges.size(1) != 3 && edges.size(1) != 2))
+        throw TensorSizeMismatchException(edges, "Edge list must be a 3 or 2 column tensor");
+    marius_lp_desc& d = ctx.desc;
+    d = marius_lp_desc{};
+    const bool has_rel = edges.size(1) == 3;
+    d.relop = has_rel ? dec->relation_operator_->kind() : MARIUS_OP_NOOP;
+    d.cmp = dec->comparator_->kind();
+    d.d = (int32_t)emb.size(1);
+    d.edge_cols = (int32_t)edges.size(1);
+    d.B = edges.size(0);
+    d.C = (int32_t)dst_negs.size(0);
+    d.N = (int32_t)dst_negs.size(1);
+    d.use_inverse = (has_rel && dec->use_inverse_relations_ && dec->inverse_relations_.defined() && src_negs.defined()) ? 1 : 0;
+    d.reduction = reduction == LossReduction::MEAN ? MARIUS_REDUCE_MEAN : MARIUS_REDUCE_SUM;
+    Tensor e = edges.contiguous(), dn = dst_negs.contiguous(), sn = src_negs.defined() ? src_negs.contiguous() : Tensor();
+    d.emb = fp(emb);
+    d.emb_ld = emb.stride(0);
+    d.U = emb.size(0);
+    d.edges = ip(e);
+    d.dst_neg = ip(dn);
+    d.src_neg = ip(sn);
+    d.rel = has_rel ? fp(dec->relations_) : nullptr;
+    d.inv_rel = d.use_inverse ? fp(dec->inverse_relations_) : nullptr;
+    d.rel_ld = has_rel ? dec->relations_.stride(0) : 0;
+    d.R = has_rel ? dec->relations_.size(0) : 0;
+    Tensor df = (dst_filter.defined() && dst_filter.numel() > 0) ? dst_filter.contiguous() : Tensor();
+    Tensor sf = (src_filter.defined() && src_filter.numel() > 0) ? src_filter.contiguous() : Tensor();
+    d.dst_filter = ip(df);
+    d.n_dst_filter = df.defined() ? df.size(0) : 0;
+    d.src_filter = ip(sf);
+    d.n_src_filter = sf.defined() ? sf.size(0) : 0;
+    ctx.keep = {emb, e, dn, sn, df, sf};
+    mcheck(marius_lp_plan(&d, &ctx.layout));
+    if (!ctx.workspace.defined() || (size_t)ctx.workspace.numel() < ctx.layout.total_bytes || ctx.workspace.device() != emb.device())
+        ctx.workspace = torch::empty({(int64_t)ctx.layout.total_bytes}, torch::TensorOptions().dtype(torch::kUInt8).device(emb.device()));
+    ctx.has_loss = false;
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> node_corrupt_forward(shared_ptr<EdgeDecoder> decoder, Tensor positive_edges, Tensor node_embeddings,
+                                                                Tensor dst_negs, Tensor src_negs, LpContext* ctx, Tensor dst_filter, Tensor src_filter,
+                                                                LossReduction reduction) {
+    LpContext local;
+    LpContext& c = ctx ? *ctx : local;
+    lp_setup(c, decoder, positive_edges, node_embeddings, dst_negs, src_negs, dst_filter, src_filter, reduction);
+    mcheck(marius_lp_forward(&c.desc, &c.layout, c.workspace.data_ptr(), cur_stream()));
+    const int64_t Bp = c.layout.Bp, N = c.desc.N, nld = c.layout.n_ld;
+    Tensor pos = c.view(c.layout.pos[0], {Bp});
+    Tensor neg = c.view(c.layout.neg[0], {Bp, N}, {nld, 1});
+    Tensor inv_pos, inv_neg;
+    if (c.desc.use_inverse) {
+        inv_pos = c.view(c.layout.pos[1], {Bp});
+        inv_neg = c.view(c.layout.neg[1], {Bp, N}, {nld, 1});
+    }
+    if (!ctx) {  // the workspace dies with `local`: hand out owning copies
+        pos = pos.clone();
+        neg = neg.clone();
+        if (inv_pos.defined()) {
+            inv_pos = inv_pos.clone();
+            inv_neg = inv_neg.clone();
+        }
+    }
+    return std::forward_as_tuple(pos, neg, inv_pos, inv_neg);
+}
+
+std::tuple<Tensor, Tensor> only_pos_forward(shared_ptr<EdgeDecoder> decoder, Tensor edges, Tensor node_embeddings) {
+    // decoder_methods.cpp:7-42: same positive-score path; run the fused forward with one dummy negative per direction
+    auto dev = node_embeddings.device();
+    Tensor dummy = torch::zeros({1, 1}, i64(dev));
+    auto t = node_corrupt_forward(decoder, edges, node_embeddings, dummy, dummy, nullptr);
+    const int64_t B = edges.size(0);
+    Tensor pos = std::get<0>(t).narrow(0, 0, B);
+    Tensor inv = std::get<2>(t);
+    if (inv.defined()) inv = inv.narrow(0, 0, B);
+    return std::forward_as_tuple(pos, inv);
+}
+
+// API-level operator calls (not on the fused training path): expressed through the same fused forward so that they, too, run on
+// the HIP kernels only.
+Tensor RelationOperator::operator()(const Tensor& embs, const Tensor& rels) {
+    if (!rels.defined()) return embs;
+    require_device(embs, "RelationOperator");
+    const int64_t B = embs.size(0);
+    auto dev = embs.device();
+    struct D : EdgeDecoder { void reset() override {} };
+    auto dec = std::make_shared<D>();
+    dec->relation_operator_ = nullptr;
+    dec->comparator_ = std::make_shared<DotCompare>();
+    dec->relations_ = rels.contiguous();
+    dec->use_inverse_relations_ = false;
+    struct Op : RelationOperator { int k; int kind() const override { return k; } };
+    auto op = std::make_shared<Op>();
+    op->k = kind();
+    dec->relation_operator_ = op;
+    Tensor idx = torch::arange(B, i64(dev));
+    Tensor edges = torch::stack({idx, idx, idx}, 1);
+    Tensor dummy = torch::zeros({1, 1}, i64(dev));
+    LpContext ctx;
+    node_corrupt_forward(dec, edges, embs.contiguous(), dummy, Tensor(), &ctx);
+    return ctx.view(ctx.layout.adj[0], {B, embs.size(1)}, {ctx.layout.d_ld, 1}).clone();
+}
+
+Tensor Comparator::operator()(Tensor src, Tensor dst) {
+    if (!src.defined() || !dst.defined()) throw UndefinedTensorException();  // comparators.cpp:23-25
+    require_device(src, "Comparator");
+    auto dev = src.device();
+    struct D : EdgeDecoder { void reset() override {} };
+    auto dec = std::make_shared<D>();
+    dec->relation_operator_ = std::make_shared<NoOp>();
+    struct Cmp : Comparator { int k; int kind() const override { return k; } };
+    auto cmp = std::make_shared<Cmp>();
+    cmp->k = kind();
+    dec->comparator_ = cmp;
+    dec->use_inverse_relations_ = false;
+    const int64_t B = src.size(0);
+    Tensor idx = torch::arange(B, i64(dev));
+    if (src.sizes() == dst.sizes()) {
+        Tensor emb = torch::cat({src, dst}, 0).contiguous();
+        Tensor edges = torch::stack({idx, idx + B}, 1);
+        Tensor dummy = torch::zeros({1, 1}, i64(dev));
+        auto t = node_corrupt_forward(dec, edges, emb, dummy, Tensor(), nullptr);
+        return std::get<0>(t).narrow(0, 0, B);
+    }
+    const int64_t C = dst.size(0), N = dst.size(1);
+    Tensor emb = torch::cat({src, dst.reshape({C * N, dst.size(2)})}, 0).contiguous();
+    Tensor edges = torch::stack({idx, idx}, 1);
+    Tensor negs = (torch::arange(C * N, i64(dev)) + B).reshape({C, N});
+    auto t = node_corrupt_forward(dec, edges, emb, negs, Tensor(), nullptr);
+    return std::get<1>(t);
+}
+
+// ------------------------------------------------------------------------------------------------ edge decoders
+Tensor EdgeDecoder::apply_relation(Tensor nodes, Tensor relations) { return (*relation_operator_)(nodes, relations); }
+Tensor EdgeDecoder::compute_scores(Tensor src, Tensor dst) { return (*comparator_)(src, dst); }
+Tensor EdgeDecoder::select_relations(Tensor indices, bool inverse) {  // edge_decoder.cpp:11-20
+    Tensor& table = inverse ? inverse_relations_ : relations_;
+    if (!table.defined()) throw UndefinedTensorException();
+    Tensor out = torch::empty({indices.size(0), table.size(1)}, table.options());
+    mcheck(marius_gather_rows(fp(table), table.stride(0), ip(indices), indices.size(0), (int32_t)table.size(1), fp(out), out.stride(0), cur_stream()));
+    return out;
+}
+static void init_decoder(EdgeDecoder* d, int num_relations, int dim, torch::TensorOptions opts, bool inv, EdgeDecoderMethod m) {
+    d->num_relations_ = num_relations;
+    d->embedding_size_ = dim;
+    d->tensor_options_ = opts;
+    d->use_inverse_relations_ = inv;
+    d->decoder_method_ = m;
+}
+DistMult::DistMult(int num_relations, int embedding_dim, torch::TensorOptions o, bool inv, EdgeDecoderMethod m) {
+    comparator_ = std::make_shared<DotCompare>();
+    relation_operator_ = std::make_shared<HadamardOperator>();
+    init_decoder(this, num_relations, embedding_dim, o, inv, m);
+    reset();
+}
+void DistMult::reset() {  // distmult.cpp:21-27
+    relations_ = torch::ones({num_relations_, embedding_size_}, tensor_options_);
+    if (use_inverse_relations_) inverse_relations_ = torch::ones({num_relations_, embedding_size_}, tensor_options_);
+}
+ComplEx::ComplEx(int num_relations, int embedding_dim, torch::TensorOptions o, bool inv, EdgeDecoderMethod m) {
+    comparator_ = std::make_shared<DotCompare>();
+    relation_operator_ = std::make_shared<ComplexHadamardOperator>();
+    init_decoder(this, num_relations, embedding_dim, o, inv, m);
+    reset();
+}
+void ComplEx::reset() {  // complex.cpp:21-29
+    relations_ = torch::zeros({num_relations_, embedding_size_}, tensor_options_);
+    relations_.narrow(1, 0, embedding_size_ / 2).fill_(1);
+    if (use_inverse_relations_) {
+        inverse_relations_ = torch::zeros({num_relations_, embedding_size_}, tensor_options_);
+        inverse_relations_.narrow(1, 0, embedding_size_ / 2).fill_(1);
+    }
+}
+TransE::TransE(int num_relations, int embedding_dim, torch::TensorOptions o, bool inv, EdgeDecoderMethod m) {
+    comparator_ = std::make_shared<L2Compare>();
+    relation_operator_ = std::make_shared<TranslationOperator>();
+    init_decoder(this, num_relations, embedding_dim, o, inv, m);
+    reset();
+}
+void TransE::reset() {  // transe.cpp:21-28
+    relations_ = torch::zeros({num_relations_, embedding_size_}, tensor_options_);
+    if (use_inverse_relations_) inverse_relations_ = torch::zeros({num_relations_, embedding_size_}, tensor_options_);
+}
+shared_ptr<EdgeDecoder> get_edge_decoder(DecoderType type, EdgeDecoderMethod method, int num_relations, int dim, torch::TensorOptions opts, bool inv) {
+    switch (type) {  // model_helpers.h:23-38
+        case DecoderType::DISTMULT: return std::make_shared<DistMult>(num_relations, dim, opts, inv, method);
+        case DecoderType::TRANSE: return std::make_shared<TransE>(num_relations, dim, opts, inv, method);
+        case DecoderType::COMPLEX: return std::make_shared<ComplEx>(num_relations, dim, opts, inv, method);
+    }
+    throw MariusRuntimeException("Decoder currently not supported.");
+}
+
+// ------------------------------------------------------------------------------------------------ loss / optimizers / reporter
+Tensor SoftmaxCrossEntropy::operator()(Tensor pos, Tensor neg, bool scores) {
+    if (!scores)
+        throw MariusRuntimeException(
+            "Input to SoftmaxCrossEntropy loss function must be scores. SoftmaxCrossEntropy is currently unsupported for classification.");
+    if (!pos.defined() || !neg.defined()) throw UndefinedTensorException();                    // loss.cpp:7-14
+    if (pos.dim() != 1) throw TensorSizeMismatchException(pos, "Positive scores should be 1-dimensional");
+    if (neg.dim() != 2) throw TensorSizeMismatchException(neg, "Negative scores should be 2-dimensional");
+    if (pos.size(0) != neg.size(0)) throw TensorSizeMismatchException(pos, "First dimension of pos_scores and neg_scores should match.");
+    require_device(pos, "SoftmaxCrossEntropy");
+    Tensor n = neg;
+    if (n.stride(1) != 1 || n.stride(0) % 4 != 0) {  // give the kernel a 16-B aligned row pitch
+        const int64_t nld = (neg.size(1) + 3) / 4 * 4;
+        Tensor buf = torch::empty({neg.size(0), nld}, neg.options());
+        buf.narrow(1, 0, neg.size(1)).copy_(neg);
+        n = buf.narrow(1, 0, neg.size(1));
+    }
+    Tensor p = pos.contiguous();
+    Tensor lse = torch::empty_like(p), rowloss = torch::empty_like(p), loss = torch::empty({4}, p.options());
+    mcheck(marius_softmax_ce(fp(p), fp(n), p.size(0), (int32_t)n.size(1), n.stride(0),
+                             reduction_type_ == LossReduction::MEAN ? MARIUS_REDUCE_MEAN : MARIUS_REDUCE_SUM, fp(lse), fp(rowloss), fp(loss), cur_stream()));
+    return loss[0];
+}
+
+void Optimizer::clear_grad() {
+    for (auto& pg : params_) pg.second.zero_();
+}
+AdagradOptimizer::AdagradOptimizer(std::vector<std::pair<Tensor, Tensor>> params, float lr, float eps, float init_value) {
+    params_ = std::move(params);
+    learning_rate_ = lr;
+    eps_ = eps;
+    for (auto& pg : params_) state_.push_back(torch::full_like(pg.first, init_value));
+}
+void AdagradOptimizer::step() {  // optim.cpp:114-145
+    for (size_t i = 0; i < params_.size(); ++i)
+        mcheck(marius_dense_adagrad_step(fp(params_[i].first), fp(state_[i]), fp(params_[i].second), params_[i].first.numel(), learning_rate_, eps_,
+                                         weight_decay_, cur_stream()));
+}
+SGDOptimizer::SGDOptimizer(std::vector<std::pair<Tensor, Tensor>> params, float lr) {
+    params_ = std::move(params);
+    learning_rate_ = lr;
+}
+void SGDOptimizer::step() {  // optim.cpp:59-79: param -= lr * grad (plain libtorch elementwise op, as in the reference)
+    for (auto& pg : params_) pg.first.add_(pg.second, -learning_rate_);
+}
+
+Tensor LinkPredictionReporter::computeRanks(Tensor pos, Tensor neg) {
+    require_device(pos, "computeRanks");
+    Tensor p = pos.contiguous();
+    Tensor n = neg.stride(1) == 1 ? neg : neg.contiguous();
+    Tensor ranks = torch::empty({p.size(0)}, i64(p.device()));
+    mcheck(marius_compute_ranks(fp(p), fp(n), p.size(0), (int32_t)n.size(1), n.stride(0), ip(ranks), cur_stream()));
+    return ranks;
+}
+void LinkPredictionReporter::addResult(Tensor pos, Tensor neg) { ranks_.push_back(computeRanks(pos, neg)); }
+std::vector<double> LinkPredictionReporter::report() {  // reporting.cpp:11-31, model.cpp:29-38
+    if (ranks_.empty()) return {};
+    Tensor r = torch::cat(ranks_).to(torch::kFloat64).cpu();
+    std::vector<double> out;
+    out.push_back(r.reciprocal().mean().item<double>());
+    out.push_back(r.mean().item<double>());
+    for (int k : {1, 3, 5, 10, 50, 100}) out.push_back(r.le(k).to(torch::kFloat64).mean().item<double>());
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------ model
+Model::Model(shared_ptr<EdgeDecoder> decoder, shared_ptr<LossFunction> loss, shared_ptr<LinkPredictionReporter> reporter, torch::Device device)
+    : decoder_(decoder), loss_function_(loss), reporter_(reporter), device_(device) {
+    if (decoder_->relations_.defined()) relations_grad_ = torch::zeros_like(decoder_->relations_);
+    if (decoder_->inverse_relations_.defined()) inverse_relations_grad_ = torch::zeros_like(decoder_->inverse_relations_);
+}
+void Model::setup_optimizers(float dense_lr) {
+    std::vector<std::pair<Tensor, Tensor>> params;
+    if (decoder_->relations_.defined()) params.emplace_back(decoder_->relations_, relations_grad_);
+    if (decoder_->inverse_relations_.defined()) params.emplace_back(decoder_->inverse_relations_, inverse_relations_grad_);
+    optimizers_ = {std::make_shared<AdagradOptimizer>(params, dense_lr)};
+}
+void Model::clear_grad() {
+    for (auto& o : optimizers_) o->clear_grad();
+}
+void Model::step() {
+    for (auto& o : optimizers_) o->step();
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> Model::forward_lp(shared_ptr<Batch> batch, bool train) {
+    (void)train;  // evaluation also calls forward_lp(batch, true) in the reference (model.cpp:337)
+    if (decoder_->decoder_method_ == EdgeDecoderMethod::ONLY_POS) {
+        auto t = only_pos_forward(decoder_, batch->edges_, batch->node_embeddings_);
+        return std::forward_as_tuple(std::get<0>(t), Tensor(), std::get<1>(t), Tensor());
+    }
+    if (decoder_->decoder_method_ != EdgeDecoderMethod::CORRUPT_NODE) throw MariusRuntimeException("Decoder method currently unsupported.");
+    return node_corrupt_forward(decoder_, batch->edges_, batch->node_embeddings_, batch->dst_neg_indices_mapping_, batch->src_neg_indices_mapping_, &ctx_,
+                                batch->dst_neg_filter_, batch->src_neg_filter_, loss_function_ ? loss_function_->reduction_type_ : LossReduction::SUM);
+}
+
+static void ensure(Tensor& t, int64_t bytes, torch::Device dev) {
+    if (!t.defined() || t.numel() < bytes || t.device() != dev) t = torch::empty({bytes}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+}
+
+// forward + loss + hand-derived backward; leaves per-occurrence node gradients in ctx_ (gocc) and dense relation gradients in *_grad_
+static void model_backward(Model& m, shared_ptr<Batch> batch) {
+    auto st = cur_stream();
+    LpContext& c = m.ctx_;
+    mcheck(marius_lp_loss(&c.desc, &c.layout, c.workspace.data_ptr(), st));
+    mcheck(marius_lp_backward(&c.desc, &c.layout, c.workspace.data_ptr(), st));
+    m.loss_ = c.view(c.layout.loss, {4});
+    if (c.desc.edge_cols == 3) {  // index_select backward into [R, d]: sort relation ids, segmented sum, no atomics
+        const int64_t B = c.desc.B;
+        auto dev = m.ctx_.workspace.device();
+        if (!m.rel_ids_.defined() || m.rel_ids_.size(0) != B) {
+            m.rel_ids_ = torch::empty({B}, i64(dev));
+            m.rel_uniq_ = torch::empty({B}, i64(dev));
+            m.rel_inverse_ = torch::empty({B}, i64(dev));
+            m.rel_perm_ = torch::empty({B}, i32(dev));
+            m.rel_seg_ = torch::empty({B + 1}, i32(dev));
+            m.rel_count_ = torch::zeros({1}, i64(dev));
+            ensure(m.rel_ws_, (int64_t)marius_sort_unique_workspace_bytes(B), dev);
+            ensure(m.rel_carry_, (int64_t)marius_segment_carry_bytes(B, c.desc.d), dev);
+        }
+        m.rel_ids_.copy_(batch->edges_.select(1, 1));
+        mcheck(marius_sort_unique(ip(m.rel_ids_), B, key_bits_for(c.desc.R), ip(m.rel_uniq_), ip(m.rel_inverse_), m.rel_perm_.data_ptr<int32_t>(),
+                                  m.rel_seg_.data_ptr<int32_t>(), ip(m.rel_count_), m.rel_ws_.data_ptr(), (size_t)m.rel_ws_.numel(), st));
+        Tensor* grads[2] = {&m.relations_grad_, &m.inverse_relations_grad_};
+        for (int dir = 0; dir < (c.desc.use_inverse ? 2 : 1); ++dir) {
+            grads[dir]->zero_();
+            const float* rows = (const float*)((const char*)c.workspace.data_ptr() + c.layout.grel[dir]);
+            mcheck(marius_segment_sum_rows(rows, c.layout.d_ld, m.rel_perm_.data_ptr<int32_t>(), ip(m.rel_inverse_), m.rel_seg_.data_ptr<int32_t>(), B,
+                                           c.desc.d, ip(m.rel_uniq_), fp(*grads[dir]), grads[dir]->stride(0), m.rel_carry_.data_ptr(), st));
+        }
+    }
+}
+
+void Model::train_batch(shared_ptr<Batch> batch, bool call_step) {
+    if (call_step) clear_grad();
+    forward_lp(batch, true);
+    model_backward(*this, batch);
+    // node_embeddings_.grad [U, d]: sum of the occurrence gradients per unique row (autograd's index_add), atomic-free
+    const int64_t L = batch->occ_perm_.size(0);
+    const int64_t U = batch->node_embeddings_.size(0);
+    ensure(carry_, (int64_t)marius_segment_carry_bytes(L, ctx_.desc.d), device_);
+    batch->node_embeddings_grad_ = torch::zeros({U, (int64_t)ctx_.desc.d}, batch->node_embeddings_.options());
+    const float* gocc = (const float*)((const char*)ctx_.workspace.data_ptr() + ctx_.layout.gocc);
+    mcheck(marius_segment_sum_rows(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
+                                   batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, nullptr, fp(batch->node_embeddings_grad_),
+                                   batch->node_embeddings_grad_.stride(0), carry_.data_ptr(), cur_stream()));
+    if (call_step) step();
+    if (batch->node_embeddings_.defined()) batch->accumulateGradients(sparse_lr_);
+}
+
+void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor state) {
+    clear_grad();
+    forward_lp(batch, true);
+    model_backward(*this, batch);
+    step();
+    const int64_t L = batch->occ_perm_.size(0);
+    ensure(carry_, (int64_t)marius_segment_carry_bytes(L, ctx_.desc.d), device_);
+    const float* gocc = (const float*)((const char*)ctx_.workspace.data_ptr() + ctx_.layout.gocc);
+    mcheck(marius_segment_adagrad_scatter(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
+                                          batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, ip(batch->unique_node_indices_), fp(table),
+                                          fp(state), table.stride(0), sparse_lr_, 1e-10f, carry_.data_ptr(), cur_stream()));
+}
+
+void Model::evaluate_batch(shared_ptr<Batch> batch) {
+    auto t = forward_lp(batch, true);
+    if (std::get<1>(t).defined()) reporter_->addResult(std::get<0>(t), std::get<1>(t));
+    if (std::get<3>(t).defined()) reporter_->addResult(std::get<2>(t), std::get<3>(t));
+}
+
+// ------------------------------------------------------------------------------------------------ dataloader
+DataLoader::DataLoader(shared_ptr<InMemory> edges, shared_ptr<InMemory> node_embeddings, shared_ptr<InMemory> node_embeddings_state,
+                       shared_ptr<CorruptNodeNegativeSampler> negative_sampler, shared_ptr<MariusGenerator> generator, int64_t batch_size, bool train)
+    : edges_(edges), node_embeddings_(node_embeddings), node_embeddings_state_(node_embeddings_state), negative_sampler_(negative_sampler),
+      generator_(generator), batch_size_(batch_size), train_(train) {
+    graph_ = std::make_shared<MariusGraph>();
+    graph_->num_nodes_in_memory_ = node_embeddings_->dim0_size_;
+    num_edges_ = edges_->dim0_size_;
+    key_bits_ = key_bits_for(graph_->num_nodes_in_memory_);
+    if (negative_sampler_) negative_sampler_->generator_ = generator_;
+}
+
+void DataLoader::initializeBatches(bool shuffle) {
+    // setActiveEdges (dataloader.cpp:176-182): randperm over all edges on the generator stream, consumed even for evaluation
+    Tensor perm = generator_->randperm(num_edges_);
+    active_perm_ = shuffle ? perm.to(edges_->device_) : torch::arange(num_edges_, i64(edges_->device_));
+    total_batches_ = (num_edges_ + batch_size_ - 1) / batch_size_;
+    batches_left_ = total_batches_;
+    batch_id_ = 0;
+}
+
+shared_ptr<Batch> DataLoader::getBatch(bool exact_unique) {
+    auto st = cur_stream();
+    auto dev = edges_->device_;
+    auto batch = std::make_shared<Batch>(train_);
+    batch->batch_id_ = (int)batch_id_;
+    batch->start_idx_ = batch_id_ * batch_size_;
+    batch->batch_size_ = std::min(batch_size_, num_edges_ - batch->start_idx_);
+    batch_id_++;
+    batches_left_--;
+    const int64_t B = batch->batch_size_;
+    const int cols = (int)edges_->dim1_size_;
+    // edge_sampler_->getEdges (edge.cpp:12-14): slice of the shuffled edges, cast to int64
+    Tensor edges = torch::empty({B, cols}, i64(dev));
+    mcheck(marius_select_edges(edges_->data_.data_ptr(), edges_->dtype_ == torch::kInt64 ? 1 : 0, cols, ip(active_perm_), batch->start_idx_, B, ip(edges), st));
+    // negativeSample (dataloader.cpp:498-503): inverse (src corruption) first, then dst
+    std::tie(batch->src_neg_indices_, batch->src_neg_filter_) = negative_sampler_->getNegatives(graph_, edges, true);
+    std::tie(batch->dst_neg_indices_, batch->dst_neg_filter_) = negative_sampler_->getNegatives(graph_, edges, false);
+    const int64_t CN = batch->dst_neg_indices_.numel();
+    const int64_t L = 2 * B + 2 * CN;
+    // map_tensors (util.cpp:180-205)
+    all_ids_ = torch::empty({L}, i64(dev));
+    uniq_ = torch::empty({L}, i64(dev));
+    inverse_ = torch::empty({L}, i64(dev));
+    perm_ = torch::empty({L}, i32(dev));
+    seg_ = torch::empty({L + 1}, i32(dev));
+    count_ = torch::zeros({1}, i64(dev));
+    const size_t wsb = marius_sort_unique_workspace_bytes(L);
+    if (!sort_ws_.defined() || (size_t)sort_ws_.numel() < wsb) sort_ws_ = torch::empty({(int64_t)wsb}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+    mcheck(marius_assemble_ids(ip(edges), B, cols, ip(batch->src_neg_indices_), ip(batch->dst_neg_indices_), CN, ip(all_ids_), st));
+    mcheck(marius_sort_unique(ip(all_ids_), L, key_bits_, ip(uniq_), ip(inverse_), perm_.data_ptr<int32_t>(), seg_.data_ptr<int32_t>(), ip(count_),
+                              sort_ws_.data_ptr(), (size_t)sort_ws_.numel(), st));
+    batch->edges_ = torch::empty({B, cols}, i64(dev));
+    mcheck(marius_remap_edges(ip(edges), ip(inverse_), B, cols, ip(batch->edges_), st));
+    batch->src_neg_indices_mapping_ = inverse_.narrow(0, 2 * B, CN).view(batch->src_neg_indices_.sizes());
+    batch->dst_neg_indices_mapping_ = inverse_.narrow(0, 2 * B + CN, CN).view(batch->dst_neg_indices_.sizes());
+    // exact_unique: the reference's tensor [U] (one 8-byte D2H copy); otherwise capacity-sized with a zero tail (no host sync)
+    const int64_t U = exact_unique ? count_.item<int64_t>() : L;
+    batch->unique_node_indices_ = uniq_.narrow(0, 0, U);
+    batch->occ_perm_ = perm_;
+    batch->occ_inverse_ = inverse_;
+    batch->occ_seg_offsets_ = seg_;
+    batch->num_unique_dev_ = count_;
+    return batch;
+}
+
+void DataLoader::loadGPUParameters(shared_ptr<Batch> batch) {
+    if (train_ && node_embeddings_state_) {
+        const int64_t U = batch->unique_node_indices_.size(0), d = node_embeddings_->dim1_size_;
+        batch->node_embeddings_ = torch::empty({U, d}, node_embeddings_->data_.options());
+        batch->node_embeddings_state_ = torch::empty({U, d}, node_embeddings_->data_.options());
+        mcheck(marius_gather_rows2(fp(node_embeddings_->data_), fp(node_embeddings_state_->data_), node_embeddings_->data_.stride(0),
+                                   ip(batch->unique_node_indices_), U, (int32_t)d, fp(batch->node_embeddings_), fp(batch->node_embeddings_state_), d,
+                                   cur_stream()));
+    } else {
+        batch->node_embeddings_ = node_embeddings_->indexRead(batch->unique_node_indices_);
+    }
+}
+
+void DataLoader::updateEmbeddings(shared_ptr<Batch> batch, bool gpu) {
+    (void)gpu;
+    node_embeddings_->indexAdd(batch->unique_node_indices_, batch->node_gradients_);          // graph_storage.cpp:289
+    node_embeddings_state_->indexAdd(batch->unique_node_indices_, batch->node_state_update_);  // graph_storage.cpp:319-323
+}
+
+// ------------------------------------------------------------------------------------------------ trainer / evaluator
+void SynchronousTrainer::train(int num_epochs) {
+    for (int epoch = 0; epoch < num_epochs; ++epoch) {
+        dataloader_->initializeBatches(true);
+        c10::hip::getCurrentHIPStream().synchronize();
+        auto t0 = std::chrono::steady_clock::now();
+        while (dataloader_->hasNextBatch()) {
+            if (fused_update_) {
+                auto batch = dataloader_->getBatch(/*exact_unique=*/false);  // no host sync anywhere in the step
+                batch->node_embeddings_ = dataloader_->node_embeddings_->indexRead(batch->unique_node_indices_);
+                model_->backward_into_tables(batch, dataloader_->node_embeddings_->data_, dataloader_->node_embeddings_state_->data_);
+            } else {  // API-granular path, call for call the reference's loop (trainer.cpp:106-138)
+                auto batch = dataloader_->getBatch(true);
+                dataloader_->loadGPUParameters(batch);
+                model_->train_batch(batch);
+                dataloader_->updateEmbeddings(batch, true);
+                batch->clear();
+            }
+        }
+        c10::hip::getCurrentHIPStream().synchronize();
+        last_epoch_seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        last_edges_per_second_ = (double)dataloader_->getNumEdges() / last_epoch_seconds_;  // trainer.cpp:156-159
+    }
+}
+
+std::vector<double> SynchronousEvaluator::evaluate() {
+    model_->reporter_->clear();
+    dataloader_->initializeBatches(false);
+    while (dataloader_->hasNextBatch()) {
+        auto batch = dataloader_->getBatch(true);
+        dataloader_->loadGPUParameters(batch);
+        model_->evaluate_batch(batch);
+    }
+    return model_->reporter_->report();
+}
+
+}  // namespace marius_amd

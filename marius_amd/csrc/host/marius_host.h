@@ -1,0 +1,351 @@
+// C++ host layer on libtorch (PyTorch-ROCm): the reference's operator API for the link-prediction hot path, with every
+// device operation routed through the C-ABI of libmarius_hip.so (include/marius_hip.h).  Class / method / field names follow
+// the reference (paths relative to /root/reference/src/cpp) so that code written against Marius reads the same here.
+//
+//   include/common/exception.h            -> MariusRuntimeException, TensorSizeMismatchException, UndefinedTensorException
+//   include/storage/storage.h:35-86       -> Storage, InMemory (device-resident node table / edge list)
+//   include/data/samplers/negative.h      -> NegativeSampler, CorruptNodeNegativeSampler
+//   include/data/batch.h                  -> Batch
+//   include/nn/decoders/edge/*.h          -> RelationOperator, Comparator, EdgeDecoder, DistMult, ComplEx, TransE, decoder methods
+//   include/nn/loss.h                     -> LossFunction, SoftmaxCrossEntropy
+//   include/nn/optim.h                    -> Optimizer, AdagradOptimizer, SGDOptimizer
+//   include/nn/model.h                    -> Model (forward_lp, train_batch, evaluate_batch, step)
+//   include/data/dataloader.h             -> DataLoader (initializeBatches, getBatch, loadGPUParameters, updateEmbeddings)
+//   include/pipeline/trainer.h            -> SynchronousTrainer ; include/pipeline/evaluator.h -> SynchronousEvaluator
+//   include/reporting/reporting.h         -> LinkPredictionReporter (ranks, MRR, Hits@k)
+// There is no CPU fallback: tensors handed to these classes must live on the MI355X.
+#pragma once
+#include <torch/torch.h>
+
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "marius_hip.h"
+
+namespace marius_amd {
+
+using std::shared_ptr;
+using torch::Tensor;
+
+// ------------------------------------------------------------------------------------------------ exceptions (exception.h:12-42)
+struct MariusRuntimeException : public std::runtime_error {
+    explicit MariusRuntimeException(const std::string& msg) : std::runtime_error(msg) {}
+};
+struct UndefinedTensorException : public MariusRuntimeException {
+    UndefinedTensorException() : MariusRuntimeException("Tensor undefined") {}
+};
+struct TensorSizeMismatchException : public MariusRuntimeException {
+    TensorSizeMismatchException(const Tensor& t, const std::string& msg) : MariusRuntimeException(describe(t, msg)) {}
+    static std::string describe(const Tensor& t, const std::string& msg);
+};
+
+void mcheck(int rc);                 // non-zero C-ABI status -> MariusRuntimeException(marius_hip_last_error())
+marius_stream_t cur_stream();        // current HIP stream of the current device
+void require_device(const Tensor& t, const char* what);
+
+// ------------------------------------------------------------------------------------------------ options (configuration/options.h)
+enum class LossReduction { MEAN, SUM };
+enum class EdgeDecoderMethod { ONLY_POS, POS_AND_NEG, CORRUPT_NODE, CORRUPT_REL };
+enum class LocalFilterMode { ALL, DEG };
+enum class DecoderType { DISTMULT, TRANSE, COMPLEX };
+
+// ------------------------------------------------------------------------------------------------ generator (ATen CPU MT19937 stream)
+// torch::manual_seed(seed) + the global CPU generator of the reference (marius.cpp:47), as an explicit object whose state can
+// live on the host (randperm) or on the device (negative sampling).
+class MariusGenerator {
+   public:
+    explicit MariusGenerator(uint64_t seed);
+    Tensor randperm(int64_t n);                       // host int64, consumes the stream like torch::randperm on CPU
+    Tensor raw_words(int64_t n, torch::Device dev);   // n raw 32-bit draws on `dev` (int32 tensor), advances the stream
+    void to_device(torch::Device dev);
+    void to_host();
+    Tensor state_host_;  // [625] int32
+    Tensor state_dev_;   // defined while the state lives on the device
+};
+
+// ------------------------------------------------------------------------------------------------ storage (storage.h:35-86)
+class Storage {
+   public:
+    virtual ~Storage() = default;
+    int64_t dim0_size_ = 0;
+    int64_t dim1_size_ = 0;
+    torch::Dtype dtype_ = torch::kFloat32;
+    Tensor data_;
+    torch::Device device_ = torch::kCPU;
+    std::string filename_;
+    bool loaded_ = false;
+
+    virtual Tensor indexRead(Tensor indices) = 0;
+    virtual void indexAdd(Tensor indices, Tensor values) = 0;
+    virtual Tensor range(int64_t offset, int64_t n) = 0;
+    virtual void indexPut(Tensor indices, Tensor values) = 0;
+    virtual void rangePut(int64_t offset, Tensor values) = 0;
+    virtual void load() = 0;
+    virtual void write() = 0;
+    virtual void unload(bool perform_write) = 0;
+};
+
+// DEVICE_MEMORY backend (storage.cpp:515-760) on the MI355X: raw row-major binary file <-> HBM tensor.
+class InMemory : public Storage {
+   public:
+    InMemory(std::string filename, int64_t dim0_size, int64_t dim1_size, torch::Dtype dtype, torch::Device device);
+    InMemory(Tensor data);  // tensor constructor (storage.cpp:538-545)
+    Tensor indexRead(Tensor indices) override;
+    void indexAdd(Tensor indices, Tensor values) override;
+    Tensor range(int64_t offset, int64_t n) override;
+    void indexPut(Tensor indices, Tensor values) override;
+    void rangePut(int64_t offset, Tensor values) override;
+    void load() override;
+    void write() override;
+    void unload(bool perform_write) override;
+};
+
+// ------------------------------------------------------------------------------------------------ graph stub + samplers
+struct MariusGraph {  // only the field the LP sampler reads (graph.h: num_nodes_in_memory_)
+    int64_t num_nodes_in_memory_ = 0;
+};
+
+class NegativeSampler {
+   public:
+    virtual ~NegativeSampler() = default;
+    virtual std::tuple<Tensor, Tensor> getNegatives(shared_ptr<MariusGraph> graph, Tensor edges = Tensor(), bool inverse = false) = 0;
+};
+
+class CorruptNodeNegativeSampler : public NegativeSampler {
+   public:
+    int num_chunks_;
+    int num_negatives_;
+    float degree_fraction_;
+    bool filtered_;
+    LocalFilterMode local_filter_mode_;
+    shared_ptr<MariusGenerator> generator_;
+
+    CorruptNodeNegativeSampler(int num_chunks, int num_negatives, float degree_fraction, bool filtered = false,
+                               LocalFilterMode local_filter_mode = LocalFilterMode::DEG, shared_ptr<MariusGenerator> generator = nullptr);
+    // (ids [C,N] int64, filter [F,2] int64) — negative.cpp:328-366.  compact_filter=false keeps the uncompacted filter (rows of -1)
+    std::tuple<Tensor, Tensor> getNegatives(shared_ptr<MariusGraph> graph, Tensor edges = Tensor(), bool inverse = false) override;
+    bool compact_filter_ = true;
+};
+
+// ------------------------------------------------------------------------------------------------ batch (batch.h:32-89)
+class Batch {
+   public:
+    explicit Batch(bool train) : train_(train) {}
+    bool train_;
+    int batch_id_ = -1;
+    int64_t start_idx_ = 0;
+    int64_t batch_size_ = 0;
+    Tensor edges_;                      // [B, 3|2] int64 (global ids before map, batch-local after)
+    Tensor unique_node_indices_;        // [U] ascending
+    Tensor node_embeddings_;            // [U, d]
+    Tensor node_embeddings_state_;      // [U, d]
+    Tensor node_embeddings_grad_;       // [U, d]  (node_embeddings_.grad() in the reference)
+    Tensor node_gradients_;             // dw
+    Tensor node_state_update_;          // ds
+    Tensor src_neg_indices_, dst_neg_indices_;                   // [C, N] global ids
+    Tensor src_neg_indices_mapping_, dst_neg_indices_mapping_;   // [C, N] batch-local
+    Tensor src_neg_filter_, dst_neg_filter_;                     // [F, 2]
+    // device-side products of the unique map that the fused update consumes
+    Tensor occ_perm_, occ_inverse_, occ_seg_offsets_, num_unique_dev_;
+
+    void accumulateGradients(float learning_rate);  // batch.cpp:62-79
+    void clear();                                   // batch.cpp:105-...
+};
+
+// ------------------------------------------------------------------------------------------------ decoder pieces
+class RelationOperator {
+   public:
+    virtual ~RelationOperator() = default;
+    virtual int kind() const = 0;  // MARIUS_OP_*
+    Tensor operator()(const Tensor& embs, const Tensor& rels);  // undefined rels => identity (relation_operators.cpp)
+};
+struct HadamardOperator : RelationOperator { int kind() const override { return MARIUS_OP_HADAMARD; } };
+struct ComplexHadamardOperator : RelationOperator { int kind() const override { return MARIUS_OP_COMPLEX_HADAMARD; } };
+struct TranslationOperator : RelationOperator { int kind() const override { return MARIUS_OP_TRANSLATION; } };
+struct NoOp : RelationOperator { int kind() const override { return MARIUS_OP_NOOP; } };
+
+class Comparator {
+   public:
+    virtual ~Comparator() = default;
+    virtual int kind() const = 0;  // MARIUS_CMP_*
+    Tensor operator()(Tensor src, Tensor dst);  // dst [B,d] -> [B]; dst [C,N,d] -> [C*ceil(B/C), N]  (comparators.cpp)
+};
+struct DotCompare : Comparator { int kind() const override { return MARIUS_CMP_DOT; } };
+struct L2Compare : Comparator { int kind() const override { return MARIUS_CMP_L2; } };
+struct CosineCompare : Comparator { int kind() const override { return MARIUS_CMP_COSINE; } };
+
+class EdgeDecoder {
+   public:
+    virtual ~EdgeDecoder() = default;
+    shared_ptr<Comparator> comparator_;
+    shared_ptr<RelationOperator> relation_operator_;
+    Tensor relations_;
+    Tensor inverse_relations_;
+    int num_relations_ = 0;
+    int embedding_size_ = 0;
+    torch::TensorOptions tensor_options_;
+    EdgeDecoderMethod decoder_method_ = EdgeDecoderMethod::CORRUPT_NODE;
+    bool use_inverse_relations_ = true;
+
+    Tensor apply_relation(Tensor nodes, Tensor relations);
+    Tensor compute_scores(Tensor src, Tensor dst);
+    Tensor select_relations(Tensor indices, bool inverse = false);
+    virtual void reset() = 0;
+};
+class DistMult : public EdgeDecoder {
+   public:
+    DistMult(int num_relations, int embedding_dim, torch::TensorOptions tensor_options, bool use_inverse_relations = true,
+             EdgeDecoderMethod decoder_method = EdgeDecoderMethod::CORRUPT_NODE);
+    void reset() override;
+};
+class ComplEx : public EdgeDecoder {
+   public:
+    ComplEx(int num_relations, int embedding_dim, torch::TensorOptions tensor_options, bool use_inverse_relations = true,
+            EdgeDecoderMethod decoder_method = EdgeDecoderMethod::CORRUPT_NODE);
+    void reset() override;
+};
+class TransE : public EdgeDecoder {
+   public:
+    TransE(int num_relations, int embedding_dim, torch::TensorOptions tensor_options, bool use_inverse_relations = true,
+           EdgeDecoderMethod decoder_method = EdgeDecoderMethod::CORRUPT_NODE);
+    void reset() override;
+};
+shared_ptr<EdgeDecoder> get_edge_decoder(DecoderType type, EdgeDecoderMethod method, int num_relations, int dim, torch::TensorOptions opts,
+                                         bool use_inverse_relations);
+
+// One workspace per batch shape holding everything the fused forward / loss / backward produce (marius_lp_layout).
+struct LpContext {
+    marius_lp_desc desc{};
+    marius_lp_layout layout{};
+    Tensor workspace;
+    std::vector<Tensor> keep;  // tensors whose pointers sit in desc
+    bool has_loss = false;
+    Tensor view(size_t off, std::vector<int64_t> shape, std::vector<int64_t> strides = {}) const;
+};
+
+// decoder_methods.h:11-21
+std::tuple<Tensor, Tensor> only_pos_forward(shared_ptr<EdgeDecoder> decoder, Tensor edges, Tensor node_embeddings);
+std::tuple<Tensor, Tensor, Tensor, Tensor> node_corrupt_forward(shared_ptr<EdgeDecoder> decoder, Tensor positive_edges, Tensor node_embeddings,
+                                                                Tensor dst_negs, Tensor src_negs, LpContext* ctx = nullptr,
+                                                                Tensor dst_filter = Tensor(), Tensor src_filter = Tensor(),
+                                                                LossReduction reduction = LossReduction::SUM);
+
+// ------------------------------------------------------------------------------------------------ loss / optimizers / reporter
+class LossFunction {
+   public:
+    virtual ~LossFunction() = default;
+    LossReduction reduction_type_ = LossReduction::SUM;
+    virtual Tensor operator()(Tensor y_pred, Tensor targets, bool scores) = 0;
+};
+class SoftmaxCrossEntropy : public LossFunction {
+   public:
+    explicit SoftmaxCrossEntropy(LossReduction reduction = LossReduction::SUM) { reduction_type_ = reduction; }
+    Tensor operator()(Tensor pos_scores, Tensor neg_scores, bool scores) override;  // loss.cpp:50-67
+};
+
+class Optimizer {
+   public:
+    virtual ~Optimizer() = default;
+    float learning_rate_ = 0.1f;
+    std::vector<std::pair<Tensor, Tensor>> params_;  // (param, grad)
+    std::vector<Tensor> state_;
+    virtual void step() = 0;
+    void clear_grad();
+};
+class AdagradOptimizer : public Optimizer {  // optim.cpp:82-145
+   public:
+    float eps_ = 1e-10f, weight_decay_ = 0.f;
+    AdagradOptimizer(std::vector<std::pair<Tensor, Tensor>> params, float lr, float eps = 1e-10f, float init_value = 0.f);
+    void step() override;
+};
+class SGDOptimizer : public Optimizer {  // optim.cpp:59-79
+   public:
+    SGDOptimizer(std::vector<std::pair<Tensor, Tensor>> params, float lr);
+    void step() override;
+};
+
+class LinkPredictionReporter {  // reporting.cpp:11-57
+   public:
+    std::vector<Tensor> ranks_;
+    Tensor computeRanks(Tensor pos_scores, Tensor neg_scores);
+    void addResult(Tensor pos_scores, Tensor neg_scores);
+    void clear() { ranks_.clear(); }
+    // (MRR, MeanRank, Hits@1, @3, @5, @10, @50, @100)
+    std::vector<double> report();
+};
+
+// ------------------------------------------------------------------------------------------------ model (model.h:16-65)
+class Model {
+   public:
+    shared_ptr<EdgeDecoder> decoder_;
+    shared_ptr<LossFunction> loss_function_;
+    shared_ptr<LinkPredictionReporter> reporter_;
+    std::vector<shared_ptr<Optimizer>> optimizers_;
+    float sparse_lr_ = 0.1f;
+    torch::Device device_ = torch::kCPU;
+    Tensor relations_grad_, inverse_relations_grad_;
+    LpContext ctx_;
+    Tensor loss_;  // [4] device floats: total, rhs, lhs, -
+    // scratch for the gradient reductions
+    Tensor carry_, rel_carry_, rel_ws_, rel_uniq_, rel_inverse_, rel_perm_, rel_seg_, rel_count_, rel_ids_;
+
+    Model(shared_ptr<EdgeDecoder> decoder, shared_ptr<LossFunction> loss, shared_ptr<LinkPredictionReporter> reporter, torch::Device device);
+    std::tuple<Tensor, Tensor, Tensor, Tensor> forward_lp(shared_ptr<Batch> batch, bool train);  // model.cpp:252-288
+    void train_batch(shared_ptr<Batch> batch, bool call_step = true);                            // model.cpp:290-333
+    void evaluate_batch(shared_ptr<Batch> batch);                                                // model.cpp:335-359
+    void clear_grad();
+    void step();
+    void setup_optimizers(float dense_lr);
+    // fused tail used by the trainer for DEVICE_MEMORY tables: backward products -> table/state update in one call
+    void backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor state);
+};
+
+// ------------------------------------------------------------------------------------------------ dataloader (dataloader.h)
+class DataLoader {
+   public:
+    shared_ptr<InMemory> edges_;             // [E, 3|2] int32/int64 on device
+    shared_ptr<InMemory> node_embeddings_;   // [num_nodes, d]
+    shared_ptr<InMemory> node_embeddings_state_;
+    shared_ptr<CorruptNodeNegativeSampler> negative_sampler_;
+    shared_ptr<MariusGraph> graph_;
+    shared_ptr<MariusGenerator> generator_;
+    int64_t batch_size_;
+    bool train_;
+    int64_t num_edges_ = 0;
+    int64_t batches_left_ = 0, batch_id_ = 0, total_batches_ = 0;
+    Tensor active_perm_;  // device int64 permutation of the epoch
+    // unique-map scratch (capacity-sized)
+    Tensor all_ids_, uniq_, inverse_, perm_, seg_, count_, sort_ws_;
+    int key_bits_ = 63;
+
+    DataLoader(shared_ptr<InMemory> edges, shared_ptr<InMemory> node_embeddings, shared_ptr<InMemory> node_embeddings_state,
+               shared_ptr<CorruptNodeNegativeSampler> negative_sampler, shared_ptr<MariusGenerator> generator, int64_t batch_size, bool train);
+    void initializeBatches(bool shuffle = true);    // dataloader.cpp:202-248 (+ setActiveEdges :120-183)
+    bool hasNextBatch() const { return batches_left_ > 0; }
+    shared_ptr<Batch> getBatch(bool exact_unique = true);  // dataloader.cpp:360-471
+    void loadGPUParameters(shared_ptr<Batch> batch);       // dataloader.cpp:529-548
+    void updateEmbeddings(shared_ptr<Batch> batch, bool gpu = true);  // dataloader.cpp:550-564
+    int64_t getNumEdges() const { return num_edges_; }
+};
+
+// ------------------------------------------------------------------------------------------------ trainer / evaluator
+class SynchronousTrainer {  // trainer.cpp:94-161
+   public:
+    shared_ptr<DataLoader> dataloader_;
+    shared_ptr<Model> model_;
+    bool fused_update_ = true;  // DEVICE_MEMORY fast path: segmented sum + Adagrad + scatter in one C-ABI call
+    double last_epoch_seconds_ = 0, last_edges_per_second_ = 0;
+    SynchronousTrainer(shared_ptr<DataLoader> dataloader, shared_ptr<Model> model) : dataloader_(dataloader), model_(model) {}
+    void train(int num_epochs = 1);
+};
+class SynchronousEvaluator {  // evaluator.cpp:58-97
+   public:
+    shared_ptr<DataLoader> dataloader_;
+    shared_ptr<Model> model_;
+    SynchronousEvaluator(shared_ptr<DataLoader> dataloader, shared_ptr<Model> model) : dataloader_(dataloader), model_(model) {}
+    std::vector<double> evaluate();
+};
+
+}  // namespace marius_amd

@@ -911,3 +911,18 @@ extern "C" int marius_compute_ranks(const float* pos, const float* neg, int64_t 
     lp_ranks_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, as_stream(stream)>>>(pos, neg, rows, N, neg_ld, ranks);
     return check_launch("compute_ranks");
 }
+
+// SoftmaxCrossEntropy on materialised scores (loss.cpp:50-67): lse[i] = log(e^pos_i + sum_j e^neg_ij), rowloss = lse - pos,
+// loss[0] = sum (SUM) or mean (MEAN) of rowloss.  Scratch: lse[rows], rowloss[rows], loss[4].
+extern "C" int marius_softmax_ce(const float* pos, const float* neg, int64_t rows, int32_t N, int64_t neg_ld, int32_t reduction, float* lse,
+                                 float* rowloss, float* loss, marius_stream_t stream) {
+    MARIUS_REQUIRE(rows > 0 && N > 0 && neg_ld >= N && (neg_ld % 4 == 0 || N < 4), "softmax_ce: bad sizes (neg_ld must be a multiple of 4)");
+    MARIUS_REQUIRE(pos && neg && lse && rowloss && loss, "softmax_ce: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int n_eff = (neg_ld % 4 == 0) ? N : 0;
+    (void)n_eff;
+    lp_lse_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>(neg, neg_ld, pos, rows, N, lse, rowloss);
+    lp_loss_reduce_kernel<<<dim3(1), dim3(1024), 0, st>>>(rowloss, rows, reduction == MARIUS_REDUCE_MEAN ? 1.f / (float)rows : 1.f, loss);
+    lp_loss_total_kernel<<<dim3(1), dim3(1), 0, st>>>(1, loss);
+    return check_launch("softmax_ce");
+}

@@ -75,6 +75,7 @@ SIGNATURES = {
     "marius_lp_forward": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),
     "marius_lp_loss": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),
     "marius_lp_backward": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),
+    "marius_softmax_ce": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
     "marius_compute_ranks": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "marius_segment_carry_bytes": (_sz, [_i64, _i32]),
     "marius_segment_sum_rows": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp]),

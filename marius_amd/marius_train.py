@@ -1,0 +1,119 @@
+"""`marius_train <config.yaml>` — drop-in entry point for link-prediction training on the MI355X.
+
+Mirrors marius_init + marius_train of the reference (src/cpp/src/marius.cpp:38-163; console script
+src/python/console_scripts/marius_train.py): load the configuration, seed the generator, build the decoder / loss / optimizers,
+open the dataset's raw binaries (edges/train_edges.bin [E,3] int32, written by marius_preprocess) as DEVICE_MEMORY storage, create
+<model_dir>/embeddings.bin + embeddings_state.bin, then per epoch: SynchronousTrainer::train(1), evaluation on the validation / test
+edges, checkpoint of the node table.  All compute runs in the C++ host classes (marius_amd.host()) over the HIP kernels.
+"""
+import math
+import os
+import sys
+import time
+
+import torch
+import yaml
+
+from . import config as C
+
+
+def _edge_file(ddir, split):
+    return os.path.join(ddir, "edges", "%s_edges.bin" % split)
+
+
+def marius_train(cfg, log=print):
+    import marius_amd
+
+    H = marius_amd.host()
+    if cfg["storage"]["device_type"] == "cpu":
+        raise RuntimeError("device_type cpu: this build has no CPU path (MI355X only); set storage.device_type: cuda")
+    dev = torch.device("cuda", 0)
+    ds = cfg["storage"]["dataset"]
+    ddir, mdir = ds["dataset_dir"], cfg["storage"]["model_dir"]
+    os.makedirs(mdir, exist_ok=True)
+    with open(os.path.join(mdir, "full_config.yaml"), "w") as f:
+        yaml.safe_dump(cfg, f)
+    d = C.embedding_dim(cfg)
+    num_nodes, R = int(ds["num_nodes"]), int(ds.get("num_relations", 1))
+    cols = 3 if R > 1 else 2  # io.cpp:42-45
+    edge_dtype = torch.int32 if cfg["storage"]["edges"]["options"]["dtype"] == "int" else torch.int64
+    seed = int(cfg["model"]["random_seed"])
+    gen = H.MariusGenerator(seed)  # torch::manual_seed(seed) stream (marius.cpp:47)
+    torch.manual_seed(seed)
+
+    # ---- model (initModelFromConfig, model.cpp:381-440)
+    dec_cfg = cfg["model"]["decoder"]
+    dec_cls = {"DISTMULT": H.DistMult, "COMPLEX": H.ComplEx, "TRANSE": H.TransE}[dec_cfg["type"]]
+    method = getattr(H.EdgeDecoderMethod, dec_cfg["options"].get("edge_decoder_method", "CORRUPT_NODE"))
+    decoder = dec_cls(R, d, dev, bool(dec_cfg["options"].get("inverse_edges", True)), method)
+    if cfg["model"]["loss"]["type"] != "SOFTMAX_CE":
+        raise NotImplementedError("loss %s: only SOFTMAX_CE is on the fused path" % cfg["model"]["loss"]["type"])
+    loss = H.SoftmaxCrossEntropy(cfg["model"]["loss"]["options"].get("reduction", "SUM"))
+    model = H.Model(decoder, loss, H.LinkPredictionReporter(), dev)
+    model.setup_optimizers(float(cfg["model"]["dense_optimizer"]["options"]["learning_rate"]))
+    sp = cfg["model"].get("sparse_optimizer") or cfg["model"]["dense_optimizer"]
+    model.sparse_lr = float(sp["options"]["learning_rate"])  # model.cpp:425-429: only the learning rate is read
+
+    # ---- storage (initializeStorage, io.cpp:433-448)
+    def edges(split, n):
+        st = H.InMemory(_edge_file(ddir, split), int(n), cols, edge_dtype, dev)
+        st.load()
+        return st
+
+    train_edges = edges("train", ds["num_train"])
+    limit = math.sqrt(6.0 / (num_nodes + d))  # GLOROT_UNIFORM over the table shape (initialization.cpp:26-41)
+    table = torch.empty((num_nodes, d), dtype=torch.float32, device=dev).uniform_(-limit, limit)
+    emb = H.InMemory(table)
+    emb.filename = os.path.join(mdir, "embeddings.bin")
+    state = H.InMemory(torch.zeros_like(table))
+    state.filename = os.path.join(mdir, "embeddings_state.bin")
+
+    tr, ev = cfg["training"], cfg["evaluation"]
+
+    def sampler(ns):
+        return H.CorruptNodeNegativeSampler(int(ns["num_chunks"]), int(ns["negatives_per_positive"]), float(ns["degree_fraction"]),
+                                            bool(ns["filtered"]), getattr(H.LocalFilterMode, ns.get("local_filter_mode", "DEG")), gen)
+
+    loader = H.DataLoader(train_edges, emb, state, sampler(tr["negative_sampling"]), gen, int(tr["batch_size"]), True)
+    trainer = H.SynchronousTrainer(loader, model)
+    evals = {}
+    for split, key in (("validation", "num_valid"), ("test", "num_test")):
+        n = int(ds.get(key, -1))
+        if n > 0 and os.path.exists(_edge_file(ddir, split)):
+            evals[split] = H.SynchronousEvaluator(H.DataLoader(edges(split, n), emb, None, sampler(ev["negative_sampling"]), gen, int(ev["batch_size"]), False), model)
+
+    results = []
+    for epoch in range(1, int(tr["num_epochs"]) + 1):
+        log("################ Starting training epoch %d ################" % epoch)
+        trainer.train(1)
+        log("Epoch Runtime: %dms" % int(trainer.last_epoch_seconds * 1e3))
+        log("Edges per Second: %.2f" % trainer.last_edges_per_second)  # trainer.cpp:156-159
+        rec = {"epoch": epoch, "edges_per_second": trainer.last_edges_per_second}
+        if epoch % int(ev.get("epochs_per_eval", 1)) == 0:
+            for split, e in evals.items():
+                t0 = time.time()
+                r = e.evaluate()
+                names = ["MRR", "Mean Rank", "Hits@1", "Hits@3", "Hits@5", "Hits@10", "Hits@50", "Hits@100"]
+                log("%s evaluation (%.0f ms): %s" % (split, (time.time() - t0) * 1e3, ", ".join("%s: %.6f" % kv for kv in zip(names, r))))
+                rec[split] = dict(zip(names, r))
+        results.append(rec)
+    if cfg["storage"].get("save_model", True):  # Checkpointer::save (checkpointer.cpp:39-54): node table + state as raw binaries
+        emb.write()
+        state.write()
+        torch.save({"relation_embeddings": decoder.relations.cpu(),
+                    "inverse_relation_embeddings": None if decoder.inverse_relations is None else decoder.inverse_relations.cpu()},
+                   os.path.join(mdir, "model.pt"))
+    return results
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) != 1:
+        print("usage: marius_train <config.yaml>")
+        return 2
+    marius_train(C.load_config(argv[0]))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,213 @@
+"""GPU tests of the C++ host layer (marius_amd.host()): the reference's operator API over the HIP kernels.
+
+Written to read like the reference's own binding tests (test/python/bindings/integration/test_nn.py, test_data.py) plus
+whole-epoch parity of SynchronousTrainer against the CPU oracle."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import lp_oracle as O
+from oracle.cpu_step import CpuLinkPredictionStep
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def M():
+    import marius_amd
+
+    return marius_amd.host()
+
+
+def close(got, want, rtol=1e-4):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    atol = rtol * max(want.abs().max().item(), 1e-30)
+    assert got.shape == want.shape
+    assert bool(((got - want).abs() <= atol + rtol * want.abs()).all()), (got - want).abs().max().item()
+
+
+def test_forward_lp_known_scores(M, dev):
+    """test_nn.py:148-160: DistMult, no inverse relations, expected [12.5, -3.75, -0.25]."""
+    k = json.load(open(os.path.join(GOLD, "ref_known_answers.json")))["distmult_forward"]
+    decoder = M.DistMult(k["num_relations"], k["embedding_dim"], dev, False, M.EdgeDecoderMethod.ONLY_POS)
+    model = M.Model(decoder, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+    batch = M.Batch(False)
+    batch.node_embeddings = torch.tensor(k["node_embeddings"], device=dev)
+    batch.edges = torch.tensor(k["batch_edges"], device=dev)
+    scores, _, inv, _ = model.forward_lp(batch, False)
+    assert torch.equal(scores.cpu(), torch.tensor(k["expected_scores"]))
+    assert inv is None
+
+
+def test_accumulate_gradients_known(M, dev):
+    """test_data.py:34-47."""
+    k = json.load(open(os.path.join(GOLD, "ref_known_answers.json")))["accumulate_gradients"]
+    b = M.Batch(True)
+    b.node_embeddings = torch.tensor(k["node_embeddings"], device=dev)
+    b.node_embeddings_grad = torch.tensor(k["grad"], device=dev)
+    b.node_embeddings_state = torch.tensor(k["state"], device=dev)
+    b.accumulateGradients(k["learning_rate"])
+    assert b.node_embeddings_state is None
+    grad = torch.tensor(k["grad"])
+    assert torch.equal(b.node_state_update.cpu(), grad.pow(2))
+    expected = -1.0 * (grad / (grad.pow(2).sqrt().add_(1e-10)))
+    assert torch.equal(b.node_gradients.cpu(), expected)
+
+
+def test_operators_and_comparators_match_reference_vectors(M, dev):
+    g = np.load(os.path.join(GOLD, "ref_scores_golden.npz"))
+    e, r, o = [torch.from_numpy(g[k]).to(dev) for k in ("op_in_e", "op_in_r", "cmp_in_o")]
+    for cls, name in [(M.HadamardOperator, "hadamard"), (M.ComplexHadamardOperator, "complex_hadamard"), (M.TranslationOperator, "translation")]:
+        close(cls()(e, r), torch.from_numpy(g["op_" + name]), rtol=1e-6)
+    for cls, name in [(M.DotCompare, "dot"), (M.L2Compare, "l2"), (M.CosineCompare, "cosine")]:
+        close(cls()(e, o), torch.from_numpy(g["cmp_same_" + name]))
+        for B in (12, 10):
+            src, negs = torch.from_numpy(g["neg_in_src_%d" % B]).to(dev), torch.from_numpy(g["neg_in_negs_%d" % B]).to(dev)
+            close(cls()(src, negs), torch.from_numpy(g["cmp_neg_%s_%d" % (name, B)]))
+
+
+def test_softmax_ce_and_errors(M, dev):
+    pos, neg = torch.randn(37, device=dev), torch.randn(37, 13, device=dev)
+    for red in ("sum", "mean"):
+        got = M.SoftmaxCrossEntropy(red)(pos, neg, True)
+        close(got.reshape(1), O.softmax_cross_entropy(pos.cpu(), neg.cpu(), red).reshape(1))
+    with pytest.raises(M.MariusRuntimeException, match="must be scores"):
+        M.SoftmaxCrossEntropy("sum")(pos, neg, False)
+    with pytest.raises(M.MariusRuntimeException, match="3 or 2 column"):
+        M.node_corrupt_forward(M.DistMult(2, 4, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE), torch.zeros(3, 4, dtype=torch.int64, device=dev),
+                               torch.randn(5, 4, device=dev), torch.zeros(1, 2, dtype=torch.int64, device=dev))
+
+
+def test_storage_roundtrip_and_index_ops(M, dev, tmp_path):
+    t = torch.randn(100, 12)
+    path = str(tmp_path / "embeddings.bin")
+    t.numpy().tofile(path)
+    st = M.InMemory(path, 100, 12, torch.float32, dev)
+    st.load()
+    ids = torch.tensor([3, 17, 42, 99], device=dev)
+    assert torch.equal(st.indexRead(ids).cpu(), t[ids.cpu()])
+    st.indexAdd(ids, torch.ones(4, 12, device=dev))
+    st.write()
+    back = torch.from_numpy(np.fromfile(path, dtype=np.float32).reshape(100, 12))
+    want = t.clone()
+    want[ids.cpu()] += 1
+    assert torch.equal(back, want)
+    with pytest.raises(RuntimeError):
+        st.indexRead(torch.zeros(2, 2, dtype=torch.int64, device=dev))
+
+
+def _setup(M, dev, decoder, num_nodes, R, d, B, C, N, E, seed, f=0.0):
+    g = torch.Generator().manual_seed(1)
+    table = (torch.rand(num_nodes, d, generator=g) - 0.5) * 0.6
+    edges_all = torch.stack([torch.randint(num_nodes, (E,), generator=g), torch.randint(R, (E,), generator=g),
+                             torch.randint(num_nodes, (E,), generator=g)], 1)
+    gen = M.MariusGenerator(seed)
+    emb = M.InMemory(table.to(dev))
+    state = M.InMemory(torch.zeros(num_nodes, d, device=dev))
+    edges = M.InMemory(edges_all.to(torch.int32).to(dev))
+    sampler = M.CorruptNodeNegativeSampler(C, N, f, False, M.LocalFilterMode.DEG, gen)
+    loader = M.DataLoader(edges, emb, state, sampler, gen, B, True)
+    dec = {"DISTMULT": M.DistMult, "COMPLEX": M.ComplEx, "TRANSE": M.TransE}[decoder](R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+    model = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+    model.setup_optimizers(0.1)
+    model.sparse_lr = 0.1
+    return table, edges_all, emb, state, loader, model
+
+
+@pytest.mark.parametrize("decoder,f,fused", [("COMPLEX", 0.0, True), ("COMPLEX", 0.0, False), ("DISTMULT", 0.5, True), ("TRANSE", 0.0, False)])
+def test_trainer_epoch_matches_cpu_reference_path(M, dev, decoder, f, fused):
+    num_nodes, R, d, B, C, N, E, seed = 4000, 11, 20, 250, 5, 40, 1000, 123
+    table, edges_all, emb, state, loader, model = _setup(M, dev, decoder, num_nodes, R, d, B, C, N, E, seed, f)
+    trainer = M.SynchronousTrainer(loader, model)
+    trainer.fused_update = fused
+    trainer.train(1)
+    # the reference's CPU path with the same global generator stream
+    cpu = CpuLinkPredictionStep(decoder, table.clone(), torch.zeros(num_nodes, d), R, B, C, N, degree_fraction=f)
+    torch.manual_seed(seed)
+    perm = torch.randperm(E)
+    assert torch.equal(loader.active_perm.cpu(), perm)
+    for s in range(E // B):
+        cpu.step(edges_all[perm[s * B:(s + 1) * B]])
+    close(emb.data, cpu.table, rtol=3e-4)
+    close(state.data, cpu.state, rtol=3e-4)
+    close(model.decoder.relations, cpu.rel, rtol=3e-4)
+    close(model.decoder.inverse_relations, cpu.inv_rel, rtol=3e-4)
+    assert trainer.last_edges_per_second > 0
+
+
+def test_get_batch_matches_reference_dataloader(M, dev):
+    """getBatch: edge slice, negatives (inverse first), map_tensors outputs — all integer work, bit exact."""
+    num_nodes, R, d, B, C, N, E, seed = 3000, 7, 8, 100, 4, 30, 400, 5
+    table, edges_all, emb, state, loader, model = _setup(M, dev, "DISTMULT", num_nodes, R, d, B, C, N, E, seed, 0.5)
+    loader.initializeBatches(True)
+    torch.manual_seed(seed)
+    perm = torch.randperm(E)
+    cpu = CpuLinkPredictionStep("DISTMULT", table.clone(), torch.zeros(num_nodes, d), R, B, C, N, degree_fraction=0.5)
+    for s in range(2):
+        batch = loader.getBatch(True)
+        be = edges_all[perm[s * B:(s + 1) * B]]
+        src_neg, sf = cpu.get_negatives(be, True)
+        dst_neg, df = cpu.get_negatives(be, False)
+        uniq, mapped = O.map_tensors([be[:, 0], be[:, 2], src_neg.flatten(), dst_neg.flatten()])
+        assert torch.equal(batch.src_neg_indices.cpu(), src_neg) and torch.equal(batch.dst_neg_indices.cpu(), dst_neg)
+        assert torch.equal(batch.src_neg_filter.cpu(), sf) and torch.equal(batch.dst_neg_filter.cpu(), df)
+        assert torch.equal(batch.unique_node_indices.cpu(), uniq)
+        assert torch.equal(batch.edges.cpu(), torch.stack([mapped[0], be[:, 1], mapped[1]], 1))
+        assert torch.equal(batch.dst_neg_indices_mapping.cpu(), mapped[3].reshape(C, N))
+        loader.loadGPUParameters(batch)
+        assert torch.equal(batch.node_embeddings.cpu(), table[uniq])
+
+
+def test_evaluator_ranks(M, dev):
+    num_nodes, R, d, B, C, N, E, seed = 500, 3, 8, 50, 1, 100, 200, 9
+    table, edges_all, emb, state, loader, model = _setup(M, dev, "DISTMULT", num_nodes, R, d, B, C, N, E, seed)
+    gen = M.MariusGenerator(seed)
+    ev_loader = M.DataLoader(M.InMemory(edges_all.to(torch.int32).to(dev)), emb, None, M.CorruptNodeNegativeSampler(1, 100, 0.0, False, M.LocalFilterMode.DEG, gen),
+                             gen, B, False)
+    res = M.SynchronousEvaluator(ev_loader, model).evaluate()
+    assert len(res) == 8 and 0 < res[0] <= 1 and res[1] >= 1  # MRR in (0,1], mean rank >= 1
+    pos, neg = torch.randn(20, device=dev), torch.randn(20, 33, device=dev)
+    assert torch.equal(M.LinkPredictionReporter().computeRanks(pos, neg).cpu(), O.compute_ranks(pos.cpu(), neg.cpu()))
+
+
+def test_marius_train_end_to_end(M, dev, tmp_path):
+    """marius_train <config.yaml> on a dataset directory in the reference's on-disk layout."""
+    from marius_amd import config as C
+    from marius_amd.marius_train import marius_train
+
+    num_nodes, R, E = 300, 4, 6000
+    g = torch.Generator().manual_seed(0)
+    src = torch.randint(num_nodes, (E,), generator=g)
+    rel = torch.randint(R, (E,), generator=g)
+    dst = (src * 7 + rel * 13 + 1) % num_nodes  # learnable structure
+    edges = torch.stack([src, rel, dst], 1).to(torch.int32)
+    ddir = tmp_path / "ds"
+    (ddir / "edges").mkdir(parents=True)
+    edges[:5000].numpy().tofile(str(ddir / "edges" / "train_edges.bin"))
+    edges[5000:5500].numpy().tofile(str(ddir / "edges" / "validation_edges.bin"))
+    edges[5500:].numpy().tofile(str(ddir / "edges" / "test_edges.bin"))
+    yaml.safe_dump({"dataset_dir": str(ddir), "num_edges": E, "num_nodes": num_nodes, "num_relations": R, "num_train": 5000, "num_valid": 500,
+                    "num_test": 500}, open(ddir / "dataset.yaml", "w"))
+    cfg_path = tmp_path / "cfg.yaml"
+    yaml.safe_dump({
+        "model": {"learning_task": "LINK_PREDICTION", "random_seed": 3, "encoder": {"layers": [[{"type": "EMBEDDING", "output_dim": 32}]]},
+                  "decoder": {"type": "DISTMULT"}, "loss": {"type": "SOFTMAX_CE", "options": {"reduction": "SUM"}},
+                  "dense_optimizer": {"type": "ADAGRAD", "options": {"learning_rate": 0.1}},
+                  "sparse_optimizer": {"type": "ADAGRAD", "options": {"learning_rate": 0.1}}},
+        "storage": {"device_type": "cuda", "dataset": {"dataset_dir": str(ddir)}, "edges": {"type": "DEVICE_MEMORY"}, "embeddings": {"type": "DEVICE_MEMORY"}},
+        "training": {"batch_size": 500, "negative_sampling": {"num_chunks": 5, "negatives_per_positive": 100}, "num_epochs": 6},
+        "evaluation": {"batch_size": 500, "negative_sampling": {"num_chunks": 1, "negatives_per_positive": 200}},
+    }, open(cfg_path, "w"))
+    cfg = C.load_config(str(cfg_path))
+    assert cfg["training"]["negative_sampling"]["degree_fraction"] == 0.0 and cfg["model"]["decoder"]["options"]["inverse_edges"] is True
+    res = marius_train(cfg, log=lambda *a: None)
+    assert res[-1]["validation"]["MRR"] > res[0]["validation"]["MRR"]  # it learns
+    mdir = cfg["storage"]["model_dir"]
+    assert os.path.getsize(os.path.join(mdir, "embeddings.bin")) == num_nodes * 32 * 4
+    assert os.path.exists(os.path.join(mdir, "embeddings_state.bin")) and os.path.exists(os.path.join(mdir, "full_config.yaml"))
