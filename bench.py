@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--workload", default="freebase86m", choices=sorted(WORKLOADS))
     ap.add_argument("--num-nodes", type=int, default=0, help="override the node count (smaller table for quick tests)")
     ap.add_argument("--edge-dist", default="zipf", choices=["zipf", "uniform"])
+    ap.add_argument("--driver", default="cpp", choices=["cpp", "py"], help="host loop: C++ SynchronousTrainer (default) or the ctypes step driver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     a = ap.parse_args()
@@ -95,15 +96,39 @@ def main():
     table = torch.empty((num_nodes, d), dtype=torch.float32, device=dev).uniform_(-limit, limit, generator=torch.Generator(device=dev).manual_seed(0))
     state = torch.zeros((num_nodes, d), dtype=torch.float32, device=dev)
     edges_all = synth_edges(num_nodes, R, cfg["num_edges"], a.edge_dist, dev)
-    stepper = DeviceLinkPredictionStep(cfg["decoder"], num_nodes, R, d, B, C, N, seed=42, device=dev, node_table=table, node_state=state)
-    perm = stepper.gen.randperm_host(edges_all.size(0)).to(dev)  # setActiveEdges: randperm on the same generator stream
-    stepper.gen.to_device(dev)
-    nbatches = edges_all.size(0) // B
 
-    def run(k0, k):
-        for s in range(k0, k0 + k):
-            edges = H.select_edges(edges_all, perm, (s % nbatches) * B, B)
-            stepper.step(edges)
+    if a.driver == "cpp":
+        # host side in C++ on libtorch (marius_amd/csrc/host): DataLoader / Model / SynchronousTrainer of the reference's API
+        import marius_amd
+        M = marius_amd.host()
+        gen = M.MariusGenerator(42)
+        sampler = M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen)
+        loader = M.DataLoader(M.InMemory(edges_all), M.InMemory(table), M.InMemory(state), sampler, gen, B, True)
+        dec = {"DISTMULT": M.DistMult, "COMPLEX": M.ComplEx, "TRANSE": M.TransE}[cfg["decoder"]](R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+        model = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+        model.setup_optimizers(0.1)
+        model.sparse_lr = 0.1
+        trainer = M.SynchronousTrainer(loader, model)
+        loader.initializeBatches(True)  # setActiveEdges: randperm on the same generator stream
+
+        def run(k0, k):
+            trainer.train_steps(k)
+
+        def last_stats():
+            return int(loader.num_unique.item()), float(model.loss[0].item()), model, None
+    else:
+        stepper = DeviceLinkPredictionStep(cfg["decoder"], num_nodes, R, d, B, C, N, seed=42, device=dev, node_table=table, node_state=state)
+        perm = stepper.gen.randperm_host(edges_all.size(0)).to(dev)
+        stepper.gen.to_device(dev)
+        nbatches = edges_all.size(0) // B
+
+        def run(k0, k):
+            for s in range(k0, k0 + k):
+                edges = H.select_edges(edges_all, perm, (s % nbatches) * B, B)
+                stepper.step(edges)
+
+        def last_stats():
+            return int(stepper.um.count.item()), float(stepper.W.loss_values()[0].item()), None, stepper
 
     run(0, a.warmup)
     torch.cuda.synchronize()
@@ -119,13 +144,12 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     pos_eps = B * a.steps / dt
     scored_eps = pos_eps * (2 + 2 * N)
-    U = int(stepper.um.count.item())
-    loss = float(stepper.W.loss_values()[0].item())
+    U, loss, _, _ = last_stats()
 
     # ---- roofline of the kernels, from HIP events recorded on the launch stream inside the timed region
-    Bp = stepper.W.layout.Bp
+    Bp = C * math.ceil(B / C)
     contraction_flops = 2.0 * Bp * N * d * 2  # one [Bc x d] x [d x N] contraction per chunk, both directions
-    L = stepper.L
+    L = 2 * B + 2 * C * N
     alg = {  # algorithmic work per launch
         "lp_scores": ("mfma", contraction_flops),
         "lp_grad_adj": ("mfma", contraction_flops),
@@ -175,7 +199,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %s d=%d in-memory, B=%d C=%d N=%d inverse_edges, SoftmaxCE SUM, Adagrad lr 0.1, %s edges" % (
             a.workload, cfg["decoder"], d, B, C, N, a.edge_dist), "num_nodes": num_nodes, "num_relations": R, "num_edges": cfg["num_edges"],
-            "parallelism": "single GPU"},
+            "parallelism": "single GPU", "host": "C++ SynchronousTrainer (libtorch)" if a.driver == "cpp" else "python ctypes driver"},
         "positive_edges_per_s": round(pos_eps, 1), "unique_rows_last_batch": U, "loss_last_batch": loss,
         "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
     }

@@ -25,6 +25,8 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("randperm", &MariusGenerator::randperm)
         .def("raw_words", [](MariusGenerator& g, int64_t n, torch::Device d) { return g.raw_words(n, d); })
         .def("to_host", &MariusGenerator::to_host)
+        .def_readwrite("prefetch", &MariusGenerator::prefetch_)
+        .def_readwrite("pool_requests", &MariusGenerator::pool_requests_)
         .def_readwrite("state_host", &MariusGenerator::state_host_);
 
     py::class_<InMemory, std::shared_ptr<InMemory>>(m, "InMemory")
@@ -181,11 +183,13 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("loadGPUParameters", &DataLoader::loadGPUParameters)
         .def("updateEmbeddings", &DataLoader::updateEmbeddings, py::arg("batch"), py::arg("gpu") = true)
         .def("getNumEdges", &DataLoader::getNumEdges)
-        .def_readonly("active_perm", &DataLoader::active_perm_);
+        .def_readonly("active_perm", &DataLoader::active_perm_)
+        .def_readonly("num_unique", &DataLoader::count_);
 
     py::class_<SynchronousTrainer, std::shared_ptr<SynchronousTrainer>>(m, "SynchronousTrainer")
         .def(py::init<std::shared_ptr<DataLoader>, std::shared_ptr<Model>>())
         .def("train", &SynchronousTrainer::train, py::arg("num_epochs") = 1, py::call_guard<py::gil_scoped_release>())
+        .def("train_steps", &SynchronousTrainer::train_steps, py::arg("n"), py::call_guard<py::gil_scoped_release>())
         .def_readwrite("fused_update", &SynchronousTrainer::fused_update_)
         .def_readonly("last_epoch_seconds", &SynchronousTrainer::last_epoch_seconds_)
         .def_readonly("last_edges_per_second", &SynchronousTrainer::last_edges_per_second_);

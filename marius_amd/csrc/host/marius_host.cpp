@@ -2,6 +2,7 @@
 #include "marius_host.h"
 
 #include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
 
 #include <chrono>
 #include <cmath>
@@ -41,15 +42,46 @@ static torch::TensorOptions i32(torch::Device d) { return torch::TensorOptions()
 static torch::TensorOptions f32(torch::Device d) { return torch::TensorOptions().dtype(torch::kFloat32).device(d); }
 
 // ------------------------------------------------------------------------------------------------ generator
+#define HIPCHECK(x)                                                                                         \
+    do {                                                                                                    \
+        hipError_t e_ = (x);                                                                                \
+        if (e_ != hipSuccess) throw MariusRuntimeException(std::string("HIP: ") + hipGetErrorString(e_));   \
+    } while (0)
+
 MariusGenerator::MariusGenerator(uint64_t seed) {
     state_host_ = torch::zeros({MARIUS_MT_STATE_WORDS}, torch::kInt32);
     marius_mt19937_seed_host((uint32_t*)state_host_.data_ptr<int32_t>(), seed);
 }
-void MariusGenerator::to_host() {
-    if (state_dev_.defined()) {
-        state_host_ = state_dev_.cpu();
-        state_dev_ = Tensor();
+MariusGenerator::~MariusGenerator() {
+    for (auto& p : pools_) {
+        if (p.ready) hipEventDestroy((hipEvent_t)p.ready);
+        if (p.done) hipEventDestroy((hipEvent_t)p.done);
     }
+    if (side_stream_) hipStreamDestroy((hipStream_t)side_stream_);
+}
+void MariusGenerator::drop_pools() {
+    for (auto& p : pools_) {
+        p.filled = p.waited = p.has_done = false;
+        p.used = 0;
+    }
+    cur_ = 0;
+}
+void MariusGenerator::to_host() {
+    if (!state_dev_.defined()) return;
+    if (side_stream_) HIPCHECK(hipStreamSynchronize((hipStream_t)side_stream_));
+    Pool& p = pools_[cur_];
+    if (prefetch_ && p.filled) {
+        // the device state has run ahead: rewind to the start of the pool being consumed and replay what was consumed
+        state_host_ = p.state_before.cpu();
+        if (p.used > 0) {
+            Tensor scratch = torch::empty({p.used}, torch::kInt32);
+            marius_mt19937_fill_host((uint32_t*)state_host_.data_ptr<int32_t>(), (uint32_t*)scratch.data_ptr<int32_t>(), p.used);
+        }
+    } else {
+        state_host_ = state_dev_.cpu();
+    }
+    state_dev_ = Tensor();
+    drop_pools();
 }
 void MariusGenerator::to_device(torch::Device dev) {
     if (!state_dev_.defined()) state_dev_ = state_host_.to(dev);
@@ -60,11 +92,91 @@ Tensor MariusGenerator::randperm(int64_t n) {
     mcheck(marius_mt19937_randperm_host((uint32_t*)state_host_.data_ptr<int32_t>(), out.data_ptr<int64_t>(), n));
     return out;
 }
+void MariusGenerator::fill_pool(int i, torch::Device dev) {
+    Pool& p = pools_[i];
+    hipStream_t side = (hipStream_t)side_stream_;
+    if (p.has_done) HIPCHECK(hipStreamWaitEvent(side, (hipEvent_t)p.done, 0));  // previous contents fully consumed
+    HIPCHECK(hipMemcpyAsync(p.state_before.data_ptr(), state_dev_.data_ptr(), MARIUS_MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, side));
+    mcheck(marius_mt19937_fill((uint32_t*)state_dev_.data_ptr<int32_t>(), (uint32_t*)p.buf.data_ptr<int32_t>(), p.size, (marius_stream_t)side));
+    HIPCHECK(hipEventRecord((hipEvent_t)p.ready, side));
+    p.filled = true;
+    p.waited = false;
+    p.used = 0;
+    p.has_done = false;
+    (void)dev;
+}
 Tensor MariusGenerator::raw_words(int64_t n, torch::Device dev) {
     to_device(dev);
-    Tensor out = torch::empty({n}, i32(dev));
-    mcheck(marius_mt19937_fill((uint32_t*)state_dev_.data_ptr<int32_t>(), (uint32_t*)out.data_ptr<int32_t>(), n, cur_stream()));
-    return out;
+    hipStream_t main = (hipStream_t)cur_stream();
+    if (!prefetch_) {
+        Tensor out = torch::empty({n}, i32(dev));
+        mcheck(marius_mt19937_fill((uint32_t*)state_dev_.data_ptr<int32_t>(), (uint32_t*)out.data_ptr<int32_t>(), n, (marius_stream_t)main));
+        return out;
+    }
+    if (!side_stream_) {
+        hipStream_t s;
+        HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        side_stream_ = s;
+        // the state upload / earlier direct fills were enqueued on the main stream: order the side stream after them
+        hipEvent_t e;
+        HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHECK(hipEventRecord(e, main));
+        HIPCHECK(hipStreamWaitEvent(s, e, 0));
+        HIPCHECK(hipEventDestroy(e));
+    }
+    const int64_t want = std::max<int64_t>(n * pool_requests_, 1 << 16);
+    for (int i = 0; i < 2; ++i) {
+        Pool& p = pools_[i];
+        if (!p.buf.defined() || p.size < n || p.buf.device() != dev) {
+            if (p.filled) throw MariusRuntimeException("MariusGenerator: request larger than the run-ahead pool");
+            p.buf = torch::empty({want}, i32(dev));
+            p.state_before = torch::empty({MARIUS_MT_STATE_WORDS}, i32(dev));
+            p.size = want;
+            if (!p.ready) {
+                hipEvent_t a, b;
+                HIPCHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+                HIPCHECK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+                p.ready = a;
+                p.done = b;
+            }
+        }
+    }
+    if (!pools_[cur_].filled) {  // cold start: fill the current pool and the next one
+        fill_pool(cur_, dev);
+        fill_pool(cur_ ^ 1, dev);
+    }
+    auto take = [&](int64_t cnt) {
+        Pool& p = pools_[cur_];
+        if (!p.waited) {
+            HIPCHECK(hipStreamWaitEvent(main, (hipEvent_t)p.ready, 0));
+            p.waited = true;
+        }
+        Tensor v = p.buf.narrow(0, p.used, cnt);
+        p.used += cnt;
+        return v;
+    };
+    auto advance = [&]() {  // current pool exhausted: hand it back to the producer and move on
+        Pool& p = pools_[cur_];
+        HIPCHECK(hipEventRecord((hipEvent_t)p.done, main));
+        p.has_done = true;
+        p.filled = false;
+        const int old = cur_;
+        cur_ ^= 1;
+        if (!pools_[cur_].filled) fill_pool(cur_, dev);
+        fill_pool(old, dev);  // becomes the pool after the one now current
+    };
+    Pool& p = pools_[cur_];
+    if (p.size - p.used >= n) {
+        Tensor v = take(n);
+        if (p.used == p.size) advance();
+        return v;
+    }
+    // request straddles two pools
+    const int64_t first = p.size - p.used;
+    Tensor a = first > 0 ? take(first).clone() : Tensor();
+    advance();
+    Tensor b = take(n - first);
+    return first > 0 ? torch::cat({a, b}) : b;
 }
 
 // ------------------------------------------------------------------------------------------------ storage
@@ -646,27 +758,36 @@ void DataLoader::updateEmbeddings(shared_ptr<Batch> batch, bool gpu) {
 }
 
 // ------------------------------------------------------------------------------------------------ trainer / evaluator
+void SynchronousTrainer::train_one(bool fused) {
+    if (fused) {
+        auto batch = dataloader_->getBatch(/*exact_unique=*/false);  // no host sync anywhere in the step
+        batch->node_embeddings_ = dataloader_->node_embeddings_->indexRead(batch->unique_node_indices_);
+        model_->backward_into_tables(batch, dataloader_->node_embeddings_->data_, dataloader_->node_embeddings_state_->data_);
+    } else {  // API-granular path, call for call the reference's loop (trainer.cpp:106-138)
+        auto batch = dataloader_->getBatch(true);
+        dataloader_->loadGPUParameters(batch);
+        model_->train_batch(batch);
+        dataloader_->updateEmbeddings(batch, true);
+        batch->clear();
+    }
+}
+
 void SynchronousTrainer::train(int num_epochs) {
     for (int epoch = 0; epoch < num_epochs; ++epoch) {
         dataloader_->initializeBatches(true);
         c10::hip::getCurrentHIPStream().synchronize();
         auto t0 = std::chrono::steady_clock::now();
-        while (dataloader_->hasNextBatch()) {
-            if (fused_update_) {
-                auto batch = dataloader_->getBatch(/*exact_unique=*/false);  // no host sync anywhere in the step
-                batch->node_embeddings_ = dataloader_->node_embeddings_->indexRead(batch->unique_node_indices_);
-                model_->backward_into_tables(batch, dataloader_->node_embeddings_->data_, dataloader_->node_embeddings_state_->data_);
-            } else {  // API-granular path, call for call the reference's loop (trainer.cpp:106-138)
-                auto batch = dataloader_->getBatch(true);
-                dataloader_->loadGPUParameters(batch);
-                model_->train_batch(batch);
-                dataloader_->updateEmbeddings(batch, true);
-                batch->clear();
-            }
-        }
+        while (dataloader_->hasNextBatch()) train_one(fused_update_);
         c10::hip::getCurrentHIPStream().synchronize();
         last_epoch_seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         last_edges_per_second_ = (double)dataloader_->getNumEdges() / last_epoch_seconds_;  // trainer.cpp:156-159
+    }
+}
+
+void SynchronousTrainer::train_steps(int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        if (!dataloader_->hasNextBatch()) dataloader_->initializeBatches(true);
+        train_one(fused_update_);
     }
 }
 

@@ -57,12 +57,33 @@ enum class DecoderType { DISTMULT, TRANSE, COMPLEX };
 class MariusGenerator {
    public:
     explicit MariusGenerator(uint64_t seed);
+    ~MariusGenerator();
     Tensor randperm(int64_t n);                       // host int64, consumes the stream like torch::randperm on CPU
     Tensor raw_words(int64_t n, torch::Device dev);   // n raw 32-bit draws on `dev` (int32 tensor), advances the stream
     void to_device(torch::Device dev);
     void to_host();
     Tensor state_host_;  // [625] int32
     Tensor state_dev_;   // defined while the state lives on the device
+    // Run-ahead pools: the single-workgroup MT19937 kernel produces the next `pool_requests_` requests' worth of raw words on a
+    // side stream while the main stream trains (same stream of numbers, produced early; two pools alternate).  to_host() rewinds
+    // to exactly the consumed position, so host draws (randperm at the epoch boundary) stay in sequence.
+    bool prefetch_ = true;
+    int pool_requests_ = 16;
+
+   private:
+    struct Pool {
+        Tensor buf, state_before;
+        int64_t size = 0, used = 0;
+        bool filled = false, waited = false;
+        void* ready = nullptr;  // hipEvent_t: fill finished (side stream)
+        void* done = nullptr;   // hipEvent_t: last consumer enqueued (main stream)
+        bool has_done = false;
+    };
+    Pool pools_[2];
+    int cur_ = 0;
+    void* side_stream_ = nullptr;  // hipStream_t
+    void fill_pool(int i, torch::Device dev);
+    void drop_pools();
 };
 
 // ------------------------------------------------------------------------------------------------ storage (storage.h:35-86)
@@ -339,6 +360,9 @@ class SynchronousTrainer {  // trainer.cpp:94-161
     double last_epoch_seconds_ = 0, last_edges_per_second_ = 0;
     SynchronousTrainer(shared_ptr<DataLoader> dataloader, shared_ptr<Model> model) : dataloader_(dataloader), model_(model) {}
     void train(int num_epochs = 1);
+    // run `n` batches of the current epoch (starting a new epoch when the batches run out); no host synchronisation inside
+    void train_steps(int64_t n);
+    void train_one(bool fused);
 };
 class SynchronousEvaluator {  // evaluator.cpp:58-97
    public:

@@ -126,14 +126,15 @@ def test_trainer_epoch_matches_cpu_reference_path(M, dev, decoder, f, fused):
     table, edges_all, emb, state, loader, model = _setup(M, dev, decoder, num_nodes, R, d, B, C, N, E, seed, f)
     trainer = M.SynchronousTrainer(loader, model)
     trainer.fused_update = fused
-    trainer.train(1)
+    trainer.train(2)  # two epochs: the second randperm must continue the generator stream exactly where the sampler left it
     # the reference's CPU path with the same global generator stream
     cpu = CpuLinkPredictionStep(decoder, table.clone(), torch.zeros(num_nodes, d), R, B, C, N, degree_fraction=f)
     torch.manual_seed(seed)
-    perm = torch.randperm(E)
+    for epoch in range(2):
+        perm = torch.randperm(E)
+        for s in range(E // B):
+            cpu.step(edges_all[perm[s * B:(s + 1) * B]])
     assert torch.equal(loader.active_perm.cpu(), perm)
-    for s in range(E // B):
-        cpu.step(edges_all[perm[s * B:(s + 1) * B]])
     close(emb.data, cpu.table, rtol=3e-4)
     close(state.data, cpu.state, rtol=3e-4)
     close(model.decoder.relations, cpu.rel, rtol=3e-4)
