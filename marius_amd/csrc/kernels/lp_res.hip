@@ -32,7 +32,8 @@ __device__ __forceinline__ float4 mul4(const float4& v, float m) { return make_f
 // =========================================================================================== scores, adj tile resident
 constexpr int R_T = 64;  // output tile 64 x 64 per iteration; 4 waves as 2 x 2, one 32x32 MFMA tile each
 
-template <bool L2>
+// NQ = d / 4 as a compile-time constant (fully unrolled, software-pipelined MFMA chain) or 0 for a runtime K loop
+template <bool L2, int NQ>
 __global__ __launch_bounds__(256, 2) void lp_scores_res_kernel(ScoreArgs a, int ngroups, int nt_per_group, int units_per_cd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const LpDims& D = a.D;
@@ -116,8 +117,24 @@ __global__ __launch_bounds__(256, 2) void lp_scores_res_kernel(ScoreArgs a, int 
         v16f acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        if (!(a.ablate & 2)) {
-#pragma unroll 5
+        if constexpr (NQ > 0) {
+            // operands of step q+1 are read from LDS before the two MFMAs of step q issue (sched_barrier pins that order: left to
+            // itself the compiler re-uses one register pair and waits lgkmcnt(0) before every MFMA pair, exposing the LDS latency)
+            float2 av[2], bv[2];
+            av[0] = *reinterpret_cast<const float2*>(ap);
+            bv[0] = *reinterpret_cast<const float2*>(bp);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q + 1 < NQ) {
+                    av[(q + 1) & 1] = *reinterpret_cast<const float2*>(ap + 4 * (q + 1));
+                    bv[(q + 1) & 1] = *reinterpret_cast<const float2*>(bp + 4 * (q + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mfma32(av[q & 1].x, bv[q & 1].x, acc);
+                acc = mfma32(av[q & 1].y, bv[q & 1].y, acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
             for (int q = 0; q < nq; ++q) {
                 const float2 a2 = *reinterpret_cast<const float2*>(ap + 4 * q);
                 const float2 b2 = *reinterpret_cast<const float2*>(bp + 4 * q);
@@ -126,16 +143,13 @@ __global__ __launch_bounds__(256, 2) void lp_scores_res_kernel(ScoreArgs a, int 
             }
         }
         // tile t+1 (in registers since the previous iteration) -> the other LDS buffer; then put tile t+2 in flight
-        if (t + 1 < T && !(a.ablate & 4)) write_b((t & 1) ? Bs0 : Bs1, t + 1);
-        if (t + 2 < T && !(a.ablate & 4)) {
+        if (t + 1 < T) write_b((t & 1) ? Bs0 : Bs1, t + 1);
+        if (t + 2 < T) {
             issue_b();  // uses ids of tile t+2
             if (t + 3 < T) load_ids(t + 3);
         }
         // epilogue of tile t
-        if (a.ablate & 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]));
-        } else {
+        {
             const int n = (nt0 + t) * R_T + wn * 32 + l31;
             float yy = 0.f;
             if (L2 && n < D.N) yy = a.y2[(int64_t)dir * D.C * D.N + (int64_t)c * D.N + n];
@@ -257,16 +271,31 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
     auto compute = [&](int buf) {
         const float* qp = &Qs[buf][(wave * 16 + l15) * H_QS_MK + 4 * kq];
         const float* bp = &Bs[buf][(4 * kq) * H_BS + l15];
-#pragma unroll 1
-        for (int s = 0; s < H_KC / 16; ++s) {
-            const float4 a4 = *reinterpret_cast<const float4*>(qp + 16 * s);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+        // 8 steps of NT MFMAs; the NT B values (and the A value) of step i+1 are read from LDS before the MFMAs of step i issue
+        float bc[NT], bn[NT];
+        float4 a4 = *reinterpret_cast<const float4*>(qp);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float* brow_p = bp + (16 * s + e) * H_BS;
+        for (int t = 0; t < NT; ++t) bc[t] = bp[16 * t];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = mfma16(av[e], brow_p[16 * t], acc[t]);
+        for (int i = 0; i < H_KC / 4; ++i) {
+            const int s_ = i >> 2, e = i & 3;
+            const float av = (e == 0) ? a4.x : (e == 1) ? a4.y : (e == 2) ? a4.z : a4.w;
+            float4 a4n = a4;
+            if (i + 1 < H_KC / 4) {
+                const int sn = (i + 1) >> 2, en = (i + 1) & 3;
+                const float* brow_p = bp + (16 * sn + en) * H_BS;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bn[t] = brow_p[16 * t];
+                if (en == 0) a4n = *reinterpret_cast<const float4*>(qp + 16 * sn);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma16(av, bc[t], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bc[t] = bn[t];
+            a4 = a4n;
+            (void)s_;
         }
     };
 
@@ -396,15 +425,26 @@ __device__ __forceinline__ void grad_neg16_body(const GradArgs& a, int cd, int u
     auto compute = [&](int buf) {
         const float* qp = &Qs[buf][(4 * kq) * H_QS_KM + wave * 16 + l15];
         const float* bp = &Bs[buf][(4 * kq) * H_BS + l15];
-#pragma unroll 1
-        for (int s = 0; s < H_KC / 16; ++s) {
+        float bc[NT], bn[NT];
+        float ac = qp[0], an = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float av = qp[(16 * s + e) * H_QS_KM];
-                const float* brow_p = bp + (16 * s + e) * H_BS;
+        for (int t = 0; t < NT; ++t) bc[t] = bp[16 * t];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = mfma16(av, brow_p[16 * t], acc[t]);
+        for (int i = 0; i < H_KC / 4; ++i) {
+            if (i + 1 < H_KC / 4) {
+                const int sn = (i + 1) >> 2, en = (i + 1) & 3;
+                const float* brow_p = bp + (16 * sn + en) * H_BS;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bn[t] = brow_p[16 * t];
+                an = qp[(16 * sn + en) * H_QS_KM];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma16(ac, bc[t], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bc[t] = bn[t];
+            ac = an;
         }
     };
 
@@ -486,13 +526,27 @@ bool launch_scores_res(const ScoreArgs& a_in, bool l2, hipStream_t st) {
     const int units = mtiles * ngroups;
     const size_t lds = (size_t)3 * R_T * a.KS * sizeof(float);
     dim3 grid(xcd_grid2(units, a.D.C * a.D.ndir));
-    if (l2) {
-        if (lds > 65536) hipFuncSetAttribute((const void*)lp_scores_res_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lp_scores_res_kernel<true><<<grid, dim3(256), lds, st>>>(a, ngroups, nt_per_group, units);
-    } else {
-        if (lds > 65536) hipFuncSetAttribute((const void*)lp_scores_res_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lp_scores_res_kernel<false><<<grid, dim3(256), lds, st>>>(a, ngroups, nt_per_group, units);
-    }
+#define SCORES_RES_LAUNCH(L2V, NQV)                                                                                                     \
+    do {                                                                                                                                  \
+        if (lds > 65536) hipFuncSetAttribute((const void*)lp_scores_res_kernel<L2V, NQV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        lp_scores_res_kernel<L2V, NQV><<<grid, dim3(256), lds, st>>>(a, ngroups, nt_per_group, units);                                      \
+    } while (0)
+#define SCORES_RES_DISPATCH(L2V)                          \
+    do {                                                  \
+        switch (a.D.d / 4) {                              \
+            case 8: SCORES_RES_LAUNCH(L2V, 8); break;     \
+            case 16: SCORES_RES_LAUNCH(L2V, 16); break;   \
+            case 25: SCORES_RES_LAUNCH(L2V, 25); break;   \
+            case 32: SCORES_RES_LAUNCH(L2V, 32); break;   \
+            default: SCORES_RES_LAUNCH(L2V, 0); break;    \
+        }                                                 \
+    } while (0)
+    if (l2)
+        SCORES_RES_DISPATCH(true);
+    else
+        SCORES_RES_DISPATCH(false);
+#undef SCORES_RES_DISPATCH
+#undef SCORES_RES_LAUNCH
     return true;
 }
 
