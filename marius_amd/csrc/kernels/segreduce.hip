@@ -176,7 +176,30 @@ __global__ __launch_bounds__(256) void seg_fixup_kernel(SegArgs a, Apply apply) 
         for (int e = 0; e < VEC; ++e) acc[it][e] = 0.f;
         if (col < a.d) load_vec<VEC>(a.carry + ((chunk * 2) + (u_last == u_first ? 0 : 1)) * a.dpad + col, acc[it]);
     }
-    for (int64_t ch = chunk + 1; ch <= last_chunk; ++ch) {
+    // a hub segment can span hundreds of chunks: keep FIX_U carry loads in flight per lane instead of one dependent load per chunk
+    constexpr int FIX_U = 8;
+    int64_t ch = chunk + 1;
+    for (; ch + FIX_U - 1 <= last_chunk; ch += FIX_U) {
+        float t[FIX_U][NIT][VEC];
+#pragma unroll
+        for (int j = 0; j < FIX_U; ++j)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int col = (lane + it * 64) * VEC;
+                if (col < a.d) load_vec<VEC>(a.carry + ((ch + j) * 2) * a.dpad + col, t[j][it]);
+            }
+#pragma unroll
+        for (int j = 0; j < FIX_U; ++j)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int col = (lane + it * 64) * VEC;
+                if (col < a.d) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[it][e] += t[j][it][e];
+                }
+            }
+    }
+    for (; ch <= last_chunk; ++ch) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int col = (lane + it * 64) * VEC;
