@@ -156,7 +156,7 @@ def main():
         "lp_grad_neg": ("mfma", contraction_flops),
         "gather_rows": ("hbm", U * d * 4.0 * 2 + U * 8.0),                    # read rows + write batch copy + ids
         "segment_adagrad_scatter": ("hbm", L * d * 4.0 + U * d * 4.0 * 4),    # occurrence grads + r/w of w and s
-        "lp_lse": ("hbm", 2.0 * Bp * N * 4.0),
+        "lp_lse": ("hbm", 2.0 * Bp * (math.ceil(math.ceil(N / 64) / 4) * 8.0 + 12.0)),  # fused SoftmaxCE: only the per-group partials are re-read
         "lp_prep": ("hbm", 2.0 * Bp * d * 4.0 * 4),
         "lp_edge_bwd": ("hbm", 2.0 * B * d * 4.0 * 6),
         "sort_unique": ("hbm", L * (8.0 + 4.0) * 2 * 4),

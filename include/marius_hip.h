@@ -176,6 +176,7 @@ typedef struct marius_lp_layout {
     size_t gocc;      /* [2B + 2CN, d] occurrence gradients in map_tensors order (src, dst, src_neg, dst_neg)    */
     size_t grel[2];   /* [B, d]      per-edge relation gradients (dir 0 -> relations_, dir 1 -> inverse)         */
     size_t aux;       /* scratch (row norms etc.)                                                                */
+    size_t lsepart;   /* [ndir][Bp][groups][2] partial (max, sum exp) of the score epilogue (fused SoftmaxCE)                */
 } marius_lp_layout;
 
 int marius_lp_plan(const marius_lp_desc* desc, marius_lp_layout* layout);

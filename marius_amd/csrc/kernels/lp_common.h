@@ -55,6 +55,7 @@ struct ScoreArgs {
     const float* y2;           // L2
     int KC, KS, nkc, dk;
     int ablate;  // debug only (MARIUS_ABLATE): 1 = skip S stores, 2 = skip MFMAs, 4 = skip negative-tile staging
+    float* lse_part;  // optional [ndir][Bp][ngroups][2]: per (row, negative-tile group) running (max, sum exp) from the score epilogue
     LpDims D;
 };
 
@@ -95,6 +96,13 @@ __device__ __forceinline__ float dscore(float s, float lse, float gscale) {
 bool launch_scores_fast(const ScoreArgs& a, bool l2, hipStream_t st);
 bool launch_grad_adj_fast(const GradArgs& a, bool l2, hipStream_t st);
 bool launch_grad_neg_fast(const GradArgs& a, bool l2, hipStream_t st);
+// geometry of the resident-operand score kernel: 64-column negative tiles, `ntpg` tiles per workgroup, `ngroups` groups per chunk
+inline void scores_res_geometry(int N, int& ntpg, int& ngroups) {
+    const int ntiles = (N + 63) / 64;
+    ntpg = ntiles >= 8 ? 4 : ntiles;
+    ngroups = (ntiles + ntpg - 1) / ntpg;
+}
+bool scores_res_applicable(const float* emb, int64_t emb_ld, int d);
 // resident-operand / 16x16x4 variants (lp_res.hip): additionally d <= 128 for the score kernel
 bool launch_scores_res(const ScoreArgs& a, bool l2, hipStream_t st);
 bool launch_scores_pp(const ScoreArgs& a, bool l2, hipStream_t st);  // ping-pong persistent variant (level 3)

@@ -256,6 +256,22 @@ __global__ __launch_bounds__(256) void lp_lse_kernel(const float* __restrict__ S
     }
 }
 
+// merge the per-group partials of the fused score epilogue with the positive score: lse = log(e^pos + sum_g l_g e^{m_g})
+__global__ __launch_bounds__(256) void lp_lse_merge_kernel(const float* __restrict__ part, int ng, const float* __restrict__ pos, int64_t rows,
+                                                           float* __restrict__ lse, float* __restrict__ rowloss) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const float p = pos[row];
+    const float* pr = part + row * ng * 2;
+    float m = p;
+    for (int g = 0; g < ng; ++g) m = fmaxf(m, pr[2 * g]);
+    float sum = __expf(p - m);
+    for (int g = 0; g < ng; ++g) sum += pr[2 * g + 1] * __expf(pr[2 * g] - m);
+    const float l = m + __logf(sum);
+    lse[row] = l;
+    rowloss[row] = l - p;
+}
+
 // deterministic sum of rowloss: one block per direction -> loss[1 + dir]; lp_loss_total_kernel then writes loss[0] = lhs + rhs
 // (model.cpp:309-312)
 __global__ __launch_bounds__(1024) void lp_loss_reduce_kernel(const float* rowloss, int64_t Bp, float scale, float* loss) {
@@ -622,6 +638,16 @@ static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 // 1 = fast (lp_fast.hip), 0 = generic.
 // MARIUS_KERNELS=generic|fast|res (or MARIUS_NO_FAST=1) selects a lower level for A/B runs and for tests of every code path;
 // a level that does not apply to the shape falls through to the next lower one.
+static int kernel_level();
+// SoftmaxCE partial (max, sum exp) per (row, negative-tile group) come out of the score kernel's epilogue when nothing can change
+// the scores afterwards (no score filter) and the resident-operand kernel runs; marius_lp_loss then only merges the partials.
+static bool lse_fused(const marius_lp_desc* d, const LpDims& D) {
+    const char* e = getenv("MARIUS_NO_FUSED_LSE");
+    if (e && e[0] == '1') return false;
+    if (kernel_level() != 2) return false;
+    if ((d->dst_filter && d->n_dst_filter > 0) || (d->src_filter && d->n_src_filter > 0)) return false;
+    return scores_res_applicable(d->emb, d->emb_ld, D.d);
+}
 static int kernel_level() {
     const char* e = getenv("MARIUS_NO_FAST");
     if (e && e[0] == '1') return 0;
@@ -689,6 +715,11 @@ static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layou
     base = take((size_t)D.B * D.d_ld * 4 * D.ndir);
     for (int dir = 0; dir < D.ndir; ++dir) L->grel[dir] = base + (size_t)dir * D.B * D.d_ld * 4;
     L->aux = take((rows + (size_t)D.C * D.N) * 4 * D.ndir);
+    {
+        int ntpg, ng;
+        scores_res_geometry(D.N, ntpg, ng);
+        L->lsepart = take(rows * (size_t)ng * 2 * 4 * D.ndir);
+    }
     L->total_bytes = off;
     return MARIUS_OK;
 }
@@ -759,6 +790,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     sa.KS = ((sa.KC / 2) & 1) ? sa.KC : sa.KC + 2;  // stride/2 odd -> conflict-free ds_read_b64 across 32 rows
     sa.D = D;
     { const char* ab = getenv("MARIUS_ABLATE"); sa.ablate = ab ? atoi(ab) : 0; }
+    sa.lse_part = lse_fused(desc, D) ? (float*)(ws + L->lsepart) : nullptr;
     dim3 grid((unsigned)cdiv(D.N, F_TN), (unsigned)cdiv(D.Bc, F_TM), (unsigned)(D.C * D.ndir));
     size_t lds = (size_t)(F_TM + F_TN) * sa.KS * sizeof(float);
     {
@@ -799,9 +831,17 @@ extern "C" int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout
     const int64_t rows = D.Bp * D.ndir;
     {
         ProfScope ps(PROF_LP_LSE, st);
-        lp_lse_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>((const float*)(ws + L->neg[0]), D.n_ld,
-                                                                          (const float*)(ws + L->pos[0]), rows, D.N,
-                                                                          (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]));
+        if (lse_fused(desc, D)) {
+            int ntpg, ng;
+            scores_res_geometry(D.N, ntpg, ng);
+            lp_lse_merge_kernel<<<dim3((unsigned)cdiv(rows, 256)), dim3(256), 0, st>>>((const float*)(ws + L->lsepart), ng,
+                                                                                      (const float*)(ws + L->pos[0]), rows,
+                                                                                      (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]));
+        } else {
+            lp_lse_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>((const float*)(ws + L->neg[0]), D.n_ld,
+                                                                              (const float*)(ws + L->pos[0]), rows, D.N,
+                                                                              (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]));
+        }
     }
     rc = check_launch("lp_lse");
     if (rc) return rc;

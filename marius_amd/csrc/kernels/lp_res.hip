@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256, 2) void lp_scores_res_kernel(ScoreArgs a, int 
     float* S = a.S + ((int64_t)dir * D.Bp + (int64_t)c * D.Bc) * D.n_ld;
     const float* ap = As + (wm * 32 + l31) * KS + 2 * h;
     const int nq = D.d >> 2;
+    float run_m = -3.0e38f, run_l = 0.f;  // running (max, sum exp) of this lane's row over the unit's columns
     for (int t = 0; t < T; ++t) {
         const float* bp = ((t & 1) ? Bs1 : Bs0) + (wn * 32 + l31) * KS + 2 * h;
         v16f acc;
@@ -130,16 +131,16 @@ __global__ __launch_bounds__(256, 2) void lp_scores_res_kernel(ScoreArgs a, int 
                     bv[(q + 1) & 1] = *reinterpret_cast<const float2*>(bp + 4 * (q + 1));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                acc = mfma32(av[q & 1].x, bv[q & 1].x, acc);
-                acc = mfma32(av[q & 1].y, bv[q & 1].y, acc);
+                acc = mfma32(bv[q & 1].x, av[q & 1].x, acc);  // swapped: D[n][m], a lane owns ONE row m and 16 columns n
+                acc = mfma32(bv[q & 1].y, av[q & 1].y, acc);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             for (int q = 0; q < nq; ++q) {
                 const float2 a2 = *reinterpret_cast<const float2*>(ap + 4 * q);
                 const float2 b2 = *reinterpret_cast<const float2*>(bp + 4 * q);
-                acc = mfma32(a2.x, b2.x, acc);
-                acc = mfma32(a2.y, b2.y, acc);
+                acc = mfma32(b2.x, a2.x, acc);
+                acc = mfma32(b2.y, a2.y, acc);
             }
         }
         // tile t+1 (in registers since the previous iteration) -> the other LDS buffer; then put tile t+2 in flight
@@ -148,27 +149,79 @@ __global__ __launch_bounds__(256, 2) void lp_scores_res_kernel(ScoreArgs a, int 
             issue_b();  // uses ids of tile t+2
             if (t + 3 < T) load_ids(t + 3);
         }
-        // epilogue of tile t
+        // epilogue of tile t: lane (m = l31, h) holds S[m][nb + 8q + 4h + e] in acc[4q + e]: four 16-B stores per lane, and the
+        // row-wise (max, sum exp) of the SoftmaxCE is lane-local (no cross-lane traffic until the end of the unit)
         {
-            const int n = (nt0 + t) * R_T + wn * 32 + l31;
-            float yy = 0.f;
-            if (L2 && n < D.N) yy = a.y2[(int64_t)dir * D.C * D.N + (int64_t)c * D.N + n];
+            const int m = m0 + wm * 32 + l31;
+            const int nb = (nt0 + t) * R_T + wn * 32 + 4 * h;
+            float xx = 0.f;
+            if (L2 && m < D.Bc) xx = a.x2[(int64_t)dir * D.Bp + (int64_t)c * D.Bc + m];
+            float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 32 + acc_row(r, h);
-                if (m < D.Bc && n < D.N) {
-                    float v = acc[r];
-                    if (L2) {
+                v[r] = acc[r];
+                if (L2) {
 #pragma clang fp contract(off)
-                        const float xx = a.x2[(int64_t)dir * D.Bp + (int64_t)c * D.Bc + m];
-                        const float tt = (xx + yy) - 2.f * v;
-                        v = sqrtf(fmaxf(tt, 1e-8f));
-                    }
-                    S[(int64_t)m * D.n_ld + n] = v;
+                    const int n = nb + 8 * (r >> 2) + (r & 3);
+                    const float yy = (n < D.N) ? a.y2[(int64_t)dir * D.C * D.N + (int64_t)c * D.N + n] : 0.f;
+                    const float tt = (xx + yy) - 2.f * v[r];
+                    v[r] = sqrtf(fmaxf(tt, 1e-8f));
                 }
+            }
+            if (m < D.Bc) {
+                float* srow = S + (int64_t)m * D.n_ld;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nb + 8 * q;
+                    if (n + 3 < D.N) {
+                        *reinterpret_cast<float4*>(srow + n) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < D.N) srow[n + e] = v[4 * q + e];
+                    }
+                }
+            }
+            if (a.lse_part) {
+                float tmax = -3.0e38f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = nb + 8 * (r >> 2) + (r & 3);
+                    if (n < D.N) tmax = fmaxf(tmax, v[r]);
+                }
+                const float mnew = fmaxf(run_m, tmax);
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = nb + 8 * (r >> 2) + (r & 3);
+                    if (n < D.N) sum += __expf(v[r] - mnew);
+                }
+                run_l = run_l * __expf(run_m - mnew) + sum;
+                run_m = mnew;
             }
         }
         __syncthreads();
+    }
+    if (a.lse_part) {
+        // combine the two half-waves (columns +0..3 / +4..7 of every 8), then the two waves that cover the 64-column tile
+        const float m2 = __shfl_xor(run_m, 32, 64), l2 = __shfl_xor(run_l, 32, 64);
+        const float mm = fmaxf(run_m, m2);
+        const float ll = run_l * __expf(run_m - mm) + l2 * __expf(m2 - mm);
+        float* red = smem;  // LDS is free after the last barrier of the tile loop
+        if (h == 0) {
+            red[((wm * 2 + wn) * 32 + l31) * 2] = mm;
+            red[((wm * 2 + wn) * 32 + l31) * 2 + 1] = ll;
+        }
+        __syncthreads();
+        const int m = m0 + wm * 32 + l31;
+        if (wn == 0 && h == 0 && m < D.Bc) {
+            const float ma = red[((wm * 2) * 32 + l31) * 2], la = red[((wm * 2) * 32 + l31) * 2 + 1];
+            const float mb = red[((wm * 2 + 1) * 32 + l31) * 2], lb = red[((wm * 2 + 1) * 32 + l31) * 2 + 1];
+            const float mx = fmaxf(ma, mb);
+            float* out = a.lse_part + ((((int64_t)dir * D.Bp + (int64_t)c * D.Bc + m) * ngroups) + ng) * 2;
+            out[0] = mx;
+            out[1] = la * __expf(ma - mx) + lb * __expf(mb - mx);
+        }
     }
 }
 
@@ -516,13 +569,15 @@ static bool res_ok(const float* emb, int64_t emb_ld, int d) {
     return (d % 4 == 0) && (emb_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(emb) & 15) == 0);
 }
 
+bool scores_res_applicable(const float* emb, int64_t emb_ld, int d) { return res_ok(emb, emb_ld, d) && d <= 128; }
+
 bool launch_scores_res(const ScoreArgs& a_in, bool l2, hipStream_t st) {
-    if (!res_ok(a_in.emb, a_in.emb_ld, a_in.D.d) || a_in.D.d > 128) return false;
+    if (!scores_res_applicable(a_in.emb, a_in.emb_ld, a_in.D.d)) return false;
     ScoreArgs a = a_in;
     a.KS = a.D.d + 2;  // (d + 2) / 2 odd for d % 4 == 0: conflict-free ds_read_b64 across 32 rows
-    const int mtiles = (int)cdiv(a.D.Bc, R_T), ntiles = (int)cdiv(a.D.N, R_T);
-    const int nt_per_group = ntiles >= 8 ? 4 : ntiles;  // 4 negative tiles per workgroup: fine-grained enough to balance 256 CUs
-    const int ngroups = (int)cdiv(ntiles, nt_per_group);
+    const int mtiles = (int)cdiv(a.D.Bc, R_T);
+    int nt_per_group, ngroups;  // 4 negative tiles per workgroup: fine-grained enough to balance 256 CUs
+    scores_res_geometry(a.D.N, nt_per_group, ngroups);
     const int units = mtiles * ngroups;
     const size_t lds = (size_t)3 * R_T * a.KS * sizeof(float);
     dim3 grid(xcd_grid2(units, a.D.C * a.D.ndir));
