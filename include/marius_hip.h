@@ -41,6 +41,8 @@ int marius_profile_reset(void);
 int marius_profile_kernel_count(void);
 const char* marius_profile_kernel_name(int id);
 int marius_profile_read(int id, double* total_ms, int64_t* launches);
+/* debug only: device buffer of >= 256*2*64 uint64 that receives per-phase cycle stamps of the score kernel (NULL = off) */
+int marius_debug_set_timeline(unsigned long long* buf);
 
 /* ------------------------------------------------------------------------------------------------ storage */
 

@@ -55,6 +55,7 @@ struct ScoreArgs {
     const float* y2;           // L2
     int KC, KS, nkc, dk;
     int ablate;  // debug only (MARIUS_ABLATE): 1 = skip S stores, 2 = skip MFMAs, 4 = skip negative-tile staging
+    unsigned long long* dbg;  // debug only: per-phase s_memtime stamps of the first workgroups (MARIUS_DBG_TIMELINE)
     float* lse_part;  // optional [ndir][Bp][ngroups][2]: per (row, negative-tile group) running (max, sum exp) from the score epilogue
     LpDims D;
 };
@@ -103,6 +104,14 @@ inline void scores_res_geometry(int N, int& ntpg, int& ngroups) {
     ngroups = (ntiles + ntpg - 1) / ntpg;
 }
 bool scores_res_applicable(const float* emb, int64_t emb_ld, int d);
+// adj-in-registers score kernel: 32-column negative tiles, 4 tiles (128 columns) per workgroup
+inline void scores_a_geometry(int N, int& ntpg, int& ngroups) {
+    const int ntiles = (N + 31) / 32;
+    ntpg = ntiles >= 8 ? 4 : ntiles;
+    ngroups = (ntiles + ntpg - 1) / ntpg;
+}
+bool scores_a_applicable(const float* emb, int64_t emb_ld, int d);
+bool launch_scores_a(const ScoreArgs& a, bool l2, hipStream_t st);
 // resident-operand / 16x16x4 variants (lp_res.hip): additionally d <= 128 for the score kernel
 bool launch_scores_res(const ScoreArgs& a, bool l2, hipStream_t st);
 bool launch_scores_pp(const ScoreArgs& a, bool l2, hipStream_t st);  // ping-pong persistent variant (level 3)

@@ -639,15 +639,31 @@ static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 // MARIUS_KERNELS=generic|fast|res (or MARIUS_NO_FAST=1) selects a lower level for A/B runs and for tests of every code path;
 // a level that does not apply to the shape falls through to the next lower one.
 static int kernel_level();
+static unsigned long long* g_dbg_timeline = nullptr;
 // SoftmaxCE partial (max, sum exp) per (row, negative-tile group) come out of the score kernel's epilogue when nothing can change
 // the scores afterwards (no score filter) and the resident-operand kernel runs; marius_lp_loss then only merges the partials.
-static bool lse_fused(const marius_lp_desc* d, const LpDims& D) {
-    const char* e = getenv("MARIUS_NO_FUSED_LSE");
-    if (e && e[0] == '1') return false;
-    if (kernel_level() != 2) return false;
-    if ((d->dst_filter && d->n_dst_filter > 0) || (d->src_filter && d->n_src_filter > 0)) return false;
-    return scores_res_applicable(d->emb, d->emb_ld, D.d);
+// which level-2 score kernel runs: 'a' (adj fragments in registers; default) or 'r' (resident adj tile in LDS; MARIUS_SCORES=res)
+static char scores_variant(const marius_lp_desc* d, const LpDims& D) {
+    const char* v = getenv("MARIUS_SCORES");
+    const bool want_res = v && v[0] == 'r';
+    if (!want_res && scores_a_applicable(d->emb, d->emb_ld, D.d)) return 'a';
+    if (scores_res_applicable(d->emb, d->emb_ld, D.d)) return 'r';
+    return 0;
 }
+// number of column groups of the fused SoftmaxCE partials, 0 when the loss must be computed from the materialised scores
+static int lse_fused_groups(const marius_lp_desc* d, const LpDims& D) {
+    const char* e = getenv("MARIUS_NO_FUSED_LSE");
+    if (e && e[0] == '1') return 0;
+    if (kernel_level() != 2) return 0;
+    if ((d->dst_filter && d->n_dst_filter > 0) || (d->src_filter && d->n_src_filter > 0)) return 0;
+    int ntpg, ng;
+    const char v = scores_variant(d, D);
+    if (v == 'a') scores_a_geometry(D.N, ntpg, ng);
+    else if (v == 'r') scores_res_geometry(D.N, ntpg, ng);
+    else return 0;
+    return ng;
+}
+static bool lse_fused(const marius_lp_desc* d, const LpDims& D) { return lse_fused_groups(d, D) > 0; }
 static int kernel_level() {
     const char* e = getenv("MARIUS_NO_FAST");
     if (e && e[0] == '1') return 0;
@@ -716,9 +732,8 @@ static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layou
     for (int dir = 0; dir < D.ndir; ++dir) L->grel[dir] = base + (size_t)dir * D.B * D.d_ld * 4;
     L->aux = take((rows + (size_t)D.C * D.N) * 4 * D.ndir);
     {
-        int ntpg, ng;
-        scores_res_geometry(D.N, ntpg, ng);
-        L->lsepart = take(rows * (size_t)ng * 2 * 4 * D.ndir);
+        const size_t ng = (size_t)(D.N + 127) / 128 + 1;  // upper bound over the score-kernel variants
+        L->lsepart = take(rows * ng * 2 * 4 * D.ndir);
     }
     L->total_bytes = off;
     return MARIUS_OK;
@@ -791,12 +806,14 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     sa.D = D;
     { const char* ab = getenv("MARIUS_ABLATE"); sa.ablate = ab ? atoi(ab) : 0; }
     sa.lse_part = lse_fused(desc, D) ? (float*)(ws + L->lsepart) : nullptr;
+    sa.dbg = g_dbg_timeline;
     dim3 grid((unsigned)cdiv(D.N, F_TN), (unsigned)cdiv(D.Bc, F_TM), (unsigned)(D.C * D.ndir));
     size_t lds = (size_t)(F_TM + F_TN) * sa.KS * sizeof(float);
     {
         ProfScope ps(PROF_LP_SCORES, st);
         const int lvl = kernel_level();
-        if (!((lvl >= 3 && launch_scores_pp(sa, l2, st)) || (lvl >= 2 && launch_scores_res(sa, l2, st)) || (lvl >= 1 && launch_scores_fast(sa, l2, st)))) {
+        if (!((lvl >= 3 && launch_scores_pp(sa, l2, st)) || (lvl == 2 && scores_variant(desc, D) == 'a' && launch_scores_a(sa, l2, st)) ||
+              (lvl >= 2 && launch_scores_res(sa, l2, st)) || (lvl >= 1 && launch_scores_fast(sa, l2, st)))) {
             if (l2)
                 lp_scores_kernel<true><<<grid, dim3(256), lds, st>>>(sa);
             else
@@ -832,8 +849,7 @@ extern "C" int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout
     {
         ProfScope ps(PROF_LP_LSE, st);
         if (lse_fused(desc, D)) {
-            int ntpg, ng;
-            scores_res_geometry(D.N, ntpg, ng);
+            const int ng = lse_fused_groups(desc, D);
             lp_lse_merge_kernel<<<dim3((unsigned)cdiv(rows, 256)), dim3(256), 0, st>>>((const float*)(ws + L->lsepart), ng,
                                                                                       (const float*)(ws + L->pos[0]), rows,
                                                                                       (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]));
@@ -965,4 +981,10 @@ extern "C" int marius_softmax_ce(const float* pos, const float* neg, int64_t row
     lp_loss_reduce_kernel<<<dim3(1), dim3(1024), 0, st>>>(rowloss, rows, reduction == MARIUS_REDUCE_MEAN ? 1.f / (float)rows : 1.f, loss);
     lp_loss_total_kernel<<<dim3(1), dim3(1), 0, st>>>(1, loss);
     return check_launch("softmax_ce");
+}
+
+// debug only: device buffer (>= 256 * 2 * 64 u64) receiving per-phase cycle stamps of the score kernel; NULL disables
+extern "C" int marius_debug_set_timeline(unsigned long long* buf) {
+    g_dbg_timeline = buf;
+    return MARIUS_OK;
 }

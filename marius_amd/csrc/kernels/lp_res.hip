@@ -8,6 +8,8 @@
 //     padded to 112 instead of 128 (v_mfma_f32_16x16x4_f32), K streamed in chunks of 32 through a double-buffered LDS
 //     ring (one barrier per chunk), V = dL/dS recomputed from S while staging.
 // All three use the XCD-aware block decoding of lp_fast.hip.  No atomics; every output element has one owner.
+#include <cstdlib>
+
 #include "lp_common.h"
 
 namespace marius {
@@ -40,6 +42,12 @@ __global__ __launch_bounds__(256, 2) void lp_scores_res_kernel(ScoreArgs a, int 
     int cd, unit;
     if (!decode_block2(blockIdx.x, units_per_cd, D.C * D.ndir, cd, unit)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // debug timeline: entry stamp + 5 stamps per tile for the first 256 workgroups of XCD 0 (wave 0 and wave 3 only)
+    unsigned long long* dbg = (a.dbg && blockIdx.x < 2048 && (blockIdx.x & 7) == 0 && lane == 0 && (wave == 0 || wave == 3))
+                                  ? a.dbg + ((size_t)(blockIdx.x >> 3) * 2 + (wave ? 1 : 0)) * 64 : nullptr;
+    int dbi = 0;
+#define STAMP() do { if (dbg && dbi < 64) dbg[dbi++] = __builtin_readcyclecounter(); } while (0)
+    STAMP();
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int dir = cd / D.C, c = cd - dir * D.C;
@@ -113,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void lp_scores_res_kernel(ScoreArgs a, int 
     const float* ap = As + (wm * 32 + l31) * KS + 2 * h;
     const int nq = D.d >> 2;
     float run_m = -3.0e38f, run_l = 0.f;  // running (max, sum exp) of this lane's row over the unit's columns
+    STAMP();
     for (int t = 0; t < T; ++t) {
         const float* bp = ((t & 1) ? Bs1 : Bs0) + (wn * 32 + l31) * KS + 2 * h;
         v16f acc;
@@ -143,12 +152,15 @@ __global__ __launch_bounds__(256, 2) void lp_scores_res_kernel(ScoreArgs a, int 
                 acc = mfma32(b2.y, a2.y, acc);
             }
         }
+        STAMP();  // after the MFMA chain issued
         // tile t+1 (in registers since the previous iteration) -> the other LDS buffer; then put tile t+2 in flight
-        if (t + 1 < T) write_b((t & 1) ? Bs0 : Bs1, t + 1);
-        if (t + 2 < T) {
+        if (t + 1 < T && !(a.ablate & 4)) write_b((t & 1) ? Bs0 : Bs1, t + 1);
+        STAMP();  // after LDS writes (includes the wait for the loads issued one tile ago)
+        if (t + 2 < T && !(a.ablate & 4)) {
             issue_b();  // uses ids of tile t+2
             if (t + 3 < T) load_ids(t + 3);
         }
+        STAMP();  // after issuing the next loads
         // epilogue of tile t: lane (m = l31, h) holds S[m][nb + 8q + 4h + e] in acc[4q + e]: four 16-B stores per lane, and the
         // row-wise (max, sum exp) of the SoftmaxCE is lane-local (no cross-lane traffic until the end of the unit)
         {
@@ -164,6 +176,477 @@ __global__ __launch_bounds__(256, 2) void lp_scores_res_kernel(ScoreArgs a, int 
 #pragma clang fp contract(off)
                     const int n = nb + 8 * (r >> 2) + (r & 3);
                     const float yy = (n < D.N) ? a.y2[(int64_t)dir * D.C * D.N + (int64_t)c * D.N + n] : 0.f;
+                    const float tt = (xx + yy) - 2.f * v[r];
+                    v[r] = sqrtf(fmaxf(tt, 1e-8f));
+                }
+            }
+            if (m < D.Bc && !(a.ablate & 1)) {
+                float* srow = S + (int64_t)m * D.n_ld;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nb + 8 * q;
+                    if (n + 3 < D.N) {
+                        *reinterpret_cast<float4*>(srow + n) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < D.N) srow[n + e] = v[4 * q + e];
+                    }
+                }
+            }
+            if (a.lse_part) {
+                float tmax = -3.0e38f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = nb + 8 * (r >> 2) + (r & 3);
+                    if (n < D.N) tmax = fmaxf(tmax, v[r]);
+                }
+                const float mnew = fmaxf(run_m, tmax);
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = nb + 8 * (r >> 2) + (r & 3);
+                    if (n < D.N) sum += __expf(v[r] - mnew);
+                }
+                run_l = run_l * __expf(run_m - mnew) + sum;
+                run_m = mnew;
+            }
+        }
+        STAMP();  // after stores + partial LSE
+        __syncthreads();
+        STAMP();  // after the barrier
+    }
+#undef STAMP
+    if (a.lse_part) {
+        // combine the two half-waves (columns +0..3 / +4..7 of every 8), then the two waves that cover the 64-column tile
+        const float m2 = __shfl_xor(run_m, 32, 64), l2 = __shfl_xor(run_l, 32, 64);
+        const float mm = fmaxf(run_m, m2);
+        const float ll = run_l * __expf(run_m - mm) + l2 * __expf(m2 - mm);
+        float* red = smem;  // LDS is free after the last barrier of the tile loop
+        if (h == 0) {
+            red[((wm * 2 + wn) * 32 + l31) * 2] = mm;
+            red[((wm * 2 + wn) * 32 + l31) * 2 + 1] = ll;
+        }
+        __syncthreads();
+        const int m = m0 + wm * 32 + l31;
+        if (wn == 0 && h == 0 && m < D.Bc) {
+            const float ma = red[((wm * 2) * 32 + l31) * 2], la = red[((wm * 2) * 32 + l31) * 2 + 1];
+            const float mb = red[((wm * 2 + 1) * 32 + l31) * 2], lb = red[((wm * 2 + 1) * 32 + l31) * 2 + 1];
+            const float mx = fmaxf(ma, mb);
+            float* out = a.lse_part + ((((int64_t)dir * D.Bp + (int64_t)c * D.Bc + m) * ngroups) + ng) * 2;
+            out[0] = mx;
+            out[1] = la * __expf(ma - mx) + lb * __expf(mb - mx);
+        }
+    }
+}
+
+// =========================================================================================== scores, interleaved schedule
+// Same data flow as lp_scores_res_kernel, but the non-MFMA work of the neighbouring tiles is issued BETWEEN the MFMAs of the
+// current tile: a dependent 32x32x2 MFMA chain leaves ~60 of every 64 issue cycles free, so the stores + SoftmaxCE partials of
+// tile t-1, the LDS writes of tile t+1 and the global loads of tile t+2 ride in those shadows instead of running after the
+// chain (measured before: MFMA-only 0.16 ms, stores + staging + prologue added another 0.15 ms because the two workgroups
+// of a CU move in lockstep and never hid each other's non-MFMA phases).
+template <bool L2, int NQ>
+__global__ __launch_bounds__(256, 2) void lp_scores_il_kernel(ScoreArgs a, int ngroups, int nt_per_group, int units_per_cd) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LpDims& D = a.D;
+    int cd, unit;
+    if (!decode_block2(blockIdx.x, units_per_cd, D.C * D.ndir, cd, unit)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int dir = cd / D.C, c = cd - dir * D.C;
+    const int mt = unit / ngroups, ng = unit - mt * ngroups;
+    const int m0 = mt * R_T;
+    const int ntiles = (D.N + R_T - 1) / R_T;
+    const int nt0 = ng * nt_per_group;
+    const int T = min(nt_per_group, ntiles - nt0);
+    if (T <= 0) return;
+    const int KS = a.KS;
+    float* As = smem;
+    float* Bs0 = smem + R_T * KS;
+    float* Bs1 = Bs0 + R_T * KS;
+    const float* adj = a.adj + ((int64_t)dir * D.Bp + (int64_t)c * D.Bc) * D.d_ld;
+    const int64_t* negmap = a.negmap[dir] + (int64_t)c * D.N;
+    const int piece = tid & 31, row = tid >> 5;
+    const bool col_ok = 4 * piece < D.d;
+    const int colc = col_ok ? 4 * piece : 0;
+
+    float4 vb[8];
+    int64_t ids[8];
+    auto load_id = [&](int t, int it) {
+        const int n = (nt0 + t) * R_T + row + 8 * it;
+        ids[it] = negmap[n < D.N ? n : 0];
+    };
+    auto issue_b1 = [&](int it) { vb[it] = *reinterpret_cast<const float4*>(a.emb + ids[it] * a.emb_ld + colc); };
+    auto write_b1 = [&](float* buf, int t, int it) {
+        if (col_ok) {
+            const int n = (nt0 + t) * R_T + row + 8 * it;
+            lds_store4x(buf + (row + 8 * it) * KS + 4 * piece, mul4(vb[it], n < D.N ? 1.f : 0.f));
+        }
+    };
+
+    // ---- prologue (not interleaved: once per workgroup)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) load_id(0, it);
+    {
+        float4 va[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int m = m0 + row + 8 * it;
+            va[it] = *reinterpret_cast<const float4*>(adj + (int64_t)(m < D.Bc ? m : 0) * D.d_ld + colc);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) issue_b1(it);
+        if (col_ok) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int m = m0 + row + 8 * it;
+                lds_store4x(As + (row + 8 * it) * KS + 4 * piece, mul4(va[it], m < D.Bc ? 1.f : 0.f));
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) write_b1(Bs0, 0, it);
+    if (T > 1) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) load_id(1, it);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) issue_b1(it);
+    }
+    if (T > 2) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) load_id(2, it);
+    }
+    __syncthreads();
+
+    float* S = a.S + ((int64_t)dir * D.Bp + (int64_t)c * D.Bc) * D.n_ld;
+    const float* ap = As + (wm * 32 + l31) * KS + 2 * h;
+    const int m_row = m0 + wm * 32 + l31;
+    float xx = 0.f;
+    if (L2 && m_row < D.Bc) xx = a.x2[(int64_t)dir * D.Bp + (int64_t)c * D.Bc + m_row];
+    float run_m = -3.0e38f, run_l = 0.f;
+    float* srow = S + (int64_t)(m_row < D.Bc ? m_row : 0) * D.n_ld;
+
+    // store quad q (4 consecutive columns) of tile tp held in `accp`, and fold it into the running (max, sum exp)
+    auto store_quad = [&](const v16f& accp, int tp, int q) {
+        const int n = (nt0 + tp) * R_T + wn * 32 + 4 * h + 8 * q;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = accp[4 * q + e];
+            if (L2) {
+#pragma clang fp contract(off)
+                const float yy = (n + e < D.N) ? a.y2[(int64_t)dir * D.C * D.N + (int64_t)c * D.N + n + e] : 0.f;
+                const float tt = (xx + yy) - 2.f * v[e];
+                v[e] = sqrtf(fmaxf(tt, 1e-8f));
+            }
+        }
+        if (m_row < D.Bc) {
+            if (n + 3 < D.N) {
+                *reinterpret_cast<float4*>(srow + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < D.N) srow[n + e] = v[e];
+            }
+        }
+        if (a.lse_part) {
+            float tmax = -3.0e38f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < D.N) tmax = fmaxf(tmax, v[e]);
+            const float mnew = fmaxf(run_m, tmax);
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < D.N) sum += __expf(v[e] - mnew);
+            run_l = run_l * __expf(run_m - mnew) + sum;
+            run_m = mnew;
+        }
+    };
+
+    v16f acc0, acc1;
+    // one tile: MFMA chain into `accc`; after every second MFMA pair one piece of the neighbours' work
+    auto tile_step = [&](int t, v16f& accc, const v16f& accp) {
+        const float* bp = ((t & 1) ? Bs1 : Bs0) + (wn * 32 + l31) * KS + 2 * h;
+        float* bnext = (t & 1) ? Bs0 : Bs1;
+        const bool has_prev = t >= 1, has_next = t + 1 < T, has_next2 = t + 2 < T, has_next3 = t + 3 < T;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accc[r] = 0.f;
+        float2 av[2], bv[2];
+        av[0] = *reinterpret_cast<const float2*>(ap);
+        bv[0] = *reinterpret_cast<const float2*>(bp);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q + 1 < NQ) {
+                av[(q + 1) & 1] = *reinterpret_cast<const float2*>(ap + 4 * (q + 1));
+                bv[(q + 1) & 1] = *reinterpret_cast<const float2*>(bp + 4 * (q + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            accc = mfma32(bv[q & 1].x, av[q & 1].x, accc);
+            accc = mfma32(bv[q & 1].y, av[q & 1].y, accc);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- shadow work: pieces 0..12 after q = 0, 2, 4, ... (NQ >= 8 gives at least 4 slots; the rest runs after the chain)
+            if ((q & 1) == 0) {
+                const int p = q >> 1;
+                if (p < 4) {
+                    if (has_prev) store_quad(accp, t - 1, p);
+                } else if (p < 12) {
+                    const int it = p - 4;
+                    if (has_next) write_b1(bnext, t + 1, it);
+                    if (has_next2) issue_b1(it);
+                } else if (p == 12) {
+                    if (has_next3) {
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) load_id(t + 3, it);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // pieces that did not fit under the chain (NQ < 25)
+        constexpr int SLOTS = (NQ + 1) / 2;
+#pragma unroll
+        for (int p = SLOTS; p < 13; ++p) {
+            if (p < 4) {
+                if (has_prev) store_quad(accp, t - 1, p);
+            } else if (p < 12) {
+                const int it = p - 4;
+                if (has_next) write_b1(bnext, t + 1, it);
+                if (has_next2) issue_b1(it);
+            } else {
+                if (has_next3) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) load_id(t + 3, it);
+                }
+            }
+        }
+        __syncthreads();
+    };
+
+    for (int t = 0; t < T; t += 2) {
+        tile_step(t, acc0, acc1);
+        if (t + 1 < T) tile_step(t + 1, acc1, acc0);
+    }
+    // epilogue of the last tile
+    {
+        const int tl = T - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (tl & 1) store_quad(acc1, tl, q); else store_quad(acc0, tl, q);
+        }
+    }
+    if (a.lse_part) {
+        const float m2 = __shfl_xor(run_m, 32, 64), l2 = __shfl_xor(run_l, 32, 64);
+        const float mm = fmaxf(run_m, m2);
+        const float ll = run_l * __expf(run_m - mm) + l2 * __expf(m2 - mm);
+        float* red = smem;
+        if (h == 0) {
+            red[((wm * 2 + wn) * 32 + l31) * 2] = mm;
+            red[((wm * 2 + wn) * 32 + l31) * 2 + 1] = ll;
+        }
+        __syncthreads();
+        if (wn == 0 && h == 0 && m_row < D.Bc) {
+            const float ma = red[((wm * 2) * 32 + l31) * 2], la = red[((wm * 2) * 32 + l31) * 2 + 1];
+            const float mb = red[((wm * 2 + 1) * 32 + l31) * 2], lb = red[((wm * 2 + 1) * 32 + l31) * 2 + 1];
+            const float mx = fmaxf(ma, mb);
+            float* out = a.lse_part + ((((int64_t)dir * D.Bp + (int64_t)c * D.Bc + m_row) * ngroups) + ng) * 2;
+            out[0] = mx;
+            out[1] = la * __expf(ma - mx) + lb * __expf(mb - mx);
+        }
+    }
+}
+
+// =========================================================================================== scores, persistent workgroups
+// Timeline stamps of lp_scores_res_kernel (tools/timeline_scores.py) showed that a workgroup spends ~8.3k cycles per 64x64 tile
+// (3.7k of them in the MFMA chain) but ~24k cycles per 4-tile unit in launch + prologue (negative ids -> rows -> LDS is two
+// dependent HBM round trips) — 40 % of the kernel.  Here 2 workgroups per CU stay resident and walk a static list of units
+// that belong to their XCD; the tile stream is continuous across unit seams (the first negative tile and the adj tile of the
+// next unit are prefetched like any other tile), so the prologue is paid once per workgroup instead of once per unit.
+struct PSDesc {
+    bool valid, new_unit, last_of_unit;
+    int dir, c, m0, ntile, ng;
+};
+
+template <bool L2, int NQ>
+__global__ __launch_bounds__(256, 2) void lp_scores_ps_kernel(ScoreArgs a, int ngroups, int ntpg, int units_per_cd, int wg_per_xcd) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LpDims& D = a.D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int KS = a.KS;
+    float* As = smem;
+    float* Bs0 = smem + R_T * KS;
+    float* Bs1 = Bs0 + R_T * KS;
+    float* red = Bs1 + R_T * KS;  // 256 floats for the SoftmaxCE partial exchange
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, W = wg_per_xcd;
+    const int ncd = D.C * D.ndir;
+    const int ncd_x = (ncd - xcd + 7) / 8;
+    const int total_units = ncd_x * units_per_cd;
+    const int my_units = w < total_units ? (total_units - w + W - 1) / W : 0;
+    const int K = my_units * ntpg;
+    if (K == 0) return;
+    const int ntiles = (D.N + R_T - 1) / R_T;
+
+    // step descriptors are advanced incrementally (the divisions run once per unit, not four times per tile)
+    auto unit_fields = [&](PSDesc& d, int ui) {
+        const int g = w + ui * W;
+        const int cdi = g / units_per_cd, unit = g - cdi * units_per_cd;
+        const int cd = xcd + 8 * cdi;
+        d.dir = cd / D.C;
+        d.c = cd - d.dir * D.C;
+        const int mt = unit / ngroups;
+        d.ng = unit - mt * ngroups;
+        d.m0 = mt * R_T;
+    };
+    int adv_ui = 0, adv_ti = -1;  // position of the most recently produced descriptor
+    PSDesc adv_d;
+    adv_d.valid = adv_d.new_unit = adv_d.last_of_unit = false;
+    adv_d.dir = adv_d.c = adv_d.m0 = adv_d.ntile = adv_d.ng = 0;
+    auto next_desc = [&]() {
+        ++adv_ti;
+        if (adv_ti == ntpg) {
+            adv_ti = 0;
+            ++adv_ui;
+        }
+        const bool in_range = adv_ui < my_units;
+        if (adv_ti == 0 && in_range) unit_fields(adv_d, adv_ui);
+        adv_d.ntile = adv_d.ng * ntpg + adv_ti;
+        adv_d.valid = in_range && (adv_d.ntile < ntiles);
+        adv_d.new_unit = in_range && (adv_ti == 0);
+        adv_d.last_of_unit = in_range && (adv_ti == ntpg - 1);
+        return adv_d;
+    };
+
+    const int piece = tid & 31, row = tid >> 5;
+    const bool col_ok = 4 * piece < D.d;
+    const int colc = col_ok ? 4 * piece : 0;
+    float4 va[8], vb[8];
+    int64_t ids[8];
+    auto load_ids = [&](const PSDesc& d) {
+        const int64_t* negmap = a.negmap[d.dir] + (int64_t)d.c * D.N;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int n = d.ntile * R_T + row + 8 * it;
+            ids[it] = negmap[(d.valid && n < D.N) ? n : 0];
+        }
+    };
+    auto issue_b = [&]() {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) vb[it] = *reinterpret_cast<const float4*>(a.emb + ids[it] * a.emb_ld + colc);
+    };
+    auto issue_a = [&](const PSDesc& d) {
+        const float* adj = a.adj + ((int64_t)d.dir * D.Bp + (int64_t)d.c * D.Bc) * D.d_ld;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int m = d.m0 + row + 8 * it;
+            va[it] = *reinterpret_cast<const float4*>(adj + (int64_t)(m < D.Bc ? m : 0) * D.d_ld + colc);
+        }
+    };
+    auto write_b = [&](float* buf, const PSDesc& d) {
+        if (col_ok) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int n = d.ntile * R_T + row + 8 * it;
+                lds_store4x(buf + (row + 8 * it) * KS + 4 * piece, mul4(vb[it], n < D.N ? 1.f : 0.f));
+            }
+        }
+    };
+    auto write_a = [&](const PSDesc& d) {
+        if (col_ok) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int m = d.m0 + row + 8 * it;
+                lds_store4x(As + (row + 8 * it) * KS + 4 * piece, mul4(va[it], m < D.Bc ? 1.f : 0.f));
+            }
+        }
+    };
+
+    // ---- prologue: step 0 in LDS, step 1 in flight, ids of step 2 loaded
+    PSDesc q0 = next_desc(), q1 = next_desc(), q2 = next_desc(), q3 = next_desc();  // steps k, k+1, k+2, k+3
+    {
+        const PSDesc &d0 = q0, &d1 = q1, &d2 = q2;
+        load_ids(d0);
+        issue_a(d0);
+        issue_b();
+        write_a(d0);
+        write_b(Bs0, d0);
+        load_ids(d1);
+        issue_b();
+        if (d1.new_unit) issue_a(d1);
+        load_ids(d2);
+    }
+    __syncthreads();
+
+    const float* ap = As + (wm * 32 + l31) * KS + 2 * h;
+    const int nq = D.d >> 2;
+    float run_m = -3.0e38f, run_l = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const PSDesc dk = q0, dn = q1, d2 = q2, d3 = q3;
+        q0 = q1;
+        q1 = q2;
+        q2 = q3;
+        q3 = next_desc();
+        const float* bp = ((k & 1) ? Bs1 : Bs0) + (wn * 32 + l31) * KS + 2 * h;
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (dk.valid) {
+            if constexpr (NQ > 0) {
+                float2 av[2], bv[2];
+                av[0] = *reinterpret_cast<const float2*>(ap);
+                bv[0] = *reinterpret_cast<const float2*>(bp);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (q + 1 < NQ) {
+                        av[(q + 1) & 1] = *reinterpret_cast<const float2*>(ap + 4 * (q + 1));
+                        bv[(q + 1) & 1] = *reinterpret_cast<const float2*>(bp + 4 * (q + 1));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = mfma32(bv[q & 1].x, av[q & 1].x, acc);
+                    acc = mfma32(bv[q & 1].y, av[q & 1].y, acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                for (int q = 0; q < nq; ++q) {
+                    const float2 a2 = *reinterpret_cast<const float2*>(ap + 4 * q);
+                    const float2 b2 = *reinterpret_cast<const float2*>(bp + 4 * q);
+                    acc = mfma32(b2.x, a2.x, acc);
+                    acc = mfma32(b2.y, a2.y, acc);
+                }
+            }
+        }
+        // step k+1's negative tile (in vb since the previous step) -> the other LDS buffer; step k+2's rows into flight
+        if (dn.valid) write_b((k & 1) ? Bs0 : Bs1, dn);
+        // (va may still hold step k+1's adj tile: it is written to LDS after the barrier below, before any new issue_a)
+        float4 va_keep[8];
+        const bool seam = dn.new_unit;
+        if (seam) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) va_keep[it] = va[it];
+        }
+        if (d2.valid) {
+            issue_b();
+            if (d2.new_unit) issue_a(d2);
+        }
+        load_ids(d3);
+        // epilogue of step k
+        if (dk.valid) {
+            const int m = dk.m0 + wm * 32 + l31;
+            const int nb = dk.ntile * R_T + wn * 32 + 4 * h;
+            float* S = a.S + ((int64_t)dk.dir * D.Bp + (int64_t)dk.c * D.Bc) * D.n_ld;
+            float xx = 0.f;
+            if (L2 && m < D.Bc) xx = a.x2[(int64_t)dk.dir * D.Bp + (int64_t)dk.c * D.Bc + m];
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v[r] = acc[r];
+                if (L2) {
+#pragma clang fp contract(off)
+                    const int n = nb + 8 * (r >> 2) + (r & 3);
+                    const float yy = (n < D.N) ? a.y2[(int64_t)dk.dir * D.C * D.N + (int64_t)dk.c * D.N + n] : 0.f;
                     const float tt = (xx + yy) - 2.f * v[r];
                     v[r] = sqrtf(fmaxf(tt, 1e-8f));
                 }
@@ -200,29 +683,230 @@ __global__ __launch_bounds__(256, 2) void lp_scores_res_kernel(ScoreArgs a, int 
                 run_m = mnew;
             }
         }
+        // end of a unit: publish the unit's SoftmaxCE partial (two half-waves, then the two waves that share the rows)
+        const bool unit_end = dk.last_of_unit;
+        if (a.lse_part && unit_end) {
+            const float m2 = __shfl_xor(run_m, 32, 64), l2 = __shfl_xor(run_l, 32, 64);
+            const float mm = fmaxf(run_m, m2);
+            const float ll = run_l * __expf(run_m - mm) + l2 * __expf(m2 - mm);
+            if (h == 0) {
+                red[((wm * 2 + wn) * 32 + l31) * 2] = mm;
+                red[((wm * 2 + wn) * 32 + l31) * 2 + 1] = ll;
+            }
+            run_m = -3.0e38f;
+            run_l = 0.f;
+        }
         __syncthreads();
+        if (a.lse_part && unit_end) {
+            const int m = dk.m0 + wm * 32 + l31;
+            if (wn == 0 && h == 0 && m < D.Bc) {
+                const float ma = red[((wm * 2) * 32 + l31) * 2], la = red[((wm * 2) * 32 + l31) * 2 + 1];
+                const float mb = red[((wm * 2 + 1) * 32 + l31) * 2], lb = red[((wm * 2 + 1) * 32 + l31) * 2 + 1];
+                const float mx = fmaxf(ma, mb);
+                float* out = a.lse_part + ((((int64_t)dk.dir * D.Bp + (int64_t)dk.c * D.Bc + m) * ngroups) + dk.ng) * 2;
+                out[0] = mx;
+                out[1] = la * __expf(ma - mx) + lb * __expf(mb - mx);
+            }
+        }
+        if (seam) {  // next step starts a new unit: its adj tile replaces As now that every wave is past the barrier
+            if (col_ok) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int m = dn.m0 + row + 8 * it;
+                    lds_store4x(As + (row + 8 * it) * KS + 4 * piece, mul4(va_keep[it], m < D.Bc ? 1.f : 0.f));
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// =========================================================================================== scores, adj fragments in registers
+// Lessons from the timeline / ablation runs above: (1) the random 400-B row gathers need ~2-4 us under load, more than one
+// tile period, (2) two co-resident workgroups with the same phase pattern fall into lockstep.  This variant therefore
+//   * keeps each wave's 32 adj rows as MFMA fragments in REGISTERS for the whole unit (no adj tile in LDS, half the LDS reads),
+//   * multiplies 128 rows x 32 negatives per step: one 32-row negative tile (12.8 kB) feeds all four waves, i.e. half the
+//     gather traffic per MFMA of the 64x64 variant,
+//   * prefetches four tiles deep: two register sets in flight (issued two steps before they are written to LDS) and a 3-slot
+//     LDS ring (written two steps before it is read),
+//   * fits 3 workgroups per CU (40 kB LDS, <= 168 VGPRs), which breaks the two-workgroup lockstep.
+// Each wave owns its rows for every column, so the SoftmaxCE partial needs no cross-wave exchange.
+constexpr int A_TM = 128, A_TN = 32, A_SLOTS = 3;
+
+template <bool L2, int NQ>
+__global__ __launch_bounds__(256, 3) void lp_scores_a_kernel(ScoreArgs a, int ngroups, int ntpg, int units_per_cd) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LpDims& D = a.D;
+    int cd, unit;
+    if (!decode_block2(blockIdx.x, units_per_cd, D.C * D.ndir, cd, unit)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long* dbg = (a.dbg && blockIdx.x < 2048 && (blockIdx.x & 7) == 0 && lane == 0 && (wave == 0 || wave == 3))
+                                  ? a.dbg + ((size_t)(blockIdx.x >> 3) * 2 + (wave ? 1 : 0)) * 64 : nullptr;
+    int dbi = 0;
+#define STAMP() do { if (dbg && dbi < 64) dbg[dbi++] = __builtin_readcyclecounter(); } while (0)
+    STAMP();
+    const int l31 = lane & 31, h = lane >> 5;
+    const int dir = cd / D.C, c = cd - dir * D.C;
+    const int mt = unit / ngroups, ng = unit - mt * ngroups;
+    const int ntiles = (D.N + A_TN - 1) / A_TN;
+    const int nt0 = ng * ntpg;
+    const int T = min(ntpg, ntiles - nt0);
+    if (T <= 0) return;
+    const int KS = a.KS;
+    const int m_row = mt * A_TM + wave * 32 + l31;
+    const bool m_ok = m_row < D.Bc;
+    const int64_t rowbase = (int64_t)dir * D.Bp + (int64_t)c * D.Bc;
+    const int64_t* negmap = a.negmap[dir] + (int64_t)c * D.N;
+
+    // adj fragments of this lane: A[m_row][4q + 2h .. +1]
+    float2 af[NQ];
+    {
+        const float* arow = a.adj + (rowbase + (m_ok ? m_row : 0)) * D.d_ld + 2 * h;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) af[q] = *reinterpret_cast<const float2*>(arow + 4 * q);
+        if (!m_ok) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) af[q] = make_float2(0.f, 0.f);
+        }
+    }
+
+    const int piece = tid & 31, row = tid >> 5;  // 32 thr x 16 B per row, 8 rows per pass, 4 passes = 32 rows
+    const bool col_ok = 4 * piece < D.d;
+    const int colc = col_ok ? 4 * piece : 0;
+    int64_t ids0[4], ids1[4];
+    float4 vb0[4], vb1[4];
+    auto load_ids = [&](int t, int64_t(&ids)[4]) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int n = (nt0 + t) * A_TN + row + 8 * it;
+            ids[it] = negmap[(t < T && n < D.N) ? n : 0];
+        }
+    };
+    auto issue = [&](const int64_t(&ids)[4], float4(&vb)[4]) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) vb[it] = *reinterpret_cast<const float4*>(a.emb + ids[it] * a.emb_ld + colc);
+    };
+    auto write = [&](int t, const float4(&vb)[4]) {
+        if (t < T && col_ok) {
+            float* buf = smem + (t % A_SLOTS) * (A_TN * KS);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int n = (nt0 + t) * A_TN + row + 8 * it;
+                lds_store4x(buf + (row + 8 * it) * KS + 4 * piece, mul4(vb[it], n < D.N ? 1.f : 0.f));
+            }
+        }
+    };
+
+    // ---- prologue: tiles 0,1 -> LDS, tiles 2,3 in flight (sets 0,1), ids of tiles 4,5 loaded
+    load_ids(0, ids0);
+    load_ids(1, ids1);
+    issue(ids0, vb0);
+    issue(ids1, vb1);
+    load_ids(2, ids0);
+    load_ids(3, ids1);
+    write(0, vb0);
+    write(1, vb1);
+    issue(ids0, vb0);  // tile 2
+    issue(ids1, vb1);  // tile 3
+    load_ids(4, ids0);
+    load_ids(5, ids1);
+    __syncthreads();
+    STAMP();
+
+    float* srow = a.S + (rowbase + (m_ok ? m_row : 0)) * D.n_ld;
+    float xx = 0.f;
+    if (L2 && m_ok) xx = a.x2[rowbase + m_row];
+    float run_m = -3.0e38f, run_l = 0.f;
+
+    auto step = [&](int t, const int64_t(&ids)[4], float4(&vb)[4]) {
+        // on entry: LDS holds tiles t, t+1; `vb` holds tile t+2 (issued two steps ago); `ids` holds the ids of tile t+4
+        const float* bp = smem + (t % A_SLOTS) * (A_TN * KS) + l31 * KS + 2 * h;
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float2 bv[2];
+        bv[0] = *reinterpret_cast<const float2*>(bp);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q + 1 < NQ) bv[(q + 1) & 1] = *reinterpret_cast<const float2*>(bp + 4 * (q + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma32(bv[q & 1].x, af[q].x, acc);  // D[n][m]: the lane owns row m and 16 columns n
+            acc = mfma32(bv[q & 1].y, af[q].y, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        STAMP();
+        write(t + 2, vb);                 // slot (t+2) % 3 was last read in step t-1
+        STAMP();
+        if (t + 4 < T) issue(ids, vb);    // tile t+4 into the register set just freed
+        STAMP();
+        // epilogue of tile t
+        const int nb = (nt0 + t) * A_TN + 4 * h;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v[r] = acc[r];
+            if (L2) {
+#pragma clang fp contract(off)
+                const int n = nb + 8 * (r >> 2) + (r & 3);
+                const float yy = (n < D.N) ? a.y2[(int64_t)dir * D.C * D.N + (int64_t)c * D.N + n] : 0.f;
+                const float tt = (xx + yy) - 2.f * v[r];
+                v[r] = sqrtf(fmaxf(tt, 1e-8f));
+            }
+        }
+        if (m_ok && !(a.ablate & 1)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = nb + 8 * q;
+                if (n + 3 < D.N) {
+                    *reinterpret_cast<float4*>(srow + n) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < D.N) srow[n + e] = v[4 * q + e];
+                }
+            }
+        }
+        if (a.lse_part && !(a.ablate & 8)) {
+            float tmax = -3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nb + 8 * (r >> 2) + (r & 3);
+                if (n < D.N) tmax = fmaxf(tmax, v[r]);
+            }
+            const float mnew = fmaxf(run_m, tmax);
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nb + 8 * (r >> 2) + (r & 3);
+                if (n < D.N) sum += __expf(v[r] - mnew);
+            }
+            run_l = run_l * __expf(run_m - mnew) + sum;
+            run_m = mnew;
+        }
+        STAMP();
+        __syncthreads();
+        STAMP();
+    };
+
+    for (int t = 0; t < T; t += 2) {
+        step(t, ids0, vb0);
+        load_ids(t + 6, ids0);
+        if (t + 1 < T) {
+            step(t + 1, ids1, vb1);
+            load_ids(t + 7, ids1);
+        }
     }
     if (a.lse_part) {
-        // combine the two half-waves (columns +0..3 / +4..7 of every 8), then the two waves that cover the 64-column tile
         const float m2 = __shfl_xor(run_m, 32, 64), l2 = __shfl_xor(run_l, 32, 64);
         const float mm = fmaxf(run_m, m2);
         const float ll = run_l * __expf(run_m - mm) + l2 * __expf(m2 - mm);
-        float* red = smem;  // LDS is free after the last barrier of the tile loop
-        if (h == 0) {
-            red[((wm * 2 + wn) * 32 + l31) * 2] = mm;
-            red[((wm * 2 + wn) * 32 + l31) * 2 + 1] = ll;
-        }
-        __syncthreads();
-        const int m = m0 + wm * 32 + l31;
-        if (wn == 0 && h == 0 && m < D.Bc) {
-            const float ma = red[((wm * 2) * 32 + l31) * 2], la = red[((wm * 2) * 32 + l31) * 2 + 1];
-            const float mb = red[((wm * 2 + 1) * 32 + l31) * 2], lb = red[((wm * 2 + 1) * 32 + l31) * 2 + 1];
-            const float mx = fmaxf(ma, mb);
-            float* out = a.lse_part + ((((int64_t)dir * D.Bp + (int64_t)c * D.Bc + m) * ngroups) + ng) * 2;
-            out[0] = mx;
-            out[1] = la * __expf(ma - mx) + lb * __expf(mb - mx);
+        if (h == 0 && m_ok) {
+            float* out = a.lse_part + (((rowbase + m_row) * ngroups) + ng) * 2;
+            out[0] = mm;
+            out[1] = ll;
         }
     }
+#undef STAMP
 }
 
 // =========================================================================================== backward contractions, 16x16x4 tiles
@@ -571,6 +1255,40 @@ static bool res_ok(const float* emb, int64_t emb_ld, int d) {
 
 bool scores_res_applicable(const float* emb, int64_t emb_ld, int d) { return res_ok(emb, emb_ld, d) && d <= 128; }
 
+bool scores_a_applicable(const float* emb, int64_t emb_ld, int d) {
+    const int nq = d / 4;
+    return res_ok(emb, emb_ld, d) && (nq == 8 || nq == 16 || nq == 25 || nq == 32);
+}
+
+bool launch_scores_a(const ScoreArgs& a_in, bool l2, hipStream_t st) {
+    if (!scores_a_applicable(a_in.emb, a_in.emb_ld, a_in.D.d)) return false;
+    ScoreArgs a = a_in;
+    a.KS = a.D.d + 2;
+    int ntpg, ngroups;
+    scores_a_geometry(a.D.N, ntpg, ngroups);
+    const int mtiles = (int)cdiv(a.D.Bc, A_TM);
+    const int units = mtiles * ngroups;
+    const size_t lds = (size_t)A_SLOTS * A_TN * a.KS * sizeof(float);
+    dim3 grid(xcd_grid2(units, a.D.C * a.D.ndir));
+#define SCORES_A_LAUNCH(L2V, NQV) lp_scores_a_kernel<L2V, NQV><<<grid, dim3(256), lds, st>>>(a, ngroups, ntpg, units)
+#define SCORES_A_DISPATCH(L2V)                         \
+    do {                                               \
+        switch (a.D.d / 4) {                           \
+            case 8: SCORES_A_LAUNCH(L2V, 8); break;    \
+            case 16: SCORES_A_LAUNCH(L2V, 16); break;  \
+            case 25: SCORES_A_LAUNCH(L2V, 25); break;  \
+            default: SCORES_A_LAUNCH(L2V, 32); break;  \
+        }                                              \
+    } while (0)
+    if (l2)
+        SCORES_A_DISPATCH(true);
+    else
+        SCORES_A_DISPATCH(false);
+#undef SCORES_A_DISPATCH
+#undef SCORES_A_LAUNCH
+    return true;
+}
+
 bool launch_scores_res(const ScoreArgs& a_in, bool l2, hipStream_t st) {
     if (!scores_res_applicable(a_in.emb, a_in.emb_ld, a_in.D.d)) return false;
     ScoreArgs a = a_in;
@@ -581,10 +1299,49 @@ bool launch_scores_res(const ScoreArgs& a_in, bool l2, hipStream_t st) {
     const int units = mtiles * ngroups;
     const size_t lds = (size_t)3 * R_T * a.KS * sizeof(float);
     dim3 grid(xcd_grid2(units, a.D.C * a.D.ndir));
+    const char* ile = getenv("MARIUS_SCORES_IL");
+    const bool use_il = (ile && ile[0] == '1');  // interleaved-schedule experiment (measured slower)
+    const char* pse = getenv("MARIUS_SCORES_PS");
+    const bool use_ps = !(pse && pse[0] == '0');
+    if (use_ps) {  // persistent workgroups (default)
+        const int ncd = a.D.C * a.D.ndir;
+        const int units_x = (int)cdiv(ncd, 8) * units;
+        int wg_per_xcd = 64;  // 2 resident workgroups on each of the XCD's 32 CUs
+        if (units_x < wg_per_xcd) wg_per_xcd = units_x;
+        const size_t lds_ps = lds + 256 * sizeof(float);
+        dim3 pgrid((unsigned)(8 * wg_per_xcd));
+#define SCORES_PS_LAUNCH(L2V, NQV)                                                                                                       \
+    do {                                                                                                                                   \
+        if (lds_ps > 65536) hipFuncSetAttribute((const void*)lp_scores_ps_kernel<L2V, NQV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ps); \
+        lp_scores_ps_kernel<L2V, NQV><<<pgrid, dim3(256), lds_ps, st>>>(a, ngroups, nt_per_group, units, wg_per_xcd);                         \
+    } while (0)
+#define SCORES_PS_DISPATCH(L2V)                          \
+    do {                                                 \
+        switch (a.D.d / 4) {                             \
+            case 8: SCORES_PS_LAUNCH(L2V, 8); break;     \
+            case 16: SCORES_PS_LAUNCH(L2V, 16); break;   \
+            case 25: SCORES_PS_LAUNCH(L2V, 25); break;   \
+            case 32: SCORES_PS_LAUNCH(L2V, 32); break;   \
+            default: SCORES_PS_LAUNCH(L2V, 0); break;    \
+        }                                                \
+    } while (0)
+        if (l2)
+            SCORES_PS_DISPATCH(true);
+        else
+            SCORES_PS_DISPATCH(false);
+#undef SCORES_PS_DISPATCH
+#undef SCORES_PS_LAUNCH
+        return true;
+    }
 #define SCORES_RES_LAUNCH(L2V, NQV)                                                                                                     \
     do {                                                                                                                                  \
-        if (lds > 65536) hipFuncSetAttribute((const void*)lp_scores_res_kernel<L2V, NQV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        lp_scores_res_kernel<L2V, NQV><<<grid, dim3(256), lds, st>>>(a, ngroups, nt_per_group, units);                                      \
+        if (use_il && NQV > 0) {                                                                                                          \
+            if (lds > 65536) hipFuncSetAttribute((const void*)lp_scores_il_kernel<L2V, (NQV > 0 ? NQV : 8)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            lp_scores_il_kernel<L2V, (NQV > 0 ? NQV : 8)><<<grid, dim3(256), lds, st>>>(a, ngroups, nt_per_group, units);                    \
+        } else {                                                                                                                          \
+            if (lds > 65536) hipFuncSetAttribute((const void*)lp_scores_res_kernel<L2V, NQV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            lp_scores_res_kernel<L2V, NQV><<<grid, dim3(256), lds, st>>>(a, ngroups, nt_per_group, units);                                  \
+        }                                                                                                                                 \
     } while (0)
 #define SCORES_RES_DISPATCH(L2V)                          \
     do {                                                  \

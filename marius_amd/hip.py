@@ -63,6 +63,7 @@ SIGNATURES = {
     "marius_select_edges": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _i64, _vp, _vp]),
     "marius_assemble_ids": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp]),
     "marius_remap_edges": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "marius_debug_set_timeline": (C.c_int, [_vp]),
     "marius_profile_enable": (C.c_int, [C.c_int]),
     "marius_profile_reset": (C.c_int, []),
     "marius_profile_kernel_count": (C.c_int, []),
