@@ -13,11 +13,15 @@ One synchronous data-parallel step on every rank (each rank trains its own batch
   3. forward / loss / backward locally; per-unique-row gradient by atomic-free segmented sum.
   4. all-to-all(v) of the row gradients to the owners; the owner sort/uniques everything it received (a row may be requested
      by several ranks), sums per row and applies sparse Adagrad once:  exactly the single-GPU update for the union batch.
-  5. relation-table gradients are all-reduced (sum) and every replica takes the same dense Adagrad step (model.cpp:136-159).
+  5. relation tables are replicated.  sync_interval == 1: their gradients are all-reduced (sum) and every replica takes the same
+     dense Adagrad step (model.cpp:136-159).  sync_interval == K > 1 (the reference's pipeline.gpu_sync_interval, default 16,
+     with gpu_model_average: pipeline_gpu.cpp:52-80): every replica steps on its own gradient and every K-th step the tables and
+     their Adagrad sums are averaged across ranks — 1/K of the all-reduce volume.
 Only the exchange lives here; every local operation goes through a backend (HIP kernels in production, the oracle in the
 CPU gloo tests) so the N>1 plumbing is testable without a GPU while the product path still has no CPU fallback.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -51,7 +55,7 @@ def a2a_rows(buf, send_counts, recv_counts, group=None):
     return out
 
 
-def sharded_step(backend, edges, rank, world, num_nodes, group=None):
+def sharded_step(backend, edges, rank, world, num_nodes, group=None, sync_interval=1, step_index=0):
     """One synchronous step. `backend` provides the local operations (see HipBackend below)."""
     S = shard_rows(num_nodes, world)
     lo, _ = shard_range(num_nodes, rank, world)
@@ -65,10 +69,17 @@ def sharded_step(backend, edges, rank, world, num_nodes, group=None):
     grad, rel_grads, loss = backend.compute(ctx, emb)           # grad [U, d]
     recv_grad = a2a_rows(grad, send_counts, recv_counts, group)
     backend.apply_local(req_ids - lo, recv_grad)                # dedupe across senders + Adagrad + scatter on my shard
-    for g in rel_grads:
-        if g is not None:
-            dist.all_reduce(g, group=group)
-    backend.dense_step(rel_grads)
+    if sync_interval <= 1:
+        for g in rel_grads:
+            if g is not None:
+                dist.all_reduce(g, group=group)
+        backend.dense_step(rel_grads)
+    else:
+        backend.dense_step(rel_grads)  # local step; replicas drift for at most sync_interval steps
+        if (step_index + 1) % sync_interval == 0:
+            for t in backend.dense_state():
+                dist.all_reduce(t, group=group)
+                t.div_(world)
     return loss
 
 
@@ -145,6 +156,10 @@ class HipBackend:
         self.um_recv.run(local_ids.contiguous(), bits)
         H.segment_adagrad_scatter(grads, self.um_recv, n, s.d, self.table, self.state, s.sparse_lr, carry=self.carry_recv)
 
+    def dense_state(self):
+        s = self.s
+        return [t for t in (s.rel, s.inv_rel, s.rel_sum, s.inv_rel_sum) if t is not None]
+
     def dense_step(self, rel_grads):
         s, H = self.s, self.H
         H.dense_adagrad_step(s.rel, s.rel_sum, rel_grads[0], s.dense_lr)
@@ -174,10 +189,12 @@ def run_sharded_bench(a, cfg, rank, world, dev):
     perm = stepper.gen.randperm_host(edges_all.size(0)).to(dev)
     nb = edges_all.size(0) // B
 
+    sync_interval = int(os.environ.get("MARIUS_GPU_SYNC_INTERVAL", "16"))  # pipeline.gpu_sync_interval default (marius_config.py:672-685)
+
     def run(k0, k):
         for s in range(k0, k0 + k):
             edges = H.select_edges(edges_all, perm, (s % nb) * B, B)
-            sharded_step(backend, edges, rank, world, num_nodes)
+            sharded_step(backend, edges, rank, world, num_nodes, sync_interval=sync_interval, step_index=s)
 
     run(0, a.warmup)
     torch.cuda.synchronize()
@@ -199,7 +216,7 @@ def run_sharded_bench(a, cfg, rank, world, dev):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %s d=%d, node table sharded by contiguous id range over %d GPUs, B=%d per GPU, C=%d N=%d, %s edges" % (
                 a.workload, cfg["decoder"], d, world, B, C, N, a.edge_dist), "num_nodes": num_nodes, "num_relations": R,
-                "parallelism": "dp%d + sharded node table, RCCL all-to-all(v) row fetch / gradient return" % world},
+                "parallelism": "dp%d + sharded node table, RCCL all-to-all(v) row fetch / gradient return, relation tables averaged every %d steps" % (world, sync_interval)},
             "positive_edges_per_s": round(pos_eps, 1), "roofline": None, "cpu_baseline": None,
         }
         print(json.dumps(out))

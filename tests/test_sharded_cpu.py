@@ -54,6 +54,10 @@ class OracleBackend:
         O.index_add(self.table, uniq, dw)
         O.index_add(self.state, uniq, ds)
 
+    def dense_state(self):
+        s = self.step
+        return [s.rel, s.inv_rel, s.rel_sum, s.inv_rel_sum]
+
     def dense_step(self, rel_grads):
         s = self.step
         O.dense_adagrad_step(s.rel, rel_grads[0], s.rel_sum, self.c["lr"])
@@ -69,7 +73,7 @@ def make_inputs(cfg):
     return table, edges
 
 
-def worker(rank, world, port, outdir):
+def worker(rank, world, port, outdir, sync_interval=1):
     from marius_amd.sharded import shard_range, sharded_step
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -83,7 +87,7 @@ def worker(rank, world, port, outdir):
     losses = []
     for s in range(cfg["steps"]):
         batch = edges[rank][s * cfg["B"]:(s + 1) * cfg["B"]]
-        losses.append(float(sharded_step(be, batch, rank, world, cfg["num_nodes"])))
+        losses.append(float(sharded_step(be, batch, rank, world, cfg["num_nodes"], sync_interval=sync_interval, step_index=s)))
     torch.save({"shard": shard, "state": state, "rel": be.step.rel, "inv_rel": be.step.inv_rel, "losses": losses}, os.path.join(outdir, "r%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -159,3 +163,13 @@ def test_shard_ranges_follow_marius_partition_rule():
     assert shard_rows(86054151, 8) == 10756769  # ceil(num_nodes / num_partitions), storage.cpp:75
     assert shard_range(86054151, 7, 8) == (75297383, 86054151)
     assert shard_range(10, 3, 4) == (9, 10) and shard_range(8, 3, 3) == (8, 8)
+
+
+def test_sharded_step_sync_interval_averages_relation_tables():
+    """gpu_sync_interval semantics: local dense steps, tables + Adagrad sums averaged every K steps -> replicas identical right after a sync."""
+    world, port = 2, 31000 + os.getpid() % 2000
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(worker, args=(world, port, outdir, 3), nprocs=world, join=True)  # steps = 3 -> one sync at the last step
+        res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(world)]
+    assert torch.equal(res[0]["rel"], res[1]["rel"]) and torch.equal(res[0]["inv_rel"], res[1]["inv_rel"])
+    assert torch.isfinite(res[0]["shard"]).all() and torch.isfinite(res[1]["shard"]).all()
