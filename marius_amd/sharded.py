@@ -48,9 +48,10 @@ def exchange_splits(send_offsets, group=None):
     return send.tolist(), r.cpu().tolist()
 
 
-def a2a_rows(buf, send_counts, recv_counts, group=None):
+def a2a_rows(buf, send_counts, recv_counts, group=None, out=None):
     """all-to-all(v) along dim 0 of a [n, ...] tensor."""
-    out = buf.new_empty((sum(recv_counts),) + tuple(buf.shape[1:]))
+    if out is None:
+        out = buf.new_empty((sum(recv_counts),) + tuple(buf.shape[1:]))
     dist.all_to_all_single(out, buf.contiguous(), recv_counts, send_counts, group=group)
     return out
 
@@ -167,6 +168,155 @@ class HipBackend:
             H.dense_adagrad_step(s.inv_rel, s.inv_rel_sum, rel_grads[1], s.dense_lr)
 
 
+class _Slot:
+    """Per-batch buffers of the pipelined trainer (two slots alternate)."""
+
+    def __init__(self, H, B, cols, L, world, dev):
+        self.edges = torch.empty((B, cols), dtype=torch.int64, device=dev)
+        self.edges_local = torch.empty((B, cols), dtype=torch.int64, device=dev)
+        self.all_ids = torch.empty(L, dtype=torch.int64, device=dev)
+        self.um = H.UniqueMap(L, dev)
+        self.offs_dev = torch.empty(world + 1, dtype=torch.int64, device=dev)
+        self.offs_host = torch.empty(world + 1, dtype=torch.int64).pin_memory()
+        self.recv_host = torch.empty(world, dtype=torch.int64)
+        self.ready = torch.cuda.Event()
+        self.free = torch.cuda.Event()
+        self.used = False
+        self.src_neg = self.dst_neg = None
+        self.filters = (None, None)
+
+
+class PipelinedShardedTrainer:
+    """sharded_step with the batch preparation (edge slice, negatives, sort/unique, owner split points, count exchange) running one
+    step ahead on a side stream.  Nothing about the update semantics changes — preparation does not read
+    the table — but the two host read-backs an all-to-all(v) needs (split points, receive counts) are then served from work that
+    finished long ago, so the main stream never drains while the host waits."""
+
+    def __init__(self, stepper, shard_table, shard_state, edges_all, perm, rank, world, num_nodes, sync_interval=1, group=None, side_group=None):
+        from . import hip as H
+
+        self.H, self.s = H, stepper
+        self.backend = HipBackend(stepper, shard_table, shard_state)
+        self.edges_all, self.perm = edges_all, perm
+        self.rank, self.world, self.num_nodes = rank, world, num_nodes
+        self.S = shard_rows(num_nodes, world)
+        self.lo, _ = shard_range(num_nodes, rank, world)
+        self.sync_interval = sync_interval
+        self.group, self.side_group = group, side_group
+        dev = shard_table.device
+        self.dev = dev
+        self.prep_stream = torch.cuda.Stream(device=dev)
+        self.slots = [_Slot(H, stepper.B, stepper.edge_cols, stepper.L, world, dev) for _ in range(2)]
+        self.nb = edges_all.size(0) // stepper.B
+        self.next_prepared = 0
+        self.step_index = 0
+        self._pool = {}
+
+    def _buf(self, name, n, tail, dtype):
+        """[n, *tail] view of a grow-only buffer: per-step sizes vary with the number of unique ids, and a fresh torch.empty per
+        step keeps the caching allocator splitting/merging blocks (visible as multi-100-us jitter)."""
+        b = self._pool.get(name)
+        if b is None or b.size(0) < n:
+            b = torch.empty((max(n + n // 4, 1),) + tuple(tail), dtype=dtype, device=self.dev)
+            self._pool[name] = b
+        return b[:n]
+
+    def _prepare(self, t):
+        H, s = self.H, self.s
+        slot = self.slots[t & 1]
+        B, CN = s.B, s.C * s.N
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.prep_stream):
+            if slot.used:
+                self.prep_stream.wait_event(slot.free)   # the step that used this slot two steps ago is done with it
+            else:
+                self.prep_stream.wait_stream(main)
+            st = H.stream_ptr()
+            L_ = H.lib()
+            H.check(L_.marius_select_edges(H.ptr(self.edges_all), 1 if self.edges_all.dtype == torch.int64 else 0, s.edge_cols, H.ptr(self.perm),
+                                           (t % self.nb) * B, B, H.ptr(slot.edges), st), "select_edges")
+            slot.src_neg, slot.dst_neg, sdeg, ddeg = s.sample(slot.edges)
+            slot.filters = (H.deg_filter(ddeg, B), H.deg_filter(sdeg, B)) if s.n_deg > 0 else (None, None)
+            H.check(L_.marius_assemble_ids(H.ptr(slot.edges), B, s.edge_cols, H.ptr(slot.src_neg), H.ptr(slot.dst_neg), CN, H.ptr(slot.all_ids), st), "assemble")
+            slot.um.run(slot.all_ids, s.key_bits)
+            H.check(L_.marius_remap_edges(H.ptr(slot.edges), H.ptr(slot.um.inverse), B, s.edge_cols, H.ptr(slot.edges_local), st), "remap")
+            H.check(L_.marius_owner_offsets(H.ptr(slot.um.uniq), H.ptr(slot.um.count), self.S, self.world, H.ptr(slot.offs_dev), st), "owner_offsets")
+            slot.offs_host.copy_(slot.offs_dev, non_blocking=True)
+            slot.ready.record(self.prep_stream)
+            for tns in (slot.src_neg, slot.dst_neg) + tuple(f for f in slot.filters if f is not None):
+                tns.record_stream(main)
+        slot.used = True
+
+    def step(self):
+        H, s, be = self.H, self.s, self.backend
+        t = self.step_index
+        if self.next_prepared <= t:
+            self._prepare(t)
+            self.next_prepared = t + 1
+        slot = self.slots[t & 1]
+        main = torch.cuda.current_stream()
+        main.wait_event(slot.ready)
+        slot.ready.synchronize()  # host: split points + receive counts of THIS batch (prepared a step ago: no drain of the main stream)
+        offs = slot.offs_host.tolist()
+        send_counts = [offs[i + 1] - offs[i] for i in range(self.world)]
+        if self.world > 1:
+            # counts travel over the CPU (gloo) group: a second RCCL communicator on another stream could share a hardware queue with
+            # the main one and order differently on different ranks; 8 integers over loopback cost less than that risk
+            send_t = torch.tensor(send_counts, dtype=torch.int64)
+            dist.all_to_all_single(slot.recv_host, send_t, group=self.side_group)
+            recv_counts = slot.recv_host.tolist()
+        else:
+            recv_counts = list(send_counts)
+        U = offs[-1]
+        uniq = slot.um.uniq[:U]
+        nrecv = sum(recv_counts)
+        d = s.d
+        req_ids = a2a_rows(uniq, send_counts, recv_counts, self.group, out=self._buf("req", nrecv, (), torch.int64))
+        local_ids = torch.sub(req_ids, self.lo, out=self._buf("local", nrecv, (), torch.int64))
+        rows = H.gather_rows(be.table, local_ids, out=self._buf("rows", nrecv, (d,), torch.float32))
+        emb = a2a_rows(rows, recv_counts, send_counts, self.group, out=self._buf("emb", U, (d,), torch.float32))
+        # next batch's preparation overlaps with this batch's compute
+        self._prepare(t + 1)
+        self.next_prepared = t + 2
+        # ---- forward / loss / backward on this batch (same kernels as the single-GPU path)
+        B, CN = s.B, s.C * s.N
+        W = s.W
+        src_map = slot.um.inverse[2 * B: 2 * B + CN]
+        dst_map = slot.um.inverse[2 * B + CN: 2 * B + 2 * CN]
+        W.bind(emb, slot.edges_local, dst_map, src_map, s.rel, s.inv_rel, slot.filters[0], slot.filters[1])
+        W.forward()
+        W.loss()
+        W.backward()
+        grad = self._buf("grad", U, (d,), torch.float32)
+        H.segment_sum_rows(W.gocc(), slot.um, s.L, d, grad, carry=s.carry)
+        s.rel_ids.copy_(slot.edges[:, 1])
+        s.um_rel.run(s.rel_ids, s.rel_bits)
+        s.rel_grad.zero_()
+        H.segment_sum_rows(W.grel(0), s.um_rel, B, d, s.rel_grad, out_rows=s.um_rel.uniq, carry=s.carry_rel)
+        inv = None
+        if s.inverse:
+            s.inv_rel_grad.zero_()
+            H.segment_sum_rows(W.grel(1), s.um_rel, B, d, s.inv_rel_grad, out_rows=s.um_rel.uniq, carry=s.carry_rel)
+            inv = s.inv_rel_grad
+        recv_grad = a2a_rows(grad, send_counts, recv_counts, self.group, out=self._buf("recv_grad", nrecv, (d,), torch.float32))
+        be.apply_local(local_ids, recv_grad)
+        rel_grads = [s.rel_grad, inv]
+        if self.sync_interval <= 1:
+            for g in rel_grads:
+                if g is not None:
+                    dist.all_reduce(g, group=self.group)
+            be.dense_step(rel_grads)
+        else:
+            be.dense_step(rel_grads)
+            if (t + 1) % self.sync_interval == 0:
+                for tt in be.dense_state():
+                    dist.all_reduce(tt, group=self.group)
+                    tt.div_(self.world)
+        slot.free.record(main)
+        self.step_index += 1
+        return W.loss_values()[0]
+
+
 def run_sharded_bench(a, cfg, rank, world, dev):
     """bench.py body for N > 1: weak scaling (every rank trains its own B-edge batches against the sharded table)."""
     import json
@@ -185,16 +335,24 @@ def run_sharded_bench(a, cfg, rank, world, dev):
 
     edges_all = bench_mod.synth_edges(num_nodes, R, cfg["num_edges"], a.edge_dist, dev, seed=1 + rank)
     stepper = DeviceLinkPredictionStep(cfg["decoder"], num_nodes, R, d, B, C, N, seed=42 + rank, device=dev, node_table=None, node_state=None)
-    backend = HipBackend(stepper, table, state)
     perm = stepper.gen.randperm_host(edges_all.size(0)).to(dev)
     nb = edges_all.size(0) // B
-
     sync_interval = int(os.environ.get("MARIUS_GPU_SYNC_INTERVAL", "16"))  # pipeline.gpu_sync_interval default (marius_config.py:672-685)
+    pipelined = os.environ.get("MARIUS_SHARDED_PIPELINE", "1") != "0"
+    if pipelined:
+        side_group = dist.new_group(backend="gloo")  # per-step count exchange (world integers) stays on the CPU
+        trainer = PipelinedShardedTrainer(stepper, table, state, edges_all, perm, rank, world, num_nodes, sync_interval=sync_interval, side_group=side_group)
 
-    def run(k0, k):
-        for s in range(k0, k0 + k):
-            edges = H.select_edges(edges_all, perm, (s % nb) * B, B)
-            sharded_step(backend, edges, rank, world, num_nodes, sync_interval=sync_interval, step_index=s)
+        def run(k0, k):
+            for _ in range(k):
+                trainer.step()
+    else:
+        backend = HipBackend(stepper, table, state)
+
+        def run(k0, k):
+            for s in range(k0, k0 + k):
+                edges = H.select_edges(edges_all, perm, (s % nb) * B, B)
+                sharded_step(backend, edges, rank, world, num_nodes, sync_interval=sync_interval, step_index=s)
 
     run(0, a.warmup)
     torch.cuda.synchronize()

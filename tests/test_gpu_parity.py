@@ -421,4 +421,17 @@ def test_sharded_hip_backend_equals_single_gpu_step(H, dev):
     assert_close(tb, ta, "table", rtol=1e-6)
     assert_close(sb, sa, "state", rtol=1e-6)
     assert_close(split.rel, fused.rel, "rel", rtol=1e-6)
+    # pipelined variant (preparation one step ahead on a side stream + second communicator): same numbers
+    from marius_amd.sharded import PipelinedShardedTrainer
+
+    tc, sc = table.to(dev), torch.zeros(num_nodes, d, device=dev)
+    piped = DeviceLinkPredictionStep("COMPLEX", num_nodes, R, d, B, C, N, seed=seed, device=dev)
+    side = dist.new_group(backend="gloo")
+    tr = PipelinedShardedTrainer(piped, tc, sc, edges_all, None, 0, 1, num_nodes, sync_interval=1, side_group=side)
+    for s in range(3):
+        tr.step()
+    torch.cuda.synchronize()
+    assert_close(tc, ta, "pipelined table", rtol=1e-6)
+    assert_close(sc, sa, "pipelined state", rtol=1e-6)
+    assert_close(piped.rel, fused.rel, "pipelined rel", rtol=1e-6)
     dist.destroy_process_group()
