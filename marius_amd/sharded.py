@@ -169,7 +169,7 @@ class HipBackend:
 
 
 class _Slot:
-    """Per-batch buffers of the pipelined trainer (two slots alternate)."""
+    """Per-batch buffers of the pipelined trainer (a ring of four)."""
 
     def __init__(self, H, B, cols, L, world, dev):
         self.edges = torch.empty((B, cols), dtype=torch.int64, device=dev)
@@ -179,22 +179,41 @@ class _Slot:
         self.offs_dev = torch.empty(world + 1, dtype=torch.int64, device=dev)
         self.offs_host = torch.empty(world + 1, dtype=torch.int64).pin_memory()
         self.recv_host = torch.empty(world, dtype=torch.int64)
-        self.ready = torch.cuda.Event()
-        self.free = torch.cuda.Event()
+        self.ready = torch.cuda.Event()     # prep stream: ids sorted, split points on their way to the host
+        self.fetched = torch.cuda.Event()   # rows of this batch have arrived
+        self.computed = torch.cuda.Event()  # per-row gradients of this batch are complete
+        self.free = torch.cuda.Event()      # owners applied this batch's gradients: every buffer of the slot is reusable
         self.used = False
         self.src_neg = self.dst_neg = None
         self.filters = (None, None)
+        self.send_counts = self.recv_counts = None
+        self.U = self.nrecv = 0
+        self.emb = self.grad = self.local_ids = None
 
 
 class PipelinedShardedTrainer:
-    """sharded_step with the batch preparation (edge slice, negatives, sort/unique, owner split points, count exchange) running one
-    step ahead on a side stream.  Nothing about the update semantics changes — preparation does not read
-    the table — but the two host read-backs an all-to-all(v) needs (split points, receive counts) are then served from work that
-    finished long ago, so the main stream never drains while the host waits."""
+    """sharded_step as a pipeline over HIP streams.
 
-    def __init__(self, stepper, shard_table, shard_state, edges_all, perm, rank, world, num_nodes, sync_interval=1, group=None, side_group=None):
+    staleness = 0 (synchronous, the `sync` variant of SURVEY.md 8e): exactly sharded_step — every row a batch reads carries all
+    earlier updates — but the batch preparation (edge slice, negatives, sort/unique, owner split points) runs one step ahead on a
+    side stream: it never reads the table, so nothing changes, and the host read-back an all-to-all(v) needs (split points /
+    receive counts) is served from work that finished a step ago instead of draining the main stream.
+
+    staleness = 1 (the overlapped exchange of SURVEY.md 8e): additionally the row fetch of batch t+1 (ids all-to-all, owner gather,
+    rows all-to-all) and the gradient return + owner update of batch t run on an exchange stream underneath the scoring of
+    batch t / t+1.  Rows of batch t+1 are therefore read after the update of batch t-1 and before the update of batch t: a
+    staleness of exactly one step, inside the bound the reference's own multi-GPU trainer runs with (its multi-GPU mode exists only
+    as the asynchronous pipeline, pipeline_gpu.cpp:23-80, staleness_bound default 16, marius_config.py:673-676).
+    Stream order on the exchange stream:  fetch(t+1) | grads(t), update(t) | fetch(t+2) | ...
+    """
+
+    RING = 4
+
+    def __init__(self, stepper, shard_table, shard_state, edges_all, perm, rank, world, num_nodes, sync_interval=1, group=None,
+                 side_group=None, staleness=0, trace=None):
         from . import hip as H
 
+        assert staleness in (0, 1)
         self.H, self.s = H, stepper
         self.backend = HipBackend(stepper, shard_table, shard_state)
         self.edges_all, self.perm = edges_all, perm
@@ -203,12 +222,17 @@ class PipelinedShardedTrainer:
         self.lo, _ = shard_range(num_nodes, rank, world)
         self.sync_interval = sync_interval
         self.group, self.side_group = group, side_group
+        self.staleness = staleness
+        self.trace = trace
         dev = shard_table.device
         self.dev = dev
+        self.main_stream = torch.cuda.current_stream()
         self.prep_stream = torch.cuda.Stream(device=dev)
-        self.slots = [_Slot(H, stepper.B, stepper.edge_cols, stepper.L, world, dev) for _ in range(2)]
+        self.xchg_stream = torch.cuda.Stream(device=dev) if staleness else self.main_stream
+        self.slots = [_Slot(H, stepper.B, stepper.edge_cols, stepper.L, world, dev) for _ in range(self.RING)]
         self.nb = edges_all.size(0) // stepper.B
         self.next_prepared = 0
+        self.next_fetched = 0
         self.step_index = 0
         self._pool = {}
 
@@ -217,24 +241,33 @@ class PipelinedShardedTrainer:
         step keeps the caching allocator splitting/merging blocks (visible as multi-100-us jitter)."""
         b = self._pool.get(name)
         if b is None or b.size(0) < n:
+            if b is not None:  # the old block may still be read on either stream
+                b.record_stream(self.main_stream)
+                b.record_stream(self.xchg_stream)
             b = torch.empty((max(n + n // 4, 1),) + tuple(tail), dtype=dtype, device=self.dev)
             self._pool[name] = b
         return b[:n]
 
+    def _slot(self, t):
+        return self.slots[t % self.RING]
+
+    # ---- stage 1 (prep stream): everything that does not read the table
     def _prepare(self, t):
         H, s = self.H, self.s
-        slot = self.slots[t & 1]
+        slot = self._slot(t)
         B, CN = s.B, s.C * s.N
-        main = torch.cuda.current_stream()
         with torch.cuda.stream(self.prep_stream):
             if slot.used:
-                self.prep_stream.wait_event(slot.free)   # the step that used this slot two steps ago is done with it
+                self.prep_stream.wait_event(slot.free)   # the batch that used this slot RING steps ago is fully retired
             else:
-                self.prep_stream.wait_stream(main)
+                self.prep_stream.wait_stream(self.main_stream)
             st = H.stream_ptr()
             L_ = H.lib()
-            H.check(L_.marius_select_edges(H.ptr(self.edges_all), 1 if self.edges_all.dtype == torch.int64 else 0, s.edge_cols, H.ptr(self.perm),
-                                           (t % self.nb) * B, B, H.ptr(slot.edges), st), "select_edges")
+            if self.perm is None:
+                slot.edges.copy_(self.edges_all[(t % self.nb) * B: (t % self.nb) * B + B])
+            else:
+                H.check(L_.marius_select_edges(H.ptr(self.edges_all), 1 if self.edges_all.dtype == torch.int64 else 0, s.edge_cols, H.ptr(self.perm),
+                                               (t % self.nb) * B, B, H.ptr(slot.edges), st), "select_edges")
             slot.src_neg, slot.dst_neg, sdeg, ddeg = s.sample(slot.edges)
             slot.filters = (H.deg_filter(ddeg, B), H.deg_filter(sdeg, B)) if s.n_deg > 0 else (None, None)
             H.check(L_.marius_assemble_ids(H.ptr(slot.edges), B, s.edge_cols, H.ptr(slot.src_neg), H.ptr(slot.dst_neg), CN, H.ptr(slot.all_ids), st), "assemble")
@@ -244,51 +277,63 @@ class PipelinedShardedTrainer:
             slot.offs_host.copy_(slot.offs_dev, non_blocking=True)
             slot.ready.record(self.prep_stream)
             for tns in (slot.src_neg, slot.dst_neg) + tuple(f for f in slot.filters if f is not None):
-                tns.record_stream(main)
+                tns.record_stream(self.main_stream)
         slot.used = True
 
-    def step(self):
+    def _prepare_through(self, t):
+        while self.next_prepared <= t:
+            self._prepare(self.next_prepared)
+            self.next_prepared += 1
+
+    # ---- stage 2 (host + exchange stream): split sizes, then ids -> owners, rows -> requesters
+    def _fetch(self, t):
         H, s, be = self.H, self.s, self.backend
-        t = self.step_index
-        if self.next_prepared <= t:
-            self._prepare(t)
-            self.next_prepared = t + 1
-        slot = self.slots[t & 1]
-        main = torch.cuda.current_stream()
-        main.wait_event(slot.ready)
-        slot.ready.synchronize()  # host: split points + receive counts of THIS batch (prepared a step ago: no drain of the main stream)
+        slot = self._slot(t)
+        slot.ready.synchronize()  # host: split points of a batch prepared at least one step ago — no stream drains for this
         offs = slot.offs_host.tolist()
-        send_counts = [offs[i + 1] - offs[i] for i in range(self.world)]
+        slot.send_counts = [offs[i + 1] - offs[i] for i in range(self.world)]
         if self.world > 1:
             # counts travel over the CPU (gloo) group: a second RCCL communicator on another stream could share a hardware queue with
-            # the main one and order differently on different ranks; 8 integers over loopback cost less than that risk
-            send_t = torch.tensor(send_counts, dtype=torch.int64)
-            dist.all_to_all_single(slot.recv_host, send_t, group=self.side_group)
-            recv_counts = slot.recv_host.tolist()
+            # the main one and order differently on different ranks; `world` integers over loopback cost less than that risk
+            dist.all_to_all_single(slot.recv_host, torch.tensor(slot.send_counts, dtype=torch.int64), group=self.side_group)
+            slot.recv_counts = slot.recv_host.tolist()
         else:
-            recv_counts = list(send_counts)
-        U = offs[-1]
-        uniq = slot.um.uniq[:U]
-        nrecv = sum(recv_counts)
-        d = s.d
-        req_ids = a2a_rows(uniq, send_counts, recv_counts, self.group, out=self._buf("req", nrecv, (), torch.int64))
-        local_ids = torch.sub(req_ids, self.lo, out=self._buf("local", nrecv, (), torch.int64))
-        rows = H.gather_rows(be.table, local_ids, out=self._buf("rows", nrecv, (d,), torch.float32))
-        emb = a2a_rows(rows, recv_counts, send_counts, self.group, out=self._buf("emb", U, (d,), torch.float32))
-        # next batch's preparation overlaps with this batch's compute
-        self._prepare(t + 1)
-        self.next_prepared = t + 2
-        # ---- forward / loss / backward on this batch (same kernels as the single-GPU path)
-        B, CN = s.B, s.C * s.N
+            slot.recv_counts = list(slot.send_counts)
+        U, nrecv, d = offs[-1], sum(slot.recv_counts), s.d
+        slot.U, slot.nrecv = U, nrecv
+        k = t % self.RING
+        with torch.cuda.stream(self.xchg_stream):
+            self.xchg_stream.wait_event(slot.ready)
+            req_ids = a2a_rows(slot.um.uniq[:U], slot.send_counts, slot.recv_counts, self.group, out=self._buf("req", nrecv, (), torch.int64))
+            slot.local_ids = torch.sub(req_ids, self.lo, out=self._buf("local%d" % k, nrecv, (), torch.int64))
+            rows = H.gather_rows(be.table, slot.local_ids, out=self._buf("rows", nrecv, (d,), torch.float32))
+            slot.emb = a2a_rows(rows, slot.recv_counts, slot.send_counts, self.group, out=self._buf("emb%d" % k, U, (d,), torch.float32))
+            slot.fetched.record(self.xchg_stream)
+
+    def _fetch_through(self, t):
+        while self.next_fetched <= t:
+            self._prepare_through(self.next_fetched)
+            self._fetch(self.next_fetched)
+            self.next_fetched += 1
+
+    # ---- stage 3 (main stream): the same forward / loss / backward kernels as the single-GPU step
+    def _compute(self, t):
+        H, s = self.H, self.s
+        slot = self._slot(t)
+        B, CN, d, U = s.B, s.C * s.N, s.d, slot.U
+        self.main_stream.wait_event(slot.fetched)
         W = s.W
         src_map = slot.um.inverse[2 * B: 2 * B + CN]
         dst_map = slot.um.inverse[2 * B + CN: 2 * B + 2 * CN]
-        W.bind(emb, slot.edges_local, dst_map, src_map, s.rel, s.inv_rel, slot.filters[0], slot.filters[1])
+        W.bind(slot.emb, slot.edges_local, dst_map, src_map, s.rel, s.inv_rel, slot.filters[0], slot.filters[1])
         W.forward()
         W.loss()
         W.backward()
-        grad = self._buf("grad", U, (d,), torch.float32)
-        H.segment_sum_rows(W.gocc(), slot.um, s.L, d, grad, carry=s.carry)
+        slot.grad = self._buf("grad%d" % (t % self.RING), U, (d,), torch.float32)
+        H.segment_sum_rows(W.gocc(), slot.um, s.L, d, slot.grad, carry=s.carry)
+        slot.computed.record(self.main_stream)
+        if self.trace is not None:
+            self.trace.append({"uniq": slot.um.uniq[:U].clone(), "emb": slot.emb.clone(), "grad": slot.grad.clone()})
         s.rel_ids.copy_(slot.edges[:, 1])
         s.um_rel.run(s.rel_ids, s.rel_bits)
         s.rel_grad.zero_()
@@ -298,23 +343,50 @@ class PipelinedShardedTrainer:
             s.inv_rel_grad.zero_()
             H.segment_sum_rows(W.grel(1), s.um_rel, B, d, s.inv_rel_grad, out_rows=s.um_rel.uniq, carry=s.carry_rel)
             inv = s.inv_rel_grad
-        recv_grad = a2a_rows(grad, send_counts, recv_counts, self.group, out=self._buf("recv_grad", nrecv, (d,), torch.float32))
-        be.apply_local(local_ids, recv_grad)
-        rel_grads = [s.rel_grad, inv]
+        return [s.rel_grad, inv]
+
+    # ---- stage 4 (exchange stream): gradients -> owners, owners dedupe across senders + Adagrad + scatter
+    def _update(self, t):
+        slot = self._slot(t)
+        with torch.cuda.stream(self.xchg_stream):
+            self.xchg_stream.wait_event(slot.computed)
+            recv_grad = a2a_rows(slot.grad, slot.send_counts, slot.recv_counts, self.group, out=self._buf("recv_grad", slot.nrecv, (self.s.d,), torch.float32))
+            self.backend.apply_local(slot.local_ids, recv_grad)
+            slot.free.record(self.xchg_stream)
+
+    def _dense(self, t, rel_grads):
+        be = self.backend
         if self.sync_interval <= 1:
             for g in rel_grads:
                 if g is not None:
                     dist.all_reduce(g, group=self.group)
             be.dense_step(rel_grads)
         else:
-            be.dense_step(rel_grads)
+            be.dense_step(rel_grads)  # local step; replicas drift for at most sync_interval steps
             if (t + 1) % self.sync_interval == 0:
                 for tt in be.dense_state():
                     dist.all_reduce(tt, group=self.group)
                     tt.div_(self.world)
-        slot.free.record(main)
+
+    def step(self):
+        t = self.step_index
+        self._fetch_through(t)              # no-op except on the first step
+        if self.staleness:
+            self._prepare_through(t + 2)
+            self._fetch_through(t + 1)      # rows of the next batch move while this one is scored (read before update(t))
+            rel_grads = self._compute(t)
+            self._update(t)
+        else:
+            self._prepare_through(t + 1)    # next batch's preparation overlaps with this batch's compute
+            rel_grads = self._compute(t)
+            self._update(t)
+        self._dense(t, rel_grads)
         self.step_index += 1
-        return W.loss_values()[0]
+        return self.s.W.loss_values()[0]
+
+    def finish(self):
+        """Retire everything in flight (prefetched batches are simply dropped: preparation and fetch have no side effects)."""
+        torch.cuda.synchronize(self.dev)
 
 
 def run_sharded_bench(a, cfg, rank, world, dev):
@@ -339,9 +411,12 @@ def run_sharded_bench(a, cfg, rank, world, dev):
     nb = edges_all.size(0) // B
     sync_interval = int(os.environ.get("MARIUS_GPU_SYNC_INTERVAL", "16"))  # pipeline.gpu_sync_interval default (marius_config.py:672-685)
     pipelined = os.environ.get("MARIUS_SHARDED_PIPELINE", "1") != "0"
+    staleness = 0
     if pipelined:
         side_group = dist.new_group(backend="gloo")  # per-step count exchange (world integers) stays on the CPU
-        trainer = PipelinedShardedTrainer(stepper, table, state, edges_all, perm, rank, world, num_nodes, sync_interval=sync_interval, side_group=side_group)
+        staleness = int(os.environ.get("MARIUS_SHARDED_STALENESS", "1"))
+        trainer = PipelinedShardedTrainer(stepper, table, state, edges_all, perm, rank, world, num_nodes, sync_interval=sync_interval, side_group=side_group,
+                                          staleness=staleness)
 
         def run(k0, k):
             for _ in range(k):
@@ -374,7 +449,9 @@ def run_sharded_bench(a, cfg, rank, world, dev):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %s d=%d, node table sharded by contiguous id range over %d GPUs, B=%d per GPU, C=%d N=%d, %s edges" % (
                 a.workload, cfg["decoder"], d, world, B, C, N, a.edge_dist), "num_nodes": num_nodes, "num_relations": R,
-                "parallelism": "dp%d + sharded node table, RCCL all-to-all(v) row fetch / gradient return, relation tables averaged every %d steps" % (world, sync_interval)},
+                "parallelism": "dp%d + sharded node table, RCCL all-to-all(v) row fetch / gradient return, relation tables averaged every %d steps, %s" % (
+                    world, sync_interval, ("row exchange overlapped with scoring on a second stream (staleness 1 step; reference pipeline bound: 16)"
+                                           if pipelined and staleness else "synchronous exchange"))},
             "positive_edges_per_s": round(pos_eps, 1), "roofline": None, "cpu_baseline": None,
         }
         print(json.dumps(out))

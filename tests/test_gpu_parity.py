@@ -434,4 +434,28 @@ def test_sharded_hip_backend_equals_single_gpu_step(H, dev):
     assert_close(tc, ta, "pipelined table", rtol=1e-6)
     assert_close(sc, sa, "pipelined state", rtol=1e-6)
     assert_close(piped.rel, fused.rel, "pipelined rel", rtol=1e-6)
+    # overlapped exchange (staleness 1): rows of batch t are read after update t-2 and before update t-1 — replay the recorded
+    # (ids, rows used, row gradients) of every step through the Adagrad rule and check exactly that.
+    td, sd = table.to(dev), torch.zeros(num_nodes, d, device=dev)
+    ovl = DeviceLinkPredictionStep("COMPLEX", num_nodes, R, d, B, C, N, seed=seed, device=dev)
+    trace = []
+    tr = PipelinedShardedTrainer(ovl, td, sd, edges_all, None, 0, 1, num_nodes, sync_interval=1, side_group=side, staleness=1, trace=trace)
+    steps = 5
+    for s in range(steps):
+        tr.step()
+    tr.finish()
+    T, S_ = table.to(dev).clone(), torch.zeros(num_nodes, d, device=dev)
+    snaps = [T.clone()]  # snaps[k] = table after updates 0..k-1
+    for t in range(steps):
+        u, g = trace[t]["uniq"], trace[t]["grad"]
+        assert u.numel() == torch.unique(u).numel()
+        S_[u] += g * g
+        T[u] += -0.1 * g / (S_[u].sqrt() + 1e-10)
+        snaps.append(T.clone())
+    for t in range(steps):
+        expect = snaps[max(t - 1, 0)][trace[t]["uniq"]]
+        assert_close(trace[t]["emb"], expect, "rows of step %d carry updates < %d" % (t, max(t - 1, 0)), rtol=1e-6)
+    assert not torch.equal(trace[2]["emb"], snaps[2][trace[2]["uniq"]])  # the test data does make consecutive batches share rows
+    assert_close(td, T, "overlapped table", rtol=1e-5)
+    assert_close(sd, S_, "overlapped state", rtol=1e-5)
     dist.destroy_process_group()
