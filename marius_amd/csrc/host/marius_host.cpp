@@ -2,6 +2,7 @@
 #include "marius_host.h"
 
 #include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPFunctions.h>
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
@@ -296,6 +297,7 @@ void Batch::clear() {
     unique_node_indices_ = node_embeddings_ = node_embeddings_grad_ = node_gradients_ = node_state_update_ = node_embeddings_state_ = Tensor();
     edges_ = src_neg_indices_ = dst_neg_indices_ = src_neg_indices_mapping_ = dst_neg_indices_mapping_ = Tensor();
     src_neg_filter_ = dst_neg_filter_ = occ_perm_ = occ_inverse_ = occ_seg_offsets_ = num_unique_dev_ = Tensor();
+    rel_uniq_ = rel_inverse_ = rel_perm_ = rel_seg_ = rel_count_ = Tensor();
 }
 
 // ------------------------------------------------------------------------------------------------ LP context / fused decoder calls
@@ -610,36 +612,82 @@ static void model_backward(Model& m, shared_ptr<Batch> batch) {
     mcheck(marius_lp_loss(&c.desc, &c.layout, c.workspace.data_ptr(), st));
     mcheck(marius_lp_backward(&c.desc, &c.layout, c.workspace.data_ptr(), st));
     m.loss_ = c.view(c.layout.loss, {4});
-    if (c.desc.edge_cols == 3) {  // index_select backward into [R, d]: sort relation ids, segmented sum, no atomics
-        const int64_t B = c.desc.B;
-        auto dev = m.ctx_.workspace.device();
-        if (!m.rel_ids_.defined() || m.rel_ids_.size(0) != B) {
-            m.rel_ids_ = torch::empty({B}, i64(dev));
-            m.rel_uniq_ = torch::empty({B}, i64(dev));
-            m.rel_inverse_ = torch::empty({B}, i64(dev));
-            m.rel_perm_ = torch::empty({B}, i32(dev));
-            m.rel_seg_ = torch::empty({B + 1}, i32(dev));
-            m.rel_count_ = torch::zeros({1}, i64(dev));
-            ensure(m.rel_ws_, (int64_t)marius_sort_unique_workspace_bytes(B), dev);
-            ensure(m.rel_carry_, (int64_t)marius_segment_carry_bytes(B, c.desc.d), dev);
-        }
-        m.rel_ids_.copy_(batch->edges_.select(1, 1));
-        mcheck(marius_sort_unique(ip(m.rel_ids_), B, key_bits_for(c.desc.R), ip(m.rel_uniq_), ip(m.rel_inverse_), m.rel_perm_.data_ptr<int32_t>(),
-                                  m.rel_seg_.data_ptr<int32_t>(), ip(m.rel_count_), m.rel_ws_.data_ptr(), (size_t)m.rel_ws_.numel(), st));
-        Tensor* grads[2] = {&m.relations_grad_, &m.inverse_relations_grad_};
-        for (int dir = 0; dir < (c.desc.use_inverse ? 2 : 1); ++dir) {
-            grads[dir]->zero_();
-            const float* rows = (const float*)((const char*)c.workspace.data_ptr() + c.layout.grel[dir]);
-            mcheck(marius_segment_sum_rows(rows, c.layout.d_ld, m.rel_perm_.data_ptr<int32_t>(), ip(m.rel_inverse_), m.rel_seg_.data_ptr<int32_t>(), B,
-                                           c.desc.d, ip(m.rel_uniq_), fp(*grads[dir]), grads[dir]->stride(0), m.rel_carry_.data_ptr(), st));
-        }
+    (void)st;
+}
+
+// relation ids of the batch grouped by value: taken from the loader when it prepared them ahead, sorted here otherwise
+struct RelMap {
+    const int64_t* uniq;
+    const int64_t* inverse;
+    const int32_t* perm;
+    const int32_t* seg;
+};
+static RelMap relation_map(Model& m, shared_ptr<Batch> batch) {
+    LpContext& c = m.ctx_;
+    const int64_t B = c.desc.B;
+    if (batch->rel_perm_.defined() && batch->rel_perm_.size(0) == B)
+        return {ip(batch->rel_uniq_), ip(batch->rel_inverse_), batch->rel_perm_.data_ptr<int32_t>(), batch->rel_seg_.data_ptr<int32_t>()};
+    auto dev = c.workspace.device();
+    if (!m.rel_ids_.defined() || m.rel_ids_.size(0) != B) {
+        m.rel_ids_ = torch::empty({B}, i64(dev));
+        m.rel_uniq_ = torch::empty({B}, i64(dev));
+        m.rel_inverse_ = torch::empty({B}, i64(dev));
+        m.rel_perm_ = torch::empty({B}, i32(dev));
+        m.rel_seg_ = torch::empty({B + 1}, i32(dev));
+        m.rel_count_ = torch::zeros({1}, i64(dev));
+        ensure(m.rel_ws_, (int64_t)marius_sort_unique_workspace_bytes(B), dev);
     }
+    m.rel_ids_.copy_(batch->edges_.select(1, 1));
+    mcheck(marius_sort_unique(ip(m.rel_ids_), B, key_bits_for(c.desc.R), ip(m.rel_uniq_), ip(m.rel_inverse_), m.rel_perm_.data_ptr<int32_t>(),
+                              m.rel_seg_.data_ptr<int32_t>(), ip(m.rel_count_), m.rel_ws_.data_ptr(), (size_t)m.rel_ws_.numel(), cur_stream()));
+    return {ip(m.rel_uniq_), ip(m.rel_inverse_), m.rel_perm_.data_ptr<int32_t>(), m.rel_seg_.data_ptr<int32_t>()};
+}
+
+// relations_.grad / inverse_relations_.grad [R, d] (dense, as autograd leaves them): index_select backward without atomics
+static void relation_grads_dense(Model& m, shared_ptr<Batch> batch) {
+    LpContext& c = m.ctx_;
+    if (c.desc.edge_cols != 3) return;
+    const int64_t B = c.desc.B;
+    RelMap rm = relation_map(m, batch);
+    ensure(m.rel_carry_, (int64_t)marius_segment_carry_bytes(B, c.desc.d), c.workspace.device());
+    Tensor* grads[2] = {&m.relations_grad_, &m.inverse_relations_grad_};
+    for (int dir = 0; dir < (c.desc.use_inverse ? 2 : 1); ++dir) {
+        grads[dir]->zero_();
+        const float* rows = (const float*)((const char*)c.workspace.data_ptr() + c.layout.grel[dir]);
+        mcheck(marius_segment_sum_rows(rows, c.layout.d_ld, rm.perm, rm.inverse, rm.seg, B, c.desc.d, rm.uniq, fp(*grads[dir]), grads[dir]->stride(0),
+                                       m.rel_carry_.data_ptr(), cur_stream()));
+    }
+}
+
+// Dense Adagrad step on the relation tables restricted to the rows the batch touched.  A row with zero gradient is a fixed point of
+// the dense rule (sum += 0; w -= lr*0/(sqrt(sum)+eps)), so this equals AdagradOptimizer::step() on the dense gradient bit for bit
+// while skipping the [R, d] zero-fill, the dense scatter target and the full-table pass.  Returns false if the optimizer is not
+// plain Adagrad (then the caller takes the dense route).
+static bool relation_step_sparse(Model& m, shared_ptr<Batch> batch) {
+    LpContext& c = m.ctx_;
+    if (c.desc.edge_cols != 3) return true;
+    if (m.optimizers_.size() != 1) return false;
+    auto* opt = dynamic_cast<AdagradOptimizer*>(m.optimizers_[0].get());
+    if (!opt || opt->weight_decay_ != 0.f) return false;
+    const int ndir = c.desc.use_inverse ? 2 : 1;
+    if ((int)opt->params_.size() != ndir) return false;
+    const int64_t B = c.desc.B;
+    RelMap rm = relation_map(m, batch);
+    ensure(m.rel_carry_, (int64_t)marius_segment_carry_bytes(B, c.desc.d), c.workspace.device());
+    for (int dir = 0; dir < ndir; ++dir) {
+        Tensor& w = opt->params_[dir].first;
+        const float* rows = (const float*)((const char*)c.workspace.data_ptr() + c.layout.grel[dir]);
+        mcheck(marius_segment_adagrad_scatter(rows, c.layout.d_ld, rm.perm, rm.inverse, rm.seg, B, c.desc.d, rm.uniq, fp(w), fp(opt->state_[dir]), w.stride(0),
+                                              opt->learning_rate_, opt->eps_, m.rel_carry_.data_ptr(), cur_stream()));
+    }
+    return true;
 }
 
 void Model::train_batch(shared_ptr<Batch> batch, bool call_step) {
     if (call_step) clear_grad();
     forward_lp(batch, true);
     model_backward(*this, batch);
+    relation_grads_dense(*this, batch);
     // node_embeddings_.grad [U, d]: sum of the occurrence gradients per unique row (autograd's index_add), atomic-free
     const int64_t L = batch->occ_perm_.size(0);
     const int64_t U = batch->node_embeddings_.size(0);
@@ -654,10 +702,13 @@ void Model::train_batch(shared_ptr<Batch> batch, bool call_step) {
 }
 
 void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor state) {
-    clear_grad();
     forward_lp(batch, true);
     model_backward(*this, batch);
-    step();
+    if (!relation_step_sparse(*this, batch)) {
+        clear_grad();
+        relation_grads_dense(*this, batch);
+        step();
+    }
     const int64_t L = batch->occ_perm_.size(0);
     ensure(carry_, (int64_t)marius_segment_carry_bytes(L, ctx_.desc.d), device_);
     const float* gocc = (const float*)((const char*)ctx_.workspace.data_ptr() + ctx_.layout.gocc);
@@ -690,10 +741,82 @@ void DataLoader::initializeBatches(bool shuffle) {
     active_perm_ = shuffle ? perm.to(edges_->device_) : torch::arange(num_edges_, i64(edges_->device_));
     total_batches_ = (num_edges_ + batch_size_ - 1) / batch_size_;
     batches_left_ = total_batches_;
+    prepared_left_ = total_batches_;
+    next_.reset();
     batch_id_ = 0;
 }
 
+DataLoader::~DataLoader() {
+    next_.reset();
+    for (auto& e : ev_pool_)
+        if (e) (void)hipEventDestroy((hipEvent_t)e);
+    for (auto& e : ev_main_)
+        if (e) (void)hipEventDestroy((hipEvent_t)e);
+    delete (c10::hip::HIPStream*)loader_stream_;
+}
+
+namespace {
+struct StreamScope {  // make `s` the current torch stream of this thread for the lifetime of the object
+    c10::hip::HIPStream prev;
+    explicit StreamScope(c10::hip::HIPStream s) : prev(c10::hip::getCurrentHIPStream(s.device_index())) { c10::hip::setCurrentHIPStream(s); }
+    ~StreamScope() { c10::hip::setCurrentHIPStream(prev); }
+};
+}  // namespace
+
 shared_ptr<Batch> DataLoader::getBatch(bool exact_unique) {
+    if (!run_ahead_ && !next_) {
+        batches_left_--;
+        prepared_left_--;
+        return prepareBatch(exact_unique);
+    }
+    const auto dev_index = edges_->device_.index();
+    c10::hip::HIPStream main = c10::hip::getCurrentHIPStream(dev_index);
+    if (!loader_stream_) {
+        loader_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(false, dev_index));
+        for (auto& e : ev_pool_) {
+            hipEvent_t ev;
+            HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            e = ev;
+        }
+        for (auto& e : ev_main_) {
+            hipEvent_t ev;
+            HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            e = ev;
+        }
+    }
+    c10::hip::HIPStream loader = *(c10::hip::HIPStream*)loader_stream_;
+    auto prepare_on_loader = [&](bool exact) {
+        // Everything the compute stream has been given so far (the previous step; at an epoch start also the permutation upload) must
+        // be complete before the loader runs: it orders the reads of active_perm_ and makes the caching allocator's per-stream reuse
+        // safe (blocks freed by the previous batch return to the loader stream's pool while that step may still be executing).
+        hipEvent_t em = (hipEvent_t)ev_main_[ev_main_next_];
+        ev_main_next_ = (ev_main_next_ + 1) & 3;
+        HIPCHECK(hipEventRecord(em, main.stream()));
+        HIPCHECK(hipStreamWaitEvent(loader.stream(), em, 0));
+        shared_ptr<Batch> b;
+        {
+            StreamScope scope(loader);
+            b = prepareBatch(exact);
+        }
+        b->ready_ = ev_pool_[ev_next_];
+        ev_next_ = (ev_next_ + 1) & 3;
+        HIPCHECK(hipEventRecord((hipEvent_t)b->ready_, loader.stream()));
+        prepared_left_--;
+        return b;
+    };
+    if (next_ && next_exact_ != exact_unique) throw MariusRuntimeException("DataLoader: exact_unique changed while a batch was prepared ahead");
+    shared_ptr<Batch> batch = next_ ? next_ : prepare_on_loader(exact_unique);
+    next_.reset();
+    batches_left_--;
+    if (run_ahead_ && prepared_left_ > 0) {
+        next_ = prepare_on_loader(exact_unique);
+        next_exact_ = exact_unique;
+    }
+    HIPCHECK(hipStreamWaitEvent(main.stream(), (hipEvent_t)batch->ready_, 0));
+    return batch;
+}
+
+shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
     auto st = cur_stream();
     auto dev = edges_->device_;
     auto batch = std::make_shared<Batch>(train_);
@@ -701,7 +824,6 @@ shared_ptr<Batch> DataLoader::getBatch(bool exact_unique) {
     batch->start_idx_ = batch_id_ * batch_size_;
     batch->batch_size_ = std::min(batch_size_, num_edges_ - batch->start_idx_);
     batch_id_++;
-    batches_left_--;
     const int64_t B = batch->batch_size_;
     const int cols = (int)edges_->dim1_size_;
     // edge_sampler_->getEdges (edge.cpp:12-14): slice of the shuffled edges, cast to int64
@@ -735,6 +857,17 @@ shared_ptr<Batch> DataLoader::getBatch(bool exact_unique) {
     batch->occ_inverse_ = inverse_;
     batch->occ_seg_offsets_ = seg_;
     batch->num_unique_dev_ = count_;
+    if (train_ && cols == 3 && num_relations_ > 0) {  // index_select backward into [R, d] wants the relation ids grouped: sort them here
+        Tensor rel_ids = edges.select(1, 1).contiguous();
+        batch->rel_uniq_ = torch::empty({B}, i64(dev));
+        batch->rel_inverse_ = torch::empty({B}, i64(dev));
+        batch->rel_perm_ = torch::empty({B}, i32(dev));
+        batch->rel_seg_ = torch::empty({B + 1}, i32(dev));
+        batch->rel_count_ = torch::zeros({1}, i64(dev));
+        mcheck(marius_sort_unique(ip(rel_ids), B, key_bits_for(num_relations_), ip(batch->rel_uniq_), ip(batch->rel_inverse_),
+                                  batch->rel_perm_.data_ptr<int32_t>(), batch->rel_seg_.data_ptr<int32_t>(), ip(batch->rel_count_), sort_ws_.data_ptr(),
+                                  (size_t)sort_ws_.numel(), st));
+    }
     return batch;
 }
 
@@ -759,6 +892,8 @@ void DataLoader::updateEmbeddings(shared_ptr<Batch> batch, bool gpu) {
 
 // ------------------------------------------------------------------------------------------------ trainer / evaluator
 void SynchronousTrainer::train_one(bool fused) {
+    dataloader_->run_ahead_ = fused;
+    dataloader_->num_relations_ = fused ? model_->decoder_->num_relations_ : 0;
     if (fused) {
         auto batch = dataloader_->getBatch(/*exact_unique=*/false);  // no host sync anywhere in the step
         batch->node_embeddings_ = dataloader_->node_embeddings_->indexRead(batch->unique_node_indices_);

@@ -170,6 +170,10 @@ class Batch {
     Tensor src_neg_filter_, dst_neg_filter_;                     // [F, 2]
     // device-side products of the unique map that the fused update consumes
     Tensor occ_perm_, occ_inverse_, occ_seg_offsets_, num_unique_dev_;
+    // sorted-unique map of the batch's relation ids (column 1), prepared by the loader so the relation-gradient reduction needs no
+    // sort on the compute stream: uniq [B] (zero tail), inverse [B], perm [B] int32, seg [B+1] int32
+    Tensor rel_uniq_, rel_inverse_, rel_perm_, rel_seg_, rel_count_;
+    void* ready_ = nullptr;  // hipEvent_t recorded on the loader stream when the batch was prepared ahead (DataLoader owns it)
 
     void accumulateGradients(float learning_rate);  // batch.cpp:62-79
     void clear();                                   // batch.cpp:105-...
@@ -340,6 +344,20 @@ class DataLoader {
     // unique-map scratch (capacity-sized)
     Tensor all_ids_, uniq_, inverse_, perm_, seg_, count_, sort_ws_;
     int key_bits_ = 63;
+    // run-ahead: getBatch() hands out a batch prepared on the loader stream while the previous step was computing, then starts the
+    // next one.  Preparation (edge slice, negatives, map_tensors, relation-id sort) never reads the tables and consumes the generator
+    // in the same order, so results are identical to the serial loop; only small launch-bound kernels leave the compute stream.
+    bool run_ahead_ = false;
+    int num_relations_ = 0;   // > 0: also prepare the relation-id map (Batch::rel_*)
+    void* loader_stream_ = nullptr;
+    void* ev_pool_[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* ev_main_[4] = {nullptr, nullptr, nullptr, nullptr};
+    int ev_next_ = 0, ev_main_next_ = 0;
+    shared_ptr<Batch> next_;
+    bool next_exact_ = false;
+    int64_t prepared_left_ = 0;
+    ~DataLoader();
+    shared_ptr<Batch> prepareBatch(bool exact_unique);  // the body of getBatch, on the current stream
 
     DataLoader(shared_ptr<InMemory> edges, shared_ptr<InMemory> node_embeddings, shared_ptr<InMemory> node_embeddings_state,
                shared_ptr<CorruptNodeNegativeSampler> negative_sampler, shared_ptr<MariusGenerator> generator, int64_t batch_size, bool train);
