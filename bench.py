@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--edge-dist", default="zipf", choices=["zipf", "uniform"])
     ap.add_argument("--driver", default="cpp", choices=["cpp", "py"], help="host loop: C++ SynchronousTrainer (default) or the ctypes step driver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     a = ap.parse_args()
 
@@ -133,18 +134,32 @@ def main():
     run(0, a.warmup)
     torch.cuda.synchronize()
     H.profile_reset()
-    H.profile_enable(True)
+    # Timed region: HIP events only around the dominant kernel (the merged backward contraction) — every event pair costs a few
+    # microseconds of stream time, and a pair around each of the ~20 kernels of a step inflated the step by 6 %.
+    DOMINANT = "lp_grad_adj"
+    H.profile_enable(not a.no_profile, only=DOMINANT)
     t0 = time.perf_counter()
     run(a.warmup, a.steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     H.profile_enable(False)
-    prof = H.profile_read()
+    prof_timed = H.profile_read()
+    U, loss, _, _ = last_stats()
+    # Untimed follow-up pass with events around every instrumented kernel: the per-kernel table (`kernels`)
+    prof = {}
+    if not a.no_profile:
+        H.profile_reset()
+        H.profile_enable(True)
+        run(a.warmup + a.steps, min(10, a.steps))
+        torch.cuda.synchronize()
+        H.profile_enable(False)
+        prof = H.profile_read()
+        if prof_timed.get(DOMINANT, (0, 0))[1] > 0:
+            prof[DOMINANT] = prof_timed[DOMINANT]
 
     ms_per_step = dt / a.steps * 1e3
     pos_eps = B * a.steps / dt
     scored_eps = pos_eps * (2 + 2 * N)
-    U, loss, _, _ = last_stats()
 
     # ---- roofline of the kernels, from HIP events recorded on the launch stream inside the timed region
     Bp = C * math.ceil(B / C)
@@ -175,7 +190,7 @@ def main():
         else:
             ach, peak, unit = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         kernels[name] = {"bound": bound, "avg_ms": round(avg_ms, 4), "launches": cnt, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                         "frac": round(ach / peak, 4)}
+                         "frac": round(ach / peak, 4), "measured_in": "timed region" if name == DOMINANT else "untimed follow-up pass"}
     if "mt19937_fill" in kernels:  # run-ahead pool fills: one launch per 16 sampler requests, on a side stream (off the critical path)
         kernels["mt19937_fill"]["side_stream"] = True
         kernels["mt19937_fill"]["achieved"] = round(kernels["mt19937_fill"]["achieved"] * 16, 2)

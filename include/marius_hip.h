@@ -35,7 +35,9 @@ int marius_hip_abi_version(void);
 const char* marius_hip_last_error(void);
 
 /* Optional HIP-event profiler (bench.py's roofline): when enabled, the library records hipEvents on the launch stream
- * around its main kernels; marius_profile_read waits for them and returns the accumulated kernel time. */
+ * around its main kernels; marius_profile_read waits for them and returns the accumulated kernel time.
+ * marius_profile_enable(on): 0 = off, 1 = every instrumented kernel, 2 + id = only kernel `id` (two events per launch of that kernel
+ * and nothing else: each event pair costs a few microseconds of stream time, which matters inside a timed region). */
 int marius_profile_enable(int on);
 int marius_profile_reset(void);
 int marius_profile_kernel_count(void);

@@ -31,6 +31,7 @@ bool prof_enabled() { return g_prof_on != 0; }
 void prof_begin(int id, hipStream_t st, ProfMark& m) {
     m.id = -1;
     if (!g_prof_on) return;
+    if (g_prof_on >= 2 && id != g_prof_on - 2) return;  // single-kernel mode
     if (hipEventCreate(&m.a) != hipSuccess || hipEventCreate(&m.b) != hipSuccess) return;
     m.id = id;
     hipEventRecord(m.a, st);

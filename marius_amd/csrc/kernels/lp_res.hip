@@ -915,11 +915,10 @@ constexpr int H_KC = 32;          // K chunk
 constexpr int H_NT = 8;           // up to 8 x 16 = 128 output columns per n-block
 constexpr int H_QS_MK = H_KC + 4; // V staged [m][k] (grad_adj): 16-B aligned rows
 constexpr int H_QS_KM = H_TM + 4; // V staged [k][m] (grad_neg)
-constexpr int H_BS = 128 + 4;     // B staged [k][n]
 constexpr int H_QSZ = (H_TM * H_QS_MK > H_KC * H_QS_KM) ? H_TM * H_QS_MK : H_KC * H_QS_KM;
 constexpr int H_MAXIDS = 2048;    // negative-row indices of one chunk kept in LDS as int32 (N <= 2048 on this path)
-// dynamic LDS layout (floats): Qs[2][H_QSZ] | Bs[2][H_KC * H_BS] | sums[H_TM] | ids[H_MAXIDS] (grad_adj only, sized by N)
-static inline size_t grad16_lds_bytes(int N) { return (size_t)(2 * H_QSZ + 2 * H_KC * H_BS + H_TM + ((N + 3) / 4) * 4) * sizeof(float); }
+// dynamic LDS layout (floats): Qs[2][H_QSZ] | Bs[2][H_KC * (16 NT + 4)] | sums[H_TM] | ids[H_MAXIDS] (grad_adj only, sized by N)
+static inline size_t grad16_lds_bytes(int N, int nt) { return (size_t)(2 * H_QSZ + 2 * H_KC * (16 * nt + 4) + H_TM + ((N + 3) / 4) * 4) * sizeof(float); }
 
 // Both backward contractions stream K in chunks of 32 through a double-buffered LDS ring with ONE barrier per chunk and
 // a two-chunk-deep register prefetch (register sets 0/1 alternate, so every global load has two chunk periods to land).
@@ -927,9 +926,10 @@ static inline size_t grad16_lds_bytes(int N) { return (size_t)(2 * H_QSZ + 2 * H
 // dAdj_c[m, n] = sum_j V[m, j] * Neg_c[j, n]
 template <bool L2, int NT>
 __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int unit, int tiles_m, float* smem) {
+    constexpr int BS = 16 * NT + 4;  // B staged [k][n]: stride % 8 == 4 keeps the four k-rows of an MFMA B fragment on disjoint banks
     float(*Qs)[H_QSZ] = reinterpret_cast<float(*)[H_QSZ]>(smem);
-    float(*Bs)[H_KC * H_BS] = reinterpret_cast<float(*)[H_KC * H_BS]>(smem + 2 * H_QSZ);
-    float* rsum = smem + 2 * H_QSZ + 2 * H_KC * H_BS;
+    float(*Bs)[H_KC * BS] = reinterpret_cast<float(*)[H_KC * BS]>(smem + 2 * H_QSZ);
+    float* rsum = smem + 2 * H_QSZ + 2 * H_KC * BS;
     int* idl = reinterpret_cast<int*>(rsum + H_TM);
     const LpDims& D = a.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1002,12 +1002,12 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
                 const int e = ones_col & 3;
                 if (e == 0) v.x = 1.f; else if (e == 1) v.y = 1.f; else if (e == 2) v.z = 1.f; else v.w = 1.f;
             }
-            *reinterpret_cast<float4*>(&Bs[buf][r * H_BS + 4 * bpiece]) = v;
+            if (4 * bpiece < 16 * NT) *reinterpret_cast<float4*>(&Bs[buf][r * BS + 4 * bpiece]) = v;
         }
     };
     auto compute = [&](int buf) {
         const float* qp = &Qs[buf][(wave * 16 + l15) * H_QS_MK + 4 * kq];
-        const float* bp = &Bs[buf][(4 * kq) * H_BS + l15];
+        const float* bp = &Bs[buf][(4 * kq) * BS + l15];
         // 8 steps of NT MFMAs; the NT B values (and the A value) of step i+1 are read from LDS before the MFMAs of step i issue
         float bc[NT], bn[NT];
         float4 a4 = *reinterpret_cast<const float4*>(qp);
@@ -1020,7 +1020,7 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
             float4 a4n = a4;
             if (i + 1 < H_KC / 4) {
                 const int sn = (i + 1) >> 2, en = (i + 1) & 3;
-                const float* brow_p = bp + (16 * sn + en) * H_BS;
+                const float* brow_p = bp + (16 * sn + en) * BS;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) bn[t] = brow_p[16 * t];
                 if (en == 0) a4n = *reinterpret_cast<const float4*>(qp + 16 * sn);
@@ -1087,9 +1087,10 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
 // dNeg_c[m, n] = sum_i V[i, m] * adj_c[i, n]
 template <bool L2, int NT>
 __device__ __forceinline__ void grad_neg16_body(const GradArgs& a, int cd, int unit, int tiles_m, float* smem) {
+    constexpr int BS = 16 * NT + 4;  // B staged [k][n]: stride % 8 == 4 keeps the four k-rows of an MFMA B fragment on disjoint banks
     float(*Qs)[H_QSZ] = reinterpret_cast<float(*)[H_QSZ]>(smem);
-    float(*Bs)[H_KC * H_BS] = reinterpret_cast<float(*)[H_KC * H_BS]>(smem + 2 * H_QSZ);
-    float* csum = smem + 2 * H_QSZ + 2 * H_KC * H_BS;
+    float(*Bs)[H_KC * BS] = reinterpret_cast<float(*)[H_KC * BS]>(smem + 2 * H_QSZ);
+    float* csum = smem + 2 * H_QSZ + 2 * H_KC * BS;
     const LpDims& D = a.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -1156,12 +1157,12 @@ __device__ __forceinline__ void grad_neg16_body(const GradArgs& a, int cd, int u
                 const int e = ones_col & 3;
                 if (e == 0) v.x = 1.f; else if (e == 1) v.y = 1.f; else if (e == 2) v.z = 1.f; else v.w = 1.f;
             }
-            *reinterpret_cast<float4*>(&Bs[buf][r * H_BS + 4 * bpiece]) = v;
+            if (4 * bpiece < 16 * NT) *reinterpret_cast<float4*>(&Bs[buf][r * BS + 4 * bpiece]) = v;
         }
     };
     auto compute = [&](int buf) {
         const float* qp = &Qs[buf][(4 * kq) * H_QS_KM + wave * 16 + l15];
-        const float* bp = &Bs[buf][(4 * kq) * H_BS + l15];
+        const float* bp = &Bs[buf][(4 * kq) * BS + l15];
         float bc[NT], bn[NT];
         float ac = qp[0], an = 0.f;
 #pragma unroll
@@ -1170,7 +1171,7 @@ __device__ __forceinline__ void grad_neg16_body(const GradArgs& a, int cd, int u
         for (int i = 0; i < H_KC / 4; ++i) {
             if (i + 1 < H_KC / 4) {
                 const int sn = (i + 1) >> 2, en = (i + 1) & 3;
-                const float* brow_p = bp + (16 * sn + en) * H_BS;
+                const float* brow_p = bp + (16 * sn + en) * BS;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) bn[t] = brow_p[16 * t];
                 an = qp[(16 * sn + en) * H_QS_KM];
@@ -1388,7 +1389,8 @@ bool launch_grad16(const GradArgs& a, bool l2, int which, hipStream_t st) {
     const int tiles_adj = (int)cdiv(a.D.Bc, H_TM), tiles_neg = (int)cdiv(a.D.N, H_TM);
     const int units_adj = (which == 2) ? 0 : tiles_adj * nblk;
     const int units_neg = (which == 1) ? 0 : tiles_neg * nblk;
-    const size_t lds = grad16_lds_bytes(a.D.N);
+    const int nt_inst = nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : nt <= 7 ? 7 : 8;
+    const size_t lds = grad16_lds_bytes(a.D.N, nt_inst);
     dim3 grid(xcd_grid2(units_adj + units_neg, a.D.C * a.D.ndir));
     if (l2)
         GRAD16_DISPATCH(true);

@@ -373,8 +373,13 @@ def segment_adagrad_scatter(rows, um, n, d, table, state, lr, eps=1e-10, carry=N
           "segment_adagrad_scatter")
 
 
-def profile_enable(on=True):
-    lib().marius_profile_enable(1 if on else 0)
+def profile_enable(on=True, only=None):
+    """on: record HIP events around every instrumented kernel; only="name": around that kernel alone (cheap enough for a timed region)."""
+    mode = 1 if on else 0
+    if on and only is not None:
+        names = [lib().marius_profile_kernel_name(i).decode() for i in range(lib().marius_profile_kernel_count())]
+        mode = 2 + names.index(only)
+    lib().marius_profile_enable(mode)
 
 
 def profile_reset():
