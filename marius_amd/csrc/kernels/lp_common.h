@@ -57,6 +57,12 @@ struct ScoreArgs {
     int ablate;  // debug only (MARIUS_ABLATE): 1 = skip S stores, 2 = skip MFMAs, 4 = skip negative-tile staging
     unsigned long long* dbg;  // debug only: per-phase s_memtime stamps of the first workgroups (MARIUS_DBG_TIMELINE)
     float* lse_part;  // optional [ndir][Bp][ngroups][2]: per (row, negative-tile group) running (max, sum exp) from the score epilogue
+    // bf16-split operand planes (lp_split.hip): [3][rows][kp] bf16, plane stride in elements
+    const void* embp;
+    int64_t embp_plane;
+    const void* adjp;
+    int64_t adjp_plane;
+    int kp;
     LpDims D;
 };
 
@@ -75,6 +81,7 @@ struct GradArgs {
     int64_t negocc_off[2];  // first gocc row of dir's negatives
     int ncols;              // useful columns per n-block (128, or 127 when the ones column is appended for L2)
     int ablate;             // debug only (MARIUS_ABLATE): 2 = skip MFMAs, 4 = skip V staging, 8 = skip B staging, 16 = skip exp
+    unsigned long long* dbg;  // debug only: cycle stamps (marius_debug_set_timeline)
     LpDims D;
 };
 
@@ -111,6 +118,14 @@ inline void scores_a_geometry(int N, int& ntpg, int& ngroups) {
     ngroups = (ntiles + ntpg - 1) / ntpg;
 }
 bool scores_a_applicable(const float* emb, int64_t emb_ld, int d);
+// persistent variant of the same kernel: units of two 32-column tiles, one SoftmaxCE partial per (row, unit)
+inline int scores_ap_groups(int N) { return ((N + 31) / 32 + 1) / 2; }
+bool launch_scores_ap(const ScoreArgs& a, bool l2, hipStream_t st);
+// same structure on the BF16 matrix pipe with exact 3-way operand splitting (lp_split.hip)
+bool scores_b6_applicable(const float* emb, int64_t emb_ld, int d);
+// rows[n][ld] fp32 -> planes[3][n][kp] bf16 (exact hi/mid/lo split, zero K padding)
+int launch_split_rows(const float* src, int64_t ld, int64_t rows, int d, int kp, void* planes, int64_t plane_elems, hipStream_t st);
+bool launch_scores_b6(const ScoreArgs& a, bool l2, hipStream_t st);
 bool launch_scores_a(const ScoreArgs& a, bool l2, hipStream_t st);
 // resident-operand / 16x16x4 variants (lp_res.hip): additionally d <= 128 for the score kernel
 bool launch_scores_res(const ScoreArgs& a, bool l2, hipStream_t st);

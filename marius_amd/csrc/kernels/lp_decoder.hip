@@ -646,7 +646,9 @@ static unsigned long long* g_dbg_timeline = nullptr;
 static char scores_variant(const marius_lp_desc* d, const LpDims& D) {
     const char* v = getenv("MARIUS_SCORES");
     const bool want_res = v && v[0] == 'r';
-    if (!want_res && scores_a_applicable(d->emb, d->emb_ld, D.d)) return 'a';
+    if (v && v[0] == 'b' && scores_b6_applicable(d->emb, d->emb_ld, D.d) && d->U <= 2 * D.B + (int64_t)(d->src_neg ? 2 : 1) * D.C * D.N)
+        return 'b';  // bf16x6 split (lp_split.hip); the plane buffers hold at most 2B + 2CN rows
+    if (!want_res && scores_a_applicable(d->emb, d->emb_ld, D.d)) return (v && v[0] == 'p') ? 'p' : 'a';  // 'p': persistent variant
     if (scores_res_applicable(d->emb, d->emb_ld, D.d)) return 'r';
     return 0;
 }
@@ -659,6 +661,7 @@ static int lse_fused_groups(const marius_lp_desc* d, const LpDims& D) {
     int ntpg, ng;
     const char v = scores_variant(d, D);
     if (v == 'a') scores_a_geometry(D.N, ntpg, ng);
+    else if (v == 'p' || v == 'b') ng = scores_ap_groups(D.N);
     else if (v == 'r') scores_res_geometry(D.N, ntpg, ng);
     else return 0;
     return ng;
@@ -732,9 +735,12 @@ static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layou
     for (int dir = 0; dir < D.ndir; ++dir) L->grel[dir] = base + (size_t)dir * D.B * D.d_ld * 4;
     L->aux = take((rows + (size_t)D.C * D.N) * 4 * D.ndir);
     {
-        const size_t ng = (size_t)(D.N + 127) / 128 + 1;  // upper bound over the score-kernel variants
+        const size_t ng = (size_t)(D.N + 63) / 64 + 1;  // upper bound over the score-kernel variants (finest: one partial per 64 columns)
         L->lsepart = take(rows * ng * 2 * 4 * D.ndir);
     }
+    L->kp = (D.d + 15) / 16 * 16;
+    L->embp = take(nocc * (size_t)L->kp * 2 * 3);
+    L->adjp = take(rows * D.ndir * (size_t)L->kp * 2 * 3);
     L->total_bytes = off;
     return MARIUS_OK;
 }
@@ -790,6 +796,9 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     }
 
     ScoreArgs sa;
+    sa.embp = sa.adjp = nullptr;
+    sa.embp_plane = sa.adjp_plane = 0;
+    sa.kp = (int)L->kp;
     sa.adj = pa.adj;
     sa.emb = desc->emb;
     sa.emb_ld = desc->emb_ld;
@@ -806,13 +815,27 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     sa.D = D;
     { const char* ab = getenv("MARIUS_ABLATE"); sa.ablate = ab ? atoi(ab) : 0; }
     sa.lse_part = lse_fused(desc, D) ? (float*)(ws + L->lsepart) : nullptr;
-    sa.dbg = g_dbg_timeline;
+    sa.dbg = getenv("MARIUS_TIMELINE_GRADS") ? nullptr : g_dbg_timeline;
     dim3 grid((unsigned)cdiv(D.N, F_TN), (unsigned)cdiv(D.Bc, F_TM), (unsigned)(D.C * D.ndir));
     size_t lds = (size_t)(F_TM + F_TN) * sa.KS * sizeof(float);
+    if (kernel_level() == 2 && scores_variant(desc, D) == 'b') {
+        const int64_t nocc = 2 * D.B + (int64_t)(desc->src_neg ? 2 : 1) * D.C * D.N;
+        const int64_t erows = desc->U < nocc ? desc->U : nocc;
+        sa.embp = ws + L->embp;
+        sa.embp_plane = nocc * L->kp;
+        sa.adjp = ws + L->adjp;
+        sa.adjp_plane = D.Bp * D.ndir * L->kp;
+        rc = launch_split_rows(desc->emb, desc->emb_ld, erows, D.d, (int)L->kp, ws + L->embp, sa.embp_plane, st);
+        if (rc) return rc;
+        rc = launch_split_rows(pa.adj, D.d_ld, D.Bp * D.ndir, D.d, (int)L->kp, ws + L->adjp, sa.adjp_plane, st);
+        if (rc) return rc;
+    }
     {
         ProfScope ps(PROF_LP_SCORES, st);
         const int lvl = kernel_level();
-        if (!((lvl >= 3 && launch_scores_pp(sa, l2, st)) || (lvl == 2 && scores_variant(desc, D) == 'a' && launch_scores_a(sa, l2, st)) ||
+        if (!((lvl >= 3 && launch_scores_pp(sa, l2, st)) || (lvl == 2 && scores_variant(desc, D) == 'b' && launch_scores_b6(sa, l2, st)) ||
+              (lvl == 2 && scores_variant(desc, D) == 'p' && launch_scores_ap(sa, l2, st)) ||
+              (lvl == 2 && scores_variant(desc, D) == 'a' && launch_scores_a(sa, l2, st)) ||
               (lvl >= 2 && launch_scores_res(sa, l2, st)) || (lvl >= 1 && launch_scores_fast(sa, l2, st)))) {
             if (l2)
                 lp_scores_kernel<true><<<grid, dim3(256), lds, st>>>(sa);
@@ -893,6 +916,7 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     ga.ncols = l2 ? G_TN - 1 : G_TN;
     ga.D = D;
     { const char* ab = getenv("MARIUS_ABLATE"); ga.ablate = ab ? atoi(ab) : 0; }
+    ga.dbg = getenv("MARIUS_TIMELINE_GRADS") ? g_dbg_timeline : nullptr;
     const unsigned nblk = (unsigned)cdiv(D.d, ga.ncols);
     dim3 ga_grid(nblk, (unsigned)cdiv(D.Bc, G_TM), (unsigned)(D.C * D.ndir));
     dim3 gn_grid(nblk, (unsigned)cdiv(D.N, G_TM), (unsigned)(D.C * D.ndir));

@@ -810,6 +810,10 @@ __global__ __launch_bounds__(256, 3) void lp_scores_a_kernel(ScoreArgs a, int ng
     issue(ids1, vb1);  // tile 3
     load_ids(4, ids0);
     load_ids(5, ids1);
+    // land the adj fragments before the step loop: a wait at their first use inside the loop is merged conservatively at the loop
+    // header and drains younger loads on every step (see lp_split.hip)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(af[q].x), "+v"(af[q].y));
     __syncthreads();
     STAMP();
 
@@ -909,7 +913,227 @@ __global__ __launch_bounds__(256, 3) void lp_scores_a_kernel(ScoreArgs a, int ng
 #undef STAMP
 }
 
+// =========================================================================================== scores, adj in registers, persistent
+// lp_scores_a_kernel spends 28 % of a workgroup's life in its prologue (ids -> rows -> LDS, adj fragments) for only four 32-column
+// steps, and 6400 equal workgroups over 768 resident slots quantise to 8.33 -> 9 rounds.  Here 768 workgroups (3 per CU, all
+// resident) each walk a contiguous range of the global unit list in (chunk-direction, row tile, column pair) order, a unit being two
+// 32-column steps: one prologue per workgroup, the negative-tile pipeline (ids six steps ahead, rows four, LDS two) runs straight
+// through unit and tile seams, and the ranges are balanced to +-1 unit (12800 units / 768 = 16.67).  Only the adj fragments are
+// reloaded at a row-tile seam.  Ranges are contiguous per XCD (block b runs on XCD b % 8), so a chunk's negative rows stay in one
+// L2.  SoftmaxCE partials are flushed per unit: lse_part[row][npairs][2].
+template <bool L2, int NQ>
+__global__ __launch_bounds__(256, 3) void lp_scores_ap_kernel(ScoreArgs a, int npairs, int mtiles, int total_units, int nwg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LpDims& D = a.D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int per_xcd = nwg >> 3;
+    const int wlin = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int u0 = (int)((int64_t)wlin * total_units / nwg), u1 = (int)((int64_t)(wlin + 1) * total_units / nwg);
+    if (u0 >= u1) return;
+    const int ntiles = (D.N + A_TN - 1) / A_TN;
+    const int ncd = D.C * D.ndir;
+    const int KS = a.KS;
+
+    struct Cur { int cd, mt, g; };
+    auto advance = [&](Cur& c) {
+        if (++c.g == npairs) {
+            c.g = 0;
+            if (++c.mt == mtiles) { c.mt = 0; ++c.cd; }
+        }
+    };
+    Cur cur;
+    {
+        const int per_cd = mtiles * npairs;
+        cur.cd = u0 / per_cd;
+        const int r = u0 - cur.cd * per_cd;
+        cur.mt = r / npairs;
+        cur.g = r - cur.mt * npairs;
+    }
+    Cur pre = cur;
+
+    const int piece = tid & 31, row = tid >> 5;  // 32 thr x 16 B per row, 8 rows per pass, 4 passes = 32 rows
+    const bool col_ok = 4 * piece < D.d;
+    const int colc = col_ok ? 4 * piece : 0;
+    int64_t ids0[4], ids1[4];
+    float4 vb0[4], vb1[4];
+    auto load_ids = [&](const Cur& c, int s_, int64_t(&ids)[4]) {
+        const int cdc = c.cd < ncd ? c.cd : ncd - 1;  // prefetch past the end of the list re-reads valid rows
+        const int dir = cdc / D.C, cc = cdc - dir * D.C;
+        const int64_t* negmap = (dir ? a.negmap[1] : a.negmap[0]) + (int64_t)cc * D.N;
+        const int t = 2 * c.g + s_;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int n = t * A_TN + row + 8 * it;
+            ids[it] = negmap[n < D.N ? n : 0];
+        }
+    };
+    auto issue = [&](const int64_t(&ids)[4], float4(&vb)[4]) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) vb[it] = *reinterpret_cast<const float4*>(a.emb + ids[it] * a.emb_ld + colc);
+    };
+    auto write = [&](int slot, const float4(&vb)[4]) {  // columns past N hold a valid row; their scores are never stored nor summed
+        if (col_ok) {
+            float* buf = smem + slot * (A_TN * KS);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) lds_store4x(buf + (row + 8 * it) * KS + 4 * piece, vb[it]);
+        }
+    };
+
+    // ---- prologue: steps 0,1 -> LDS, steps 2,3 in flight (sets 0,1), ids of steps 4,5 loaded
+    load_ids(pre, 0, ids0);
+    load_ids(pre, 1, ids1);
+    issue(ids0, vb0);
+    issue(ids1, vb1);
+    advance(pre);
+    load_ids(pre, 0, ids0);
+    load_ids(pre, 1, ids1);
+    write(0, vb0);
+    write(1, vb1);
+    issue(ids0, vb0);
+    issue(ids1, vb1);
+    advance(pre);
+    load_ids(pre, 0, ids0);
+    load_ids(pre, 1, ids1);
+    advance(pre);  // pre = u0 + 3: the next ids to fetch
+
+    // per row-tile state
+    float2 af[NQ];
+    float* srow = nullptr;
+    float xx = 0.f;
+    bool m_ok = false;
+    int64_t rowbase = 0;
+    int m_row = 0, dirc = 0, cc = 0;
+    auto load_tile = [&](const Cur& c) {
+        dirc = c.cd / D.C;
+        cc = c.cd - dirc * D.C;
+        rowbase = (int64_t)dirc * D.Bp + (int64_t)cc * D.Bc;
+        m_row = c.mt * A_TM + wave * 32 + l31;
+        m_ok = m_row < D.Bc;
+        const float* arow = a.adj + (rowbase + (m_ok ? m_row : 0)) * D.d_ld + 2 * h;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) af[q] = *reinterpret_cast<const float2*>(arow + 4 * q);
+        if (!m_ok) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) af[q] = make_float2(0.f, 0.f);
+        }
+        srow = a.S + (rowbase + (m_ok ? m_row : 0)) * D.n_ld;
+        if (L2) xx = m_ok ? a.x2[rowbase + m_row] : 0.f;
+        // land the fragments here: a wait at their first use inside the step loop would be vmcnt(0) on every step (see lp_split.hip)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(af[q].x), "+v"(af[q].y));
+    };
+    load_tile(cur);
+    {
+        // All 768 workgroups start together, so the three that share a CU would run their MFMA / store phases in lockstep and the
+        // phases would add up instead of overlapping.  Skew them by a third of a step period each, keyed on the hardware wave slot
+        // of wave 0 (HW_ID[3:0]; co-resident waves of one SIMD hold different slots).
+        __shared__ int phase_s;
+        if (tid == 0) phase_s = (int)(__builtin_amdgcn_s_getreg(0x1804) % 3u);
+        __syncthreads();
+        const int ph = a.ablate & 32 ? 0 : phase_s;
+        for (int k = 0; k < ph; ++k) __builtin_amdgcn_s_sleep(60);
+    }
+    __syncthreads();
+
+    float run_m = -3.0e38f, run_l = 0.f;
+    int slot = 0;  // LDS slot of the current step; the step two ahead goes to (slot + 2) % 3
+
+    auto step = [&](int t, const int64_t(&ids)[4], float4(&vb)[4]) {
+        // on entry: LDS holds this step and the next; `vb` holds the step two ahead; `ids` the ids of the step four ahead
+        const float* bp = smem + slot * (A_TN * KS) + l31 * KS + 2 * h;
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float2 bv[2];
+        bv[0] = *reinterpret_cast<const float2*>(bp);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q + 1 < NQ) bv[(q + 1) & 1] = *reinterpret_cast<const float2*>(bp + 4 * (q + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            acc = mfma32(bv[q & 1].x, af[q].x, acc);  // D[n][m]: the lane owns row m and 16 columns n
+            acc = mfma32(bv[q & 1].y, af[q].y, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int wslot = slot >= 1 ? slot - 1 : 2;  // (slot + 2) % 3, last read one step ago
+        write(wslot, vb);
+        issue(ids, vb);
+        slot = slot == 2 ? 0 : slot + 1;
+        if (t < ntiles) {
+            const int nb = t * A_TN + 4 * h;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v[r] = acc[r];
+                if (L2) {
+#pragma clang fp contract(off)
+                    const int n = nb + 8 * (r >> 2) + (r & 3);
+                    const float yy = (n < D.N) ? a.y2[(int64_t)dirc * D.C * D.N + (int64_t)cc * D.N + n] : 0.f;
+                    const float tt = (xx + yy) - 2.f * v[r];
+                    v[r] = sqrtf(fmaxf(tt, 1e-8f));
+                }
+            }
+            if (m_ok) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nb + 8 * q;
+                    if (n + 3 < D.N) {
+                        *reinterpret_cast<float4*>(srow + n) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < D.N) srow[n + e] = v[4 * q + e];
+                    }
+                }
+            }
+            if (a.lse_part) {
+                float tmax = -3.0e38f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = nb + 8 * (r >> 2) + (r & 3);
+                    if (n < D.N) tmax = fmaxf(tmax, v[r]);
+                }
+                const float mnew = fmaxf(run_m, tmax);
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = nb + 8 * (r >> 2) + (r & 3);
+                    if (n < D.N) sum += __expf(v[r] - mnew);
+                }
+                run_l = run_l * __expf(run_m - mnew) + sum;
+                run_m = mnew;
+            }
+        }
+        __syncthreads();
+    };
+
+    for (int u = u0; u < u1; ++u) {
+        step(2 * cur.g, ids0, vb0);
+        load_ids(pre, 0, ids0);
+        step(2 * cur.g + 1, ids1, vb1);
+        load_ids(pre, 1, ids1);
+        advance(pre);
+        if (a.lse_part) {
+            const float m2 = __shfl_xor(run_m, 32, 64), l2 = __shfl_xor(run_l, 32, 64);
+            const float mm = fmaxf(run_m, m2);
+            const float ll = run_l * __expf(run_m - mm) + l2 * __expf(m2 - mm);
+            if (h == 0 && m_ok) {
+                float* out = a.lse_part + (((rowbase + m_row) * npairs) + cur.g) * 2;
+                out[0] = mm;
+                out[1] = ll;
+            }
+            run_m = -3.0e38f;
+            run_l = 0.f;
+        }
+        advance(cur);
+        if (cur.g == 0 && u + 1 < u1) load_tile(cur);  // row-tile seam: new adj fragments (the B pipeline keeps running)
+    }
+}
+
 // =========================================================================================== backward contractions, 16x16x4 tiles
+#ifndef GRAD_ABLATE
+#define GRAD_ABLATE 0  // experiment builds only (tools/ablate_grad16.sh): 2 = VALU stand-in for the MFMAs, 4 = no LDS staging writes, 8 = no global loads after the prologue
+#endif
 constexpr int H_TM = 64;          // output rows per workgroup (4 waves x 16)
 constexpr int H_KC = 32;          // K chunk
 constexpr int H_NT = 8;           // up to 8 x 16 = 128 output columns per n-block
@@ -941,6 +1165,11 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
     const float* S = a.S + rowbase * D.n_ld;
     const int64_t* negmap = a.negmap[dir] + (int64_t)c * D.N;
 
+    unsigned long long* dbg = (a.dbg && blockIdx.x < 2048 && (blockIdx.x & 7) == 0 && lane == 0 && (wave == 0 || wave == 3))
+                                  ? a.dbg + ((size_t)(blockIdx.x >> 3) * 2 + (wave ? 1 : 0)) * 64 : nullptr;
+    int dbi = 0;
+#define GSTAMP() do { if (dbg && dbi < 64) dbg[dbi++] = __builtin_readcyclecounter(); } while (0)
+    GSTAMP();
     for (int j = tid; j < D.N; j += 256) idl[j] = (int)negmap[j];  // batch-local row ids of this chunk's negatives
 
     v4f acc[NT];
@@ -967,8 +1196,10 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
     const int nchunks = (D.N + H_KC - 1) / H_KC;
     __syncthreads();  // idl visible
 
+    // issue/write are branch-free on purpose: with a conditional early-out the compiler's waitcnt pass merges the two paths
+    // conservatively and drains vmcnt to 0 in every write phase, which collapses the two-chunk prefetch distance to one
     auto issue = [&](int ch, float4(&vs)[2], float4(&vb)[4]) {
-        if (ch >= nchunks) return;
+        ch = ch < nchunks ? ch : nchunks - 1;
         const int j0 = ch * H_KC;
         const int j = j0 + 4 * qpiece;
 #pragma unroll
@@ -981,7 +1212,6 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
         }
     };
     auto write = [&](int buf, int ch, const float4(&vs)[2], const float4(&vb)[4]) {
-        if (ch >= nchunks) return;
         const int j0 = ch * H_KC;
         const int j = j0 + 4 * qpiece;
 #pragma unroll
@@ -1027,7 +1257,8 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma16(av, bc[t], acc[t]);
+            for (int t = 0; t < NT; ++t)
+                if (!(GRAD_ABLATE & 2)) acc[t] = mfma16(av, bc[t], acc[t]); else acc[t][0] += av * bc[t];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) bc[t] = bn[t];
@@ -1042,16 +1273,23 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
     write(0, 0, vs0, vb0);
     issue(2, vs0, vb0);
     __syncthreads();
+    GSTAMP();
     for (int ch = 0; ch < nchunks; ch += 2) {
         compute(0);                       // chunk ch
-        write(1, ch + 1, vs1, vb1);
-        issue(ch + 3, vs1, vb1);
+        if (ch < 12) GSTAMP();
+        if (!(GRAD_ABLATE & 4)) write(1, ch + 1, vs1, vb1);
+        if (ch < 12) GSTAMP();
+        if (!(GRAD_ABLATE & 8)) issue(ch + 3, vs1, vb1);
+        if (ch < 12) GSTAMP();
         __syncthreads();
+        if (ch < 12) GSTAMP();
         if (ch + 1 < nchunks) compute(1);  // chunk ch + 1
-        write(0, ch + 2, vs0, vb0);
-        issue(ch + 4, vs0, vb0);
+        if (!(GRAD_ABLATE & 4)) write(0, ch + 2, vs0, vb0);
+        if (!(GRAD_ABLATE & 8)) issue(ch + 4, vs0, vb0);
         __syncthreads();
+        if (ch < 12) GSTAMP();
     }
+    GSTAMP();
 
     // lane holds D[m = 4 * kq + r][n = l15] of each 16x16 tile
     if (L2) {
@@ -1082,6 +1320,8 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
             }
         }
     }
+    GSTAMP();
+#undef GSTAMP
 }
 
 // dNeg_c[m, n] = sum_i V[i, m] * adj_c[i, n]
@@ -1118,7 +1358,7 @@ __device__ __forceinline__ void grad_neg16_body(const GradArgs& a, int cd, int u
     const int nchunks = (D.Bc + H_KC - 1) / H_KC;
 
     auto issue = [&](int ch, float4(&vs)[2], float(&lv)[2], float4(&vb)[4]) {
-        if (ch >= nchunks) return;
+        ch = ch < nchunks ? ch : nchunks - 1;  // branch-free (see grad_adj16_body)
         const int i0 = ch * H_KC;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -1134,7 +1374,6 @@ __device__ __forceinline__ void grad_neg16_body(const GradArgs& a, int cd, int u
         }
     };
     auto write = [&](int buf, int ch, const float4(&vs)[2], const float(&lv)[2], const float4(&vb)[4]) {
-        if (ch >= nchunks) return;
         const int i0 = ch * H_KC;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -1178,7 +1417,8 @@ __device__ __forceinline__ void grad_neg16_body(const GradArgs& a, int cd, int u
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma16(ac, bc[t], acc[t]);
+            for (int t = 0; t < NT; ++t)
+                if (!(GRAD_ABLATE & 2)) acc[t] = mfma16(ac, bc[t], acc[t]); else acc[t][0] += ac * bc[t];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) bc[t] = bn[t];
@@ -1195,12 +1435,12 @@ __device__ __forceinline__ void grad_neg16_body(const GradArgs& a, int cd, int u
     __syncthreads();
     for (int ch = 0; ch < nchunks; ch += 2) {
         compute(0);
-        write(1, ch + 1, vs1, lv1, vb1);
-        issue(ch + 3, vs1, lv1, vb1);
+        if (!(GRAD_ABLATE & 4)) write(1, ch + 1, vs1, lv1, vb1);
+        if (!(GRAD_ABLATE & 8)) issue(ch + 3, vs1, lv1, vb1);
         __syncthreads();
         if (ch + 1 < nchunks) compute(1);
-        write(0, ch + 2, vs0, lv0, vb0);
-        issue(ch + 4, vs0, lv0, vb0);
+        if (!(GRAD_ABLATE & 4)) write(0, ch + 2, vs0, lv0, vb0);
+        if (!(GRAD_ABLATE & 8)) issue(ch + 4, vs0, lv0, vb0);
         __syncthreads();
     }
 
@@ -1259,6 +1499,34 @@ bool scores_res_applicable(const float* emb, int64_t emb_ld, int d) { return res
 bool scores_a_applicable(const float* emb, int64_t emb_ld, int d) {
     const int nq = d / 4;
     return res_ok(emb, emb_ld, d) && (nq == 8 || nq == 16 || nq == 25 || nq == 32);
+}
+
+bool launch_scores_ap(const ScoreArgs& a_in, bool l2, hipStream_t st) {
+    if (!scores_a_applicable(a_in.emb, a_in.emb_ld, a_in.D.d)) return false;
+    ScoreArgs a = a_in;
+    a.KS = a.D.d + 2;
+    const int npairs = scores_ap_groups(a.D.N);
+    const int mtiles = (int)cdiv(a.D.Bc, A_TM);
+    const int total = a.D.C * a.D.ndir * mtiles * npairs;
+    const int nwg = 768;  // 3 workgroups x 256 CUs, all resident
+    const size_t lds = (size_t)A_SLOTS * A_TN * a.KS * sizeof(float);
+#define SCORES_AP_LAUNCH(L2V, NQV) lp_scores_ap_kernel<L2V, NQV><<<dim3(nwg), dim3(256), lds, st>>>(a, npairs, mtiles, total, nwg)
+#define SCORES_AP_DISPATCH(L2V)                         \
+    do {                                                \
+        switch (a.D.d / 4) {                            \
+            case 8: SCORES_AP_LAUNCH(L2V, 8); break;    \
+            case 16: SCORES_AP_LAUNCH(L2V, 16); break;  \
+            case 25: SCORES_AP_LAUNCH(L2V, 25); break;  \
+            default: SCORES_AP_LAUNCH(L2V, 32); break;  \
+        }                                               \
+    } while (0)
+    if (l2)
+        SCORES_AP_DISPATCH(true);
+    else
+        SCORES_AP_DISPATCH(false);
+#undef SCORES_AP_DISPATCH
+#undef SCORES_AP_LAUNCH
+    return true;
 }
 
 bool launch_scores_a(const ScoreArgs& a_in, bool l2, hipStream_t st) {

@@ -38,7 +38,7 @@ class LpLayout(C.Structure):
         ("Bp", C.c_int64), ("n_ld", C.c_int64), ("d_ld", C.c_int64), ("total_bytes", C.c_size_t),
         ("adj", C.c_size_t * 2), ("pos", C.c_size_t * 2), ("neg", C.c_size_t * 2), ("lse", C.c_size_t * 2),
         ("rowloss", C.c_size_t * 2), ("loss", C.c_size_t), ("dadj", C.c_size_t * 2), ("gocc", C.c_size_t),
-        ("grel", C.c_size_t * 2), ("aux", C.c_size_t), ("lsepart", C.c_size_t),
+        ("grel", C.c_size_t * 2), ("aux", C.c_size_t), ("lsepart", C.c_size_t), ("embp", C.c_size_t), ("adjp", C.c_size_t), ("kp", C.c_int64),
     ]
 
 
@@ -90,10 +90,11 @@ def lib():
     """Load libmarius_hip.so; raise (never fall back) if it is absent."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("MARIUS_HIP_LIB", LIB_PATH)  # override: experiment builds of the same C-ABI (tools/ablate_*.sh)
+        if not os.path.exists(path):
             raise MariusHipError(
-                "libmarius_hip.so not found at %s — build it with `python -m marius_amd.build`; there is no CPU fallback" % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
+                "libmarius_hip.so not found at %s — build it with `python -m marius_amd.build`; there is no CPU fallback" % path)
+        L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res
