@@ -642,13 +642,14 @@ static int kernel_level();
 static unsigned long long* g_dbg_timeline = nullptr;
 // SoftmaxCE partial (max, sum exp) per (row, negative-tile group) come out of the score kernel's epilogue when nothing can change
 // the scores afterwards (no score filter) and the resident-operand kernel runs; marius_lp_loss then only merges the partials.
-// which level-2 score kernel runs: 'a' (adj fragments in registers; default) or 'r' (resident adj tile in LDS; MARIUS_SCORES=res)
+// which level-2 score kernel runs: 'p' (adj fragments in registers, persistent workgroups; default), 'a' (same, one workgroup per
+// 128x128 unit; MARIUS_SCORES=a), 'b' (bf16x6 split on the BF16 matrix pipe; MARIUS_SCORES=b) or 'r' (adj tile in LDS; MARIUS_SCORES=res)
 static char scores_variant(const marius_lp_desc* d, const LpDims& D) {
     const char* v = getenv("MARIUS_SCORES");
     const bool want_res = v && v[0] == 'r';
     if (v && v[0] == 'b' && scores_b6_applicable(d->emb, d->emb_ld, D.d) && d->U <= 2 * D.B + (int64_t)(d->src_neg ? 2 : 1) * D.C * D.N)
         return 'b';  // bf16x6 split (lp_split.hip); the plane buffers hold at most 2B + 2CN rows
-    if (!want_res && scores_a_applicable(d->emb, d->emb_ld, D.d)) return (v && v[0] == 'p') ? 'p' : 'a';  // 'p': persistent variant
+    if (!want_res && scores_a_applicable(d->emb, d->emb_ld, D.d)) return (v && v[0] == 'a') ? 'a' : 'p';  // default 'p': persistent variant
     if (scores_res_applicable(d->emb, d->emb_ld, D.d)) return 'r';
     return 0;
 }

@@ -1142,7 +1142,7 @@ constexpr int H_QS_KM = H_TM + 4; // V staged [k][m] (grad_neg)
 constexpr int H_QSZ = (H_TM * H_QS_MK > H_KC * H_QS_KM) ? H_TM * H_QS_MK : H_KC * H_QS_KM;
 constexpr int H_MAXIDS = 2048;    // negative-row indices of one chunk kept in LDS as int32 (N <= 2048 on this path)
 // dynamic LDS layout (floats): Qs[2][H_QSZ] | Bs[2][H_KC * (16 NT + 4)] | sums[H_TM] | ids[H_MAXIDS] (grad_adj only, sized by N)
-static inline size_t grad16_lds_bytes(int N, int nt) { return (size_t)(2 * H_QSZ + 2 * H_KC * (16 * nt + 4) + H_TM + ((N + 3) / 4) * 4) * sizeof(float); }
+static inline size_t grad16_lds_bytes(int N, int nt) { return (size_t)(2 * H_QSZ + 2 * H_KC * (16 * nt + 4) + H_TM + ((N + 31) / 32) * 32) * sizeof(float); }
 
 // Both backward contractions stream K in chunks of 32 through a double-buffered LDS ring with ONE barrier per chunk and
 // a two-chunk-deep register prefetch (register sets 0/1 alternate, so every global load has two chunk periods to land).
@@ -1170,7 +1170,8 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
     int dbi = 0;
 #define GSTAMP() do { if (dbg && dbi < 64) dbg[dbi++] = __builtin_readcyclecounter(); } while (0)
     GSTAMP();
-    for (int j = tid; j < D.N; j += 256) idl[j] = (int)negmap[j];  // batch-local row ids of this chunk's negatives
+    const int nchunks = (D.N + H_KC - 1) / H_KC;
+    for (int j = tid; j < nchunks * H_KC; j += 256) idl[j] = j < D.N ? (int)negmap[j] : 0;  // batch-local row ids of this chunk's negatives (tail: a valid row)
 
     v4f acc[NT];
 #pragma unroll
@@ -1193,7 +1194,19 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
     const bool col_ok = ncol + 3 < D.d;
     const int ncol_c = col_ok ? ncol : 0;
     const int ones_col = L2 ? D.d - n0 : -1;  // local column of the ones column (L2, single n-block)
-    const int nchunks = (D.N + H_KC - 1) / H_KC;
+    // Dot: dL/dS = gscale * exp(S - lse) = exp2(S * log2e + c), c = log2(gscale) - lse * log2e; c = -inf switches a padding row off.
+    // FP32 MFMAs and VALU instructions exclude each other on a SIMD (tools/micro/mfma_valu_overlap*.hip), so every VALU instruction of
+    // the staging code is paid in full: keep the per-element work at two instructions and the masks out of the common path.
+    constexpr float LOG2E = 1.4426950408889634f;
+    float cexp[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        cexp[it] = qmask[it] != 0.f ? __log2f(D.gscale) - lse_r[it] * LOG2E : -INFINITY;
+        asm volatile("" : "+v"(cexp[it]), "+v"(lse_r[it]));  // keep in registers (the compiler otherwise re-loads lse every chunk)
+    }
+    if (!col_ok && 4 * bpiece < 16 * NT) {  // K-padding columns of the B tile: zero once, the staging of real columns never touches them
+        for (int r = brow; r < 2 * H_KC; r += 8) *reinterpret_cast<float4*>(&Bs[0][r * BS + 4 * bpiece]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();  // idl visible
 
     // issue/write are branch-free on purpose: with a conditional early-out the compiler's waitcnt pass merges the two paths
@@ -1206,14 +1219,29 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
         for (int it = 0; it < 2; ++it) vs[it] = *reinterpret_cast<const float4*>(srow[it] + (j < D.N ? j : 0));
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int jj = j0 + brow + 8 * it;
-            const int id = idl[jj < D.N ? jj : 0];
+            const int id = idl[j0 + brow + 8 * it];
             vb[it] = *reinterpret_cast<const float4*>(a.emb + (int64_t)id * a.emb_ld + ncol_c);
         }
     };
     auto write = [&](int buf, int ch, const float4(&vs)[2], const float4(&vb)[4]) {
         const int j0 = ch * H_KC;
         const int j = j0 + 4 * qpiece;
+        if (!L2 && j0 + H_KC <= D.N) {  // common case (uniform): a full chunk of real negatives, no masks
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                float4 v;
+                v.x = __builtin_amdgcn_exp2f(fmaf(vs[it].x, LOG2E, cexp[it]));
+                v.y = __builtin_amdgcn_exp2f(fmaf(vs[it].y, LOG2E, cexp[it]));
+                v.z = __builtin_amdgcn_exp2f(fmaf(vs[it].z, LOG2E, cexp[it]));
+                v.w = __builtin_amdgcn_exp2f(fmaf(vs[it].w, LOG2E, cexp[it]));
+                *reinterpret_cast<float4*>(&Qs[buf][(qrow + 32 * it) * H_QS_MK + 4 * qpiece]) = v;
+            }
+            if (col_ok) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) *reinterpret_cast<float4*>(&Bs[buf][(brow + 8 * it) * BS + 4 * bpiece]) = vb[it];
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             float4 v;
@@ -1373,8 +1401,30 @@ __device__ __forceinline__ void grad_neg16_body(const GradArgs& a, int cd, int u
             vb[it] = *reinterpret_cast<const float4*>(adj + (int64_t)(i < D.Bc ? i : 0) * D.d_ld + ncol_c);
         }
     };
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float lg = __log2f(D.gscale);
+    if (!col_ok && 4 * bpiece < 16 * NT) {  // K-padding columns of the B tile: zero once, the staging of real columns never touches them
+        for (int r = brow; r < 2 * H_KC; r += 8) *reinterpret_cast<float4*>(&Bs[0][r * BS + 4 * bpiece]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     auto write = [&](int buf, int ch, const float4(&vs)[2], const float(&lv)[2], const float4(&vb)[4]) {
         const int i0 = ch * H_KC;
+        if (!L2 && i0 + H_KC <= D.Bc) {  // common case (uniform): a full chunk of real rows; columns j >= N feed output rows that are never stored
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const float c_ = fmaf(-lv[it], LOG2E, lg);
+                float4 v;
+                v.x = __builtin_amdgcn_exp2f(fmaf(vs[it].x, LOG2E, c_));
+                v.y = __builtin_amdgcn_exp2f(fmaf(vs[it].y, LOG2E, c_));
+                v.z = __builtin_amdgcn_exp2f(fmaf(vs[it].z, LOG2E, c_));
+                v.w = __builtin_amdgcn_exp2f(fmaf(vs[it].w, LOG2E, c_));
+                *reinterpret_cast<float4*>(&Qs[buf][(qrow + 16 * it) * H_QS_KM + 4 * qpiece]) = v;
+            }
+            if (col_ok) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) *reinterpret_cast<float4*>(&Bs[buf][(brow + 8 * it) * BS + 4 * bpiece]) = vb[it];
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int r = qrow + 16 * it;
