@@ -184,6 +184,8 @@ typedef struct marius_lp_layout {
     size_t embp;      /* [3][2B + 2CN][kp] bf16: exact 3-way split (hi, mid, lo) of the batch rows, kp = 16 ceil(d/16)          */
     size_t adjp;      /* [3][ndir Bp][kp]  bf16: the same split of adj (operands of the bf16-split contraction kernels)        */
     int64_t kp;
+    size_t negt;      /* [ncd][3][kp][N  rounded to 32] bf16: negatives of each chunk-direction, contraction-major                */
+    size_t adjt;      /* [ncd][3][kp][Bc rounded to 32] bf16: adj rows of each chunk-direction, contraction-major                 */
 } marius_lp_layout;
 
 int marius_lp_plan(const marius_lp_desc* desc, marius_lp_layout* layout);

@@ -124,6 +124,9 @@ bool launch_scores_ap(const ScoreArgs& a, bool l2, hipStream_t st);
 // same structure on the BF16 matrix pipe with exact 3-way operand splitting (lp_split.hip)
 bool scores_b6_applicable(const float* emb, int64_t emb_ld, int d);
 // rows[n][ld] fp32 -> planes[3][n][kp] bf16 (exact hi/mid/lo split, zero K padding)
+// backward contractions of the same scheme (lp_split_grad.hip); builds the contraction-major operand copies negT / adjT first
+bool launch_grad_b6(const GradArgs& ga, const void* embp, int64_t embp_plane, const void* adjp, int64_t adjp_plane, int kp, void* negT, void* adjT,
+                    hipStream_t st);
 int launch_split_rows(const float* src, int64_t ld, int64_t rows, int d, int kp, void* planes, int64_t plane_elems, hipStream_t st);
 bool launch_scores_b6(const ScoreArgs& a, bool l2, hipStream_t st);
 bool launch_scores_a(const ScoreArgs& a, bool l2, hipStream_t st);

@@ -742,6 +742,8 @@ static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layou
     L->kp = (D.d + 15) / 16 * 16;
     L->embp = take(nocc * (size_t)L->kp * 2 * 3);
     L->adjp = take(rows * D.ndir * (size_t)L->kp * 2 * 3);
+    L->negt = take((size_t)D.C * D.ndir * 3 * L->kp * ((D.N + 31) / 32 * 32) * 2);
+    L->adjt = take((size_t)D.C * D.ndir * 3 * L->kp * ((D.Bc + 31) / 32 * 32) * 2);
     L->total_bytes = off;
     return MARIUS_OK;
 }
@@ -926,7 +928,12 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
         const char* sp = getenv("MARIUS_GRAD_SPLIT");  // 1 = separate launches for dAdj / dNeg (per-kernel timing)
         const bool split = sp && sp[0] == '1';
         bool done = false;
-        if (lvl >= 2 && !split) {
+        if (lvl == 2 && !split && scores_variant(desc, D) == 'b') {  // operand planes were produced by this step's forward
+            const int64_t nocc = 2 * D.B + (int64_t)(desc->src_neg ? 2 : 1) * D.C * D.N;
+            ProfScope ps(PROF_LP_GRAD_ADJ, st);
+            done = launch_grad_b6(ga, ws + L->embp, nocc * L->kp, ws + L->adjp, D.Bp * D.ndir * L->kp, (int)L->kp, ws + L->negt, ws + L->adjt, st);
+        }
+        if (!done && lvl >= 2 && !split) {
             ProfScope ps(PROF_LP_GRAD_ADJ, st);  // merged launch is accounted under lp_grad_adj (both contractions)
             done = launch_grad16(ga, l2, 0, st);
         }
