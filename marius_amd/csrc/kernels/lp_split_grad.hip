@@ -13,6 +13,10 @@
 // cycles per wave and K chunk, underneath the VALU work (BF16 MFMAs and VALU overlap; FP32 MFMAs and VALU do not).
 #include "lp_common.h"
 
+#ifndef GB6_ABLATE
+#define GB6_ABLATE 0  // experiment builds only: 2 = no MFMAs, 4 = no B staging, 8 = no S loads, 16 = no exp/split (constant V)
+#endif
+
 namespace marius {
 
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
@@ -21,11 +25,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // first-class vectors: structs of HIP's float4 carried through the loop end up in scratch
 
-constexpr int GB_TM = 64;            // output rows per workgroup (4 waves x 16)
-constexpr int GB_KC = 32;            // K chunk = one MFMA
-constexpr int GB_RS = GB_KC + 8;     // bf16 per LDS row of the B tile (80 B): 16-B slots of 8 consecutive rows on disjoint banks
+constexpr int GB_TM = 128;           // output rows per workgroup (4 waves x 32)
+constexpr int GB_KC = 32;            // K chunk = two 32x32x16 MFMA blocks
+constexpr int GB_RS = GB_KC;         // bf16 per LDS row of the B tile (64 B, no padding); the 16-B slot w of row n lives at slot
+                                     // w ^ ((n >> 2) & 3), which keeps 8 consecutive rows of one fragment read on disjoint bank groups
 
-__device__ __forceinline__ v4f mfma16_bf16(const v8bf& a, const v8bf& b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+typedef float v16f __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ v16f mfma32_bf16(const v8bf& a, const v8bf& b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ void split8v(const float (&x)[8], v8bf& H, v8bf& M, v8bf& L) {
 #pragma clang fp contract(off)
@@ -104,37 +110,49 @@ struct GradB6Args {
     LpDims D;
 };
 
-// common K loop: B tile [3][NT*16][GB_RS] double-buffered in LDS; `loadA(ch, aH, aM, aL)` produces the wave's V fragments of chunk ch
-template <int NT, class LoadS, class MakeA>
-__device__ __forceinline__ void gradb6_loop(const __bf16* __restrict__ bT, int kld, int nchunks, __bf16* lds, v4f (&acc)[NT], LoadS loadS, MakeA makeA) {
-    constexpr int NR = NT * 16;                 // B rows (output columns)
+// Why 32 rows per wave and 32x32x16 MFMAs: with 16-row wave tiles (16x16x32) the kernel was bound by LDS reads — every wave re-reads
+// the whole B tile for 16 rows of output (ablation: 0.14 ms of pure fragment traffic, 8.8 GB at 69 TB/s) — and by the L2 -> LDS copies of
+// the B tile (0.12 ms).  A 32-row wave tile halves the fragment bytes per flop, a 128-row workgroup tile halves the copies.
+//
+// common K loop: B tile [3][NTB*32][GB_RS] double-buffered in LDS; loadS(ch) fetches the wave's S values of chunk ch (two chunks ahead),
+// makeA(ch, s, kb, ...) turns them into the V fragments of K block kb
+template <int NTB, class LoadS, class MakeA>
+__device__ __forceinline__ void gradb6_loop(const __bf16* __restrict__ bT, int kp, int kld, int nchunks, __bf16* lds, v16f (&acc)[NTB], LoadS loadS, MakeA makeA) {
+    constexpr int NR = NTB * 32;                // B rows held in LDS (output columns, zero rows past kp)
     constexpr int PLANE = NR * GB_RS;           // bf16 per plane in LDS
     constexpr int BUF = 3 * PLANE;
-    constexpr int NP = 3 * NR * 4;              // 16-B pieces per chunk
-    constexpr int NI = (NP + 255) / 256;
+    constexpr int NI = (3 * NR * 4 + 255) / 256;  // upper bound of 16-B pieces per thread and chunk
     const int tid = threadIdx.x, lane = tid & 63;
-    const int l15 = lane & 15, g = lane >> 4;
-    // staging: piece q = tid + 256 i  ->  (plane, n, w): global bT[plane][n][k0 + 8 w], LDS [plane][n][8 w]
+    const int l31 = lane & 31, h = lane >> 5;
+    const int np = 3 * kp * 4;                  // 16-B pieces per chunk: (plane, n < kp, w)
+    // staging: piece q = tid + 256 i  ->  (plane, n, w): global bT[plane][n][k0 + 8 w], LDS [plane][n][8 (w ^ swz)]
     uint32_t goff[NI];
     int loff[NI];
     bool pok[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int q = tid + 256 * i;
-        pok[i] = q < NP;
+        pok[i] = q < np;
         const int qc = pok[i] ? q : 0;
-        const int row = qc >> 2, w = qc & 3;    // row = plane * NR + n
-        const int plane = row / NR, n = row - plane * NR;
-        goff[i] = (uint32_t)(((int64_t)plane * (NR) + n) * kld + 8 * w) * 2u;  // plane stride inside one cd is kp * kld with kp == NR
-        loff[i] = plane * PLANE + n * GB_RS + 8 * w;
+        const int row = qc >> 2, w = qc & 3;    // row = plane * kp + n
+        const int plane = row / kp, n = row - plane * kp;
+        goff[i] = (uint32_t)(((int64_t)plane * kp + n) * kld + 8 * w) * 2u;
+        loff[i] = plane * PLANE + n * GB_RS + 8 * (w ^ ((n >> 2) & 3));
+    }
+    for (int i = tid; i < 2 * 3 * (NR - kp) * 4; i += 256) {  // rows kp .. NR of every plane of both buffers: zero, never staged
+        const int b_ = i / (3 * (NR - kp) * 4), r = i % (3 * (NR - kp) * 4);
+        const int plane = r / ((NR - kp) * 4), rr = r % ((NR - kp) * 4);
+        *reinterpret_cast<u32x4*>(lds + b_ * BUF + plane * PLANE + (kp + (rr >> 2)) * GB_RS + 8 * (rr & 3)) = (u32x4){0u, 0u, 0u, 0u};
     }
     struct Tile { u32x4 v[NI]; };
+    // buffer loads: per-lane byte offset in a VGPR (constant over the K loop) + the chunk offset in an SGPR: no per-load address
+    // arithmetic on the VALU, and reads past the end of the buffer return zero instead of faulting
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(bT), 0, 3 * kp * kld * 2, 0x00020000);
     auto issueB = [&](int ch) __attribute__((always_inline)) {
         Tile t;
         const int chc = ch < nchunks ? ch : nchunks - 1;
-        const char* base = reinterpret_cast<const char*>(bT) + (size_t)chc * GB_KC * 2;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) t.v[i] = *reinterpret_cast<const u32x4*>(base + goff[i]);
+        for (int i = 0; i < NI; ++i) t.v[i] = __builtin_amdgcn_raw_buffer_load_b128(brs, (int)goff[i], chc * GB_KC * 2, 0);
         return t;
     };
     auto writeB = [&](int buf, Tile t) __attribute__((always_inline)) {
@@ -143,71 +161,84 @@ __device__ __forceinline__ void gradb6_loop(const __bf16* __restrict__ bT, int k
         for (int i = 0; i < NI; ++i)
             if (pok[i]) *reinterpret_cast<u32x4*>(b + loff[i]) = t.v[i];
     };
-    auto compute = [&](int buf, const v8bf& aH, const v8bf& aM, const v8bf& aL) __attribute__((always_inline)) {
-        const __bf16* bp = lds + buf * BUF + l15 * GB_RS + 8 * g;
+    auto compute = [&](int buf, const v8bf (&aH)[2], const v8bf (&aM)[2], const v8bf (&aL)[2]) __attribute__((always_inline)) {
+        // lane reads row n = 32 t + l31, K block kb: slot (2 kb + h) ^ ((n >> 2) & 3), and (n >> 2) & 3 == (l31 >> 2) & 3 for every t
+        const int swz = (l31 >> 2) & 3;
+        const __bf16* bp = lds + buf * BUF + l31 * GB_RS;
         v8bf bH[2], bM[2], bL[2];
-        bH[0] = *reinterpret_cast<const v8bf*>(bp);
-        bM[0] = *reinterpret_cast<const v8bf*>(bp + PLANE);
-        bL[0] = *reinterpret_cast<const v8bf*>(bp + 2 * PLANE);
+        bH[0] = *reinterpret_cast<const v8bf*>(bp + 8 * (h ^ swz));
+        bM[0] = *reinterpret_cast<const v8bf*>(bp + 8 * (h ^ swz) + PLANE);
+        bL[0] = *reinterpret_cast<const v8bf*>(bp + 8 * (h ^ swz) + 2 * PLANE);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int c_ = t & 1, n_ = c_ ^ 1;
-            if (t + 1 < NT) {
-                bH[n_] = *reinterpret_cast<const v8bf*>(bp + (t + 1) * 16 * GB_RS);
-                bM[n_] = *reinterpret_cast<const v8bf*>(bp + (t + 1) * 16 * GB_RS + PLANE);
-                bL[n_] = *reinterpret_cast<const v8bf*>(bp + (t + 1) * 16 * GB_RS + 2 * PLANE);
+        for (int it = 0; it < 2 * NTB; ++it) {
+            const int t = it >> 1, kb = it & 1;
+            const int c_ = it & 1, n_ = c_ ^ 1;
+            if (it + 1 < 2 * NTB) {
+                const int t2 = (it + 1) >> 1, kb2 = (it + 1) & 1;
+                const __bf16* q = bp + t2 * 32 * GB_RS + 8 * ((2 * kb2 + h) ^ swz);
+                bH[n_] = *reinterpret_cast<const v8bf*>(q);
+                bM[n_] = *reinterpret_cast<const v8bf*>(q + PLANE);
+                bL[n_] = *reinterpret_cast<const v8bf*>(q + 2 * PLANE);
             }
-            acc[t] = mfma16_bf16(aL, bH[c_], acc[t]);
-            acc[t] = mfma16_bf16(aH, bL[c_], acc[t]);
-            acc[t] = mfma16_bf16(aM, bM[c_], acc[t]);
-            acc[t] = mfma16_bf16(aM, bH[c_], acc[t]);
-            acc[t] = mfma16_bf16(aH, bM[c_], acc[t]);
-            acc[t] = mfma16_bf16(aH, bH[c_], acc[t]);
+            if (GB6_ABLATE & 2) { acc[t][0] += (float)aH[kb][0] * (float)bH[c_][0] + (float)bM[c_][1] + (float)bL[c_][2]; continue; }
+            acc[t] = mfma32_bf16(aL[kb], bH[c_], acc[t]);
+            acc[t] = mfma32_bf16(aH[kb], bL[c_], acc[t]);
+            acc[t] = mfma32_bf16(aM[kb], bM[c_], acc[t]);
+            acc[t] = mfma32_bf16(aM[kb], bH[c_], acc[t]);
+            acc[t] = mfma32_bf16(aH[kb], bM[c_], acc[t]);
+            acc[t] = mfma32_bf16(aH[kb], bH[c_], acc[t]);
         }
     };
 
     // pipeline: B tile of chunk ch+1 is written to the other LDS buffer while chunk ch is multiplied; its global loads were
-    // issued one chunk earlier; the S values of chunk ch+2 are in flight
+    // issued one chunk earlier; the S values of chunk ch+2 are in flight.  The V fragments of chunk ch+1 are produced (exp2 + split,
+    // ~150 VALU instructions) in the same scheduling region as the 48 MFMAs of chunk ch, so the scheduler is free to interleave them
+    // (forcing a 1 MFMA : 4 VALU pattern with sched_group_barrier was measured slower: 0.467 vs 0.444 ms).
     Tile tb = issueB(0);
     auto s0 = loadS(0);
     auto s1 = loadS(1);
     writeB(0, tb);
     tb = issueB(1);
+    v8bf cH[2], cM[2], cL[2];
+    makeA(0, s0, cH, cM, cL);
+    s0 = loadS(2);
     __syncthreads();
     for (int ch = 0; ch < nchunks; ch += 2) {
+        v8bf nH[2], nM[2], nL[2];
         {
-            v8bf aH, aM, aL;
-            makeA(ch, s0, aH, aM, aL);
-            s0 = loadS(ch + 2);
-            compute(0, aH, aM, aL);
-            writeB(1, tb);
-            tb = issueB(ch + 2);
+            makeA(ch + 1, s1, nH, nM, nL);   // masks every element of a phantom chunk past the end: branch-free on purpose
+            compute(0, cH, cM, cL);
+            if (!(GB6_ABLATE & 8)) s1 = loadS(ch + 3);
+            if (!(GB6_ABLATE & 4)) {
+                writeB(1, tb);
+                tb = issueB(ch + 2);
+            }
             __syncthreads();
         }
-        {   // unconditional (a phantom chunk past the end multiplies zeros: makeA masks every element): a branch around the loads
-            // would make the compiler merge the vmcnt state conservatively and drain the prefetch queue every chunk
-            v8bf aH, aM, aL;
-            makeA(ch + 1, s1, aH, aM, aL);
-            s1 = loadS(ch + 3);
-            compute(1, aH, aM, aL);
+        {
+            makeA(ch + 2, s0, cH, cM, cL);
+            compute(1, nH, nM, nL);
+            if (!(GB6_ABLATE & 8)) s0 = loadS(ch + 4);
         }
-        writeB(0, tb);
-        tb = issueB(ch + 3);
+        if (!(GB6_ABLATE & 4)) {
+            writeB(0, tb);
+            tb = issueB(ch + 3);
+        }
         __syncthreads();
     }
 }
 
-struct SAdj { f32x4 a, b; };                 // dAdj: S[m][j0 + 8 g .. + 7]
-struct SNeg { f32x4 s0, s1, la, lb; };      // dNeg: S[m0 + 8 g + e][j] (e = 0..7), lse[m0 + 8 g .. + 7]
+struct SAdj { f32x4 v[4]; };                 // dAdj: S[m][j0 + 16 kb + 8 h .. + 7], kb = 0, 1
+struct SNeg { f32x4 s[4]; f32x4 l[4]; };     // dNeg: S[m0 + 16 kb + 8 h + e][j] (e = 0..7) and lse[m0 + 16 kb + 8 h .. + 7], kb = 0, 1
 
-template <int NT>
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void lp_grad_b6_kernel(GradB6Args a, int tiles_adj, int tiles_neg) {
+template <int NTB>
+__global__ __launch_bounds__(256, 2) void lp_grad_b6_kernel(GradB6Args a, int tiles_adj, int tiles_neg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     __bf16* lds = reinterpret_cast<__bf16*>(gsm);
     const LpDims& D = a.D;
     constexpr float LOG2E = 1.4426950408889634f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
+    const int l31 = lane & 31, h = lane >> 5;
     // block -> (cd, unit): XCD-aware as in the FP32 kernels (block b runs on XCD b % 8; a chunk's tiles stay on one XCD)
     const int units = tiles_adj + tiles_neg;
     const int ncd = D.C * D.ndir;
@@ -219,103 +250,125 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int64_t rowbase = (int64_t)dir * D.Bp + (int64_t)c * D.Bc;
     const float* S = a.S + rowbase * D.n_ld;
     const float lg = __log2f(D.gscale);
+    // S of this chunk-direction as a buffer: rows past Bc / columns past the row end are other rows of S or (past the end) zero; all masked
+    const int64_t sbytes = ((int64_t)D.ndir * D.Bp - rowbase) * D.n_ld * 4;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S), 0, (int)(sbytes < 0x7fffffff ? sbytes : 0x7fffffff), 0x00020000);
 
-    v4f acc[NT];
+    v16f acc[NTB];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NTB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     if (unit < tiles_adj) {
-        // ---------------- dAdj tile: rows m0 .. m0 + 63, K = negatives j
+        // ---------------- dAdj tile: rows m0 .. m0 + 127, K = negatives j
         const int m0 = unit * GB_TM;
-        const int m = m0 + wave * 16 + l15;
+        const int m = m0 + wave * 32 + l31;
         const bool m_ok = m < D.Bc;
-        const float* srow = S + (int64_t)(m_ok ? m : 0) * D.n_ld;
         const float cexp = m_ok ? lg - a.lse[rowbase + m] * LOG2E : -INFINITY;  // -inf switches a padding row off
         const int nchunks = (D.N + GB_KC - 1) / GB_KC;
         const __bf16* bT = a.negT + (int64_t)cd * 3 * a.kp * a.nld;
+        const int svoff = (int)(((int64_t)m * D.n_ld + 8 * h) * 4);
         auto loadS = [&](int ch) __attribute__((always_inline)) {
             SAdj s;
             const int chc = ch < nchunks ? ch : nchunks - 1;
-            const int j = chc * GB_KC + 8 * g;
-            // n_ld is N rounded up to 4: each 16-B half is either entirely inside the row or entirely masked (then: any valid address)
-            s.a = *reinterpret_cast<const f32x4*>(srow + ((j + 3 < (int)D.n_ld) ? j : 0));
-            s.b = *reinterpret_cast<const f32x4*>(srow + ((j + 7 < (int)D.n_ld) ? j + 4 : 0));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)  // i = 2 kb + half
+                s.v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, svoff + (i >> 1) * 64 + (i & 1) * 16, chc * GB_KC * 4, 0));
             return s;
         };
-        auto makeA = [&](int ch, const SAdj& s, v8bf& aH, v8bf& aM, v8bf& aL) __attribute__((always_inline)) {
-            const float sv[8] = {s.a[0], s.a[1], s.a[2], s.a[3], s.b[0], s.b[1], s.b[2], s.b[3]};
-            float x[8];
-            const int j = ch * GB_KC + 8 * g;
-            if (ch * GB_KC + GB_KC <= D.N) {
+        auto makeA = [&](int ch, const SAdj& s, v8bf (&aH)[2], v8bf (&aM)[2], v8bf (&aL)[2]) __attribute__((always_inline)) {
+            const bool full = ch * GB_KC + GB_KC <= D.N;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = __builtin_amdgcn_exp2f(fmaf(sv[e], LOG2E, cexp));
-            } else {
+            for (int kb = 0; kb < 2; ++kb) {
+                const float sv[8] = {s.v[2 * kb][0], s.v[2 * kb][1], s.v[2 * kb][2], s.v[2 * kb][3],
+                                     s.v[2 * kb + 1][0], s.v[2 * kb + 1][1], s.v[2 * kb + 1][2], s.v[2 * kb + 1][3]};
+                float x[8];
+                const int j = ch * GB_KC + 16 * kb + 8 * h;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = (j + e < D.N) ? __builtin_amdgcn_exp2f(fmaf(sv[e], LOG2E, cexp)) : 0.f;
+                for (int e = 0; e < 8; ++e) {
+                    x[e] = __builtin_amdgcn_exp2f(fmaf(sv[e], LOG2E, cexp));
+                    if (!full && j + e >= D.N) x[e] = 0.f;
+                }
+                if (GB6_ABLATE & 16) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) aH[kb][e] = aM[kb][e] = aL[kb][e] = (__bf16)sv[e];
+                } else {
+                    split8v(x, aH[kb], aM[kb], aL[kb]);
+                }
             }
-            split8v(x, aH, aM, aL);
         };
-        gradb6_loop<NT>(bT, a.nld, nchunks, lds, acc, loadS, makeA);
-        // lane holds D[m = 4 g + r][n = l15] of each 16x16 tile
+        gradb6_loop<NTB>(bT, a.kp, a.nld, nchunks, lds, acc, loadS, makeA);
+        // lane holds D[row = (r & 3) + 8 (r >> 2) + 4 h][col = l31] of each 32x32 tile
         float* out = a.dadj + rowbase * D.d_ld;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = 16 * t + l15;
+        for (int t = 0; t < NTB; ++t) {
+            const int n = 32 * t + l31;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mm = m0 + wave * 16 + 4 * g + r;
+            for (int r = 0; r < 16; ++r) {
+                const int mm = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (mm < D.Bc && n < D.d) out[(int64_t)mm * D.d_ld + n] = acc[t][r];
             }
         }
     } else {
-        // ---------------- dNeg tile: rows j0 .. j0 + 63 (negatives), K = batch rows m
+        // ---------------- dNeg tile: rows j0 .. j0 + 127 (negatives), K = batch rows m
         const int j0 = (unit - tiles_adj) * GB_TM;
-        const int j = j0 + wave * 16 + l15;
+        const int j = j0 + wave * 32 + l31;
         const int jc = j < D.N ? j : 0;  // rows past N are computed on valid data and never stored
-        const float* scol = S + jc;
-        const float* lse = a.lse + rowbase;
         const int nchunks = (D.Bc + GB_KC - 1) / GB_KC;
         const __bf16* bT = a.adjT + (int64_t)cd * 3 * a.kp * a.bld;
+        // lse of this chunk-direction; the (masked) entries past its Bc rows are the next chunk's, or zero past the end of the array
+        const __amdgpu_buffer_rsrc_t lrs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lse + rowbase), 0, (int)(((int64_t)D.ndir * D.Bp - rowbase) * 4), 0x00020000);
+        const int svoff = (int)(((int64_t)8 * h * D.n_ld + jc) * 4);  // row 8 h of the K block, column j; + (32 ch + 16 kb + e) rows in the SGPR offset
+        const int rstride = (int)D.n_ld * 4;
         auto loadS = [&](int ch) __attribute__((always_inline)) {
             SNeg s;
             const int chc = ch < nchunks ? ch : nchunks - 1;
-            const int mb = chc * GB_KC + 8 * g;
-            float t[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int mm = mb + e;
-                t[e] = scol[(int64_t)(mm < D.Bc ? mm : 0) * D.n_ld];
+            for (int kb = 0; kb < 2; ++kb) {
+                const int so = (chc * GB_KC + 16 * kb) * rstride;
+                float t[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, svoff, so + e * rstride, 0));
+                s.s[2 * kb] = (f32x4){t[0], t[1], t[2], t[3]};
+                s.s[2 * kb + 1] = (f32x4){t[4], t[5], t[6], t[7]};
+                s.l[2 * kb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, 32 * h, (chc * GB_KC + 16 * kb) * 4, 0));
+                s.l[2 * kb + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, 32 * h + 16, (chc * GB_KC + 16 * kb) * 4, 0));
             }
-            s.s0 = (f32x4){t[0], t[1], t[2], t[3]};
-            s.s1 = (f32x4){t[4], t[5], t[6], t[7]};
-            // lse is [ndir][Bp] inside the workspace, followed by rowloss: the (masked) entries past this chunk's Bc rows — at the very
-            // end of the array up to 31 floats past it — are readable memory
-            s.la = *reinterpret_cast<const f32x4*>(lse + mb);
-            s.lb = *reinterpret_cast<const f32x4*>(lse + mb + 4);
             return s;
         };
-        auto makeA = [&](int ch, const SNeg& s, v8bf& aH, v8bf& aM, v8bf& aL) __attribute__((always_inline)) {
-            const float lv[8] = {s.la[0], s.la[1], s.la[2], s.la[3], s.lb[0], s.lb[1], s.lb[2], s.lb[3]};
-            const float sv[8] = {s.s0[0], s.s0[1], s.s0[2], s.s0[3], s.s1[0], s.s1[1], s.s1[2], s.s1[3]};
-            float x[8];
-            const int mb = ch * GB_KC + 8 * g;
-            if (ch * GB_KC + GB_KC <= D.Bc) {
+        auto makeA = [&](int ch, const SNeg& s, v8bf (&aH)[2], v8bf (&aM)[2], v8bf (&aL)[2]) __attribute__((always_inline)) {
+            const bool full = ch * GB_KC + GB_KC <= D.Bc;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = __builtin_amdgcn_exp2f(fmaf(sv[e], LOG2E, fmaf(-lv[e], LOG2E, lg)));
-            } else {
+            for (int kb = 0; kb < 2; ++kb) {
+                const float sv[8] = {s.s[2 * kb][0], s.s[2 * kb][1], s.s[2 * kb][2], s.s[2 * kb][3],
+                                     s.s[2 * kb + 1][0], s.s[2 * kb + 1][1], s.s[2 * kb + 1][2], s.s[2 * kb + 1][3]};
+                const float lv[8] = {s.l[2 * kb][0], s.l[2 * kb][1], s.l[2 * kb][2], s.l[2 * kb][3],
+                                     s.l[2 * kb + 1][0], s.l[2 * kb + 1][1], s.l[2 * kb + 1][2], s.l[2 * kb + 1][3]};
+                float x[8];
+                const int mb = ch * GB_KC + 16 * kb + 8 * h;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = (mb + e < D.Bc) ? __builtin_amdgcn_exp2f(fmaf(sv[e], LOG2E, fmaf(-lv[e], LOG2E, lg))) : 0.f;
+                for (int e = 0; e < 8; ++e) {
+                    x[e] = __builtin_amdgcn_exp2f(fmaf(sv[e], LOG2E, fmaf(-lv[e], LOG2E, lg)));
+                    if (!full && mb + e >= D.Bc) x[e] = 0.f;
+                }
+                if (GB6_ABLATE & 16) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) aH[kb][e] = aM[kb][e] = aL[kb][e] = (__bf16)sv[e];
+                } else {
+                    split8v(x, aH[kb], aM[kb], aL[kb]);
+                }
             }
-            split8v(x, aH, aM, aL);
         };
-        gradb6_loop<NT>(bT, a.bld, nchunks, lds, acc, loadS, makeA);
+        gradb6_loop<NTB>(bT, a.kp, a.bld, nchunks, lds, acc, loadS, makeA);
         float* out = a.gocc + (a.negocc_off[dir] + (int64_t)c * D.N) * D.d_ld;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = 16 * t + l15;
+        for (int t = 0; t < NTB; ++t) {
+            const int n = 32 * t + l31;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int jj = j0 + wave * 16 + 4 * g + r;
+            for (int r = 0; r < 16; ++r) {
+                const int jj = j0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (jj < D.N && n < D.d) out[(int64_t)jj * D.d_ld + n] = acc[t][r];
             }
         }
@@ -350,21 +403,13 @@ bool launch_grad_b6(const GradArgs& ga, const void* embp, int64_t embp_plane, co
     const int tiles_adj = (int)cdiv(D.Bc, GB_TM), tiles_neg = (int)cdiv(D.N, GB_TM);
     const int units = tiles_adj + tiles_neg;
     const unsigned grid = (unsigned)(((ncd + 7) / 8) * 8 * units);
-    const size_t lds = (size_t)2 * 3 * kp * GB_RS * sizeof(__bf16);
-#define GB_LAUNCH(NTV)                                                                                                              \
-    do {                                                                                                                            \
-        static bool attr_set = false;                                                                                               \
-        if (!attr_set && lds > 65536) {                                                                                             \
-            (void)hipFuncSetAttribute((const void*)lp_grad_b6_kernel<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-            attr_set = true;                                                                                                        \
-        }                                                                                                                           \
-        lp_grad_b6_kernel<NTV><<<dim3(grid), dim3(256), lds, st>>>(a, tiles_adj, tiles_neg);                                        \
-    } while (0)
-    switch (nt) {
+    const int ntb = (kp + 31) / 32;
+    const size_t lds = (size_t)2 * 3 * ntb * 32 * GB_RS * sizeof(__bf16);  // 48 kB at kp = 112
+#define GB_LAUNCH(NTV) lp_grad_b6_kernel<NTV><<<dim3(grid), dim3(256), lds, st>>>(a, tiles_adj, tiles_neg)
+    switch (ntb) {
+        case 1: GB_LAUNCH(1); break;
         case 2: GB_LAUNCH(2); break;
-        case 4: GB_LAUNCH(4); break;
-        case 7: GB_LAUNCH(7); break;
-        default: GB_LAUNCH(8); break;
+        default: GB_LAUNCH(4); break;
     }
 #undef GB_LAUNCH
     return true;
