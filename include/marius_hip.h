@@ -186,6 +186,7 @@ typedef struct marius_lp_layout {
     int64_t kp;
     size_t negt;      /* [ncd][3][kp][N  rounded to 32] bf16: negatives of each chunk-direction, contraction-major                */
     size_t adjt;      /* [ncd][3][kp][Bc rounded to 32] bf16: adj rows of each chunk-direction, contraction-major                 */
+    size_t gradpart;  /* partial accumulators of the stream-K backward launch (two tiles per persistent workgroup)               */
 } marius_lp_layout;
 
 int marius_lp_plan(const marius_lp_desc* desc, marius_lp_layout* layout);

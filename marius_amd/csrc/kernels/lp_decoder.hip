@@ -744,6 +744,7 @@ static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layou
     L->adjp = take(rows * D.ndir * (size_t)L->kp * 2 * 3);
     L->negt = take((size_t)D.C * D.ndir * 3 * L->kp * ((D.N + 31) / 32 * 32) * 2);
     L->adjt = take((size_t)D.C * D.ndir * 3 * L->kp * ((D.Bc + 31) / 32 * 32) * 2);
+    L->gradpart = take(grad16_sk_part_bytes());
     L->total_bytes = off;
     return MARIUS_OK;
 }
@@ -935,7 +936,7 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
         }
         if (!done && lvl >= 2 && !split) {
             ProfScope ps(PROF_LP_GRAD_ADJ, st);  // merged launch is accounted under lp_grad_adj (both contractions)
-            done = launch_grad16(ga, l2, 0, st);
+            done = launch_grad16_sk(ga, l2, (float*)(ws + L->gradpart), st) || launch_grad16(ga, l2, 0, st);
         }
         if (!done) {
             {

@@ -1073,35 +1073,51 @@ __global__ __launch_bounds__(256, 3) void lp_scores_ap_kernel(ScoreArgs a, int n
                     v[r] = sqrtf(fmaxf(tt, 1e-8f));
                 }
             }
-            if (m_ok) {
+            if ((t + 1) * A_TN <= D.N) {
+                // every column of this tile is a real negative (uniform test): no per-element guards.  FP32 MFMAs and VALU
+                // instructions exclude each other on a SIMD, so the epilogue is kept to ~5 instructions per score
+                if (m_ok) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = nb + 8 * q;
-                    if (n + 3 < D.N) {
-                        *reinterpret_cast<float4*>(srow + n) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-                    } else {
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(srow + nb + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                }
+                if (a.lse_part) {
+                    constexpr float LOG2E = 1.4426950408889634f;
+                    float tmax = v[0];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < D.N) srow[n + e] = v[4 * q + e];
+                    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, v[r]);
+                    const float mnew = fmaxf(run_m, tmax);
+                    const float cs = -mnew * LOG2E;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(fmaf(v[r], LOG2E, cs));
+                    run_l = run_l * __builtin_amdgcn_exp2f(fmaf(run_m, LOG2E, cs)) + sum;
+                    run_m = mnew;
+                }
+            } else {
+                if (m_ok) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = nb + 8 * (r >> 2) + (r & 3);
+                        if (n < D.N) srow[n] = v[r];
                     }
                 }
-            }
-            if (a.lse_part) {
-                float tmax = -3.0e38f;
+                if (a.lse_part) {
+                    float tmax = -3.0e38f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = nb + 8 * (r >> 2) + (r & 3);
-                    if (n < D.N) tmax = fmaxf(tmax, v[r]);
-                }
-                const float mnew = fmaxf(run_m, tmax);
-                float sum = 0.f;
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = nb + 8 * (r >> 2) + (r & 3);
+                        if (n < D.N) tmax = fmaxf(tmax, v[r]);
+                    }
+                    const float mnew = fmaxf(run_m, tmax);
+                    float sum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = nb + 8 * (r >> 2) + (r & 3);
-                    if (n < D.N) sum += __expf(v[r] - mnew);
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = nb + 8 * (r >> 2) + (r & 3);
+                        if (n < D.N) sum += __expf(v[r] - mnew);
+                    }
+                    run_l = run_l * __expf(run_m - mnew) + sum;
+                    run_m = mnew;
                 }
-                run_l = run_l * __expf(run_m - mnew) + sum;
-                run_m = mnew;
             }
         }
         __syncthreads();
@@ -1149,7 +1165,7 @@ static inline size_t grad16_lds_bytes(int N, int nt) { return (size_t)(2 * H_QSZ
 
 // dAdj_c[m, n] = sum_j V[m, j] * Neg_c[j, n]
 template <bool L2, int NT>
-__device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int unit, int tiles_m, float* smem) {
+__device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int unit, int tiles_m, float* smem, int cbeg = 0, int cend = -1, float* part = nullptr) {
     constexpr int BS = 16 * NT + 4;  // B staged [k][n]: stride % 8 == 4 keeps the four k-rows of an MFMA B fragment on disjoint banks
     float(*Qs)[H_QSZ] = reinterpret_cast<float(*)[H_QSZ]>(smem);
     float(*Bs)[H_KC * BS] = reinterpret_cast<float(*)[H_KC * BS]>(smem + 2 * H_QSZ);
@@ -1295,14 +1311,16 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
         }
     };
 
+    // K range of this call: chunks [cbeg, cend) (the stream-K launch gives a workgroup a slice of a tile's K loop)
+    const int cend_ = cend < 0 ? nchunks : cend;
     float4 vs0[2], vb0[4], vs1[2], vb1[4];
-    issue(0, vs0, vb0);
-    issue(1, vs1, vb1);
-    write(0, 0, vs0, vb0);
-    issue(2, vs0, vb0);
+    issue(cbeg, vs0, vb0);
+    issue(cbeg + 1, vs1, vb1);
+    write(0, cbeg, vs0, vb0);
+    issue(cbeg + 2, vs0, vb0);
     __syncthreads();
     GSTAMP();
-    for (int ch = 0; ch < nchunks; ch += 2) {
+    for (int ch = cbeg; ch < cend_; ch += 2) {
         compute(0);                       // chunk ch
         if (ch < 12) GSTAMP();
         if (!(GRAD_ABLATE & 4)) write(1, ch + 1, vs1, vb1);
@@ -1311,13 +1329,20 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
         if (ch < 12) GSTAMP();
         __syncthreads();
         if (ch < 12) GSTAMP();
-        if (ch + 1 < nchunks) compute(1);  // chunk ch + 1
+        if (ch + 1 < cend_) compute(1);  // chunk ch + 1
         if (!(GRAD_ABLATE & 4)) write(0, ch + 2, vs0, vb0);
         if (!(GRAD_ABLATE & 8)) issue(ch + 4, vs0, vb0);
         __syncthreads();
         if (ch < 12) GSTAMP();
     }
     GSTAMP();
+    if (part) {  // partial K range: park the accumulators, the fix-up kernel adds the other part and stores the tile
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(t * 4 + r) * 256 + tid] = acc[t][r];
+        return;
+    }
 
     // lane holds D[m = 4 * kq + r][n = l15] of each 16x16 tile
     if (L2) {
@@ -1354,7 +1379,7 @@ __device__ __forceinline__ void grad_adj16_body(const GradArgs& a, int cd, int u
 
 // dNeg_c[m, n] = sum_i V[i, m] * adj_c[i, n]
 template <bool L2, int NT>
-__device__ __forceinline__ void grad_neg16_body(const GradArgs& a, int cd, int unit, int tiles_m, float* smem) {
+__device__ __forceinline__ void grad_neg16_body(const GradArgs& a, int cd, int unit, int tiles_m, float* smem, int cbeg = 0, int cend = -1, float* part = nullptr) {
     constexpr int BS = 16 * NT + 4;  // B staged [k][n]: stride % 8 == 4 keeps the four k-rows of an MFMA B fragment on disjoint banks
     float(*Qs)[H_QSZ] = reinterpret_cast<float(*)[H_QSZ]>(smem);
     float(*Bs)[H_KC * BS] = reinterpret_cast<float(*)[H_KC * BS]>(smem + 2 * H_QSZ);
@@ -1476,22 +1501,30 @@ __device__ __forceinline__ void grad_neg16_body(const GradArgs& a, int cd, int u
         }
     };
 
+    const int cend_ = cend < 0 ? nchunks : cend;
     float4 vs0[2], vb0[4], vs1[2], vb1[4];
     float lv0[2], lv1[2];
-    issue(0, vs0, lv0, vb0);
-    issue(1, vs1, lv1, vb1);
-    write(0, 0, vs0, lv0, vb0);
-    issue(2, vs0, lv0, vb0);
+    issue(cbeg, vs0, lv0, vb0);
+    issue(cbeg + 1, vs1, lv1, vb1);
+    write(0, cbeg, vs0, lv0, vb0);
+    issue(cbeg + 2, vs0, lv0, vb0);
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ch += 2) {
+    for (int ch = cbeg; ch < cend_; ch += 2) {
         compute(0);
         if (!(GRAD_ABLATE & 4)) write(1, ch + 1, vs1, lv1, vb1);
         if (!(GRAD_ABLATE & 8)) issue(ch + 3, vs1, lv1, vb1);
         __syncthreads();
-        if (ch + 1 < nchunks) compute(1);
+        if (ch + 1 < cend_) compute(1);
         if (!(GRAD_ABLATE & 4)) write(0, ch + 2, vs0, lv0, vb0);
         if (!(GRAD_ABLATE & 8)) issue(ch + 4, vs0, lv0, vb0);
         __syncthreads();
+    }
+    if (part) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(t * 4 + r) * 256 + threadIdx.x] = acc[t][r];
+        return;
     }
 
     if (L2) {
@@ -1537,6 +1570,86 @@ __global__ __launch_bounds__(256, 3) void lp_grad16_kernel(GradArgs a, int tiles
         grad_adj16_body<L2, NT>(a, cd, unit, tiles_adj, smem);
     else
         grad_neg16_body<L2, NT>(a, cd, unit - units_adj, tiles_neg, smem);
+}
+
+// ---- stream-K launch of the same two bodies (Dot comparator).  3200 equal tiles over 768 resident workgroups run 4.17 -> 5 rounds
+// (83 % fill).  Here 768 persistent workgroups split the flat list of (tile, K chunk) units evenly (+-1 chunk): a workgroup finishes
+// the tail of the tile its predecessor started, a few whole tiles, and the head of one more.  Partial accumulators (at most two per
+// workgroup; a tile is shared by at most two workgroups because every range is longer than a tile's K loop) go to `part`, and
+// lp_grad16_fixup_kernel adds the two halves in a fixed order and stores the tile: deterministic, no atomics.
+struct SkUnit {
+    int cd, kind, tile, chunk, nch;  // kind 0 = dAdj tile, 1 = dNeg tile
+};
+__device__ __forceinline__ SkUnit sk_decode(int u, int tiles_adj, int tiles_neg, int nch_adj, int nch_neg) {
+    const int per_cd = tiles_adj * nch_adj + tiles_neg * nch_neg;
+    SkUnit k;
+    k.cd = u / per_cd;
+    int r = u - k.cd * per_cd;
+    if (r < tiles_adj * nch_adj) {
+        k.kind = 0;
+        k.nch = nch_adj;
+    } else {
+        r -= tiles_adj * nch_adj;
+        k.kind = 1;
+        k.nch = nch_neg;
+    }
+    k.tile = r / k.nch;
+    k.chunk = r - k.tile * k.nch;
+    return k;
+}
+__device__ __forceinline__ int sk_wlin(int b, int nwg) { return (nwg & 7) ? b : (b & 7) * (nwg >> 3) + (b >> 3); }  // XCD-major when possible
+
+template <int NT>
+__global__ __launch_bounds__(256, 3) void lp_grad16_sk_kernel(GradArgs a, int tiles_adj, int tiles_neg, int nch_adj, int nch_neg, int total_units, int nwg,
+                                                              float* part) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wlin = sk_wlin((int)blockIdx.x, nwg);
+    int u = (int)((int64_t)wlin * total_units / nwg);
+    const int u1 = (int)((int64_t)(wlin + 1) * total_units / nwg);
+    while (u < u1) {
+        const SkUnit k = sk_decode(u, tiles_adj, tiles_neg, nch_adj, nch_neg);
+        const int c0 = k.chunk;
+        const int c1 = min(k.nch, c0 + (u1 - u));
+        const bool full = c0 == 0 && c1 == k.nch;
+        // slot 0: tail of a tile the predecessor started (c0 > 0); slot 1: head of a tile the successor finishes
+        float* p = full ? nullptr : part + ((size_t)wlin * 2 + (c0 > 0 ? 0 : 1)) * (NT * 4 * 256);
+        __syncthreads();  // the previous segment's last LDS reads are done before this segment's prologue overwrites the buffers
+        if (k.kind == 0)
+            grad_adj16_body<false, NT>(a, k.cd, k.tile, tiles_adj, smem, c0, c1, p);
+        else
+            grad_neg16_body<false, NT>(a, k.cd, k.tile, tiles_neg, smem, c0, c1, p);
+        u += c1 - c0;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void lp_grad16_fixup_kernel(GradArgs a, int tiles_adj, int tiles_neg, int nch_adj, int nch_neg, int total_units, int nwg,
+                                                              const float* part) {
+    const int b = blockIdx.x;  // boundary between workgroup ranges b and b + 1
+    const int ub = (int)((int64_t)(b + 1) * total_units / nwg);
+    if (ub >= total_units) return;
+    const SkUnit k = sk_decode(ub, tiles_adj, tiles_neg, nch_adj, nch_neg);
+    if (k.chunk == 0) return;  // the boundary coincides with a tile boundary: nothing was split
+    const LpDims& D = a.D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const float* p0 = part + ((size_t)b * 2 + 1) * (NT * 4 * 256);        // head part (workgroup b)
+    const float* p1 = part + ((size_t)(b + 1) * 2 + 0) * (NT * 4 * 256);  // tail part (workgroup b + 1)
+    const int dir = k.cd / D.C, c = k.cd - dir * D.C;
+    const int64_t rowbase = (int64_t)dir * D.Bp + (int64_t)c * D.Bc;
+    const int m0 = k.tile * H_TM;
+    float* out = k.kind == 0 ? a.dadj + rowbase * D.d_ld : a.gocc + (a.negocc_off[dir] + (int64_t)c * D.N) * D.d_ld;
+    const int mlimit = k.kind == 0 ? D.Bc : D.N;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = 16 * t + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wave * 16 + 4 * kq + r;
+            const int e = (t * 4 + r) * 256 + tid;
+            if (m < mlimit && n < D.d) out[(int64_t)m * D.d_ld + n] = p0[e] + p1[e];
+        }
+    }
 }
 
 // =========================================================================================== launchers
@@ -1701,6 +1814,44 @@ static bool grad16_shape(const GradArgs& a, bool l2, int& nblk, int& nt) {
     } while (0)
 
 // which: 0 = both contractions in one launch, 1 = dAdj only, 2 = dNeg only
+// stream-K variant; `part` must hold grad16_sk_part_bytes() bytes.  Returns false when it does not apply (L2, several n-blocks, tiny shapes).
+size_t grad16_sk_part_bytes() { return (size_t)768 * 2 * 8 * 4 * 256 * sizeof(float); }
+bool launch_grad16_sk(const GradArgs& a, bool l2, float* part, hipStream_t st) {
+    int nblk, nt;
+    if (l2 || !part || !grad16_shape(a, l2, nblk, nt) || nblk != 1) return false;
+    const char* e = getenv("MARIUS_GRAD_SK");  // opt-in: measured SLOWER than the plain launch on the bench workload (0.515 vs 0.476 ms) —
+    if (!(e && e[0] == '1')) return false;     // the dynamic dispatch of 3200 staggered workgroups already hides most of the last round,
+                                               // while 768 persistent workgroups start in phase and pay two extra prologues each
+    const int tiles_adj = (int)cdiv(a.D.Bc, H_TM), tiles_neg = (int)cdiv(a.D.N, H_TM);
+    const int nch_adj = (int)cdiv(a.D.N, H_KC), nch_neg = (int)cdiv(a.D.Bc, H_KC);
+    const int ncd = a.D.C * a.D.ndir;
+    const int64_t total64 = (int64_t)ncd * (tiles_adj * nch_adj + tiles_neg * nch_neg);
+    if (total64 >= ((int64_t)1 << 30)) return false;
+    const int total = (int)total64;
+    int nwg = 768;
+    const char* w = getenv("MARIUS_GRAD_NWG");  // tests: force splits at small shapes
+    if (w) nwg = atoi(w);
+    const int maxch = nch_adj > nch_neg ? nch_adj : nch_neg;
+    if (nwg > total / maxch) nwg = total / maxch;  // every range at least one full K loop long: a tile is shared by at most two workgroups
+    if (nwg > 768) nwg = 768;
+    if (nwg < 1) return false;
+    const int nt_inst = nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : nt <= 7 ? 7 : 8;
+    const size_t lds = grad16_lds_bytes(a.D.N, nt_inst);
+#define GRAD16_SK(NTV)                                                                                                              \
+    do {                                                                                                                            \
+        lp_grad16_sk_kernel<NTV><<<dim3(nwg), dim3(256), lds, st>>>(a, tiles_adj, tiles_neg, nch_adj, nch_neg, total, nwg, part);   \
+        if (nwg > 1)                                                                                                                \
+            lp_grad16_fixup_kernel<NTV><<<dim3(nwg - 1), dim3(256), 0, st>>>(a, tiles_adj, tiles_neg, nch_adj, nch_neg, total, nwg, part); \
+    } while (0)
+    if (nt_inst == 1) GRAD16_SK(1);
+    else if (nt_inst == 2) GRAD16_SK(2);
+    else if (nt_inst == 4) GRAD16_SK(4);
+    else if (nt_inst == 7) GRAD16_SK(7);
+    else GRAD16_SK(8);
+#undef GRAD16_SK
+    return true;
+}
+
 bool launch_grad16(const GradArgs& a, bool l2, int which, hipStream_t st) {
     int nblk, nt;
     if (!grad16_shape(a, l2, nblk, nt)) return false;

@@ -487,3 +487,24 @@ def test_split_bf16_kernels_match_oracle_and_fp32_path(H, dev, monkeypatch, deco
     neg_p, gocc_p, _ = out["p"]
     assert (neg_b - neg_p).abs().max() <= 2e-5 * max(1.0, neg_p.abs().max().item())
     assert (gocc_b - gocc_p).abs().max() <= 2e-5 * max(1.0, gocc_p.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nwg", ["", "3"])
+def test_stream_k_backward_matches_plain_launch(H, dev, monkeypatch, nwg):
+    """MARIUS_GRAD_SK=1: persistent workgroups split the flat (tile, K chunk) list; tiles cut by a range boundary are completed by
+    the fix-up kernel.  Must reproduce the plain launch up to summation order."""
+    decoder, B, C, N, d = "COMPLEX", 1000, 10, 500, 100
+    U, R = B, 11
+    emb, state, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=77)
+    monkeypatch.setenv("MARIUS_GRAD_SK", "0")
+    W = run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, "sum")
+    torch.cuda.synchronize()
+    want = W.gocc()[:, :d].cpu().clone()
+    monkeypatch.setenv("MARIUS_GRAD_SK", "1")
+    if nwg:
+        monkeypatch.setenv("MARIUS_GRAD_NWG", nwg)
+    W = run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, "sum")
+    torch.cuda.synchronize()
+    got = W.gocc()[:, :d].cpu()
+    assert (got - want).abs().max() <= 1e-5 * max(1.0, want.abs().max().item())
