@@ -100,6 +100,120 @@ __global__ __launch_bounds__(256) void lp_prep_kernel(PrepArgs a) {
     }
 }
 
+// Vectorised prep: half a wave (32 lanes) per edge, BOTH directions at once (they share the two endpoint rows), lane l owns the
+// element pairs {2l, 2l+1} of the first half of the row and {d/2 + 2l, d/2 + 2l + 1} of the second half — for ComplEx exactly the
+// (re, im) partners.  Four times fewer waves than lp_prep_kernel and four independent 8-B loads per row and lane instead of a
+// dependent chain of 4-B ones (that kernel is latency-bound: 62 us for 120 MB).  Requires d % 4 == 0, d <= 128, even row strides.
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void lp_prep2_kernel(PrepArgs a) {
+#pragma clang fp contract(off)
+    const LpDims& D = a.D;
+    const int l = threadIdx.x & 31;
+    const int64_t i = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (i >= D.Bp) return;
+    const int h2 = D.d / 2;
+    const bool act = 4 * l < D.d;          // lanes that own elements
+    const int c0 = 2 * l, c1 = h2 + 2 * l;  // first-half pair, second-half pair
+    if (i >= D.B) {  // pad_and_reshape zero rows; F.pad zero positives
+        for (int dir = 0; dir < D.ndir; ++dir) {
+            float* adj = a.adj + ((int64_t)dir * D.Bp + i) * D.d_ld;
+            if (act) {
+                *reinterpret_cast<float2*>(adj + c0) = make_float2(0.f, 0.f);
+                *reinterpret_cast<float2*>(adj + c1) = make_float2(0.f, 0.f);
+            }
+            if (l == 0) {
+                a.pos[(int64_t)dir * D.Bp + i] = 0.f;
+                if (a.x2) a.x2[(int64_t)dir * D.Bp + i] = 0.f;
+            }
+        }
+        return;
+    }
+    const int64_t* ed = a.edges + i * D.edge_cols;
+    const int64_t s = ed[0], t = ed[D.edge_cols - 1];
+    const float* es = a.emb + s * a.emb_ld;
+    const float* et = a.emb + t * a.emb_ld;
+    float x[2][4];  // [0] = src row, [1] = dst row; elements {c0, c0+1, c1, c1+1}
+    float r[2][4];
+    const bool has_rel0 = (D.edge_cols == 3) && a.rel[0], has_rel1 = (D.edge_cols == 3) && a.rel[1];
+    if (act) {
+        const float2 a0 = *reinterpret_cast<const float2*>(es + c0), a1 = *reinterpret_cast<const float2*>(es + c1);
+        const float2 b0 = *reinterpret_cast<const float2*>(et + c0), b1 = *reinterpret_cast<const float2*>(et + c1);
+        x[0][0] = a0.x; x[0][1] = a0.y; x[0][2] = a1.x; x[0][3] = a1.y;
+        x[1][0] = b0.x; x[1][1] = b0.y; x[1][2] = b1.x; x[1][3] = b1.y;
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            const bool hr = dir == 0 ? has_rel0 : has_rel1;
+            if (hr && dir < D.ndir) {
+                const float* rr = a.rel[dir] + ed[1] * a.rel_ld;
+                const float2 q0 = *reinterpret_cast<const float2*>(rr + c0), q1 = *reinterpret_cast<const float2*>(rr + c1);
+                r[dir][0] = q0.x; r[dir][1] = q0.y; r[dir][2] = q1.x; r[dir][3] = q1.y;
+            } else {
+                r[dir][0] = r[dir][1] = r[dir][2] = r[dir][3] = 0.f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[0][k] = x[1][k] = r[0][k] = r[1][k] = 0.f;
+    }
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+        if (dir >= D.ndir) break;
+        const float* e = x[dir];        // operand that goes through the relation operator
+        const float* o = x[dir ^ 1];    // the other endpoint
+        const bool hr = dir == 0 ? has_rel0 : has_rel1;
+        float v[4];
+        if (!hr) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = e[k];
+        } else if (D.relop == MARIUS_OP_HADAMARD) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = e[k] * r[dir][k];
+        } else if (D.relop == MARIUS_OP_TRANSLATION) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = e[k] + r[dir][k];
+        } else if (D.relop == MARIUS_OP_COMPLEX_HADAMARD) {  // same expressions as relop_fwd, (re, im) = (k, k + 2)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                v[k] = (e[k] * r[dir][k]) - (e[k + 2] * r[dir][k + 2]);
+                v[k + 2] = (e[k] * r[dir][k + 2]) + (e[k + 2] * r[dir][k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = e[k];
+        }
+        float acc = 0.f, nrm = 0.f;
+        if (act) {
+            if (D.cmp == MARIUS_CMP_L2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float df = (v[k] - o[k]) + 1e-6f;  // pairwise_distance: ||x1 - x2 + eps||
+                    acc += df * df;
+                    nrm += v[k] * v[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc += v[k] * o[k];
+            }
+            float* adj = a.adj + ((int64_t)dir * D.Bp + i) * D.d_ld;
+            *reinterpret_cast<float2*>(adj + c0) = make_float2(v[0], v[1]);
+            *reinterpret_cast<float2*>(adj + c1) = make_float2(v[2], v[3]);
+        }
+        acc = half_sum(acc);
+        if (D.cmp == MARIUS_CMP_L2) {
+            nrm = half_sum(nrm);
+            acc = sqrtf(acc);
+        }
+        if (l == 0) {
+            a.pos[(int64_t)dir * D.Bp + i] = acc;
+            if (a.x2) a.x2[(int64_t)dir * D.Bp + i] = nrm;
+        }
+    }
+}
+
 // L2 only: y2[dir][c*N + j] = ||neg row||^2
 __global__ __launch_bounds__(256) void lp_negnorm_kernel(const float* emb, int64_t emb_ld, const int64_t* neg0, const int64_t* neg1,
                                                          int64_t CN, int d, int ndir, float* y2) {
@@ -611,6 +725,103 @@ __global__ __launch_bounds__(256) void lp_edge_bwd_kernel(EdgeBwdArgs a) {
     }
 }
 
+// Vectorised edge backward: half a wave per edge, lane l owns the element pairs {2l, 2l+1} and {d/2 + 2l, d/2 + 2l + 1} (ComplEx:
+// the (re, im) partners), every operand arrives as two independent 8-B loads.  Same arithmetic as lp_edge_bwd_kernel.
+__global__ __launch_bounds__(256) void lp_edge_bwd2_kernel(EdgeBwdArgs a) {
+    const LpDims& D = a.D;
+    const int l = threadIdx.x & 31;
+    const int64_t i = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (i >= D.B || 4 * l >= D.d) return;
+    const int c0 = 2 * l, c1 = D.d / 2 + 2 * l;
+    const int64_t* ed = a.edges + i * D.edge_cols;
+    const int64_t s = ed[0], t = ed[D.edge_cols - 1];
+    auto ld4 = [&](const float* row, float (&v)[4]) {
+        const float2 p = *reinterpret_cast<const float2*>(row + c0), q = *reinterpret_cast<const float2*>(row + c1);
+        v[0] = p.x; v[1] = p.y; v[2] = q.x; v[3] = q.y;
+    };
+    auto st4 = [&](float* row, const float (&v)[4]) {
+        *reinterpret_cast<float2*>(row + c0) = make_float2(v[0], v[1]);
+        *reinterpret_cast<float2*>(row + c1) = make_float2(v[2], v[3]);
+    };
+    float x[2][4], av[2][4], dv[2][4], r[2][4];
+    ld4(a.emb + s * a.emb_ld, x[0]);
+    ld4(a.emb + t * a.emb_ld, x[1]);
+    bool has_rel[2];
+    float coef[2], posv[2];
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+        has_rel[dir] = false;
+        coef[dir] = posv[dir] = 0.f;
+        if (dir >= D.ndir) continue;
+        const int64_t rowoff = ((int64_t)dir * D.Bp + i) * D.d_ld;
+        ld4(a.adj + rowoff, av[dir]);
+        ld4(a.dadj + rowoff, dv[dir]);
+        has_rel[dir] = (D.edge_cols == 3) && (a.rel[dir] != nullptr);
+        if (has_rel[dir]) ld4(a.rel[dir] + ed[1] * a.rel_ld, r[dir]);
+        const float p = a.pos[(int64_t)dir * D.Bp + i];
+        const float lse = a.lse[(int64_t)dir * D.Bp + i];
+        coef[dir] = (__expf(p - lse) - 1.f) * D.gscale;  // dL/dpos
+        posv[dir] = p;
+    }
+    float out_s[4] = {0.f, 0.f, 0.f, 0.f}, out_t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+        if (dir >= D.ndir) continue;
+        const float* e = x[dir];       // operand that went through the relation operator
+        const float* o = x[dir ^ 1];   // the other endpoint
+        float ga[4], go[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float g = dv[dir][k];
+            if (D.cmp == MARIUS_CMP_L2) {
+                const float df = (av[dir][k] - o[k]) + 1e-6f;
+                const float w = (posv[dir] > 0.f) ? coef[dir] * df / posv[dir] : 0.f;
+                g += w;
+                go[k] = -w;
+            } else {
+                g += coef[dir] * o[k];
+                go[k] = coef[dir] * av[dir][k];
+            }
+            ga[k] = g;
+        }
+        float ge[4] = {ga[0], ga[1], ga[2], ga[3]}, gr[4] = {0.f, 0.f, 0.f, 0.f};
+        if (has_rel[dir]) {
+            if (D.relop == MARIUS_OP_HADAMARD) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ge[k] = ga[k] * r[dir][k];
+                    gr[k] = ga[k] * e[k];
+                }
+            } else if (D.relop == MARIUS_OP_TRANSLATION) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gr[k] = ga[k];
+            } else if (D.relop == MARIUS_OP_COMPLEX_HADAMARD) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float er = e[k], ei = e[k + 2], rr = r[dir][k], ri = r[dir][k + 2];
+                    ge[k] = ga[k] * rr + ga[k + 2] * ri;
+                    ge[k + 2] = -ga[k] * ri + ga[k + 2] * rr;
+                    gr[k] = ga[k] * er + ga[k + 2] * ei;
+                    gr[k + 2] = -ga[k] * ei + ga[k + 2] * er;
+                }
+            }
+            st4(a.grel[dir] + i * D.d_ld, gr);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (dir == 0) {
+                out_s[k] += ge[k];
+                out_t[k] += go[k];
+            } else {
+                out_t[k] += ge[k];
+                out_s[k] += go[k];
+            }
+        }
+    }
+    st4(a.gocc + i * D.d_ld, out_s);
+    st4(a.gocc + (D.B + i) * D.d_ld, out_t);
+}
+
 __global__ __launch_bounds__(256) void lp_zero_rows_kernel(float* p, int64_t n) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) p[t] = 0.f;
 }
@@ -787,7 +998,14 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     pa.D = D;
     {
         ProfScope ps(PROF_LP_PREP, st);
-        lp_prep_kernel<<<dim3((unsigned)cdiv(D.Bp * D.ndir, 4)), dim3(256), 0, st>>>(pa);
+        const char* pv = getenv("MARIUS_PREP");  // MARIUS_PREP=1: one-wave-per-row kernel (any shape)
+        const bool vec_ok = (D.d % 4 == 0) && D.d <= 128 && (desc->emb_ld % 2 == 0) && (desc->rel_ld % 2 == 0 || !desc->rel) && (D.d == D.d_ld) &&
+                            ((reinterpret_cast<uintptr_t>(desc->emb) & 7) == 0) && ((reinterpret_cast<uintptr_t>(desc->rel) & 7) == 0) &&
+                            ((reinterpret_cast<uintptr_t>(desc->inv_rel) & 7) == 0) && !(pv && pv[0] == '1');
+        if (vec_ok)
+            lp_prep2_kernel<<<dim3((unsigned)cdiv(D.Bp, 8)), dim3(256), 0, st>>>(pa);
+        else
+            lp_prep_kernel<<<dim3((unsigned)cdiv(D.Bp * D.ndir, 4)), dim3(256), 0, st>>>(pa);
     }
     rc = check_launch("lp_prep");
     if (rc) return rc;
@@ -987,7 +1205,14 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     ea.D = D;
     {
         ProfScope ps(PROF_LP_EDGE_BWD, st);
-        lp_edge_bwd_kernel<<<dim3((unsigned)cdiv(D.B, 4)), dim3(256), 0, st>>>(ea);
+        const char* pv = getenv("MARIUS_PREP");  // MARIUS_PREP=1: one-wave-per-edge kernel (any shape)
+        const bool vec_ok = (D.d % 4 == 0) && D.d <= 128 && (desc->emb_ld % 2 == 0) && (desc->rel_ld % 2 == 0 || !desc->rel) && (D.d == D.d_ld) &&
+                            ((reinterpret_cast<uintptr_t>(desc->emb) & 7) == 0) && ((reinterpret_cast<uintptr_t>(desc->rel) & 7) == 0) &&
+                            ((reinterpret_cast<uintptr_t>(desc->inv_rel) & 7) == 0) && !(pv && pv[0] == '1');
+        if (vec_ok)
+            lp_edge_bwd2_kernel<<<dim3((unsigned)cdiv(D.B, 8)), dim3(256), 0, st>>>(ea);
+        else
+            lp_edge_bwd_kernel<<<dim3((unsigned)cdiv(D.B, 4)), dim3(256), 0, st>>>(ea);
     }
     return check_launch("lp_edge_bwd");
 }
