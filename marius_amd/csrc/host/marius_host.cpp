@@ -49,6 +49,14 @@ static torch::TensorOptions f32(torch::Device d) { return torch::TensorOptions()
         if (e_ != hipSuccess) throw MariusRuntimeException(std::string("HIP: ") + hipGetErrorString(e_));   \
     } while (0)
 
+namespace {
+struct StreamScope {  // make `s` the current torch stream of this thread for the lifetime of the object
+    c10::hip::HIPStream prev;
+    explicit StreamScope(c10::hip::HIPStream s) : prev(c10::hip::getCurrentHIPStream(s.device_index())) { c10::hip::setCurrentHIPStream(s); }
+    ~StreamScope() { c10::hip::setCurrentHIPStream(prev); }
+};
+}  // namespace
+
 MariusGenerator::MariusGenerator(uint64_t seed) {
     state_host_ = torch::zeros({MARIUS_MT_STATE_WORDS}, torch::kInt32);
     marius_mt19937_seed_host((uint32_t*)state_host_.data_ptr<int32_t>(), seed);
@@ -704,7 +712,28 @@ void Model::train_batch(shared_ptr<Batch> batch, bool call_step) {
 void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor state) {
     forward_lp(batch, true);
     model_backward(*this, batch);
-    if (!relation_step_sparse(*this, batch)) {
+    // The relation-table update (6 small, latency-bound launches) and the node-table update are independent: run the former on a side
+    // stream underneath the latter and join before returning (the next forward reads the relation tables).
+    const auto dev_index = device_.index();
+    c10::hip::HIPStream main = c10::hip::getCurrentHIPStream(dev_index);
+    if (!side_stream_) {
+        side_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(false, dev_index));
+        hipEvent_t e0, e1;
+        HIPCHECK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        ev_fork_ = e0;
+        ev_join_ = e1;
+    }
+    c10::hip::HIPStream side = *(c10::hip::HIPStream*)side_stream_;
+    HIPCHECK(hipEventRecord((hipEvent_t)ev_fork_, main.stream()));
+    HIPCHECK(hipStreamWaitEvent(side.stream(), (hipEvent_t)ev_fork_, 0));
+    bool sparse_ok;
+    {
+        StreamScope scope(side);
+        sparse_ok = relation_step_sparse(*this, batch);
+    }
+    HIPCHECK(hipEventRecord((hipEvent_t)ev_join_, side.stream()));
+    if (!sparse_ok) {
         clear_grad();
         relation_grads_dense(*this, batch);
         step();
@@ -715,6 +744,13 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
     mcheck(marius_segment_adagrad_scatter(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
                                           batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, ip(batch->unique_node_indices_), fp(table),
                                           fp(state), table.stride(0), sparse_lr_, 1e-10f, carry_.data_ptr(), cur_stream()));
+    HIPCHECK(hipStreamWaitEvent(main.stream(), (hipEvent_t)ev_join_, 0));
+}
+
+Model::~Model() {
+    if (ev_fork_) (void)hipEventDestroy((hipEvent_t)ev_fork_);
+    if (ev_join_) (void)hipEventDestroy((hipEvent_t)ev_join_);
+    delete (c10::hip::HIPStream*)side_stream_;
 }
 
 void Model::evaluate_batch(shared_ptr<Batch> batch) {
@@ -754,14 +790,6 @@ DataLoader::~DataLoader() {
         if (e) (void)hipEventDestroy((hipEvent_t)e);
     delete (c10::hip::HIPStream*)loader_stream_;
 }
-
-namespace {
-struct StreamScope {  // make `s` the current torch stream of this thread for the lifetime of the object
-    c10::hip::HIPStream prev;
-    explicit StreamScope(c10::hip::HIPStream s) : prev(c10::hip::getCurrentHIPStream(s.device_index())) { c10::hip::setCurrentHIPStream(s); }
-    ~StreamScope() { c10::hip::setCurrentHIPStream(prev); }
-};
-}  // namespace
 
 shared_ptr<Batch> DataLoader::getBatch(bool exact_unique) {
     if (!run_ahead_ && !next_) {

@@ -315,6 +315,10 @@ class Model {
     Tensor loss_;  // [4] device floats: total, rhs, lhs, -
     // scratch for the gradient reductions
     Tensor carry_, rel_carry_, rel_ws_, rel_uniq_, rel_inverse_, rel_perm_, rel_seg_, rel_count_, rel_ids_;
+    void* side_stream_ = nullptr;  // relation-table update runs here, underneath the node-table update (backward_into_tables)
+    void* ev_fork_ = nullptr;
+    void* ev_join_ = nullptr;
+    ~Model();
 
     Model(shared_ptr<EdgeDecoder> decoder, shared_ptr<LossFunction> loss, shared_ptr<LinkPredictionReporter> reporter, torch::Device device);
     std::tuple<Tensor, Tensor, Tensor, Tensor> forward_lp(shared_ptr<Batch> batch, bool train);  // model.cpp:252-288
