@@ -176,6 +176,8 @@ class _Slot:
         self.edges_local = torch.empty((B, cols), dtype=torch.int64, device=dev)
         self.all_ids = torch.empty(L, dtype=torch.int64, device=dev)
         self.um = H.UniqueMap(L, dev)
+        self.um_rel = H.UniqueMap(B, dev)   # relation ids of the batch, grouped (prepared ahead like the node map)
+        self.rel_ids = torch.empty(B, dtype=torch.int64, device=dev)
         self.offs_dev = torch.empty(world + 1, dtype=torch.int64, device=dev)
         self.offs_host = torch.empty(world + 1, dtype=torch.int64).pin_memory()
         self.recv_host = torch.empty(world, dtype=torch.int64)
@@ -274,6 +276,9 @@ class PipelinedShardedTrainer:
             slot.um.run(slot.all_ids, s.key_bits)
             H.check(L_.marius_remap_edges(H.ptr(slot.edges), H.ptr(slot.um.inverse), B, s.edge_cols, H.ptr(slot.edges_local), st), "remap")
             H.check(L_.marius_owner_offsets(H.ptr(slot.um.uniq), H.ptr(slot.um.count), self.S, self.world, H.ptr(slot.offs_dev), st), "owner_offsets")
+            if s.edge_cols == 3:
+                slot.rel_ids.copy_(slot.edges[:, 1])
+                slot.um_rel.run(slot.rel_ids, s.rel_bits)
             slot.offs_host.copy_(slot.offs_dev, non_blocking=True)
             slot.ready.record(self.prep_stream)
             for tns in (slot.src_neg, slot.dst_neg) + tuple(f for f in slot.filters if f is not None):
@@ -334,14 +339,19 @@ class PipelinedShardedTrainer:
         slot.computed.record(self.main_stream)
         if self.trace is not None:
             self.trace.append({"uniq": slot.um.uniq[:U].clone(), "emb": slot.emb.clone(), "grad": slot.grad.clone()})
-        s.rel_ids.copy_(slot.edges[:, 1])
-        s.um_rel.run(s.rel_ids, s.rel_bits)
+        if self.sync_interval > 1:
+            # replicas step on their own gradients between averaging points: update only the relation rows this batch touched
+            # (a zero-gradient row is a fixed point of the dense Adagrad rule, so this equals the dense step bit for bit)
+            H.segment_adagrad_scatter(W.grel(0), slot.um_rel, B, d, s.rel, s.rel_sum, s.dense_lr, carry=s.carry_rel)
+            if s.inverse:
+                H.segment_adagrad_scatter(W.grel(1), slot.um_rel, B, d, s.inv_rel, s.inv_rel_sum, s.dense_lr, carry=s.carry_rel)
+            return None
         s.rel_grad.zero_()
-        H.segment_sum_rows(W.grel(0), s.um_rel, B, d, s.rel_grad, out_rows=s.um_rel.uniq, carry=s.carry_rel)
+        H.segment_sum_rows(W.grel(0), slot.um_rel, B, d, s.rel_grad, out_rows=slot.um_rel.uniq, carry=s.carry_rel)
         inv = None
         if s.inverse:
             s.inv_rel_grad.zero_()
-            H.segment_sum_rows(W.grel(1), s.um_rel, B, d, s.inv_rel_grad, out_rows=s.um_rel.uniq, carry=s.carry_rel)
+            H.segment_sum_rows(W.grel(1), slot.um_rel, B, d, s.inv_rel_grad, out_rows=slot.um_rel.uniq, carry=s.carry_rel)
             inv = s.inv_rel_grad
         return [s.rel_grad, inv]
 
@@ -362,7 +372,8 @@ class PipelinedShardedTrainer:
                     dist.all_reduce(g, group=self.group)
             be.dense_step(rel_grads)
         else:
-            be.dense_step(rel_grads)  # local step; replicas drift for at most sync_interval steps
+            if rel_grads is not None:
+                be.dense_step(rel_grads)  # local step; replicas drift for at most sync_interval steps
             if (t + 1) % self.sync_interval == 0:
                 for tt in be.dense_state():
                     dist.all_reduce(tt, group=self.group)

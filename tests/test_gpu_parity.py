@@ -434,6 +434,17 @@ def test_sharded_hip_backend_equals_single_gpu_step(H, dev):
     assert_close(tc, ta, "pipelined table", rtol=1e-6)
     assert_close(sc, sa, "pipelined state", rtol=1e-6)
     assert_close(piped.rel, fused.rel, "pipelined rel", rtol=1e-6)
+    # gpu_sync_interval > 1: replicas step locally on the relation rows their batch touched (no per-step all-reduce); at world 1 that
+    # is the same trajectory as the dense step
+    te, se = table.to(dev), torch.zeros(num_nodes, d, device=dev)
+    loc = DeviceLinkPredictionStep("COMPLEX", num_nodes, R, d, B, C, N, seed=seed, device=dev)
+    tr = PipelinedShardedTrainer(loc, te, se, edges_all, None, 0, 1, num_nodes, sync_interval=16, side_group=side)
+    for s in range(3):
+        tr.step()
+    torch.cuda.synchronize()
+    assert_close(te, ta, "sync_interval table", rtol=1e-6)
+    assert_close(loc.rel, fused.rel, "sync_interval rel", rtol=1e-6)
+    assert_close(loc.inv_rel, fused.inv_rel, "sync_interval inv_rel", rtol=1e-6)
     # overlapped exchange (staleness 1): rows of batch t are read after update t-2 and before update t-1 — replay the recorded
     # (ids, rows used, row gradients) of every step through the Adagrad rule and check exactly that.
     td, sd = table.to(dev), torch.zeros(num_nodes, d, device=dev)
