@@ -180,7 +180,7 @@ typedef struct marius_lp_layout {
     size_t gocc;      /* [2B + 2CN, d] occurrence gradients in map_tensors order (src, dst, src_neg, dst_neg)    */
     size_t grel[2];   /* [B, d]      per-edge relation gradients (dir 0 -> relations_, dir 1 -> inverse)         */
     size_t aux;       /* scratch (row norms etc.)                                                                */
-    size_t lsepart;   /* [ndir][Bp][groups][2] partial (max, sum exp) of the score epilogue (fused SoftmaxCE)                */
+    size_t lsepart;   /* [groups][ndir][Bp][2] partial (max, sum exp) of the score epilogue (fused SoftmaxCE)                */
     size_t embp;      /* [3][2B + 2CN][kp] bf16: exact 3-way split (hi, mid, lo) of the batch rows, kp = 16 ceil(d/16)          */
     size_t adjp;      /* [3][ndir Bp][kp]  bf16: the same split of adj (operands of the bf16-split contraction kernels)        */
     int64_t kp;

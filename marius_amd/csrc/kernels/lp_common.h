@@ -56,7 +56,7 @@ struct ScoreArgs {
     int KC, KS, nkc, dk;
     int ablate;  // debug only (MARIUS_ABLATE): 1 = skip S stores, 2 = skip MFMAs, 4 = skip negative-tile staging
     unsigned long long* dbg;  // debug only: per-phase s_memtime stamps of the first workgroups (MARIUS_DBG_TIMELINE)
-    float* lse_part;  // optional [ndir][Bp][ngroups][2]: per (row, negative-tile group) running (max, sum exp) from the score epilogue
+    float* lse_part;  // optional [ngroups][ndir][Bp][2]: per (negative-tile group, row) running (max, sum exp) from the score epilogue
     // bf16-split operand planes (lp_split.hip): [3][rows][kp] bf16, plane stride in elements
     const void* embp;
     int64_t embp_plane;

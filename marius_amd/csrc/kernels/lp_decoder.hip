@@ -376,11 +376,15 @@ __global__ __launch_bounds__(256) void lp_lse_merge_kernel(const float* __restri
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
     const float p = pos[row];
-    const float* pr = part + row * ng * 2;
+    // part is [group][row][2]: consecutive threads read consecutive 8-B pairs
+    const float2* pr = reinterpret_cast<const float2*>(part) + row;
     float m = p;
-    for (int g = 0; g < ng; ++g) m = fmaxf(m, pr[2 * g]);
+    for (int g = 0; g < ng; ++g) m = fmaxf(m, pr[(int64_t)g * rows].x);
     float sum = __expf(p - m);
-    for (int g = 0; g < ng; ++g) sum += pr[2 * g + 1] * __expf(pr[2 * g] - m);
+    for (int g = 0; g < ng; ++g) {
+        const float2 v = pr[(int64_t)g * rows];
+        sum += v.y * __expf(v.x - m);
+    }
     const float l = m + __logf(sum);
     lse[row] = l;
     rowloss[row] = l - p;

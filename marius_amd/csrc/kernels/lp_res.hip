@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void lp_scores_res_kernel(ScoreArgs a, int 
             const float ma = red[((wm * 2) * 32 + l31) * 2], la = red[((wm * 2) * 32 + l31) * 2 + 1];
             const float mb = red[((wm * 2 + 1) * 32 + l31) * 2], lb = red[((wm * 2 + 1) * 32 + l31) * 2 + 1];
             const float mx = fmaxf(ma, mb);
-            float* out = a.lse_part + ((((int64_t)dir * D.Bp + (int64_t)c * D.Bc + m) * ngroups) + ng) * 2;
+            float* out = a.lse_part + ((int64_t)ng * D.ndir * D.Bp + (int64_t)dir * D.Bp + (int64_t)c * D.Bc + m) * 2;  // [group][row][2]: rows of a wave are contiguous
             out[0] = mx;
             out[1] = la * __expf(ma - mx) + lb * __expf(mb - mx);
         }
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void lp_scores_il_kernel(ScoreArgs a, int n
             const float ma = red[((wm * 2) * 32 + l31) * 2], la = red[((wm * 2) * 32 + l31) * 2 + 1];
             const float mb = red[((wm * 2 + 1) * 32 + l31) * 2], lb = red[((wm * 2 + 1) * 32 + l31) * 2 + 1];
             const float mx = fmaxf(ma, mb);
-            float* out = a.lse_part + ((((int64_t)dir * D.Bp + (int64_t)c * D.Bc + m_row) * ngroups) + ng) * 2;
+            float* out = a.lse_part + ((int64_t)ng * D.ndir * D.Bp + (int64_t)dir * D.Bp + (int64_t)c * D.Bc + m_row) * 2;
             out[0] = mx;
             out[1] = la * __expf(ma - mx) + lb * __expf(mb - mx);
         }
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256, 2) void lp_scores_ps_kernel(ScoreArgs a, int n
                 const float ma = red[((wm * 2) * 32 + l31) * 2], la = red[((wm * 2) * 32 + l31) * 2 + 1];
                 const float mb = red[((wm * 2 + 1) * 32 + l31) * 2], lb = red[((wm * 2 + 1) * 32 + l31) * 2 + 1];
                 const float mx = fmaxf(ma, mb);
-                float* out = a.lse_part + ((((int64_t)dk.dir * D.Bp + (int64_t)dk.c * D.Bc + m) * ngroups) + dk.ng) * 2;
+                float* out = a.lse_part + ((int64_t)dk.ng * D.ndir * D.Bp + (int64_t)dk.dir * D.Bp + (int64_t)dk.c * D.Bc + m) * 2;
                 out[0] = mx;
                 out[1] = la * __expf(ma - mx) + lb * __expf(mb - mx);
             }
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(256, 3) void lp_scores_a_kernel(ScoreArgs a, int ng
         const float mm = fmaxf(run_m, m2);
         const float ll = run_l * __expf(run_m - mm) + l2 * __expf(m2 - mm);
         if (h == 0 && m_ok) {
-            float* out = a.lse_part + (((rowbase + m_row) * ngroups) + ng) * 2;
+            float* out = a.lse_part + ((int64_t)ng * D.ndir * D.Bp + rowbase + m_row) * 2;
             out[0] = mm;
             out[1] = ll;
         }
@@ -1134,7 +1134,7 @@ __global__ __launch_bounds__(256, 3) void lp_scores_ap_kernel(ScoreArgs a, int n
             const float mm = fmaxf(run_m, m2);
             const float ll = run_l * __expf(run_m - mm) + l2 * __expf(m2 - mm);
             if (h == 0 && m_ok) {
-                float* out = a.lse_part + (((rowbase + m_row) * npairs) + cur.g) * 2;
+                float* out = a.lse_part + ((int64_t)cur.g * D.ndir * D.Bp + rowbase + m_row) * 2;
                 out[0] = mm;
                 out[1] = ll;
             }

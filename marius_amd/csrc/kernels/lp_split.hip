@@ -356,7 +356,7 @@ __global__ __launch_bounds__(B6_NT, 1) __attribute__((amdgpu_waves_per_eu(2, 2))
             const float mm = fmaxf(run_m, m2);
             const float ll = run_l * __expf(run_m - mm) + l2 * __expf(m2 - mm);
             if (h == 0 && m_ok) {
-                float* out = a.lse_part + (((rowbase + m_row) * npairs) + cur.g) * 2;
+                float* out = a.lse_part + ((int64_t)cur.g * D.ndir * D.Bp + rowbase + m_row) * 2;
                 out[0] = mm;
                 out[1] = ll;
             }
