@@ -72,6 +72,12 @@ int marius_adagrad_rule(const float* grad, float* state, float* dw, float* ds, i
 int marius_dense_adagrad_step(float* param, float* state_sum, const float* grad, int64_t n, float lr, float eps,
                               float weight_decay, marius_stream_t stream);
 
+/* dense AdamOptimizer::step  src/nn/optim.cpp:186-232 (the reference's fb15k_237 example trains the relation tables with it):
+ * exp_avg = exp_avg*b1 + g*(1-b1); exp_avg_sq = exp_avg_sq*b2 + (1-b2)*g*g; denom = sqrt(exp_avg_sq or its running max)/sqrt(1-b2^t) + eps;
+ * w -= lr/(1-b1^t) * exp_avg/denom, t = num_steps + 1.  max_exp_avg_sq = NULL unless amsgrad. */
+int marius_dense_adam_step(float* param, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, const float* grad, int64_t n, float lr,
+                           float beta1, float beta2, float eps, float weight_decay, int64_t num_steps, marius_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------ sampling */
 
 /* ATen CPU generator stream (at::mt19937 as used by torch::randint / torch::randperm on CPU tensors).

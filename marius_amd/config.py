@@ -81,9 +81,10 @@ def load_config(path):
     layers = cfg["model"]["encoder"]["layers"]
     if len(layers) != 1 or len(layers[0]) != 1 or layers[0][0]["type"] != "EMBEDDING":
         raise NotImplementedError("only the embedding-only encoder is on the link-prediction hot path")
-    if cfg["training"]["negative_sampling"]["filtered"] or cfg["evaluation"]["negative_sampling"]["filtered"]:
-        # config.cpp:365-376: filtered forces num_chunks=1, negatives=-1 (all nodes)
-        warnings.warn("filtered negative sampling: evaluation scores against all nodes; the global true-edge filter is a 'next' row")
+    # filtered (config.cpp:365-376): num_chunks = 1, negatives = -1 (every node), scores of true edges masked (negative.cpp:212-311);
+    # for evaluation marius_train sorts train + validation + test edges (GraphModelStorage::sortAllEdges)
+    if cfg["training"]["negative_sampling"]["filtered"]:
+        raise NotImplementedError("filtered negative sampling during training is not on the path (the reference's examples train unfiltered)")
     if not cfg["training"]["pipeline"].get("sync", True):
         warnings.warn("async pipeline is out of scope; running the synchronous trainer")
     if cfg["storage"]["model_dir"] is None:

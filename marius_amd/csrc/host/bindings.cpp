@@ -55,7 +55,11 @@ PYBIND11_MODULE(_marius_host, m) {
                  return g;
              }),
              py::arg("num_nodes_in_memory"))
-        .def_readwrite("num_nodes_in_memory", &MariusGraph::num_nodes_in_memory_);
+        .def_readwrite("num_nodes_in_memory", &MariusGraph::num_nodes_in_memory_)
+        .def_readwrite("all_src_sorted_edges", &MariusGraph::all_src_sorted_edges_)
+        .def_readwrite("all_dst_sorted_edges", &MariusGraph::all_dst_sorted_edges_)
+        .def("sortAllEdges", &MariusGraph::sortAllEdges, py::arg("all_edges"));
+    m.def("compute_filter_corruption_global", &compute_filter_corruption_global, py::arg("graph"), py::arg("edges"), py::arg("inverse"));
 
     py::class_<CorruptNodeNegativeSampler, std::shared_ptr<CorruptNodeNegativeSampler>>(m, "CorruptNodeNegativeSampler")
         .def(py::init<int, int, float, bool, LocalFilterMode, std::shared_ptr<MariusGenerator>>(), py::arg("num_chunks") = 1, py::arg("num_negatives") = 500,
@@ -163,6 +167,8 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("train_batch", &Model::train_batch, py::arg("batch"), py::arg("call_step") = true)
         .def("evaluate_batch", &Model::evaluate_batch)
         .def("setup_optimizers", &Model::setup_optimizers, py::arg("dense_lr"))
+        .def("setup_optimizer", &Model::setup_optimizer, py::arg("type"), py::arg("lr"), py::arg("eps") = 1e-10f, py::arg("beta_1") = 0.9f,
+             py::arg("beta_2") = 0.999f, py::arg("weight_decay") = 0.f, py::arg("amsgrad") = false)
         .def("step", &Model::step)
         .def("clear_grad", &Model::clear_grad)
         .def_readwrite("sparse_lr", &Model::sparse_lr_)
@@ -183,6 +189,7 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("loadGPUParameters", &DataLoader::loadGPUParameters)
         .def("updateEmbeddings", &DataLoader::updateEmbeddings, py::arg("batch"), py::arg("gpu") = true)
         .def("getNumEdges", &DataLoader::getNumEdges)
+        .def_readonly("graph", &DataLoader::graph_)
         .def_readonly("active_perm", &DataLoader::active_perm_)
         .def_readonly("num_unique", &DataLoader::count_);
 
@@ -195,5 +202,6 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_readonly("last_edges_per_second", &SynchronousTrainer::last_edges_per_second_);
     py::class_<SynchronousEvaluator, std::shared_ptr<SynchronousEvaluator>>(m, "SynchronousEvaluator")
         .def(py::init<std::shared_ptr<DataLoader>, std::shared_ptr<Model>>())
+        .def_readonly("dataloader", &SynchronousEvaluator::dataloader_)
         .def("evaluate", &SynchronousEvaluator::evaluate);
 }

@@ -267,9 +267,9 @@ std::tuple<Tensor, Tensor> CorruptNodeNegativeSampler::getNegatives(shared_ptr<M
     require_device(edges, "getNegatives");
     auto dev = edges.device();
     const int64_t num_nodes = graph->num_nodes_in_memory_;
-    if (num_negatives_ == -1) {  // filtered evaluation: all nodes (negative.cpp:354-356); global filter construction is the "next" row
+    if (num_negatives_ == -1) {  // filtered evaluation: every node is a negative (negative.cpp:354-356), true edges are masked
         Tensor ids = torch::arange(num_nodes, i64(dev)).unsqueeze(0);
-        return std::forward_as_tuple(ids, torch::empty({0, 2}, i64(dev)));
+        return std::forward_as_tuple(ids, compute_filter_corruption_global(graph, edges, inverse));
     }
     const int n_deg = (int)(num_negatives_ * degree_fraction_);
     const int64_t B = edges.size(0);
@@ -288,6 +288,45 @@ std::tuple<Tensor, Tensor> CorruptNodeNegativeSampler::getNegatives(shared_ptr<M
         throw MariusRuntimeException("Local filtering against all edges in the batch not yet supported on GPU.");  // negative.cpp:301
     }
     return std::forward_as_tuple(ids, filter);
+}
+
+void MariusGraph::sortAllEdges(Tensor all_edges) {  // graph.cpp:233-236
+    all_src_sorted_edges_ = all_edges.index_select(0, all_edges.select(1, 0).argsort(0, false)).to(torch::kInt64);
+    all_dst_sorted_edges_ = all_edges.index_select(0, all_edges.select(1, -1).argsort(0, false)).to(torch::kInt64);
+}
+
+// negative.cpp:212-293, global branch: plain libtorch tensor ops in the reference too (searchsorted / repeat_interleave / masked_select)
+Tensor compute_filter_corruption_global(shared_ptr<MariusGraph> graph, Tensor edges, bool inverse) {
+    if (edges.dim() == 3) edges = edges.flatten(0, 1);
+    else if (edges.dim() != 2) throw TensorSizeMismatchException(edges, "Edge list must have three (if chunked) or two dimensions");
+    bool has_relations;
+    if (edges.size(-1) == 3) has_relations = true;
+    else if (edges.size(-1) == 2) has_relations = false;
+    else throw TensorSizeMismatchException(edges, "Edge list tensor must have 3 or 2 columns.");
+    Tensor all_sorted_edges = inverse ? graph->all_dst_sorted_edges_ : graph->all_src_sorted_edges_;
+    if (!all_sorted_edges.defined()) throw MariusRuntimeException("filtered evaluation needs MariusGraph::sortAllEdges (all known edges) first");
+    const int tup_id = inverse ? (has_relations ? 2 : 1) : 0;
+    const int corrupt_id = inverse ? 0 : (has_relations ? 2 : 1);
+    Tensor nodes = edges.select(1, tup_id).contiguous();
+    Tensor all_sorted_nodes = all_sorted_edges.select(1, tup_id).contiguous();
+    Tensor starts = torch::searchsorted(all_sorted_nodes, nodes);
+    Tensor ends = torch::searchsorted(all_sorted_nodes, nodes + 1);
+    Tensor num_neighbors = ends - starts;
+    Tensor summed = num_neighbors.cumsum(0);
+    Tensor local_offsets = summed - num_neighbors;
+    Tensor repeated_starts = starts.repeat_interleave(num_neighbors);
+    Tensor repeated_offsets = local_offsets.repeat_interleave(num_neighbors);
+    Tensor arange = torch::arange(repeated_offsets.size(0), edges.options());
+    Tensor sorted_list_idx = repeated_starts + arange - repeated_offsets;
+    Tensor batch_neighbors = all_sorted_edges.index_select(0, sorted_list_idx);
+    Tensor edge_ids = torch::arange(edges.size(0), edges.options()).repeat_interleave(num_neighbors);
+    if (has_relations) {
+        Tensor rel_ids = edges.select(1, 1).repeat_interleave(num_neighbors);
+        Tensor mask = batch_neighbors.select(1, 1) == rel_ids;
+        Tensor keep = torch::arange(edge_ids.size(0), edge_ids.options()).masked_select(mask);
+        return torch::stack({edge_ids.index_select(0, keep), batch_neighbors.select(1, corrupt_id).index_select(0, keep)}, 1).contiguous();
+    }
+    return torch::stack({edge_ids, batch_neighbors.select(1, corrupt_id)}, 1).contiguous();
 }
 
 // ------------------------------------------------------------------------------------------------ batch
@@ -552,6 +591,27 @@ void AdagradOptimizer::step() {  // optim.cpp:114-145
         mcheck(marius_dense_adagrad_step(fp(params_[i].first), fp(state_[i]), fp(params_[i].second), params_[i].first.numel(), learning_rate_, eps_,
                                          weight_decay_, cur_stream()));
 }
+AdamOptimizer::AdamOptimizer(std::vector<std::pair<Tensor, Tensor>> params, float lr, float eps, float beta_1, float beta_2, float weight_decay, bool amsgrad) {
+    params_ = std::move(params);
+    learning_rate_ = lr;
+    eps_ = eps;
+    beta_1_ = beta_1;
+    beta_2_ = beta_2;
+    weight_decay_ = weight_decay;
+    amsgrad_ = amsgrad;
+    for (auto& pg : params_) {  // reset_state (optim.cpp:160-184)
+        state_.push_back(torch::zeros_like(pg.first));
+        exp_avg_sq_.push_back(torch::zeros_like(pg.first));
+        if (amsgrad_) max_exp_avg_sq_.push_back(torch::zeros_like(pg.first));
+    }
+}
+void AdamOptimizer::step() {  // optim.cpp:186-232
+    for (size_t i = 0; i < params_.size(); ++i)
+        mcheck(marius_dense_adam_step(fp(params_[i].first), fp(state_[i]), fp(exp_avg_sq_[i]), amsgrad_ ? fp(max_exp_avg_sq_[i]) : nullptr,
+                                      fp(params_[i].second), params_[i].first.numel(), learning_rate_, beta_1_, beta_2_, eps_, weight_decay_, num_steps_,
+                                      cur_stream()));
+    num_steps_++;
+}
 SGDOptimizer::SGDOptimizer(std::vector<std::pair<Tensor, Tensor>> params, float lr) {
     params_ = std::move(params);
     learning_rate_ = lr;
@@ -590,6 +650,22 @@ void Model::setup_optimizers(float dense_lr) {
     if (decoder_->relations_.defined()) params.emplace_back(decoder_->relations_, relations_grad_);
     if (decoder_->inverse_relations_.defined()) params.emplace_back(decoder_->inverse_relations_, inverse_relations_grad_);
     optimizers_ = {std::make_shared<AdagradOptimizer>(params, dense_lr)};
+}
+void Model::setup_optimizer(const std::string& type, float lr, float eps, float beta_1, float beta_2, float weight_decay, bool amsgrad) {
+    std::vector<std::pair<Tensor, Tensor>> params;
+    if (decoder_->relations_.defined()) params.emplace_back(decoder_->relations_, relations_grad_);
+    if (decoder_->inverse_relations_.defined()) params.emplace_back(decoder_->inverse_relations_, inverse_relations_grad_);
+    if (type == "ADAGRAD") {
+        auto o = std::make_shared<AdagradOptimizer>(params, lr, eps);
+        o->weight_decay_ = weight_decay;
+        optimizers_ = {o};
+    } else if (type == "ADAM") {
+        optimizers_ = {std::make_shared<AdamOptimizer>(params, lr, eps, beta_1, beta_2, weight_decay, amsgrad)};
+    } else if (type == "SGD") {
+        optimizers_ = {std::make_shared<SGDOptimizer>(params, lr)};
+    } else {
+        throw MariusRuntimeException("Unrecognized optimizer type: " + type);
+    }
 }
 void Model::clear_grad() {
     for (auto& o : optimizers_) o->clear_grad();

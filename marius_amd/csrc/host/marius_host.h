@@ -124,9 +124,16 @@ class InMemory : public Storage {
 };
 
 // ------------------------------------------------------------------------------------------------ graph stub + samplers
-struct MariusGraph {  // only the field the LP sampler reads (graph.h: num_nodes_in_memory_)
+struct MariusGraph {  // the fields the LP sampler reads (graph.h)
     int64_t num_nodes_in_memory_ = 0;
+    // every known edge (train + validation + test [+ filter edges]) sorted by source / by destination, int64: the "true edge" lookup
+    // of filtered evaluation (graph.cpp:233-236; assembled by GraphModelStorage::sortAllEdges, graph_storage.cpp:745-777)
+    Tensor all_src_sorted_edges_, all_dst_sorted_edges_;
+    void sortAllEdges(Tensor all_edges);
 };
+// compute_filter_corruption, global (filtered-evaluation) branch, negative.cpp:212-293: (edge_id, node) pairs of every true edge that
+// shares the uncorrupted endpoint (and the relation) with batch edge edge_id; apply_score_filter sets those scores to -1e9
+Tensor compute_filter_corruption_global(shared_ptr<MariusGraph> graph, Tensor edges, bool inverse);
 
 class NegativeSampler {
    public:
@@ -285,6 +292,16 @@ class AdagradOptimizer : public Optimizer {  // optim.cpp:82-145
     AdagradOptimizer(std::vector<std::pair<Tensor, Tensor>> params, float lr, float eps = 1e-10f, float init_value = 0.f);
     void step() override;
 };
+class AdamOptimizer : public Optimizer {  // optim.cpp:147-232
+   public:
+    float eps_ = 1e-8f, beta_1_ = 0.9f, beta_2_ = 0.999f, weight_decay_ = 0.f;
+    bool amsgrad_ = false;
+    int64_t num_steps_ = 0;
+    std::vector<Tensor> exp_avg_sq_, max_exp_avg_sq_;  // state_ holds exp_avg
+    AdamOptimizer(std::vector<std::pair<Tensor, Tensor>> params, float lr, float eps = 1e-8f, float beta_1 = 0.9f, float beta_2 = 0.999f,
+                  float weight_decay = 0.f, bool amsgrad = false);
+    void step() override;
+};
 class SGDOptimizer : public Optimizer {  // optim.cpp:59-79
    public:
     SGDOptimizer(std::vector<std::pair<Tensor, Tensor>> params, float lr);
@@ -327,6 +344,8 @@ class Model {
     void clear_grad();
     void step();
     void setup_optimizers(float dense_lr);
+    // dense optimizer by name (ModelConfig::dense_optimizer, model.cpp:381-440): "ADAGRAD", "ADAM" or "SGD"
+    void setup_optimizer(const std::string& type, float lr, float eps, float beta_1, float beta_2, float weight_decay, bool amsgrad);
     // fused tail used by the trainer for DEVICE_MEMORY tables: backward products -> table/state update in one call
     void backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor state);
 };

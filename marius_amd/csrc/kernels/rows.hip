@@ -4,6 +4,8 @@
 // ids int64 ascending (map_tensors returns them sorted) so consecutive workgroups walk monotone addresses.
 // A row of d floats is moved as 16/8/4-byte pieces by TX adjacent lanes (TX = pow2 >= d/VEC, <= 64), TY rows per
 // workgroup pass, UNROLL passes in flight per thread so that >= UNROLL independent loads are outstanding per lane.
+#include <cmath>
+
 #include "common.h"
 
 namespace marius {
@@ -123,6 +125,33 @@ __global__ __launch_bounds__(256) void dense_adagrad_kernel(float* __restrict__ 
     }
 }
 
+// optim.cpp:186-232 (AdamOptimizer::step), same op order: g' = g + wd*w; m = m*b1 + g'*(1-b1); v = v*b2 + (1-b2)*g'*g';
+// denom = sqrt(max_v or v) / sqrt(bc2) + eps; w += -(lr / bc1) * (m / denom)
+__global__ __launch_bounds__(256) void dense_adam_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v, float* __restrict__ vmax,
+                                                         const float* __restrict__ grad, int64_t n, float step_size, float b1, float b2, float eps,
+                                                         float wd, float sqrt_bc2) {
+#pragma clang fp contract(off)
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+    for (; i < n; i += stride) {
+        float g = grad[i];
+        const float p = w[i];
+        if (wd != 0.f) g = g + wd * p;
+        const float mn = m[i] * b1 + g * omb1;
+        const float vn = v[i] * b2 + (omb2 * g) * g;
+        m[i] = mn;
+        v[i] = vn;
+        float vv = vn;
+        if (vmax) {
+            vv = fmaxf(vmax[i], vn);
+            vmax[i] = vv;
+        }
+        const float denom = sqrtf(vv) / sqrt_bc2 + eps;
+        w[i] = p + (-step_size) * (mn / denom);
+    }
+}
+
 static void row_geometry(int vpr, dim3& block, int& rows_per_block) {
     int tx = 1;
     while (tx < vpr && tx < 64) tx <<= 1;
@@ -221,4 +250,19 @@ extern "C" int marius_dense_adagrad_step(float* param, float* state_sum, const f
     dense_adagrad_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(param, state_sum, grad, n, lr, eps,
                                                                                      weight_decay);
     return check_launch("dense_adagrad_step");
+}
+
+extern "C" int marius_dense_adam_step(float* param, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, const float* grad, int64_t n, float lr,
+                                      float beta1, float beta2, float eps, float weight_decay, int64_t num_steps, marius_stream_t stream) {
+    MARIUS_REQUIRE(n >= 0 && num_steps >= 0, "dense_adam_step: bad sizes");
+    if (n == 0) return MARIUS_OK;
+    MARIUS_REQUIRE(param && exp_avg && exp_avg_sq && grad, "dense_adam_step: null pointer");
+    // float arithmetic as in the reference: 1 - std::pow(beta, num_steps + 1) on floats (optim.cpp:204-205)
+    const float bc1 = 1.f - std::pow(beta1, (float)(num_steps + 1));
+    const float bc2 = 1.f - std::pow(beta2, (float)(num_steps + 1));
+    int64_t blocks = cdiv(n, 256);
+    if (blocks > 8192) blocks = 8192;
+    dense_adam_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(param, exp_avg, exp_avg_sq, max_exp_avg_sq, grad, n, lr / bc1, beta1,
+                                                                                  beta2, eps, weight_decay, std::sqrt(bc2));
+    return check_launch("dense_adam_step");
 }

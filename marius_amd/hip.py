@@ -53,6 +53,7 @@ SIGNATURES = {
     "marius_scatter_add_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
     "marius_adagrad_rule": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp]),
     "marius_dense_adagrad_step": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp]),
+    "marius_dense_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _vp]),
     "marius_mt19937_seed_host": (None, [_vp, C.c_uint64]),
     "marius_mt19937_fill_host": (None, [_vp, _vp, _i64]),
     "marius_mt19937_randperm_host": (C.c_int, [_vp, _vp, _i64]),
@@ -163,6 +164,12 @@ def dense_adagrad_step(param, state_sum, grad, lr, eps=1e-10, weight_decay=0.0):
     _dev(param)
     check(lib().marius_dense_adagrad_step(ptr(param), ptr(state_sum), ptr(grad), param.numel(), lr, eps, weight_decay, stream_ptr()),
           "dense_adagrad_step")
+
+
+def dense_adam_step(param, exp_avg, exp_avg_sq, grad, lr, num_steps, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, max_exp_avg_sq=None):
+    _dev(param)
+    check(lib().marius_dense_adam_step(ptr(param), ptr(exp_avg), ptr(exp_avg_sq), ptr(max_exp_avg_sq), ptr(grad), param.numel(), lr, beta1, beta2,
+                                       eps, weight_decay, num_steps, stream_ptr()), "dense_adam_step")
 
 
 class Generator:

@@ -50,7 +50,12 @@ def marius_train(cfg, log=print):
         raise NotImplementedError("loss %s: only SOFTMAX_CE is on the fused path" % cfg["model"]["loss"]["type"])
     loss = H.SoftmaxCrossEntropy(cfg["model"]["loss"]["options"].get("reduction", "SUM"))
     model = H.Model(decoder, loss, H.LinkPredictionReporter(), dev)
-    model.setup_optimizers(float(cfg["model"]["dense_optimizer"]["options"]["learning_rate"]))
+    dopt = cfg["model"]["dense_optimizer"]
+    o = dopt.get("options") or {}
+    dtype_ = str(dopt.get("type", "ADAGRAD")).upper()
+    # option defaults of the reference's config classes (src/python/tools/configuration/datatypes.py:54-80: Adagrad eps 1e-10; Adam eps 1e-8, betas 0.9 / 0.999)
+    model.setup_optimizer(dtype_, float(o.get("learning_rate", 0.1)), float(o.get("eps", 1e-8 if dtype_ == "ADAM" else 1e-10)),
+                          float(o.get("beta_1", 0.9)), float(o.get("beta_2", 0.999)), float(o.get("weight_decay", 0.0)), bool(o.get("amsgrad", False)))
     sp = cfg["model"].get("sparse_optimizer") or cfg["model"]["dense_optimizer"]
     model.sparse_lr = float(sp["options"]["learning_rate"])  # model.cpp:425-429: only the learning rate is read
 
@@ -77,10 +82,18 @@ def marius_train(cfg, log=print):
     loader = H.DataLoader(train_edges, emb, state, sampler(tr["negative_sampling"]), gen, int(tr["batch_size"]), True)
     trainer = H.SynchronousTrainer(loader, model)
     evals = {}
+    eval_edges = {}
     for split, key in (("validation", "num_valid"), ("test", "num_test")):
         n = int(ds.get(key, -1))
         if n > 0 and os.path.exists(_edge_file(ddir, split)):
-            evals[split] = H.SynchronousEvaluator(H.DataLoader(edges(split, n), emb, None, sampler(ev["negative_sampling"]), gen, int(ev["batch_size"]), False), model)
+            eval_edges[split] = edges(split, n)
+            evals[split] = H.SynchronousEvaluator(H.DataLoader(eval_edges[split], emb, None, sampler(ev["negative_sampling"]), gen, int(ev["batch_size"]), False), model)
+    if bool(ev["negative_sampling"].get("filtered", False)) and evals:
+        # GraphModelStorage::sortAllEdges (graph_storage.cpp:745-777): train + validation + test edges are the "true" edges a filtered
+        # ranking must not count as negatives
+        all_edges = torch.cat([train_edges.data.to(torch.int64)] + [e.data.to(torch.int64) for e in eval_edges.values()])
+        for e in evals.values():
+            e.dataloader.graph.sortAllEdges(all_edges)
 
     results = []
     for epoch in range(1, int(tr["num_epochs"]) + 1):

@@ -221,6 +221,65 @@ def dense_adagrad_step(param, grad, state_sum, lr, eps=1e-10, weight_decay=0.0, 
     param.addcdiv_(g, std, value=-clr)
 
 
+def dense_adam_step(param, grad, exp_avg, exp_avg_sq, lr, num_steps, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, max_exp_avg_sq=None):
+    """nn/optim.cpp:186-232 (AdamOptimizer::step), same tensor ops in the same order; num_steps = steps taken before this one."""
+    import math
+
+    import numpy as np
+
+    bc1 = float(np.float32(1) - np.float32(np.power(np.float32(beta1), np.float32(num_steps + 1))))
+    bc2 = float(np.float32(1) - np.float32(np.power(np.float32(beta2), np.float32(num_steps + 1))))
+    g = grad
+    if weight_decay != 0:
+        g = g.add(param, alpha=weight_decay)
+    # beta_1_ / beta_2_ are C++ floats in the reference: `1 - beta_2_` is evaluated in float (0.999f -> 0.00099998713), not in double
+    omb1 = float(np.float32(1) - np.float32(beta1))
+    omb2 = float(np.float32(1) - np.float32(beta2))
+    exp_avg.mul_(beta1).add_(g, alpha=omb1)
+    exp_avg_sq.mul_(beta2).addcmul_(g, g, value=omb2)
+    if max_exp_avg_sq is not None:
+        torch.max(max_exp_avg_sq, exp_avg_sq, out=max_exp_avg_sq)
+        denom = (max_exp_avg_sq.sqrt() / math.sqrt(bc2)).add_(eps)
+    else:
+        denom = (exp_avg_sq.sqrt() / math.sqrt(bc2)).add_(eps)
+    param.addcdiv_(exp_avg, denom, value=-(lr / bc1))
+
+
+# ----------------------------------------------------------------------------- a4 (evaluation): global score filter
+def sort_all_edges(all_edges):
+    """data/graph.cpp:233-236 (MariusGraph::sortAllEdges)"""
+    all_edges = all_edges.to(torch.int64)
+    return (all_edges.index_select(0, all_edges[:, 0].argsort()), all_edges.index_select(0, all_edges[:, -1].argsort()))
+
+
+def compute_filter_corruption_global(all_src_sorted, all_dst_sorted, edges, inverse):
+    """data/samplers/negative.cpp:50-205, global branch of compute_filter_corruption_cpu, loop for loop: for every batch edge, every known
+    edge with the same uncorrupted endpoint (and relation) contributes (edge_id, corrupted endpoint).  Returns int64 [F, 2]."""
+    has_rel = edges.size(1) == 3
+    if inverse:
+        tup_id, corrupt_id, srt = (2 if has_rel else 1), 0, all_dst_sorted
+    else:
+        tup_id, corrupt_id, srt = 0, (2 if has_rel else 1), all_src_sorted
+    nodes = edges[:, tup_id].contiguous()
+    sorted_nodes = srt[:, tup_id].contiguous()
+    starts = torch.searchsorted(sorted_nodes, nodes)
+    ends = torch.searchsorted(sorted_nodes, nodes + 1)
+    out = []
+    e_l, s_l = edges.tolist(), srt.tolist()
+    for edge_id in range(edges.size(0)):
+        for cur in range(int(starts[edge_id]), int(ends[edge_id])):
+            if (not has_rel) or s_l[cur][1] == e_l[edge_id][1]:
+                out.append((edge_id, s_l[cur][corrupt_id]))
+    return torch.tensor(out, dtype=torch.int64).reshape(-1, 2)
+
+
+def apply_score_filter(scores, flt):
+    """data/samplers/negative.cpp:306-311"""
+    if flt is not None and flt.numel() > 0:
+        scores.index_put_((flt[:, 0], flt[:, 1]), torch.tensor(-1e9, dtype=scores.dtype))
+    return scores
+
+
 # ----------------------------------------------------------------------------- a18: ranks
 def compute_ranks(pos, neg):
     """reporting/reporting.cpp:55-57"""

@@ -212,3 +212,83 @@ def test_marius_train_end_to_end(M, dev, tmp_path):
     mdir = cfg["storage"]["model_dir"]
     assert os.path.getsize(os.path.join(mdir, "embeddings.bin")) == num_nodes * 32 * 4
     assert os.path.exists(os.path.join(mdir, "embeddings_state.bin")) and os.path.exists(os.path.join(mdir, "full_config.yaml"))
+
+
+def test_marius_train_reference_example_config_shape(M, dev, tmp_path):
+    """The shape of the reference's own example (examples/configuration/fb15k_237.yaml): dense ADAM for the relation tables, filtered
+    evaluation over all nodes."""
+    from marius_amd import config as C
+    from marius_amd.marius_train import marius_train
+
+    num_nodes, R, E = 200, 3, 4000
+    g = torch.Generator().manual_seed(1)
+    src = torch.randint(num_nodes, (E,), generator=g)
+    rel = torch.randint(R, (E,), generator=g)
+    dst = (src * 5 + rel * 11 + 2) % num_nodes
+    edges = torch.stack([src, rel, dst], 1).to(torch.int32)
+    ddir = tmp_path / "ds"
+    (ddir / "edges").mkdir(parents=True)
+    edges[:3400].numpy().tofile(str(ddir / "edges" / "train_edges.bin"))
+    edges[3400:3700].numpy().tofile(str(ddir / "edges" / "validation_edges.bin"))
+    edges[3700:].numpy().tofile(str(ddir / "edges" / "test_edges.bin"))
+    yaml.safe_dump({"dataset_dir": str(ddir), "num_edges": E, "num_nodes": num_nodes, "num_relations": R, "num_train": 3400, "num_valid": 300,
+                    "num_test": 300}, open(ddir / "dataset.yaml", "w"))
+    cfg_path = tmp_path / "cfg.yaml"
+    yaml.safe_dump({
+        "model": {"learning_task": "LINK_PREDICTION", "random_seed": 2, "encoder": {"layers": [[{"type": "EMBEDDING", "output_dim": 32}]]},
+                  "decoder": {"type": "DISTMULT", "options": {"input_dim": 32}}, "loss": {"type": "SOFTMAX_CE", "options": {"reduction": "SUM"}},
+                  "dense_optimizer": {"type": "ADAM", "options": {"learning_rate": 0.1}},
+                  "sparse_optimizer": {"type": "ADAGRAD", "options": {"learning_rate": 0.1}}},
+        "storage": {"device_type": "cuda", "dataset": {"dataset_dir": str(ddir)}, "edges": {"type": "DEVICE_MEMORY"}, "embeddings": {"type": "DEVICE_MEMORY"},
+                    "save_model": True},
+        "training": {"batch_size": 200, "negative_sampling": {"num_chunks": 4, "negatives_per_positive": 50, "degree_fraction": 0.0, "filtered": False},
+                     "num_epochs": 5, "pipeline": {"sync": True}, "epochs_per_shuffle": 1},
+        "evaluation": {"batch_size": 100, "negative_sampling": {"filtered": True}, "pipeline": {"sync": True}},
+    }, open(cfg_path, "w"))
+    cfg = C.load_config(str(cfg_path))
+    res = marius_train(cfg, log=lambda *a: None)
+    assert res[-1]["validation"]["MRR"] > res[0]["validation"]["MRR"] and res[-1]["test"]["Hits@10"] > 0.2
+    assert res[-1]["validation"]["Mean Rank"] <= num_nodes  # ranks are over all nodes, true edges masked
+
+
+def test_filtered_evaluation_matches_oracle(M, dev):
+    """evaluation.negative_sampling.filtered: true — every node is a negative, true edges are masked to -1e9 before ranking
+    (negative.cpp:212-311, evaluator.cpp:58-97).  Filter pairs and ranks against the CPU restatement."""
+    num_nodes, R, d, B, E, seed = 300, 3, 16, 40, 600, 4
+    g = torch.Generator().manual_seed(seed)
+    all_edges = torch.stack([torch.randint(num_nodes, (E,), generator=g), torch.randint(R, (E,), generator=g), torch.randint(num_nodes, (E,), generator=g)], 1)
+    test_edges = all_edges[:120]
+    table = (torch.rand(num_nodes, d, generator=g) - 0.5)
+    gen = M.MariusGenerator(seed)
+    emb = M.InMemory(table.to(dev))
+    sampler = M.CorruptNodeNegativeSampler(10, 100, 0.0, True, M.LocalFilterMode.DEG, gen)  # filtered -> 1 chunk, all nodes
+    loader = M.DataLoader(M.InMemory(test_edges.to(torch.int32).to(dev)), emb, None, sampler, gen, B, False)
+    loader.graph.sortAllEdges(all_edges.to(dev))
+    src_sorted, dst_sorted = O.sort_all_edges(all_edges)
+    # filter pairs
+    for inverse in (False, True):
+        got = M.compute_filter_corruption_global(loader.graph, test_edges[:B].to(dev), inverse).cpu()
+        want = O.compute_filter_corruption_global(src_sorted, dst_sorted, test_edges[:B], inverse)
+        assert set(map(tuple, got.tolist())) == set(map(tuple, want.tolist()))
+    # ranks of a full evaluation pass
+    dec = M.DistMult(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+    rel = torch.rand(R, d, generator=g) + 0.5
+    inv = torch.rand(R, d, generator=g) + 0.5
+    dec.relations.copy_(rel.to(dev))
+    dec.inverse_relations.copy_(inv.to(dev))
+    model = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+    res = M.SynchronousEvaluator(loader, model).evaluate()
+    ranks = []
+    nodes = torch.arange(num_nodes).unsqueeze(0)
+    for b0 in range(0, test_edges.size(0), B):
+        be = test_edges[b0:b0 + B]
+        pos, neg, ipos, ineg = O.node_corrupt_forward("DISTMULT", be, table, nodes, nodes, rel, inv)
+        n = be.size(0)
+        neg = O.apply_score_filter(neg[:n].clone(), O.compute_filter_corruption_global(src_sorted, dst_sorted, be, False))
+        ineg = O.apply_score_filter(ineg[:n].clone(), O.compute_filter_corruption_global(src_sorted, dst_sorted, be, True))
+        ranks.append(O.compute_ranks(pos[:n], neg))
+        ranks.append(O.compute_ranks(ipos[:n], ineg))
+    ranks = torch.cat(ranks).double()
+    assert abs(res[0] - (1.0 / ranks).mean().item()) < 1e-6   # MRR
+    assert abs(res[1] - ranks.mean().item()) < 1e-6           # mean rank
+    assert abs(res[5] - (ranks <= 10).double().mean().item()) < 1e-9  # Hits@10

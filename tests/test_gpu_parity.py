@@ -519,3 +519,26 @@ def test_stream_k_backward_matches_plain_launch(H, dev, monkeypatch, nwg):
     torch.cuda.synchronize()
     got = W.gocc()[:, :d].cpu()
     assert (got - want).abs().max() <= 1e-5 * max(1.0, want.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------ dense Adam (optim.cpp:186-232)
+@pytest.mark.gpu
+@pytest.mark.parametrize("amsgrad,wd", [(False, 0.0), (True, 0.0), (False, 0.01)])
+def test_dense_adam_step_matches_reference_ops(H, dev, amsgrad, wd):
+    g = torch.Generator().manual_seed(5)
+    n = (37, 100)
+    p_ref = torch.randn(n, generator=g)
+    m_ref, v_ref = torch.zeros(n), torch.zeros(n)
+    vm_ref = torch.zeros(n) if amsgrad else None
+    p, m, v = p_ref.to(dev), m_ref.to(dev), v_ref.to(dev)
+    vm = vm_ref.to(dev) if amsgrad else None
+    for step in range(4):
+        grad = torch.randn(n, generator=g) * (0.1 if step != 2 else 3.0)
+        O.dense_adam_step(p_ref, grad, m_ref, v_ref, 0.1, step, weight_decay=wd, max_exp_avg_sq=vm_ref)
+        H.dense_adam_step(p, m, v, grad.to(dev), 0.1, step, weight_decay=wd, max_exp_avg_sq=vm)
+    torch.cuda.synchronize()
+    assert_close(m, m_ref, "exp_avg", rtol=1e-6)
+    assert_close(v, v_ref, "exp_avg_sq", rtol=1e-6)
+    assert_close(p, p_ref, "param", rtol=1e-5)
+    if amsgrad:
+        assert_close(vm, vm_ref, "max_exp_avg_sq", rtol=1e-6)

@@ -242,3 +242,50 @@ def test_lp_plan_validation_and_layout():
     assert b"3 or 2 column" in hip.lib().marius_hip_last_error()
     d.edge_cols, d.d = 3, 7  # ComplEx needs even d
     assert hip.lib().marius_lp_plan(C.byref(d), C.byref(lay)) != 0
+
+
+def test_global_score_filter_entries_are_exactly_the_true_edges():
+    """Property the reference's own test states (test/cpp/unit/data/samplers/test_negative.cpp:108-166): every filter entry is a real
+    edge sharing the uncorrupted endpoint and relation with its batch edge — and, for the global filter, none is missing."""
+    from oracle import lp_oracle as O
+
+    g = torch.Generator().manual_seed(3)
+    num_nodes, R, E = 40, 3, 400
+    all_edges = torch.stack([torch.randint(num_nodes, (E,), generator=g), torch.randint(R, (E,), generator=g), torch.randint(num_nodes, (E,), generator=g)], 1)
+    src_sorted, dst_sorted = O.sort_all_edges(all_edges)
+    batch = all_edges[torch.randperm(E, generator=g)[:25]]
+    truth = set(map(tuple, all_edges.tolist()))
+    for inverse in (False, True):
+        flt = O.compute_filter_corruption_global(src_sorted, dst_sorted, batch, inverse)
+        got = set()
+        for eid, node in flt.tolist():
+            s, r, d = batch[eid].tolist()
+            assert ((node, r, d) if inverse else (s, r, node)) in truth
+            got.add((eid, node))
+        want = set()
+        for eid, (s, r, d) in enumerate(batch.tolist()):
+            for (s2, r2, d2) in truth:
+                if r2 == r and ((d2 == d) if inverse else (s2 == s)):
+                    want.add((eid, s2 if inverse else d2))
+        assert got == want
+        # the batch edge itself is always filtered (its own tail / head is a true edge)
+        for eid, (s, r, d) in enumerate(batch.tolist()):
+            assert (eid, s if inverse else d) in got
+
+
+def test_oracle_adam_matches_torch_optim():
+    """oracle.dense_adam_step (restatement of optim.cpp:186-232) against torch.optim.Adam on the same gradients (float-vs-double bias
+    corrections differ in the last bits only)."""
+    from oracle import lp_oracle as O
+
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(13, 7, generator=g)
+    p_ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p_ref], lr=0.1)
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    for step in range(5):
+        grad = torch.randn(13, 7, generator=g)
+        p_ref.grad = grad.clone()
+        opt.step()
+        O.dense_adam_step(p, grad, m, v, 0.1, step)
+    assert torch.allclose(p, p_ref.detach(), rtol=2e-5, atol=1e-6)
