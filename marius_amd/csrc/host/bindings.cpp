@@ -166,6 +166,8 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("forward_lp", &Model::forward_lp, py::arg("batch"), py::arg("train") = true)
         .def("train_batch", &Model::train_batch, py::arg("batch"), py::arg("call_step") = true)
         .def("evaluate_batch", &Model::evaluate_batch)
+        .def("save", &Model::save, py::arg("directory"))
+        .def("load", &Model::load, py::arg("directory"), py::arg("train") = true)
         .def("setup_optimizers", &Model::setup_optimizers, py::arg("dense_lr"))
         .def("setup_optimizer", &Model::setup_optimizer, py::arg("type"), py::arg("lr"), py::arg("eps") = 1e-10f, py::arg("beta_1") = 0.9f,
              py::arg("beta_2") = 0.999f, py::arg("weight_decay") = 0.f, py::arg("amsgrad") = false)

@@ -577,6 +577,30 @@ Tensor SoftmaxCrossEntropy::operator()(Tensor pos, Tensor neg, bool scores) {
     return loss[0];
 }
 
+void Optimizer::save(torch::serialize::OutputArchive& archive, const std::vector<std::string>& keys) {  // optim.cpp:25-40
+    archive.write("num_steps", torch::IValue(num_steps()));
+    auto slots = state_slots();
+    for (size_t i = 0; i < keys.size() && i < params_.size(); ++i) {
+        torch::serialize::OutputArchive tmp;
+        for (auto& sl : slots) tmp.write(sl.first, (*sl.second)[i]);
+        archive.write(keys[i], tmp);
+    }
+}
+void Optimizer::load(torch::serialize::InputArchive& archive, const std::vector<std::string>& keys) {  // optim.cpp:7-23
+    torch::IValue tmp;
+    archive.read("num_steps", tmp);
+    set_num_steps(tmp.toInt());
+    auto slots = state_slots();
+    for (size_t i = 0; i < keys.size() && i < params_.size(); ++i) {
+        torch::serialize::InputArchive sub;
+        archive.read(keys[i], sub);
+        for (auto& sl : slots) {
+            Tensor t;
+            sub.read(sl.first, t);
+            (*sl.second)[i].copy_(t);
+        }
+    }
+}
 void Optimizer::clear_grad() {
     for (auto& pg : params_) pg.second.zero_();
 }
@@ -590,6 +614,7 @@ void AdagradOptimizer::step() {  // optim.cpp:114-145
     for (size_t i = 0; i < params_.size(); ++i)
         mcheck(marius_dense_adagrad_step(fp(params_[i].first), fp(state_[i]), fp(params_[i].second), params_[i].first.numel(), learning_rate_, eps_,
                                          weight_decay_, cur_stream()));
+    num_steps_++;
 }
 AdamOptimizer::AdamOptimizer(std::vector<std::pair<Tensor, Tensor>> params, float lr, float eps, float beta_1, float beta_2, float weight_decay, bool amsgrad) {
     params_ = std::move(params);
@@ -665,6 +690,53 @@ void Model::setup_optimizer(const std::string& type, float lr, float eps, float 
         optimizers_ = {std::make_shared<SGDOptimizer>(params, lr)};
     } else {
         throw MariusRuntimeException("Unrecognized optimizer type: " + type);
+    }
+}
+static std::vector<std::string> decoder_param_keys(const Model& m) {  // named_parameters() order of the decoder (distmult.cpp:21-27)
+    std::vector<std::string> k;
+    if (m.decoder_->relations_.defined()) k.push_back("relation_embeddings");
+    if (m.decoder_->inverse_relations_.defined()) k.push_back("inverse_relation_embeddings");
+    return k;
+}
+void Model::save(const std::string& directory) {  // model.cpp:82-106
+    torch::serialize::OutputArchive model_archive, state_archive;
+    // encoder_->save: GeneralEncoder registers its embedding layer as the (parameter-less) submodule "embedding:0_0" (encoder.cpp:43-45)
+    torch::serialize::OutputArchive embedding_layer;
+    model_archive.write("embedding:0_0", embedding_layer);
+    // decoder_->save: its parameters by registered name
+    if (decoder_->relations_.defined()) model_archive.write("relation_embeddings", decoder_->relations_);
+    if (decoder_->inverse_relations_.defined()) model_archive.write("inverse_relation_embeddings", decoder_->inverse_relations_);
+    const auto keys = decoder_param_keys(*this);
+    for (size_t i = 0; i < optimizers_.size(); ++i) {
+        torch::serialize::OutputArchive optim_archive;
+        optimizers_[i]->save(optim_archive, keys);
+        state_archive.write(std::to_string(i), optim_archive);
+    }
+    model_archive.save_to(directory + "model.pt");
+    state_archive.save_to(directory + "model_state.pt");
+}
+void Model::load(const std::string& directory, bool train) {  // model.cpp:108-134
+    torch::serialize::InputArchive model_archive, state_archive;
+    model_archive.load_from(directory + "model.pt");
+    const auto keys = decoder_param_keys(*this);
+    if (train) {
+        state_archive.load_from(directory + "model_state.pt");
+        for (size_t i = 0; i < optimizers_.size(); ++i) {
+            torch::serialize::InputArchive tmp;
+            state_archive.read(std::to_string(i), tmp);
+            optimizers_[i]->load(tmp, keys);
+        }
+    }
+    torch::NoGradGuard ng;
+    if (decoder_->relations_.defined()) {
+        Tensor t;
+        model_archive.read("relation_embeddings", t);
+        decoder_->relations_.copy_(t);
+    }
+    if (decoder_->inverse_relations_.defined()) {
+        Tensor t;
+        model_archive.read("inverse_relation_embeddings", t);
+        decoder_->inverse_relations_.copy_(t);
     }
 }
 void Model::clear_grad() {

@@ -280,6 +280,13 @@ class SoftmaxCrossEntropy : public LossFunction {
 class Optimizer {
    public:
     virtual ~Optimizer() = default;
+    // optim.cpp:7-40: "num_steps" + one nested archive per parameter key holding its state tensors
+    virtual void save(torch::serialize::OutputArchive& archive, const std::vector<std::string>& keys);
+    virtual void load(torch::serialize::InputArchive& archive, const std::vector<std::string>& keys);
+    virtual int64_t num_steps() const { return 0; }
+    virtual void set_num_steps(int64_t) {}
+    // (name, tensors) of the per-parameter state in the reference's naming: Adagrad {"sum"}, Adam {"exp_avg", "exp_avg_sq"[, "max_exp_avg_sq"]}
+    virtual std::vector<std::pair<std::string, std::vector<Tensor>*>> state_slots() { return {}; }
     float learning_rate_ = 0.1f;
     std::vector<std::pair<Tensor, Tensor>> params_;  // (param, grad)
     std::vector<Tensor> state_;
@@ -291,6 +298,10 @@ class AdagradOptimizer : public Optimizer {  // optim.cpp:82-145
     float eps_ = 1e-10f, weight_decay_ = 0.f;
     AdagradOptimizer(std::vector<std::pair<Tensor, Tensor>> params, float lr, float eps = 1e-10f, float init_value = 0.f);
     void step() override;
+    int64_t num_steps_ = 0;
+    int64_t num_steps() const override { return num_steps_; }
+    void set_num_steps(int64_t n) override { num_steps_ = n; }
+    std::vector<std::pair<std::string, std::vector<Tensor>*>> state_slots() override { return {{"sum", &state_}}; }
 };
 class AdamOptimizer : public Optimizer {  // optim.cpp:147-232
    public:
@@ -301,6 +312,13 @@ class AdamOptimizer : public Optimizer {  // optim.cpp:147-232
     AdamOptimizer(std::vector<std::pair<Tensor, Tensor>> params, float lr, float eps = 1e-8f, float beta_1 = 0.9f, float beta_2 = 0.999f,
                   float weight_decay = 0.f, bool amsgrad = false);
     void step() override;
+    int64_t num_steps() const override { return num_steps_; }
+    void set_num_steps(int64_t n) override { num_steps_ = n; }
+    std::vector<std::pair<std::string, std::vector<Tensor>*>> state_slots() override {
+        std::vector<std::pair<std::string, std::vector<Tensor>*>> v = {{"exp_avg", &state_}, {"exp_avg_sq", &exp_avg_sq_}};
+        if (amsgrad_) v.push_back({"max_exp_avg_sq", &max_exp_avg_sq_});
+        return v;
+    }
 };
 class SGDOptimizer : public Optimizer {  // optim.cpp:59-79
    public:
@@ -344,6 +362,10 @@ class Model {
     void clear_grad();
     void step();
     void setup_optimizers(float dense_lr);
+    // model.cpp:82-134: model.pt (encoder + decoder parameters) and model_state.pt (optimizer state) as torch::serialize archives with
+    // the reference's key structure, so a model directory written here loads in the reference and vice versa
+    void save(const std::string& directory);
+    void load(const std::string& directory, bool train);
     // dense optimizer by name (ModelConfig::dense_optimizer, model.cpp:381-440): "ADAGRAD", "ADAM" or "SGD"
     void setup_optimizer(const std::string& type, float lr, float eps, float beta_1, float beta_2, float weight_decay, bool amsgrad);
     // fused tail used by the trainer for DEVICE_MEMORY tables: backward products -> table/state update in one call

@@ -110,12 +110,15 @@ def marius_train(cfg, log=print):
                 log("%s evaluation (%.0f ms): %s" % (split, (time.time() - t0) * 1e3, ", ".join("%s: %.6f" % kv for kv in zip(names, r))))
                 rec[split] = dict(zip(names, r))
         results.append(rec)
-    if cfg["storage"].get("save_model", True):  # Checkpointer::save (checkpointer.cpp:39-54): node table + state as raw binaries
+    if cfg["storage"].get("save_model", True) and cfg["training"].get("save_model", True):
+        # Checkpointer::save (checkpointer.cpp:39-54) into model_dir: node table + optimizer state as raw binaries, model.pt / model_state.pt
+        # as torch::serialize archives with the reference's keys (Model::save, model.cpp:82-106), metadata.csv (checkpointer.cpp:104-116)
         emb.write()
         state.write()
-        torch.save({"relation_embeddings": decoder.relations.cpu(),
-                    "inverse_relation_embeddings": None if decoder.inverse_relations is None else decoder.inverse_relations.cpu()},
-                   os.path.join(mdir, "model.pt"))
+        model.save(os.path.join(mdir, ""))
+        with open(os.path.join(mdir, "metadata.csv"), "w") as f:
+            # name, num_epochs, checkpoint_id, link_prediction, has_state, has_encoded, has_model  (CheckpointMeta, checkpointer.h:12-21)
+            f.write("checkpoint\n%d\n-1\n1\n1\n%d\n1\n" % (int(tr["num_epochs"]), 1 if cfg["storage"].get("export_encoded_nodes", False) else 0))
     return results
 
 

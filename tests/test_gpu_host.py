@@ -249,6 +249,22 @@ def test_marius_train_reference_example_config_shape(M, dev, tmp_path):
     res = marius_train(cfg, log=lambda *a: None)
     assert res[-1]["validation"]["MRR"] > res[0]["validation"]["MRR"] and res[-1]["test"]["Hits@10"] > 0.2
     assert res[-1]["validation"]["Mean Rank"] <= num_nodes  # ranks are over all nodes, true edges masked
+    # model directory in the reference's layout (checkpointer.cpp:39-54, model.cpp:82-106)
+    mdir = cfg["storage"]["model_dir"]
+    assert open(os.path.join(mdir, "metadata.csv")).read().split("\n")[:7] == ["checkpoint", "5", "-1", "1", "1", "0", "1"]
+    arch = torch.jit.load(os.path.join(mdir, "model.pt"), map_location="cpu")
+    names = dict(arch.named_parameters())
+    assert set(names) == {"relation_embeddings", "inverse_relation_embeddings"} and names["relation_embeddings"].shape == (R, 32)
+    assert hasattr(arch, "embedding:0_0")
+    st = torch.jit.load(os.path.join(mdir, "model_state.pt"), map_location="cpu")
+    opt0 = getattr(st, "0")
+    assert int(opt0.num_steps) == 5 * (3400 // 200) and getattr(opt0, "relation_embeddings").exp_avg.shape == (R, 32)
+    # round trip: a fresh model loads the archives and reproduces the relation tables and the Adam state
+    dec = M.DistMult(R, 32, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+    m2 = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+    m2.setup_optimizer("ADAM", 0.1, 1e-8)
+    m2.load(os.path.join(mdir, ""), True)
+    assert torch.equal(dec.relations.cpu(), names["relation_embeddings"].detach())
 
 
 def test_filtered_evaluation_matches_oracle(M, dev):
