@@ -21,7 +21,12 @@ def _edge_file(ddir, split):
     return os.path.join(ddir, "edges", "%s_edges.bin" % split)
 
 
-def marius_train(cfg, log=print):
+METRICS = ["MRR", "Mean Rank", "Hits@1", "Hits@3", "Hits@5", "Hits@10", "Hits@50", "Hits@100"]
+
+
+def marius_train(cfg, log=print, train=True):
+    """train=True: marius_train (marius.cpp:98-163).  train=False: marius_eval (marius.cpp:165-184) — load the model directory written by a
+    training run (embeddings.bin, model.pt, metadata.csv) and evaluate the test edges once."""
     import marius_amd
 
     H = marius_amd.host()
@@ -31,8 +36,9 @@ def marius_train(cfg, log=print):
     ds = cfg["storage"]["dataset"]
     ddir, mdir = ds["dataset_dir"], cfg["storage"]["model_dir"]
     os.makedirs(mdir, exist_ok=True)
-    with open(os.path.join(mdir, "full_config.yaml"), "w") as f:
-        yaml.safe_dump(cfg, f)
+    if train:
+        with open(os.path.join(mdir, "full_config.yaml"), "w") as f:
+            yaml.safe_dump(cfg, f)
     d = C.embedding_dim(cfg)
     num_nodes, R = int(ds["num_nodes"]), int(ds.get("num_relations", 1))
     cols = 3 if R > 1 else 2  # io.cpp:42-45
@@ -66,12 +72,27 @@ def marius_train(cfg, log=print):
         return st
 
     train_edges = edges("train", ds["num_train"])
-    limit = math.sqrt(6.0 / (num_nodes + d))  # GLOROT_UNIFORM over the table shape (initialization.cpp:26-41)
-    table = torch.empty((num_nodes, d), dtype=torch.float32, device=dev).uniform_(-limit, limit)
-    emb = H.InMemory(table)
-    emb.filename = os.path.join(mdir, "embeddings.bin")
-    state = H.InMemory(torch.zeros_like(table))
-    state.filename = os.path.join(mdir, "embeddings_state.bin")
+    resume = (not train) or bool(cfg["training"].get("resume_training", False))
+    if resume:  # Checkpointer::load (checkpointer.cpp:56-74): the model directory of an earlier run
+        meta = open(os.path.join(mdir, "metadata.csv")).read().split("\n")
+        if not int(meta[6]):
+            raise RuntimeError("checkpoint in %s has no model" % mdir)
+        emb = H.InMemory(os.path.join(mdir, "embeddings.bin"), num_nodes, d, torch.float32, dev)
+        emb.load()
+        if train and int(meta[4]) and os.path.exists(os.path.join(mdir, "embeddings_state.bin")):
+            state = H.InMemory(os.path.join(mdir, "embeddings_state.bin"), num_nodes, d, torch.float32, dev)
+            state.load()
+        else:
+            state = H.InMemory(torch.zeros((num_nodes, d), dtype=torch.float32, device=dev))
+            state.filename = os.path.join(mdir, "embeddings_state.bin")
+        model.load(os.path.join(mdir, ""), train)
+    else:
+        limit = math.sqrt(6.0 / (num_nodes + d))  # GLOROT_UNIFORM over the table shape (initialization.cpp:26-41)
+        table = torch.empty((num_nodes, d), dtype=torch.float32, device=dev).uniform_(-limit, limit)
+        emb = H.InMemory(table)
+        emb.filename = os.path.join(mdir, "embeddings.bin")
+        state = H.InMemory(torch.zeros_like(table))
+        state.filename = os.path.join(mdir, "embeddings_state.bin")
 
     tr, ev = cfg["training"], cfg["evaluation"]
 
@@ -95,6 +116,18 @@ def marius_train(cfg, log=print):
         for e in evals.values():
             e.dataloader.graph.sortAllEdges(all_edges)
 
+    def run_eval(split, rec):
+        t0 = time.time()
+        r = evals[split].evaluate()
+        log("%s evaluation (%.0f ms): %s" % (split, (time.time() - t0) * 1e3, ", ".join("%s: %.6f" % kv for kv in zip(METRICS, r))))
+        rec[split] = dict(zip(METRICS, r))
+
+    if not train:  # marius_eval: evaluator->evaluate(false) = the test edges
+        rec = {}
+        if "test" in evals:
+            run_eval("test", rec)
+        return [rec]
+
     results = []
     for epoch in range(1, int(tr["num_epochs"]) + 1):
         log("################ Starting training epoch %d ################" % epoch)
@@ -103,12 +136,8 @@ def marius_train(cfg, log=print):
         log("Edges per Second: %.2f" % trainer.last_edges_per_second)  # trainer.cpp:156-159
         rec = {"epoch": epoch, "edges_per_second": trainer.last_edges_per_second}
         if epoch % int(ev.get("epochs_per_eval", 1)) == 0:
-            for split, e in evals.items():
-                t0 = time.time()
-                r = e.evaluate()
-                names = ["MRR", "Mean Rank", "Hits@1", "Hits@3", "Hits@5", "Hits@10", "Hits@50", "Hits@100"]
-                log("%s evaluation (%.0f ms): %s" % (split, (time.time() - t0) * 1e3, ", ".join("%s: %.6f" % kv for kv in zip(names, r))))
-                rec[split] = dict(zip(names, r))
+            for split in evals:
+                run_eval(split, rec)
         results.append(rec)
     if cfg["storage"].get("save_model", True) and cfg["training"].get("save_model", True):
         # Checkpointer::save (checkpointer.cpp:39-54) into model_dir: node table + optimizer state as raw binaries, model.pt / model_state.pt
@@ -122,12 +151,16 @@ def marius_train(cfg, log=print):
     return results
 
 
-def main(argv=None):
+def marius_eval(cfg, log=print):
+    return marius_train(cfg, log=log, train=False)
+
+
+def main(argv=None, train=True):
     argv = sys.argv[1:] if argv is None else argv
     if len(argv) != 1:
-        print("usage: marius_train <config.yaml>")
+        print("usage: %s <config.yaml>" % ("marius_train" if train else "marius_eval"))
         return 2
-    marius_train(C.load_config(argv[0]))
+    marius_train(C.load_config(argv[0]), train=train)
     return 0
 
 

@@ -265,6 +265,12 @@ def test_marius_train_reference_example_config_shape(M, dev, tmp_path):
     m2.setup_optimizer("ADAM", 0.1, 1e-8)
     m2.load(os.path.join(mdir, ""), True)
     assert torch.equal(dec.relations.cpu(), names["relation_embeddings"].detach())
+    # marius_eval on the saved model directory reproduces the last test metrics of the training run
+    from marius_amd.marius_train import marius_eval
+
+    ev = marius_eval(cfg, log=lambda *a: None)
+    for k in ("MRR", "Mean Rank", "Hits@10"):
+        assert abs(ev[0]["test"][k] - res[-1]["test"][k]) < 1e-9, k
 
 
 def test_filtered_evaluation_matches_oracle(M, dev):
