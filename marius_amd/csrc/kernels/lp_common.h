@@ -132,7 +132,6 @@ bool launch_scores_b6(const ScoreArgs& a, bool l2, hipStream_t st);
 bool launch_scores_a(const ScoreArgs& a, bool l2, hipStream_t st);
 // resident-operand / 16x16x4 variants (lp_res.hip): additionally d <= 128 for the score kernel
 bool launch_scores_res(const ScoreArgs& a, bool l2, hipStream_t st);
-bool launch_scores_pp(const ScoreArgs& a, bool l2, hipStream_t st);  // ping-pong persistent variant (level 3)
 bool launch_grad16(const GradArgs& a, bool l2, int which, hipStream_t st);  // which: 0 both (one launch), 1 dAdj, 2 dNeg
 size_t grad16_sk_part_bytes();
 bool launch_grad16_sk(const GradArgs& a, bool l2, float* part, hipStream_t st);  // both contractions, stream-K balanced persistent launch

@@ -889,7 +889,6 @@ static int kernel_level() {
     const char* k = getenv("MARIUS_KERNELS");
     if (k && k[0] == 'g') return 0;
     if (k && k[0] == 'f') return 1;
-    if (k && k[0] == 'p') return 3;
     return 2;
 }
 
@@ -1059,7 +1058,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     {
         ProfScope ps(PROF_LP_SCORES, st);
         const int lvl = kernel_level();
-        if (!((lvl >= 3 && launch_scores_pp(sa, l2, st)) || (lvl == 2 && scores_variant(desc, D) == 'b' && launch_scores_b6(sa, l2, st)) ||
+        if (!((lvl == 2 && scores_variant(desc, D) == 'b' && launch_scores_b6(sa, l2, st)) ||
               (lvl == 2 && scores_variant(desc, D) == 'p' && launch_scores_ap(sa, l2, st)) ||
               (lvl == 2 && scores_variant(desc, D) == 'a' && launch_scores_a(sa, l2, st)) ||
               (lvl >= 2 && launch_scores_res(sa, l2, st)) || (lvl >= 1 && launch_scores_fast(sa, l2, st)))) {

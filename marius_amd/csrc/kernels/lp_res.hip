@@ -240,224 +240,6 @@ __global__ __launch_bounds__(256, 2) void lp_scores_res_kernel(ScoreArgs a, int 
     }
 }
 
-// =========================================================================================== scores, interleaved schedule
-// Same data flow as lp_scores_res_kernel, but the non-MFMA work of the neighbouring tiles is issued BETWEEN the MFMAs of the
-// current tile: a dependent 32x32x2 MFMA chain leaves ~60 of every 64 issue cycles free, so the stores + SoftmaxCE partials of
-// tile t-1, the LDS writes of tile t+1 and the global loads of tile t+2 ride in those shadows instead of running after the
-// chain (measured before: MFMA-only 0.16 ms, stores + staging + prologue added another 0.15 ms because the two workgroups
-// of a CU move in lockstep and never hid each other's non-MFMA phases).
-template <bool L2, int NQ>
-__global__ __launch_bounds__(256, 2) void lp_scores_il_kernel(ScoreArgs a, int ngroups, int nt_per_group, int units_per_cd) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const LpDims& D = a.D;
-    int cd, unit;
-    if (!decode_block2(blockIdx.x, units_per_cd, D.C * D.ndir, cd, unit)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int dir = cd / D.C, c = cd - dir * D.C;
-    const int mt = unit / ngroups, ng = unit - mt * ngroups;
-    const int m0 = mt * R_T;
-    const int ntiles = (D.N + R_T - 1) / R_T;
-    const int nt0 = ng * nt_per_group;
-    const int T = min(nt_per_group, ntiles - nt0);
-    if (T <= 0) return;
-    const int KS = a.KS;
-    float* As = smem;
-    float* Bs0 = smem + R_T * KS;
-    float* Bs1 = Bs0 + R_T * KS;
-    const float* adj = a.adj + ((int64_t)dir * D.Bp + (int64_t)c * D.Bc) * D.d_ld;
-    const int64_t* negmap = a.negmap[dir] + (int64_t)c * D.N;
-    const int piece = tid & 31, row = tid >> 5;
-    const bool col_ok = 4 * piece < D.d;
-    const int colc = col_ok ? 4 * piece : 0;
-
-    float4 vb[8];
-    int64_t ids[8];
-    auto load_id = [&](int t, int it) {
-        const int n = (nt0 + t) * R_T + row + 8 * it;
-        ids[it] = negmap[n < D.N ? n : 0];
-    };
-    auto issue_b1 = [&](int it) { vb[it] = *reinterpret_cast<const float4*>(a.emb + ids[it] * a.emb_ld + colc); };
-    auto write_b1 = [&](float* buf, int t, int it) {
-        if (col_ok) {
-            const int n = (nt0 + t) * R_T + row + 8 * it;
-            lds_store4x(buf + (row + 8 * it) * KS + 4 * piece, mul4(vb[it], n < D.N ? 1.f : 0.f));
-        }
-    };
-
-    // ---- prologue (not interleaved: once per workgroup)
-#pragma unroll
-    for (int it = 0; it < 8; ++it) load_id(0, it);
-    {
-        float4 va[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int m = m0 + row + 8 * it;
-            va[it] = *reinterpret_cast<const float4*>(adj + (int64_t)(m < D.Bc ? m : 0) * D.d_ld + colc);
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) issue_b1(it);
-        if (col_ok) {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int m = m0 + row + 8 * it;
-                lds_store4x(As + (row + 8 * it) * KS + 4 * piece, mul4(va[it], m < D.Bc ? 1.f : 0.f));
-            }
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) write_b1(Bs0, 0, it);
-    if (T > 1) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) load_id(1, it);
-#pragma unroll
-        for (int it = 0; it < 8; ++it) issue_b1(it);
-    }
-    if (T > 2) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) load_id(2, it);
-    }
-    __syncthreads();
-
-    float* S = a.S + ((int64_t)dir * D.Bp + (int64_t)c * D.Bc) * D.n_ld;
-    const float* ap = As + (wm * 32 + l31) * KS + 2 * h;
-    const int m_row = m0 + wm * 32 + l31;
-    float xx = 0.f;
-    if (L2 && m_row < D.Bc) xx = a.x2[(int64_t)dir * D.Bp + (int64_t)c * D.Bc + m_row];
-    float run_m = -3.0e38f, run_l = 0.f;
-    float* srow = S + (int64_t)(m_row < D.Bc ? m_row : 0) * D.n_ld;
-
-    // store quad q (4 consecutive columns) of tile tp held in `accp`, and fold it into the running (max, sum exp)
-    auto store_quad = [&](const v16f& accp, int tp, int q) {
-        const int n = (nt0 + tp) * R_T + wn * 32 + 4 * h + 8 * q;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] = accp[4 * q + e];
-            if (L2) {
-#pragma clang fp contract(off)
-                const float yy = (n + e < D.N) ? a.y2[(int64_t)dir * D.C * D.N + (int64_t)c * D.N + n + e] : 0.f;
-                const float tt = (xx + yy) - 2.f * v[e];
-                v[e] = sqrtf(fmaxf(tt, 1e-8f));
-            }
-        }
-        if (m_row < D.Bc) {
-            if (n + 3 < D.N) {
-                *reinterpret_cast<float4*>(srow + n) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < D.N) srow[n + e] = v[e];
-            }
-        }
-        if (a.lse_part) {
-            float tmax = -3.0e38f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (n + e < D.N) tmax = fmaxf(tmax, v[e]);
-            const float mnew = fmaxf(run_m, tmax);
-            float sum = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (n + e < D.N) sum += __expf(v[e] - mnew);
-            run_l = run_l * __expf(run_m - mnew) + sum;
-            run_m = mnew;
-        }
-    };
-
-    v16f acc0, acc1;
-    // one tile: MFMA chain into `accc`; after every second MFMA pair one piece of the neighbours' work
-    auto tile_step = [&](int t, v16f& accc, const v16f& accp) {
-        const float* bp = ((t & 1) ? Bs1 : Bs0) + (wn * 32 + l31) * KS + 2 * h;
-        float* bnext = (t & 1) ? Bs0 : Bs1;
-        const bool has_prev = t >= 1, has_next = t + 1 < T, has_next2 = t + 2 < T, has_next3 = t + 3 < T;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accc[r] = 0.f;
-        float2 av[2], bv[2];
-        av[0] = *reinterpret_cast<const float2*>(ap);
-        bv[0] = *reinterpret_cast<const float2*>(bp);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (q + 1 < NQ) {
-                av[(q + 1) & 1] = *reinterpret_cast<const float2*>(ap + 4 * (q + 1));
-                bv[(q + 1) & 1] = *reinterpret_cast<const float2*>(bp + 4 * (q + 1));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            accc = mfma32(bv[q & 1].x, av[q & 1].x, accc);
-            accc = mfma32(bv[q & 1].y, av[q & 1].y, accc);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- shadow work: pieces 0..12 after q = 0, 2, 4, ... (NQ >= 8 gives at least 4 slots; the rest runs after the chain)
-            if ((q & 1) == 0) {
-                const int p = q >> 1;
-                if (p < 4) {
-                    if (has_prev) store_quad(accp, t - 1, p);
-                } else if (p < 12) {
-                    const int it = p - 4;
-                    if (has_next) write_b1(bnext, t + 1, it);
-                    if (has_next2) issue_b1(it);
-                } else if (p == 12) {
-                    if (has_next3) {
-#pragma unroll
-                        for (int it = 0; it < 8; ++it) load_id(t + 3, it);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // pieces that did not fit under the chain (NQ < 25)
-        constexpr int SLOTS = (NQ + 1) / 2;
-#pragma unroll
-        for (int p = SLOTS; p < 13; ++p) {
-            if (p < 4) {
-                if (has_prev) store_quad(accp, t - 1, p);
-            } else if (p < 12) {
-                const int it = p - 4;
-                if (has_next) write_b1(bnext, t + 1, it);
-                if (has_next2) issue_b1(it);
-            } else {
-                if (has_next3) {
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) load_id(t + 3, it);
-                }
-            }
-        }
-        __syncthreads();
-    };
-
-    for (int t = 0; t < T; t += 2) {
-        tile_step(t, acc0, acc1);
-        if (t + 1 < T) tile_step(t + 1, acc1, acc0);
-    }
-    // epilogue of the last tile
-    {
-        const int tl = T - 1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (tl & 1) store_quad(acc1, tl, q); else store_quad(acc0, tl, q);
-        }
-    }
-    if (a.lse_part) {
-        const float m2 = __shfl_xor(run_m, 32, 64), l2 = __shfl_xor(run_l, 32, 64);
-        const float mm = fmaxf(run_m, m2);
-        const float ll = run_l * __expf(run_m - mm) + l2 * __expf(m2 - mm);
-        float* red = smem;
-        if (h == 0) {
-            red[((wm * 2 + wn) * 32 + l31) * 2] = mm;
-            red[((wm * 2 + wn) * 32 + l31) * 2 + 1] = ll;
-        }
-        __syncthreads();
-        if (wn == 0 && h == 0 && m_row < D.Bc) {
-            const float ma = red[((wm * 2) * 32 + l31) * 2], la = red[((wm * 2) * 32 + l31) * 2 + 1];
-            const float mb = red[((wm * 2 + 1) * 32 + l31) * 2], lb = red[((wm * 2 + 1) * 32 + l31) * 2 + 1];
-            const float mx = fmaxf(ma, mb);
-            float* out = a.lse_part + ((int64_t)ng * D.ndir * D.Bp + (int64_t)dir * D.Bp + (int64_t)c * D.Bc + m_row) * 2;
-            out[0] = mx;
-            out[1] = la * __expf(ma - mx) + lb * __expf(mb - mx);
-        }
-    }
-}
-
 // =========================================================================================== scores, persistent workgroups
 // Timeline stamps of lp_scores_res_kernel (tools/timeline_scores.py) showed that a workgroup spends ~8.3k cycles per 64x64 tile
 // (3.7k of them in the MFMA chain) but ~24k cycles per 4-tile unit in launch + prologue (negative ids -> rows -> LDS is two
@@ -1731,8 +1513,6 @@ bool launch_scores_res(const ScoreArgs& a_in, bool l2, hipStream_t st) {
     const int units = mtiles * ngroups;
     const size_t lds = (size_t)3 * R_T * a.KS * sizeof(float);
     dim3 grid(xcd_grid2(units, a.D.C * a.D.ndir));
-    const char* ile = getenv("MARIUS_SCORES_IL");
-    const bool use_il = (ile && ile[0] == '1');  // interleaved-schedule experiment (measured slower)
     const char* pse = getenv("MARIUS_SCORES_PS");
     const bool use_ps = !(pse && pse[0] == '0');
     if (use_ps) {  // persistent workgroups (default)
@@ -1767,13 +1547,8 @@ bool launch_scores_res(const ScoreArgs& a_in, bool l2, hipStream_t st) {
     }
 #define SCORES_RES_LAUNCH(L2V, NQV)                                                                                                     \
     do {                                                                                                                                  \
-        if (use_il && NQV > 0) {                                                                                                          \
-            if (lds > 65536) hipFuncSetAttribute((const void*)lp_scores_il_kernel<L2V, (NQV > 0 ? NQV : 8)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            lp_scores_il_kernel<L2V, (NQV > 0 ? NQV : 8)><<<grid, dim3(256), lds, st>>>(a, ngroups, nt_per_group, units);                    \
-        } else {                                                                                                                          \
-            if (lds > 65536) hipFuncSetAttribute((const void*)lp_scores_res_kernel<L2V, NQV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            lp_scores_res_kernel<L2V, NQV><<<grid, dim3(256), lds, st>>>(a, ngroups, nt_per_group, units);                                  \
-        }                                                                                                                                 \
+        if (lds > 65536) (void)hipFuncSetAttribute((const void*)lp_scores_res_kernel<L2V, NQV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        lp_scores_res_kernel<L2V, NQV><<<grid, dim3(256), lds, st>>>(a, ngroups, nt_per_group, units);                                      \
     } while (0)
 #define SCORES_RES_DISPATCH(L2V)                          \
     do {                                                  \
@@ -1868,203 +1643,5 @@ bool launch_grad16(const GradArgs& a, bool l2, int which, hipStream_t st) {
     return true;
 }
 #undef GRAD16_DISPATCH
-
-}  // namespace marius
-
-// =========================================================================================== scores, ping-pong persistent
-// 512-thread workgroup = two 4-wave sets that run the SAME program half a period apart: while one set issues the 50 MFMAs of
-// its 64x64 tile, the other stores its previous tile and stages its next negative tile — each SIMD hosts one wave of each
-// set, so its matrix pipe always has a computing wave.  (With two independent 256-thread workgroups per CU the two ran in
-// lockstep: both staged, both multiplied, both stored together and the phases added up instead of overlapping — measured by
-// ablation: full 0.30 ms = skeleton 0.07 + MFMA 0.16 + stores 0.05 + staging 0.04.)  Workgroups are persistent: each set
-// walks a static list of (chunk, dir, row-tile, negative-tile-group) units that belong to its XCD, so the prologue latency is
-// paid once per workgroup and the loads of the next step (also across unit seams) are always in flight behind the MFMAs.
-namespace marius {
-
-struct PPDesc {
-    bool valid, new_unit;
-    int dir, c, m0, ntile;
-};
-
-template <bool L2>
-__global__ __launch_bounds__(512) void lp_scores_pp_kernel(ScoreArgs a, int ngroups, int ntpg, int units_per_cd, int wg_per_xcd) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const LpDims& D = a.D;
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // within the set
-    const int set = threadIdx.x >> 8;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int KS = a.KS;
-    float* As = smem + set * (2 * R_T * KS);
-    float* Bs = As + R_T * KS;
-    const int xcd = blockIdx.x & 7, wgx = blockIdx.x >> 3;
-    const int W = 2 * wg_per_xcd;
-    const int ncd = D.C * D.ndir;
-    const int ncd_x = (ncd - xcd + 7) / 8;
-    const int total_units = ncd_x * units_per_cd;
-    auto units_of = [&](int w) { return w < total_units ? (total_units - w + W - 1) / W : 0; };
-    const int w = wgx * 2 + set;
-    const int my_units = units_of(w);
-    const int K = max(units_of(wgx * 2), units_of(wgx * 2 + 1)) * ntpg;  // steps (both sets run the same number of phases)
-    const int ntiles = (D.N + R_T - 1) / R_T;
-
-    auto desc = [&](int k) {
-        PPDesc d;
-        const int ui = k / ntpg, ti = k - ui * ntpg;
-        d.valid = (k >= 0) && (ui < my_units);
-        const int g = w + ui * W;
-        const int cdi = g / units_per_cd, unit = g - cdi * units_per_cd;
-        const int cd = xcd + 8 * cdi;
-        d.dir = cd / D.C;
-        d.c = cd - d.dir * D.C;
-        const int mt = unit / ngroups, ng = unit - mt * ngroups;
-        d.m0 = mt * R_T;
-        d.ntile = ng * ntpg + ti;
-        d.valid = d.valid && (d.ntile < ntiles);
-        d.new_unit = (ti == 0);
-        return d;
-    };
-
-    const int piece = tid & 31, row = tid >> 5;
-    const bool col_ok = 4 * piece < D.d;
-    const int colc = col_ok ? 4 * piece : 0;
-    float4 va[8], vb[8];
-    int64_t ids[8];
-    auto load_ids = [&](const PPDesc& d) {
-        const int64_t* negmap = a.negmap[d.dir] + (int64_t)d.c * D.N;
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int n = d.ntile * R_T + row + 8 * it;
-            ids[it] = negmap[n < D.N ? n : 0];
-        }
-    };
-    auto issue_b = [&]() {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) vb[it] = *reinterpret_cast<const float4*>(a.emb + ids[it] * a.emb_ld + colc);
-    };
-    auto issue_a = [&](const PPDesc& d) {
-        const float* adj = a.adj + ((int64_t)d.dir * D.Bp + (int64_t)d.c * D.Bc) * D.d_ld;
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int m = d.m0 + row + 8 * it;
-            va[it] = *reinterpret_cast<const float4*>(adj + (int64_t)(m < D.Bc ? m : 0) * D.d_ld + colc);
-        }
-    };
-    auto write_b = [&](const PPDesc& d) {
-        if (col_ok) {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int n = d.ntile * R_T + row + 8 * it;
-                lds_store4x(Bs + (row + 8 * it) * KS + 4 * piece, mul4(vb[it], n < D.N ? 1.f : 0.f));
-            }
-        }
-    };
-    auto write_a = [&](const PPDesc& d) {
-        if (col_ok) {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int m = d.m0 + row + 8 * it;
-                lds_store4x(As + (row + 8 * it) * KS + 4 * piece, mul4(va[it], m < D.Bc ? 1.f : 0.f));
-            }
-        }
-    };
-
-    // ---- prologue: step 0 staged, ids of step 1 loaded
-    {
-        const PPDesc d0 = desc(0), d1 = desc(1);
-        if (d0.valid) {
-            load_ids(d0);
-            issue_a(d0);
-            issue_b();
-            write_a(d0);
-            write_b(d0);
-        }
-        if (d1.valid) load_ids(d1);
-    }
-    __syncthreads();
-
-    v16f acc;
-    const float* ap = As + (wm * 32 + l31) * KS + 2 * h;
-    const float* bp = Bs + (wn * 32 + l31) * KS + 2 * h;
-    const int nq = D.d >> 2;
-    const int P = 2 * K + 1;
-    for (int p = 0; p < P; ++p) {
-        if ((p & 1) == set) {
-            // ---------------- compute phase of step k; first put step k+1's rows (and step k+2's ids) in flight
-            const int k = (p - set) >> 1;
-            const PPDesc dk = desc(k), dn = desc(k + 1), d2 = desc(k + 2);
-            if (dn.valid) {
-                issue_b();
-                if (dn.new_unit) issue_a(dn);
-            }
-            if (d2.valid) load_ids(d2);
-            if (dk.valid) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 5
-                for (int q = 0; q < nq; ++q) {
-                    const float2 a2 = *reinterpret_cast<const float2*>(ap + 4 * q);
-                    const float2 b2 = *reinterpret_cast<const float2*>(bp + 4 * q);
-                    acc = mfma32(a2.x, b2.x, acc);
-                    acc = mfma32(a2.y, b2.y, acc);
-                }
-            }
-        } else if (p - 1 - set >= 0) {
-            // ---------------- memory phase after step kk: store its tile, stage step kk+1 into this set's LDS
-            const int kk = (p - 1 - set) >> 1;
-            const PPDesc dk = desc(kk), dn = desc(kk + 1);
-            if (dk.valid) {
-                float* S = a.S + ((int64_t)dk.dir * D.Bp + (int64_t)dk.c * D.Bc) * D.n_ld;
-                const int n = dk.ntile * R_T + wn * 32 + l31;
-                float yy = 0.f;
-                if (L2 && n < D.N) yy = a.y2[(int64_t)dk.dir * D.C * D.N + (int64_t)dk.c * D.N + n];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = dk.m0 + wm * 32 + acc_row(r, h);
-                    if (m < D.Bc && n < D.N) {
-                        float v = acc[r];
-                        if (L2) {
-#pragma clang fp contract(off)
-                            const float xx = a.x2[(int64_t)dk.dir * D.Bp + (int64_t)dk.c * D.Bc + m];
-                            const float tt = (xx + yy) - 2.f * v;
-                            v = sqrtf(fmaxf(tt, 1e-8f));
-                        }
-                        S[(int64_t)m * D.n_ld + n] = v;
-                    }
-                }
-            }
-            if (dn.valid) {
-                write_b(dn);
-                if (dn.new_unit) write_a(dn);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-bool launch_scores_pp(const ScoreArgs& a_in, bool l2, hipStream_t st) {
-    if (!res_ok(a_in.emb, a_in.emb_ld, a_in.D.d) || a_in.D.d > 128) return false;
-    ScoreArgs a = a_in;
-    a.KS = a.D.d + 2;
-    const int mtiles = (int)cdiv(a.D.Bc, R_T), ntiles = (int)cdiv(a.D.N, R_T);
-    const int ntpg = ntiles >= 8 ? 4 : ntiles;
-    const int ngroups = (int)cdiv(ntiles, ntpg);
-    const int units = mtiles * ngroups;
-    const int ncd = a.D.C * a.D.ndir;
-    // one persistent 512-thread workgroup per CU (32 per XCD) unless the problem is smaller than that
-    const int units_x = (int)cdiv(ncd, 8) * units;
-    int wg_per_xcd = 32;
-    if (units_x < 64) wg_per_xcd = (int)cdiv(units_x, 2);
-    const size_t lds = (size_t)4 * R_T * a.KS * sizeof(float);
-    dim3 grid((unsigned)(8 * wg_per_xcd));
-    if (l2) {
-        hipFuncSetAttribute((const void*)lp_scores_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lp_scores_pp_kernel<true><<<grid, dim3(512), lds, st>>>(a, ngroups, ntpg, units, wg_per_xcd);
-    } else {
-        hipFuncSetAttribute((const void*)lp_scores_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lp_scores_pp_kernel<false><<<grid, dim3(512), lds, st>>>(a, ngroups, ntpg, units, wg_per_xcd);
-    }
-    return true;
-}
 
 }  // namespace marius
