@@ -107,6 +107,7 @@ struct GradB6Args {
     float* gocc;
     int64_t negocc_off[2];
     int kp, nld, bld;
+    unsigned long long* dbg;  // debug only: cycle stamps (marius_debug_set_timeline + MARIUS_TIMELINE_GRADS)
     LpDims D;
 };
 
@@ -162,31 +163,40 @@ __device__ __forceinline__ void gradb6_loop(const __bf16* __restrict__ bT, int k
             if (pok[i]) *reinterpret_cast<u32x4*>(b + loff[i]) = t.v[i];
     };
     auto compute = [&](int buf, const v8bf (&aH)[2], const v8bf (&aM)[2], const v8bf (&aL)[2]) __attribute__((always_inline)) {
-        // lane reads row n = 32 t + l31, K block kb: slot (2 kb + h) ^ ((n >> 2) & 3), and (n >> 2) & 3 == (l31 >> 2) & 3 for every t
+        // lane reads row n = 32 t + l31, K block kb: slot (2 kb + h) ^ ((n >> 2) & 3), and (n >> 2) & 3 == (l31 >> 2) & 3 for every t.
+        // Two column tiles are multiplied in lock step: a v_mfma_f32_32x32x16_bf16 occupies the pipe for 32 cycles but its result is
+        // only available to a dependent MFMA after ~64 (timeline: a 48-long chain on one accumulator ran at 66 cycles per MFMA), so
+        // consecutive MFMAs must alternate between two accumulators.
         const int swz = (l31 >> 2) & 3;
         const __bf16* bp = lds + buf * BUF + l31 * GB_RS;
-        v8bf bH[2], bM[2], bL[2];
-        bH[0] = *reinterpret_cast<const v8bf*>(bp + 8 * (h ^ swz));
-        bM[0] = *reinterpret_cast<const v8bf*>(bp + 8 * (h ^ swz) + PLANE);
-        bL[0] = *reinterpret_cast<const v8bf*>(bp + 8 * (h ^ swz) + 2 * PLANE);
+        constexpr int TP = NTB >= 2 ? 2 : 1;          // tiles per step
+        constexpr int NS = (NTB / TP) * 2;            // steps: (tile pair, K block)
+        v8bf bH[2][TP], bM[2][TP], bL[2][TP];
+        auto rd = [&](int s_, int slot) __attribute__((always_inline)) {
+            const int kb2 = s_ & 1, pr = s_ >> 1;
 #pragma unroll
-        for (int it = 0; it < 2 * NTB; ++it) {
-            const int t = it >> 1, kb = it & 1;
-            const int c_ = it & 1, n_ = c_ ^ 1;
-            if (it + 1 < 2 * NTB) {
-                const int t2 = (it + 1) >> 1, kb2 = (it + 1) & 1;
-                const __bf16* q = bp + t2 * 32 * GB_RS + 8 * ((2 * kb2 + h) ^ swz);
-                bH[n_] = *reinterpret_cast<const v8bf*>(q);
-                bM[n_] = *reinterpret_cast<const v8bf*>(q + PLANE);
-                bL[n_] = *reinterpret_cast<const v8bf*>(q + 2 * PLANE);
+            for (int j = 0; j < TP; ++j) {
+                const __bf16* q = bp + (pr * TP + j) * 32 * GB_RS + 8 * ((2 * kb2 + h) ^ swz);
+                bH[slot][j] = *reinterpret_cast<const v8bf*>(q);
+                bM[slot][j] = *reinterpret_cast<const v8bf*>(q + PLANE);
+                bL[slot][j] = *reinterpret_cast<const v8bf*>(q + 2 * PLANE);
             }
-            if (GB6_ABLATE & 2) { acc[t][0] += (float)aH[kb][0] * (float)bH[c_][0] + (float)bM[c_][1] + (float)bL[c_][2]; continue; }
-            acc[t] = mfma32_bf16(aL[kb], bH[c_], acc[t]);
-            acc[t] = mfma32_bf16(aH[kb], bL[c_], acc[t]);
-            acc[t] = mfma32_bf16(aM[kb], bM[c_], acc[t]);
-            acc[t] = mfma32_bf16(aM[kb], bH[c_], acc[t]);
-            acc[t] = mfma32_bf16(aH[kb], bM[c_], acc[t]);
-            acc[t] = mfma32_bf16(aH[kb], bH[c_], acc[t]);
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const int kb = s_ & 1, pr = s_ >> 1, c_ = s_ & 1;
+            if (s_ + 1 < NS) rd(s_ + 1, c_ ^ 1);
+            if (GB6_ABLATE & 2) continue;
+#define GB6_STEP(AX, BX)                                                                  \
+    _Pragma("unroll") for (int j = 0; j < TP; ++j) acc[pr * TP + j] = mfma32_bf16(AX[kb], BX[c_][j], acc[pr * TP + j]);
+            GB6_STEP(aL, bH)
+            GB6_STEP(aH, bL)
+            GB6_STEP(aM, bM)
+            GB6_STEP(aM, bH)
+            GB6_STEP(aH, bM)
+            GB6_STEP(aH, bH)
+#undef GB6_STEP
         }
     };
 
@@ -228,11 +238,181 @@ __device__ __forceinline__ void gradb6_loop(const __bf16* __restrict__ bT, int k
     }
 }
 
+// ---- ping-pong form: an 8-wave workgroup = two groups of four waves that run the same K loop half a phase apart.  In every phase one
+// group issues the 48 MFMAs of a chunk while the other produces its next V fragments (exp2 + split), moves the next B tile to LDS
+// (group B only) and issues its loads; a workgroup barrier ends the phase.  Each SIMD hosts one wave of each group, so its matrix pipe
+// always has a computing wave and its VALU a preparing one — BF16 MFMAs and VALU overlap on gfx950 (FP32 MFMAs do not: the same
+// structure was a loss for the FP32 score kernel).  Three LDS buffers: tile c is read by group A in phase 2c and by group B in
+// phase 2c + 1 while group B writes tile c + 1 in phase 2c.
+template <int NTB, bool GROUPB, class LoadS, class MakeA>
+__device__ __forceinline__ void gradb6_pp_loop(const __bf16* __restrict__ bT, int kp, int kld, int nchunks, __bf16* lds, v16f (&acc)[NTB], LoadS loadS, MakeA makeA,
+                                               unsigned long long* dbg_base) {
+    unsigned long long* dbg = (dbg_base && blockIdx.x < 2048 && (blockIdx.x & 7) == 0 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 4))
+                                  ? dbg_base + ((size_t)(blockIdx.x >> 3) * 2 + ((threadIdx.x >> 6) ? 1 : 0)) * 64 : nullptr;
+    int dbi = 0;
+#define PSTAMP() do { if (dbg && dbi < 64) dbg[dbi++] = __builtin_readcyclecounter(); } while (0)
+    PSTAMP();
+    constexpr int NR = NTB * 32;
+    constexpr int PLANE = NR * GB_RS;
+    constexpr int BUF = 3 * PLANE;
+    constexpr int NI = (3 * NR * 4 + 255) / 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int st = tid & 255;                   // staging thread index inside group B
+    const int l31 = lane & 31, h = lane >> 5;
+    const int np = 3 * kp * 4;
+    uint32_t goff[NI];
+    int loff[NI];
+    bool pok[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int q = st + 256 * i;
+        pok[i] = q < np;
+        const int qc = pok[i] ? q : 0;
+        const int row = qc >> 2, w = qc & 3;
+        const int plane = row / kp, n = row - plane * kp;
+        goff[i] = (uint32_t)(((int64_t)plane * kp + n) * kld + 8 * w) * 2u;
+        loff[i] = plane * PLANE + n * GB_RS + 8 * (w ^ ((n >> 2) & 3));
+    }
+    struct Tile { u32x4 v[NI]; };
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(bT), 0, 3 * kp * kld * 2, 0x00020000);
+    auto issueB = [&](int ch) __attribute__((always_inline)) {
+        Tile t;
+        const int chc = ch < nchunks ? ch : nchunks - 1;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) t.v[i] = __builtin_amdgcn_raw_buffer_load_b128(brs, (int)goff[i], chc * GB_KC * 2, 0);
+        return t;
+    };
+    auto writeB = [&](int buf, Tile t) __attribute__((always_inline)) {
+        __bf16* b = lds + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (pok[i]) *reinterpret_cast<u32x4*>(b + loff[i]) = t.v[i];
+    };
+    auto compute = [&](int buf, const v8bf (&aH)[2], const v8bf (&aM)[2], const v8bf (&aL)[2]) __attribute__((always_inline)) {
+        // lane reads row n = 32 t + l31, K block kb: slot (2 kb + h) ^ ((n >> 2) & 3), and (n >> 2) & 3 == (l31 >> 2) & 3 for every t.
+        // Two column tiles are multiplied in lock step: a v_mfma_f32_32x32x16_bf16 occupies the pipe for 32 cycles but its result is
+        // only available to a dependent MFMA after ~64 (timeline: a 48-long chain on one accumulator ran at 66 cycles per MFMA), so
+        // consecutive MFMAs must alternate between two accumulators.
+        const int swz = (l31 >> 2) & 3;
+        const __bf16* bp = lds + buf * BUF + l31 * GB_RS;
+        constexpr int TP = NTB >= 2 ? 2 : 1;          // tiles per step
+        constexpr int NS = (NTB / TP) * 2;            // steps: (tile pair, K block)
+        v8bf bH[2][TP], bM[2][TP], bL[2][TP];
+        auto rd = [&](int s_, int slot) __attribute__((always_inline)) {
+            const int kb2 = s_ & 1, pr = s_ >> 1;
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const __bf16* q = bp + (pr * TP + j) * 32 * GB_RS + 8 * ((2 * kb2 + h) ^ swz);
+                bH[slot][j] = *reinterpret_cast<const v8bf*>(q);
+                bM[slot][j] = *reinterpret_cast<const v8bf*>(q + PLANE);
+                bL[slot][j] = *reinterpret_cast<const v8bf*>(q + 2 * PLANE);
+            }
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const int kb = s_ & 1, pr = s_ >> 1, c_ = s_ & 1;
+            if (s_ + 1 < NS) rd(s_ + 1, c_ ^ 1);
+            __builtin_amdgcn_sched_barrier(0);  // pin the fragment prefetch above the MFMAs of this step (hipcc otherwise sinks each read to its use)
+            if (GB6_ABLATE & 2) continue;
+#define GB6_STEP(AX, BX)                                                                  \
+    _Pragma("unroll") for (int j = 0; j < TP; ++j) acc[pr * TP + j] = mfma32_bf16(AX[kb], BX[c_][j], acc[pr * TP + j]);
+            GB6_STEP(aL, bH)
+            GB6_STEP(aH, bL)
+            GB6_STEP(aM, bM)
+            GB6_STEP(aM, bH)
+            GB6_STEP(aH, bM)
+            GB6_STEP(aH, bH)
+#undef GB6_STEP
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const int npair = (nchunks + 1) / 2;   // the loop is unrolled by two chunks (static register sets); a phantom last chunk multiplies zeros
+    v8bf cH[2], cM[2], cL[2];
+    auto s0 = loadS(0);
+    auto s1 = loadS(1);
+    if (!GROUPB) {
+        // ------------------------------------------------ group A: computes chunk c in phase 2c, prepares chunk c + 1 in phase 2c + 1
+        makeA(0, s0, cH, cM, cL);
+        s0 = loadS(2);
+        __syncthreads();
+        PSTAMP();
+        int buf = 0;
+        for (int p = 0; p < npair; ++p) {
+            const int c = 2 * p;
+            __builtin_amdgcn_s_setprio(0);
+            compute(buf, cH, cM, cL);                       // phase 2c
+            if (p < 7) PSTAMP();
+            __syncthreads();
+            if (p < 7) PSTAMP();
+            __builtin_amdgcn_s_setprio(3);
+            makeA(c + 1, s1, cH, cM, cL);                   // phase 2c + 1
+            s1 = loadS(c + 3);
+            if (p < 7) PSTAMP();
+            __syncthreads();
+            if (p < 7) PSTAMP();
+            buf = buf == 2 ? 0 : buf + 1;
+            __builtin_amdgcn_s_setprio(0);
+            compute(buf, cH, cM, cL);                       // phase 2c + 2
+            __syncthreads();
+            __builtin_amdgcn_s_setprio(3);
+            makeA(c + 2, s0, cH, cM, cL);                   // phase 2c + 3
+            s0 = loadS(c + 4);
+            __syncthreads();
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    } else {
+        // ------------------------------------------------ group B: stages the B tiles; prepares chunk c in phase 2c, computes it in phase 2c + 1
+        for (int i = st; i < 3 * 3 * (NR - kp) * 4; i += 256) {  // rows kp .. NR of every plane of the three buffers: zero, never staged
+            const int b_ = i / (3 * (NR - kp) * 4), r = i % (3 * (NR - kp) * 4);
+            const int plane = r / ((NR - kp) * 4), rr = r % ((NR - kp) * 4);
+            *reinterpret_cast<u32x4*>(lds + b_ * BUF + plane * PLANE + (kp + (rr >> 2)) * GB_RS + 8 * (rr & 3)) = (u32x4){0u, 0u, 0u, 0u};
+        }
+        Tile tb = issueB(0);
+        writeB(0, tb);
+        tb = issueB(1);
+        __syncthreads();
+        PSTAMP();
+        int buf = 0;
+        for (int p = 0; p < npair; ++p) {
+            const int c = 2 * p;
+            __builtin_amdgcn_s_setprio(3);
+            makeA(c, s0, cH, cM, cL);                       // phase 2c
+            s0 = loadS(c + 2);
+            writeB(buf == 2 ? 0 : buf + 1, tb);             // tile c + 1
+            tb = issueB(c + 2);
+            if (p < 7) PSTAMP();
+            __syncthreads();
+            if (p < 7) PSTAMP();
+            __builtin_amdgcn_s_setprio(0);
+            compute(buf, cH, cM, cL);                       // phase 2c + 1
+            if (p < 7) PSTAMP();
+            __syncthreads();
+            if (p < 7) PSTAMP();
+            buf = buf == 2 ? 0 : buf + 1;
+            __builtin_amdgcn_s_setprio(3);
+            makeA(c + 1, s1, cH, cM, cL);                   // phase 2c + 2
+            s1 = loadS(c + 3);
+            writeB(buf == 2 ? 0 : buf + 1, tb);             // tile c + 2
+            tb = issueB(c + 3);
+            __syncthreads();
+            __builtin_amdgcn_s_setprio(0);
+            compute(buf, cH, cM, cL);                       // phase 2c + 3
+            __syncthreads();
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    PSTAMP();
+#undef PSTAMP
+}
+
 struct SAdj { f32x4 v[4]; };                 // dAdj: S[m][j0 + 16 kb + 8 h .. + 7], kb = 0, 1
 struct SNeg { f32x4 s[4]; f32x4 l[4]; };     // dNeg: S[m0 + 16 kb + 8 h + e][j] (e = 0..7) and lse[m0 + 16 kb + 8 h .. + 7], kb = 0, 1
 
-template <int NTB>
-__global__ __launch_bounds__(256, 2) void lp_grad_b6_kernel(GradB6Args a, int tiles_adj, int tiles_neg) {
+template <int NTB, bool PP>
+__global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void lp_grad_b6_kernel(GradB6Args a, int tiles_adj, int tiles_neg) {
+    constexpr int TM = PP ? 256 : GB_TM;  // rows per workgroup: 32 per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     __bf16* lds = reinterpret_cast<__bf16*>(gsm);
     const LpDims& D = a.D;
@@ -262,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void lp_grad_b6_kernel(GradB6Args a, int ti
 
     if (unit < tiles_adj) {
         // ---------------- dAdj tile: rows m0 .. m0 + 127, K = negatives j
-        const int m0 = unit * GB_TM;
+        const int m0 = unit * TM;
         const int m = m0 + wave * 32 + l31;
         const bool m_ok = m < D.Bc;
         const float cexp = m_ok ? lg - a.lse[rowbase + m] * LOG2E : -INFINITY;  // -inf switches a padding row off
@@ -298,7 +478,9 @@ __global__ __launch_bounds__(256, 2) void lp_grad_b6_kernel(GradB6Args a, int ti
                 }
             }
         };
-        gradb6_loop<NTB>(bT, a.kp, a.nld, nchunks, lds, acc, loadS, makeA);
+        if (!PP) gradb6_loop<NTB>(bT, a.kp, a.nld, nchunks, lds, acc, loadS, makeA);
+        else if (wave < 4) gradb6_pp_loop<NTB, false>(bT, a.kp, a.nld, nchunks, lds, acc, loadS, makeA, a.dbg);
+        else gradb6_pp_loop<NTB, true>(bT, a.kp, a.nld, nchunks, lds, acc, loadS, makeA, a.dbg);
         // lane holds D[row = (r & 3) + 8 (r >> 2) + 4 h][col = l31] of each 32x32 tile
         float* out = a.dadj + rowbase * D.d_ld;
 #pragma unroll
@@ -312,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void lp_grad_b6_kernel(GradB6Args a, int ti
         }
     } else {
         // ---------------- dNeg tile: rows j0 .. j0 + 127 (negatives), K = batch rows m
-        const int j0 = (unit - tiles_adj) * GB_TM;
+        const int j0 = (unit - tiles_adj) * TM;
         const int j = j0 + wave * 32 + l31;
         const int jc = j < D.N ? j : 0;  // rows past N are computed on valid data and never stored
         const int nchunks = (D.Bc + GB_KC - 1) / GB_KC;
@@ -361,7 +543,9 @@ __global__ __launch_bounds__(256, 2) void lp_grad_b6_kernel(GradB6Args a, int ti
                 }
             }
         };
-        gradb6_loop<NTB>(bT, a.kp, a.bld, nchunks, lds, acc, loadS, makeA);
+        if (!PP) gradb6_loop<NTB>(bT, a.kp, a.bld, nchunks, lds, acc, loadS, makeA);
+        else if (wave < 4) gradb6_pp_loop<NTB, false>(bT, a.kp, a.bld, nchunks, lds, acc, loadS, makeA, nullptr);
+        else gradb6_pp_loop<NTB, true>(bT, a.kp, a.bld, nchunks, lds, acc, loadS, makeA, nullptr);
         float* out = a.gocc + (a.negocc_off[dir] + (int64_t)c * D.N) * D.d_ld;
 #pragma unroll
         for (int t = 0; t < NTB; ++t) {
@@ -399,13 +583,33 @@ bool launch_grad_b6(const GradArgs& ga, const void* embp, int64_t embp_plane, co
     a.kp = kp;
     a.nld = nld;
     a.bld = bld;
+    a.dbg = ga.dbg;
     a.D = D;
-    const int tiles_adj = (int)cdiv(D.Bc, GB_TM), tiles_neg = (int)cdiv(D.N, GB_TM);
+    const char* ppe = getenv("MARIUS_GB6");
+    // MARIUS_GB6=p: the ping-pong kernel (8 waves, 256-row tiles, three LDS buffers).  Measured no faster than the single-group kernel
+    // (0.47 vs 0.44 ms incl. transposes): its phase timeline shows the MFMA phase at ~60 cycles per v_mfma_f32_32x32x16_bf16 instead of 32
+    // (tools/timeline_gb6.py; tools/micro/mfma_lds_operands.hip reproduces ~46 with alternating operands) — the matrix pipe, not the
+    // overlap structure, is what falls short.
+    const bool pp = ppe && ppe[0] == 'p';
+    const int tm = pp ? 256 : GB_TM;
+    const int tiles_adj = (int)cdiv(D.Bc, tm), tiles_neg = (int)cdiv(D.N, tm);
     const int units = tiles_adj + tiles_neg;
     const unsigned grid = (unsigned)(((ncd + 7) / 8) * 8 * units);
     const int ntb = (kp + 31) / 32;
-    const size_t lds = (size_t)2 * 3 * ntb * 32 * GB_RS * sizeof(__bf16);  // 48 kB at kp = 112
-#define GB_LAUNCH(NTV) lp_grad_b6_kernel<NTV><<<dim3(grid), dim3(256), lds, st>>>(a, tiles_adj, tiles_neg)
+    const size_t lds = (size_t)(pp ? 3 : 2) * 3 * ntb * 32 * GB_RS * sizeof(__bf16);  // 48 kB / 72 kB at kp = 112
+#define GB_LAUNCH(NTV)                                                                                                              \
+    do {                                                                                                                            \
+        if (pp) {                                                                                                                   \
+            static bool attr_set = false;                                                                                           \
+            if (!attr_set && lds > 65536) {                                                                                         \
+                (void)hipFuncSetAttribute((const void*)lp_grad_b6_kernel<NTV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                attr_set = true;                                                                                                    \
+            }                                                                                                                       \
+            lp_grad_b6_kernel<NTV, true><<<dim3(grid), dim3(512), lds, st>>>(a, tiles_adj, tiles_neg);                              \
+        } else {                                                                                                                    \
+            lp_grad_b6_kernel<NTV, false><<<dim3(grid), dim3(256), lds, st>>>(a, tiles_adj, tiles_neg);                             \
+        }                                                                                                                           \
+    } while (0)
     switch (ntb) {
         case 1: GB_LAUNCH(1); break;
         case 2: GB_LAUNCH(2); break;
