@@ -237,6 +237,23 @@ class PipelinedShardedTrainer:
         self.next_fetched = 0
         self.step_index = 0
         self._pool = {}
+        self._prime_collectives()
+
+    def _prime_collectives(self):
+        """RCCL sets a collective up lazily on its first use per communicator (tens of milliseconds for the first all-reduce); the
+        relation-table averaging only happens every sync_interval steps, so without this its one-time cost lands in the middle of a run."""
+        s = self.s
+        # the averaging step itself, on the real tensors: every replica starts from the same relation tables and zero sums, so
+        # sum / world leaves them unchanged (exactly, for a power-of-two world)
+        for tt in self.backend.dense_state():
+            dist.all_reduce(tt, group=self.group)
+            tt.div_(self.world)
+        cnt = [1] * self.world
+        a2a_rows(torch.zeros((self.world, s.d), dtype=torch.float32, device=self.dev), cnt, cnt, self.group)
+        a2a_rows(torch.zeros(self.world, dtype=torch.int64, device=self.dev), cnt, cnt, self.group)
+        if self.world > 1:
+            dist.all_to_all_single(torch.zeros(self.world, dtype=torch.int64), torch.zeros(self.world, dtype=torch.int64), group=self.side_group)
+        torch.cuda.synchronize(self.dev)
 
     def _buf(self, name, n, tail, dtype):
         """[n, *tail] view of a grow-only buffer: per-step sizes vary with the number of unique ids, and a fresh torch.empty per
@@ -444,11 +461,15 @@ def run_sharded_bench(a, cfg, rank, world, dev):
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
+    H.profile_reset()
+    H.profile_enable(True, only="lp_grad_adj")  # HIP events around the dominant kernel only (one pair per step)
     t0 = time.perf_counter()
     run(a.warmup, a.steps)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
+    H.profile_enable(False)
+    prof = H.profile_read()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
@@ -465,5 +486,13 @@ def run_sharded_bench(a, cfg, rank, world, dev):
                                            if pipelined and staleness else "synchronous exchange"))},
             "positive_edges_per_s": round(pos_eps, 1), "roofline": None, "cpu_baseline": None,
         }
+        ms, cnt = prof.get("lp_grad_adj", (0.0, 0))
+        if cnt:  # rank 0's dominant kernel (both backward contractions in one launch), same accounting as the N = 1 line
+            Bp = C * math.ceil(B / C)
+            flops = 2.0 * Bp * N * d * 2 * 2
+            ach = flops / (ms / cnt * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "lp_grad_adj (dAdj + dNeg contractions, one launch; rank 0)", "bound": "mfma", "achieved": round(ach, 2),
+                               "peak": bench_mod.MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / bench_mod.MFMA_F32_PEAK_TF, 4), "traffic": None,
+                               "avg_ms": round(ms / cnt, 4)}
         print(json.dumps(out))
     dist.destroy_process_group()
