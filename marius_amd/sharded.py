@@ -441,7 +441,10 @@ def run_sharded_bench(a, cfg, rank, world, dev):
     pipelined = os.environ.get("MARIUS_SHARDED_PIPELINE", "1") != "0"
     staleness = 0
     if pipelined:
-        side_group = dist.new_group(backend="gloo")  # per-step count exchange (world integers) stays on the CPU
+        # per-step count exchange (world integers) stays on the CPU.  One node only: pin gloo to the loopback interface — its default
+        # picks the interface by resolving the hostname, which containers do not always allow
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        side_group = dist.new_group(backend="gloo")
         staleness = int(os.environ.get("MARIUS_SHARDED_STALENESS", "1"))
         trainer = PipelinedShardedTrainer(stepper, table, state, edges_all, perm, rank, world, num_nodes, sync_interval=sync_interval, side_group=side_group,
                                           staleness=staleness)
