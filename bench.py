@@ -71,6 +71,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
+        # one node: RCCL's socket bootstrap and the gloo side group over loopback (interface discovery by hostname can fail in containers)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("nccl", device_id=dev)
     assert a.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
 
