@@ -51,8 +51,8 @@ def synth_edges(num_nodes, num_relations, E, dist, device, seed=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="freebase86m", choices=sorted(WORKLOADS))
     ap.add_argument("--num-nodes", type=int, default=0, help="override the node count (smaller table for quick tests)")
     ap.add_argument("--edge-dist", default="zipf", choices=["zipf", "uniform"])
