@@ -390,33 +390,36 @@ __global__ __launch_bounds__(256) void lp_lse_merge_kernel(const float* __restri
     rowloss[row] = l - p;
 }
 
-// deterministic sum of rowloss: one block per direction -> loss[1 + dir]; lp_loss_total_kernel then writes loss[0] = lhs + rhs
-// (model.cpp:309-312)
-__global__ __launch_bounds__(1024) void lp_loss_reduce_kernel(const float* rowloss, int64_t Bp, float scale, float* loss) {
+// deterministic sum of rowloss: ONE block reduces each direction in turn -> loss[1 + dir], then loss[0] = rhs + lhs (model.cpp:309-312)
+__global__ __launch_bounds__(1024) void lp_loss_reduce_kernel(const float* rowloss, int64_t Bp, int ndir, float scale, float* loss) {
     __shared__ float red[1024];
-    const int dir = blockIdx.x;
-    const float* r = rowloss + (int64_t)dir * Bp;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int64_t i = threadIdx.x;
-    for (; i + 3 * 1024 < Bp; i += 4 * 1024) {
-        s0 += r[i];
-        s1 += r[i + 1024];
-        s2 += r[i + 2048];
-        s3 += r[i + 3072];
-    }
-    for (; i < Bp; i += 1024) s0 += r[i];
-    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    float tot[2] = {0.f, 0.f};
+    for (int dir = 0; dir < ndir; ++dir) {
+        const float* r = rowloss + (int64_t)dir * Bp;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int64_t i = threadIdx.x;
+        for (; i + 3 * 1024 < Bp; i += 4 * 1024) {
+            s0 += r[i];
+            s1 += r[i + 1024];
+            s2 += r[i + 2048];
+            s3 += r[i + 3072];
+        }
+        for (; i < Bp; i += 1024) s0 += r[i];
+        __syncthreads();  // red[] of the previous direction fully consumed
+        red[threadIdx.x] = (s0 + s1) + (s2 + s3);
         __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        tot[dir] = red[0] * scale;
     }
-    if (threadIdx.x == 0) loss[1 + dir] = red[0] * scale;
-}
-__global__ void lp_loss_total_kernel(int ndir, float* loss) {
-    if (ndir == 1) loss[2] = 0.f;
-    loss[0] = loss[1] + (ndir == 2 ? loss[2] : 0.f);
-    loss[3] = 0.f;
+    if (threadIdx.x == 0) {
+        loss[1] = tot[0];
+        loss[2] = ndir == 2 ? tot[1] : 0.f;
+        loss[0] = tot[0] + (ndir == 2 ? tot[1] : 0.f);
+        loss[3] = 0.f;
+    }
 }
 
 // =========================================================================================== backward contractions
@@ -1109,8 +1112,7 @@ extern "C" int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout
     }
     rc = check_launch("lp_lse");
     if (rc) return rc;
-    lp_loss_reduce_kernel<<<dim3(D.ndir), dim3(1024), 0, st>>>((const float*)(ws + L->rowloss[0]), D.Bp, D.gscale, (float*)(ws + L->loss));
-    lp_loss_total_kernel<<<dim3(1), dim3(1), 0, st>>>(D.ndir, (float*)(ws + L->loss));
+    lp_loss_reduce_kernel<<<dim3(1), dim3(1024), 0, st>>>((const float*)(ws + L->rowloss[0]), D.Bp, D.ndir, D.gscale, (float*)(ws + L->loss));
     return check_launch("lp_loss_reduce");
 }
 
@@ -1239,8 +1241,7 @@ extern "C" int marius_softmax_ce(const float* pos, const float* neg, int64_t row
     const int n_eff = (neg_ld % 4 == 0) ? N : 0;
     (void)n_eff;
     lp_lse_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>(neg, neg_ld, pos, rows, N, lse, rowloss);
-    lp_loss_reduce_kernel<<<dim3(1), dim3(1024), 0, st>>>(rowloss, rows, reduction == MARIUS_REDUCE_MEAN ? 1.f / (float)rows : 1.f, loss);
-    lp_loss_total_kernel<<<dim3(1), dim3(1), 0, st>>>(1, loss);
+    lp_loss_reduce_kernel<<<dim3(1), dim3(1024), 0, st>>>(rowloss, rows, 1, reduction == MARIUS_REDUCE_MEAN ? 1.f / (float)rows : 1.f, loss);
     return check_launch("softmax_ce");
 }
 
