@@ -109,6 +109,18 @@ int marius_sample_negatives(const uint32_t* raw, const int64_t* edges, int64_t B
  * Rows with -1 are ignored by marius_lp_forward's filter; dropping them yields the reference's tensor in its order. */
 int marius_deg_filter(const int64_t* deg_pos, int32_t num_chunks, int32_t num_deg, int64_t B, int64_t* out, marius_stream_t stream);
 
+/* Filtered evaluation, global filter: compute_filter_corruption  src/data/samplers/negative.cpp:50-205 (CPU) / :212-293 (GPU, libtorch ops).
+ * sorted_edges [n_sorted, cols] int64 = every known edge sorted by source (inverse = 0) or by destination (inverse = 1)
+ * (MariusGraph::sortAllEdges, src/data/graph.cpp:233-236); edges [B, cols] the batch (global ids).
+ * _offsets: counts[B] scratch, offsets[B + 1] = exclusive prefix of the number of true edges that share each batch edge's uncorrupted
+ * endpoint and relation; the caller reads offsets[B] (= F) to size the output.  _emit: filter [F, 2] = (edge id, corrupted node),
+ * ordered by edge id then by position in sorted_edges (the reference's order); apply_score_filter (negative.cpp:306-311) is
+ * marius_lp_forward's dst_filter / src_filter. */
+int marius_true_edge_filter_offsets(const int64_t* sorted_edges, int64_t n_sorted, int32_t cols, int32_t inverse, const int64_t* edges, int64_t B,
+                                    int64_t* counts, int64_t* offsets, marius_stream_t stream);
+int marius_true_edge_filter_emit(const int64_t* sorted_edges, int64_t n_sorted, int32_t cols, int32_t inverse, const int64_t* edges, int64_t B,
+                                 const int64_t* offsets, int64_t* filter, marius_stream_t stream);
+
 /* out[i, :] = edges[perm[start + i], :] cast to int64      replaces active_edges_ index_select + RandomEdgeSampler::getEdges
  * src/data/dataloader.cpp:180-182, src/data/samplers/edge.cpp:12-14.  edges_in is int32 or int64 ([E, cols]). */
 int marius_select_edges(const void* edges_in, int32_t in_is_int64, int32_t cols, const int64_t* perm, int64_t start,

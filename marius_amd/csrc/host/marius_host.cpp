@@ -295,38 +295,29 @@ void MariusGraph::sortAllEdges(Tensor all_edges) {  // graph.cpp:233-236
     all_dst_sorted_edges_ = all_edges.index_select(0, all_edges.select(1, -1).argsort(0, false)).to(torch::kInt64);
 }
 
-// negative.cpp:212-293, global branch: plain libtorch tensor ops in the reference too (searchsorted / repeat_interleave / masked_select)
+// negative.cpp:50-293, global branch.  The reference builds the pairs with a chain of libtorch ops on the GPU; here two small kernels
+// (count, emit) walk the sorted edge list per batch edge (eval_filter.hip); one 8-byte read-back sizes the output tensor.
 Tensor compute_filter_corruption_global(shared_ptr<MariusGraph> graph, Tensor edges, bool inverse) {
     if (edges.dim() == 3) edges = edges.flatten(0, 1);
     else if (edges.dim() != 2) throw TensorSizeMismatchException(edges, "Edge list must have three (if chunked) or two dimensions");
-    bool has_relations;
-    if (edges.size(-1) == 3) has_relations = true;
-    else if (edges.size(-1) == 2) has_relations = false;
-    else throw TensorSizeMismatchException(edges, "Edge list tensor must have 3 or 2 columns.");
+    if (edges.size(-1) != 3 && edges.size(-1) != 2) throw TensorSizeMismatchException(edges, "Edge list tensor must have 3 or 2 columns.");
+    require_device(edges, "compute_filter_corruption");
     Tensor all_sorted_edges = inverse ? graph->all_dst_sorted_edges_ : graph->all_src_sorted_edges_;
     if (!all_sorted_edges.defined()) throw MariusRuntimeException("filtered evaluation needs MariusGraph::sortAllEdges (all known edges) first");
-    const int tup_id = inverse ? (has_relations ? 2 : 1) : 0;
-    const int corrupt_id = inverse ? 0 : (has_relations ? 2 : 1);
-    Tensor nodes = edges.select(1, tup_id).contiguous();
-    Tensor all_sorted_nodes = all_sorted_edges.select(1, tup_id).contiguous();
-    Tensor starts = torch::searchsorted(all_sorted_nodes, nodes);
-    Tensor ends = torch::searchsorted(all_sorted_nodes, nodes + 1);
-    Tensor num_neighbors = ends - starts;
-    Tensor summed = num_neighbors.cumsum(0);
-    Tensor local_offsets = summed - num_neighbors;
-    Tensor repeated_starts = starts.repeat_interleave(num_neighbors);
-    Tensor repeated_offsets = local_offsets.repeat_interleave(num_neighbors);
-    Tensor arange = torch::arange(repeated_offsets.size(0), edges.options());
-    Tensor sorted_list_idx = repeated_starts + arange - repeated_offsets;
-    Tensor batch_neighbors = all_sorted_edges.index_select(0, sorted_list_idx);
-    Tensor edge_ids = torch::arange(edges.size(0), edges.options()).repeat_interleave(num_neighbors);
-    if (has_relations) {
-        Tensor rel_ids = edges.select(1, 1).repeat_interleave(num_neighbors);
-        Tensor mask = batch_neighbors.select(1, 1) == rel_ids;
-        Tensor keep = torch::arange(edge_ids.size(0), edge_ids.options()).masked_select(mask);
-        return torch::stack({edge_ids.index_select(0, keep), batch_neighbors.select(1, corrupt_id).index_select(0, keep)}, 1).contiguous();
-    }
-    return torch::stack({edge_ids, batch_neighbors.select(1, corrupt_id)}, 1).contiguous();
+    if (all_sorted_edges.size(1) != edges.size(1)) throw TensorSizeMismatchException(all_sorted_edges, "sorted edge list and batch edges differ in column count");
+    edges = edges.contiguous();
+    all_sorted_edges = all_sorted_edges.contiguous();
+    const int64_t B = edges.size(0);
+    auto dev = edges.device();
+    Tensor counts = torch::empty({std::max<int64_t>(B, 1)}, i64(dev)), offsets = torch::empty({B + 1}, i64(dev));
+    mcheck(marius_true_edge_filter_offsets(ip(all_sorted_edges), all_sorted_edges.size(0), (int32_t)edges.size(1), inverse ? 1 : 0, ip(edges), B, ip(counts),
+                                           ip(offsets), cur_stream()));
+    const int64_t F = offsets[B].item<int64_t>();
+    Tensor filter = torch::empty({F, 2}, i64(dev));
+    if (F > 0)
+        mcheck(marius_true_edge_filter_emit(ip(all_sorted_edges), all_sorted_edges.size(0), (int32_t)edges.size(1), inverse ? 1 : 0, ip(edges), B, ip(offsets),
+                                            ip(filter), cur_stream()));
+    return filter;
 }
 
 // ------------------------------------------------------------------------------------------------ batch

@@ -61,6 +61,8 @@ SIGNATURES = {
     "marius_negatives_raw_words": (_i64, [_i64, _i64, _i32, _i32, _i32]),
     "marius_sample_negatives": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "marius_deg_filter": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp]),
+    "marius_true_edge_filter_offsets": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "marius_true_edge_filter_emit": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
     "marius_select_edges": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _i64, _vp, _vp]),
     "marius_assemble_ids": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp]),
     "marius_remap_edges": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),

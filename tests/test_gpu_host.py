@@ -291,7 +291,14 @@ def test_filtered_evaluation_matches_oracle(M, dev):
     for inverse in (False, True):
         got = M.compute_filter_corruption_global(loader.graph, test_edges[:B].to(dev), inverse).cpu()
         want = O.compute_filter_corruption_global(src_sorted, dst_sorted, test_edges[:B], inverse)
-        assert set(map(tuple, got.tolist())) == set(map(tuple, want.tolist()))
+        assert set(map(tuple, got.tolist())) == set(map(tuple, want.tolist())) and got.size(0) == want.size(0)
+        assert torch.equal(got[:, 0], want[:, 0])  # grouped by edge id in ascending order, like the reference
+    # edge cases: an endpoint that occurs nowhere in the known edges, and an empty batch
+    lonely = torch.tensor([[num_nodes - 1, 0, num_nodes - 1]])
+    g2 = M.MariusGraph(num_nodes)
+    g2.sortAllEdges(all_edges[(all_edges[:, 0] != num_nodes - 1) & (all_edges[:, 2] != num_nodes - 1)].to(dev))
+    assert M.compute_filter_corruption_global(g2, lonely.to(dev), False).shape == (0, 2)
+    assert M.compute_filter_corruption_global(g2, lonely[:0].to(dev), True).shape == (0, 2)
     # ranks of a full evaluation pass
     dec = M.DistMult(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
     rel = torch.rand(R, d, generator=g) + 0.5
