@@ -168,33 +168,22 @@ class HipBackend:
             H.dense_adagrad_step(s.inv_rel, s.inv_rel_sum, rel_grads[1], s.dense_lr)
 
 
-class _Slot:
-    """Per-batch buffers of the pipelined trainer (a ring of four)."""
+class _NullEvent:
+    """Event stand-in for a backend without streams (the CPU test backend)."""
 
-    def __init__(self, H, B, cols, L, world, dev):
-        self.edges = torch.empty((B, cols), dtype=torch.int64, device=dev)
-        self.edges_local = torch.empty((B, cols), dtype=torch.int64, device=dev)
-        self.all_ids = torch.empty(L, dtype=torch.int64, device=dev)
-        self.um = H.UniqueMap(L, dev)
-        self.um_rel = H.UniqueMap(B, dev)   # relation ids of the batch, grouped (prepared ahead like the node map)
-        self.rel_ids = torch.empty(B, dtype=torch.int64, device=dev)
-        self.offs_dev = torch.empty(world + 1, dtype=torch.int64, device=dev)
-        self.offs_host = torch.empty(world + 1, dtype=torch.int64).pin_memory()
-        self.recv_host = torch.empty(world, dtype=torch.int64)
-        self.ready = torch.cuda.Event()     # prep stream: ids sorted, split points on their way to the host
-        self.fetched = torch.cuda.Event()   # rows of this batch have arrived
-        self.computed = torch.cuda.Event()  # per-row gradients of this batch are complete
-        self.free = torch.cuda.Event()      # owners applied this batch's gradients: every buffer of the slot is reusable
-        self.used = False
-        self.src_neg = self.dst_neg = None
-        self.filters = (None, None)
-        self.send_counts = self.recv_counts = None
-        self.U = self.nrecv = 0
-        self.emb = self.grad = self.local_ids = None
+    def record(self, stream=None):
+        pass
+
+    def synchronize(self):
+        pass
 
 
-class PipelinedShardedTrainer:
-    """sharded_step as a pipeline over HIP streams.
+class PipelineSchedule:
+    """Control flow of the pipelined / overlapped sharded step, independent of where the local work runs.
+
+    Subclasses provide the local operations (`PipelinedShardedTrainer` below: HIP kernels and HIP streams; the CPU gloo tests: the
+    oracle, no streams) — the exchange logic that only matters for world > 1 (split sizes, the order of the all-to-alls, slot reuse,
+    staleness) is this class and is therefore covered by a world-size-2 test without a GPU.
 
     staleness = 0 (synchronous, the `sync` variant of SURVEY.md 8e): exactly sharded_step — every row a batch reads carries all
     earlier updates — but the batch preparation (edge slice, negatives, sort/unique, owner split points) runs one step ahead on a
@@ -211,32 +200,193 @@ class PipelinedShardedTrainer:
 
     RING = 4
 
-    def __init__(self, stepper, shard_table, shard_state, edges_all, perm, rank, world, num_nodes, sync_interval=1, group=None,
-                 side_group=None, staleness=0, trace=None):
-        from . import hip as H
-
+    def __init__(self, rank, world, num_nodes, d, device, sync_interval=1, group=None, side_group=None, staleness=0):
         assert staleness in (0, 1)
-        self.H, self.s = H, stepper
-        self.backend = HipBackend(stepper, shard_table, shard_state)
-        self.edges_all, self.perm = edges_all, perm
-        self.rank, self.world, self.num_nodes = rank, world, num_nodes
+        self.rank, self.world, self.num_nodes, self.d = rank, world, num_nodes, d
         self.S = shard_rows(num_nodes, world)
         self.lo, _ = shard_range(num_nodes, rank, world)
         self.sync_interval = sync_interval
         self.group, self.side_group = group, side_group
         self.staleness = staleness
+        self.dev = device
+        self.next_prepared = 0
+        self.next_fetched = 0
+        self.step_index = 0
+        self._pool = {}
+        self.slots = None  # the subclass creates RING slots
+
+    # ---- hooks -----------------------------------------------------------------------------------------------------------------
+    def _on(self, which):                      # context manager: run the enclosed work on stream "main" | "xchg"
+        import contextlib
+        return contextlib.nullcontext()
+
+    def _wait(self, which, event):             # stream `which` waits for `event`
+        pass
+
+    def _record(self, event, which):
+        event.record()
+
+    def _retire_buffer(self, buf):             # a pooled buffer is being replaced while other streams may still read it
+        pass
+
+    def _prepare(self, t):                     # everything that does not read the table; ends by recording slot.ready
+        raise NotImplementedError
+
+    def _split_points(self, slot):             # host list [world + 1] of the slot's sorted unique ids (may block on slot.ready)
+        raise NotImplementedError
+
+    def _unique_ids(self, slot, U):
+        raise NotImplementedError
+
+    def _gather_local(self, local_ids, out):
+        raise NotImplementedError
+
+    def _compute(self, t):                     # forward / loss / backward of slot t: sets slot.grad [U, d], returns relation grads or None
+        raise NotImplementedError
+
+    def _apply_local(self, local_ids, grads):
+        raise NotImplementedError
+
+    def _dense_step(self, rel_grads):
+        raise NotImplementedError
+
+    def _dense_state(self):
+        raise NotImplementedError
+
+    def _loss(self):
+        raise NotImplementedError
+
+    # ---- generic part ----------------------------------------------------------------------------------------------------------
+    def _buf(self, name, n, tail, dtype):
+        """[n, *tail] view of a grow-only buffer: per-step sizes vary with the number of unique ids, and a fresh torch.empty per
+        step keeps the caching allocator splitting/merging blocks (visible as multi-100-us jitter)."""
+        b = self._pool.get(name)
+        if b is None or b.size(0) < n:
+            if b is not None:
+                self._retire_buffer(b)
+            b = torch.empty((max(n + n // 4, 1),) + tuple(tail), dtype=dtype, device=self.dev)
+            self._pool[name] = b
+        return b[:n]
+
+    def _slot(self, t):
+        return self.slots[t % self.RING]
+
+    def _prepare_through(self, t):
+        while self.next_prepared <= t:
+            self._prepare(self.next_prepared)
+            self.next_prepared += 1
+
+    # stage 2 (host + exchange stream): split sizes, then ids -> owners, rows -> requesters
+    def _fetch(self, t):
+        slot = self._slot(t)
+        offs = self._split_points(slot)  # of a batch prepared at least one step ago — no stream drains for this
+        slot.send_counts = [offs[i + 1] - offs[i] for i in range(self.world)]
+        if self.world > 1:
+            # counts travel over the CPU (gloo) group: a second RCCL communicator on another stream could share a hardware queue with
+            # the main one and order differently on different ranks; `world` integers over loopback cost less than that risk
+            recv = torch.empty(self.world, dtype=torch.int64)
+            dist.all_to_all_single(recv, torch.tensor(slot.send_counts, dtype=torch.int64), group=self.side_group)
+            slot.recv_counts = recv.tolist()
+        else:
+            slot.recv_counts = list(slot.send_counts)
+        U, nrecv, d = offs[-1], sum(slot.recv_counts), self.d
+        slot.U, slot.nrecv = U, nrecv
+        k = t % self.RING
+        with self._on("xchg"):
+            self._wait("xchg", slot.ready)
+            req_ids = a2a_rows(self._unique_ids(slot, U), slot.send_counts, slot.recv_counts, self.group, out=self._buf("req", nrecv, (), torch.int64))
+            slot.local_ids = torch.sub(req_ids, self.lo, out=self._buf("local%d" % k, nrecv, (), torch.int64))
+            rows = self._gather_local(slot.local_ids, self._buf("rows", nrecv, (d,), torch.float32))
+            slot.emb = a2a_rows(rows, slot.recv_counts, slot.send_counts, self.group, out=self._buf("emb%d" % k, U, (d,), torch.float32))
+            self._record(slot.fetched, "xchg")
+
+    def _fetch_through(self, t):
+        while self.next_fetched <= t:
+            self._prepare_through(self.next_fetched)
+            self._fetch(self.next_fetched)
+            self.next_fetched += 1
+
+    # stage 4 (exchange stream): gradients -> owners, owners dedupe across senders + Adagrad + scatter
+    def _update(self, t):
+        slot = self._slot(t)
+        with self._on("xchg"):
+            self._wait("xchg", slot.computed)
+            recv_grad = a2a_rows(slot.grad, slot.send_counts, slot.recv_counts, self.group, out=self._buf("recv_grad", slot.nrecv, (self.d,), torch.float32))
+            self._apply_local(slot.local_ids, recv_grad)
+            self._record(slot.free, "xchg")
+
+    def _dense(self, t, rel_grads):
+        if self.sync_interval <= 1:
+            for g in rel_grads:
+                if g is not None:
+                    dist.all_reduce(g, group=self.group)
+            self._dense_step(rel_grads)
+        else:
+            if rel_grads is not None:
+                self._dense_step(rel_grads)  # local step; replicas drift for at most sync_interval steps
+            if (t + 1) % self.sync_interval == 0:
+                for tt in self._dense_state():
+                    dist.all_reduce(tt, group=self.group)
+                    tt.div_(self.world)
+
+    def step(self):
+        t = self.step_index
+        self._fetch_through(t)              # no-op except on the first step
+        if self.staleness:
+            self._prepare_through(t + 2)
+            self._fetch_through(t + 1)      # rows of the next batch move while this one is scored (read before update(t))
+        else:
+            self._prepare_through(t + 1)    # next batch's preparation overlaps with this batch's compute
+        rel_grads = self._compute(t)
+        self._update(t)
+        self._dense(t, rel_grads)
+        self.step_index += 1
+        return self._loss()
+
+
+class _Slot:
+    """Per-batch buffers of the pipelined trainer (a ring of four)."""
+
+    def __init__(self, H, B, cols, L, world, dev):
+        self.edges = torch.empty((B, cols), dtype=torch.int64, device=dev)
+        self.edges_local = torch.empty((B, cols), dtype=torch.int64, device=dev)
+        self.all_ids = torch.empty(L, dtype=torch.int64, device=dev)
+        self.um = H.UniqueMap(L, dev)
+        self.um_rel = H.UniqueMap(B, dev)   # relation ids of the batch, grouped (prepared ahead like the node map)
+        self.rel_ids = torch.empty(B, dtype=torch.int64, device=dev)
+        self.offs_dev = torch.empty(world + 1, dtype=torch.int64, device=dev)
+        self.offs_host = torch.empty(world + 1, dtype=torch.int64).pin_memory()
+        self.ready = torch.cuda.Event()     # prep stream: ids sorted, split points on their way to the host
+        self.fetched = torch.cuda.Event()   # rows of this batch have arrived
+        self.computed = torch.cuda.Event()  # per-row gradients of this batch are complete
+        self.free = torch.cuda.Event()      # owners applied this batch's gradients: every buffer of the slot is reusable
+        self.used = False
+        self.src_neg = self.dst_neg = None
+        self.filters = (None, None)
+        self.send_counts = self.recv_counts = None
+        self.U = self.nrecv = 0
+        self.emb = self.grad = self.local_ids = None
+
+
+class PipelinedShardedTrainer(PipelineSchedule):
+    """PipelineSchedule over HIP streams: preparation on a prep stream, the exchange on an exchange stream (staleness 1) or the main
+    stream (staleness 0), forward / loss / backward on the main stream.  Local work = the same kernels as the single-GPU step."""
+
+    def __init__(self, stepper, shard_table, shard_state, edges_all, perm, rank, world, num_nodes, sync_interval=1, group=None,
+                 side_group=None, staleness=0, trace=None):
+        from . import hip as H
+
+        super().__init__(rank, world, num_nodes, stepper.d, shard_table.device, sync_interval, group, side_group, staleness)
+        self.H, self.s = H, stepper
+        self.backend = HipBackend(stepper, shard_table, shard_state)
+        self.edges_all, self.perm = edges_all, perm
         self.trace = trace
-        dev = shard_table.device
-        self.dev = dev
+        dev = self.dev
         self.main_stream = torch.cuda.current_stream()
         self.prep_stream = torch.cuda.Stream(device=dev)
         self.xchg_stream = torch.cuda.Stream(device=dev) if staleness else self.main_stream
         self.slots = [_Slot(H, stepper.B, stepper.edge_cols, stepper.L, world, dev) for _ in range(self.RING)]
         self.nb = edges_all.size(0) // stepper.B
-        self.next_prepared = 0
-        self.next_fetched = 0
-        self.step_index = 0
-        self._pool = {}
         self._prime_collectives()
 
     def _prime_collectives(self):
@@ -255,22 +405,24 @@ class PipelinedShardedTrainer:
             dist.all_to_all_single(torch.zeros(self.world, dtype=torch.int64), torch.zeros(self.world, dtype=torch.int64), group=self.side_group)
         torch.cuda.synchronize(self.dev)
 
-    def _buf(self, name, n, tail, dtype):
-        """[n, *tail] view of a grow-only buffer: per-step sizes vary with the number of unique ids, and a fresh torch.empty per
-        step keeps the caching allocator splitting/merging blocks (visible as multi-100-us jitter)."""
-        b = self._pool.get(name)
-        if b is None or b.size(0) < n:
-            if b is not None:  # the old block may still be read on either stream
-                b.record_stream(self.main_stream)
-                b.record_stream(self.xchg_stream)
-            b = torch.empty((max(n + n // 4, 1),) + tuple(tail), dtype=dtype, device=self.dev)
-            self._pool[name] = b
-        return b[:n]
+    # ---- hooks
+    def _stream(self, which):
+        return self.xchg_stream if which == "xchg" else self.main_stream
 
-    def _slot(self, t):
-        return self.slots[t % self.RING]
+    def _on(self, which):
+        return torch.cuda.stream(self._stream(which))
 
-    # ---- stage 1 (prep stream): everything that does not read the table
+    def _wait(self, which, event):
+        self._stream(which).wait_event(event)
+
+    def _record(self, event, which):
+        event.record(self._stream(which))
+
+    def _retire_buffer(self, buf):  # the old block may still be read on either stream
+        buf.record_stream(self.main_stream)
+        buf.record_stream(self.xchg_stream)
+
+    # stage 1 (prep stream): everything that does not read the table
     def _prepare(self, t):
         H, s = self.H, self.s
         slot = self._slot(t)
@@ -302,43 +454,17 @@ class PipelinedShardedTrainer:
                 tns.record_stream(self.main_stream)
         slot.used = True
 
-    def _prepare_through(self, t):
-        while self.next_prepared <= t:
-            self._prepare(self.next_prepared)
-            self.next_prepared += 1
+    def _split_points(self, slot):
+        slot.ready.synchronize()
+        return slot.offs_host.tolist()
 
-    # ---- stage 2 (host + exchange stream): split sizes, then ids -> owners, rows -> requesters
-    def _fetch(self, t):
-        H, s, be = self.H, self.s, self.backend
-        slot = self._slot(t)
-        slot.ready.synchronize()  # host: split points of a batch prepared at least one step ago — no stream drains for this
-        offs = slot.offs_host.tolist()
-        slot.send_counts = [offs[i + 1] - offs[i] for i in range(self.world)]
-        if self.world > 1:
-            # counts travel over the CPU (gloo) group: a second RCCL communicator on another stream could share a hardware queue with
-            # the main one and order differently on different ranks; `world` integers over loopback cost less than that risk
-            dist.all_to_all_single(slot.recv_host, torch.tensor(slot.send_counts, dtype=torch.int64), group=self.side_group)
-            slot.recv_counts = slot.recv_host.tolist()
-        else:
-            slot.recv_counts = list(slot.send_counts)
-        U, nrecv, d = offs[-1], sum(slot.recv_counts), s.d
-        slot.U, slot.nrecv = U, nrecv
-        k = t % self.RING
-        with torch.cuda.stream(self.xchg_stream):
-            self.xchg_stream.wait_event(slot.ready)
-            req_ids = a2a_rows(slot.um.uniq[:U], slot.send_counts, slot.recv_counts, self.group, out=self._buf("req", nrecv, (), torch.int64))
-            slot.local_ids = torch.sub(req_ids, self.lo, out=self._buf("local%d" % k, nrecv, (), torch.int64))
-            rows = H.gather_rows(be.table, slot.local_ids, out=self._buf("rows", nrecv, (d,), torch.float32))
-            slot.emb = a2a_rows(rows, slot.recv_counts, slot.send_counts, self.group, out=self._buf("emb%d" % k, U, (d,), torch.float32))
-            slot.fetched.record(self.xchg_stream)
+    def _unique_ids(self, slot, U):
+        return slot.um.uniq[:U]
 
-    def _fetch_through(self, t):
-        while self.next_fetched <= t:
-            self._prepare_through(self.next_fetched)
-            self._fetch(self.next_fetched)
-            self.next_fetched += 1
+    def _gather_local(self, local_ids, out):
+        return self.H.gather_rows(self.backend.table, local_ids, out=out)
 
-    # ---- stage 3 (main stream): the same forward / loss / backward kernels as the single-GPU step
+    # stage 3 (main stream): the same forward / loss / backward kernels as the single-GPU step
     def _compute(self, t):
         H, s = self.H, self.s
         slot = self._slot(t)
@@ -372,44 +498,16 @@ class PipelinedShardedTrainer:
             inv = s.inv_rel_grad
         return [s.rel_grad, inv]
 
-    # ---- stage 4 (exchange stream): gradients -> owners, owners dedupe across senders + Adagrad + scatter
-    def _update(self, t):
-        slot = self._slot(t)
-        with torch.cuda.stream(self.xchg_stream):
-            self.xchg_stream.wait_event(slot.computed)
-            recv_grad = a2a_rows(slot.grad, slot.send_counts, slot.recv_counts, self.group, out=self._buf("recv_grad", slot.nrecv, (self.s.d,), torch.float32))
-            self.backend.apply_local(slot.local_ids, recv_grad)
-            slot.free.record(self.xchg_stream)
+    def _apply_local(self, local_ids, grads):
+        self.backend.apply_local(local_ids, grads)
 
-    def _dense(self, t, rel_grads):
-        be = self.backend
-        if self.sync_interval <= 1:
-            for g in rel_grads:
-                if g is not None:
-                    dist.all_reduce(g, group=self.group)
-            be.dense_step(rel_grads)
-        else:
-            if rel_grads is not None:
-                be.dense_step(rel_grads)  # local step; replicas drift for at most sync_interval steps
-            if (t + 1) % self.sync_interval == 0:
-                for tt in be.dense_state():
-                    dist.all_reduce(tt, group=self.group)
-                    tt.div_(self.world)
+    def _dense_step(self, rel_grads):
+        self.backend.dense_step(rel_grads)
 
-    def step(self):
-        t = self.step_index
-        self._fetch_through(t)              # no-op except on the first step
-        if self.staleness:
-            self._prepare_through(t + 2)
-            self._fetch_through(t + 1)      # rows of the next batch move while this one is scored (read before update(t))
-            rel_grads = self._compute(t)
-            self._update(t)
-        else:
-            self._prepare_through(t + 1)    # next batch's preparation overlaps with this batch's compute
-            rel_grads = self._compute(t)
-            self._update(t)
-        self._dense(t, rel_grads)
-        self.step_index += 1
+    def _dense_state(self):
+        return self.backend.dense_state()
+
+    def _loss(self):
         return self.s.W.loss_values()[0]
 
     def finish(self):

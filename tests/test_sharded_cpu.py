@@ -92,9 +92,10 @@ def worker(rank, world, port, outdir, sync_interval=1):
     dist.destroy_process_group()
 
 
-def simulate(cfg, world=2):
+def simulate(cfg, world=2, staleness=0):
     """Single process: every 'rank' gathers from the same table state, gradients are summed per node over all ranks'
-    batches, Adagrad is applied once; relation gradients are summed (all-reduce) before the dense step."""
+    batches, Adagrad is applied once; relation gradients are summed (all-reduce) before the dense step.
+    staleness = 1: the rows of batch s are read BEFORE the update of batch s-1 is applied (after the update of s-2)."""
     table, edges = make_inputs(cfg)
     state = torch.zeros_like(table)
     steppers, gens = [], []
@@ -109,19 +110,32 @@ def simulate(cfg, world=2):
         torch.manual_seed(cfg["seed"] + r)
         rng_states.append(torch.get_rng_state())
     losses = [[] for _ in range(world)]
+
+    def prepare(r, s):
+        torch.set_rng_state(rng_states[r])
+        batch = edges[r][s * cfg["B"]:(s + 1) * cfg["B"]]
+        src_neg, _ = steppers[r].get_negatives(batch, True)
+        dst_neg, _ = steppers[r].get_negatives(batch, False)
+        rng_states[r] = torch.get_rng_state()
+        uniq, mapped = O.map_tensors([batch[:, 0], batch[:, -1], src_neg.flatten(), dst_neg.flatten()])
+        el = torch.stack([mapped[0], batch[:, 1], mapped[1]]).transpose(0, 1)
+        return uniq, el, mapped[3].reshape(dst_neg.shape), mapped[2].reshape(src_neg.shape)
+
+    def fetch(s):
+        got = [prepare(r, s) for r in range(world)]
+        return [g + (O.index_read(table, g[0]),) for g in got]
+
+    ahead = fetch(0) if staleness else None
     for s in range(cfg["steps"]):
         all_ids, all_g, rg, ig = [], [], torch.zeros_like(rel), torch.zeros_like(inv)
+        if staleness:
+            cur = ahead
+            ahead = fetch(s + 1) if s + 1 < cfg["steps"] else None  # read before this step's update lands
+        else:
+            cur = fetch(s)
         for r in range(world):
-            torch.set_rng_state(rng_states[r])
-            batch = edges[r][s * cfg["B"]:(s + 1) * cfg["B"]]
-            st = steppers[r]
-            src_neg, _ = st.get_negatives(batch, True)
-            dst_neg, _ = st.get_negatives(batch, False)
-            rng_states[r] = torch.get_rng_state()
-            uniq, mapped = O.map_tensors([batch[:, 0], batch[:, -1], src_neg.flatten(), dst_neg.flatten()])
-            el = torch.stack([mapped[0], batch[:, 1], mapped[1]]).transpose(0, 1)
-            emb = O.index_read(table, uniq)
-            out = O.train_batch(cfg["decoder"], emb, torch.zeros_like(emb), el, mapped[3].reshape(dst_neg.shape), mapped[2].reshape(src_neg.shape), rel, inv)
+            uniq, el, dst_map, src_map, emb = cur[r]
+            out = O.train_batch(cfg["decoder"], emb, torch.zeros_like(emb), el, dst_map, src_map, rel, inv)
             all_ids.append(uniq)
             all_g.append(out["node_grad"])
             rg += out["rel_grad"]
@@ -170,6 +184,108 @@ def test_sharded_step_sync_interval_averages_relation_tables():
     world, port = 2, 31000 + os.getpid() % 2000
     with tempfile.TemporaryDirectory() as outdir:
         mp.spawn(worker, args=(world, port, outdir, 3), nprocs=world, join=True)  # steps = 3 -> one sync at the last step
+        res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(world)]
+    assert torch.equal(res[0]["rel"], res[1]["rel"]) and torch.equal(res[0]["inv_rel"], res[1]["inv_rel"])
+    assert torch.isfinite(res[0]["shard"]).all() and torch.isfinite(res[1]["shard"]).all()
+
+
+# ---- the pipelined schedule (marius_amd.sharded.PipelineSchedule) with the oracle doing the local work ---------------------------
+class _OracleSlot:
+    def __init__(self):
+        from marius_amd.sharded import _NullEvent
+
+        self.ready = self.fetched = self.computed = self.free = _NullEvent()
+        self.ctx = None
+
+
+def make_oracle_pipeline(cfg, rank, world, be, edges, sync_interval, staleness, side_group):
+    from marius_amd.sharded import PipelineSchedule
+
+    class OraclePipeline(PipelineSchedule):
+        def __init__(self):
+            super().__init__(rank, world, cfg["num_nodes"], cfg["d"], torch.device("cpu"), sync_interval, None, side_group, staleness)
+            self.slots = [_OracleSlot() for _ in range(self.RING)]
+            self.nb = edges.size(0) // cfg["B"]
+            self.loss = None
+
+        def _prepare(self, t):
+            b = t % self.nb
+            self._slot(t).ctx = be.get_batch(edges[b * cfg["B"]:(b + 1) * cfg["B"]])
+
+        def _split_points(self, slot):
+            return be.owner_offsets(slot.ctx, self.S, self.world).tolist()
+
+        def _unique_ids(self, slot, U):
+            assert slot.ctx["uniq"].numel() == U
+            return slot.ctx["uniq"]
+
+        def _gather_local(self, local_ids, out):
+            return out.copy_(be.gather_local(local_ids))
+
+        def _compute(self, t):
+            slot = self._slot(t)
+            slot.grad, rel_grads, self.loss = be.compute(slot.ctx, slot.emb)
+            return rel_grads
+
+        def _apply_local(self, local_ids, grads):
+            be.apply_local(local_ids, grads)
+
+        def _dense_step(self, rel_grads):
+            be.dense_step(rel_grads)
+
+        def _dense_state(self):
+            return be.dense_state()
+
+        def _loss(self):
+            return self.loss
+
+    return OraclePipeline()
+
+
+def pipeline_worker(rank, world, port, outdir, sync_interval, staleness):
+    from marius_amd.sharded import shard_range
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    side = dist.new_group(backend="gloo")
+    cfg = CFG
+    table, edges = make_inputs(cfg)
+    lo, hi = shard_range(cfg["num_nodes"], rank, world)
+    shard, state = table[lo:hi].clone(), torch.zeros(hi - lo, cfg["d"])
+    be = OracleBackend(cfg, rank, shard, state)
+    torch.manual_seed(cfg["seed"] + rank)
+    tr = make_oracle_pipeline(cfg, rank, world, be, edges[rank], sync_interval, staleness, side)
+    losses = [float(tr.step()) for _ in range(cfg["steps"])]
+    torch.save({"shard": shard, "state": state, "rel": be.step.rel, "inv_rel": be.step.inv_rel, "losses": losses}, os.path.join(outdir, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("staleness", [0, 1])
+def test_pipeline_schedule_world2_gloo(staleness):
+    """The schedule the GPUs run (slot ring, count exchange over the side group, fetch / update order): staleness 0 must equal the
+    synchronous union-batch update, staleness 1 the same update with rows read one step early."""
+    from marius_amd.sharded import shard_range
+
+    world, port = 2, 33000 + 2000 * staleness + os.getpid() % 2000
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(pipeline_worker, args=(world, port, outdir, 1, staleness), nprocs=world, join=True)
+        res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(world)]
+    table, state, rel, inv, losses = simulate(CFG, world, staleness)
+    for r in range(world):
+        lo, hi = shard_range(CFG["num_nodes"], r, world)
+        assert torch.allclose(res[r]["shard"], table[lo:hi], rtol=1e-5, atol=1e-6), "shard %d" % r
+        assert torch.allclose(res[r]["state"], state[lo:hi], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(res[r]["rel"], rel, rtol=1e-5, atol=1e-6) and torch.allclose(res[r]["inv_rel"], inv, rtol=1e-5, atol=1e-6)
+        assert res[r]["losses"] == pytest.approx(losses[r], rel=1e-5)
+    if staleness:  # and the stale run really differs from the synchronous one (the test would otherwise prove nothing)
+        t0 = simulate(CFG, world, 0)[0]
+        assert not torch.allclose(t0, table, rtol=1e-5, atol=1e-6)
+
+
+def test_pipeline_schedule_sync_interval_world2_gloo():
+    world, port = 2, 37000 + os.getpid() % 2000
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(pipeline_worker, args=(world, port, outdir, 3, 1), nprocs=world, join=True)
         res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(world)]
     assert torch.equal(res[0]["rel"], res[1]["rel"]) and torch.equal(res[0]["inv_rel"], res[1]["inv_rel"])
     assert torch.isfinite(res[0]["shard"]).all() and torch.isfinite(res[1]["shard"]).all()
