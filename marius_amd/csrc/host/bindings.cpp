@@ -3,6 +3,7 @@
 #include <torch/extension.h>
 
 #include "marius_host.h"
+#include "partition_buffer.h"
 
 namespace py = pybind11;
 using namespace marius_amd;
@@ -29,7 +30,12 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_readwrite("pool_requests", &MariusGenerator::pool_requests_)
         .def_readwrite("state_host", &MariusGenerator::state_host_);
 
-    py::class_<InMemory, std::shared_ptr<InMemory>>(m, "InMemory")
+    py::class_<Storage, std::shared_ptr<Storage>>(m, "Storage")
+        .def_readwrite("data", &Storage::data_)
+        .def_readwrite("dim0_size", &Storage::dim0_size_)
+        .def_readwrite("dim1_size", &Storage::dim1_size_)
+        .def_readwrite("filename", &Storage::filename_);
+    py::class_<InMemory, Storage, std::shared_ptr<InMemory>>(m, "InMemory")
         .def(py::init<torch::Tensor>(), py::arg("data"))
         .def(py::init([](std::string filename, int64_t dim0, int64_t dim1, py::object dtype, torch::Device device) {
                  return std::make_shared<InMemory>(filename, dim0, dim1, torch::python::detail::py_object_to_dtype(dtype), device);
@@ -42,11 +48,73 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("rangePut", &InMemory::rangePut)
         .def("load", &InMemory::load)
         .def("write", &InMemory::write)
-        .def("unload", &InMemory::unload, py::arg("perform_write") = false)
-        .def_readwrite("data", &InMemory::data_)
-        .def_readwrite("dim0_size", &InMemory::dim0_size_)
-        .def_readwrite("dim1_size", &InMemory::dim1_size_)
-        .def_readwrite("filename", &InMemory::filename_);
+        .def("unload", &InMemory::unload, py::arg("perform_write") = false);
+
+    py::enum_<EdgeBucketOrdering>(m, "EdgeBucketOrdering")
+        .value("OLD_BETA", EdgeBucketOrdering::OLD_BETA)
+        .value("NEW_BETA", EdgeBucketOrdering::NEW_BETA)
+        .value("ALL_BETA", EdgeBucketOrdering::ALL_BETA)
+        .value("COMET", EdgeBucketOrdering::COMET)
+        .value("CUSTOM", EdgeBucketOrdering::CUSTOM);
+    py::class_<PartitionBufferOptions, std::shared_ptr<PartitionBufferOptions>>(m, "PartitionBufferOptions")
+        .def(py::init<>())
+        .def_readwrite("num_partitions", &PartitionBufferOptions::num_partitions)
+        .def_readwrite("buffer_capacity", &PartitionBufferOptions::buffer_capacity)
+        .def_readwrite("prefetching", &PartitionBufferOptions::prefetching)
+        .def_readwrite("fine_to_coarse_ratio", &PartitionBufferOptions::fine_to_coarse_ratio)
+        .def_readwrite("num_cache_partitions", &PartitionBufferOptions::num_cache_partitions)
+        .def_readwrite("edge_bucket_ordering", &PartitionBufferOptions::edge_bucket_ordering)
+        .def_readwrite("randomly_assign_edge_buckets", &PartitionBufferOptions::randomly_assign_edge_buckets);
+    py::class_<PartitionBuffer, std::shared_ptr<PartitionBuffer>>(m, "PartitionBuffer")  // buffer.h:128-190, float32 rows, slab on `device`
+        .def(py::init([](int capacity, int num_partitions, int fine_to_coarse_ratio, int64_t partition_size, int embedding_size, int64_t total_embeddings,
+                         std::string filename, bool prefetching, torch::Device device) {
+                 return std::make_shared<PartitionBuffer>(capacity, num_partitions, fine_to_coarse_ratio, partition_size, embedding_size, total_embeddings,
+                                                          torch::kFloat32, filename, prefetching, device);
+             }),
+             py::arg("capacity"), py::arg("num_partitions"), py::arg("fine_to_coarse_ratio"), py::arg("partition_size"), py::arg("embedding_size"),
+             py::arg("total_embeddings"), py::arg("filename"), py::arg("prefetching"), py::arg("device"))
+        .def("load", &PartitionBuffer::load, py::call_guard<py::gil_scoped_release>())
+        .def("unload", &PartitionBuffer::unload, py::arg("write"), py::call_guard<py::gil_scoped_release>())
+        .def("sync", &PartitionBuffer::sync, py::call_guard<py::gil_scoped_release>())
+        .def("getNextAdmit", &PartitionBuffer::getNextAdmit)
+        .def("getNextEvict", &PartitionBuffer::getNextEvict)
+        .def("getRandomIds", &PartitionBuffer::getRandomIds)
+        .def("indexRead", &PartitionBuffer::indexRead)
+        .def("indexAdd", &PartitionBuffer::indexAdd)
+        .def("getGlobalToLocalMap", &PartitionBuffer::getGlobalToLocalMap, py::arg("get_current") = true)
+        .def("setBufferOrdering", &PartitionBuffer::setBufferOrdering, py::arg("buffer_states"))
+        .def("hasSwap", &PartitionBuffer::hasSwap)
+        .def("performNextSwap", &PartitionBuffer::performNextSwap, py::call_guard<py::gil_scoped_release>())
+        .def("getNumInMemory", &PartitionBuffer::getNumInMemory)
+        .def_readonly("swaps", &PartitionBuffer::swaps_)
+        .def_readonly("prefetch_hits", &PartitionBuffer::prefetch_hits_)
+        .def_readonly("buffer_tensor_view", &PartitionBuffer::buffer_tensor_view_);
+    py::class_<PartitionBufferStorage, Storage, std::shared_ptr<PartitionBufferStorage>>(m, "PartitionBufferStorage")
+        .def(py::init<std::string, int64_t, int64_t, std::shared_ptr<PartitionBufferOptions>, torch::Device>(), py::arg("filename"), py::arg("dim0_size"),
+             py::arg("dim1_size"), py::arg("options"), py::arg("device"))
+        .def("indexRead", &PartitionBufferStorage::indexRead)
+        .def("indexAdd", &PartitionBufferStorage::indexAdd)
+        .def("range", &PartitionBufferStorage::range)
+        .def("indexPut", &PartitionBufferStorage::indexPut)
+        .def("rangePut", &PartitionBufferStorage::rangePut)
+        .def("load", &PartitionBufferStorage::load, py::call_guard<py::gil_scoped_release>())
+        .def("write", &PartitionBufferStorage::write, py::call_guard<py::gil_scoped_release>())
+        .def("unload", &PartitionBufferStorage::unload, py::arg("perform_write") = false, py::call_guard<py::gil_scoped_release>())
+        .def("getRandomIds", &PartitionBufferStorage::getRandomIds)
+        .def("hasSwap", &PartitionBufferStorage::hasSwap)
+        .def("performNextSwap", &PartitionBufferStorage::performNextSwap, py::call_guard<py::gil_scoped_release>())
+        .def("getGlobalToLocalMap", &PartitionBufferStorage::getGlobalToLocalMap, py::arg("get_current") = true)
+        .def("sync", &PartitionBufferStorage::sync, py::call_guard<py::gil_scoped_release>())
+        .def("setBufferOrdering", &PartitionBufferStorage::setBufferOrdering, py::arg("buffer_states"))
+        .def("getNextAdmit", &PartitionBufferStorage::getNextAdmit)
+        .def("getNextEvict", &PartitionBufferStorage::getNextEvict)
+        .def("getNumInMemory", &PartitionBufferStorage::getNumInMemory)
+        .def_property_readonly("swaps", [](PartitionBufferStorage& s) { return s.buffer_->swaps_; })
+        .def_property_readonly("prefetch_hits", [](PartitionBufferStorage& s) { return s.buffer_->prefetch_hits_; })
+        .def_property_readonly("swap_seconds", [](PartitionBufferStorage& s) { return s.buffer_->swap_seconds_; })
+        .def_readonly("options", &PartitionBufferStorage::options_);
+    m.def("getEdgeBucketOrdering", &getEdgeBucketOrdering, py::arg("edge_bucket_ordering"), py::arg("num_partitions"), py::arg("buffer_capacity"),
+          py::arg("fine_to_coarse_ratio"), py::arg("num_cache_partitions"), py::arg("randomly_assign_edge_buckets"), py::arg("generator"));
 
     py::class_<MariusGraph, std::shared_ptr<MariusGraph>>(m, "MariusGraph")
         .def(py::init([](int64_t n) {
@@ -181,7 +249,7 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_readonly("inverse_relations_grad", &Model::inverse_relations_grad_);
 
     py::class_<DataLoader, std::shared_ptr<DataLoader>>(m, "DataLoader")
-        .def(py::init<std::shared_ptr<InMemory>, std::shared_ptr<InMemory>, std::shared_ptr<InMemory>, std::shared_ptr<CorruptNodeNegativeSampler>,
+        .def(py::init<std::shared_ptr<InMemory>, std::shared_ptr<Storage>, std::shared_ptr<Storage>, std::shared_ptr<CorruptNodeNegativeSampler>,
                       std::shared_ptr<MariusGenerator>, int64_t, bool>(),
              py::arg("edges"), py::arg("node_embeddings"), py::arg("node_embeddings_state"), py::arg("negative_sampler"), py::arg("generator"),
              py::arg("batch_size"), py::arg("train") = true)
@@ -191,6 +259,12 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("loadGPUParameters", &DataLoader::loadGPUParameters)
         .def("updateEmbeddings", &DataLoader::updateEmbeddings, py::arg("batch"), py::arg("gpu") = true)
         .def("getNumEdges", &DataLoader::getNumEdges)
+        .def("setEdgeBucketSizes", &DataLoader::setEdgeBucketSizes, py::arg("sizes"))
+        .def("loadStorage", &DataLoader::loadStorage)
+        .def("nextEpoch", &DataLoader::nextEpoch)
+        .def_readonly("buffer_states", &DataLoader::buffer_states_)
+        .def_readonly("edge_buckets_per_buffer", &DataLoader::edge_buckets_per_buffer_)
+        .def_readonly("active_edges", &DataLoader::active_edges_)
         .def_readonly("graph", &DataLoader::graph_)
         .def_readonly("active_perm", &DataLoader::active_perm_)
         .def_readonly("num_unique", &DataLoader::count_);

@@ -1,5 +1,6 @@
 // Implementation of the host layer (see marius_host.h).  Every device operation is a call into libmarius_hip.so.
 #include "marius_host.h"
+#include "partition_buffer.h"
 
 #include <c10/hip/HIPStream.h>
 #include <c10/hip/HIPFunctions.h>
@@ -899,20 +900,95 @@ void Model::evaluate_batch(shared_ptr<Batch> batch) {
 }
 
 // ------------------------------------------------------------------------------------------------ dataloader
-DataLoader::DataLoader(shared_ptr<InMemory> edges, shared_ptr<InMemory> node_embeddings, shared_ptr<InMemory> node_embeddings_state,
+DataLoader::DataLoader(shared_ptr<InMemory> edges, shared_ptr<Storage> node_embeddings, shared_ptr<Storage> node_embeddings_state,
                        shared_ptr<CorruptNodeNegativeSampler> negative_sampler, shared_ptr<MariusGenerator> generator, int64_t batch_size, bool train)
     : edges_(edges), node_embeddings_(node_embeddings), node_embeddings_state_(node_embeddings_state), negative_sampler_(negative_sampler),
       generator_(generator), batch_size_(batch_size), train_(train) {
     graph_ = std::make_shared<MariusGraph>();
-    graph_->num_nodes_in_memory_ = node_embeddings_->dim0_size_;
+    pb_embeddings_ = std::dynamic_pointer_cast<PartitionBufferStorage>(node_embeddings_);
+    pb_state_ = std::dynamic_pointer_cast<PartitionBufferStorage>(node_embeddings_state_);
+    if (pb_embeddings_ && node_embeddings_state_ && !pb_state_)
+        throw MariusRuntimeException("DataLoader: embeddings and optimizer state must use the same storage backend");
+    // graph_storage.h:255-268: the id range negatives are drawn from is what is in memory
+    graph_->num_nodes_in_memory_ = pb_embeddings_ ? pb_embeddings_->getNumInMemory() : node_embeddings_->dim0_size_;
     num_edges_ = edges_->dim0_size_;
     key_bits_ = key_bits_for(graph_->num_nodes_in_memory_);
     if (negative_sampler_) negative_sampler_->generator_ = generator_;
 }
 
+void DataLoader::setEdgeBucketSizes(std::vector<int64_t> sizes) {
+    edge_bucket_starts_.assign(sizes.size() + 1, 0);
+    for (size_t i = 0; i < sizes.size(); ++i) edge_bucket_starts_[i + 1] = edge_bucket_starts_[i] + sizes[i];
+    if (edge_bucket_starts_.back() != edges_->dim0_size_) throw MariusRuntimeException("edge bucket sizes do not add up to the number of edges");
+}
+
+void DataLoader::loadStorage() {
+    if (!partitioned()) return;
+    auto o = pb_embeddings_->options_;
+    if ((int64_t)edge_bucket_starts_.size() != (int64_t)o->num_partitions * o->num_partitions + 1)
+        throw MariusRuntimeException("DataLoader: partitioned training needs the edge bucket sizes (num_partitions^2 entries)");
+    std::tie(buffer_states_, edge_buckets_per_buffer_) = getEdgeBucketOrdering(o->edge_bucket_ordering, o->num_partitions, o->buffer_capacity,
+                                                                                o->fine_to_coarse_ratio, o->num_cache_partitions,
+                                                                                o->randomly_assign_edge_buckets, generator_);
+    pb_embeddings_->setBufferOrdering(buffer_states_);
+    pb_embeddings_->load();
+    if (pb_state_) {
+        pb_state_->setBufferOrdering(buffer_states_);
+        pb_state_->load();
+    }
+    buffer_cursor_ = 0;
+}
+
+void DataLoader::nextEpoch() {
+    if (!partitioned()) return;
+    next_.reset();
+    pb_embeddings_->unload(true);
+    if (pb_state_) pb_state_->unload(true);
+}
+
+void DataLoader::setActiveEdges() {
+    auto dev = edges_->device_;
+    const int64_t P = pb_embeddings_->options_->num_partitions;
+    Tensor buckets = edge_buckets_per_buffer_.at(buffer_cursor_);
+    auto b = buckets.accessor<int64_t, 2>();
+    std::vector<Tensor> parts;
+    for (int64_t i = 0; i < buckets.size(0); ++i) {
+        const int64_t id = b[i][0] * P + b[i][1];
+        const int64_t n = edge_bucket_starts_[id + 1] - edge_bucket_starts_[id];
+        if (n > 0) parts.push_back(edges_->data_.narrow(0, edge_bucket_starts_[id], n));
+    }
+    const int64_t cols = edges_->dim1_size_;
+    if (parts.empty()) {
+        active_edges_ = torch::empty({0, cols}, i64(dev));
+        return;
+    }
+    Tensor act = torch::cat(parts).to(torch::kInt64);
+    Tensor g2l = pb_embeddings_->getGlobalToLocalMap(true).to(dev);  // graph_storage.cpp:395-420: node columns -> buffer rows
+    std::vector<Tensor> columns{g2l.index_select(0, act.select(1, 0))};
+    if (cols == 3) columns.push_back(act.select(1, 1));
+    columns.push_back(g2l.index_select(0, act.select(1, -1)));
+    active_edges_ = torch::stack(columns, 1).contiguous();
+}
+
+bool DataLoader::hasNextBatch() {
+    if (batches_left_ > 0 || !partitioned()) return batches_left_ > 0;
+    // dataloader.cpp:308-340: all batches of this buffer state are done -> swap and lay out the next state's batches
+    while (batches_left_ == 0 && pb_embeddings_->hasSwap()) {
+        pb_embeddings_->performNextSwap();
+        if (pb_state_) pb_state_->performNextSwap();
+        ++buffer_cursor_;
+        initializeBatches(true);
+    }
+    return batches_left_ > 0;
+}
+
 void DataLoader::initializeBatches(bool shuffle) {
+    if (partitioned()) {
+        setActiveEdges();
+        num_edges_ = active_edges_.size(0);
+    }
     // setActiveEdges (dataloader.cpp:176-182): randperm over all edges on the generator stream, consumed even for evaluation
-    Tensor perm = generator_->randperm(num_edges_);
+    Tensor perm = num_edges_ > 0 ? generator_->randperm(num_edges_) : torch::empty({0}, torch::kInt64);
     active_perm_ = shuffle ? perm.to(edges_->device_) : torch::arange(num_edges_, i64(edges_->device_));
     total_batches_ = (num_edges_ + batch_size_ - 1) / batch_size_;
     batches_left_ = total_batches_;
@@ -995,7 +1071,10 @@ shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
     const int cols = (int)edges_->dim1_size_;
     // edge_sampler_->getEdges (edge.cpp:12-14): slice of the shuffled edges, cast to int64
     Tensor edges = torch::empty({B, cols}, i64(dev));
-    mcheck(marius_select_edges(edges_->data_.data_ptr(), edges_->dtype_ == torch::kInt64 ? 1 : 0, cols, ip(active_perm_), batch->start_idx_, B, ip(edges), st));
+    if (partitioned())
+        mcheck(marius_select_edges(active_edges_.data_ptr(), 1, cols, ip(active_perm_), batch->start_idx_, B, ip(edges), st));
+    else
+        mcheck(marius_select_edges(edges_->data_.data_ptr(), edges_->dtype_ == torch::kInt64 ? 1 : 0, cols, ip(active_perm_), batch->start_idx_, B, ip(edges), st));
     // negativeSample (dataloader.cpp:498-503): inverse (src corruption) first, then dst
     std::tie(batch->src_neg_indices_, batch->src_neg_filter_) = negative_sampler_->getNegatives(graph_, edges, true);
     std::tie(batch->dst_neg_indices_, batch->dst_neg_filter_) = negative_sampler_->getNegatives(graph_, edges, false);
@@ -1076,19 +1155,25 @@ void SynchronousTrainer::train_one(bool fused) {
 
 void SynchronousTrainer::train(int num_epochs) {
     for (int epoch = 0; epoch < num_epochs; ++epoch) {
+        dataloader_->loadStorage();  // out-of-core tables: a fresh ordering per epoch (trainer.cpp:96 -> setTrainSet -> loadStorage); else a no-op
         dataloader_->initializeBatches(true);
         c10::hip::getCurrentHIPStream().synchronize();
         auto t0 = std::chrono::steady_clock::now();
         while (dataloader_->hasNextBatch()) train_one(fused_update_);
         c10::hip::getCurrentHIPStream().synchronize();
+        dataloader_->nextEpoch();  // out-of-core: write the buffer back (inside the timed region, as in the reference)
         last_epoch_seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        last_edges_per_second_ = (double)dataloader_->getNumEdges() / last_epoch_seconds_;  // trainer.cpp:156-159
+        last_edges_per_second_ = (double)dataloader_->edges_->dim0_size_ / last_epoch_seconds_;  // trainer.cpp:156-159
     }
 }
 
 void SynchronousTrainer::train_steps(int64_t n) {
     for (int64_t i = 0; i < n; ++i) {
-        if (!dataloader_->hasNextBatch()) dataloader_->initializeBatches(true);
+        if (!dataloader_->hasNextBatch()) {
+            dataloader_->nextEpoch();
+            dataloader_->loadStorage();
+            dataloader_->initializeBatches(true);
+        }
         train_one(fused_update_);
     }
 }

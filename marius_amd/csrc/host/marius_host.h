@@ -373,11 +373,12 @@ class Model {
 };
 
 // ------------------------------------------------------------------------------------------------ dataloader (dataloader.h)
+class PartitionBufferStorage;  // partition_buffer.h
 class DataLoader {
    public:
     shared_ptr<InMemory> edges_;             // [E, 3|2] int32/int64 on device
-    shared_ptr<InMemory> node_embeddings_;   // [num_nodes, d]
-    shared_ptr<InMemory> node_embeddings_state_;
+    shared_ptr<Storage> node_embeddings_;    // [num_nodes, d]: InMemory (DEVICE_MEMORY) or PartitionBufferStorage (out-of-core)
+    shared_ptr<Storage> node_embeddings_state_;
     shared_ptr<CorruptNodeNegativeSampler> negative_sampler_;
     shared_ptr<MariusGraph> graph_;
     shared_ptr<MariusGenerator> generator_;
@@ -404,10 +405,21 @@ class DataLoader {
     ~DataLoader();
     shared_ptr<Batch> prepareBatch(bool exact_unique);  // the body of getBatch, on the current stream
 
-    DataLoader(shared_ptr<InMemory> edges, shared_ptr<InMemory> node_embeddings, shared_ptr<InMemory> node_embeddings_state,
+    DataLoader(shared_ptr<InMemory> edges, shared_ptr<Storage> node_embeddings, shared_ptr<Storage> node_embeddings_state,
                shared_ptr<CorruptNodeNegativeSampler> negative_sampler, shared_ptr<MariusGenerator> generator, int64_t batch_size, bool train);
     void initializeBatches(bool shuffle = true);    // dataloader.cpp:202-248 (+ setActiveEdges :120-183)
-    bool hasNextBatch() const { return batches_left_ > 0; }
+    bool hasNextBatch();                            // out-of-core: swaps to the next buffer state when the current one is exhausted
+    // ---- out-of-core mode (both tables are PartitionBufferStorage; edges_ sorted by edge bucket, torch_partitioner.py:12-46)
+    shared_ptr<PartitionBufferStorage> pb_embeddings_, pb_state_;
+    std::vector<int64_t> edge_bucket_starts_;       // [p*p + 1] prefix sums of the bucket sizes
+    std::vector<Tensor> buffer_states_, edge_buckets_per_buffer_;
+    size_t buffer_cursor_ = 0;
+    Tensor active_edges_;                           // [n, cols] int64, buffer-local node ids: the edges assigned to the current buffer state
+    bool partitioned() const { return pb_embeddings_ != nullptr; }
+    void setEdgeBucketSizes(std::vector<int64_t> sizes);  // Storage::edge_bucket_sizes_ (storage.h:50) of the train edges
+    void loadStorage();                             // dataloader.cpp:566-600: new ordering (consumes the generator), load the first buffer state
+    void nextEpoch();                               // dataloader.cpp:108-118: write the buffer back, unload
+    void setActiveEdges();                          // dataloader.cpp:120-175 for the current buffer state
     shared_ptr<Batch> getBatch(bool exact_unique = true);  // dataloader.cpp:360-471
     void loadGPUParameters(shared_ptr<Batch> batch);       // dataloader.cpp:529-548
     void updateEmbeddings(shared_ptr<Batch> batch, bool gpu = true);  // dataloader.cpp:550-564

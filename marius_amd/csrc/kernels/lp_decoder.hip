@@ -917,7 +917,7 @@ static int fill_dims(const marius_lp_desc* d, LpDims& D) {
     D.n_ld = (d->N + 3) / 4 * 4;
     D.d_ld = (d->d + 3) / 4 * 4;
     D.gscale = (d->reduction == MARIUS_REDUCE_MEAN) ? 1.f / (float)D.Bp : 1.f;
-    MARIUS_REQUIRE((int64_t)D.Bc * (D.C - 1) < d->B, "lp: num_chunks too large for batch (empty chunk)");
+    // Bc * (C - 1) >= B leaves whole chunks of padding rows (a short last batch): legal, pad_and_reshape pads to Bc * C rows
     return MARIUS_OK;
 }
 

@@ -211,7 +211,8 @@ def run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inve
 
 @pytest.mark.parametrize("decoder", ["DISTMULT", "COMPLEX", "TRANSE"])
 @pytest.mark.parametrize("use_inverse", [True, False])
-@pytest.mark.parametrize("B,C,N,d", [(6, 3, 5, 2), (100, 10, 50, 50), (1000, 10, 500, 100), (250, 7, 130, 100), (300, 4, 260, 200)])
+@pytest.mark.parametrize("B,C,N,d", [(6, 3, 5, 2), (100, 10, 50, 50), (1000, 10, 500, 100), (250, 7, 130, 100), (300, 4, 260, 200),
+                                     (5, 4, 6, 8), (2, 4, 64, 100), (1, 3, 33, 100)])  # the last three: whole chunks of padding rows
 @pytest.mark.parametrize("reduction", ["sum"])
 def test_lp_forward_loss_backward(H, dev, decoder, use_inverse, B, C, N, d, reduction):
     U, R = max(40, B), 11

@@ -1,0 +1,208 @@
+"""Out-of-core row on the MI355X: PartitionBufferStorage (slab in HBM, swaps through pinned staging) against the
+expectations of the reference's test/cpp/unit/test_buffer.cpp:241-318 and against the CPU oracle; a partitioned training epoch
+(BETA / COMET ordering, swap per buffer state) against the oracle's restatement of the same loop."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import partition_oracle as P
+from oracle.cpu_step import CpuLinkPredictionStep
+
+pytestmark = pytest.mark.gpu
+
+REF_STATES = [[0, 1], [0, 2], [0, 3], [0, 4], [1, 4], [1, 3], [1, 2], [2, 3], [2, 4], [3, 4]]                       # test_buffer.cpp:58-87
+REF_SWAPS = [([2], [1]), ([3], [2]), ([4], [3]), ([1], [0]), ([3], [4]), ([2], [3]), ([3], [1]), ([4], [3]), ([3], [2])]  # :241-256
+
+
+@pytest.fixture(scope="module")
+def M():
+    import marius_amd
+
+    return marius_amd.host()
+
+
+def make_storage(M, dev, tmp_path, prefetching, d=12, total=45, name="embeddings.bin"):
+    """The fixture of test_buffer.cpp:21-96: capacity 2, 5 partitions of 10 rows over 45 rows (the last one holds 5)."""
+    g = torch.Generator().manual_seed(5)
+    table = torch.rand(total, d, generator=g)
+    path = str(tmp_path / name)
+    P.write_table(path, table.numpy())
+    st = M.PartitionBuffer(2, 5, 2, 10, d, total, path, prefetching, dev)
+    st.setBufferOrdering([torch.tensor(s) for s in REF_STATES])
+    st.load()
+    return st, table, path
+
+
+@pytest.mark.parametrize("prefetching", [False, True])
+def test_swap_sequence_of_reference_test(M, dev, tmp_path, prefetching):
+    st, table, path = make_storage(M, dev, tmp_path, prefetching)
+    for admit, evict in REF_SWAPS:
+        assert st.hasSwap()
+        assert st.getNextAdmit() == admit and st.getNextEvict() == evict
+        st.performNextSwap()
+    assert not st.hasSwap()
+    # final state [3, 4]: partition 3 sits in the slot 2 left, partition 4 (5 rows) in the other one with a zero tail
+    m = st.getGlobalToLocalMap(True)
+    rows = torch.arange(30, 45)
+    assert (m[:30] == -1).all()
+    assert torch.equal(st.indexRead(m[rows].to(dev)).cpu(), table[rows])
+    assert st.swaps == 9 and (st.prefetch_hits == 9 if prefetching else st.prefetch_hits == 0)
+    st.unload(True)
+    assert np.array_equal(np.fromfile(path, dtype=np.float32).reshape(table.shape), table.numpy())  # nothing was modified
+
+
+def test_global_map_of_reference_test(M, dev, tmp_path):  # test_buffer.cpp:309-318
+    st, _, _ = make_storage(M, dev, tmp_path, False)
+    exp = -torch.ones(45, dtype=torch.int64)
+    exp[0:20] = torch.arange(20)
+    assert torch.equal(st.getGlobalToLocalMap(True), exp)
+    exp[10:20] = -1
+    exp[20:30] = torch.arange(10, 20)
+    assert torch.equal(st.getGlobalToLocalMap(False), exp)
+
+
+def test_index_read_add_sync_of_reference_test(M, dev, tmp_path):  # test_buffer.cpp:270-307
+    st, table, path = make_storage(M, dev, tmp_path, False)
+    assert st.getNumInMemory() == 20
+    ids = st.getRandomIds(20)
+    assert int(ids.max()) < 20
+    assert torch.equal(st.indexRead(ids).cpu(), table.index_select(0, ids.cpu()))
+    with pytest.raises(RuntimeError):
+        st.indexRead(torch.zeros(10, 10, dtype=torch.int64, device=dev))
+    uniq = torch.unique(st.getRandomIds(1000))
+    vals = torch.randint(1000, (uniq.numel(), table.size(1))).float()
+    want = table.clone().index_add_(0, uniq.cpu(), vals)
+    st.indexAdd(uniq, vals.to(dev))
+    assert torch.equal(st.indexRead(uniq).cpu(), want.index_select(0, uniq.cpu()))
+    with pytest.raises(RuntimeError):
+        st.indexAdd(uniq, torch.zeros(uniq.numel() + 1, table.size(1), device=dev))
+    with pytest.raises(RuntimeError):
+        st.indexAdd(uniq, torch.zeros(uniq.numel(), table.size(1) + 1, device=dev))
+    with pytest.raises(RuntimeError):
+        st.indexAdd(torch.zeros(10, 10, dtype=torch.int64, device=dev), vals.to(dev))
+    st.unload(True)     # sync: the update reaches the file
+    assert np.array_equal(np.fromfile(path, dtype=np.float32).reshape(table.shape), want.numpy())
+
+
+@pytest.mark.parametrize("prefetching", [False, True])
+def test_random_ordering_with_updates_matches_oracle(M, dev, tmp_path, prefetching):
+    """Every buffer state adds to random resident rows; after the last state the files of the device buffer and of the oracle agree
+    bit for bit (an evicted partition's updates must reach the file before it is read again)."""
+    total, d, p, c = 1003, 24, 8, 4
+    g = torch.Generator().manual_seed(2)
+    table = torch.rand(total, d, generator=g)
+    paths = [str(tmp_path / n) for n in ("dev.bin", "cpu.bin")]
+    for pth in paths:
+        P.write_table(pth, table.numpy())
+    gen = M.MariusGenerator(77)
+    states, _ = M.getEdgeBucketOrdering(M.EdgeBucketOrdering.COMET, p, c, 2, 0, False, gen)
+    o = M.PartitionBufferOptions()
+    o.num_partitions, o.buffer_capacity, o.prefetching, o.fine_to_coarse_ratio = p, c, prefetching, 2
+    st = M.PartitionBufferStorage(paths[0], total, d, o, dev)
+    st.setBufferOrdering(states)
+    st.load()
+    ps = -(-total // p)
+    ora = P.PartitionBufferOracle(c, p, ps, d, total, paths[1])
+    ora.set_buffer_ordering([s.tolist() for s in states])
+    ora.load()
+    i = 0
+    while True:
+        m = st.getGlobalToLocalMap(True)
+        assert np.array_equal(m.numpy(), ora.global_to_local_map(True))
+        resident = m[m >= 0]
+        ids = resident[torch.randperm(resident.numel(), generator=g)[:200]]
+        vals = torch.rand(200, d, generator=g)
+        st.indexAdd(ids.to(dev), vals.to(dev))
+        ora.index_add(ids.numpy(), vals.numpy())
+        if not st.hasSwap():
+            break
+        assert np.array_equal(st.getGlobalToLocalMap(False).numpy(), ora.global_to_local_map(False))
+        st.performNextSwap()
+        ora.perform_next_swap()
+        i += 1
+    assert i == len(states) - 1 and not ora.has_swap()
+    st.unload(True)
+    ora.unload(True)
+    a, b = (np.fromfile(pth, dtype=np.float32) for pth in paths)
+    assert np.array_equal(a, b)
+    assert not np.array_equal(a.reshape(total, d), table.numpy())
+
+
+def _close(got, want, rtol=3e-4):
+    got, want = torch.as_tensor(got).double(), torch.as_tensor(want).double()
+    atol = rtol * max(want.abs().max().item(), 1e-30)
+    assert got.shape == want.shape
+    assert bool(((got - want).abs() <= atol + rtol * want.abs()).all()), (got - want).abs().max().item()
+
+
+@pytest.mark.parametrize("ordering,ratio,random_assign,prefetching,fused",
+                         [("OLD_BETA", 1, False, False, True), ("COMET", 2, True, True, True), ("NEW_BETA", 1, True, True, False)])
+def test_partitioned_epochs_match_oracle(M, dev, tmp_path, ordering, ratio, random_assign, prefetching, fused):
+    """Two epochs of out-of-core training: ordering from the generator stream, per buffer state the assigned edge buckets with
+    buffer-local ids, negatives from the in-memory id range, swap, write-back — against the same loop on the CPU oracle."""
+    num_nodes, R, d, B, C, N, E, seed, p, c = 2003, 7, 16, 96, 4, 24, 3000, 99, 8, 4
+    g = torch.Generator().manual_seed(1)
+    table = (torch.rand(num_nodes, d, generator=g) - 0.5) * 0.6
+    raw = torch.stack([torch.randint(num_nodes, (E,), generator=g), torch.randint(R, (E,), generator=g), torch.randint(num_nodes, (E,), generator=g)], 1)
+    edges_sorted, sizes = P.partition_edges(raw, num_nodes, p)
+    files = {}
+    for side in ("dev", "cpu"):
+        files[side] = (str(tmp_path / (side + "_emb.bin")), str(tmp_path / (side + "_state.bin")))
+        P.write_table(files[side][0], table.numpy())
+        P.write_table(files[side][1], np.zeros((num_nodes, d), dtype=np.float32))
+    # ---- device
+    o = M.PartitionBufferOptions()
+    o.num_partitions, o.buffer_capacity, o.prefetching, o.fine_to_coarse_ratio = p, c, prefetching, ratio
+    o.edge_bucket_ordering = getattr(M.EdgeBucketOrdering, ordering)
+    o.randomly_assign_edge_buckets = random_assign
+    emb = M.PartitionBufferStorage(files["dev"][0], num_nodes, d, o, dev)
+    state = M.PartitionBufferStorage(files["dev"][1], num_nodes, d, o, dev)
+    gen = M.MariusGenerator(seed)
+    sampler = M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen)
+    loader = M.DataLoader(M.InMemory(edges_sorted.to(torch.int32).to(dev)), emb, state, sampler, gen, B, True)
+    loader.setEdgeBucketSizes(sizes)
+    dec = M.ComplEx(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+    model = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+    model.setup_optimizers(0.1)
+    model.sparse_lr = 0.1
+    trainer = M.SynchronousTrainer(loader, model)
+    trainer.fused_update = fused
+    trainer.train(2)
+    assert emb.swaps > 0 and loader.graph.num_nodes_in_memory == c * (-(-num_nodes // p))
+    # ---- oracle: the same loop (trainer.cpp:94-161 with dataloader.cpp:120-183, 296-345, 566-600)
+    ps = -(-num_nodes // p)
+    o_emb = P.PartitionBufferOracle(c, p, ps, d, num_nodes, files["cpu"][0])
+    o_state = P.PartitionBufferOracle(c, p, ps, d, num_nodes, files["cpu"][1])
+    cpu = CpuLinkPredictionStep("COMPLEX", torch.zeros(1, d), torch.zeros(1, d), R, B, C, N)
+    cpu.num_nodes = c * ps
+    torch.manual_seed(seed)
+    eff_ratio = ratio if ordering == "COMET" else 1
+    eff_random = {"OLD_BETA": False, "NEW_BETA": True, "COMET": random_assign}[ordering]
+    seen = 0
+    for epoch in range(2):
+        states, buckets = P.two_level_beta_ordering(p, c, eff_ratio, 0, eff_random, choose=lambda k: int(torch.randperm(k)[0]))
+        for buf in (o_emb, o_state):
+            buf.set_buffer_ordering(states)
+            buf.load()
+        for i, bs in enumerate(buckets):
+            if i > 0:
+                o_emb.perform_next_swap()
+                o_state.perform_next_swap()
+            cpu.table, cpu.state = torch.from_numpy(o_emb.slab), torch.from_numpy(o_state.slab)
+            act = P.active_edges_for_state(edges_sorted, sizes, bs, o_emb.global_to_local_map(True), p)
+            if act.size(0) == 0:
+                continue
+            perm = torch.randperm(act.size(0))
+            for s in range(0, act.size(0), B):
+                cpu.step(act[perm[s:s + B]])
+            seen += act.size(0)
+        o_emb.unload(True)
+        o_state.unload(True)
+    assert seen == 2 * E
+    got_emb, want_emb = (np.fromfile(files[k][0], dtype=np.float32).reshape(num_nodes, d) for k in ("dev", "cpu"))
+    got_st, want_st = (np.fromfile(files[k][1], dtype=np.float32).reshape(num_nodes, d) for k in ("dev", "cpu"))
+    assert not np.allclose(want_emb, table.numpy())
+    _close(got_emb, want_emb)
+    _close(got_st, want_st)
+    _close(model.decoder.relations.cpu(), cpu.rel)
+    _close(model.decoder.inverse_relations.cpu(), cpu.inv_rel)

@@ -142,3 +142,17 @@ def test_active_edges_cover_every_edge_once_with_local_ids(tmp_path):
         assert (act[:, 0] >= 0).all() and (act[:, -1] >= 0).all() and (act[:, [0, -1]] < pb.num_in_memory()).all()
         seen += act.size(0)
     assert seen == 300 and not pb.has_swap()
+
+
+@pytest.mark.parametrize("p,c,ratio,random_assign", [(8, 4, 1, False), (8, 4, 2, False), (16, 8, 2, True), (5, 2, 1, True), (12, 6, 3, True)])
+def test_host_ordering_equals_oracle_under_the_same_seed(p, c, ratio, random_assign):
+    """The C++ host function (partition_buffer.cpp, no GPU needed: pure host logic on the MT19937 restatement) and the oracle on
+    torch's CPU generator produce the same buffer states and edge-bucket assignment from the same seed."""
+    import marius_amd
+
+    M = marius_amd.host()
+    states, buckets = M.getEdgeBucketOrdering(M.EdgeBucketOrdering.COMET, p, c, ratio, 0, random_assign, M.MariusGenerator(123))
+    torch.manual_seed(123)
+    o_states, o_buckets = P.two_level_beta_ordering(p, c, ratio, 0, random_assign, choose=lambda k: int(torch.randperm(k)[0]))
+    assert [s.tolist() for s in states] == o_states
+    assert [[tuple(x) for x in b.tolist()] for b in buckets] == o_buckets
