@@ -1,8 +1,9 @@
 """YAML configuration surface of `marius_train` for the link-prediction path.
 
 Same keys and defaults as the reference's OmegaConf schema (src/python/tools/configuration/marius_config.py; defaults cited in
-SURVEY.md §5.6) for everything the hot path reads; keys that configure subsystems outside the path (GNN layers, partition
-buffer, async pipeline) are accepted and ignored with a warning.  Dataset statistics come from <dataset_dir>/dataset.yaml
+SURVEY.md §5.6) for everything the hot path reads, including storage.embeddings.type PARTITION_BUFFER (out-of-core node table,
+options as datatypes.py:161-185); keys that configure subsystems outside the path (GNN layers, async pipeline) are accepted and
+ignored with a warning.  Dataset statistics come from <dataset_dir>/dataset.yaml
 (marius_config.py:470-493), model_dir defaults to <dataset_dir>/model_<i> (:47-56,562-565).
 """
 import copy
@@ -40,6 +41,11 @@ DEFAULTS = {
         "pipeline": {"sync": True}, "epochs_per_eval": 1,
     },
 }
+
+
+# PartitionBufferOptions (src/python/tools/configuration/datatypes.py:161-169)
+PARTITION_BUFFER_DEFAULTS = {"dtype": "float", "num_partitions": 16, "buffer_capacity": 8, "prefetching": True, "fine_to_coarse_ratio": 1,
+                             "num_cache_partitions": 0, "edge_bucket_ordering": "COMET", "randomly_assign_edge_buckets": True}
 
 
 def _merge(base, over, path=""):
@@ -85,6 +91,17 @@ def load_config(path):
     # for evaluation marius_train sorts train + validation + test edges (GraphModelStorage::sortAllEdges)
     if cfg["training"]["negative_sampling"]["filtered"]:
         raise NotImplementedError("filtered negative sampling during training is not on the path (the reference's examples train unfiltered)")
+    emb = cfg["storage"]["embeddings"]
+    if emb["type"] == "PARTITION_BUFFER":
+        o = _merge(PARTITION_BUFFER_DEFAULTS, emb.get("options"))
+        if o["num_partitions"] < 2:   # datatypes.py:171-179
+            raise ValueError("There must be at least two partitions to use the partition buffer, got: %d" % o["num_partitions"])
+        if o["buffer_capacity"] < 2:
+            raise ValueError("The partition buffer must have capacity of at least 2, got: %d" % o["buffer_capacity"])
+        o["buffer_capacity"] = min(o["buffer_capacity"], o["num_partitions"])  # :181-183
+        emb["options"] = o
+    elif emb["type"] not in ("DEVICE_MEMORY", "HOST_MEMORY"):
+        raise NotImplementedError("storage.embeddings.type %s" % emb["type"])
     if not cfg["training"]["pipeline"].get("sync", True):
         warnings.warn("async pipeline is out of scope; running the synchronous trainer")
     if cfg["storage"]["model_dir"] is None:

@@ -115,7 +115,7 @@ struct PartitionBufferOptions {  // configuration/options.h (PartitionBufferOpti
     bool prefetching = true;
     int fine_to_coarse_ratio = 1;
     int num_cache_partitions = 0;
-    EdgeBucketOrdering edge_bucket_ordering = EdgeBucketOrdering::NEW_BETA;
+    EdgeBucketOrdering edge_bucket_ordering = EdgeBucketOrdering::COMET;  // datatypes.py:161-169 defaults
     bool randomly_assign_edge_buckets = true;
 };
 

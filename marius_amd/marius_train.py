@@ -73,7 +73,40 @@ def marius_train(cfg, log=print, train=True):
 
     train_edges = edges("train", ds["num_train"])
     resume = (not train) or bool(cfg["training"].get("resume_training", False))
-    if resume:  # Checkpointer::load (checkpointer.cpp:56-74): the model directory of an earlier run
+    emb_cfg = cfg["storage"]["embeddings"]
+    partitioned = train and emb_cfg["type"] == "PARTITION_BUFFER"
+    emb_path, state_path = os.path.join(mdir, "embeddings.bin"), os.path.join(mdir, "embeddings_state.bin")
+    eval_emb = None
+    if partitioned:
+        # out-of-core node table (io.cpp:300-330 -> PartitionBufferStorage over <model_dir>/embeddings.bin + embeddings_state.bin; the
+        # train edges are sorted by edge bucket and edges/train_partition_offsets.txt lists the bucket sizes, io.cpp:110-121)
+        po = emb_cfg["options"]
+        opts = H.PartitionBufferOptions()
+        opts.num_partitions, opts.buffer_capacity = int(po["num_partitions"]), int(po["buffer_capacity"])
+        opts.prefetching, opts.fine_to_coarse_ratio = bool(po["prefetching"]), int(po["fine_to_coarse_ratio"])
+        opts.num_cache_partitions = int(po["num_cache_partitions"])
+        opts.edge_bucket_ordering = getattr(H.EdgeBucketOrdering, str(po["edge_bucket_ordering"]).upper())
+        opts.randomly_assign_edge_buckets = bool(po["randomly_assign_edge_buckets"])
+        with open(os.path.join(ddir, "edges", "train_partition_offsets.txt")) as f:
+            bucket_sizes = [int(x) for x in f.read().split()]
+        if not resume:
+            limit = math.sqrt(6.0 / (num_nodes + d))
+            rows = max(1, (256 << 20) // (4 * d))
+            with open(emb_path, "wb") as fe, open(state_path, "wb") as fs:  # initialised in slabs: the table need not fit anywhere at once
+                for lo in range(0, num_nodes, rows):
+                    n = min(rows, num_nodes - lo)
+                    fe.write(torch.empty((n, d), dtype=torch.float32, device=dev).uniform_(-limit, limit).cpu().numpy().tobytes())
+                    fs.write(bytes(4 * d * n))
+        else:
+            model.load(os.path.join(mdir, ""), train)
+            if not os.path.exists(state_path):
+                with open(state_path, "wb") as fs:
+                    fs.write(bytes(4 * d * num_nodes))
+        emb = H.PartitionBufferStorage(emb_path, num_nodes, d, opts, dev)
+        state = H.PartitionBufferStorage(state_path, num_nodes, d, opts, dev)
+        # full_graph_evaluation (graph_storage.cpp:104-112): evaluation reads the whole table from the file the epoch wrote back
+        eval_emb = H.InMemory(emb_path, num_nodes, d, torch.float32, dev)
+    elif resume:  # Checkpointer::load (checkpointer.cpp:56-74): the model directory of an earlier run
         meta = open(os.path.join(mdir, "metadata.csv")).read().split("\n")
         if not int(meta[6]):
             raise RuntimeError("checkpoint in %s has no model" % mdir)
@@ -101,6 +134,8 @@ def marius_train(cfg, log=print, train=True):
                                             bool(ns["filtered"]), getattr(H.LocalFilterMode, ns.get("local_filter_mode", "DEG")), gen)
 
     loader = H.DataLoader(train_edges, emb, state, sampler(tr["negative_sampling"]), gen, int(tr["batch_size"]), True)
+    if partitioned:
+        loader.setEdgeBucketSizes(bucket_sizes)
     trainer = H.SynchronousTrainer(loader, model)
     evals = {}
     eval_edges = {}
@@ -108,7 +143,8 @@ def marius_train(cfg, log=print, train=True):
         n = int(ds.get(key, -1))
         if n > 0 and os.path.exists(_edge_file(ddir, split)):
             eval_edges[split] = edges(split, n)
-            evals[split] = H.SynchronousEvaluator(H.DataLoader(eval_edges[split], emb, None, sampler(ev["negative_sampling"]), gen, int(ev["batch_size"]), False), model)
+            evals[split] = H.SynchronousEvaluator(H.DataLoader(eval_edges[split], eval_emb or emb, None, sampler(ev["negative_sampling"]), gen,
+                                                               int(ev["batch_size"]), False), model)
     if bool(ev["negative_sampling"].get("filtered", False)) and evals:
         # GraphModelStorage::sortAllEdges (graph_storage.cpp:745-777): train + validation + test edges are the "true" edges a filtered
         # ranking must not count as negatives
@@ -118,7 +154,11 @@ def marius_train(cfg, log=print, train=True):
 
     def run_eval(split, rec):
         t0 = time.time()
+        if eval_emb is not None:
+            eval_emb.load()
         r = evals[split].evaluate()
+        if eval_emb is not None:
+            eval_emb.unload(False)
         log("%s evaluation (%.0f ms): %s" % (split, (time.time() - t0) * 1e3, ", ".join("%s: %.6f" % kv for kv in zip(METRICS, r))))
         rec[split] = dict(zip(METRICS, r))
 
@@ -142,8 +182,9 @@ def marius_train(cfg, log=print, train=True):
     if cfg["storage"].get("save_model", True) and cfg["training"].get("save_model", True):
         # Checkpointer::save (checkpointer.cpp:39-54) into model_dir: node table + optimizer state as raw binaries, model.pt / model_state.pt
         # as torch::serialize archives with the reference's keys (Model::save, model.cpp:82-106), metadata.csv (checkpointer.cpp:104-116)
-        emb.write()
-        state.write()
+        if not partitioned:  # the partition buffer wrote both files back at the end of the epoch
+            emb.write()
+            state.write()
         model.save(os.path.join(mdir, ""))
         with open(os.path.join(mdir, "metadata.csv"), "w") as f:
             # name, num_epochs, checkpoint_id, link_prediction, has_state, has_encoded, has_model  (CheckpointMeta, checkpointer.h:12-21)

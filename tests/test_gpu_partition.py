@@ -206,3 +206,54 @@ def test_partitioned_epochs_match_oracle(M, dev, tmp_path, ordering, ratio, rand
     _close(got_st, want_st)
     _close(model.decoder.relations.cpu(), cpu.rel)
     _close(model.decoder.inverse_relations.cpu(), cpu.inv_rel)
+
+
+def test_marius_train_with_partition_buffer_config(M, dev, tmp_path):
+    """`storage.embeddings.type: PARTITION_BUFFER` (the shape of test/test_configs/lp/storage/part_buffer.yaml) end to end: dataset
+    directory with bucket-sorted train edges + train_partition_offsets.txt, COMET ordering, full-graph evaluation from the file."""
+    import os
+
+    import yaml
+
+    from marius_amd import config as C
+    from marius_amd.marius_train import marius_eval, marius_train
+
+    num_nodes, R, E, p = 300, 4, 6000, 8
+    g = torch.Generator().manual_seed(0)
+    src = torch.randint(num_nodes, (E,), generator=g)
+    rel = torch.randint(R, (E,), generator=g)
+    dst = (src * 7 + rel * 13 + 1) % num_nodes  # learnable structure
+    edges = torch.stack([src, rel, dst], 1)
+    train, sizes = P.partition_edges(edges[:5000], num_nodes, p)
+    ddir = tmp_path / "ds"
+    (ddir / "edges").mkdir(parents=True)
+    train.to(torch.int32).numpy().tofile(str(ddir / "edges" / "train_edges.bin"))
+    with open(ddir / "edges" / "train_partition_offsets.txt", "w") as f:
+        f.write("\n".join(str(s) for s in sizes) + "\n")
+    edges[5000:5500].to(torch.int32).numpy().tofile(str(ddir / "edges" / "validation_edges.bin"))
+    edges[5500:].to(torch.int32).numpy().tofile(str(ddir / "edges" / "test_edges.bin"))
+    yaml.safe_dump({"dataset_dir": str(ddir), "num_edges": E, "num_nodes": num_nodes, "num_relations": R, "num_train": 5000, "num_valid": 500,
+                    "num_test": 500}, open(ddir / "dataset.yaml", "w"))
+    cfg_path = tmp_path / "cfg.yaml"
+    yaml.safe_dump({
+        "model": {"learning_task": "LINK_PREDICTION", "random_seed": 3, "encoder": {"layers": [[{"type": "EMBEDDING", "output_dim": 32}]]},
+                  "decoder": {"type": "DISTMULT"}, "loss": {"type": "SOFTMAX_CE", "options": {"reduction": "SUM"}},
+                  "dense_optimizer": {"type": "ADAGRAD", "options": {"learning_rate": 0.1}},
+                  "sparse_optimizer": {"type": "ADAGRAD", "options": {"learning_rate": 0.1}}},
+        "storage": {"device_type": "cuda", "dataset": {"dataset_dir": str(ddir)}, "edges": {"type": "DEVICE_MEMORY"},
+                    "embeddings": {"type": "PARTITION_BUFFER", "options": {"num_partitions": p, "buffer_capacity": 4, "prefetching": True,
+                                                                           "fine_to_coarse_ratio": 2, "edge_bucket_ordering": "COMET"}}},
+        "training": {"batch_size": 500, "negative_sampling": {"num_chunks": 5, "negatives_per_positive": 100}, "num_epochs": 6},
+        "evaluation": {"batch_size": 500, "negative_sampling": {"num_chunks": 1, "negatives_per_positive": 200}},
+    }, open(cfg_path, "w"))
+    cfg = C.load_config(str(cfg_path))
+    assert cfg["storage"]["embeddings"]["options"]["randomly_assign_edge_buckets"] is True  # reference default
+    res = marius_train(cfg, log=lambda *a: None)
+    assert res[-1]["validation"]["MRR"] > res[0]["validation"]["MRR"] and res[-1]["validation"]["MRR"] > 0.2  # it learns (chance: ~0.03)
+    mdir = cfg["storage"]["model_dir"]
+    assert os.path.getsize(os.path.join(mdir, "embeddings.bin")) == num_nodes * 32 * 4
+    assert os.path.getsize(os.path.join(mdir, "embeddings_state.bin")) == num_nodes * 32 * 4
+    state = np.fromfile(os.path.join(mdir, "embeddings_state.bin"), dtype=np.float32)
+    assert (state > 0).mean() > 0.9  # every partition was trained and written back
+    again = marius_eval(C.load_config(str(cfg_path)) | {"storage": cfg["storage"]}, log=lambda *a: None)
+    assert abs(again[0]["test"]["MRR"] - res[-1]["test"]["MRR"]) < 0.05
