@@ -96,6 +96,8 @@ void PartitionBuffer::alloc_staging() {
     hipStream_t s;
     PB_HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     swap_stream_ = s;
+    PB_HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    swap_stream2_ = s;
 }
 
 void PartitionBuffer::free_staging() {
@@ -106,7 +108,8 @@ void PartitionBuffer::free_staging() {
     admit_mem_.clear();
     evict_mem_.clear();
     if (swap_stream_) (void)hipStreamDestroy((hipStream_t)swap_stream_);
-    swap_stream_ = nullptr;
+    if (swap_stream2_) (void)hipStreamDestroy((hipStream_t)swap_stream2_);
+    swap_stream_ = swap_stream2_ = nullptr;
 }
 
 void PartitionBuffer::stage_in(const Partition& p, int64_t slot, void* staging) {
@@ -246,14 +249,40 @@ void PartitionBuffer::performNextSwap() {  // buffer.cpp:501-547 (+ evict :637-6
         staged = staged_admits_ == admit;
         if (staged) ++prefetch_hits_;
     }
-    for (size_t i = 0; i < evict.size(); ++i)
-        PB_HIPCHECK(hipMemcpyAsync(evict_mem_[i], slot_ptr(slots[i]), (size_t)partition_table_[evict[i]].total_size_, hipMemcpyDeviceToHost, s));
-    for (size_t i = 0; i < admit.size(); ++i) {
-        Partition& p = partition_table_[admit[i]];
-        if (!staged) file_->readPartition(admit_mem_[i], p);  // a partition evicted earlier was written before this point (FIFO / synchronous)
-        stage_in(p, slots[i], admit_mem_[i]);
+    // PCIe is full duplex: the slot is drained (D2H, swap stream) and refilled (H2D, second stream) in chunks, chunk k of the
+    // admission following chunk k of the eviction by an event, so both directions are busy for most of the swap
+    hipStream_t s2 = (hipStream_t)swap_stream2_;
+    const int64_t CH = 32ll << 20;
+    std::vector<hipEvent_t> events;
+    for (size_t i = 0; i < evict.size(); ++i) {
+        const Partition& pe = partition_table_[evict[i]];
+        Partition* pa = i < admit.size() ? &partition_table_[admit[i]] : nullptr;
+        if (pa && !staged) file_->readPartition(admit_mem_[i], *pa);  // a partition evicted earlier was written before this point (FIFO / synchronous)
+        const int64_t span = std::max<int64_t>(pe.total_size_, pa ? pa->total_size_ : 0);
+        for (int64_t off = 0; off < span; off += CH) {
+            const int64_t ne = std::min(CH, pe.total_size_ - off), na = pa ? std::min(CH, pa->total_size_ - off) : 0;
+            if (ne > 0) PB_HIPCHECK(hipMemcpyAsync((char*)evict_mem_[i] + off, slot_ptr(slots[i]) + off, (size_t)ne, hipMemcpyDeviceToHost, s));
+            if (na > 0) {
+                hipEvent_t e;
+                PB_HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                PB_HIPCHECK(hipEventRecord(e, s));
+                PB_HIPCHECK(hipStreamWaitEvent(s2, e, 0));
+                events.push_back(e);
+                PB_HIPCHECK(hipMemcpyAsync(slot_ptr(slots[i]) + off, (char*)admit_mem_[i] + off, (size_t)na, hipMemcpyHostToDevice, s2));
+            }
+        }
+        if (pa && pa->total_size_ < slot_bytes()) {  // short last partition: zero tail, after the eviction has drained the slot
+            hipEvent_t e;
+            PB_HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            PB_HIPCHECK(hipEventRecord(e, s));
+            PB_HIPCHECK(hipStreamWaitEvent(s2, e, 0));
+            events.push_back(e);
+            PB_HIPCHECK(hipMemsetAsync(slot_ptr(slots[i]) + pa->total_size_, 0, (size_t)(slot_bytes() - pa->total_size_), s2));
+        }
     }
     PB_HIPCHECK(hipStreamSynchronize(s));
+    PB_HIPCHECK(hipStreamSynchronize(s2));
+    for (auto e : events) PB_HIPCHECK(hipEventDestroy(e));
     for (int e : evict) partition_table_[e].present_ = false;  // buffer_idx_ stays, as in the reference
     for (size_t i = 0; i < admit.size(); ++i) {
         partition_table_[admit[i]].present_ = true;

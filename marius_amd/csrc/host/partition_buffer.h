@@ -86,7 +86,8 @@ class PartitionBuffer {
     // pinned staging: `lanes_` partitions each way
     int lanes_ = 1;
     std::vector<void*> admit_mem_, evict_mem_;
-    void* swap_stream_ = nullptr;
+    void* swap_stream_ = nullptr;   // evictions (D2H), initial load
+    void* swap_stream2_ = nullptr;  // admissions (H2D) during a swap
     std::vector<int> staged_admits_;  // partition ids currently (being) read into admit_mem_ by the IO thread
 
     // one FIFO IO thread
