@@ -134,6 +134,7 @@ bool launch_scores_a(const ScoreArgs& a, bool l2, hipStream_t st);
 bool launch_scores_res(const ScoreArgs& a, bool l2, hipStream_t st);
 bool launch_grad16(const GradArgs& a, bool l2, int which, hipStream_t st);  // which: 0 both (one launch), 1 dAdj, 2 dNeg
 size_t grad16_sk_part_bytes();
-bool launch_grad16_sk(const GradArgs& a, bool l2, float* part, hipStream_t st);  // both contractions, stream-K balanced persistent launch
+bool launch_grad16_sk(const GradArgs& a, bool l2, float* part, hipStream_t st);
+bool launch_grad16_hy(const GradArgs& a, bool l2, float* part, hipStream_t st);  // both contractions, whole tiles + K-split tiles for the last round  // both contractions, stream-K balanced persistent launch
 
 }  // namespace marius

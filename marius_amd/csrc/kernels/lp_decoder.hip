@@ -1159,7 +1159,8 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
         }
         if (!done && lvl >= 2 && !split) {
             ProfScope ps(PROF_LP_GRAD_ADJ, st);  // merged launch is accounted under lp_grad_adj (both contractions)
-            done = launch_grad16_sk(ga, l2, (float*)(ws + L->gradpart), st) || launch_grad16(ga, l2, 0, st);
+            done = launch_grad16_sk(ga, l2, (float*)(ws + L->gradpart), st) || launch_grad16_hy(ga, l2, (float*)(ws + L->gradpart), st) ||
+                   launch_grad16(ga, l2, 0, st);
         }
         if (!done) {
             {

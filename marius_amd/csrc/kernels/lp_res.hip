@@ -1434,6 +1434,96 @@ __global__ __launch_bounds__(256) void lp_grad16_fixup_kernel(GradArgs a, int ti
     }
 }
 
+// ---- tail-split launch of the same two bodies (Dot comparator).  Whole tiles keep the plain one-workgroup-per-tile dynamic dispatch
+// for as many FULL rounds of the resident slots as there are; only the tiles of the last, partly filled round are cut along their K
+// loop into `sp` pieces so that this round also fills every slot, with pieces 1/sp as long.  Each XCD owns a contiguous range of
+// tiles (Tx), Wx of them whole, the other Tx - Wx split; blocks are numbered so that block b runs on XCD b % 8 for both kinds.
+// Pieces write their accumulators to `part`; lp_grad16_hyfix_kernel adds the sp pieces of a tile in index order (deterministic).
+constexpr int HY_SLOTS = 96;  // resident workgroups per XCD: 32 CUs x 3 (launch bounds of the grad16 kernels)
+
+struct HyTile {
+    int t, piece;  // tile index (< 0: nothing to do), piece (-1 = whole tile)
+    int slot;      // index of the split tile among all split tiles (part buffer addressing)
+};
+__device__ __forceinline__ HyTile hy_decode(int b, int T, int Tx, int Wx, int sp) {
+    HyTile h;
+    h.piece = -1;
+    h.slot = 0;
+    const int nwhole = 8 * Wx;
+    int xcd;
+    if (b < nwhole) {
+        xcd = b & 7;
+        h.t = xcd * Tx + (b >> 3);
+    } else {
+        const int q = b - nwhole;
+        xcd = q & 7;
+        const int r = q >> 3;
+        const int tt = r / sp;
+        h.piece = r - tt * sp;
+        h.t = xcd * Tx + Wx + tt;
+        h.slot = xcd * (Tx - Wx) + tt;
+    }
+    const int end = min(T, (xcd + 1) * Tx);
+    if (h.t >= end) h.t = -1;
+    return h;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 3) void lp_grad16_hy_kernel(GradArgs a, int tiles_adj, int tiles_neg, int nch_adj, int nch_neg, int T, int Tx, int Wx, int sp,
+                                                              float* part) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const HyTile h = hy_decode((int)blockIdx.x, T, Tx, Wx, sp);
+    if (h.t < 0) return;
+    const int per = tiles_adj + tiles_neg;
+    const int cd = h.t / per, unit = h.t - cd * per;
+    const bool adj = unit < tiles_adj;
+    int c0 = 0, c1 = -1;
+    float* p = nullptr;
+    if (h.piece >= 0 && sp > 1) {
+        const int nch = adj ? nch_adj : nch_neg;
+        c0 = nch * h.piece / sp;
+        c1 = nch * (h.piece + 1) / sp;
+        p = part + ((size_t)h.slot * sp + h.piece) * (NT * 4 * 256);
+    }
+    if (adj)
+        grad_adj16_body<false, NT>(a, cd, unit, tiles_adj, smem, c0, c1, p);
+    else
+        grad_neg16_body<false, NT>(a, cd, unit - tiles_adj, tiles_neg, smem, c0, c1, p);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void lp_grad16_hyfix_kernel(GradArgs a, int tiles_adj, int tiles_neg, int T, int Tx, int Wx, int sp, const float* part) {
+    const int rx = Tx - Wx;
+    const int xcd = (int)blockIdx.x / rx, tt = (int)blockIdx.x - xcd * rx;
+    const int t = xcd * Tx + Wx + tt;
+    if (t >= min(T, (xcd + 1) * Tx)) return;
+    const LpDims& D = a.D;
+    const int per = tiles_adj + tiles_neg;
+    const int cd = t / per, unit = t - cd * per;
+    const bool adj = unit < tiles_adj;
+    const int tile = adj ? unit : unit - tiles_adj;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const float* p = part + (size_t)blockIdx.x * sp * (NT * 4 * 256);
+    const int dir = cd / D.C, c = cd - dir * D.C;
+    const int64_t rowbase = (int64_t)dir * D.Bp + (int64_t)c * D.Bc;
+    const int m0 = tile * H_TM;
+    float* out = adj ? a.dadj + rowbase * D.d_ld : a.gocc + (a.negocc_off[dir] + (int64_t)c * D.N) * D.d_ld;
+    const int mlimit = adj ? D.Bc : D.N;
+#pragma unroll
+    for (int tc = 0; tc < NT; ++tc) {
+        const int n = 16 * tc + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wave * 16 + 4 * kq + r;
+            const int e = (tc * 4 + r) * 256 + tid;
+            float acc = p[e];
+            for (int j = 1; j < sp; ++j) acc += p[(size_t)j * (NT * 4 * 256) + e];
+            if (m < mlimit && n < D.d) out[(int64_t)m * D.d_ld + n] = acc;
+        }
+    }
+}
+
 // =========================================================================================== launchers
 static bool res_ok(const float* emb, int64_t emb_ld, int d) {
     return (d % 4 == 0) && (emb_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(emb) & 15) == 0);
@@ -1624,6 +1714,52 @@ bool launch_grad16_sk(const GradArgs& a, bool l2, float* part, hipStream_t st) {
     else if (nt_inst == 7) GRAD16_SK(7);
     else GRAD16_SK(8);
 #undef GRAD16_SK
+    return true;
+}
+
+// tail-split variant.  Opt-in (MARIUS_GRAD_HY=1; =2: only the balanced contiguous tile ranges per XCD, no K split): measured on the
+// bench workload 0.500 ms (split) / 0.473 ms (balance only) vs 0.474 ms for the plain launch.  The "5 rounds at 83 % fill" model of the
+// plain launch is wrong: in the partly filled last round a CU hosts fewer workgroups and each of them runs correspondingly faster
+// (the kernel is bound by the SIMDs' issue slots, not by the number of resident workgroups), so there is no tail to reclaim.
+bool launch_grad16_hy(const GradArgs& a, bool l2, float* part, hipStream_t st) {
+    int nblk, nt;
+    if (l2 || !part || !grad16_shape(a, l2, nblk, nt) || nblk != 1) return false;
+    const char* e = getenv("MARIUS_GRAD_HY");
+    if (!(e && (e[0] == '1' || e[0] == '2'))) return false;
+    const int tiles_adj = (int)cdiv(a.D.Bc, H_TM), tiles_neg = (int)cdiv(a.D.N, H_TM);
+    const int nch_adj = (int)cdiv(a.D.N, H_KC), nch_neg = (int)cdiv(a.D.Bc, H_KC);
+    const int64_t T64 = (int64_t)a.D.C * a.D.ndir * (tiles_adj + tiles_neg);
+    if (T64 >= ((int64_t)1 << 28)) return false;
+    const int T = (int)T64;
+    const int Tx = (T + 7) / 8;
+    int slots = HY_SLOTS;
+    const char* w = getenv("MARIUS_GRAD_HY_SLOTS");  // tests: force splits at small shapes
+    if (w) slots = atoi(w);
+    if (slots < 1) return false;
+    const int Wx = Tx / slots * slots, rx = Tx - Wx;
+    if (rx == 0) return false;                    // whole rounds only: the plain launch is already balanced
+    int sp = slots / rx;
+    sp = sp < nch_adj ? sp : nch_adj;
+    sp = sp < nch_neg ? sp : nch_neg;
+    sp = sp < 8 ? sp : 8;
+    const bool balance_only = e && e[0] == '2';  // experiment: contiguous, balanced tile ranges per XCD, no K split
+    if (balance_only) sp = 1;
+    if (sp < 2 && !balance_only) return false;    // the last round is more than half full
+    const int nt_inst = nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : nt <= 7 ? 7 : 8;
+    if ((size_t)8 * rx * sp * nt_inst * 4 * 256 * sizeof(float) > grad16_sk_part_bytes()) return false;
+    const size_t lds = grad16_lds_bytes(a.D.N, nt_inst);
+    const unsigned grid = (unsigned)(8 * Wx + 8 * rx * sp);
+#define GRAD16_HY(NTV)                                                                                                          \
+    do {                                                                                                                        \
+        lp_grad16_hy_kernel<NTV><<<dim3(grid), dim3(256), lds, st>>>(a, tiles_adj, tiles_neg, nch_adj, nch_neg, T, Tx, Wx, sp, part); \
+        if (sp > 1) lp_grad16_hyfix_kernel<NTV><<<dim3(8 * rx), dim3(256), 0, st>>>(a, tiles_adj, tiles_neg, T, Tx, Wx, sp, part); \
+    } while (0)
+    if (nt_inst == 1) GRAD16_HY(1);
+    else if (nt_inst == 2) GRAD16_HY(2);
+    else if (nt_inst == 4) GRAD16_HY(4);
+    else if (nt_inst == 7) GRAD16_HY(7);
+    else GRAD16_HY(8);
+#undef GRAD16_HY
     return true;
 }
 

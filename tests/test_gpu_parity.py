@@ -510,6 +510,7 @@ def test_stream_k_backward_matches_plain_launch(H, dev, monkeypatch, nwg):
     U, R = B, 11
     emb, state, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=77)
     monkeypatch.setenv("MARIUS_GRAD_SK", "0")
+    monkeypatch.setenv("MARIUS_GRAD_HY", "0")
     W = run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, "sum")
     torch.cuda.synchronize()
     want = W.gocc()[:, :d].cpu().clone()
@@ -520,6 +521,32 @@ def test_stream_k_backward_matches_plain_launch(H, dev, monkeypatch, nwg):
     torch.cuda.synchronize()
     got = W.gocc()[:, :d].cpu()
     assert (got - want).abs().max() <= 1e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slots", ["", "7", "20", "64"])
+@pytest.mark.parametrize("decoder,use_inverse,B,C,N,d", [("COMPLEX", True, 1000, 10, 500, 100), ("DISTMULT", False, 250, 7, 130, 100)])
+def test_tail_split_backward_matches_plain_launch(H, dev, monkeypatch, slots, decoder, use_inverse, B, C, N, d):
+    """MARIUS_GRAD_HY=1 (opt-in, measured no faster): whole tiles for the full rounds, the tiles of the last round cut along K into
+    pieces + a fix-up that adds the pieces in order.  Must reproduce the plain launch up to summation order, and the oracle."""
+    U, R = B, 11
+    emb, state, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=78)
+    monkeypatch.setenv("MARIUS_GRAD_SK", "0")
+    monkeypatch.setenv("MARIUS_GRAD_HY", "0")
+    W = run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, "sum")
+    torch.cuda.synchronize()
+    want = W.gocc()[:, :d].cpu().clone()
+    monkeypatch.setenv("MARIUS_GRAD_HY", "1")
+    if slots:
+        monkeypatch.setenv("MARIUS_GRAD_HY_SLOTS", slots)
+    W = run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, "sum")
+    torch.cuda.synchronize()
+    got = W.gocc()[:, :d].cpu()
+    assert (got - want).abs().max() <= 1e-5 * max(1.0, want.abs().max().item())
+    ref = O.train_batch(decoder, emb, state, edges, dst_neg, src_neg, rel, inv if use_inverse else None, reduction="sum")
+    occ_ids = torch.cat([edges[:, 0], edges[:, 2], src_neg.flatten(), dst_neg.flatten()])
+    node_grad = torch.zeros(U, d, dtype=torch.float64).index_add_(0, occ_ids, got.double())
+    assert_close(node_grad.float(), ref["node_grad"], "node_grad (tail split)")
 
 
 # ------------------------------------------------------------------------------------------------ dense Adam (optim.cpp:186-232)
