@@ -20,6 +20,9 @@ template <>
 struct VecT<1> { using type = float; };
 
 constexpr int ROW_UNROLL = 4;
+// rows in flight per thread row of the gather: tools/micro/gather_variants.hip on random 400-B rows of a 34 GB table (fresh ids per
+// launch) gives 37.8 us with 4, 34.8 us with 2, 38 us with 8 (a contiguous copy of the same 80 + 80 MB: 28.6 us)
+constexpr int GATHER_UNROLL = 2;
 
 template <int VEC, int NT>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ ta, const float* __restrict__ tb,
@@ -28,24 +31,24 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
                                                           int64_t out_ld) {
     using V = typename VecT<VEC>::type;
     const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
-    int64_t rows[ROW_UNROLL];
-    int64_t src[ROW_UNROLL];
+    int64_t rows[GATHER_UNROLL];
+    int64_t src[GATHER_UNROLL];
 #pragma unroll
-    for (int k = 0; k < ROW_UNROLL; ++k) {
-        rows[k] = ((int64_t)blockIdx.x * ROW_UNROLL + k) * TY + ty;
+    for (int k = 0; k < GATHER_UNROLL; ++k) {
+        rows[k] = ((int64_t)blockIdx.x * GATHER_UNROLL + k) * TY + ty;
         src[k] = rows[k] < n ? ids[rows[k]] : -1;
     }
     for (int c = tx; c < vpr; c += TX) {
-        V va[ROW_UNROLL], vb[ROW_UNROLL];
+        V va[GATHER_UNROLL], vb[GATHER_UNROLL];
 #pragma unroll
-        for (int k = 0; k < ROW_UNROLL; ++k) {
+        for (int k = 0; k < GATHER_UNROLL; ++k) {
             if (src[k] >= 0) {
                 va[k] = reinterpret_cast<const V*>(ta + src[k] * table_ld)[c];
                 if (NT == 2) vb[k] = reinterpret_cast<const V*>(tb + src[k] * table_ld)[c];
             }
         }
 #pragma unroll
-        for (int k = 0; k < ROW_UNROLL; ++k) {
+        for (int k = 0; k < GATHER_UNROLL; ++k) {
             if (src[k] >= 0) {
                 reinterpret_cast<V*>(oa + rows[k] * out_ld)[c] = va[k];
                 if (NT == 2) reinterpret_cast<V*>(ob + rows[k] * out_ld)[c] = vb[k];
@@ -152,12 +155,12 @@ __global__ __launch_bounds__(256) void dense_adam_kernel(float* __restrict__ w, 
     }
 }
 
-static void row_geometry(int vpr, dim3& block, int& rows_per_block) {
+static void row_geometry(int vpr, dim3& block, int& rows_per_block, int unroll = ROW_UNROLL) {
     int tx = 1;
     while (tx < vpr && tx < 64) tx <<= 1;
     int ty = 256 / tx;
     block = dim3(tx, ty, 1);
-    rows_per_block = ty * ROW_UNROLL;
+    rows_per_block = ty * unroll;
 }
 
 template <int NT>
@@ -175,7 +178,7 @@ static int launch_gather(const float* ta, const float* tb, int64_t table_ld, con
     int vpr = d / vec;
     dim3 block;
     int rpb;
-    row_geometry(vpr, block, rpb);
+    row_geometry(vpr, block, rpb, GATHER_UNROLL);
     dim3 grid((unsigned)cdiv(n, rpb));
     ProfScope ps(PROF_GATHER, st);
     if (vec == 4)
