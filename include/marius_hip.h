@@ -30,6 +30,17 @@ enum { MARIUS_OP_HADAMARD = 0, MARIUS_OP_COMPLEX_HADAMARD = 1, MARIUS_OP_TRANSLA
 enum { MARIUS_CMP_DOT = 0, MARIUS_CMP_L2 = 1, MARIUS_CMP_COSINE = 2 };
 /* LossReduction: include/configuration/options.h */
 enum { MARIUS_REDUCE_SUM = 0, MARIUS_REDUCE_MEAN = 1 };
+/* LossFunction subclasses of src/nn/loss.cpp:50-187 on (pos [B'], neg [B', N]) scores.  CROSS_ENTROPY over [pos, neg...] with label 0
+ * (loss.cpp:89-103) is the same function as SOFTMAX_CE (log-sum-exp over the same 1 + N scores) and shares its kernels. */
+enum {
+    MARIUS_LOSS_SOFTMAX_CE = 0,
+    MARIUS_LOSS_RANKING = 1,           /* margin_ranking_loss(neg, pos[:,None], -1, margin): max(0, neg - pos + margin), mean over B' N */
+    MARIUS_LOSS_CROSS_ENTROPY = 2,
+    MARIUS_LOSS_BCE_AFTER_SIGMOID = 3, /* binary_cross_entropy(sigmoid([pos, neg.flatten]), [1.., 0..]), mean over B' (1 + N)          */
+    MARIUS_LOSS_BCE_WITH_LOGITS = 4,
+    MARIUS_LOSS_MSE = 5,
+    MARIUS_LOSS_SOFTPLUS = 6           /* softplus(-(2 y - 1) x)                                                                       */
+};
 
 int marius_hip_abi_version(void);
 const char* marius_hip_last_error(void);
@@ -181,6 +192,8 @@ typedef struct marius_lp_desc {
     int64_t n_dst_filter;
     const int64_t* src_filter;
     int64_t n_src_filter;
+    int32_t loss;         /* MARIUS_LOSS_* (0 = SoftmaxCrossEntropy: a zero-initialised descriptor keeps its old meaning) */
+    float margin;         /* RankingLoss margin (loss.h:43-55) */
 } marius_lp_desc;
 
 /* Workspace layout (all offsets in BYTES from the workspace base; dir 0 = (src,rel)->dst "rhs", dir 1 = inverse "lhs").
@@ -191,7 +204,7 @@ typedef struct marius_lp_layout {
     size_t adj[2];    /* [Bp, d_ld]  op(src, rel) rows (zero rows for i >= B)                                   */
     size_t pos[2];    /* [Bp]        positive scores (zero padded)  -> forward_lp pos / inv_pos                  */
     size_t neg[2];    /* [Bp, n_ld]  negative scores                -> forward_lp neg / inv_neg                  */
-    size_t lse[2];    /* [Bp]        log(e^pos + sum_j e^neg)                                                    */
+    size_t lse[2];    /* [Bp]        per-row scalar of the loss: SoftmaxCE log(e^pos + sum_j e^neg); Ranking pos - margin        */
     size_t rowloss[2];/* [Bp]        per-row loss                                                                */
     size_t loss;      /* [4] floats: total, dir0, dir1, unused                                                   */
     size_t dadj[2];   /* [Bp, d_ld]  dL/d adj (negative part)                                                    */
@@ -205,6 +218,7 @@ typedef struct marius_lp_layout {
     size_t negt;      /* [ncd][3][kp][N  rounded to 32] bf16: negatives of each chunk-direction, contraction-major                */
     size_t adjt;      /* [ncd][3][kp][Bc rounded to 32] bf16: adj rows of each chunk-direction, contraction-major                 */
     size_t gradpart;  /* partial accumulators of the stream-K backward launch (two tiles per persistent workgroup)               */
+    size_t dpos[2];   /* [Bp]        dL/d pos, written by marius_lp_loss, read by the edge backward                               */
 } marius_lp_layout;
 
 int marius_lp_plan(const marius_lp_desc* desc, marius_lp_layout* layout);
@@ -214,7 +228,8 @@ int marius_lp_plan(const marius_lp_desc* desc, marius_lp_layout* layout);
  * (src/data/samplers/negative.cpp:306-311).  Fills adj/pos/neg. */
 int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_layout* layout, void* workspace, marius_stream_t stream);
 
-/* SoftmaxCrossEntropy (src/nn/loss.cpp:50-67) of both directions, summed (model.cpp:309-312). Fills lse/rowloss/loss. */
+/* desc->loss (SoftmaxCrossEntropy src/nn/loss.cpp:50-67 by default; the others :69-187) of both directions, summed (model.cpp:309-312).
+ * Fills lse/rowloss/dpos/loss. */
 int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout* layout, void* workspace, marius_stream_t stream);
 
 /* loss.backward() (model.cpp:324) restricted to this graph: fills gocc (per-occurrence node gradients) and grel. */
@@ -224,6 +239,11 @@ int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_layout* layou
  * lse[rows], rowloss[rows], loss[4] are outputs (loss[0] = reduced loss).  neg_ld must be a multiple of 4. */
 int marius_softmax_ce(const float* pos, const float* neg, int64_t rows, int32_t N, int64_t neg_ld, int32_t reduction, float* lse,
                       float* rowloss, float* loss, marius_stream_t stream);
+
+/* Any LossFunction::operator()(pos, neg, scores = true) on materialised scores (loss.cpp:50-187): scratch[2 * rows] floats, loss[4]
+ * output (loss[0] = reduced loss). */
+int marius_loss_scores(int32_t loss_type, float margin, const float* pos, const float* neg, int64_t rows, int32_t N, int64_t neg_ld,
+                       int32_t reduction, float* scratch, float* loss, marius_stream_t stream);
 
 /* ranks = (neg >= pos[:,None]).sum(1) + 1   replaces LinkPredictionReporter::computeRanks src/reporting/reporting.cpp:55-57 */
 int marius_compute_ranks(const float* pos, const float* neg, int64_t rows, int32_t N, int64_t neg_ld, int64_t* ranks,

@@ -215,11 +215,23 @@ PYBIND11_MODULE(_marius_host, m) {
     py::class_<LossFunction, std::shared_ptr<LossFunction>>(m, "LossFunction")
         .def("__call__", [](LossFunction& l, torch::Tensor a, torch::Tensor b, bool scores) { return l(a, b, scores); }, py::arg("y_pred"),
              py::arg("targets"), py::arg("scores") = true);
-    py::class_<SoftmaxCrossEntropy, LossFunction, std::shared_ptr<SoftmaxCrossEntropy>>(m, "SoftmaxCrossEntropy")
-        .def(py::init([](std::string reduction) {
-                 return std::make_shared<SoftmaxCrossEntropy>(reduction == "mean" || reduction == "MEAN" ? LossReduction::MEAN : LossReduction::SUM);
-             }),
-             py::arg("reduction") = "sum");
+    auto red = [](const std::string& r) { return (r == "mean" || r == "MEAN") ? LossReduction::MEAN : LossReduction::SUM; };
+#define MARIUS_LOSS_BIND(NAME)                                                                                                        \
+    py::class_<NAME, LossFunction, std::shared_ptr<NAME>>(m, #NAME)                                                                   \
+        .def(py::init([red](std::string reduction) { return std::make_shared<NAME>(red(reduction)); }), py::arg("reduction") = "sum")
+    MARIUS_LOSS_BIND(SoftmaxCrossEntropy);
+    MARIUS_LOSS_BIND(CrossEntropyLoss);
+    MARIUS_LOSS_BIND(BCEAfterSigmoidLoss);
+    MARIUS_LOSS_BIND(BCEWithLogitsLoss);
+    MARIUS_LOSS_BIND(MSELoss);
+    MARIUS_LOSS_BIND(SoftPlusLoss);
+#undef MARIUS_LOSS_BIND
+    py::class_<RankingLoss, LossFunction, std::shared_ptr<RankingLoss>>(m, "RankingLoss")
+        .def(py::init([red](std::string reduction, float margin) { return std::make_shared<RankingLoss>(red(reduction), margin); }),
+             py::arg("reduction") = "sum", py::arg("margin") = 0.1f)
+        .def_readwrite("margin", &RankingLoss::margin_);
+    m.def("getLossFunction", [red](std::string type, std::string reduction, float margin) { return getLossFunction(type, red(reduction), margin); },
+          py::arg("type"), py::arg("reduction") = "sum", py::arg("margin") = 0.1f);
 
     py::class_<LinkPredictionReporter, std::shared_ptr<LinkPredictionReporter>>(m, "LinkPredictionReporter")
         .def(py::init<>())

@@ -352,7 +352,7 @@ Tensor LpContext::view(size_t off, std::vector<int64_t> shape, std::vector<int64
 }
 
 static void lp_setup(LpContext& ctx, shared_ptr<EdgeDecoder> dec, const Tensor& edges, const Tensor& emb, const Tensor& dst_negs, const Tensor& src_negs,
-                     const Tensor& dst_filter, const Tensor& src_filter, LossReduction reduction) {
+                     const Tensor& dst_filter, const Tensor& src_filter, LossReduction reduction, int loss_kind = MARIUS_LOSS_SOFTMAX_CE, float margin = 0.f) {
     require_device(emb, "forward_lp");
     require_device(edges, "forward_lp");
     if (edges.dim() != 2 || (edges.size(1) != 3 && edges.size(1) != 2))
@@ -369,6 +369,8 @@ static void lp_setup(LpContext& ctx, shared_ptr<EdgeDecoder> dec, const Tensor& 
     d.N = (int32_t)dst_negs.size(1);
     d.use_inverse = (has_rel && dec->use_inverse_relations_ && dec->inverse_relations_.defined() && src_negs.defined()) ? 1 : 0;
     d.reduction = reduction == LossReduction::MEAN ? MARIUS_REDUCE_MEAN : MARIUS_REDUCE_SUM;
+    d.loss = loss_kind;
+    d.margin = margin;
     Tensor e = edges.contiguous(), dn = dst_negs.contiguous(), sn = src_negs.defined() ? src_negs.contiguous() : Tensor();
     d.emb = fp(emb);
     d.emb_ld = emb.stride(0);
@@ -395,10 +397,10 @@ static void lp_setup(LpContext& ctx, shared_ptr<EdgeDecoder> dec, const Tensor& 
 
 std::tuple<Tensor, Tensor, Tensor, Tensor> node_corrupt_forward(shared_ptr<EdgeDecoder> decoder, Tensor positive_edges, Tensor node_embeddings,
                                                                 Tensor dst_negs, Tensor src_negs, LpContext* ctx, Tensor dst_filter, Tensor src_filter,
-                                                                LossReduction reduction) {
+                                                                LossReduction reduction, int loss_kind, float margin) {
     LpContext local;
     LpContext& c = ctx ? *ctx : local;
-    lp_setup(c, decoder, positive_edges, node_embeddings, dst_negs, src_negs, dst_filter, src_filter, reduction);
+    lp_setup(c, decoder, positive_edges, node_embeddings, dst_negs, src_negs, dst_filter, src_filter, reduction, loss_kind, margin);
     mcheck(marius_lp_forward(&c.desc, &c.layout, c.workspace.data_ptr(), cur_stream()));
     const int64_t Bp = c.layout.Bp, N = c.desc.N, nld = c.layout.n_ld;
     Tensor pos = c.view(c.layout.pos[0], {Bp});
@@ -546,15 +548,21 @@ shared_ptr<EdgeDecoder> get_edge_decoder(DecoderType type, EdgeDecoderMethod met
 }
 
 // ------------------------------------------------------------------------------------------------ loss / optimizers / reporter
-Tensor SoftmaxCrossEntropy::operator()(Tensor pos, Tensor neg, bool scores) {
-    if (!scores)
-        throw MariusRuntimeException(
-            "Input to SoftmaxCrossEntropy loss function must be scores. SoftmaxCrossEntropy is currently unsupported for classification.");
-    if (!pos.defined() || !neg.defined()) throw UndefinedTensorException();                    // loss.cpp:7-14
+Tensor LossFunction::operator()(Tensor pos, Tensor neg, bool scores) {
+    if (!scores) {
+        if (kind() == MARIUS_LOSS_SOFTMAX_CE)
+            throw MariusRuntimeException(
+                "Input to SoftmaxCrossEntropy loss function must be scores. SoftmaxCrossEntropy is currently unsupported for classification.");
+        if (kind() == MARIUS_LOSS_RANKING)
+            throw MariusRuntimeException("Input to ranking loss function must be scores. This loss function is unsupported for classification.");
+        throw MariusRuntimeException(std::string(name()) + ": classification input (scores = false) is outside the link-prediction path of this build");
+    }
+    if (!pos.defined() || !neg.defined()) throw UndefinedTensorException();                    // check_score_shapes, loss.cpp:7-29
     if (pos.dim() != 1) throw TensorSizeMismatchException(pos, "Positive scores should be 1-dimensional");
     if (neg.dim() != 2) throw TensorSizeMismatchException(neg, "Negative scores should be 2-dimensional");
     if (pos.size(0) != neg.size(0)) throw TensorSizeMismatchException(pos, "First dimension of pos_scores and neg_scores should match.");
-    require_device(pos, "SoftmaxCrossEntropy");
+    require_device(pos, name());
+    require_device(neg, name());
     Tensor n = neg;
     if (n.stride(1) != 1 || n.stride(0) % 4 != 0) {  // give the kernel a 16-B aligned row pitch
         const int64_t nld = (neg.size(1) + 3) / 4 * 4;
@@ -563,10 +571,21 @@ Tensor SoftmaxCrossEntropy::operator()(Tensor pos, Tensor neg, bool scores) {
         n = buf.narrow(1, 0, neg.size(1));
     }
     Tensor p = pos.contiguous();
-    Tensor lse = torch::empty_like(p), rowloss = torch::empty_like(p), loss = torch::empty({4}, p.options());
-    mcheck(marius_softmax_ce(fp(p), fp(n), p.size(0), (int32_t)n.size(1), n.stride(0),
-                             reduction_type_ == LossReduction::MEAN ? MARIUS_REDUCE_MEAN : MARIUS_REDUCE_SUM, fp(lse), fp(rowloss), fp(loss), cur_stream()));
+    Tensor scratch = torch::empty({2 * std::max<int64_t>(p.size(0), 1)}, p.options()), loss = torch::empty({4}, p.options());
+    mcheck(marius_loss_scores(kind(), margin(), fp(p), fp(n), p.size(0), (int32_t)n.size(1), n.stride(0),
+                              reduction_type_ == LossReduction::MEAN ? MARIUS_REDUCE_MEAN : MARIUS_REDUCE_SUM, fp(scratch), fp(loss), cur_stream()));
     return loss[0];
+}
+
+shared_ptr<LossFunction> getLossFunction(const std::string& type, LossReduction reduction, float margin) {
+    if (type == "SOFTMAX_CE") return std::make_shared<SoftmaxCrossEntropy>(reduction);
+    if (type == "RANKING") return std::make_shared<RankingLoss>(reduction, margin);
+    if (type == "CROSS_ENTROPY") return std::make_shared<CrossEntropyLoss>(reduction);
+    if (type == "BCE_AFTER_SIGMOID") return std::make_shared<BCEAfterSigmoidLoss>(reduction);
+    if (type == "BCE_WITH_LOGITS") return std::make_shared<BCEWithLogitsLoss>(reduction);
+    if (type == "MSE") return std::make_shared<MSELoss>(reduction);
+    if (type == "SOFTPLUS") return std::make_shared<SoftPlusLoss>(reduction);
+    throw std::runtime_error("Unsupported loss function type");  // loss.cpp:207
 }
 
 void Optimizer::save(torch::serialize::OutputArchive& archive, const std::vector<std::string>& keys) {  // optim.cpp:25-40
@@ -746,7 +765,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> Model::forward_lp(shared_ptr<Batch> b
     }
     if (decoder_->decoder_method_ != EdgeDecoderMethod::CORRUPT_NODE) throw MariusRuntimeException("Decoder method currently unsupported.");
     return node_corrupt_forward(decoder_, batch->edges_, batch->node_embeddings_, batch->dst_neg_indices_mapping_, batch->src_neg_indices_mapping_, &ctx_,
-                                batch->dst_neg_filter_, batch->src_neg_filter_, loss_function_ ? loss_function_->reduction_type_ : LossReduction::SUM);
+                                batch->dst_neg_filter_, batch->src_neg_filter_, loss_function_ ? loss_function_->reduction_type_ : LossReduction::SUM,
+                                loss_function_ ? loss_function_->kind() : MARIUS_LOSS_SOFTMAX_CE, loss_function_ ? loss_function_->margin() : 0.f);
 }
 
 static void ensure(Tensor& t, int64_t bytes, torch::Device dev) {

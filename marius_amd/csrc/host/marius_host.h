@@ -262,20 +262,46 @@ std::tuple<Tensor, Tensor> only_pos_forward(shared_ptr<EdgeDecoder> decoder, Ten
 std::tuple<Tensor, Tensor, Tensor, Tensor> node_corrupt_forward(shared_ptr<EdgeDecoder> decoder, Tensor positive_edges, Tensor node_embeddings,
                                                                 Tensor dst_negs, Tensor src_negs, LpContext* ctx = nullptr,
                                                                 Tensor dst_filter = Tensor(), Tensor src_filter = Tensor(),
-                                                                LossReduction reduction = LossReduction::SUM);
+                                                                LossReduction reduction = LossReduction::SUM, int loss_kind = MARIUS_LOSS_SOFTMAX_CE,
+                                                                float margin = 0.f);
 
 // ------------------------------------------------------------------------------------------------ loss / optimizers / reporter
-class LossFunction {
+class LossFunction {  // loss.h:21-31; every subclass of loss.h:33-107 evaluates on the device (marius_loss_scores / marius_lp_loss)
    public:
     virtual ~LossFunction() = default;
     LossReduction reduction_type_ = LossReduction::SUM;
-    virtual Tensor operator()(Tensor y_pred, Tensor targets, bool scores) = 0;
+    virtual int kind() const = 0;  // MARIUS_LOSS_*
+    virtual float margin() const { return 0.f; }
+    virtual bool scores_only() const { return false; }  // SoftmaxCE / Ranking throw for classification input (loss.cpp:51-55, 72-74)
+    virtual const char* name() const = 0;
+    // (pos [B'], neg [B', N], scores = true) -> scalar loss.  scores = false (classification logits + labels) is outside the link-prediction path.
+    virtual Tensor operator()(Tensor y_pred, Tensor targets, bool scores);
 };
-class SoftmaxCrossEntropy : public LossFunction {
+#define MARIUS_LOSS_CLASS(NAME, KIND, SCORES_ONLY)                                                        \
+    class NAME : public LossFunction {                                                                    \
+       public:                                                                                            \
+        explicit NAME(LossReduction reduction = LossReduction::SUM) { reduction_type_ = reduction; }      \
+        int kind() const override { return KIND; }                                                        \
+        bool scores_only() const override { return SCORES_ONLY; }                                         \
+        const char* name() const override { return #NAME; }                                               \
+    }
+MARIUS_LOSS_CLASS(SoftmaxCrossEntropy, MARIUS_LOSS_SOFTMAX_CE, true);        // loss.cpp:50-67
+MARIUS_LOSS_CLASS(CrossEntropyLoss, MARIUS_LOSS_CROSS_ENTROPY, false);      // loss.cpp:89-103
+MARIUS_LOSS_CLASS(BCEAfterSigmoidLoss, MARIUS_LOSS_BCE_AFTER_SIGMOID, false);  // loss.cpp:105-123
+MARIUS_LOSS_CLASS(BCEWithLogitsLoss, MARIUS_LOSS_BCE_WITH_LOGITS, false);   // loss.cpp:125-143
+MARIUS_LOSS_CLASS(MSELoss, MARIUS_LOSS_MSE, false);                         // loss.cpp:145-163
+MARIUS_LOSS_CLASS(SoftPlusLoss, MARIUS_LOSS_SOFTPLUS, false);               // loss.cpp:165-187
+#undef MARIUS_LOSS_CLASS
+class RankingLoss : public LossFunction {  // loss.cpp:69-87, loss.h:43-55
    public:
-    explicit SoftmaxCrossEntropy(LossReduction reduction = LossReduction::SUM) { reduction_type_ = reduction; }
-    Tensor operator()(Tensor pos_scores, Tensor neg_scores, bool scores) override;  // loss.cpp:50-67
+    float margin_;
+    explicit RankingLoss(LossReduction reduction = LossReduction::SUM, float margin = 0.1f) : margin_(margin) { reduction_type_ = reduction; }
+    int kind() const override { return MARIUS_LOSS_RANKING; }
+    float margin() const override { return margin_; }
+    bool scores_only() const override { return true; }
+    const char* name() const override { return "RankingLoss"; }
 };
+shared_ptr<LossFunction> getLossFunction(const std::string& type, LossReduction reduction, float margin = 0.1f);  // loss.cpp:189-209
 
 class Optimizer {
    public:

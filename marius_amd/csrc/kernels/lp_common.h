@@ -40,7 +40,9 @@ struct LpDims {
     int64_t B, Bp;
     int Bc, C, N, d, ndir, edge_cols, relop, cmp;
     int64_t n_ld, d_ld;
-    float gscale;  // 1 (SUM) or 1/Bp (MEAN)
+    float gscale;  // d(reduced loss)/d(loss term): 1 (SUM); MEAN: 1/Bp (SoftmaxCE: one term per row), 1/(Bp N) (Ranking), 1/(Bp (1+N)) (others)
+    int loss;      // MARIUS_LOSS_* with CROSS_ENTROPY folded into SOFTMAX_CE
+    float margin;
 };
 
 // ---- MFMA contraction kernels: argument blocks and tile constants (shared by lp_decoder.hip and lp_fast.hip)
@@ -89,6 +91,61 @@ constexpr int G_TM = 64, G_TN = 128, G_KC = 64;
 constexpr int G_KSA = G_KC + 2;   // [m][k] layout, b64 fragment reads: stride/2 odd
 constexpr int G_TMS = G_TM + 4;   // [k][m] layout
 constexpr int G_TNS = G_TN + 4;   // [k][n] layout
+
+// ---- the loss family of loss.cpp:50-187 on scores.  term(x, y): the loss of one score x with label y (1 = positive, 0 = negative);
+// dterm: its derivative.  `rowval` is the per-row scalar the loss needs (SoftmaxCE: lse; Ranking: pos - margin).
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// binary_cross_entropy(sigmoid(x), y) exactly as ATen evaluates it: log terms clamped at -100, backward (p - y) / max(p (1 - p), 1e-12)
+// times sigmoid'(x) = p (1 - p)  (Loss.cpp: binary_cross_entropy_out_cpu / _backward)
+__device__ __forceinline__ float bce_sig_term(float x, float y) {
+    const float p = sigmoidf_(x);
+    const float lp = fmaxf(__logf(p), -100.f), lq = fmaxf(__logf(1.f - p), -100.f);
+    return -(y * lp + (1.f - y) * lq);
+}
+__device__ __forceinline__ float bce_sig_dterm(float x, float y) {
+    const float p = sigmoidf_(x);
+    const float pq = p * (1.f - p);
+    return (p - y) / fmaxf(pq, 1e-12f) * pq;
+}
+__device__ __forceinline__ float loss_term(int loss, float x, float y) {
+    switch (loss) {
+        case MARIUS_LOSS_BCE_AFTER_SIGMOID: return bce_sig_term(x, y);
+        case MARIUS_LOSS_BCE_WITH_LOGITS:   // (1 - y) x + log(1 + e^-|x|) + max(-x, 0)   (Loss.cpp: binary_cross_entropy_with_logits)
+            return (1.f - y) * x + (fmaxf(-x, 0.f) + log1pf(__expf(-fabsf(x))));
+        case MARIUS_LOSS_MSE: return (x - y) * (x - y);
+        case MARIUS_LOSS_SOFTPLUS: {        // softplus(-(2y - 1) x), beta 1, threshold 20
+            const float z = -(2.f * y - 1.f) * x;
+            return z > 20.f ? z : log1pf(__expf(z));
+        }
+        default: return 0.f;
+    }
+}
+__device__ __forceinline__ float loss_dterm(int loss, float x, float y) {
+    switch (loss) {
+        case MARIUS_LOSS_BCE_AFTER_SIGMOID: return bce_sig_dterm(x, y);
+        case MARIUS_LOSS_BCE_WITH_LOGITS: return sigmoidf_(x) - y;
+        case MARIUS_LOSS_MSE: return 2.f * (x - y);
+        case MARIUS_LOSS_SOFTPLUS: {
+            const float sg = -(2.f * y - 1.f);
+            const float z = sg * x;
+            return sg * (z > 20.f ? 1.f : sigmoidf_(z));
+        }
+        default: return 0.f;
+    }
+}
+// dL/dS of a negative score (label 0) for any loss; Ranking: 1[s - pos + margin > 0]
+__device__ __forceinline__ float loss_dneg(int loss, float s, float rowval, float gscale) {
+    if (loss == MARIUS_LOSS_SOFTMAX_CE) return gscale * __expf(s - rowval);
+    if (loss == MARIUS_LOSS_RANKING) return (s - rowval > 0.f) ? gscale : 0.f;
+    return gscale * loss_dterm(loss, s, 0.f);
+}
+// generic-loss form of dscore (used by the generic backward kernels when D.loss != SOFTMAX_CE)
+template <bool L2>
+__device__ __forceinline__ float dscore_any(const LpDims& D, float s, float rowval) {
+    const float q = loss_dneg(D.loss, s, rowval, D.gscale);
+    if (L2) return (s > 1.0000001e-4f) ? (-q / s) : 0.f;
+    return q;
+}
 
 template <bool L2>
 __device__ __forceinline__ float dscore(float s, float lse, float gscale) {

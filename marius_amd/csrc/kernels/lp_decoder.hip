@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256) void lp_filter_kernel(float* S, int64_t n_ld, 
 
 // one wave per (row, dir): lse = log(e^pos + sum_j e^S_j); rowloss = lse - pos
 __global__ __launch_bounds__(256) void lp_lse_kernel(const float* __restrict__ S, int64_t n_ld, const float* __restrict__ pos,
-                                                     int64_t rows, int N, float* __restrict__ lse, float* __restrict__ rowloss) {
+                                                     int64_t rows, int N, float* __restrict__ lse, float* __restrict__ rowloss,
+                                                     float* __restrict__ dpos, float gscale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -367,12 +368,50 @@ __global__ __launch_bounds__(256) void lp_lse_kernel(const float* __restrict__ S
         const float l = m + __logf(sum);
         lse[row] = l;
         rowloss[row] = l - p;
+        if (dpos) dpos[row] = (__expf(p - l) - 1.f) * gscale;
+    }
+}
+
+// Every other loss of loss.cpp on the materialised scores: one wave per (row, dir).  rowloss = sum of the row's terms, dpos = dL/dpos,
+// rowval (stored in the lse array) = what the backward contractions need per row (Ranking: pos - margin).
+__global__ __launch_bounds__(256) void lp_loss_terms_kernel(const float* __restrict__ S, int64_t n_ld, const float* __restrict__ pos, int64_t rows, int N,
+                                                            int loss, float margin, float gscale, float* __restrict__ rowval,
+                                                            float* __restrict__ rowloss, float* __restrict__ dpos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* s = S + row * n_ld;
+    const float p = pos[row];
+    float sum = 0.f, cnt = 0.f;
+    if (loss == MARIUS_LOSS_RANKING) {
+        for (int c = lane; c < N; c += 64) {
+            const float t = s[c] - p + margin;
+            if (t > 0.f) {
+                sum += t;
+                cnt += 1.f;
+            }
+        }
+    } else {
+        for (int c = lane; c < N; c += 64) sum += loss_term(loss, s[c], 0.f);
+    }
+    sum = wave_sum(sum);
+    cnt = wave_sum(cnt);
+    if (lane == 0) {
+        if (loss == MARIUS_LOSS_RANKING) {
+            rowval[row] = p - margin;
+            rowloss[row] = sum;
+            if (dpos) dpos[row] = -cnt * gscale;
+        } else {
+            rowval[row] = 0.f;
+            rowloss[row] = sum + loss_term(loss, p, 1.f);
+            if (dpos) dpos[row] = loss_dterm(loss, p, 1.f) * gscale;
+        }
     }
 }
 
 // merge the per-group partials of the fused score epilogue with the positive score: lse = log(e^pos + sum_g l_g e^{m_g})
 __global__ __launch_bounds__(256) void lp_lse_merge_kernel(const float* __restrict__ part, int ng, const float* __restrict__ pos, int64_t rows,
-                                                           float* __restrict__ lse, float* __restrict__ rowloss) {
+                                                           float* __restrict__ lse, float* __restrict__ rowloss, float* __restrict__ dpos, float gscale) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
     const float p = pos[row];
@@ -388,6 +427,7 @@ __global__ __launch_bounds__(256) void lp_lse_merge_kernel(const float* __restri
     const float l = m + __logf(sum);
     lse[row] = l;
     rowloss[row] = l - p;
+    dpos[row] = (__expf(p - l) - 1.f) * gscale;
 }
 
 // deterministic sum of rowloss: ONE block reduces each direction in turn -> loss[1 + dir], then loss[0] = rhs + lhs (model.cpp:309-312)
@@ -464,10 +504,10 @@ __global__ __launch_bounds__(256) void lp_grad_adj_kernel(GradArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < D.Bc && j < D.N) {
                 const float4 s = *reinterpret_cast<const float4*>(S + (int64_t)m * D.n_ld + j);
-                v.x = dscore<L2>(s.x, lse_r[it], D.gscale);
-                if (j + 1 < D.N) v.y = dscore<L2>(s.y, lse_r[it], D.gscale);
-                if (j + 2 < D.N) v.z = dscore<L2>(s.z, lse_r[it], D.gscale);
-                if (j + 3 < D.N) v.w = dscore<L2>(s.w, lse_r[it], D.gscale);
+                v.x = dscore_any<L2>(D, s.x, lse_r[it]);
+                if (j + 1 < D.N) v.y = dscore_any<L2>(D, s.y, lse_r[it]);
+                if (j + 2 < D.N) v.z = dscore_any<L2>(D, s.z, lse_r[it]);
+                if (j + 3 < D.N) v.w = dscore_any<L2>(D, s.w, lse_r[it]);
             }
             float* p = Qs + row * G_KSA + 4 * qpiece;
             *reinterpret_cast<float2*>(p) = make_float2(v.x, v.y);
@@ -567,10 +607,10 @@ __global__ __launch_bounds__(256) void lp_grad_neg_kernel(GradArgs a) {
             if (i < D.Bc && j < D.N) {
                 const float l = lse[i];
                 const float4 s = *reinterpret_cast<const float4*>(S + (int64_t)i * D.n_ld + j);
-                v.x = dscore<L2>(s.x, l, D.gscale);
-                if (j + 1 < D.N) v.y = dscore<L2>(s.y, l, D.gscale);
-                if (j + 2 < D.N) v.z = dscore<L2>(s.z, l, D.gscale);
-                if (j + 3 < D.N) v.w = dscore<L2>(s.w, l, D.gscale);
+                v.x = dscore_any<L2>(D, s.x, l);
+                if (j + 1 < D.N) v.y = dscore_any<L2>(D, s.y, l);
+                if (j + 2 < D.N) v.z = dscore_any<L2>(D, s.z, l);
+                if (j + 3 < D.N) v.w = dscore_any<L2>(D, s.w, l);
             }
             *reinterpret_cast<float4*>(Qs + row * G_TMS + 4 * qpiece) = v;
         }
@@ -640,7 +680,7 @@ struct EdgeBwdArgs {
     int64_t rel_ld;
     const float* adj;
     const float* pos;
-    const float* lse;
+    const float* dpos;  // [ndir][Bp] dL/dpos (written by marius_lp_loss)
     const float* dadj;
     float* gocc;     // rows [0,B) = src occurrences, [B,2B) = dst occurrences
     float* grel[2];  // [B, d_ld]
@@ -666,10 +706,8 @@ __global__ __launch_bounds__(256) void lp_edge_bwd_kernel(EdgeBwdArgs a) {
 
     float coef[2], posv[2];
     for (int dir = 0; dir < D.ndir; ++dir) {
-        const float p = a.pos[(int64_t)dir * D.Bp + i];
-        const float l = a.lse[(int64_t)dir * D.Bp + i];
-        coef[dir] = (__expf(p - l) - 1.f) * D.gscale;  // dL/dpos
-        posv[dir] = p;
+        coef[dir] = a.dpos[(int64_t)dir * D.Bp + i];  // dL/dpos
+        posv[dir] = a.pos[(int64_t)dir * D.Bp + i];
     }
 
     for (int c = lane; c < span; c += 64) {
@@ -765,10 +803,8 @@ __global__ __launch_bounds__(256) void lp_edge_bwd2_kernel(EdgeBwdArgs a) {
         ld4(a.dadj + rowoff, dv[dir]);
         has_rel[dir] = (D.edge_cols == 3) && (a.rel[dir] != nullptr);
         if (has_rel[dir]) ld4(a.rel[dir] + ed[1] * a.rel_ld, r[dir]);
-        const float p = a.pos[(int64_t)dir * D.Bp + i];
-        const float lse = a.lse[(int64_t)dir * D.Bp + i];
-        coef[dir] = (__expf(p - lse) - 1.f) * D.gscale;  // dL/dpos
-        posv[dir] = p;
+        coef[dir] = a.dpos[(int64_t)dir * D.Bp + i];  // dL/dpos
+        posv[dir] = a.pos[(int64_t)dir * D.Bp + i];
     }
     float out_s[4] = {0.f, 0.f, 0.f, 0.f}, out_t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -876,6 +912,7 @@ static int lse_fused_groups(const marius_lp_desc* d, const LpDims& D) {
     const char* e = getenv("MARIUS_NO_FUSED_LSE");
     if (e && e[0] == '1') return 0;
     if (kernel_level() != 2) return 0;
+    if (D.loss != MARIUS_LOSS_SOFTMAX_CE) return 0;  // the other losses read the materialised scores
     if ((d->dst_filter && d->n_dst_filter > 0) || (d->src_filter && d->n_src_filter > 0)) return 0;
     int ntpg, ng;
     const char v = scores_variant(d, D);
@@ -916,7 +953,15 @@ static int fill_dims(const marius_lp_desc* d, LpDims& D) {
     D.cmp = (d->cmp == MARIUS_CMP_COSINE) ? MARIUS_CMP_DOT : d->cmp;  // CosineCompare scores un-normalised tensors (comparators.cpp:43-60)
     D.n_ld = (d->N + 3) / 4 * 4;
     D.d_ld = (d->d + 3) / 4 * 4;
-    D.gscale = (d->reduction == MARIUS_REDUCE_MEAN) ? 1.f / (float)D.Bp : 1.f;
+    MARIUS_REQUIRE(d->loss >= MARIUS_LOSS_SOFTMAX_CE && d->loss <= MARIUS_LOSS_SOFTPLUS, "lp: unknown loss type %d", d->loss);
+    D.loss = (d->loss == MARIUS_LOSS_CROSS_ENTROPY) ? MARIUS_LOSS_SOFTMAX_CE : d->loss;  // same function of the same 1 + N scores
+    D.margin = d->margin;
+    {   // MEAN divides by the number of loss terms: rows (SoftmaxCE), Bp x N (Ranking: neg vs pos pairs), Bp x (1 + N) (elementwise losses)
+        double terms = (double)D.Bp;
+        if (D.loss == MARIUS_LOSS_RANKING) terms *= (double)D.N;
+        else if (D.loss != MARIUS_LOSS_SOFTMAX_CE) terms *= (double)(D.N + 1);
+        D.gscale = (d->reduction == MARIUS_REDUCE_MEAN) ? (float)(1.0 / terms) : 1.f;
+    }
     // Bc * (C - 1) >= B leaves whole chunks of padding rows (a short last batch): legal, pad_and_reshape pads to Bc * C rows
     return MARIUS_OK;
 }
@@ -962,6 +1007,9 @@ static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layou
     L->negt = take((size_t)D.C * D.ndir * 3 * L->kp * ((D.N + 31) / 32 * 32) * 2);
     L->adjt = take((size_t)D.C * D.ndir * 3 * L->kp * ((D.Bc + 31) / 32 * 32) * 2);
     L->gradpart = take(grad16_sk_part_bytes());
+    base = take(rows * 4 * D.ndir);
+    L->dpos[0] = L->dpos[1] = 0;
+    for (int dir = 0; dir < D.ndir; ++dir) L->dpos[dir] = base + (size_t)dir * rows * 4;
     L->total_bytes = off;
     return MARIUS_OK;
 }
@@ -1099,15 +1147,22 @@ extern "C" int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout
     const int64_t rows = D.Bp * D.ndir;
     {
         ProfScope ps(PROF_LP_LSE, st);
-        if (lse_fused(desc, D)) {
+        float* dpos = (float*)(ws + L->dpos[0]);
+        if (D.loss != MARIUS_LOSS_SOFTMAX_CE) {
+            lp_loss_terms_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>((const float*)(ws + L->neg[0]), D.n_ld,
+                                                                                     (const float*)(ws + L->pos[0]), rows, D.N, D.loss, D.margin,
+                                                                                     D.gscale, (float*)(ws + L->lse[0]),
+                                                                                     (float*)(ws + L->rowloss[0]), dpos);
+        } else if (lse_fused(desc, D)) {
             const int ng = lse_fused_groups(desc, D);
             lp_lse_merge_kernel<<<dim3((unsigned)cdiv(rows, 256)), dim3(256), 0, st>>>((const float*)(ws + L->lsepart), ng,
                                                                                       (const float*)(ws + L->pos[0]), rows,
-                                                                                      (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]));
+                                                                                      (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]), dpos,
+                                                                                      D.gscale);
         } else {
             lp_lse_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>((const float*)(ws + L->neg[0]), D.n_ld,
                                                                               (const float*)(ws + L->pos[0]), rows, D.N,
-                                                                              (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]));
+                                                                              (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]), dpos, D.gscale);
         }
     }
     rc = check_launch("lp_lse");
@@ -1148,7 +1203,8 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     dim3 ga_grid(nblk, (unsigned)cdiv(D.Bc, G_TM), (unsigned)(D.C * D.ndir));
     dim3 gn_grid(nblk, (unsigned)cdiv(D.N, G_TM), (unsigned)(D.C * D.ndir));
     {
-        const int lvl = kernel_level();
+        // the tuned contraction kernels hard-code V = exp(S - lse); every other loss runs the generic kernels (dscore_any)
+        const int lvl = (D.loss == MARIUS_LOSS_SOFTMAX_CE) ? kernel_level() : 0;
         const char* sp = getenv("MARIUS_GRAD_SPLIT");  // 1 = separate launches for dAdj / dNeg (per-kernel timing)
         const bool split = sp && sp[0] == '1';
         bool done = false;
@@ -1203,7 +1259,7 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     ea.rel_ld = desc->rel_ld;
     ea.adj = ga.adj;
     ea.pos = (const float*)(ws + L->pos[0]);
-    ea.lse = ga.lse;
+    ea.dpos = (const float*)(ws + L->dpos[0]);
     ea.dadj = ga.dadj;
     ea.gocc = ga.gocc;
     ea.grel[0] = (float*)(ws + L->grel[0]);
@@ -1221,6 +1277,32 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
             lp_edge_bwd_kernel<<<dim3((unsigned)cdiv(D.B, 4)), dim3(256), 0, st>>>(ea);
     }
     return check_launch("lp_edge_bwd");
+}
+
+extern "C" int marius_loss_scores(int32_t loss_type, float margin, const float* pos, const float* neg, int64_t rows, int32_t N, int64_t neg_ld,
+                                  int32_t reduction, float* scratch, float* loss, marius_stream_t stream) {
+    MARIUS_REQUIRE(rows >= 0 && N >= 0 && neg_ld >= N, "loss_scores: bad sizes");
+    MARIUS_REQUIRE(loss_type >= MARIUS_LOSS_SOFTMAX_CE && loss_type <= MARIUS_LOSS_SOFTPLUS, "loss_scores: unknown loss type %d", loss_type);
+    MARIUS_REQUIRE(loss && (rows == 0 || (pos && neg && scratch)), "loss_scores: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int lt = loss_type == MARIUS_LOSS_CROSS_ENTROPY ? MARIUS_LOSS_SOFTMAX_CE : loss_type;
+    MARIUS_REQUIRE(lt != MARIUS_LOSS_SOFTMAX_CE || neg_ld % 4 == 0 || N < 4, "loss_scores: SoftmaxCE needs a row pitch that is a multiple of 4");
+    double terms = (double)rows;
+    if (lt == MARIUS_LOSS_RANKING) terms *= (double)N;
+    else if (lt != MARIUS_LOSS_SOFTMAX_CE) terms *= (double)(N + 1);
+    const float scale = (reduction == MARIUS_REDUCE_MEAN && terms > 0) ? (float)(1.0 / terms) : 1.f;
+    float* rowloss = scratch;
+    float* rowval = scratch + rows;
+    if (rows > 0) {
+        if (lt == MARIUS_LOSS_SOFTMAX_CE)
+            lp_lse_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>(neg, neg_ld, pos, rows, N, rowval, rowloss, nullptr, scale);
+        else
+            lp_loss_terms_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>(neg, neg_ld, pos, rows, N, lt, margin, scale, rowval, rowloss, nullptr);
+        int rc = check_launch("loss_scores");
+        if (rc) return rc;
+    }
+    lp_loss_reduce_kernel<<<dim3(1), dim3(1024), 0, st>>>(rowloss, rows, 1, scale, loss);
+    return check_launch("loss_scores_reduce");
 }
 
 extern "C" int marius_compute_ranks(const float* pos, const float* neg, int64_t rows, int32_t N, int64_t neg_ld, int64_t* ranks,
@@ -1241,7 +1323,7 @@ extern "C" int marius_softmax_ce(const float* pos, const float* neg, int64_t row
     hipStream_t st = as_stream(stream);
     const int n_eff = (neg_ld % 4 == 0) ? N : 0;
     (void)n_eff;
-    lp_lse_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>(neg, neg_ld, pos, rows, N, lse, rowloss);
+    lp_lse_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>(neg, neg_ld, pos, rows, N, lse, rowloss, nullptr, 1.f);
     lp_loss_reduce_kernel<<<dim3(1), dim3(1024), 0, st>>>(rowloss, rows, 1, reduction == MARIUS_REDUCE_MEAN ? 1.f / (float)rows : 1.f, loss);
     return check_launch("softmax_ce");
 }

@@ -52,9 +52,9 @@ def marius_train(cfg, log=print, train=True):
     dec_cls = {"DISTMULT": H.DistMult, "COMPLEX": H.ComplEx, "TRANSE": H.TransE}[dec_cfg["type"]]
     method = getattr(H.EdgeDecoderMethod, dec_cfg["options"].get("edge_decoder_method", "CORRUPT_NODE"))
     decoder = dec_cls(R, d, dev, bool(dec_cfg["options"].get("inverse_edges", True)), method)
-    if cfg["model"]["loss"]["type"] != "SOFTMAX_CE":
-        raise NotImplementedError("loss %s: only SOFTMAX_CE is on the fused path" % cfg["model"]["loss"]["type"])
-    loss = H.SoftmaxCrossEntropy(cfg["model"]["loss"]["options"].get("reduction", "SUM"))
+    lopt = cfg["model"]["loss"].get("options") or {}
+    # getLossFunction (loss.cpp:189-209); RankingLossOptions.margin defaults to 0.1 (datatypes.py:41-43)
+    loss = H.getLossFunction(str(cfg["model"]["loss"]["type"]).upper(), str(lopt.get("reduction", "SUM")), float(lopt.get("margin", 0.1)))
     model = H.Model(decoder, loss, H.LinkPredictionReporter(), dev)
     dopt = cfg["model"]["dense_optimizer"]
     o = dopt.get("options") or {}

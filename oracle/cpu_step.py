@@ -18,6 +18,7 @@ class CpuLinkPredictionStep:
         self.inverse, self.reduction, self.sparse_lr, self.dense_lr = inverse_edges, reduction, sparse_lr, dense_lr
         self.rel = O.init_relations(decoder, num_relations, self.d)
         self.inv_rel = O.init_relations(decoder, num_relations, self.d) if inverse_edges else None
+        self.loss, self.margin = "SOFTMAX_CE", 0.1
         self.rel_sum = torch.zeros_like(self.rel)
         self.inv_rel_sum = torch.zeros_like(self.rel) if inverse_edges else None
 
@@ -46,7 +47,7 @@ class CpuLinkPredictionStep:
         emb = O.index_read(self.table, uniq)
         st = O.index_read(self.state, uniq)
         out = O.train_batch(self.decoder, emb, st, edges_local, dst_map, src_map, self.rel, self.inv_rel, dst_filter, src_filter,
-                            self.reduction, self.sparse_lr)
+                            self.reduction, self.sparse_lr, self.loss, self.margin)
         O.dense_adagrad_step(self.rel, out["rel_grad"], self.rel_sum, self.dense_lr)
         if self.inverse:
             O.dense_adagrad_step(self.inv_rel, out["inv_rel_grad"], self.inv_rel_sum, self.dense_lr)

@@ -200,6 +200,36 @@ def softmax_cross_entropy(pos, neg, reduction="sum"):
     return torch.nn.functional.cross_entropy(y_pred, labels, reduction=reduction)
 
 
+def _labels(pos, neg):
+    """scores_to_labels(pos, neg.flatten(0, 1), one_hot=True), loss.cpp:37-48: 1-D [B' + B' N] predictions and 1 / 0 labels."""
+    y = torch.cat([pos, neg.flatten(0, 1)], -1)
+    return y, torch.cat([torch.ones_like(pos), torch.zeros_like(neg.flatten(0, 1))], -1)
+
+
+def loss_function(kind, pos, neg, reduction="sum", margin=0.1):
+    """Every LossFunction::operator()(pos, neg, scores=true) of loss.cpp:50-187, with the same torch.nn.functional calls."""
+    F = torch.nn.functional
+    kind = kind.upper()
+    if kind == "SOFTMAX_CE":
+        return softmax_cross_entropy(pos, neg, reduction)
+    if kind == "RANKING":  # :69-87  margin_ranking_loss(neg, pos.unsqueeze(1), -1, margin)
+        return F.margin_ranking_loss(neg, pos.unsqueeze(1), pos.new_full((1, 1), -1), margin=margin, reduction=reduction)
+    if kind == "CROSS_ENTROPY":  # :89-103  CE over [pos, neg...] with label 0
+        y = torch.cat([pos.unsqueeze(1), neg], -1)
+        return F.cross_entropy(y, torch.zeros(pos.size(0), dtype=torch.int64), reduction=reduction)
+    y, lab = _labels(pos, neg)
+    if kind == "BCE_AFTER_SIGMOID":  # :105-123
+        return F.binary_cross_entropy(y.sigmoid(), lab, reduction=reduction)
+    if kind == "BCE_WITH_LOGITS":  # :125-143
+        return F.binary_cross_entropy_with_logits(y, lab, reduction=reduction)
+    if kind == "MSE":  # :145-163
+        return F.mse_loss(y, lab, reduction=reduction)
+    if kind == "SOFTPLUS":  # :165-187
+        out = F.softplus(-1 * (2 * lab - 1) * y)
+        return out.mean() if reduction == "mean" else out.sum()
+    raise ValueError(kind)
+
+
 # ----------------------------------------------------------------------------- a15: sparse Adagrad rule
 def accumulate_gradients(grad, state, lr):
     """data/batch.cpp:62-79 — returns (node_gradients_ = dw, node_state_update_ = ds); mutates state like the reference."""
@@ -299,7 +329,7 @@ def index_add(table, ids, values):
 
 # ----------------------------------------------------------------------------- a12/a14/a17: one train step on a batch
 def train_batch(decoder, node_embeddings, node_state, edges, dst_neg_map, src_neg_map, relations, inverse_relations,
-                dst_filter=None, src_filter=None, reduction="sum", sparse_lr=0.1):
+                dst_filter=None, src_filter=None, reduction="sum", sparse_lr=0.1, loss="SOFTMAX_CE", margin=0.1):
     """nn/model.cpp:290-333 (train_batch) + :252-288 (forward_lp) on batch-local tensors.
 
     Returns dict with scores, loss, node grad [U,d], relation grads, dw, ds.
@@ -311,11 +341,11 @@ def train_batch(decoder, node_embeddings, node_state, edges, dst_neg_map, src_ne
     neg = apply_score_filter(neg, dst_filter)
     if inv_neg is not None:
         inv_neg = apply_score_filter(inv_neg, src_filter)
-        rhs = softmax_cross_entropy(pos, neg, reduction)
-        lhs = softmax_cross_entropy(inv_pos, inv_neg, reduction)
+        rhs = loss_function(loss, pos, neg, reduction, margin)
+        lhs = loss_function(loss, inv_pos, inv_neg, reduction, margin)
         loss = lhs + rhs
     else:
-        loss = softmax_cross_entropy(pos, neg, reduction)
+        loss = loss_function(loss, pos, neg, reduction, margin)
     loss.backward()
     state = node_state.clone()
     dw, ds = accumulate_gradients(emb.grad, state, sparse_lr)

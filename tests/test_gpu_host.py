@@ -321,3 +321,49 @@ def test_filtered_evaluation_matches_oracle(M, dev):
     assert abs(res[0] - (1.0 / ranks).mean().item()) < 1e-6   # MRR
     assert abs(res[1] - ranks.mean().item()) < 1e-6           # mean rank
     assert abs(res[5] - (ranks <= 10).double().mean().item()) < 1e-9  # Hits@10
+
+
+@pytest.mark.parametrize("name,kind,kw", [("SoftmaxCrossEntropy", "SOFTMAX_CE", {}), ("RankingLoss", "RANKING", {"margin": 5.0}), ("CrossEntropyLoss", "CROSS_ENTROPY", {}),
+                                          ("BCEAfterSigmoidLoss", "BCE_AFTER_SIGMOID", {}), ("BCEWithLogitsLoss", "BCE_WITH_LOGITS", {}),
+                                          ("MSELoss", "MSE", {}), ("SoftPlusLoss", "SOFTPLUS", {})])
+def test_loss_functions_on_reference_test_vectors(M, dev, name, kind, kw):
+    """LossFunction::operator()(pos, neg, scores=true) of every subclass on the fixtures of test/cpp/unit/nn/test_loss.cpp:8-16 (values
+    from the oracle = the same torch.nn.functional calls), the sum / mean relation the reference asserts, and its error behaviour."""
+    cases = [(torch.tensor([500.0]), torch.tensor([[150.0, 100.0, 50.0, 25.0, 10.0]])), (torch.tensor([.1]), torch.tensor([[.001, -.001, -.005, -.1, -10.0]])),
+             (torch.tensor([-500.0]), torch.tensor([[-150.0, -100.0, -50.0, -25.0, 10.0]])),
+             (torch.tensor([.5, 2.5, 5.0, 7.5, 100.0, 250.0]), torch.tensor([[.5, 10.0], [2.5, -1.0], [5.0, 1.0], [7.5, -5.0], [100.0, 20.0], [250.0, 10.0]]))]
+    for reduction in ("sum", "mean"):
+        fn = getattr(M, name)(reduction, **kw)
+        for pos, neg in cases:
+            got = fn(pos.to(dev), neg.to(dev), True).cpu()
+            want = O.loss_function(kind, pos, neg, reduction, kw.get("margin", 0.1))
+            close(got.reshape(1), want.reshape(1), rtol=1e-5)
+    same = M.getLossFunction(kind, "sum", kw.get("margin", 0.1))(cases[3][0].to(dev), cases[3][1].to(dev), True).cpu()
+    close(same.reshape(1), O.loss_function(kind, cases[3][0], cases[3][1], "sum", kw.get("margin", 0.1)).reshape(1), rtol=1e-5)
+    fn = getattr(M, name)("sum", **kw)
+    with pytest.raises(M.MariusRuntimeException):  # check_score_shapes (loss.cpp:7-29): TensorSizeMismatchException
+        fn(cases[3][1].to(dev), cases[3][1].to(dev), True)
+    with pytest.raises(M.MariusRuntimeException):
+        fn(cases[0][0].to(dev), cases[3][1].to(dev), True)
+    if name in ("SoftmaxCrossEntropy", "RankingLoss"):  # loss.cpp:51-55, 72-74
+        with pytest.raises(M.MariusRuntimeException):
+            fn(torch.rand(3, 2, device=dev), torch.tensor([0, 1, 0], device=dev), False)
+
+
+def test_trainer_epoch_with_ranking_loss_matches_cpu_reference_path(M, dev):
+    num_nodes, R, d, B, C, N, E, seed = 3000, 9, 16, 200, 4, 30, 800, 21
+    table, edges_all, emb, state, loader, model0 = _setup(M, dev, "DISTMULT", num_nodes, R, d, B, C, N, E, seed)
+    dec = M.DistMult(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+    model = M.Model(dec, M.RankingLoss("mean", 1.0), M.LinkPredictionReporter(), dev)
+    model.setup_optimizers(0.1)
+    model.sparse_lr = 0.1
+    trainer = M.SynchronousTrainer(loader, model)
+    trainer.train(1)
+    torch.manual_seed(seed)
+    cpu = CpuLinkPredictionStep("DISTMULT", table.clone(), torch.zeros(num_nodes, d), R, B, C, N, reduction="mean")
+    cpu.loss, cpu.margin = "RANKING", 1.0
+    perm = torch.randperm(E)
+    for s in range(E // B):
+        cpu.step(edges_all[perm[s * B:(s + 1) * B]])
+    close(emb.data, cpu.table, rtol=3e-4)
+    close(model.decoder.relations, cpu.rel, rtol=3e-4)

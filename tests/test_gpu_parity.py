@@ -570,3 +570,37 @@ def test_dense_adam_step_matches_reference_ops(H, dev, amsgrad, wd):
     assert_close(p, p_ref, "param", rtol=1e-5)
     if amsgrad:
         assert_close(vm, vm_ref, "max_exp_avg_sq", rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ the other loss functions (loss.cpp:69-187)
+LOSSES = ["RANKING", "CROSS_ENTROPY", "BCE_AFTER_SIGMOID", "BCE_WITH_LOGITS", "MSE", "SOFTPLUS"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss", LOSSES)
+@pytest.mark.parametrize("decoder,use_inverse,B,C,N,d,reduction", [("DISTMULT", True, 100, 10, 50, 50, "sum"), ("COMPLEX", True, 250, 7, 130, 100, "mean"),
+                                                                  ("TRANSE", True, 96, 4, 40, 20, "sum"), ("DISTMULT", False, 5, 4, 6, 8, "mean")])
+def test_lp_other_losses_forward_backward(H, dev, loss, decoder, use_inverse, B, C, N, d, reduction):
+    """loss value, node and relation gradients of every LossFunction subclass against the oracle (autograd through the restated forward
+    with the same torch.nn.functional loss calls as loss.cpp), incl. B % C != 0 (padding rows enter these losses) and the L2 comparator."""
+    U, R, margin = max(40, B), 11, 0.7
+    emb, state, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=B + d + len(loss))
+    want = O.train_batch(decoder, emb, state, edges, dst_neg, src_neg, rel, inv if use_inverse else None, reduction=reduction, loss=loss, margin=margin)
+    relop, cmp = DEC[decoder]
+    W = H.LpWorkspace(relop, cmp, d, B, C, N, use_inverse, H.REDUCE_SUM if reduction == "sum" else H.REDUCE_MEAN, 3, True, dev, loss=H.LOSS[loss], margin=margin)
+    t = lambda x: x.to(dev)
+    W.bind(t(emb), t(edges), t(dst_neg), t(src_neg), t(rel), t(inv) if use_inverse else None)
+    W.forward()
+    W.loss()
+    W.backward()
+    torch.cuda.synchronize()
+    assert_close(W.neg(0), want["neg"], "neg")
+    assert_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss")
+    occ_ids = torch.cat([edges[:, 0], edges[:, 2], src_neg.flatten(), dst_neg.flatten()])
+    node_grad = torch.zeros(U, d, dtype=torch.float64).index_add_(0, occ_ids, W.gocc()[:, :d].cpu().double())
+    assert_close(node_grad.float(), want["node_grad"], "node_grad")
+    rel_grad = torch.zeros(R, d, dtype=torch.float64).index_add_(0, edges[:, 1], W.grel(0)[:, :d].cpu().double())
+    assert_close(rel_grad.float(), want["rel_grad"], "rel_grad")
+    if use_inverse:
+        inv_grad = torch.zeros(R, d, dtype=torch.float64).index_add_(0, edges[:, 1], W.grel(1)[:, :d].cpu().double())
+        assert_close(inv_grad.float(), want["inv_rel_grad"], "inv_rel_grad")

@@ -289,3 +289,32 @@ def test_oracle_adam_matches_torch_optim():
         opt.step()
         O.dense_adam_step(p, grad, m, v, 0.1, step)
     assert torch.allclose(p, p_ref.detach(), rtol=2e-5, atol=1e-6)
+
+
+# ---- the loss family (loss.cpp:50-187): the vectors and assertions of test/cpp/unit/nn/test_loss.cpp:8-16, 84, 119, 141-142, 180, 215-320
+LOSS_POS4 = torch.tensor([.5, 2.5, 5.0, 7.5, 100.0, 250.0])
+LOSS_NEG4 = torch.tensor([[.5, 10.0], [2.5, -1.0], [5.0, 1.0], [7.5, -5.0], [100.0, 20.0], [250.0, 10.0]])
+LOSS_CASES = [(torch.tensor([500.0]), torch.tensor([[150.0, 100.0, 50.0, 25.0, 10.0]])), (torch.tensor([.1]), torch.tensor([[.001, -.001, -.005, -.1, -10.0]])),
+              (torch.tensor([-500.0]), torch.tensor([[-150.0, -100.0, -50.0, -25.0, 10.0]])), (LOSS_POS4, LOSS_NEG4)]
+
+
+@pytest.mark.parametrize("kind,terms", [("SOFTMAX_CE", 6), ("RANKING", 12), ("CROSS_ENTROPY", 6), ("BCE_AFTER_SIGMOID", 18), ("BCE_WITH_LOGITS", 18),
+                                        ("MSE", 18), ("SOFTPLUS", 18)])
+def test_loss_family_reductions_as_in_reference_tests(kind, terms):
+    for pos, neg in LOSS_CASES:  # "ASSERT_NO_THROW" on every fixture, both reductions
+        assert torch.isfinite(O.loss_function(kind, pos, neg, "mean", 0.0)) and torch.isfinite(O.loss_function(kind, pos, neg, "sum", 0.0))
+    s, m = O.loss_function(kind, LOSS_POS4, LOSS_NEG4, "sum", 0.0), O.loss_function(kind, LOSS_POS4, LOSS_NEG4, "mean", 0.0)
+    assert torch.equal(s / terms, m)  # sum / (number of loss terms) == mean, the denominators the reference asserts
+
+
+def test_ranking_loss_grows_with_margin():  # test_loss.cpp:120-142
+    l1, l2, l3 = (O.loss_function("RANKING", LOSS_POS4, LOSS_NEG4, "sum", mg) for mg in (-10.0, 5.0, 10.0))
+    assert l1 < l2 < l3
+
+
+def test_cross_entropy_equals_softmax_ce_on_scores():
+    """Why the device path folds CROSS_ENTROPY into SOFTMAX_CE: log-sum-exp over [pos, neg...] either way."""
+    g = torch.Generator().manual_seed(0)
+    pos, neg = torch.randn(50, generator=g), torch.randn(50, 30, generator=g)
+    a, b = O.loss_function("CROSS_ENTROPY", pos, neg, "sum"), O.loss_function("SOFTMAX_CE", pos, neg, "sum")
+    assert abs(a.item() - b.item()) <= 1e-5 * abs(b.item())
