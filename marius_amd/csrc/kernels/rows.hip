@@ -20,11 +20,19 @@ template <>
 struct VecT<1> { using type = float; };
 
 constexpr int ROW_UNROLL = 4;
-// rows in flight per thread row of the gather: tools/micro/gather_variants.hip on random 400-B rows of a 34 GB table (fresh ids per
-// launch) gives 37.8 us with 4, 34.8 us with 2, 38 us with 8 (a contiguous copy of the same 80 + 80 MB: 28.6 us)
-constexpr int GATHER_UNROLL = 2;
+// rows in flight per thread row of the gather.  tools/micro/gather_variants.hip (random 400-B rows of a 34 GB table, fresh ids per
+// launch, launches back to back) gives 37.8 us with 4, 34.8 us with 2, 38 us with 8; inside the training step (one launch between
+// other kernels) 4 is faster: 57-59 us vs 67-70 us between events.  Default 4; MARIUS_GATHER_UNROLL=2 selects the other build.
+static int gather_unroll() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MARIUS_GATHER_UNROLL");
+        v = (e && e[0] == '2') ? 2 : 4;
+    }
+    return v;
+}
 
-template <int VEC, int NT>
+template <int VEC, int NT, int GATHER_UNROLL>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ ta, const float* __restrict__ tb,
                                                           int64_t table_ld, const int64_t* __restrict__ ids, int64_t n,
                                                           int vpr, float* __restrict__ oa, float* __restrict__ ob,
@@ -178,15 +186,18 @@ static int launch_gather(const float* ta, const float* tb, int64_t table_ld, con
     int vpr = d / vec;
     dim3 block;
     int rpb;
-    row_geometry(vpr, block, rpb, GATHER_UNROLL);
+    const int gu = gather_unroll();
+    row_geometry(vpr, block, rpb, vec == 4 ? gu : 4);
     dim3 grid((unsigned)cdiv(n, rpb));
     ProfScope ps(PROF_GATHER, st);
-    if (vec == 4)
-        gather_rows_kernel<4, NT><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld);
+    if (vec == 4 && gu == 2)
+        gather_rows_kernel<4, NT, 2><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld);
+    else if (vec == 4)
+        gather_rows_kernel<4, NT, 4><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld);
     else if (vec == 2)
-        gather_rows_kernel<2, NT><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld);
+        gather_rows_kernel<2, NT, 4><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld);
     else
-        gather_rows_kernel<1, NT><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld);
+        gather_rows_kernel<1, NT, 4><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld);
     return check_launch("gather_rows");
 }
 
