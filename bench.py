@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--loss", default="SOFTMAX_CE", help="model.loss.type (the headline metric is quoted on SOFTMAX_CE; others for exploration, C++ driver only)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,7 +110,7 @@ def main():
         sampler = M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen)
         loader = M.DataLoader(M.InMemory(edges_all), M.InMemory(table), M.InMemory(state), sampler, gen, B, True)
         dec = {"DISTMULT": M.DistMult, "COMPLEX": M.ComplEx, "TRANSE": M.TransE}[cfg["decoder"]](R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
-        model = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+        model = M.Model(dec, M.getLossFunction(a.loss.upper(), "sum", 0.1), M.LinkPredictionReporter(), dev)
         model.setup_optimizers(0.1)
         model.sparse_lr = 0.1
         trainer = M.SynchronousTrainer(loader, model)

@@ -219,6 +219,7 @@ typedef struct marius_lp_layout {
     size_t adjt;      /* [ncd][3][kp][Bc rounded to 32] bf16: adj rows of each chunk-direction, contraction-major                 */
     size_t gradpart;  /* partial accumulators of the stream-K backward launch (two tiles per persistent workgroup)               */
     size_t dpos[2];   /* [Bp]        dL/d pos, written by marius_lp_loss, read by the edge backward                               */
+    size_t vlog;      /* [ndir][Bp, n_ld] log(dL/dneg / scale) for the non-negative-gradient losses (0 = not allocated)            */
 } marius_lp_layout;
 
 int marius_lp_plan(const marius_lp_desc* desc, marius_lp_layout* layout);
@@ -241,7 +242,7 @@ int marius_softmax_ce(const float* pos, const float* neg, int64_t rows, int32_t 
                       float* rowloss, float* loss, marius_stream_t stream);
 
 /* Any LossFunction::operator()(pos, neg, scores = true) on materialised scores (loss.cpp:50-187): scratch[2 * rows] floats, loss[4]
- * output (loss[0] = reduced loss). */
+ * output (loss[0] = reduced loss).  neg_ld must be a multiple of 4 (the columns N..neg_ld of a row are read but ignored). */
 int marius_loss_scores(int32_t loss_type, float margin, const float* pos, const float* neg, int64_t rows, int32_t N, int64_t neg_ld,
                        int32_t reduction, float* scratch, float* loss, marius_stream_t stream);
 

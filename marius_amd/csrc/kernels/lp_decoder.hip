@@ -376,29 +376,53 @@ __global__ __launch_bounds__(256) void lp_lse_kernel(const float* __restrict__ S
 // rowval (stored in the lse array) = what the backward contractions need per row (Ranking: pos - margin).
 __global__ __launch_bounds__(256) void lp_loss_terms_kernel(const float* __restrict__ S, int64_t n_ld, const float* __restrict__ pos, int64_t rows, int N,
                                                             int loss, float margin, float gscale, float* __restrict__ rowval,
-                                                            float* __restrict__ rowloss, float* __restrict__ dpos) {
+                                                            float* __restrict__ rowloss, float* __restrict__ dpos, float* __restrict__ vlog) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* s = S + row * n_ld;
     const float p = pos[row];
     float sum = 0.f, cnt = 0.f;
-    if (loss == MARIUS_LOSS_RANKING) {
-        for (int c = lane; c < N; c += 64) {
-            const float t = s[c] - p + margin;
+    float* vl = vlog ? vlog + row * n_ld : nullptr;
+    // per element: (loss term, log of dL/dS or -inf).  16-B accesses: n_ld is a multiple of 4 and rows are 16-B aligned.
+    auto one = [&](float x, bool valid, float& lg) {
+        lg = -INFINITY;
+        if (!valid) return;
+        if (loss == MARIUS_LOSS_RANKING) {
+            const float t = x - p + margin;
             if (t > 0.f) {
                 sum += t;
                 cnt += 1.f;
+                lg = 0.f;
             }
+        } else if (loss == MARIUS_LOSS_BCE_WITH_LOGITS || loss == MARIUS_LOSS_SOFTPLUS) {
+            // label 0: term = softplus(x) = max(x, 0) + log1p(e^-|x|); dterm = sigmoid(x), log sigmoid(x) = x - softplus(x)
+            // (SoftPlusLoss: torch's threshold 20 -> term = x, dterm = 1)
+            const float sp = fmaxf(x, 0.f) + __logf(1.f + __expf(-fabsf(x)));  // log1p's extra accuracy (< 6e-8 absolute) is below the sum's rounding
+            const bool lin = (loss == MARIUS_LOSS_SOFTPLUS) && x > 20.f;
+            sum += lin ? x : sp;
+            lg = lin ? 0.f : x - sp;
+        } else {
+            sum += loss_term(loss, x, 0.f);
+            const float v = loss_dterm(loss, x, 0.f);  // >= 0 for the losses that use the buffer
+            lg = v > 0.f ? __logf(v) : -INFINITY;
         }
-    } else {
-        for (int c = lane; c < N; c += 64) sum += loss_term(loss, s[c], 0.f);
+    };
+    for (int c4 = lane; 4 * c4 < n_ld; c4 += 64) {
+        const int c = 4 * c4;
+        const float4 x = *reinterpret_cast<const float4*>(s + c);
+        float4 lg;
+        one(x.x, c < N, lg.x);
+        one(x.y, c + 1 < N, lg.y);
+        one(x.z, c + 2 < N, lg.z);
+        one(x.w, c + 3 < N, lg.w);
+        if (vl) *reinterpret_cast<float4*>(vl + c) = lg;
     }
     sum = wave_sum(sum);
     cnt = wave_sum(cnt);
     if (lane == 0) {
         if (loss == MARIUS_LOSS_RANKING) {
-            rowval[row] = p - margin;
+            rowval[row] = vlog ? 0.f : p - margin;
             rowloss[row] = sum;
             if (dpos) dpos[row] = -cnt * gscale;
         } else {
@@ -966,6 +990,16 @@ static int fill_dims(const marius_lp_desc* d, LpDims& D) {
     return MARIUS_OK;
 }
 
+// Losses whose dL/dS is non-negative (Ranking: 0 / g; the sigmoid family: g sigma(s)) reach the MFMA-tuned backward kernels through a
+// second score-shaped buffer: marius_lp_loss writes log(dL/dS / g) per element (-inf for 0) next to the loss terms it computes anyway,
+// and the backward runs on that buffer with lse = 0, i.e. exactly its SoftmaxCE form g exp(S' - 0).  Not for MSE (dL/dS changes sign)
+// and not for the L2 comparator (its chain rule divides by the score itself).
+static bool vlog_path(const LpDims& D) {
+    const char* e = getenv("MARIUS_NO_VLOG");
+    if (e && e[0] == '1') return false;
+    return D.loss != MARIUS_LOSS_SOFTMAX_CE && D.loss != MARIUS_LOSS_MSE && D.cmp == MARIUS_CMP_DOT && kernel_level() == 2;
+}
+
 static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layout* L) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -1010,6 +1044,7 @@ static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layou
     base = take(rows * 4 * D.ndir);
     L->dpos[0] = L->dpos[1] = 0;
     for (int dir = 0; dir < D.ndir; ++dir) L->dpos[dir] = base + (size_t)dir * rows * 4;
+    L->vlog = vlog_path(D) ? take(rows * D.n_ld * 4 * D.ndir) : 0;
     L->total_bytes = off;
     return MARIUS_OK;
 }
@@ -1152,7 +1187,8 @@ extern "C" int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout
             lp_loss_terms_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>((const float*)(ws + L->neg[0]), D.n_ld,
                                                                                      (const float*)(ws + L->pos[0]), rows, D.N, D.loss, D.margin,
                                                                                      D.gscale, (float*)(ws + L->lse[0]),
-                                                                                     (float*)(ws + L->rowloss[0]), dpos);
+                                                                                     (float*)(ws + L->rowloss[0]), dpos,
+                                                                                     (vlog_path(D) && L->vlog) ? (float*)(ws + L->vlog) : nullptr);
         } else if (lse_fused(desc, D)) {
             const int ng = lse_fused_groups(desc, D);
             lp_lse_merge_kernel<<<dim3((unsigned)cdiv(rows, 256)), dim3(256), 0, st>>>((const float*)(ws + L->lsepart), ng,
@@ -1197,6 +1233,11 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     ga.negocc_off[1] = 2 * D.B;                            // src negatives
     ga.ncols = l2 ? G_TN - 1 : G_TN;
     ga.D = D;
+    const bool vlog = vlog_path(D) && L->vlog;
+    if (vlog) {  // SoftmaxCE form on the log-gradient buffer (see vlog_path)
+        ga.S = (const float*)(ws + L->vlog);
+        ga.D.loss = MARIUS_LOSS_SOFTMAX_CE;
+    }
     { const char* ab = getenv("MARIUS_ABLATE"); ga.ablate = ab ? atoi(ab) : 0; }
     ga.dbg = getenv("MARIUS_TIMELINE_GRADS") ? g_dbg_timeline : nullptr;
     const unsigned nblk = (unsigned)cdiv(D.d, ga.ncols);
@@ -1204,7 +1245,7 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     dim3 gn_grid(nblk, (unsigned)cdiv(D.N, G_TM), (unsigned)(D.C * D.ndir));
     {
         // the tuned contraction kernels hard-code V = exp(S - lse); every other loss runs the generic kernels (dscore_any)
-        const int lvl = (D.loss == MARIUS_LOSS_SOFTMAX_CE) ? kernel_level() : 0;
+        const int lvl = (D.loss == MARIUS_LOSS_SOFTMAX_CE || vlog) ? kernel_level() : 0;
         const char* sp = getenv("MARIUS_GRAD_SPLIT");  // 1 = separate launches for dAdj / dNeg (per-kernel timing)
         const bool split = sp && sp[0] == '1';
         bool done = false;
@@ -1286,7 +1327,7 @@ extern "C" int marius_loss_scores(int32_t loss_type, float margin, const float* 
     MARIUS_REQUIRE(loss && (rows == 0 || (pos && neg && scratch)), "loss_scores: null pointer");
     hipStream_t st = as_stream(stream);
     const int lt = loss_type == MARIUS_LOSS_CROSS_ENTROPY ? MARIUS_LOSS_SOFTMAX_CE : loss_type;
-    MARIUS_REQUIRE(lt != MARIUS_LOSS_SOFTMAX_CE || neg_ld % 4 == 0 || N < 4, "loss_scores: SoftmaxCE needs a row pitch that is a multiple of 4");
+    MARIUS_REQUIRE(neg_ld % 4 == 0, "loss_scores: the row pitch of neg must be a multiple of 4 floats (16-B row accesses)");
     double terms = (double)rows;
     if (lt == MARIUS_LOSS_RANKING) terms *= (double)N;
     else if (lt != MARIUS_LOSS_SOFTMAX_CE) terms *= (double)(N + 1);
@@ -1297,7 +1338,7 @@ extern "C" int marius_loss_scores(int32_t loss_type, float margin, const float* 
         if (lt == MARIUS_LOSS_SOFTMAX_CE)
             lp_lse_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>(neg, neg_ld, pos, rows, N, rowval, rowloss, nullptr, scale);
         else
-            lp_loss_terms_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>(neg, neg_ld, pos, rows, N, lt, margin, scale, rowval, rowloss, nullptr);
+            lp_loss_terms_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>(neg, neg_ld, pos, rows, N, lt, margin, scale, rowval, rowloss, nullptr, nullptr);
         int rc = check_launch("loss_scores");
         if (rc) return rc;
     }

@@ -41,7 +41,7 @@ class LpLayout(C.Structure):
         ("adj", C.c_size_t * 2), ("pos", C.c_size_t * 2), ("neg", C.c_size_t * 2), ("lse", C.c_size_t * 2),
         ("rowloss", C.c_size_t * 2), ("loss", C.c_size_t), ("dadj", C.c_size_t * 2), ("gocc", C.c_size_t),
         ("grel", C.c_size_t * 2), ("aux", C.c_size_t), ("lsepart", C.c_size_t), ("embp", C.c_size_t), ("adjp", C.c_size_t), ("kp", C.c_int64), ("negt", C.c_size_t), ("adjt", C.c_size_t), ("gradpart", C.c_size_t),
-        ("dpos", C.c_size_t * 2),
+        ("dpos", C.c_size_t * 2), ("vlog", C.c_size_t),
     ]
 
 

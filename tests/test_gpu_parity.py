@@ -580,9 +580,14 @@ LOSSES = ["RANKING", "CROSS_ENTROPY", "BCE_AFTER_SIGMOID", "BCE_WITH_LOGITS", "M
 @pytest.mark.parametrize("loss", LOSSES)
 @pytest.mark.parametrize("decoder,use_inverse,B,C,N,d,reduction", [("DISTMULT", True, 100, 10, 50, 50, "sum"), ("COMPLEX", True, 250, 7, 130, 100, "mean"),
                                                                   ("TRANSE", True, 96, 4, 40, 20, "sum"), ("DISTMULT", False, 5, 4, 6, 8, "mean")])
-def test_lp_other_losses_forward_backward(H, dev, loss, decoder, use_inverse, B, C, N, d, reduction):
+@pytest.mark.parametrize("novlog", [False, True])
+def test_lp_other_losses_forward_backward(H, dev, monkeypatch, novlog, loss, decoder, use_inverse, B, C, N, d, reduction):
     """loss value, node and relation gradients of every LossFunction subclass against the oracle (autograd through the restated forward
     with the same torch.nn.functional loss calls as loss.cpp), incl. B % C != 0 (padding rows enter these losses) and the L2 comparator."""
+    if novlog:  # generic backward kernels with the loss-specific dL/dS instead of the log-gradient buffer + tuned kernels
+        if decoder == "TRANSE":
+            pytest.skip("the L2 comparator always takes the generic kernels")
+        monkeypatch.setenv("MARIUS_NO_VLOG", "1")
     U, R, margin = max(40, B), 11, 0.7
     emb, state, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=B + d + len(loss))
     want = O.train_batch(decoder, emb, state, edges, dst_neg, src_neg, rel, inv if use_inverse else None, reduction=reduction, loss=loss, margin=margin)
@@ -594,7 +599,8 @@ def test_lp_other_losses_forward_backward(H, dev, loss, decoder, use_inverse, B,
     W.loss()
     W.backward()
     torch.cuda.synchronize()
-    assert_close(W.neg(0), want["neg"], "neg")
+    assert (W.layout.vlog != 0) == (not novlog and decoder != "TRANSE" and loss not in ("MSE", "CROSS_ENTROPY"))
+    assert_close(W.neg(0), want["neg"], "neg")   # the scores themselves stay intact for the caller
     assert_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss")
     occ_ids = torch.cat([edges[:, 0], edges[:, 2], src_neg.flatten(), dst_neg.flatten()])
     node_grad = torch.zeros(U, d, dtype=torch.float64).index_add_(0, occ_ids, W.gocc()[:, :d].cpu().double())
