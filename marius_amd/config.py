@@ -88,9 +88,13 @@ def load_config(path):
     if len(layers) != 1 or len(layers[0]) != 1 or layers[0][0]["type"] != "EMBEDDING":
         raise NotImplementedError("only the embedding-only encoder is on the link-prediction hot path")
     # filtered (config.cpp:365-376): num_chunks = 1, negatives = -1 (every node), scores of true edges masked (negative.cpp:212-311);
-    # for evaluation marius_train sorts train + validation + test edges (GraphModelStorage::sortAllEdges)
-    if cfg["training"]["negative_sampling"]["filtered"]:
-        raise NotImplementedError("filtered negative sampling during training is not on the path (the reference's examples train unfiltered)")
+    # marius_train sorts train + validation + test edges (GraphModelStorage::sortAllEdges) for every filtered sampler, training included
+    for section in ("training", "evaluation"):
+        ns = cfg[section]["negative_sampling"]
+        if ns["filtered"]:
+            ns.update({"num_chunks": 1, "degree_fraction": 0.0, "negatives_per_positive": -1, "local_filter_mode": "DEG"})
+    if cfg["training"]["negative_sampling"]["filtered"] and cfg["storage"]["embeddings"]["type"] == "PARTITION_BUFFER":
+        raise NotImplementedError("filtered training needs every node in memory: use DEVICE_MEMORY embeddings")
     emb = cfg["storage"]["embeddings"]
     if emb["type"] == "PARTITION_BUFFER":
         o = _merge(PARTITION_BUFFER_DEFAULTS, emb.get("options"))

@@ -145,12 +145,16 @@ def marius_train(cfg, log=print, train=True):
             eval_edges[split] = edges(split, n)
             evals[split] = H.SynchronousEvaluator(H.DataLoader(eval_edges[split], eval_emb or emb, None, sampler(ev["negative_sampling"]), gen,
                                                                int(ev["batch_size"]), False), model)
-    if bool(ev["negative_sampling"].get("filtered", False)) and evals:
-        # GraphModelStorage::sortAllEdges (graph_storage.cpp:745-777): train + validation + test edges are the "true" edges a filtered
-        # ranking must not count as negatives
+    f_train, f_eval = bool(tr["negative_sampling"].get("filtered", False)), bool(ev["negative_sampling"].get("filtered", False)) and bool(evals)
+    if f_train or f_eval:
+        # GraphModelStorage::sortAllEdges (graph_storage.cpp:745-777; dataloader.cpp:592-598 calls it for any filtered sampler): train +
+        # validation + test edges are the "true" edges that must not count as negatives
         all_edges = torch.cat([train_edges.data.to(torch.int64)] + [e.data.to(torch.int64) for e in eval_edges.values()])
-        for e in evals.values():
-            e.dataloader.graph.sortAllEdges(all_edges)
+        if f_eval:
+            for e in evals.values():
+                e.dataloader.graph.sortAllEdges(all_edges)
+        if f_train:
+            loader.graph.sortAllEdges(all_edges)
 
     def run_eval(split, rec):
         t0 = time.time()

@@ -19,11 +19,15 @@ class CpuLinkPredictionStep:
         self.rel = O.init_relations(decoder, num_relations, self.d)
         self.inv_rel = O.init_relations(decoder, num_relations, self.d) if inverse_edges else None
         self.loss, self.margin = "SOFTMAX_CE", 0.1
+        self.filtered_edges = None  # (src-sorted, dst-sorted) known edges: filtered sampler (negative.cpp:321-325, 354-356)
         self.rel_sum = torch.zeros_like(self.rel)
         self.inv_rel_sum = torch.zeros_like(self.rel) if inverse_edges else None
 
     def get_negatives(self, edges, inverse):
         """negative.cpp:328-366 on the global torch CPU generator."""
+        if self.filtered_edges is not None:  # every node is a negative, true edges masked; no random draw
+            ids = torch.arange(self.num_nodes).unsqueeze(0)
+            return ids, O.compute_filter_corruption_global(self.filtered_edges[0], self.filtered_edges[1], edges, inverse)
         n_deg = int(self.N * self.f)
         n_uni = self.N - n_deg
         rows, deg_rows = [], []

@@ -367,3 +367,32 @@ def test_trainer_epoch_with_ranking_loss_matches_cpu_reference_path(M, dev):
         cpu.step(edges_all[perm[s * B:(s + 1) * B]])
     close(emb.data, cpu.table, rtol=3e-4)
     close(model.decoder.relations, cpu.rel, rtol=3e-4)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_trainer_epoch_with_filtered_training_sampler_matches_cpu_reference_path(M, dev, fused):
+    """training.negative_sampling.filtered: true — one chunk, every node a negative, the scores of known edges masked to -1e9 before the
+    loss (negative.cpp:321-325, 354-364; model.cpp:277-285)."""
+    num_nodes, R, d, B, E, seed = 500, 5, 16, 100, 400, 8
+    table, edges_all, emb, state, _, _ = _setup(M, dev, "COMPLEX", num_nodes, R, d, B, 1, 10, E, seed)
+    gen = M.MariusGenerator(seed)
+    sampler = M.CorruptNodeNegativeSampler(7, 33, 0.0, True, M.LocalFilterMode.DEG, gen)  # filtered overrides chunks / negatives
+    loader = M.DataLoader(M.InMemory(edges_all.to(torch.int32).to(dev)), emb, state, sampler, gen, B, True)
+    loader.graph.sortAllEdges(edges_all.to(dev))
+    dec = M.ComplEx(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+    model = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+    model.setup_optimizers(0.1)
+    model.sparse_lr = 0.1
+    trainer = M.SynchronousTrainer(loader, model)
+    trainer.fused_update = fused
+    trainer.train(1)
+    cpu = CpuLinkPredictionStep("COMPLEX", table.clone(), torch.zeros(num_nodes, d), R, B, 1, num_nodes)
+    cpu.filtered_edges = O.sort_all_edges(edges_all)
+    torch.manual_seed(seed)
+    perm = torch.randperm(E)
+    for s in range(E // B):
+        out = cpu.step(edges_all[perm[s * B:(s + 1) * B]])
+    assert out["neg"].shape == (B, num_nodes) and (out["neg"] == -1e9).sum() >= B  # at least the positive edge itself is masked
+    close(emb.data, cpu.table, rtol=3e-4)
+    close(state.data, cpu.state, rtol=3e-4)
+    close(model.decoder.relations, cpu.rel, rtol=3e-4)
