@@ -34,7 +34,9 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_readwrite("data", &Storage::data_)
         .def_readwrite("dim0_size", &Storage::dim0_size_)
         .def_readwrite("dim1_size", &Storage::dim1_size_)
-        .def_readwrite("filename", &Storage::filename_);
+        .def_readwrite("filename", &Storage::filename_)
+        .def_readwrite("edge_bucket_sizes", &Storage::edge_bucket_sizes_)
+        .def("readPartitionSizes", &Storage::readPartitionSizes);
     py::class_<InMemory, Storage, std::shared_ptr<InMemory>>(m, "InMemory")
         .def(py::init<torch::Tensor>(), py::arg("data"))
         .def(py::init([](std::string filename, int64_t dim0, int64_t dim1, py::object dtype, torch::Device device) {
@@ -48,7 +50,9 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("rangePut", &InMemory::rangePut)
         .def("load", &InMemory::load)
         .def("write", &InMemory::write)
-        .def("unload", &InMemory::unload, py::arg("perform_write") = false);
+        .def("unload", &InMemory::unload, py::arg("perform_write") = false)
+        .def("shuffle", &InMemory::shuffle)
+        .def("sort", &InMemory::sort, py::arg("src"));
 
     py::enum_<EdgeBucketOrdering>(m, "EdgeBucketOrdering")
         .value("OLD_BETA", EdgeBucketOrdering::OLD_BETA)

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <fstream>
+#include <functional>
 #include <sstream>
 
 namespace marius_amd {
@@ -243,6 +244,35 @@ void InMemory::indexAdd(Tensor indices, Tensor values) {  // storage.cpp:651-673
     require_device(data_, "indexAdd");
     mcheck(marius_scatter_add_rows(fp(data_), data_.stride(0), ip(indices), indices.size(0), (int32_t)dim1_size_, fp(values), values.stride(0),
                                    cur_stream()));
+}
+void Storage::readPartitionSizes(const std::string& filename) {
+    std::ifstream f(filename);
+    if (!f) throw std::runtime_error("");
+    edge_bucket_sizes_.clear();
+    int64_t v;
+    while (f >> v) edge_bucket_sizes_.push_back(v);
+}
+static void permute_rows(Tensor& data, const std::vector<int64_t>& buckets, const std::function<Tensor(const Tensor&)>& order) {
+    if (buckets.empty()) {
+        data.copy_(data.index_select(0, order(data)));
+        return;
+    }
+    int64_t start = 0;
+    for (int64_t n : buckets) {
+        if (n > 1) {
+            Tensor b = data.narrow(0, start, n);
+            b.copy_(b.index_select(0, order(b)));
+        }
+        start += n;
+    }
+}
+void InMemory::shuffle() {
+    if (!loaded_) load();
+    permute_rows(data_, edge_bucket_sizes_, [](const Tensor& b) { return torch::randperm(b.size(0), torch::TensorOptions().dtype(torch::kInt64).device(b.device())); });
+}
+void InMemory::sort(bool src) {
+    if (!loaded_) load();
+    permute_rows(data_, edge_bucket_sizes_, [src](const Tensor& b) { return torch::argsort(b.select(1, src ? 0 : -1)); });
 }
 Tensor InMemory::range(int64_t offset, int64_t n) {
     if (!data_.defined()) throw std::runtime_error("");
@@ -945,6 +975,7 @@ void DataLoader::setEdgeBucketSizes(std::vector<int64_t> sizes) {
 void DataLoader::loadStorage() {
     if (!partitioned()) return;
     auto o = pb_embeddings_->options_;
+    if (edge_bucket_starts_.empty() && !edges_->edge_bucket_sizes_.empty()) setEdgeBucketSizes(edges_->edge_bucket_sizes_);
     if ((int64_t)edge_bucket_starts_.size() != (int64_t)o->num_partitions * o->num_partitions + 1)
         throw MariusRuntimeException("DataLoader: partitioned training needs the edge bucket sizes (num_partitions^2 entries)");
     std::tie(buffer_states_, edge_buckets_per_buffer_) = getEdgeBucketOrdering(o->edge_bucket_ordering, o->num_partitions, o->buffer_capacity,

@@ -97,7 +97,9 @@ class Storage {
     torch::Device device_ = torch::kCPU;
     std::string filename_;
     bool loaded_ = false;
+    std::vector<int64_t> edge_bucket_sizes_;  // storage.h:50: sizes of the (src partition, dst partition) buckets of a bucket-sorted edge list
 
+    void readPartitionSizes(const std::string& filename);  // storage.cpp:203-214: one size per line (edges/train_partition_offsets.txt)
     virtual Tensor indexRead(Tensor indices) = 0;
     virtual void indexAdd(Tensor indices, Tensor values) = 0;
     virtual Tensor range(int64_t offset, int64_t n) = 0;
@@ -121,6 +123,10 @@ class InMemory : public Storage {
     void load() override;
     void write() override;
     void unload(bool perform_write) override;
+    // storage.cpp:709-790: permute / sort the rows (within each edge bucket when edge_bucket_sizes_ is set).  torch device ops: this is
+    // data preparation, not the training path; the reference draws the permutation from the device generator, so no bit parity is defined
+    void shuffle();
+    void sort(bool src);
 };
 
 // ------------------------------------------------------------------------------------------------ graph stub + samplers

@@ -87,8 +87,7 @@ def marius_train(cfg, log=print, train=True):
         opts.num_cache_partitions = int(po["num_cache_partitions"])
         opts.edge_bucket_ordering = getattr(H.EdgeBucketOrdering, str(po["edge_bucket_ordering"]).upper())
         opts.randomly_assign_edge_buckets = bool(po["randomly_assign_edge_buckets"])
-        with open(os.path.join(ddir, "edges", "train_partition_offsets.txt")) as f:
-            bucket_sizes = [int(x) for x in f.read().split()]
+        train_edges.readPartitionSizes(os.path.join(ddir, "edges", "train_partition_offsets.txt"))  # io.cpp:110-121
         if not resume:
             limit = math.sqrt(6.0 / (num_nodes + d))
             rows = max(1, (256 << 20) // (4 * d))
@@ -134,8 +133,6 @@ def marius_train(cfg, log=print, train=True):
                                             bool(ns["filtered"]), getattr(H.LocalFilterMode, ns.get("local_filter_mode", "DEG")), gen)
 
     loader = H.DataLoader(train_edges, emb, state, sampler(tr["negative_sampling"]), gen, int(tr["batch_size"]), True)
-    if partitioned:
-        loader.setEdgeBucketSizes(bucket_sizes)
     trainer = H.SynchronousTrainer(loader, model)
     evals = {}
     eval_edges = {}

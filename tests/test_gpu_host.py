@@ -396,3 +396,27 @@ def test_trainer_epoch_with_filtered_training_sampler_matches_cpu_reference_path
     close(emb.data, cpu.table, rtol=3e-4)
     close(state.data, cpu.state, rtol=3e-4)
     close(model.decoder.relations, cpu.rel, rtol=3e-4)
+
+
+def test_storage_shuffle_and_sort_respect_edge_buckets(M, dev, tmp_path):
+    """InMemory::shuffle / sort (storage.cpp:709-790): whole list, or inside each edge bucket once the bucket sizes are known."""
+    g = torch.Generator().manual_seed(3)
+    edges = torch.stack([torch.randint(50, (200,), generator=g), torch.randint(4, (200,), generator=g), torch.randint(50, (200,), generator=g)], 1).to(torch.int32)
+    st = M.InMemory(edges.clone().to(dev))
+    st.sort(True)
+    assert bool((st.data[1:, 0] >= st.data[:-1, 0]).all())
+    st.sort(False)
+    assert bool((st.data[1:, 2] >= st.data[:-1, 2]).all())
+    st.shuffle()
+    assert sorted(map(tuple, st.data.cpu().tolist())) == sorted(map(tuple, edges.tolist()))
+    sizes = tmp_path / "offsets.txt"
+    sizes.write_text("50\n0\n120\n30\n")
+    st = M.InMemory(edges.clone().to(dev))
+    st.readPartitionSizes(str(sizes))
+    assert st.edge_bucket_sizes == [50, 0, 120, 30]
+    st.shuffle()
+    for lo, hi in ((0, 50), (50, 170), (170, 200)):
+        assert sorted(map(tuple, st.data[lo:hi].cpu().tolist())) == sorted(map(tuple, edges[lo:hi].tolist()))
+    st.sort(True)
+    for lo, hi in ((0, 50), (50, 170), (170, 200)):
+        assert bool((st.data[lo + 1:hi, 0] >= st.data[lo:hi - 1, 0]).all())
