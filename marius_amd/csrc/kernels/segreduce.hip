@@ -27,6 +27,7 @@ struct SegArgs {
     int d;
     float* carry;  // [nchunks][2][dpad]
     int dpad;
+    int skip_singletons;  // 1: segments of length 1 are neither loaded nor written (their consumer reads the occurrence row itself)
 };
 
 struct ApplySum {
@@ -87,12 +88,13 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply)
     const int cnt = (int)min((int64_t)SEG_R, a.n - k0);
     const int64_t k1 = k0 + cnt;
     // lane r < cnt owns sorted position k0 + r: its occurrence row, its segment, and whether that segment lies inside the chunk
-    int p = 0, u = -1, complete = 0;
+    int p = 0, u = -1, complete = 0, single = 0;
     if (lane < cnt) {
         p = a.perm[k0 + lane];
         u = (int)a.inverse[p];
         const int s0 = a.seg_offsets[u], s1 = a.seg_offsets[u + 1];
         complete = (s0 >= k0) && (s1 <= k1);
+        single = a.skip_singletons && (s1 - s0 == 1);
     }
     const int u_first = __shfl(u, 0, 64);
     float acc[NIT][VEC];
@@ -100,9 +102,10 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply)
     for (int it = 0; it < NIT; ++it)
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[it][e] = 0.f;
-    int cur = u_first, cur_complete = __shfl(complete, 0, 64);
+    int cur = u_first, cur_complete = __shfl(complete, 0, 64), cur_single = __shfl(single, 0, 64);
 
-    auto flush = [&](int useg, int is_complete) {
+    auto flush = [&](int useg, int is_complete, int is_single) {
+        if (is_single) return;  // nothing was accumulated and nothing is stored
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int col = (lane + it * 64) * VEC;
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply)
 
     for (int b0 = 0; b0 < cnt; b0 += SEG_BATCH) {
         float v[SEG_BATCH][NIT][VEC];
-        int ub[SEG_BATCH], cb[SEG_BATCH];
+        int ub[SEG_BATCH], cb[SEG_BATCH], sb[SEG_BATCH];
 #pragma unroll
         for (int j = 0; j < SEG_BATCH; ++j) {
             const int r = b0 + j;
@@ -130,21 +133,23 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply)
             const int pr = __shfl(p, rr, 64);
             ub[j] = (r < cnt) ? __shfl(u, rr, 64) : -1;
             cb[j] = __shfl(complete, rr, 64);
+            sb[j] = __shfl(single, rr, 64);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int col = (lane + it * 64) * VEC;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[j][it][e] = 0.f;
-                if (r < cnt && col < a.d) load_vec<VEC>(a.rows + (int64_t)pr * a.rows_ld + col, v[j][it]);
+                if (r < cnt && col < a.d && !sb[j]) load_vec<VEC>(a.rows + (int64_t)pr * a.rows_ld + col, v[j][it]);
             }
         }
 #pragma unroll
         for (int j = 0; j < SEG_BATCH; ++j) {
             if (ub[j] < 0) break;
             if (ub[j] != cur) {
-                flush(cur, cur_complete);
+                flush(cur, cur_complete, cur_single);
                 cur = ub[j];
                 cur_complete = cb[j];
+                cur_single = sb[j];
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply)
                 for (int e = 0; e < VEC; ++e) acc[it][e] += v[j][it][e];
         }
     }
-    flush(cur, cur_complete);
+    flush(cur, cur_complete, cur_single);
 }
 
 // phase 2: the chunk in which a boundary-crossing segment STARTS finishes it from the carries
@@ -226,23 +231,30 @@ template <int VEC>
 __global__ __launch_bounds__(256) void adagrad_unique_rows_kernel(const float* __restrict__ g, int64_t g_ld, const int32_t* __restrict__ perm,
                                                                   const int64_t* __restrict__ inverse, int64_t n, const int64_t* __restrict__ uniq,
                                                                   float* __restrict__ table, float* __restrict__ state, int64_t ld, int vpr,
-                                                                  float lr, float eps) {
+                                                                  float lr, float eps, const float* __restrict__ occ, int64_t occ_ld,
+                                                                  const int32_t* __restrict__ seg_offsets) {
 #pragma clang fp contract(off)
     const int64_t U = inverse[perm[n - 1]] + 1;
     const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
     constexpr int UNR = 4;
     int64_t rows[UNR], ids[UNR];
+    const float* grow[UNR];  // the row's gradient: the reduced sum, or (segment of one occurrence) that occurrence's row itself
 #pragma unroll
     for (int k = 0; k < UNR; ++k) {
         rows[k] = ((int64_t)blockIdx.x * UNR + k) * TY + ty;
         ids[k] = rows[k] < U ? uniq[rows[k]] : -1;
+        grow[k] = g + rows[k] * g_ld;
+        if (ids[k] >= 0 && occ) {
+            const int s0 = seg_offsets[rows[k]], s1 = seg_offsets[rows[k] + 1];
+            if (s1 - s0 == 1) grow[k] = occ + (int64_t)perm[s0] * occ_ld;
+        }
     }
     for (int c = tx; c < vpr; c += TX) {
         float gv[UNR][VEC], wv[UNR][VEC], sv[UNR][VEC];
 #pragma unroll
         for (int k = 0; k < UNR; ++k) {
             if (ids[k] >= 0) {
-                load_vec<VEC>(g + rows[k] * g_ld + c * VEC, gv[k]);
+                load_vec<VEC>(grow[k] + c * VEC, gv[k]);
                 load_vec<VEC>(table + ids[k] * ld + c * VEC, wv[k]);
                 load_vec<VEC>(state + ids[k] * ld + c * VEC, sv[k]);
             }
@@ -311,6 +323,7 @@ static int fill_args(SegArgs& a, const float* rows, int64_t rows_ld, const int32
     a.d = d;
     a.carry = (float*)carry;
     a.dpad = dpad_of(d);
+    a.skip_singletons = 0;
     return MARIUS_OK;
 }
 
@@ -360,6 +373,11 @@ extern "C" int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld
     const int64_t g_ld = dpad_of(d);
     int vsum = row_vec_width(rows, rows_ld, d);
     ApplySum ap{gsum, g_ld, nullptr};
+    // most rows of a batch occur once (uniform negatives over a large table): those segments skip the reduction entirely and the
+    // update kernel reads their gradient straight from the occurrence row — no 80 MB round trip through gsum
+    const char* ns = getenv("MARIUS_SEG_NO_SKIP");
+    const bool skip = !(ns && ns[0] == '1') && vec <= vsum;
+    a.skip_singletons = skip ? 1 : 0;
     rc = launch_seg(a, ap, vsum, st);
     if (rc) return rc;
     // (2) row-parallel Adagrad + scatter (ids ascending and unique: race-free, fully pipelined loads)
@@ -368,11 +386,12 @@ extern "C" int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld
     while (tx < vpr && tx < 64) tx <<= 1;
     const int ty = 256 / tx;
     dim3 block(tx, ty, 1), grid((unsigned)cdiv(n, (int64_t)ty * 4));
+    const float* occ = skip ? rows : nullptr;
     if (vec == 4)
-        adagrad_unique_rows_kernel<4><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps);
+        adagrad_unique_rows_kernel<4><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets);
     else if (vec == 2)
-        adagrad_unique_rows_kernel<2><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps);
+        adagrad_unique_rows_kernel<2><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets);
     else
-        adagrad_unique_rows_kernel<1><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps);
+        adagrad_unique_rows_kernel<1><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets);
     return check_launch("segment_adagrad_scatter");
 }
