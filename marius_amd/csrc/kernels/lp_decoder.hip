@@ -434,10 +434,8 @@ __global__ __launch_bounds__(256) void lp_loss_terms_kernel(const float* __restr
 }
 
 // merge the per-group partials of the fused score epilogue with the positive score: lse = log(e^pos + sum_g l_g e^{m_g})
-__global__ __launch_bounds__(256) void lp_lse_merge_kernel(const float* __restrict__ part, int ng, const float* __restrict__ pos, int64_t rows,
-                                                           float* __restrict__ lse, float* __restrict__ rowloss, float* __restrict__ dpos, float gscale) {
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
+__device__ __forceinline__ float lp_lse_merge_row(const float* __restrict__ part, int ng, const float* __restrict__ pos, int64_t rows,
+                                                  float* __restrict__ lse, float* __restrict__ rowloss, float* __restrict__ dpos, float gscale, int64_t row) {
     const float p = pos[row];
     // part is [group][row][2]: consecutive threads read consecutive 8-B pairs
     const float2* pr = reinterpret_cast<const float2*>(part) + row;
@@ -452,7 +450,54 @@ __global__ __launch_bounds__(256) void lp_lse_merge_kernel(const float* __restri
     lse[row] = l;
     rowloss[row] = l - p;
     dpos[row] = (__expf(p - l) - 1.f) * gscale;
+    return l - p;
 }
+
+// blocksum[block] = sum of the block's row losses in a fixed order, so that the final reduction adds a few hundred numbers instead of
+// re-reading every row (blocks never straddle the two directions: the launch covers each direction with its own blocks)
+__global__ __launch_bounds__(256) void lp_lse_merge_kernel(const float* __restrict__ part, int ng, const float* __restrict__ pos, int64_t rows,
+                                                           float* __restrict__ lse, float* __restrict__ rowloss, float* __restrict__ dpos, float gscale,
+                                                           int64_t Bp, float* __restrict__ blocksum) {
+    __shared__ float red[256];
+    const int64_t bpd = (Bp + 255) / 256;                       // blocks per direction
+    const int64_t dir = blockIdx.x / bpd, blk = blockIdx.x - dir * bpd;
+    const int64_t r = blk * 256 + threadIdx.x;
+    const int64_t row = dir * Bp + r;
+    float mine = 0.f;
+    if (r < Bp) mine = lp_lse_merge_row(part, ng, pos, rows, lse, rowloss, dpos, gscale, row);
+    red[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = red[0];
+}
+
+// sum of the per-block partials: loss[1 + dir], loss[0] = rhs + lhs (model.cpp:309-312)
+__global__ __launch_bounds__(256) void lp_loss_reduce_blocks_kernel(const float* __restrict__ blocksum, int64_t bpd, int ndir, float scale, float* loss) {
+    __shared__ float red[256];
+    float tot[2] = {0.f, 0.f};
+    for (int dir = 0; dir < ndir; ++dir) {
+        float s = 0.f;
+        for (int64_t i = threadIdx.x; i < bpd; i += 256) s += blocksum[dir * bpd + i];
+        __syncthreads();
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        tot[dir] = red[0] * scale;
+    }
+    if (threadIdx.x == 0) {
+        loss[1] = tot[0];
+        loss[2] = ndir == 2 ? tot[1] : 0.f;
+        loss[0] = tot[0] + (ndir == 2 ? tot[1] : 0.f);
+        loss[3] = 0.f;
+    }
+}
+
 
 // deterministic sum of rowloss: ONE block reduces each direction in turn -> loss[1 + dir], then loss[0] = rhs + lhs (model.cpp:309-312)
 __global__ __launch_bounds__(1024) void lp_loss_reduce_kernel(const float* rowloss, int64_t Bp, int ndir, float scale, float* loss) {
@@ -1191,10 +1236,16 @@ extern "C" int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout
                                                                                      (vlog_path(D) && L->vlog) ? (float*)(ws + L->vlog) : nullptr);
         } else if (lse_fused(desc, D)) {
             const int ng = lse_fused_groups(desc, D);
-            lp_lse_merge_kernel<<<dim3((unsigned)cdiv(rows, 256)), dim3(256), 0, st>>>((const float*)(ws + L->lsepart), ng,
-                                                                                      (const float*)(ws + L->pos[0]), rows,
-                                                                                      (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]), dpos,
-                                                                                      D.gscale);
+            const int64_t bpd = cdiv(D.Bp, 256);
+            float* blocksum = (float*)(ws + L->aux);  // aux holds row norms only for the L2 comparator's forward; free again by now
+            lp_lse_merge_kernel<<<dim3((unsigned)(bpd * D.ndir)), dim3(256), 0, st>>>((const float*)(ws + L->lsepart), ng,
+                                                                                     (const float*)(ws + L->pos[0]), rows,
+                                                                                     (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]), dpos,
+                                                                                     D.gscale, D.Bp, blocksum);
+            rc = check_launch("lp_lse_merge");
+            if (rc) return rc;
+            lp_loss_reduce_blocks_kernel<<<dim3(1), dim3(256), 0, st>>>(blocksum, bpd, D.ndir, D.gscale, (float*)(ws + L->loss));
+            return check_launch("lp_loss_reduce");
         } else {
             lp_lse_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>((const float*)(ws + L->neg[0]), D.n_ld,
                                                                               (const float*)(ws + L->pos[0]), rows, D.N,
