@@ -439,12 +439,23 @@ __device__ __forceinline__ float lp_lse_merge_row(const float* __restrict__ part
     const float p = pos[row];
     // part is [group][row][2]: consecutive threads read consecutive 8-B pairs
     const float2* pr = reinterpret_cast<const float2*>(part) + row;
-    float m = p;
-    for (int g = 0; g < ng; ++g) m = fmaxf(m, pr[(int64_t)g * rows].x);
-    float sum = __expf(p - m);
-    for (int g = 0; g < ng; ++g) {
-        const float2 v = pr[(int64_t)g * rows];
-        sum += v.y * __expf(v.x - m);
+    float m = p, sum;
+    if (ng <= 16) {  // the common case (N <= 1024): all partials in flight at once, one pass over memory
+        float2 v[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) v[g] = g < ng ? pr[(int64_t)g * rows] : make_float2(-INFINITY, 0.f);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) m = fmaxf(m, v[g].x);
+        sum = __expf(p - m);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) sum += v[g].y * __expf(v[g].x - m);
+    } else {
+        for (int g = 0; g < ng; ++g) m = fmaxf(m, pr[(int64_t)g * rows].x);
+        sum = __expf(p - m);
+        for (int g = 0; g < ng; ++g) {
+            const float2 v = pr[(int64_t)g * rows];
+            sum += v.y * __expf(v.x - m);
+        }
     }
     const float l = m + __logf(sum);
     lse[row] = l;
