@@ -1,0 +1,84 @@
+"""YAML configuration surface (marius_amd/config.py) against the reference's schema defaults and validation rules
+(src/python/tools/configuration/marius_config.py, datatypes.py; src/cpp/src/configuration/config.cpp:358-380).  No GPU needed."""
+import os
+
+import pytest
+import yaml
+
+from marius_amd import config as C
+
+
+def write(tmp_path, user, stats=None):
+    ddir = tmp_path / "ds"
+    ddir.mkdir(exist_ok=True)
+    yaml.safe_dump(stats or {"num_nodes": 100, "num_relations": 4, "num_train": 900, "num_valid": 50, "num_test": 50, "num_edges": 1000},
+                   open(ddir / "dataset.yaml", "w"))
+    user.setdefault("storage", {}).setdefault("dataset", {})["dataset_dir"] = str(ddir)
+    user["storage"].setdefault("device_type", "cuda")
+    path = tmp_path / "cfg.yaml"
+    yaml.safe_dump(user, open(path, "w"))
+    return str(path), str(ddir)
+
+
+def test_defaults_match_reference_schema(tmp_path):
+    path, ddir = write(tmp_path, {})
+    cfg = C.load_config(path)
+    assert cfg["model"]["decoder"] == {"type": "DISTMULT", "options": {"inverse_edges": True, "edge_decoder_method": "CORRUPT_NODE"}}
+    assert cfg["model"]["loss"] == {"type": "SOFTMAX_CE", "options": {"reduction": "SUM"}}
+    assert cfg["training"]["batch_size"] == 1000 and cfg["training"]["num_epochs"] == 10
+    ns = cfg["training"]["negative_sampling"]
+    assert (ns["num_chunks"], ns["negatives_per_positive"], ns["degree_fraction"], ns["filtered"], ns["local_filter_mode"]) == (1, 1000, 0.0, False, "DEG")
+    assert cfg["storage"]["dataset"]["num_nodes"] == 100 and cfg["storage"]["dataset"]["num_train"] == 900  # dataset.yaml merged in
+    assert cfg["storage"]["model_dir"] == os.path.join(ddir, "model_0")   # marius_config.py:47-56
+    os.makedirs(os.path.join(ddir, "model_0"))
+    assert C.load_config(path)["storage"]["model_dir"] == os.path.join(ddir, "model_1")
+    assert isinstance(cfg["model"]["random_seed"], int)
+    assert C.embedding_dim(cfg) == 50
+
+
+def test_filtered_sampler_overrides(tmp_path):
+    """config.cpp:365-376: filtered -> one chunk, every node (-1), no degree negatives; applies to training as well as evaluation."""
+    path, _ = write(tmp_path, {"evaluation": {"negative_sampling": {"filtered": True, "num_chunks": 7, "negatives_per_positive": 33, "degree_fraction": 0.5}},
+                              "training": {"negative_sampling": {"filtered": True}}})
+    cfg = C.load_config(path)
+    for section in ("training", "evaluation"):
+        ns = cfg[section]["negative_sampling"]
+        assert (ns["num_chunks"], ns["negatives_per_positive"], ns["degree_fraction"], ns["local_filter_mode"]) == (1, -1, 0.0, "DEG")
+
+
+def test_partition_buffer_options(tmp_path):
+    """datatypes.py:161-185: defaults, capacity clamped to the partition count, at least two partitions / capacity two."""
+    path, _ = write(tmp_path, {"storage": {"embeddings": {"type": "PARTITION_BUFFER", "options": {"num_partitions": 4, "buffer_capacity": 9}}}})
+    o = C.load_config(path)["storage"]["embeddings"]["options"]
+    assert o["buffer_capacity"] == 4 and o["prefetching"] is True and o["edge_bucket_ordering"] == "COMET" and o["fine_to_coarse_ratio"] == 1
+    assert o["randomly_assign_edge_buckets"] is True and o["num_cache_partitions"] == 0
+    for bad in ({"num_partitions": 1}, {"buffer_capacity": 1}):
+        path, _ = write(tmp_path, {"storage": {"embeddings": {"type": "PARTITION_BUFFER", "options": bad}}})
+        with pytest.raises(ValueError):
+            C.load_config(path)
+    path, _ = write(tmp_path, {"storage": {"embeddings": {"type": "PARTITION_BUFFER"}}, "training": {"negative_sampling": {"filtered": True}}})
+    with pytest.raises(NotImplementedError):
+        C.load_config(path)
+
+
+def test_out_of_scope_settings_are_refused_not_ignored(tmp_path):
+    for user, exc in (({"model": {"learning_task": "NODE_CLASSIFICATION"}}, NotImplementedError),
+                      ({"model": {"encoder": {"layers": [[{"type": "EMBEDDING", "output_dim": 8}], [{"type": "GNN", "output_dim": 8}]]}}}, NotImplementedError),
+                      ({"storage": {"embeddings": {"type": "FLAT_FILE"}}}, NotImplementedError)):
+        path, _ = write(tmp_path, user)
+        with pytest.raises(exc):
+            C.load_config(path)
+    path, ddir = write(tmp_path, {})
+    os.remove(os.path.join(ddir, "dataset.yaml"))
+    with pytest.raises(ValueError):
+        C.load_config(path)
+
+
+def test_marius_train_refuses_cpu_device(tmp_path):
+    """No CPU fallback: device_type cpu is an error, not a silent slow path."""
+    from marius_amd.marius_train import marius_train
+
+    path, _ = write(tmp_path, {"storage": {"device_type": "cpu"}})
+    with pytest.raises(Exception) as e:
+        marius_train(C.load_config(path), log=lambda *a: None)
+    assert "no CPU path" in str(e.value) or "MI355X" in str(e.value) or "HIP" in str(e.value) or "cuda" in str(e.value).lower()
