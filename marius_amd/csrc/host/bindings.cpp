@@ -4,6 +4,7 @@
 
 #include "marius_host.h"
 #include "partition_buffer.h"
+#include "sharded_trainer.h"
 
 namespace py = pybind11;
 using namespace marius_amd;
@@ -292,6 +293,18 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_readwrite("fused_update", &SynchronousTrainer::fused_update_)
         .def_readonly("last_epoch_seconds", &SynchronousTrainer::last_epoch_seconds_)
         .def_readonly("last_edges_per_second", &SynchronousTrainer::last_edges_per_second_);
+    py::class_<ShardedTrainer, std::shared_ptr<ShardedTrainer>>(m, "ShardedTrainer")
+        .def(py::init<std::shared_ptr<DataLoader>, std::shared_ptr<Model>, torch::Tensor, torch::Tensor, int, int, int64_t, std::string, std::string, int, int>(),
+             py::arg("dataloader"), py::arg("model"), py::arg("shard_table"), py::arg("shard_state"), py::arg("rank"), py::arg("world"), py::arg("num_nodes"),
+             py::arg("group_name"), py::arg("side_group_name"), py::arg("staleness") = 1, py::arg("sync_interval") = 16)
+        .def("step", &ShardedTrainer::step, py::call_guard<py::gil_scoped_release>())
+        .def("train_steps", &ShardedTrainer::train_steps, py::arg("n"), py::call_guard<py::gil_scoped_release>())
+        .def("finish", &ShardedTrainer::finish, py::call_guard<py::gil_scoped_release>())
+        .def_readwrite("host_seconds", &ShardedTrainer::host_seconds_)
+        .def_readonly("steps", &ShardedTrainer::steps_)
+        .def_property_readonly("phase_seconds", [](ShardedTrainer& t) { return std::vector<double>(t.phase_seconds_, t.phase_seconds_ + 6); });
+    m.def("c10d_exchange_selftest", &c10d_exchange_selftest, py::arg("group_name"), py::arg("send"), py::arg("send_counts"), py::arg("to_reduce"),
+          py::call_guard<py::gil_scoped_release>());
     py::class_<SynchronousEvaluator, std::shared_ptr<SynchronousEvaluator>>(m, "SynchronousEvaluator")
         .def(py::init<std::shared_ptr<DataLoader>, std::shared_ptr<Model>>())
         .def_readonly("dataloader", &SynchronousEvaluator::dataloader_)

@@ -937,6 +937,33 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
     HIPCHECK(hipStreamWaitEvent(main.stream(), (hipEvent_t)ev_join_, 0));
 }
 
+void Model::backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step) {
+    forward_lp(batch, true);
+    model_backward(*this, batch);
+    bool done = false;
+    if (local_relation_step) done = relation_step_sparse(*this, batch);
+    if (!done) {
+        relation_grads_dense(*this, batch);
+        if (local_relation_step) step();  // optimizer without a touched-rows form: dense step on this replica
+    }
+    const int64_t L = batch->occ_perm_.size(0);
+    ensure(carry_, (int64_t)marius_segment_carry_bytes(L, ctx_.desc.d), device_);
+    const float* gocc = (const float*)((const char*)ctx_.workspace.data_ptr() + ctx_.layout.gocc);
+    mcheck(marius_segment_sum_rows(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
+                                   batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, nullptr, fp(grad_out), grad_out.stride(0),
+                                   carry_.data_ptr(), cur_stream()));
+}
+
+std::vector<Tensor> Model::dense_state() {
+    std::vector<Tensor> out;
+    for (auto& o : optimizers_) {
+        for (auto& p : o->params_) out.push_back(p.first);
+        for (auto& sl : o->state_slots())
+            for (auto& t : *sl.second) out.push_back(t);
+    }
+    return out;
+}
+
 Model::~Model() {
     if (ev_fork_) (void)hipEventDestroy((hipEvent_t)ev_fork_);
     if (ev_join_) (void)hipEventDestroy((hipEvent_t)ev_join_);

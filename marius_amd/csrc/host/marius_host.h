@@ -402,6 +402,11 @@ class Model {
     void setup_optimizer(const std::string& type, float lr, float eps, float beta_1, float beta_2, float weight_decay, bool amsgrad);
     // fused tail used by the trainer for DEVICE_MEMORY tables: backward products -> table/state update in one call
     void backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor state);
+    // sharded node table (sharded_trainer.h): forward + loss + backward, then the per-unique-row gradient sums into grad_out [>= U, d] for
+    // the owners of the rows.  local_relation_step: touched-rows Adagrad step on this replica's relation tables (replicas are averaged every
+    // gpu_sync_interval steps); otherwise the dense gradients are left in relations_grad_ / inverse_relations_grad_ for an all-reduce + step()
+    void backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step);
+    std::vector<Tensor> dense_state();  // relation tables + their optimizer state (what gpu_model_average averages, pipeline_gpu.cpp:52-80)
 };
 
 // ------------------------------------------------------------------------------------------------ dataloader (dataloader.h)

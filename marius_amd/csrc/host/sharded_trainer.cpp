@@ -1,0 +1,340 @@
+// ShardedTrainer: see sharded_trainer.h.  Stream order on the exchange stream:  fetch(t+1) | grads(t), update(t) | fetch(t+2) | ...
+#include "sharded_trainer.h"
+
+#include <c10/hip/HIPCachingAllocator.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+#include <torch/csrc/distributed/c10d/GroupRegistry.hpp>
+
+#include <chrono>
+#include <cmath>
+
+namespace marius_amd {
+
+#define ST_HIPCHECK(x)                                                                                             \
+    do {                                                                                                            \
+        hipError_t e_ = (x);                                                                                        \
+        if (e_ != hipSuccess) throw MariusRuntimeException(std::string("ShardedTrainer HIP: ") + hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+struct Phase {  // adds the enclosed host time to one slot of ShardedTrainer::phase_seconds_
+    double& acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit Phase(double& a) : acc(a) {}
+    ~Phase() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+struct Scope {  // `s` is the current torch stream of this thread while the object lives
+    c10::hip::HIPStream prev;
+    explicit Scope(c10::hip::HIPStream s) : prev(c10::hip::getCurrentHIPStream(s.device_index())) { c10::hip::setCurrentHIPStream(s); }
+    ~Scope() { c10::hip::setCurrentHIPStream(prev); }
+};
+c10::hip::HIPStream& strm(void* p) { return *(c10::hip::HIPStream*)p; }
+hipEvent_t new_event() {
+    hipEvent_t e;
+    ST_HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return e;
+}
+int key_bits(int64_t n) {
+    int b = 1;
+    while ((1ll << b) <= n && b < 63) ++b;
+    return b;
+}
+}  // namespace
+
+ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> model, Tensor shard_table, Tensor shard_state, int rank, int world,
+                               int64_t num_nodes, const std::string& group_name, const std::string& side_group_name, int staleness, int sync_interval)
+    : loader_(loader), model_(model), table_(shard_table), state_(shard_state), rank_(rank), world_(world), staleness_(staleness),
+      sync_interval_(sync_interval), num_nodes_(num_nodes) {
+    if (staleness_ != 0 && staleness_ != 1) throw MariusRuntimeException("ShardedTrainer: staleness must be 0 or 1");
+    require_device(table_, "ShardedTrainer");
+    require_device(state_, "ShardedTrainer");
+    S_ = (num_nodes_ + world_ - 1) / world_;  // storage.cpp:75
+    lo_ = std::min<int64_t>((int64_t)rank_ * S_, num_nodes_);
+    if (table_.size(0) != std::min<int64_t>(lo_ + S_, num_nodes_) - lo_) throw MariusRuntimeException("ShardedTrainer: shard has the wrong number of rows");
+    d_ = (int)table_.size(1);
+    pg_ = c10d::resolve_process_group(group_name);
+    if (world_ > 1) side_pg_ = c10d::resolve_process_group(side_group_name);
+    if (pg_->getSize() != world_ || pg_->getRank() != rank_) throw MariusRuntimeException("ShardedTrainer: process group does not match rank / world");
+    const auto dev = table_.device();
+    {
+        // Experiment (MARIUS_SHARDED_HIPRIO=1): compute on a high-priority stream so that the persistent MFMA kernels win CU slots over the
+        // small kernels of the preparation / exchange streams.
+        const char* e = getenv("MARIUS_SHARDED_HIPRIO");
+        const bool hiprio = e && e[0] == '1';  // measured: 1.87 vs 1.40 ms per step — the side streams starve and the compute stream then waits for them; off
+        auto cur = c10::hip::getCurrentHIPStream(dev.index());
+        main_stream_ = new c10::hip::HIPStream(hiprio ? c10::hip::getStreamFromPool(true, dev.index()) : cur);
+        if (hiprio) {  // everything the caller enqueued so far (table initialisation ...) precedes the first step
+            hipEvent_t ev = new_event();
+            ST_HIPCHECK(hipEventRecord(ev, cur.stream()));
+            ST_HIPCHECK(hipStreamWaitEvent(strm(main_stream_).stream(), ev, 0));
+            ST_HIPCHECK(hipEventDestroy(ev));
+        }
+    }
+    prep_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(false, dev.index()));
+    xchg_stream_ = new c10::hip::HIPStream(staleness_ ? c10::hip::getStreamFromPool(false, dev.index()) : strm(main_stream_));
+    for (auto& s : slots_) {
+        s.offs_dev = torch::empty({world_ + 1}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
+        s.offs_host = torch::empty({world_ + 1}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
+        s.ready = new_event();
+        s.fetched = new_event();
+        s.computed = new_event();
+        s.free_ = new_event();
+    }
+    loader_->run_ahead_ = false;
+    loader_->num_relations_ = model_->decoder_->num_relations_;
+    {
+        Scope scope(strm(main_stream_));  // the permutation upload is ordered before the first preparation (which waits for this stream)
+        loader_->initializeBatches(true);
+    }
+    prime();
+}
+
+ShardedTrainer::~ShardedTrainer() {
+    (void)hipDeviceSynchronize();
+    for (auto& s : slots_)
+        for (void* e : {s.ready, s.fetched, s.computed, s.free_})
+            if (e) (void)hipEventDestroy((hipEvent_t)e);
+    delete (c10::hip::HIPStream*)main_stream_;
+    delete (c10::hip::HIPStream*)prep_stream_;
+    delete (c10::hip::HIPStream*)xchg_stream_;
+}
+
+// RCCL sets a collective up lazily on its first use per communicator (tens of milliseconds for the first all-reduce); the relation-table
+// averaging only happens every sync_interval steps, so without this its one-time cost would land in the middle of a run.
+void ShardedTrainer::prime() {
+    const auto dev = table_.device();
+    Scope scope(strm(main_stream_));
+    for (auto& t : model_->dense_state()) {  // every replica starts from the same tables and zero sums: sum / world leaves them unchanged
+        std::vector<Tensor> v{t};
+        pg_->allreduce(v)->wait();
+        t.div_((double)world_);
+    }
+    std::vector<int64_t> ones(world_, 1);
+    Tensor rows = torch::zeros({world_, d_}, torch::TensorOptions().dtype(torch::kFloat32).device(dev)), rows_out = torch::empty_like(rows);
+    Tensor ids = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).device(dev)), ids_out = torch::empty_like(ids);
+    pg_->alltoall_base(rows_out, rows, ones, ones)->wait();
+    pg_->alltoall_base(ids_out, ids, ones, ones)->wait();
+    if (world_ > 1) {
+        Tensor a = torch::zeros({world_}, torch::kInt64), b = torch::zeros({world_}, torch::kInt64);
+        std::vector<int64_t> none;
+        side_pg_->alltoall_base(b, a, none, none)->wait();
+    }
+    strm(main_stream_).synchronize();
+}
+
+// [n, *tail] view of a grow-only buffer: a fresh allocation per step keeps the caching allocator splitting / merging blocks
+Tensor ShardedTrainer::view(Tensor& buf, int64_t n, std::vector<int64_t> tail, torch::ScalarType dtype) {
+    if (!buf.defined() || buf.size(0) < n) {
+        if (buf.defined()) {  // the old block may still be read on either stream
+            c10::hip::HIPCachingAllocator::recordStream(buf.storage().data_ptr(), strm(main_stream_));
+            c10::hip::HIPCachingAllocator::recordStream(buf.storage().data_ptr(), strm(xchg_stream_));
+        }
+        std::vector<int64_t> shape{std::max<int64_t>(n + n / 4, 1)};
+        shape.insert(shape.end(), tail.begin(), tail.end());
+        buf = torch::empty(shape, torch::TensorOptions().dtype(dtype).device(table_.device()));
+    }
+    return buf.narrow(0, 0, n);
+}
+
+Tensor ShardedTrainer::a2a(const Tensor& in, const std::vector<int64_t>& send_counts, const std::vector<int64_t>& recv_counts, Tensor out) {
+    Tensor src = in.contiguous();
+    std::vector<int64_t> out_split = recv_counts, in_split = send_counts;
+    pg_->alltoall_base(out, src, out_split, in_split)->wait();  // NCCL work: orders the current stream behind the collective, the host does not block
+    return out;
+}
+
+// stage 1 (prep stream): everything that does not read the table — edge slice, negatives, sort / unique, owner split points
+void ShardedTrainer::prepare(int64_t t) {
+    Phase ph(phase_seconds_[0]);
+    Slot& s = slot(t);
+    auto& prep = strm(prep_stream_);
+    const auto dev_index = table_.device().index();
+    if (s.used) {
+        ST_HIPCHECK(hipStreamWaitEvent(prep.stream(), (hipEvent_t)s.free_, 0));  // the batch that used this slot RING steps ago is fully retired
+    } else {
+        hipEvent_t e = new_event();
+        ST_HIPCHECK(hipEventRecord(e, strm(main_stream_).stream()));
+        ST_HIPCHECK(hipStreamWaitEvent(prep.stream(), e, 0));
+        ST_HIPCHECK(hipEventDestroy(e));
+        (void)dev_index;
+    }
+    {
+        Scope scope(prep);
+        const int64_t B = loader_->batch_size_;
+        if ((loader_->batch_id_ + 1) * B > loader_->num_edges_) loader_->initializeBatches(true);  // next epoch: a new permutation (full batches only)
+        s.batch = loader_->prepareBatch(/*exact_unique=*/false);
+        mcheck(marius_owner_offsets(s.batch->unique_node_indices_.data_ptr<int64_t>(), s.batch->num_unique_dev_.data_ptr<int64_t>(), S_, world_,
+                                    s.offs_dev.data_ptr<int64_t>(), (marius_stream_t)prep.stream()));
+        s.offs_host.copy_(s.offs_dev, /*non_blocking=*/true);
+    }
+    ST_HIPCHECK(hipEventRecord((hipEvent_t)s.ready, prep.stream()));
+    s.used = true;
+}
+
+void ShardedTrainer::prepare_through(int64_t t) {
+    while (next_prepared_ <= t) prepare(next_prepared_++);
+}
+
+// stage 2 (host + exchange stream): split sizes, then ids -> owners, rows -> requesters
+void ShardedTrainer::fetch(int64_t t) {
+    Slot& s = slot(t);
+    {
+        Phase ph(phase_seconds_[1]);
+        ST_HIPCHECK(hipEventSynchronize((hipEvent_t)s.ready));  // a batch prepared at least one step ago: no stream drains for this
+    }
+    Phase ph(phase_seconds_[2]);
+    const int64_t* offs = s.offs_host.data_ptr<int64_t>();
+    s.send_counts.assign(world_, 0);
+    for (int i = 0; i < world_; ++i) s.send_counts[i] = offs[i + 1] - offs[i];
+    if (world_ > 1) {
+        // counts travel over the CPU (gloo) group: a second RCCL communicator on another stream could share a hardware queue with the
+        // main one and order differently on different ranks; `world` integers over loopback cost less than that risk
+        Tensor send = torch::from_blob(s.send_counts.data(), {world_}, torch::kInt64).clone(), recv = torch::empty({world_}, torch::kInt64);
+        std::vector<int64_t> none;
+        side_pg_->alltoall_base(recv, send, none, none)->wait();
+        s.recv_counts.assign(recv.data_ptr<int64_t>(), recv.data_ptr<int64_t>() + world_);
+    } else {
+        s.recv_counts = s.send_counts;
+    }
+    s.U = offs[world_];
+    s.nrecv = 0;
+    for (auto c : s.recv_counts) s.nrecv += c;
+    const int k = (int)(t % RING);
+    auto& xchg = strm(xchg_stream_);
+    ST_HIPCHECK(hipStreamWaitEvent(xchg.stream(), (hipEvent_t)s.ready, 0));
+    {
+        Scope scope(xchg);
+        Tensor req = a2a(s.batch->unique_node_indices_.narrow(0, 0, s.U), s.send_counts, s.recv_counts, view(buf_req_, s.nrecv, {}, torch::kInt64));
+        s.local_ids = view(local_[k], s.nrecv, {}, torch::kInt64);
+        torch::sub_out(s.local_ids, req, lo_);
+        Tensor rows = view(buf_rows_, s.nrecv, {d_}, torch::kFloat32);
+        if (s.nrecv > 0)
+            mcheck(marius_gather_rows(table_.data_ptr<float>(), table_.stride(0), s.local_ids.data_ptr<int64_t>(), s.nrecv, d_, rows.data_ptr<float>(),
+                                      rows.stride(0), (marius_stream_t)xchg.stream()));
+        s.emb = a2a(rows, s.recv_counts, s.send_counts, view(emb_[k], s.U, {d_}, torch::kFloat32));
+    }
+    ST_HIPCHECK(hipEventRecord((hipEvent_t)s.fetched, xchg.stream()));
+}
+
+void ShardedTrainer::fetch_through(int64_t t) {
+    while (next_fetched_ <= t) {
+        prepare_through(next_fetched_);
+        fetch(next_fetched_++);
+    }
+}
+
+// stage 3 (main stream): the same forward / loss / backward kernels as the single-GPU step
+void ShardedTrainer::compute(int64_t t) {
+    Phase ph(phase_seconds_[3]);
+    Slot& s = slot(t);
+    auto& main = strm(main_stream_);
+    Scope scope(main);
+    ST_HIPCHECK(hipStreamWaitEvent(main.stream(), (hipEvent_t)s.fetched, 0));
+    s.batch->node_embeddings_ = s.emb;
+    s.grad = view(grad_[t % RING], s.U, {d_}, torch::kFloat32);
+    // replicas step on their own relation gradients between averaging points (sync_interval > 1); with sync_interval 1 the dense
+    // gradients are all-reduced first
+    model_->backward_to_unique_grads(s.batch, s.grad, sync_interval_ > 1);
+    ST_HIPCHECK(hipEventRecord((hipEvent_t)s.computed, main.stream()));
+}
+
+// owner side: a row may have been requested by several ranks -> sort / unique the received ids, sum per row, one Adagrad step per row
+void ShardedTrainer::apply_local(const Tensor& local_ids, const Tensor& grads) {
+    const int64_t n = local_ids.size(0);
+    if (n == 0) return;
+    const auto dev = table_.device();
+    if (r_cap_ < n) {
+        r_cap_ = std::max<int64_t>(n + n / 2, 1024);
+        auto i64o = torch::TensorOptions().dtype(torch::kInt64).device(dev), i32o = torch::TensorOptions().dtype(torch::kInt32).device(dev);
+        r_uniq_ = torch::empty({r_cap_}, i64o);
+        r_inverse_ = torch::empty({r_cap_}, i64o);
+        r_perm_ = torch::empty({r_cap_}, i32o);
+        r_seg_ = torch::empty({r_cap_ + 1}, i32o);
+        r_count_ = torch::zeros({1}, i64o);
+        r_ws_ = torch::empty({(int64_t)marius_sort_unique_workspace_bytes(r_cap_)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+        r_carry_ = torch::empty({(int64_t)marius_segment_carry_bytes(r_cap_, d_)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+    }
+    auto st = cur_stream();
+    mcheck(marius_sort_unique(local_ids.data_ptr<int64_t>(), n, key_bits(table_.size(0)), r_uniq_.data_ptr<int64_t>(), r_inverse_.data_ptr<int64_t>(),
+                              r_perm_.data_ptr<int32_t>(), r_seg_.data_ptr<int32_t>(), r_count_.data_ptr<int64_t>(), r_ws_.data_ptr(), (size_t)r_ws_.numel(), st));
+    mcheck(marius_segment_adagrad_scatter(grads.data_ptr<float>(), grads.stride(0), r_perm_.data_ptr<int32_t>(), r_inverse_.data_ptr<int64_t>(),
+                                          r_seg_.data_ptr<int32_t>(), n, d_, r_uniq_.data_ptr<int64_t>(), table_.data_ptr<float>(), state_.data_ptr<float>(),
+                                          table_.stride(0), model_->sparse_lr_, 1e-10f, r_carry_.data_ptr(), st));
+}
+
+// stage 4 (exchange stream): gradients -> owners, owners update their rows
+void ShardedTrainer::update(int64_t t) {
+    Phase ph(phase_seconds_[4]);
+    Slot& s = slot(t);
+    auto& xchg = strm(xchg_stream_);
+    ST_HIPCHECK(hipStreamWaitEvent(xchg.stream(), (hipEvent_t)s.computed, 0));
+    {
+        Scope scope(xchg);
+        Tensor recv_grad = a2a(s.grad, s.send_counts, s.recv_counts, view(buf_recv_grad_, s.nrecv, {d_}, torch::kFloat32));
+        apply_local(s.local_ids, recv_grad);
+    }
+    ST_HIPCHECK(hipEventRecord((hipEvent_t)s.free_, xchg.stream()));
+}
+
+void ShardedTrainer::dense(int64_t t) {
+    Phase ph(phase_seconds_[5]);
+    Scope scope(strm(main_stream_));
+    if (sync_interval_ <= 1) {  // model.cpp:136-159: all-reduce the relation gradients, every replica takes the same dense step
+        for (Tensor* g : {&model_->relations_grad_, &model_->inverse_relations_grad_}) {
+            if (!g->defined()) continue;
+            std::vector<Tensor> v{*g};
+            pg_->allreduce(v)->wait();
+        }
+        model_->step();
+    } else if ((t + 1) % sync_interval_ == 0) {  // pipeline_gpu.cpp:52-80 (gpu_model_average): tables and optimizer state averaged every K steps
+        for (auto& tt : model_->dense_state()) {
+            std::vector<Tensor> v{tt};
+            pg_->allreduce(v)->wait();
+            tt.div_((double)world_);
+        }
+    }
+}
+
+void ShardedTrainer::step() {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int64_t t = step_index_;
+    fetch_through(t);  // no-op except on the first step
+    // The scoring of batch t goes to the device FIRST: fetching the next batch may block the host (it needs the split points of a batch
+    // whose preparation runs in the gaps the big kernels leave), and the compute stream must not run dry meanwhile.
+    compute(t);
+    prepare_through(t + AHEAD);  // preparation never reads the table: how far ahead it runs changes nothing but latency hiding
+    if (staleness_) fetch_through(t + 1);  // rows of the next batch move while this one is scored; on the exchange stream this precedes update(t)
+    update(t);
+    dense(t);
+    ++step_index_;
+    ++steps_;
+    host_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void ShardedTrainer::train_steps(int64_t n) {
+    for (int64_t i = 0; i < n; ++i) step();
+}
+
+void ShardedTrainer::finish() { ST_HIPCHECK(hipDeviceSynchronize()); }
+
+std::vector<Tensor> c10d_exchange_selftest(const std::string& group_name, Tensor send, std::vector<int64_t> send_counts, Tensor to_reduce) {
+    auto pg = c10d::resolve_process_group(group_name);
+    const int world = pg->getSize();
+    if ((int)send_counts.size() != world) throw MariusRuntimeException("c10d_exchange_selftest: one count per rank");
+    Tensor sc = torch::from_blob(send_counts.data(), {world}, torch::kInt64).clone(), rc = torch::empty({world}, torch::kInt64);
+    std::vector<int64_t> none;
+    pg->alltoall_base(rc, sc, none, none)->wait();  // as ShardedTrainer::fetch does over the side group
+    std::vector<int64_t> recv_counts(rc.data_ptr<int64_t>(), rc.data_ptr<int64_t>() + world);
+    int64_t nrecv = 0;
+    for (auto c : recv_counts) nrecv += c;
+    std::vector<int64_t> shape = send.sizes().vec();
+    shape[0] = nrecv;
+    Tensor out = torch::empty(shape, send.options()), src = send.contiguous();
+    pg->alltoall_base(out, src, recv_counts, send_counts)->wait();  // ShardedTrainer::a2a
+    std::vector<Tensor> v{to_reduce};
+    pg->allreduce(v)->wait();
+    return {rc, out, to_reduce};
+}
+
+}  // namespace marius_amd

@@ -1,0 +1,86 @@
+// Multi-GPU training step, one process per GPU: node table sharded by contiguous id range, rows fetched / gradients returned by
+// RCCL all-to-all(v), relation tables replicated (the schedule, its staleness semantics and the CPU gloo tests of the
+// control flow live in marius_amd/sharded.py: PipelineSchedule — this is the same schedule issued from C++ so that the host is not the
+// bottleneck: the Python driver needs ~1.2 ms per step to issue ~60 launches, more than the GPU needs to execute them).
+//
+// Collectives go through torch.distributed's C++ layer (c10d::ProcessGroup): the NCCL(=RCCL) group for device tensors and a gloo group
+// for the `world` split counts of every all-to-all(v), which must be known on the host.  Groups are looked up by name
+// (c10d::resolve_process_group), so nothing but two strings crosses the Python boundary.
+#pragma once
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
+
+#include "marius_host.h"
+
+namespace marius_amd {
+
+class ShardedTrainer {
+   public:
+    static constexpr int RING = 6;   // slots in flight
+    static constexpr int AHEAD = 3;  // batches prepared ahead of the one being scored: their split points must be on the host when fetch needs them
+
+    // loader: prepares this rank's batches (its node storage only supplies num_nodes = dim0_size_); shard_table / shard_state: rows
+    // [rank * S, min((rank + 1) * S, num_nodes)) of the node table and its Adagrad state, S = ceil(num_nodes / world) (storage.cpp:75).
+    // staleness 0: synchronous (every row a batch reads carries all earlier updates); 1: the fetch of batch t + 1 and the gradient
+    // return of batch t run on an exchange stream underneath the scoring (rows at most one step stale; the reference's own multi-GPU
+    // trainer is the asynchronous pipeline with staleness_bound 16).  sync_interval: pipeline.gpu_sync_interval (relation tables and
+    // their Adagrad state averaged every K steps; 1 = all-reduce the relation gradients every step, model.cpp:136-159).
+    ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> model, Tensor shard_table, Tensor shard_state, int rank, int world, int64_t num_nodes,
+                   const std::string& group_name, const std::string& side_group_name, int staleness, int sync_interval);
+    ~ShardedTrainer();
+    void step();
+    void train_steps(int64_t n);
+    void finish();  // drain the device (prefetched batches are dropped: preparation and fetch have no side effects)
+    double host_seconds_ = 0;  // time spent issuing steps (diagnostic: the host must stay ahead of the GPU)
+    int64_t steps_ = 0;
+    double phase_seconds_[6] = {0, 0, 0, 0, 0, 0};  // host time in: prepare, wait for split points, fetch, compute, update, dense
+
+   private:
+    struct Slot {
+        shared_ptr<Batch> batch;
+        Tensor offs_dev, offs_host;  // [world + 1] split points of the batch's ascending unique ids by owner
+        void* ready = nullptr;       // prep stream: batch prepared, split points on their way to the host
+        void* fetched = nullptr;     // rows of this batch have arrived
+        void* computed = nullptr;    // per-row gradients complete
+        void* free_ = nullptr;       // owners applied the gradients: every buffer of the slot is reusable
+        bool used = false;
+        std::vector<int64_t> send_counts, recv_counts;
+        int64_t U = 0, nrecv = 0;
+        Tensor emb, grad, local_ids;
+    };
+    shared_ptr<DataLoader> loader_;
+    shared_ptr<Model> model_;
+    Tensor table_, state_;
+    int rank_, world_, staleness_, sync_interval_;
+    int64_t num_nodes_, S_, lo_;
+    int d_;
+    c10::intrusive_ptr<c10d::ProcessGroup> pg_, side_pg_;
+    void* main_stream_ = nullptr;  // forward / loss / backward: a high-priority stream, so that its workgroups win CU slots over the side streams
+    void* prep_stream_ = nullptr;
+    void* xchg_stream_ = nullptr;  // == main stream when staleness == 0
+    Slot slots_[RING];
+    int64_t next_prepared_ = 0, next_fetched_ = 0, step_index_ = 0;
+    // grow-only buffers (per-step sizes vary with the number of unique ids)
+    Tensor buf_req_, buf_rows_, buf_recv_grad_, emb_[RING], grad_[RING], local_[RING];
+    // owner-side dedupe of the received ids
+    Tensor r_uniq_, r_inverse_, r_perm_, r_seg_, r_count_, r_ws_, r_carry_;
+    int64_t r_cap_ = 0;
+
+    Slot& slot(int64_t t) { return slots_[t % RING]; }
+    Tensor view(Tensor& buf, int64_t n, std::vector<int64_t> tail, torch::ScalarType dtype);
+    void prepare(int64_t t);
+    void prepare_through(int64_t t);
+    void fetch(int64_t t);
+    void fetch_through(int64_t t);
+    void compute(int64_t t);
+    void update(int64_t t);
+    void dense(int64_t t);
+    void apply_local(const Tensor& local_ids, const Tensor& grads);
+    Tensor a2a(const Tensor& in, const std::vector<int64_t>& send_counts, const std::vector<int64_t>& recv_counts, Tensor out);
+    void prime();
+};
+
+// The collective calls of ShardedTrainer in isolation, on tensors of any device the group supports (the CPU gloo tests run this with
+// world size 2): count exchange (equal split), all-to-all(v) of `send` rows with those counts, all-reduce.  Returns {recv_counts, recv, sum}.
+std::vector<Tensor> c10d_exchange_selftest(const std::string& group_name, Tensor send, std::vector<int64_t> send_counts, Tensor to_reduce);
+
+}  // namespace marius_amd

@@ -332,12 +332,14 @@ class PipelineSchedule:
     def step(self):
         t = self.step_index
         self._fetch_through(t)              # no-op except on the first step
+        # the scoring of batch t is issued first: fetching the next batch may block the host on split points of a batch whose
+        # preparation runs in the gaps the big kernels leave, and the compute stream must not run dry meanwhile
+        rel_grads = self._compute(t)
         if self.staleness:
             self._prepare_through(t + 2)
-            self._fetch_through(t + 1)      # rows of the next batch move while this one is scored (read before update(t))
+            self._fetch_through(t + 1)      # rows of the next batch move while this one is scored; on the exchange stream this precedes update(t)
         else:
             self._prepare_through(t + 1)    # next batch's preparation overlaps with this batch's compute
-        rel_grads = self._compute(t)
         self._update(t)
         self._dense(t, rel_grads)
         self.step_index += 1
@@ -532,25 +534,59 @@ def run_sharded_bench(a, cfg, rank, world, dev):
     import bench as bench_mod
 
     edges_all = bench_mod.synth_edges(num_nodes, R, cfg["num_edges"], a.edge_dist, dev, seed=1 + rank)
-    stepper = DeviceLinkPredictionStep(cfg["decoder"], num_nodes, R, d, B, C, N, seed=42 + rank, device=dev, node_table=None, node_state=None)
-    perm = stepper.gen.randperm_host(edges_all.size(0)).to(dev)
-    nb = edges_all.size(0) // B
     sync_interval = int(os.environ.get("MARIUS_GPU_SYNC_INTERVAL", "16"))  # pipeline.gpu_sync_interval default (marius_config.py:672-685)
     pipelined = os.environ.get("MARIUS_SHARDED_PIPELINE", "1") != "0"
     staleness = 0
+    driver = os.environ.get("MARIUS_SHARDED_DRIVER", "cpp")  # cpp: ShardedTrainer (csrc/host/sharded_trainer.cpp); py: the Python schedule below
+    host_s = None
+    cpp_trainer = None
     if pipelined:
         # per-step count exchange (world integers) stays on the CPU.  One node only: pin gloo to the loopback interface — its default
         # picks the interface by resolving the hostname, which containers do not always allow
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         side_group = dist.new_group(backend="gloo")
         staleness = int(os.environ.get("MARIUS_SHARDED_STALENESS", "1"))
+    if pipelined and driver == "cpp":
+        import marius_amd
+
+        M = marius_amd.host()
+        gen = M.MariusGenerator(42 + rank)
+        sampler = M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen)
+        nodes = M.InMemory("", num_nodes, d, torch.float32, dev)  # never loaded: tells the sampler how many nodes exist
+        loader = M.DataLoader(M.InMemory(edges_all), nodes, None, sampler, gen, B, True)
+        dec = {"DISTMULT": M.DistMult, "COMPLEX": M.ComplEx, "TRANSE": M.TransE}[cfg["decoder"]](R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+        model = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+        model.setup_optimizers(0.1)
+        model.sparse_lr = 0.1
+        try:
+            # the constructor already runs every collective the steps use (all-reduce, both all-to-all(v) forms, the gloo count exchange)
+            cpp_trainer = M.ShardedTrainer(loader, model, table, state, rank, world, num_nodes, dist.group.WORLD.group_name, side_group.group_name,
+                                           staleness, sync_interval)
+        except Exception as e:  # noqa: BLE001 — e.g. a c10d build without the C++ group registry: same schedule from Python
+            import sys
+            print("[rank %d] C++ ShardedTrainer unavailable (%s): falling back to the Python schedule" % (rank, e), file=sys.stderr)
+            cpp_trainer = None
+            driver = "py"
+    if cpp_trainer is not None:
+
+        def run(k0, k):
+            cpp_trainer.train_steps(k)
+    elif pipelined:
+        stepper = DeviceLinkPredictionStep(cfg["decoder"], num_nodes, R, d, B, C, N, seed=42 + rank, device=dev, node_table=None, node_state=None)
+        perm = stepper.gen.randperm_host(edges_all.size(0)).to(dev)
         trainer = PipelinedShardedTrainer(stepper, table, state, edges_all, perm, rank, world, num_nodes, sync_interval=sync_interval, side_group=side_group,
                                           staleness=staleness)
+        host_s = [0.0]
 
         def run(k0, k):
             for _ in range(k):
+                t_ = time.perf_counter()
                 trainer.step()
+                host_s[0] += time.perf_counter() - t_   # time the host spends issuing one step (it runs ahead of the GPU unless it is the bottleneck)
     else:
+        stepper = DeviceLinkPredictionStep(cfg["decoder"], num_nodes, R, d, B, C, N, seed=42 + rank, device=dev, node_table=None, node_state=None)
+        perm = stepper.gen.randperm_host(edges_all.size(0)).to(dev)
+        nb = edges_all.size(0) // B
         backend = HipBackend(stepper, table, state)
 
         def run(k0, k):
@@ -562,6 +598,10 @@ def run_sharded_bench(a, cfg, rank, world, dev):
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
+    if host_s is not None:
+        host_s[0] = 0.0
+    if cpp_trainer is not None:
+        cpp_trainer.host_seconds = 0.0
     H.profile_reset()
     H.profile_enable(True, only="lp_grad_adj")  # HIP events around the dominant kernel only (one pair per step)
     t0 = time.perf_counter()
@@ -587,6 +627,13 @@ def run_sharded_bench(a, cfg, rank, world, dev):
                                            if pipelined and staleness else "synchronous exchange"))},
             "positive_edges_per_s": round(pos_eps, 1), "roofline": None, "cpu_baseline": None,
         }
+        host_total = cpp_trainer.host_seconds if cpp_trainer is not None else (host_s[0] if host_s is not None else None)
+        if host_total is not None:  # how long the host needs to issue a step: it must stay below ms_per_step or the host is the bottleneck
+            out["host_issue_ms_per_step"] = round(host_total / a.steps * 1e3, 4)
+            out["config"]["host"] = "C++ ShardedTrainer (libtorch, c10d)" if cpp_trainer is not None else "Python schedule (marius_amd/sharded.py)"
+            if cpp_trainer is not None and os.environ.get("MARIUS_SHARDED_PHASES"):
+                out["host_phase_ms_per_step"] = dict(zip(["prepare", "wait_split_points", "fetch", "compute", "update", "dense"],
+                                                         [round(x / (a.steps + a.warmup) * 1e3, 4) for x in cpp_trainer.phase_seconds]))
         ms, cnt = prof.get("lp_grad_adj", (0.0, 0))
         if cnt:  # rank 0's dominant kernel (both backward contractions in one launch), same accounting as the N = 1 line
             Bp = C * math.ceil(B / C)

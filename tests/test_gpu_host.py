@@ -420,3 +420,106 @@ def test_storage_shuffle_and_sort_respect_edge_buckets(M, dev, tmp_path):
     st.sort(True)
     for lo, hi in ((0, 50), (50, 170), (170, 200)):
         assert bool((st.data[lo + 1:hi, 0] >= st.data[lo:hi - 1, 0]).all())
+
+
+# ------------------------------------------------------------------------------------------------ C++ sharded trainer (world 1 on the GPU)
+def _sharded_setup(M, dev, seed, num_nodes, R, d, B, C, N, E):
+    g = torch.Generator().manual_seed(2)
+    table = (torch.rand(num_nodes, d, generator=g) - 0.5) * 0.5
+    edges_all = torch.stack([torch.randint(num_nodes, (E,), generator=g), torch.randint(R, (E,), generator=g), torch.randint(num_nodes, (E,), generator=g)], 1)
+
+    def make(node_storage, state_storage):
+        gen = M.MariusGenerator(seed)
+        sampler = M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen)
+        loader = M.DataLoader(M.InMemory(edges_all.to(torch.int32).to(dev)), node_storage, state_storage, sampler, gen, B, True)
+        dec = M.ComplEx(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+        model = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+        model.setup_optimizers(0.1)
+        model.sparse_lr = 0.1
+        return loader, model
+
+    return table, edges_all, make
+
+
+def _init_nccl(dev):
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    return dist
+
+
+@pytest.mark.parametrize("sync_interval", [1, 16])
+def test_cpp_sharded_trainer_world1_equals_synchronous_trainer(M, dev, sync_interval):
+    """ShardedTrainer (owner split points, all-to-all(v) through c10d, owner-side dedupe + Adagrad, prepared one step ahead) at world
+    size 1 and staleness 0 walks the same trajectory as the fused single-GPU trainer — across an epoch boundary (new permutation)."""
+    dist = _init_nccl(dev)
+    num_nodes, R, d, B, C, N, E, seed, steps = 3000, 9, 100, 200, 4, 60, 1200, 21, 9
+    table, edges_all, make = _sharded_setup(M, dev, seed, num_nodes, R, d, B, C, N, E)
+    ea, sa = M.InMemory(table.clone().to(dev)), M.InMemory(torch.zeros(num_nodes, d, device=dev))
+    la, ma = make(ea, sa)
+    ta = M.SynchronousTrainer(la, ma)
+    ta.train_steps(steps)
+    tb, sb = table.clone().to(dev), torch.zeros(num_nodes, d, device=dev)
+    stub = M.InMemory("", num_nodes, d, torch.float32, dev)  # never loaded: tells the sampler how many nodes exist
+    lb, mb = make(stub, None)
+    tr = M.ShardedTrainer(lb, mb, tb, sb, 0, 1, num_nodes, dist.group.WORLD.group_name, "", 0, sync_interval)
+    tr.train_steps(steps)
+    tr.finish()
+    assert tr.steps == steps and tr.host_seconds > 0
+    close(tb, ea.data, rtol=1e-6)
+    close(sb, sa.data, rtol=1e-6)
+    close(mb.decoder.relations, ma.decoder.relations, rtol=1e-6)
+    close(mb.decoder.inverse_relations, ma.decoder.inverse_relations, rtol=1e-6)
+    dist.destroy_process_group()
+
+
+def test_cpp_sharded_trainer_staleness1_matches_stale_oracle(M, dev):
+    """Overlapped exchange: the rows of batch t + 1 are read before the update of batch t is applied (one step stale), the Adagrad state
+    is read by the owner at update time.  Same loop on the CPU oracle."""
+    dist = _init_nccl(dev)
+    num_nodes, R, d, B, C, N, E, seed, steps = 2000, 7, 32, 150, 3, 40, 1500, 5, 7
+    table, edges_all, make = _sharded_setup(M, dev, seed, num_nodes, R, d, B, C, N, E)
+    tb, sb = table.clone().to(dev), torch.zeros(num_nodes, d, device=dev)
+    lb, mb = make(M.InMemory("", num_nodes, d, torch.float32, dev), None)
+    tr = M.ShardedTrainer(lb, mb, tb, sb, 0, 1, num_nodes, dist.group.WORLD.group_name, "", 1, 1)
+    tr.train_steps(steps)
+    tr.finish()
+    # ---- oracle
+    T, S = table.clone(), torch.zeros(num_nodes, d)
+    cpu = CpuLinkPredictionStep("COMPLEX", T, S, R, B, C, N)
+    torch.manual_seed(seed)
+    perm = torch.randperm(E)
+
+    def prep(t):
+        e = edges_all[perm[t * B:(t + 1) * B]]
+        src_neg, _ = cpu.get_negatives(e, True)
+        dst_neg, _ = cpu.get_negatives(e, False)
+        uniq, mapped = O.map_tensors([e[:, 0], e[:, -1], src_neg.flatten(), dst_neg.flatten()])
+        return {"uniq": uniq, "el": torch.stack([mapped[0], e[:, 1], mapped[1]]).transpose(0, 1), "src_map": mapped[2].reshape(src_neg.shape),
+                "dst_map": mapped[3].reshape(dst_neg.shape)}
+
+    cur = prep(0)
+    cur["emb"] = T[cur["uniq"]].clone()
+    for t in range(steps):
+        nxt = prep(t + 1)
+        nxt["emb"] = T[nxt["uniq"]].clone()  # fetched before the update of batch t lands
+        out = O.train_batch("COMPLEX", cur["emb"], torch.zeros_like(cur["emb"]), cur["el"], cur["dst_map"], cur["src_map"], cpu.rel, cpu.inv_rel)
+        g = out["node_grad"]
+        S[cur["uniq"]] += g * g
+        T[cur["uniq"]] += -0.1 * (g / (S[cur["uniq"]].sqrt() + 1e-10))
+        O.dense_adagrad_step(cpu.rel, out["rel_grad"], cpu.rel_sum, 0.1)
+        O.dense_adagrad_step(cpu.inv_rel, out["inv_rel_grad"], cpu.inv_rel_sum, 0.1)
+        cur = nxt
+    close(tb, T, rtol=3e-4)
+    close(sb, S, rtol=3e-4)
+    close(mb.decoder.relations, cpu.rel, rtol=3e-4)
+    sync = CpuLinkPredictionStep("COMPLEX", table.clone(), torch.zeros(num_nodes, d), R, B, C, N)
+    torch.manual_seed(seed)
+    perm2 = torch.randperm(E)
+    for t in range(steps):
+        sync.step(edges_all[perm2[t * B:(t + 1) * B]])
+    assert not torch.allclose(sync.table, T, rtol=1e-4, atol=1e-6)  # the stale trajectory really differs from the synchronous one
+    dist.destroy_process_group()

@@ -289,3 +289,32 @@ def test_pipeline_schedule_sync_interval_world2_gloo():
         res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(world)]
     assert torch.equal(res[0]["rel"], res[1]["rel"]) and torch.equal(res[0]["inv_rel"], res[1]["inv_rel"])
     assert torch.isfinite(res[0]["shard"]).all() and torch.isfinite(res[1]["shard"]).all()
+
+
+def c10d_worker(rank, world, port, outdir):
+    """The C++ side of the exchange (c10d::resolve_process_group + alltoall_base / allreduce as ShardedTrainer issues them), gloo, world 2."""
+    import marius_amd
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    side = dist.new_group(backend="gloo")
+    M = marius_amd.host()
+    # rank r sends (r + 1) rows to rank 0 and (r + 3) rows to rank 1; every row is labelled [sender, destination, index]
+    counts = [rank + 1, rank + 3]
+    rows = torch.tensor([[rank, dst, i] for dst in range(world) for i in range(counts[dst])], dtype=torch.float32)
+    rc, recv, red = M.c10d_exchange_selftest(side.group_name, rows, counts, torch.full((3,), float(rank + 1)))
+    torch.save({"rc": rc, "recv": recv, "red": red}, os.path.join(outdir, "c%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_cpp_c10d_exchange_world2_gloo():
+    world, port = 2, 39000 + os.getpid() % 2000
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(c10d_worker, args=(world, port, outdir), nprocs=world, join=True)
+        res = [torch.load(os.path.join(outdir, "c%d.pt" % r)) for r in range(world)]
+    for me in range(world):
+        want_counts = [src + 1 if me == 0 else src + 3 for src in range(world)]
+        assert res[me]["rc"].tolist() == want_counts
+        want_rows = [[src, me, i] for src in range(world) for i in range(want_counts[src])]   # grouped by sender, in the sender's order
+        assert res[me]["recv"].tolist() == [[float(x) for x in r] for r in want_rows]
+        assert res[me]["red"].tolist() == [3.0, 3.0, 3.0]
