@@ -158,6 +158,14 @@ int marius_sort_unique(const int64_t* ids, int64_t n, int32_t key_bits, int64_t*
                        int32_t* seg_offsets, int64_t* num_unique_dev, void* workspace, size_t workspace_bytes,
                        marius_stream_t stream);
 
+/* Same outputs as marius_sort_unique for an input that is the concatenation of num_runs (<= 64) strictly ascending runs
+ * (run q = ids[run_offsets_host[q] .. run_offsets_host[q+1]); the owner side of the sharded exchange receives one such run per sender):
+ * the sorted position of every element comes from num_runs - 1 binary searches instead of radix passes; ties keep input order (stable).
+ * run_offsets_host is a HOST array of num_runs + 1 offsets.  Workspace as for marius_sort_unique. */
+int marius_merge_unique_runs(const int64_t* ids, int64_t n, const int64_t* run_offsets_host, int32_t num_runs, int64_t* uniq, int64_t* inverse,
+                             int32_t* perm, int32_t* seg_offsets, int64_t* num_unique_dev, void* workspace, size_t workspace_bytes,
+                             marius_stream_t stream);
+
 /* Sharded node table (partition axis of src/storage/storage.cpp:75 / buffer.cpp:340-356: shard q owns ids
  * [q * shard_rows, (q+1) * shard_rows)):  out[q] = first position in the ascending list uniq[0..*num_unique_dev) with
  * id >= q * shard_rows, q = 0..num_shards (out[num_shards] = U).  These are the all-to-all split points. */

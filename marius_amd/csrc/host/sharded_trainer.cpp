@@ -240,7 +240,7 @@ void ShardedTrainer::compute(int64_t t) {
 }
 
 // owner side: a row may have been requested by several ranks -> sort / unique the received ids, sum per row, one Adagrad step per row
-void ShardedTrainer::apply_local(const Tensor& local_ids, const Tensor& grads) {
+void ShardedTrainer::apply_local(const Tensor& local_ids, const Tensor& grads, const std::vector<int64_t>& recv_counts) {
     const int64_t n = local_ids.size(0);
     if (n == 0) return;
     const auto dev = table_.device();
@@ -256,8 +256,16 @@ void ShardedTrainer::apply_local(const Tensor& local_ids, const Tensor& grads) {
         r_carry_ = torch::empty({(int64_t)marius_segment_carry_bytes(r_cap_, d_)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
     }
     auto st = cur_stream();
-    mcheck(marius_sort_unique(local_ids.data_ptr<int64_t>(), n, key_bits(table_.size(0)), r_uniq_.data_ptr<int64_t>(), r_inverse_.data_ptr<int64_t>(),
-                              r_perm_.data_ptr<int32_t>(), r_seg_.data_ptr<int32_t>(), r_count_.data_ptr<int64_t>(), r_ws_.data_ptr(), (size_t)r_ws_.numel(), st));
+    // every sender's list is ascending and duplicate-free: merge the `world` runs (binary searches) instead of radix-sorting them
+    std::vector<int64_t> runs(recv_counts.size() + 1, 0);
+    for (size_t q = 0; q < recv_counts.size(); ++q) runs[q + 1] = runs[q] + recv_counts[q];
+    if ((int)recv_counts.size() <= 64)
+        mcheck(marius_merge_unique_runs(local_ids.data_ptr<int64_t>(), n, runs.data(), (int32_t)recv_counts.size(), r_uniq_.data_ptr<int64_t>(),
+                                        r_inverse_.data_ptr<int64_t>(), r_perm_.data_ptr<int32_t>(), r_seg_.data_ptr<int32_t>(), r_count_.data_ptr<int64_t>(),
+                                        r_ws_.data_ptr(), (size_t)r_ws_.numel(), st));
+    else
+        mcheck(marius_sort_unique(local_ids.data_ptr<int64_t>(), n, key_bits(table_.size(0)), r_uniq_.data_ptr<int64_t>(), r_inverse_.data_ptr<int64_t>(),
+                                  r_perm_.data_ptr<int32_t>(), r_seg_.data_ptr<int32_t>(), r_count_.data_ptr<int64_t>(), r_ws_.data_ptr(), (size_t)r_ws_.numel(), st));
     mcheck(marius_segment_adagrad_scatter(grads.data_ptr<float>(), grads.stride(0), r_perm_.data_ptr<int32_t>(), r_inverse_.data_ptr<int64_t>(),
                                           r_seg_.data_ptr<int32_t>(), n, d_, r_uniq_.data_ptr<int64_t>(), table_.data_ptr<float>(), state_.data_ptr<float>(),
                                           table_.stride(0), model_->sparse_lr_, 1e-10f, r_carry_.data_ptr(), st));
@@ -272,7 +280,7 @@ void ShardedTrainer::update(int64_t t) {
     {
         Scope scope(xchg);
         Tensor recv_grad = a2a(s.grad, s.send_counts, s.recv_counts, view(buf_recv_grad_, s.nrecv, {d_}, torch::kFloat32));
-        apply_local(s.local_ids, recv_grad);
+        apply_local(s.local_ids, recv_grad, s.recv_counts);
     }
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.free_, xchg.stream()));
 }

@@ -74,7 +74,7 @@ class ShardedTrainer {
     void compute(int64_t t);
     void update(int64_t t);
     void dense(int64_t t);
-    void apply_local(const Tensor& local_ids, const Tensor& grads);
+    void apply_local(const Tensor& local_ids, const Tensor& grads, const std::vector<int64_t>& recv_counts);
     Tensor a2a(const Tensor& in, const std::vector<int64_t>& send_counts, const std::vector<int64_t>& recv_counts, Tensor out);
     void prime();
 };

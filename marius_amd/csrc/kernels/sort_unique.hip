@@ -59,6 +59,42 @@ __global__ void owner_offsets_kernel(const int64_t* __restrict__ uniq, const int
     out[q] = (q == P) ? U : lo;
 }
 
+// ids = concatenation of `nruns` ascending runs (each run strictly increasing: one sender's unique ids).  Sorted position of element i of
+// run r with value v = (i - start_r) + sum over runs q < r of #{x in q : x <= v} + sum over runs q > r of #{x in q : x < v}: exactly the
+// position a stable sort by (value, input position) gives it, found with nruns - 1 binary searches instead of radix passes.
+constexpr int MERGE_MAX_RUNS = 64;
+struct RunOffsets {
+    int64_t off[MERGE_MAX_RUNS + 1];
+};
+__global__ __launch_bounds__(256) void merge_rank_kernel(const int64_t* __restrict__ ids, int64_t n, RunOffsets ro, int nruns, uint64_t* __restrict__ keys,
+                                                         int32_t* __restrict__ perm) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int r = 0;
+        while (r + 1 < nruns && i >= ro.off[r + 1]) ++r;
+        const int64_t v = ids[i];
+        int64_t rank = i - ro.off[r];
+        for (int q = 0; q < nruns; ++q) {
+            if (q == r) continue;
+            int64_t lo = ro.off[q], hi = ro.off[q + 1];
+            const int64_t base = lo;
+            if (q < r) {  // upper bound: elements <= v
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (ids[mid] <= v) lo = mid + 1; else hi = mid;
+                }
+            } else {      // lower bound: elements < v
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (ids[mid] < v) lo = mid + 1; else hi = mid;
+                }
+            }
+            rank += lo - base;
+        }
+        keys[rank] = (uint64_t)v;
+        perm[rank] = (int32_t)i;
+    }
+}
+
 struct SortPlan {
     size_t keys_off, scan_off, temp_off, temp_bytes, total;
 };
@@ -140,6 +176,52 @@ extern "C" int marius_sort_unique(const int64_t* ids, int64_t n, int32_t key_bit
     emit_unique_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const int64_t*)keys, scan, perm, n, uniq, inverse,
                                                                     seg_offsets, num_unique_dev);
     return check_launch("sort_unique");
+}
+
+extern "C" int marius_merge_unique_runs(const int64_t* ids, int64_t n, const int64_t* run_offsets_host, int32_t num_runs, int64_t* uniq, int64_t* inverse,
+                                        int32_t* perm, int32_t* seg_offsets, int64_t* num_unique_dev, void* workspace, size_t workspace_bytes,
+                                        marius_stream_t stream) {
+    MARIUS_REQUIRE(n >= 0 && n < (1ll << 31) && num_runs >= 1 && num_runs <= MERGE_MAX_RUNS, "merge_unique_runs: bad n / num_runs");
+    MARIUS_REQUIRE(seg_offsets && num_unique_dev && run_offsets_host, "merge_unique_runs: null outputs");
+    MARIUS_REQUIRE(run_offsets_host[0] == 0 && run_offsets_host[num_runs] == n, "merge_unique_runs: run offsets must span [0, n]");
+    hipStream_t st = as_stream(stream);
+    if (n == 0) {
+        zero_count_kernel<<<1, 1, 0, st>>>(num_unique_dev, seg_offsets);
+        return check_launch("merge_unique_runs(empty)");
+    }
+    MARIUS_REQUIRE(ids && uniq && inverse && perm && workspace, "merge_unique_runs: null pointer");
+    SortPlan p;
+    if (make_plan(n, p) != MARIUS_OK) {
+        set_last_error("merge_unique_runs: rocprim size query failed");
+        return MARIUS_ERR_HIP;
+    }
+    MARIUS_REQUIRE(workspace_bytes >= p.total, "merge_unique_runs: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+    RunOffsets ro;
+    for (int q = 0; q <= num_runs; ++q) {
+        ro.off[q] = run_offsets_host[q];
+        MARIUS_REQUIRE(q == 0 || ro.off[q] >= ro.off[q - 1], "merge_unique_runs: run offsets must ascend");
+    }
+    ProfScope ps(PROF_SORT_UNIQUE, st);
+    if (hipMemsetAsync(uniq, 0, (size_t)n * sizeof(int64_t), st) != hipSuccess) {
+        set_last_error("merge_unique_runs: memset failed");
+        return MARIUS_ERR_HIP;
+    }
+    char* ws = (char*)workspace;
+    uint64_t* keys = (uint64_t*)(ws + p.keys_off);
+    int32_t* flags = (int32_t*)(ws + p.scan_off);
+    int32_t* scan = flags + n;
+    int64_t blocks = cdiv(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    merge_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(ids, n, ro, num_runs, keys, perm);
+    head_flags_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const int64_t*)keys, n, flags);
+    size_t tmp_bytes = p.temp_bytes;
+    hipError_t e = rocprim::inclusive_scan(ws + p.temp_off, tmp_bytes, flags, scan, (size_t)n, rocprim::plus<int32_t>(), st);
+    if (e != hipSuccess) {
+        set_last_error("merge_unique_runs: inclusive_scan: %s", hipGetErrorString(e));
+        return MARIUS_ERR_HIP;
+    }
+    emit_unique_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const int64_t*)keys, scan, perm, n, uniq, inverse, seg_offsets, num_unique_dev);
+    return check_launch("merge_unique_runs");
 }
 
 extern "C" int marius_owner_offsets(const int64_t* uniq, const int64_t* num_unique_dev, int64_t shard_rows, int32_t num_shards,

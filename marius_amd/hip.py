@@ -77,6 +77,7 @@ SIGNATURES = {
     "marius_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "marius_sort_unique_workspace_bytes": (_sz, [_i64]),
     "marius_sort_unique": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "marius_merge_unique_runs": (C.c_int, [_vp, _i64, C.POINTER(C.c_int64), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "marius_owner_offsets": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "marius_lp_plan": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout)]),
     "marius_lp_forward": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),

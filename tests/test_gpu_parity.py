@@ -610,3 +610,30 @@ def test_lp_other_losses_forward_backward(H, dev, monkeypatch, novlog, loss, dec
     if use_inverse:
         inv_grad = torch.zeros(R, d, dtype=torch.float64).index_add_(0, edges[:, 1], W.grel(1)[:, :d].cpu().double())
         assert_close(inv_grad.float(), want["inv_rel_grad"], "inv_rel_grad")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("runs", [[1], [5000], [0, 7, 0], [3000, 2500, 4000, 1], [25000] * 8, [1000, 0, 0, 3], [17] * 64])
+def test_merge_unique_runs_equals_sort_unique(H, dev, runs):
+    """Owner side of the sharded exchange: concatenated ascending duplicate-free runs (one per sender) merged by binary searches must give
+    bit for bit what the stable radix sort gives (unique ids, inverse, stable permutation, segment offsets, count)."""
+    import ctypes as C
+
+    g = torch.Generator().manual_seed(len(runs) * 1000 + sum(runs))
+    hi = max(10, sum(runs))  # dense id range -> many ids are requested by several senders
+    parts = [torch.sort(torch.randperm(hi, generator=g)[:r])[0] for r in runs]
+    ids = torch.cat(parts).to(dev)
+    n = ids.numel()
+    a, b = H.UniqueMap(max(n, 1), dev), H.UniqueMap(max(n, 1), dev)
+    a.run(ids, 63)
+    offs = [0]
+    for r in runs:
+        offs.append(offs[-1] + r)
+    arr = (C.c_int64 * len(offs))(*offs)
+    H.check(H.lib().marius_merge_unique_runs(H.ptr(ids), n, arr, len(runs), H.ptr(b.uniq), H.ptr(b.inverse), H.ptr(b.perm), H.ptr(b.seg), H.ptr(b.count),
+                                             H.ptr(b.ws), b.ws.numel(), H.stream_ptr()), "merge_unique_runs")
+    torch.cuda.synchronize()
+    U = int(a.count.item())
+    assert int(b.count.item()) == U == torch.unique(ids).numel()
+    assert torch.equal(b.uniq[:n], a.uniq[:n]) and torch.equal(b.inverse[:n], a.inverse[:n])
+    assert torch.equal(b.perm[:n], a.perm[:n]) and torch.equal(b.seg[:U + 1], a.seg[:U + 1])
