@@ -34,11 +34,13 @@ DEFAULTS = {
         "batch_size": 1000,
         "negative_sampling": {"num_chunks": 1, "negatives_per_positive": 1000, "degree_fraction": 0.0, "filtered": False, "local_filter_mode": "DEG"},
         "num_epochs": 10, "pipeline": {"sync": True}, "epochs_per_shuffle": 1, "logs_per_epoch": 10,
+        # marius_config.py:649-652, 734-735
+        "save_model": True, "checkpoint": {"save_best": False, "interval": -1, "save_state": False}, "resume_training": False, "resume_from_checkpoint": "",
     },
     "evaluation": {
         "batch_size": 1000,
         "negative_sampling": {"num_chunks": 1, "negatives_per_positive": 1000, "degree_fraction": 0.0, "filtered": False, "local_filter_mode": "DEG"},
-        "pipeline": {"sync": True}, "epochs_per_eval": 1,
+        "pipeline": {"sync": True}, "epochs_per_eval": 1, "checkpoint_dir": "",  # marius_config.py:782
     },
 }
 

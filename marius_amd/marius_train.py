@@ -73,6 +73,19 @@ def marius_train(cfg, log=print, train=True):
 
     train_edges = edges("train", ds["num_train"])
     resume = (not train) or bool(cfg["training"].get("resume_training", False))
+    # marius.cpp:59-90: training resumes from model_dir or from training.resume_from_checkpoint (whose files marius_config.py:932-934 copies
+    # into the model directory), evaluation reads model_dir or evaluation.checkpoint_dir
+    src_dir = (cfg["training"].get("resume_from_checkpoint") or "") if train else (cfg["evaluation"].get("checkpoint_dir") or "")
+    if src_dir and os.path.abspath(src_dir) != os.path.abspath(mdir):
+        import shutil
+
+        for name in ("embeddings.bin", "embeddings_state.bin", "model.pt", "model_state.pt", "metadata.csv"):
+            if os.path.exists(os.path.join(src_dir, name)):
+                shutil.copyfile(os.path.join(src_dir, name), os.path.join(mdir, name))
+        resume = True
+    epochs_processed = 0
+    if resume and os.path.exists(os.path.join(mdir, "metadata.csv")):
+        epochs_processed = int(open(os.path.join(mdir, "metadata.csv")).read().split("\n")[1])  # CheckpointMeta.num_epochs (marius.cpp:75)
     emb_cfg = cfg["storage"]["embeddings"]
     partitioned = train and emb_cfg["type"] == "PARTITION_BUFFER"
     emb_path, state_path = os.path.join(mdir, "embeddings.bin"), os.path.join(mdir, "embeddings_state.bin")
@@ -169,9 +182,26 @@ def marius_train(cfg, log=print, train=True):
             run_eval("test", rec)
         return [rec]
 
+    def write_meta(directory, num_epochs):
+        with open(os.path.join(directory, "metadata.csv"), "w") as f:
+            # name, num_epochs, checkpoint_id, link_prediction, has_state, has_encoded, has_model  (CheckpointMeta, checkpointer.h:12-21)
+            f.write("checkpoint\n%d\n-1\n1\n1\n%d\n1\n" % (num_epochs, 1 if cfg["storage"].get("export_encoded_nodes", False) else 0))
+
+    def save_into(directory, num_epochs):
+        """Checkpointer::save (checkpointer.cpp:39-54): node table + optimizer state as raw binaries, model.pt / model_state.pt as
+        torch::serialize archives with the reference's keys (Model::save, model.cpp:82-106), metadata.csv (checkpointer.cpp:104-116)."""
+        if not partitioned:  # the partition buffer wrote both files back at the end of the epoch
+            emb.write()
+            state.write()
+        model.save(os.path.join(directory, ""))
+        write_meta(directory, num_epochs)
+
+    ck = tr.get("checkpoint") or {}
+    interval = int(ck.get("interval", -1))
+    save_model = cfg["storage"].get("save_model", True) and tr.get("save_model", True)
     results = []
     for epoch in range(1, int(tr["num_epochs"]) + 1):
-        log("################ Starting training epoch %d ################" % epoch)
+        log("################ Starting training epoch %d ################" % (epochs_processed + epoch))
         trainer.train(1)
         log("Epoch Runtime: %dms" % int(trainer.last_epoch_seconds * 1e3))
         log("Edges per Second: %.2f" % trainer.last_edges_per_second)  # trainer.cpp:156-159
@@ -180,16 +210,24 @@ def marius_train(cfg, log=print, train=True):
             for split in evals:
                 run_eval(split, rec)
         results.append(rec)
-    if cfg["storage"].get("save_model", True) and cfg["training"].get("save_model", True):
-        # Checkpointer::save (checkpointer.cpp:39-54) into model_dir: node table + optimizer state as raw binaries, model.pt / model_state.pt
-        # as torch::serialize archives with the reference's keys (Model::save, model.cpp:82-106), metadata.csv (checkpointer.cpp:104-116)
-        if not partitioned:  # the partition buffer wrote both files back at the end of the epoch
-            emb.write()
-            state.write()
-        model.save(os.path.join(mdir, ""))
-        with open(os.path.join(mdir, "metadata.csv"), "w") as f:
-            # name, num_epochs, checkpoint_id, link_prediction, has_state, has_encoded, has_model  (CheckpointMeta, checkpointer.h:12-21)
-            f.write("checkpoint\n%d\n-1\n1\n1\n%d\n1\n" % (int(tr["num_epochs"]), 1 if cfg["storage"].get("export_encoded_nodes", False) else 0))
+        if save_model and interval > 0 and epoch % interval == 0 and epoch < int(tr["num_epochs"]):
+            # Checkpointer::create_checkpoint (checkpointer.cpp:18-37): <model_dir>/checkpoint_<epochs>/ via a _tmp directory and a rename.  The
+            # reference copies the embeddings file as it was LAST written and only then writes the current table to model_dir; here the
+            # table is written first, so the checkpoint holds the state it is named after.
+            import shutil
+
+            done = epochs_processed + epoch
+            tmp, final = os.path.join(mdir, "checkpoint_%d_tmp" % done), os.path.join(mdir, "checkpoint_%d" % done)
+            os.makedirs(tmp, exist_ok=True)
+            save_into(tmp, done)
+            shutil.copyfile(emb_path, os.path.join(tmp, "embeddings.bin"))
+            if bool(ck.get("save_state", False)):
+                shutil.copyfile(state_path, os.path.join(tmp, "embeddings_state.bin"))
+            if os.path.exists(final):
+                shutil.rmtree(final)
+            os.rename(tmp, final)
+    if save_model:
+        save_into(mdir, epochs_processed + int(tr["num_epochs"]))
     return results
 
 

@@ -523,3 +523,54 @@ def test_cpp_sharded_trainer_staleness1_matches_stale_oracle(M, dev):
         sync.step(edges_all[perm2[t * B:(t + 1) * B]])
     assert not torch.allclose(sync.table, T, rtol=1e-4, atol=1e-6)  # the stale trajectory really differs from the synchronous one
     dist.destroy_process_group()
+
+
+def test_marius_train_checkpoints_and_resume(M, dev, tmp_path):
+    """training.checkpoint.interval (checkpointer.cpp:18-37: <model_dir>/checkpoint_<epochs>/), training.resume_from_checkpoint and
+    evaluation.checkpoint_dir (marius.cpp:59-90), epoch count carried by metadata.csv."""
+    from marius_amd import config as C
+    from marius_amd.marius_train import marius_eval, marius_train
+
+    num_nodes, R, E = 200, 3, 3000
+    g = torch.Generator().manual_seed(0)
+    src = torch.randint(num_nodes, (E,), generator=g)
+    rel = torch.randint(R, (E,), generator=g)
+    edges = torch.stack([src, rel, (src * 5 + rel * 11 + 1) % num_nodes], 1).to(torch.int32)
+    ddir = tmp_path / "ds"
+    (ddir / "edges").mkdir(parents=True)
+    edges[:2500].numpy().tofile(str(ddir / "edges" / "train_edges.bin"))
+    edges[2500:].numpy().tofile(str(ddir / "edges" / "test_edges.bin"))
+    yaml.safe_dump({"dataset_dir": str(ddir), "num_edges": E, "num_nodes": num_nodes, "num_relations": R, "num_train": 2500, "num_valid": -1, "num_test": 500},
+                   open(ddir / "dataset.yaml", "w"))
+
+    def cfg(extra_training=None, extra_eval=None, model_dir=None):
+        user = {"model": {"random_seed": 5, "encoder": {"layers": [[{"type": "EMBEDDING", "output_dim": 16}]]}, "decoder": {"type": "DISTMULT"}},
+                "storage": {"device_type": "cuda", "dataset": {"dataset_dir": str(ddir)}, "model_dir": model_dir or str(tmp_path / "model_a")},
+                "training": dict({"batch_size": 500, "negative_sampling": {"num_chunks": 5, "negatives_per_positive": 50}, "num_epochs": 5}, **(extra_training or {})),
+                "evaluation": dict({"batch_size": 500, "negative_sampling": {"num_chunks": 1, "negatives_per_positive": 100}}, **(extra_eval or {}))}
+        path = tmp_path / "cfg.yaml"
+        yaml.safe_dump(user, open(path, "w"))
+        return C.load_config(str(path))
+
+    a = cfg({"checkpoint": {"interval": 2, "save_state": True}})
+    assert a["training"]["checkpoint"]["save_best"] is False
+    marius_train(a, log=lambda *x: None)
+    mdir = a["storage"]["model_dir"]
+    for ep in (2, 4):
+        ck = os.path.join(mdir, "checkpoint_%d" % ep)
+        assert sorted(os.listdir(ck)) == ["embeddings.bin", "embeddings_state.bin", "metadata.csv", "model.pt", "model_state.pt"]
+        assert open(os.path.join(ck, "metadata.csv")).read().split("\n")[1] == str(ep)
+    assert not os.path.exists(os.path.join(mdir, "checkpoint_5")) and not any(n.endswith("_tmp") for n in os.listdir(mdir))
+    assert open(os.path.join(mdir, "metadata.csv")).read().split("\n")[1] == "5"
+    e2, e5 = (np.fromfile(os.path.join(p, "embeddings.bin"), dtype=np.float32) for p in (os.path.join(mdir, "checkpoint_2"), mdir))
+    assert e2.shape == e5.shape and not np.array_equal(e2, e5)
+    # resume from the epoch-2 checkpoint into a new model directory: one more epoch -> 3 epochs on record
+    b = cfg({"num_epochs": 1, "resume_training": True, "resume_from_checkpoint": os.path.join(mdir, "checkpoint_2")}, model_dir=str(tmp_path / "model_b"))
+    marius_train(b, log=lambda *x: None)
+    assert open(os.path.join(b["storage"]["model_dir"], "metadata.csv")).read().split("\n")[1] == "3"
+    e3 = np.fromfile(os.path.join(b["storage"]["model_dir"], "embeddings.bin"), dtype=np.float32)
+    assert not np.array_equal(e3, e2)
+    # evaluate a checkpoint directory
+    r4 = marius_eval(cfg(extra_eval={"checkpoint_dir": os.path.join(mdir, "checkpoint_4")}, model_dir=str(tmp_path / "model_c")), log=lambda *x: None)
+    r5 = marius_eval(cfg(model_dir=mdir), log=lambda *x: None)
+    assert r4[0]["test"]["MRR"] > 0 and r5[0]["test"]["MRR"] > 0 and r4[0]["test"]["MRR"] != r5[0]["test"]["MRR"]
