@@ -574,3 +574,31 @@ def test_marius_train_checkpoints_and_resume(M, dev, tmp_path):
     r4 = marius_eval(cfg(extra_eval={"checkpoint_dir": os.path.join(mdir, "checkpoint_4")}, model_dir=str(tmp_path / "model_c")), log=lambda *x: None)
     r5 = marius_eval(cfg(model_dir=mdir), log=lambda *x: None)
     assert r4[0]["test"]["MRR"] > 0 and r5[0]["test"]["MRR"] > 0 and r4[0]["test"]["MRR"] != r5[0]["test"]["MRR"]
+
+
+def test_marius_train_single_relation_dataset_uses_two_column_edges(M, dev, tmp_path):
+    """num_relations == 1 (social graphs such as Twitter, cfg5): edges are stored as (src, dst) (io.cpp:42-45), the relation operator is
+    skipped and only the dst direction is scored."""
+    from marius_amd import config as C
+    from marius_amd.marius_train import marius_eval, marius_train
+
+    num_nodes, E = 300, 4000
+    g = torch.Generator().manual_seed(1)
+    src = torch.randint(num_nodes, (E,), generator=g)
+    edges = torch.stack([src, (src * 7 + 3) % num_nodes], 1).to(torch.int32)
+    ddir = tmp_path / "ds"
+    (ddir / "edges").mkdir(parents=True)
+    edges[:3500].numpy().tofile(str(ddir / "edges" / "train_edges.bin"))
+    edges[3500:].numpy().tofile(str(ddir / "edges" / "test_edges.bin"))
+    yaml.safe_dump({"dataset_dir": str(ddir), "num_edges": E, "num_nodes": num_nodes, "num_relations": 1, "num_train": 3500, "num_valid": -1, "num_test": 500},
+                   open(ddir / "dataset.yaml", "w"))
+    path = tmp_path / "cfg.yaml"
+    yaml.safe_dump({"model": {"random_seed": 2, "encoder": {"layers": [[{"type": "EMBEDDING", "output_dim": 32}]]}, "decoder": {"type": "DISTMULT"}},
+                    "storage": {"device_type": "cuda", "dataset": {"dataset_dir": str(ddir)}},
+                    "training": {"batch_size": 500, "negative_sampling": {"num_chunks": 5, "negatives_per_positive": 100}, "num_epochs": 8},
+                    "evaluation": {"batch_size": 500, "negative_sampling": {"num_chunks": 1, "negatives_per_positive": 200}}}, open(path, "w"))
+    cfg = C.load_config(str(path))
+    res = marius_train(cfg, log=lambda *a: None)
+    assert res[-1]["test"]["MRR"] > 0.3  # chance level: ~0.03 (the synthetic rule is learnt within the first epoch)
+    again = marius_eval(cfg, log=lambda *a: None)
+    assert abs(again[0]["test"]["MRR"] - res[-1]["test"]["MRR"]) < 0.05
