@@ -144,7 +144,7 @@ class HipBackend:
             inv = s.inv_rel_grad
         return grad, [s.rel_grad, inv], W.loss_values()[0]
 
-    def apply_local(self, local_ids, grads):
+    def apply_local(self, local_ids, grads, recv_counts=None):
         H, s = self.H, self.s
         n = local_ids.numel()
         if n == 0:
@@ -154,7 +154,19 @@ class HipBackend:
             self.um_recv = H.UniqueMap(cap, local_ids.device)
             self.carry_recv = H.segment_carry(cap, s.d, local_ids.device)
         bits = max(1, math.ceil(math.log2(self.table.size(0) + 1)))
-        self.um_recv.run(local_ids.contiguous(), bits)
+        if recv_counts is not None and len(recv_counts) <= 64:
+            # every sender's list is ascending and duplicate-free: merge the runs instead of radix-sorting them (bit-equal result)
+            import ctypes
+
+            offs = [0]
+            for c in recv_counts:
+                offs.append(offs[-1] + int(c))
+            um, ids = self.um_recv, local_ids.contiguous()
+            H.check(H.lib().marius_merge_unique_runs(H.ptr(ids), n, (ctypes.c_int64 * len(offs))(*offs), len(recv_counts), H.ptr(um.uniq), H.ptr(um.inverse),
+                                                     H.ptr(um.perm), H.ptr(um.seg), H.ptr(um.count), H.ptr(um.ws), um.ws_bytes, H.stream_ptr()),
+                    "merge_unique_runs")
+        else:
+            self.um_recv.run(local_ids.contiguous(), bits)
         H.segment_adagrad_scatter(grads, self.um_recv, n, s.d, self.table, self.state, s.sparse_lr, carry=self.carry_recv)
 
     def dense_state(self):
@@ -244,7 +256,7 @@ class PipelineSchedule:
     def _compute(self, t):                     # forward / loss / backward of slot t: sets slot.grad [U, d], returns relation grads or None
         raise NotImplementedError
 
-    def _apply_local(self, local_ids, grads):
+    def _apply_local(self, local_ids, grads, recv_counts=None):  # recv_counts: rows per sender (each sender's ids ascend)
         raise NotImplementedError
 
     def _dense_step(self, rel_grads):
@@ -312,7 +324,7 @@ class PipelineSchedule:
         with self._on("xchg"):
             self._wait("xchg", slot.computed)
             recv_grad = a2a_rows(slot.grad, slot.send_counts, slot.recv_counts, self.group, out=self._buf("recv_grad", slot.nrecv, (self.d,), torch.float32))
-            self._apply_local(slot.local_ids, recv_grad)
+            self._apply_local(slot.local_ids, recv_grad, slot.recv_counts)
             self._record(slot.free, "xchg")
 
     def _dense(self, t, rel_grads):
@@ -500,8 +512,8 @@ class PipelinedShardedTrainer(PipelineSchedule):
             inv = s.inv_rel_grad
         return [s.rel_grad, inv]
 
-    def _apply_local(self, local_ids, grads):
-        self.backend.apply_local(local_ids, grads)
+    def _apply_local(self, local_ids, grads, recv_counts=None):
+        self.backend.apply_local(local_ids, grads, recv_counts)
 
     def _dense_step(self, rel_grads):
         self.backend.dense_step(rel_grads)

@@ -227,7 +227,8 @@ def make_oracle_pipeline(cfg, rank, world, be, edges, sync_interval, staleness, 
             slot.grad, rel_grads, self.loss = be.compute(slot.ctx, slot.emb)
             return rel_grads
 
-        def _apply_local(self, local_ids, grads):
+        def _apply_local(self, local_ids, grads, recv_counts=None):
+            assert sum(recv_counts) == local_ids.numel()
             be.apply_local(local_ids, grads)
 
         def _dense_step(self, rel_grads):
