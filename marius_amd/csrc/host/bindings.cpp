@@ -278,7 +278,7 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("getNumEdges", &DataLoader::getNumEdges)
         .def("setEdgeBucketSizes", &DataLoader::setEdgeBucketSizes, py::arg("sizes"))
         .def("loadStorage", &DataLoader::loadStorage)
-        .def("nextEpoch", &DataLoader::nextEpoch)
+        .def("nextEpoch", &DataLoader::nextEpoch, py::arg("write") = true)
         .def_readonly("buffer_states", &DataLoader::buffer_states_)
         .def_readonly("edge_buckets_per_buffer", &DataLoader::edge_buckets_per_buffer_)
         .def_readonly("active_edges", &DataLoader::active_edges_)

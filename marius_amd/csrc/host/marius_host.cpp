@@ -1017,11 +1017,11 @@ void DataLoader::loadStorage() {
     buffer_cursor_ = 0;
 }
 
-void DataLoader::nextEpoch() {
+void DataLoader::nextEpoch(bool write) {
     if (!partitioned()) return;
     next_.reset();
-    pb_embeddings_->unload(true);
-    if (pb_state_) pb_state_->unload(true);
+    pb_embeddings_->unload(write);
+    if (pb_state_) pb_state_->unload(write);
 }
 
 void DataLoader::setActiveEdges() {
@@ -1258,12 +1258,16 @@ void SynchronousTrainer::train_steps(int64_t n) {
 
 std::vector<double> SynchronousEvaluator::evaluate() {
     model_->reporter_->clear();
+    // partitioned evaluation (storage.full_graph_evaluation: false): the evaluation edges are walked buffer state by buffer state like the
+    // training edges, negatives come from the nodes in memory (dataloader.cpp:296-345 applies to both modes)
+    dataloader_->loadStorage();
     dataloader_->initializeBatches(false);
     while (dataloader_->hasNextBatch()) {
         auto batch = dataloader_->getBatch(true);
         dataloader_->loadGPUParameters(batch);
         model_->evaluate_batch(batch);
     }
+    dataloader_->nextEpoch(/*write=*/false);  // nothing was modified
     return model_->reporter_->report();
 }
 

@@ -455,7 +455,7 @@ class DataLoader {
     bool partitioned() const { return pb_embeddings_ != nullptr; }
     void setEdgeBucketSizes(std::vector<int64_t> sizes);  // Storage::edge_bucket_sizes_ (storage.h:50) of the train edges
     void loadStorage();                             // dataloader.cpp:566-600: new ordering (consumes the generator), load the first buffer state
-    void nextEpoch();                               // dataloader.cpp:108-118: write the buffer back, unload
+    void nextEpoch(bool write = true);              // dataloader.cpp:108-118: write the buffer back (training), unload
     void setActiveEdges();                          // dataloader.cpp:120-175 for the current buffer state
     shared_ptr<Batch> getBatch(bool exact_unique = true);  // dataloader.cpp:360-471
     void loadGPUParameters(shared_ptr<Batch> batch);       // dataloader.cpp:529-548

@@ -87,19 +87,25 @@ def marius_train(cfg, log=print, train=True):
     if resume and os.path.exists(os.path.join(mdir, "metadata.csv")):
         epochs_processed = int(open(os.path.join(mdir, "metadata.csv")).read().split("\n")[1])  # CheckpointMeta.num_epochs (marius.cpp:75)
     emb_cfg = cfg["storage"]["embeddings"]
-    partitioned = train and emb_cfg["type"] == "PARTITION_BUFFER"
+    pb_cfg = emb_cfg["type"] == "PARTITION_BUFFER"
+    partitioned = train and pb_cfg
+    # storage.full_graph_evaluation: false (graph_storage.cpp:104-112): evaluate buffer state by buffer state instead of loading the whole table
+    part_eval = pb_cfg and not bool(cfg["storage"].get("full_graph_evaluation", True))
     emb_path, state_path = os.path.join(mdir, "embeddings.bin"), os.path.join(mdir, "embeddings_state.bin")
     eval_emb = None
+    pb_opts = None
+    if pb_cfg:
+        po = emb_cfg["options"]
+        pb_opts = H.PartitionBufferOptions()
+        pb_opts.num_partitions, pb_opts.buffer_capacity = int(po["num_partitions"]), int(po["buffer_capacity"])
+        pb_opts.prefetching, pb_opts.fine_to_coarse_ratio = bool(po["prefetching"]), int(po["fine_to_coarse_ratio"])
+        pb_opts.num_cache_partitions = int(po["num_cache_partitions"])
+        pb_opts.edge_bucket_ordering = getattr(H.EdgeBucketOrdering, str(po["edge_bucket_ordering"]).upper())
+        pb_opts.randomly_assign_edge_buckets = bool(po["randomly_assign_edge_buckets"])
     if partitioned:
         # out-of-core node table (io.cpp:300-330 -> PartitionBufferStorage over <model_dir>/embeddings.bin + embeddings_state.bin; the
         # train edges are sorted by edge bucket and edges/train_partition_offsets.txt lists the bucket sizes, io.cpp:110-121)
-        po = emb_cfg["options"]
-        opts = H.PartitionBufferOptions()
-        opts.num_partitions, opts.buffer_capacity = int(po["num_partitions"]), int(po["buffer_capacity"])
-        opts.prefetching, opts.fine_to_coarse_ratio = bool(po["prefetching"]), int(po["fine_to_coarse_ratio"])
-        opts.num_cache_partitions = int(po["num_cache_partitions"])
-        opts.edge_bucket_ordering = getattr(H.EdgeBucketOrdering, str(po["edge_bucket_ordering"]).upper())
-        opts.randomly_assign_edge_buckets = bool(po["randomly_assign_edge_buckets"])
+        opts = pb_opts
         train_edges.readPartitionSizes(os.path.join(ddir, "edges", "train_partition_offsets.txt"))  # io.cpp:110-121
         if not resume:
             limit = math.sqrt(6.0 / (num_nodes + d))
@@ -153,7 +159,13 @@ def marius_train(cfg, log=print, train=True):
         n = int(ds.get(key, -1))
         if n > 0 and os.path.exists(_edge_file(ddir, split)):
             eval_edges[split] = edges(split, n)
-            evals[split] = H.SynchronousEvaluator(H.DataLoader(eval_edges[split], eval_emb or emb, None, sampler(ev["negative_sampling"]), gen,
+            table_for_eval = eval_emb or emb
+            if part_eval:
+                # bucket-sorted evaluation edges + edges/<split>_partition_offsets.txt (io.cpp:116-121); a buffer of its own over the same file
+                # (the training buffer is unloaded between epochs)
+                eval_edges[split].readPartitionSizes(os.path.join(ddir, "edges", "%s_partition_offsets.txt" % split))
+                table_for_eval = H.PartitionBufferStorage(emb_path, num_nodes, d, pb_opts, dev)
+            evals[split] = H.SynchronousEvaluator(H.DataLoader(eval_edges[split], table_for_eval, None, sampler(ev["negative_sampling"]), gen,
                                                                int(ev["batch_size"]), False), model)
     f_train, f_eval = bool(tr["negative_sampling"].get("filtered", False)), bool(ev["negative_sampling"].get("filtered", False)) and bool(evals)
     if f_train or f_eval:
@@ -168,10 +180,10 @@ def marius_train(cfg, log=print, train=True):
 
     def run_eval(split, rec):
         t0 = time.time()
-        if eval_emb is not None:
+        if eval_emb is not None and not part_eval:
             eval_emb.load()
         r = evals[split].evaluate()
-        if eval_emb is not None:
+        if eval_emb is not None and not part_eval:
             eval_emb.unload(False)
         log("%s evaluation (%.0f ms): %s" % (split, (time.time() - t0) * 1e3, ", ".join("%s: %.6f" % kv for kv in zip(METRICS, r))))
         rec[split] = dict(zip(METRICS, r))

@@ -257,3 +257,109 @@ def test_marius_train_with_partition_buffer_config(M, dev, tmp_path):
     assert (state > 0).mean() > 0.9  # every partition was trained and written back
     again = marius_eval(C.load_config(str(cfg_path)) | {"storage": cfg["storage"]}, log=lambda *a: None)
     assert abs(again[0]["test"]["MRR"] - res[-1]["test"]["MRR"]) < 0.05
+
+
+def test_partitioned_evaluation_matches_oracle(M, dev, tmp_path):
+    """storage.full_graph_evaluation: false — the evaluation edges are walked buffer state by buffer state, negatives come from the nodes in
+    memory; MRR / mean rank / hits against the same loop on the oracle (ranks depend on which negatives a batch drew, so batch order counts)."""
+    from oracle import lp_oracle as O
+
+    num_nodes, R, d, B, N, E, seed, p, c = 1203, 5, 16, 64, 50, 700, 31, 8, 4
+    g = torch.Generator().manual_seed(4)
+    table = torch.rand(num_nodes, d, generator=g) - 0.5
+    raw = torch.stack([torch.randint(num_nodes, (E,), generator=g), torch.randint(R, (E,), generator=g), torch.randint(num_nodes, (E,), generator=g)], 1)
+    edges_sorted, sizes = P.partition_edges(raw, num_nodes, p)
+    paths = {k: str(tmp_path / (k + ".bin")) for k in ("dev", "cpu")}
+    for pth in paths.values():
+        P.write_table(pth, table.numpy())
+    o = M.PartitionBufferOptions()
+    o.num_partitions, o.buffer_capacity, o.prefetching, o.fine_to_coarse_ratio = p, c, True, 2
+    o.edge_bucket_ordering, o.randomly_assign_edge_buckets = M.EdgeBucketOrdering.COMET, False
+    emb = M.PartitionBufferStorage(paths["dev"], num_nodes, d, o, dev)
+    gen = M.MariusGenerator(seed)
+    est = M.InMemory(edges_sorted.to(torch.int32).to(dev))
+    est.edge_bucket_sizes = sizes
+    loader = M.DataLoader(est, emb, None, M.CorruptNodeNegativeSampler(1, N, 0.0, False, M.LocalFilterMode.DEG, gen), gen, B, False)
+    dec = M.DistMult(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+    rel, inv = torch.rand(R, d, generator=g) + 0.5, torch.rand(R, d, generator=g) + 0.5
+    dec.relations.copy_(rel.to(dev))
+    dec.inverse_relations.copy_(inv.to(dev))
+    model = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+    got = M.SynchronousEvaluator(loader, model).evaluate()
+    assert emb.swaps > 0
+    assert np.array_equal(np.fromfile(paths["dev"], dtype=np.float32), np.fromfile(paths["cpu"], dtype=np.float32))  # evaluation modifies nothing
+    # ---- oracle
+    ps = -(-num_nodes // p)
+    buf = P.PartitionBufferOracle(c, p, ps, d, num_nodes, paths["cpu"])
+    cpu = CpuLinkPredictionStep("DISTMULT", torch.zeros(1, d), torch.zeros(1, d), R, B, 1, N)
+    cpu.num_nodes = c * ps
+    torch.manual_seed(seed)
+    states, buckets = P.two_level_beta_ordering(p, c, 2, 0, False)
+    buf.set_buffer_ordering(states)
+    buf.load()
+    lo_ranks, hi_ranks = [], []
+    for i, bs in enumerate(buckets):
+        if i > 0:
+            buf.perform_next_swap()
+        slab = torch.from_numpy(buf.slab)
+        act = P.active_edges_for_state(edges_sorted, sizes, bs, buf.global_to_local_map(True), p)
+        if act.size(0) == 0:
+            continue
+        perm = torch.randperm(act.size(0))
+        order = torch.arange(act.size(0)) if i == 0 else perm  # the first state keeps file order (initializeBatches(false)), the draw is consumed
+        for s in range(0, act.size(0), B):
+            e = act[order[s:s + B]]
+            src_neg, _ = cpu.get_negatives(e, True)
+            dst_neg, _ = cpu.get_negatives(e, False)
+            pos, neg, ipos, ineg = O.node_corrupt_forward("DISTMULT", e, slab, dst_neg, src_neg, rel, inv)
+            # a sampled negative can be the edge's own endpoint: its score equals the positive's up to summation order, and `neg >= pos`
+            # then falls either way (on the reference's CPU vs GPU paths as well) -> bracket the rank instead of pinning the tie-break
+            for ps_, ng_ in ((pos, neg), (ipos, ineg)):
+                tol = 1e-5 * (1 + ps_.abs().unsqueeze(1))
+                lo_ranks.append((ng_ > ps_.unsqueeze(1) + tol).sum(1) + 1)
+                hi_ranks.append((ng_ >= ps_.unsqueeze(1) - tol).sum(1) + 1)
+    lo, hi = torch.cat(lo_ranks).double(), torch.cat(hi_ranks).double()
+    assert lo.numel() == 2 * E and 0 < (hi - lo).sum() < 0.15 * lo.numel()  # only self-negatives are ambiguous (50 draws from 604 resident nodes)
+    eps = 1e-9
+    assert (1.0 / hi).mean().item() - eps <= got[0] <= (1.0 / lo).mean().item() + eps   # MRR
+    assert lo.mean().item() - eps <= got[1] <= hi.mean().item() + eps                    # mean rank
+    for j, k in enumerate((1, 3, 5, 10, 50, 100)):
+        assert (hi <= k).double().mean().item() - eps <= got[2 + j] <= (lo <= k).double().mean().item() + eps
+
+
+def test_marius_train_partitioned_evaluation_config(M, dev, tmp_path):
+    """storage.full_graph_evaluation: false with PARTITION_BUFFER embeddings: validation / test edges bucket-sorted with their own
+    partition offsets files (edges/<split>_partition_offsets.txt, io.cpp:116-121), evaluated through a partition buffer."""
+    import os
+
+    import yaml
+
+    from marius_amd import config as C
+    from marius_amd.marius_train import marius_eval, marius_train
+
+    num_nodes, R, E, p = 300, 4, 6000, 4
+    g = torch.Generator().manual_seed(0)
+    src = torch.randint(num_nodes, (E,), generator=g)
+    rel = torch.randint(R, (E,), generator=g)
+    edges = torch.stack([src, rel, (src * 7 + rel * 13 + 1) % num_nodes], 1)
+    ddir = tmp_path / "ds"
+    (ddir / "edges").mkdir(parents=True)
+    for split, part in (("train", edges[:5000]), ("validation", edges[5000:5500]), ("test", edges[5500:])):
+        srt, sizes = P.partition_edges(part, num_nodes, p)
+        srt.to(torch.int32).numpy().tofile(str(ddir / "edges" / ("%s_edges.bin" % split)))
+        (ddir / "edges" / ("%s_partition_offsets.txt" % split)).write_text("\n".join(str(s) for s in sizes) + "\n")
+    yaml.safe_dump({"dataset_dir": str(ddir), "num_edges": E, "num_nodes": num_nodes, "num_relations": R, "num_train": 5000, "num_valid": 500,
+                    "num_test": 500}, open(ddir / "dataset.yaml", "w"))
+    cfg_path = tmp_path / "cfg.yaml"
+    yaml.safe_dump({
+        "model": {"random_seed": 3, "encoder": {"layers": [[{"type": "EMBEDDING", "output_dim": 32}]]}, "decoder": {"type": "DISTMULT"}},
+        "storage": {"device_type": "cuda", "dataset": {"dataset_dir": str(ddir)}, "full_graph_evaluation": False,
+                    "embeddings": {"type": "PARTITION_BUFFER", "options": {"num_partitions": p, "buffer_capacity": 2, "edge_bucket_ordering": "NEW_BETA"}}},
+        "training": {"batch_size": 500, "negative_sampling": {"num_chunks": 5, "negatives_per_positive": 100}, "num_epochs": 4},
+        "evaluation": {"batch_size": 250, "negative_sampling": {"num_chunks": 1, "negatives_per_positive": 100}},
+    }, open(cfg_path, "w"))
+    cfg = C.load_config(str(cfg_path))
+    res = marius_train(cfg, log=lambda *a: None)
+    assert res[-1]["validation"]["MRR"] > res[0]["validation"]["MRR"] and res[-1]["test"]["MRR"] > 0.2
+    again = marius_eval(cfg, log=lambda *a: None)
+    assert abs(again[0]["test"]["MRR"] - res[-1]["test"]["MRR"]) < 0.08  # a fresh ordering and fresh negatives, same table
