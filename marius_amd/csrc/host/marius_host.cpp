@@ -1041,7 +1041,8 @@ void DataLoader::setActiveEdges() {
         return;
     }
     Tensor act = torch::cat(parts).to(torch::kInt64);
-    Tensor g2l = pb_embeddings_->getGlobalToLocalMap(true).to(dev);  // graph_storage.cpp:395-420: node columns -> buffer rows
+    Tensor g2l = pb_embeddings_->getGlobalToLocalMapDevice();  // graph_storage.cpp:395-420: node columns -> buffer rows
+    (void)dev;
     std::vector<Tensor> columns{g2l.index_select(0, act.select(1, 0))};
     if (cols == 3) columns.push_back(act.select(1, 1));
     columns.push_back(g2l.index_select(0, act.select(1, -1)));

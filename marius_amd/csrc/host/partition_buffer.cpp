@@ -321,6 +321,17 @@ Tensor PartitionBuffer::getGlobalToLocalMap(bool get_current) {  // buffer.cpp:5
     return map;
 }
 
+Tensor PartitionBuffer::getGlobalToLocalMapDevice() {
+    auto opt = torch::TensorOptions().dtype(torch::kInt64).device(device_);
+    Tensor map = torch::full({total_embeddings_}, -1, opt);
+    for (auto id : buffer_state_) {
+        const Partition& p = partition_table_[id];
+        const int64_t b = (int64_t)p.buffer_idx_ * partition_size_;
+        if (p.partition_size_ > 0) map.narrow(0, p.idx_offset_, p.partition_size_).copy_(torch::arange(b, b + p.partition_size_, opt));
+    }
+    return map;
+}
+
 Tensor PartitionBuffer::indexRead(Tensor indices) {  // buffer.cpp:434-448
     if (indices.sizes().size() != 1) throw std::runtime_error("");
     require_device(buffer_tensor_view_, "PartitionBuffer::indexRead");

@@ -57,6 +57,7 @@ class PartitionBuffer {
     Tensor indexRead(Tensor indices);               // buffer-local ids, device
     void indexAdd(Tensor indices, Tensor values);   // ids unique
     Tensor getGlobalToLocalMap(bool get_current);   // host int64 [total_embeddings], -1 = not in the buffer
+    Tensor getGlobalToLocalMapDevice();             // the current map built on the device (a few slice fills instead of a host loop + upload)
     void setBufferOrdering(std::vector<Tensor> buffer_states);
     bool hasSwap();
     void performNextSwap();
@@ -137,6 +138,7 @@ class PartitionBufferStorage : public Storage {  // storage.h:89-146
     bool hasSwap() { return buffer_->hasSwap(); }
     void performNextSwap();
     Tensor getGlobalToLocalMap(bool get_current) { return buffer_->getGlobalToLocalMap(get_current); }
+    Tensor getGlobalToLocalMapDevice() { return buffer_->getGlobalToLocalMapDevice(); }
     void sync() { buffer_->sync(); }
     void setBufferOrdering(std::vector<Tensor> buffer_states);
     std::vector<int> getNextAdmit() { return buffer_->getNextAdmit(); }

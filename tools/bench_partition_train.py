@@ -1,0 +1,89 @@
+"""One epoch of out-of-core training (PartitionBufferStorage: slab in HBM, swaps over PCIe) next to the same epoch with the table in
+DEVICE_MEMORY, Freebase86m-shaped batches on a smaller table so that the files fit a scratch disk.
+
+    python tools/bench_partition_train.py [--nodes 10000000] [--edges 5000000] [--partitions 8] [--capacity 4] [--dir /tmp]
+Prints one JSON line: positive edges/s in both modes, number of swaps and the time spent in them.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import marius_amd  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nodes", type=int, default=10_000_000)
+    ap.add_argument("--edges", type=int, default=5_000_000)
+    ap.add_argument("--partitions", type=int, default=8)
+    ap.add_argument("--capacity", type=int, default=4)
+    ap.add_argument("--d", type=int, default=100)
+    ap.add_argument("--dir", default="/tmp")
+    a = ap.parse_args()
+    M = marius_amd.host()
+    dev = torch.device("cuda", 0)
+    R, B, C, N, d, p = 14824, 50000, 50, 1000, a.d, a.partitions
+    g = torch.Generator(device=dev).manual_seed(1)
+    src = torch.randint(a.nodes, (a.edges,), generator=g, device=dev)
+    dst = torch.randint(a.nodes, (a.edges,), generator=g, device=dev)
+    rel = torch.randint(R, (a.edges,), generator=g, device=dev)
+    ps = -(-a.nodes // p)
+    bucket = (src // ps) * p + dst // ps                       # torch_partitioner.py:12-46 on the device: stable sort by edge bucket
+    order = torch.sort(bucket, stable=True)[1]
+    edges = torch.stack([src, rel, dst], 1)[order].to(torch.int32)
+    sizes = torch.bincount(bucket, minlength=p * p).tolist()
+    del src, dst, rel, bucket, order
+
+    def model():
+        dec = M.ComplEx(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+        m = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+        m.setup_optimizers(0.1)
+        m.sparse_lr = 0.1
+        return m
+
+    out = {"nodes": a.nodes, "edges": a.edges, "d": d, "partitions": p, "capacity": a.capacity, "table_GB": round(a.nodes * d * 4 / 1e9, 2)}
+    # ---- in memory
+    gen = M.MariusGenerator(7)
+    emb, st = M.InMemory(torch.zeros((a.nodes, d), device=dev).uniform_(-0.01, 0.01)), M.InMemory(torch.zeros((a.nodes, d), device=dev))
+    loader = M.DataLoader(M.InMemory(edges), emb, st, M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen), gen, B, True)
+    tr = M.SynchronousTrainer(loader, model())
+    tr.train(1)
+    out["device_memory_edges_per_s"] = round(tr.last_edges_per_second, 1)
+    del tr, loader, emb, st
+    torch.cuda.empty_cache()
+    # ---- partition buffer
+    paths = [os.path.join(a.dir, n) for n in ("pb_bench_embeddings.bin", "pb_bench_state.bin")]
+    rows = 1 << 20
+    with open(paths[0], "wb") as fe, open(paths[1], "wb") as fs:
+        for lo in range(0, a.nodes, rows):
+            n = min(rows, a.nodes - lo)
+            fe.write(torch.zeros((n, d), device=dev).uniform_(-0.01, 0.01).cpu().numpy().tobytes())
+            fs.write(bytes(4 * d * n))
+    o = M.PartitionBufferOptions()
+    o.num_partitions, o.buffer_capacity, o.prefetching, o.fine_to_coarse_ratio = p, a.capacity, True, 1
+    o.edge_bucket_ordering = M.EdgeBucketOrdering.NEW_BETA
+    emb, st = M.PartitionBufferStorage(paths[0], a.nodes, d, o, dev), M.PartitionBufferStorage(paths[1], a.nodes, d, o, dev)
+    gen = M.MariusGenerator(7)
+    est = M.InMemory(edges)
+    est.edge_bucket_sizes = sizes
+    loader = M.DataLoader(est, emb, st, M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen), gen, B, True)
+    tr = M.SynchronousTrainer(loader, model())
+    t0 = time.perf_counter()
+    tr.train(1)
+    wall = time.perf_counter() - t0
+    out.update({"partition_buffer_edges_per_s": round(tr.last_edges_per_second, 1), "epoch_wall_s_incl_load_and_writeback": round(wall, 2),
+                "swaps": emb.swaps, "prefetch_hits": emb.prefetch_hits, "swap_seconds_embeddings": round(emb.swap_seconds, 3),
+                "swap_seconds_state": round(st.swap_seconds, 3), "buffer_states": len(loader.buffer_states)})
+    for pth in paths:
+        os.remove(pth)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
