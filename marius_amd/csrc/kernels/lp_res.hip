@@ -1340,8 +1340,8 @@ __device__ __forceinline__ void grad_neg16_body(const GradArgs& a, int cd, int u
 }
 
 // One launch for both backward contractions: the unit list of a (chunk, dir) is [adj row-tiles..., neg row-tiles...].
-// (Two separate launches of 1600 workgroups each over 768 resident slots run 3 rounds at 69 % fill; 3200 units run 5 at 83 %,
-// and the two kinds of units have different load/MFMA phase patterns, which desynchronises the workgroups sharing a CU.)
+// (One launch instead of two saves a launch gap, and the two kinds of units have different load/MFMA phase patterns, which
+// desynchronises the workgroups sharing a CU.  The "rounds of resident slots" arithmetic is not the reason: see launch_grad16_hy.)
 // which: 0 = both, 1 = adj only, 2 = neg only.
 template <bool L2, int NT>
 __global__ __launch_bounds__(256, 3) void lp_grad16_kernel(GradArgs a, int tiles_adj, int units_adj, int tiles_neg, int units_neg) {
@@ -1354,8 +1354,8 @@ __global__ __launch_bounds__(256, 3) void lp_grad16_kernel(GradArgs a, int tiles
         grad_neg16_body<L2, NT>(a, cd, unit - units_adj, tiles_neg, smem);
 }
 
-// ---- stream-K launch of the same two bodies (Dot comparator).  3200 equal tiles over 768 resident workgroups run 4.17 -> 5 rounds
-// (83 % fill).  Here 768 persistent workgroups split the flat list of (tile, K chunk) units evenly (+-1 chunk): a workgroup finishes
+// ---- stream-K launch of the same two bodies (Dot comparator); an experiment against the idea that 3200 equal tiles over 768 resident
+// workgroups lose a partly filled fifth round (they do not: measured slower, see launch_grad16_sk / launch_grad16_hy).  768 persistent workgroups split the flat list of (tile, K chunk) units evenly (+-1 chunk): a workgroup finishes
 // the tail of the tile its predecessor started, a few whole tiles, and the head of one more.  Partial accumulators (at most two per
 // workgroup; a tile is shared by at most two workgroups because every range is longer than a tile's K loop) go to `part`, and
 // lp_grad16_fixup_kernel adds the two halves in a fixed order and stores the tile: deterministic, no atomics.
