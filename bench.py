@@ -213,7 +213,7 @@ def main():
         # HBM bytes per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
         # this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md) — only valid for the workload it was collected on
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r1f_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r1h_pmc_traffic.json")
         if a.workload == "freebase86m" and not a.num_nodes and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))["kernels"]
             key = {"lp_grad_adj": "lp_grad16_kernel", "lp_grad_neg": "lp_grad16_kernel", "lp_scores": "lp_scores_ap_kernel",
