@@ -1,0 +1,135 @@
+"""The C++ ShardedTrainer with TWO ranks on the GPU box.  RCCL refuses two ranks on one device, so both processes share cuda:0 and every
+collective (ids / rows / gradients all-to-all(v), count exchange, relation all-reduce) goes through gloo — the trainer only sees c10d
+process groups by name, so the schedule, the split sizes, the owner-side merge of the per-sender runs and the cross-rank dedupe are
+exactly the code that runs over RCCL.  Expected result: the synchronous union-batch update of the CPU oracle."""
+import os
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import lp_oracle as O
+from oracle.cpu_step import CpuLinkPredictionStep
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(decoder="COMPLEX", num_nodes=1501, R=5, d=16, B=48, C=3, N=20, E=480, steps=5, seed=17, lr=0.1)
+
+
+def make_inputs(cfg):
+    g = torch.Generator().manual_seed(3)
+    table = (torch.rand(cfg["num_nodes"], cfg["d"], generator=g) - 0.5) * 0.8
+    edges = [torch.stack([torch.randint(cfg["num_nodes"], (cfg["E"],), generator=g), torch.randint(cfg["R"], (cfg["E"],), generator=g),
+                          torch.randint(cfg["num_nodes"], (cfg["E"],), generator=g)], 1) for _ in range(2)]
+    return table, edges
+
+
+def worker(rank, world, port, outdir, sync_interval, staleness):
+    import marius_amd
+    from marius_amd.sharded import shard_range
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    side = dist.new_group(backend="gloo")
+    cfg = CFG
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    M = marius_amd.host()
+    table, edges = make_inputs(cfg)
+    lo, hi = shard_range(cfg["num_nodes"], rank, world)
+    tb, sb = table[lo:hi].clone().to(dev), torch.zeros(hi - lo, cfg["d"], device=dev)
+    gen = M.MariusGenerator(cfg["seed"] + rank)
+    sampler = M.CorruptNodeNegativeSampler(cfg["C"], cfg["N"], 0.0, False, M.LocalFilterMode.DEG, gen)
+    stub = M.InMemory("", cfg["num_nodes"], cfg["d"], torch.float32, dev)
+    loader = M.DataLoader(M.InMemory(edges[rank].to(torch.int32).to(dev)), stub, None, sampler, gen, cfg["B"], True)
+    dec = M.ComplEx(cfg["R"], cfg["d"], dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+    model = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+    model.setup_optimizers(cfg["lr"])
+    model.sparse_lr = cfg["lr"]
+    tr = M.ShardedTrainer(loader, model, tb, sb, rank, world, cfg["num_nodes"], dist.group.WORLD.group_name, side.group_name, staleness, sync_interval)
+    tr.train_steps(cfg["steps"])
+    tr.finish()
+    torch.save({"shard": tb.cpu(), "state": sb.cpu(), "rel": dec.relations.cpu(), "inv_rel": dec.inverse_relations.cpu()}, os.path.join(outdir, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def simulate(cfg, world=2, staleness=0):
+    """Every rank reads the same table state, gradients are summed per node over all ranks' batches, Adagrad is applied once; relation
+    gradients are summed (all-reduce) before the dense step.  Rank r's generator: seed + r, first draw = the epoch permutation.
+    staleness 1: the rows of step s + 1 (of every rank) are read before the update of step s is applied."""
+    table, edges = make_inputs(cfg)
+    state = torch.zeros_like(table)
+    steppers = []
+    for r in range(world):
+        st = CpuLinkPredictionStep(cfg["decoder"], table, state, cfg["R"], cfg["B"], cfg["C"], cfg["N"])
+        st.num_nodes = cfg["num_nodes"]
+        steppers.append(st)
+    rel, inv = steppers[0].rel, steppers[0].inv_rel
+    rel_sum, inv_sum = torch.zeros_like(rel), torch.zeros_like(inv)
+    rng, perms = [], []
+    for r in range(world):
+        torch.manual_seed(cfg["seed"] + r)
+        perms.append(torch.randperm(cfg["E"]))
+        rng.append(torch.get_rng_state())
+
+    def fetch(s):
+        out = []
+        for r in range(world):
+            torch.set_rng_state(rng[r])
+            batch = edges[r][perms[r][s * cfg["B"]:(s + 1) * cfg["B"]]]
+            src_neg, _ = steppers[r].get_negatives(batch, True)
+            dst_neg, _ = steppers[r].get_negatives(batch, False)
+            rng[r] = torch.get_rng_state()
+            uniq, mapped = O.map_tensors([batch[:, 0], batch[:, -1], src_neg.flatten(), dst_neg.flatten()])
+            el = torch.stack([mapped[0], batch[:, 1], mapped[1]]).transpose(0, 1)
+            out.append((uniq, el, mapped[3].reshape(dst_neg.shape), mapped[2].reshape(src_neg.shape), O.index_read(table, uniq)))
+        return out
+
+    ahead = fetch(0) if staleness else None
+    for s in range(cfg["steps"]):
+        if staleness:
+            cur, ahead = ahead, fetch(s + 1)  # the trainer prefetches one batch past the last step as well: same generator consumption
+        else:
+            cur = fetch(s)
+        ids, gs, rg, ig = [], [], torch.zeros_like(rel), torch.zeros_like(inv)
+        for uniq, el, dst_map, src_map, emb in cur:
+            out = O.train_batch(cfg["decoder"], emb, torch.zeros_like(emb), el, dst_map, src_map, rel, inv)
+            ids.append(uniq)
+            gs.append(out["node_grad"])
+            rg += out["rel_grad"]
+            ig += out["inv_rel_grad"]
+        allid, allg = torch.cat(ids), torch.cat(gs)
+        uniq, invx = torch.unique(allid, return_inverse=True)
+        g = torch.zeros(uniq.numel(), allg.size(1)).index_add_(0, invx, allg)
+        dw, ds = O.accumulate_gradients(g, O.index_read(state, uniq), cfg["lr"])
+        O.index_add(table, uniq, dw)
+        O.index_add(state, uniq, ds)
+        O.dense_adagrad_step(rel, rg, rel_sum, cfg["lr"])
+        O.dense_adagrad_step(inv, ig, inv_sum, cfg["lr"])
+    return table, state, rel, inv
+
+
+@pytest.mark.parametrize("staleness", [0, 1])
+def test_cpp_sharded_trainer_two_ranks_equal_union_batch_update(staleness):
+    from marius_amd.sharded import shard_range
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world, port = 2, 41000 + 2000 * staleness + os.getpid() % 2000
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(worker, args=(world, port, outdir, 1, staleness), nprocs=world, join=True)
+        res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(world)]
+    table, state, rel, inv = simulate(CFG, world, staleness)
+    shared = 0
+    for r in range(world):
+        lo, hi = shard_range(CFG["num_nodes"], r, world)
+        assert torch.allclose(res[r]["shard"], table[lo:hi], rtol=3e-4, atol=1e-6), "shard %d" % r
+        assert torch.allclose(res[r]["state"], state[lo:hi], rtol=3e-4, atol=1e-7)
+        assert torch.allclose(res[r]["rel"], rel, rtol=3e-4, atol=1e-6) and torch.allclose(res[r]["inv_rel"], inv, rtol=3e-4, atol=1e-6)
+        shared += int((res[r]["state"] > 0).any(1).sum())
+    assert torch.equal(res[0]["rel"], res[1]["rel"])  # replicas of the relation tables stay identical
+    assert shared > 0
+    if staleness:  # and the stale trajectory differs from the synchronous one
+        assert not torch.allclose(simulate(CFG, world, 0)[0], table, rtol=1e-4, atol=1e-6)
