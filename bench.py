@@ -73,6 +73,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # MARIUS_BENCH_BACKEND=gloo (testing only): several ranks may then share one GPU — RCCL refuses that, gloo does not care — so the
+    # torchrun launch path can be exercised on a single-GPU box; timings of such a run mean nothing
+    backend = os.environ.get("MARIUS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -80,7 +85,10 @@ def main():
         # one node: RCCL's socket bootstrap and the gloo side group over loopback (interface discovery by hostname can fail in containers)
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert a.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
 
     from marius_amd import hip as H

@@ -133,3 +133,28 @@ def test_cpp_sharded_trainer_two_ranks_equal_union_batch_update(staleness):
     assert shared > 0
     if staleness:  # and the stale trajectory differs from the synchronous one
         assert not torch.allclose(simulate(CFG, world, 0)[0], table, rtol=1e-4, atol=1e-6)
+
+
+def test_bench_launch_contract_two_ranks():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` as the driver launches it, with the collectives on gloo so
+    that both ranks can share this box's single GPU (MARIUS_BENCH_BACKEND, testing only): one JSON line from rank 0 with the contract's keys."""
+    import json
+    import subprocess
+    import sys
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MARIUS_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(43000 + os.getpid() % 2000), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--num-nodes", "2000000"]
+    out = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["warmup"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert "C++ ShardedTrainer" in j["config"]["host"]
