@@ -18,11 +18,11 @@ pytestmark = pytest.mark.gpu
 CFG = dict(decoder="COMPLEX", num_nodes=1501, R=5, d=16, B=48, C=3, N=20, E=480, steps=5, seed=17, lr=0.1)
 
 
-def make_inputs(cfg):
+def make_inputs(cfg, world=2):
     g = torch.Generator().manual_seed(3)
     table = (torch.rand(cfg["num_nodes"], cfg["d"], generator=g) - 0.5) * 0.8
     edges = [torch.stack([torch.randint(cfg["num_nodes"], (cfg["E"],), generator=g), torch.randint(cfg["R"], (cfg["E"],), generator=g),
-                          torch.randint(cfg["num_nodes"], (cfg["E"],), generator=g)], 1) for _ in range(2)]
+                          torch.randint(cfg["num_nodes"], (cfg["E"],), generator=g)], 1) for _ in range(world)]
     return table, edges
 
 
@@ -37,7 +37,7 @@ def worker(rank, world, port, outdir, sync_interval, staleness):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     M = marius_amd.host()
-    table, edges = make_inputs(cfg)
+    table, edges = make_inputs(cfg, world)
     lo, hi = shard_range(cfg["num_nodes"], rank, world)
     tb, sb = table[lo:hi].clone().to(dev), torch.zeros(hi - lo, cfg["d"], device=dev)
     gen = M.MariusGenerator(cfg["seed"] + rank)
@@ -59,7 +59,7 @@ def simulate(cfg, world=2, staleness=0):
     """Every rank reads the same table state, gradients are summed per node over all ranks' batches, Adagrad is applied once; relation
     gradients are summed (all-reduce) before the dense step.  Rank r's generator: seed + r, first draw = the epoch permutation.
     staleness 1: the rows of step s + 1 (of every rank) are read before the update of step s is applied."""
-    table, edges = make_inputs(cfg)
+    table, edges = make_inputs(cfg, world)
     state = torch.zeros_like(table)
     steppers = []
     for r in range(world):
@@ -111,13 +111,13 @@ def simulate(cfg, world=2, staleness=0):
     return table, state, rel, inv
 
 
-@pytest.mark.parametrize("staleness", [0, 1])
-def test_cpp_sharded_trainer_two_ranks_equal_union_batch_update(staleness):
+@pytest.mark.parametrize("world,staleness", [(2, 0), (2, 1), (8, 1)])
+def test_cpp_sharded_trainer_ranks_equal_union_batch_update(world, staleness):
     from marius_amd.sharded import shard_range
 
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    world, port = 2, 41000 + 2000 * staleness + os.getpid() % 2000
+    port = 41000 + 2000 * staleness + 100 * world + os.getpid() % 1000
     with tempfile.TemporaryDirectory() as outdir:
         mp.spawn(worker, args=(world, port, outdir, 1, staleness), nprocs=world, join=True)
         res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(world)]
@@ -129,7 +129,7 @@ def test_cpp_sharded_trainer_two_ranks_equal_union_batch_update(staleness):
         assert torch.allclose(res[r]["state"], state[lo:hi], rtol=3e-4, atol=1e-7)
         assert torch.allclose(res[r]["rel"], rel, rtol=3e-4, atol=1e-6) and torch.allclose(res[r]["inv_rel"], inv, rtol=3e-4, atol=1e-6)
         shared += int((res[r]["state"] > 0).any(1).sum())
-    assert torch.equal(res[0]["rel"], res[1]["rel"])  # replicas of the relation tables stay identical
+    assert all(torch.equal(res[0]["rel"], res[r]["rel"]) for r in range(1, world))  # replicas of the relation tables stay identical
     assert shared > 0
     if staleness:  # and the stale trajectory differs from the synchronous one
         assert not torch.allclose(simulate(CFG, world, 0)[0], table, rtol=1e-4, atol=1e-6)
