@@ -147,7 +147,7 @@ def test_bench_launch_contract_two_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MARIUS_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(43000 + os.getpid() % 2000), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--num-nodes", "2000000"]
+           str(47000 + os.getpid() % 2000), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--num-nodes", "2000000"]
     out = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
