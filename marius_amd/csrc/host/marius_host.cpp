@@ -65,10 +65,10 @@ MariusGenerator::MariusGenerator(uint64_t seed) {
 }
 MariusGenerator::~MariusGenerator() {
     for (auto& p : pools_) {
-        if (p.ready) hipEventDestroy((hipEvent_t)p.ready);
-        if (p.done) hipEventDestroy((hipEvent_t)p.done);
+        if (p.ready) (void)hipEventDestroy((hipEvent_t)p.ready);
+        if (p.done) (void)hipEventDestroy((hipEvent_t)p.done);
     }
-    if (side_stream_) hipStreamDestroy((hipStream_t)side_stream_);
+    if (side_stream_) (void)hipStreamDestroy((hipStream_t)side_stream_);
 }
 void MariusGenerator::drop_pools() {
     for (auto& p : pools_) {

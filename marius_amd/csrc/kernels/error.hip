@@ -34,11 +34,11 @@ void prof_begin(int id, hipStream_t st, ProfMark& m) {
     if (g_prof_on >= 2 && id != g_prof_on - 2) return;  // single-kernel mode
     if (hipEventCreate(&m.a) != hipSuccess || hipEventCreate(&m.b) != hipSuccess) return;
     m.id = id;
-    hipEventRecord(m.a, st);
+    (void)hipEventRecord(m.a, st);
 }
 void prof_end(hipStream_t st, ProfMark& m) {
     if (m.id < 0) return;
-    hipEventRecord(m.b, st);
+    (void)hipEventRecord(m.b, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_pending.push_back({m.id, m.a, m.b});
 }
@@ -58,8 +58,8 @@ extern "C" int marius_profile_enable(int on) {
 extern "C" int marius_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof_pending) {
-        hipEventDestroy(r.a);
-        hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
     }
     g_prof_pending.clear();
     for (int i = 0; i < PROF_COUNT; ++i) {
@@ -77,14 +77,14 @@ extern "C" int marius_profile_read(int id, double* total_ms, int64_t* launches) 
     MARIUS_REQUIRE(id >= 0 && id < PROF_COUNT && total_ms && launches, "profile_read: bad arguments");
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof_pending) {
-        hipEventSynchronize(r.b);
+        (void)hipEventSynchronize(r.b);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             g_prof_ms[r.id] += ms;
             g_prof_cnt[r.id] += 1;
         }
-        hipEventDestroy(r.a);
-        hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
     }
     g_prof_pending.clear();
     *total_ms = g_prof_ms[id];
