@@ -202,7 +202,20 @@ typedef struct marius_lp_desc {
     int64_t n_src_filter;
     int32_t loss;         /* MARIUS_LOSS_* (0 = SoftmaxCrossEntropy: a zero-initialised descriptor keeps its old meaning) */
     float margin;         /* RankingLoss margin (loss.h:43-55) */
+    int32_t flags;        /* MARIUS_LP_* (0 = the API contract: adj / pos / neg are all materialised) */
+    int32_t reserved_;
 } marius_lp_desc;
+
+/* marius_lp_desc.flags */
+enum {
+    /* The caller trains and never reads `neg` (Model::train_batch, model.cpp:290-333, as opposed to forward_lp's return value):
+     * the library may run the flash-style path (lp_flash.hip) that keeps only the SoftmaxCE row statistics and recomputes score
+     * tiles in the backward; layout.neg is then not allocated.  Honoured for SoftmaxCE + DotCompare without score filters and
+     * d in (48, 64] or (96, 128]; every other case silently takes the materialised-score kernels. */
+    MARIUS_LP_TRAIN_ONLY = 1,
+    /* with MARIUS_LP_TRAIN_ONLY: additionally store the recomputed scores into layout.neg (parity tests of the split arithmetic) */
+    MARIUS_LP_STORE_SCORES = 2
+};
 
 /* Workspace layout (all offsets in BYTES from the workspace base; dir 0 = (src,rel)->dst "rhs", dir 1 = inverse "lhs").
  * Bp = C * ceil(B / C) (pad_and_reshape, comparators.cpp:7-20); n_ld = N rounded up to 4. */
@@ -228,6 +241,11 @@ typedef struct marius_lp_layout {
     size_t gradpart;  /* partial accumulators of the stream-K backward launch (two tiles per persistent workgroup)               */
     size_t dpos[2];   /* [Bp]        dL/d pos, written by marius_lp_loss, read by the edge backward                               */
     size_t vlog;      /* [ndir][Bp, n_ld] log(dL/dneg / scale) for the non-negative-gradient losses (0 = not allocated)            */
+    size_t adjrec;    /* flash path: adj operand records      [ndir C][Bc rounded to 32][4 kp + 16 B] (hi | lo | lsec)             */
+    size_t negrec;    /* flash path: negative operand records [ndir C][N  rounded to 32][4 kp + 16 B]                              */
+    size_t fpart;     /* flash path: SoftmaxCE partials [2][ndir Bp] (max, sum exp)                                                  */
+    int32_t flash;    /* 1 when marius_lp_plan selected the flash path for this descriptor (then neg[] = 0 unless STORE_SCORES)      */
+    int32_t reserved_;
 } marius_lp_layout;
 
 int marius_lp_plan(const marius_lp_desc* desc, marius_lp_layout* layout);

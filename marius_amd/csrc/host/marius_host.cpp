@@ -382,7 +382,8 @@ Tensor LpContext::view(size_t off, std::vector<int64_t> shape, std::vector<int64
 }
 
 static void lp_setup(LpContext& ctx, shared_ptr<EdgeDecoder> dec, const Tensor& edges, const Tensor& emb, const Tensor& dst_negs, const Tensor& src_negs,
-                     const Tensor& dst_filter, const Tensor& src_filter, LossReduction reduction, int loss_kind = MARIUS_LOSS_SOFTMAX_CE, float margin = 0.f) {
+                     const Tensor& dst_filter, const Tensor& src_filter, LossReduction reduction, int loss_kind = MARIUS_LOSS_SOFTMAX_CE, float margin = 0.f,
+                     int lp_flags = 0) {
     require_device(emb, "forward_lp");
     require_device(edges, "forward_lp");
     if (edges.dim() != 2 || (edges.size(1) != 3 && edges.size(1) != 2))
@@ -401,6 +402,7 @@ static void lp_setup(LpContext& ctx, shared_ptr<EdgeDecoder> dec, const Tensor& 
     d.reduction = reduction == LossReduction::MEAN ? MARIUS_REDUCE_MEAN : MARIUS_REDUCE_SUM;
     d.loss = loss_kind;
     d.margin = margin;
+    d.flags = lp_flags;
     Tensor e = edges.contiguous(), dn = dst_negs.contiguous(), sn = src_negs.defined() ? src_negs.contiguous() : Tensor();
     d.emb = fp(emb);
     d.emb_ld = emb.stride(0);
@@ -427,25 +429,26 @@ static void lp_setup(LpContext& ctx, shared_ptr<EdgeDecoder> dec, const Tensor& 
 
 std::tuple<Tensor, Tensor, Tensor, Tensor> node_corrupt_forward(shared_ptr<EdgeDecoder> decoder, Tensor positive_edges, Tensor node_embeddings,
                                                                 Tensor dst_negs, Tensor src_negs, LpContext* ctx, Tensor dst_filter, Tensor src_filter,
-                                                                LossReduction reduction, int loss_kind, float margin) {
+                                                                LossReduction reduction, int loss_kind, float margin, int lp_flags) {
     LpContext local;
     LpContext& c = ctx ? *ctx : local;
-    lp_setup(c, decoder, positive_edges, node_embeddings, dst_negs, src_negs, dst_filter, src_filter, reduction, loss_kind, margin);
+    lp_setup(c, decoder, positive_edges, node_embeddings, dst_negs, src_negs, dst_filter, src_filter, reduction, loss_kind, margin, lp_flags);
     mcheck(marius_lp_forward(&c.desc, &c.layout, c.workspace.data_ptr(), cur_stream()));
     const int64_t Bp = c.layout.Bp, N = c.desc.N, nld = c.layout.n_ld;
+    const bool have_neg = !(c.layout.flash && c.layout.neg[0] == 0);  // the flash path keeps row statistics only
     Tensor pos = c.view(c.layout.pos[0], {Bp});
-    Tensor neg = c.view(c.layout.neg[0], {Bp, N}, {nld, 1});
+    Tensor neg = have_neg ? c.view(c.layout.neg[0], {Bp, N}, {nld, 1}) : Tensor();
     Tensor inv_pos, inv_neg;
     if (c.desc.use_inverse) {
         inv_pos = c.view(c.layout.pos[1], {Bp});
-        inv_neg = c.view(c.layout.neg[1], {Bp, N}, {nld, 1});
+        if (have_neg) inv_neg = c.view(c.layout.neg[1], {Bp, N}, {nld, 1});
     }
     if (!ctx) {  // the workspace dies with `local`: hand out owning copies
         pos = pos.clone();
-        neg = neg.clone();
+        if (neg.defined()) neg = neg.clone();
         if (inv_pos.defined()) {
             inv_pos = inv_pos.clone();
-            inv_neg = inv_neg.clone();
+            if (inv_neg.defined()) inv_neg = inv_neg.clone();
         }
     }
     return std::forward_as_tuple(pos, neg, inv_pos, inv_neg);
@@ -799,6 +802,14 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> Model::forward_lp(shared_ptr<Batch> b
                                 loss_function_ ? loss_function_->kind() : MARIUS_LOSS_SOFTMAX_CE, loss_function_ ? loss_function_->margin() : 0.f);
 }
 
+std::tuple<Tensor, Tensor, Tensor, Tensor> Model::forward_lp_train(shared_ptr<Batch> batch) {
+    if (decoder_->decoder_method_ != EdgeDecoderMethod::CORRUPT_NODE) return forward_lp(batch, true);
+    return node_corrupt_forward(decoder_, batch->edges_, batch->node_embeddings_, batch->dst_neg_indices_mapping_, batch->src_neg_indices_mapping_, &ctx_,
+                                batch->dst_neg_filter_, batch->src_neg_filter_, loss_function_ ? loss_function_->reduction_type_ : LossReduction::SUM,
+                                loss_function_ ? loss_function_->kind() : MARIUS_LOSS_SOFTMAX_CE, loss_function_ ? loss_function_->margin() : 0.f,
+                                MARIUS_LP_TRAIN_ONLY);
+}
+
 static void ensure(Tensor& t, int64_t bytes, torch::Device dev) {
     if (!t.defined() || t.numel() < bytes || t.device() != dev) t = torch::empty({bytes}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
 }
@@ -883,7 +894,7 @@ static bool relation_step_sparse(Model& m, shared_ptr<Batch> batch) {
 
 void Model::train_batch(shared_ptr<Batch> batch, bool call_step) {
     if (call_step) clear_grad();
-    forward_lp(batch, true);
+    forward_lp_train(batch);
     model_backward(*this, batch);
     relation_grads_dense(*this, batch);
     // node_embeddings_.grad [U, d]: sum of the occurrence gradients per unique row (autograd's index_add), atomic-free
@@ -900,7 +911,7 @@ void Model::train_batch(shared_ptr<Batch> batch, bool call_step) {
 }
 
 void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor state) {
-    forward_lp(batch, true);
+    forward_lp_train(batch);
     model_backward(*this, batch);
     // The relation-table update (6 small, latency-bound launches) and the node-table update are independent: run the former on a side
     // stream underneath the latter and join before returning (the next forward reads the relation tables).
@@ -938,7 +949,7 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
 }
 
 void Model::backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step) {
-    forward_lp(batch, true);
+    forward_lp_train(batch);
     model_backward(*this, batch);
     bool done = false;
     if (local_relation_step) done = relation_step_sparse(*this, batch);

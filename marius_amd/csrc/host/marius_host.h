@@ -269,7 +269,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> node_corrupt_forward(shared_ptr<EdgeD
                                                                 Tensor dst_negs, Tensor src_negs, LpContext* ctx = nullptr,
                                                                 Tensor dst_filter = Tensor(), Tensor src_filter = Tensor(),
                                                                 LossReduction reduction = LossReduction::SUM, int loss_kind = MARIUS_LOSS_SOFTMAX_CE,
-                                                                float margin = 0.f);
+                                                                float margin = 0.f, int lp_flags = 0);
 
 // ------------------------------------------------------------------------------------------------ loss / optimizers / reporter
 class LossFunction {  // loss.h:21-31; every subclass of loss.h:33-107 evaluates on the device (marius_loss_scores / marius_lp_loss)
@@ -389,6 +389,9 @@ class Model {
 
     Model(shared_ptr<EdgeDecoder> decoder, shared_ptr<LossFunction> loss, shared_ptr<LinkPredictionReporter> reporter, torch::Device device);
     std::tuple<Tensor, Tensor, Tensor, Tensor> forward_lp(shared_ptr<Batch> batch, bool train);  // model.cpp:252-288
+    // the same forward for callers that only train (nobody reads the negative scores): lets the library take the flash-style path
+    // (MARIUS_LP_TRAIN_ONLY, include/marius_hip.h); neg / inv_neg of the returned tuple are then undefined
+    std::tuple<Tensor, Tensor, Tensor, Tensor> forward_lp_train(shared_ptr<Batch> batch);
     void train_batch(shared_ptr<Batch> batch, bool call_step = true);                            // model.cpp:290-333
     void evaluate_batch(shared_ptr<Batch> batch);                                                // model.cpp:335-359
     void clear_grad();

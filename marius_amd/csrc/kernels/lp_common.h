@@ -194,4 +194,14 @@ size_t grad16_sk_part_bytes();
 bool launch_grad16_sk(const GradArgs& a, bool l2, float* part, hipStream_t st);
 bool launch_grad16_hy(const GradArgs& a, bool l2, float* part, hipStream_t st);  // both contractions, whole tiles + K-split tiles for the last round  // both contractions, stream-K balanced persistent launch
 
+// flash-style training path (lp_flash.hip): operand records, SoftmaxCE row statistics, recomputing backward
+bool flash_applicable(const marius_lp_desc* desc, const LpDims& D);
+size_t flash_adjrec_bytes(const LpDims& D);
+size_t flash_negrec_bytes(const LpDims& D);
+size_t flash_part_bytes(const LpDims& D);
+int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj, char* adjrec, char* negrec, float2* part, float* S, hipStream_t st);
+int flash_merge(const LpDims& D, const float2* part, const float* pos, float* lse, float* rowloss, float* dpos, float* blocksum, char* adjrec,
+                hipStream_t st);
+int flash_backward(const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2], bool has_src_neg, hipStream_t st);
+
 }  // namespace marius

@@ -1056,6 +1056,11 @@ static bool vlog_path(const LpDims& D) {
     return D.loss != MARIUS_LOSS_SOFTMAX_CE && D.loss != MARIUS_LOSS_MSE && D.cmp == MARIUS_CMP_DOT && kernel_level() == 2;
 }
 
+static bool flash_store_scores(const marius_lp_desc* d) {
+    const char* e = getenv("MARIUS_FLASH_STORE_S");
+    return (d->flags & MARIUS_LP_STORE_SCORES) || (e && e[0] == '1');
+}
+
 static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layout* L) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -1073,8 +1078,13 @@ static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layou
     for (int dir = 0; dir < D.ndir; ++dir) L->adj[dir] = base + (size_t)dir * rows * D.d_ld * 4;
     base = take(rows * 4 * D.ndir);
     for (int dir = 0; dir < D.ndir; ++dir) L->pos[dir] = base + (size_t)dir * rows * 4;
-    base = take(rows * D.n_ld * 4 * D.ndir);
-    for (int dir = 0; dir < D.ndir; ++dir) L->neg[dir] = base + (size_t)dir * rows * D.n_ld * 4;
+    const bool flash = kernel_level() == 2 && flash_applicable(d, D);
+    L->flash = flash ? 1 : 0;
+    L->reserved_ = 0;
+    if (!flash || flash_store_scores(d)) {  // the flash path never materialises the scores
+        base = take(rows * D.n_ld * 4 * D.ndir);
+        for (int dir = 0; dir < D.ndir; ++dir) L->neg[dir] = base + (size_t)dir * rows * D.n_ld * 4;
+    }
     base = take(rows * 4 * D.ndir);
     for (int dir = 0; dir < D.ndir; ++dir) L->lse[dir] = base + (size_t)dir * rows * 4;
     base = take(rows * 4 * D.ndir);
@@ -1092,15 +1102,23 @@ static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layou
         L->lsepart = take(rows * ng * 2 * 4 * D.ndir);
     }
     L->kp = (D.d + 15) / 16 * 16;
-    L->embp = take(nocc * (size_t)L->kp * 2 * 3);
-    L->adjp = take(rows * D.ndir * (size_t)L->kp * 2 * 3);
-    L->negt = take((size_t)D.C * D.ndir * 3 * L->kp * ((D.N + 31) / 32 * 32) * 2);
-    L->adjt = take((size_t)D.C * D.ndir * 3 * L->kp * ((D.Bc + 31) / 32 * 32) * 2);
-    L->gradpart = take(grad16_sk_part_bytes());
+    L->embp = L->adjp = L->negt = L->adjt = L->gradpart = 0;
+    L->adjrec = L->negrec = L->fpart = 0;
+    if (flash) {
+        L->adjrec = take(flash_adjrec_bytes(D));
+        L->negrec = take(flash_negrec_bytes(D));
+        L->fpart = take(flash_part_bytes(D));
+    } else {
+        L->embp = take(nocc * (size_t)L->kp * 2 * 3);
+        L->adjp = take(rows * D.ndir * (size_t)L->kp * 2 * 3);
+        L->negt = take((size_t)D.C * D.ndir * 3 * L->kp * ((D.N + 31) / 32 * 32) * 2);
+        L->adjt = take((size_t)D.C * D.ndir * 3 * L->kp * ((D.Bc + 31) / 32 * 32) * 2);
+        L->gradpart = take(grad16_sk_part_bytes());
+    }
     base = take(rows * 4 * D.ndir);
     L->dpos[0] = L->dpos[1] = 0;
     for (int dir = 0; dir < D.ndir; ++dir) L->dpos[dir] = base + (size_t)dir * rows * 4;
-    L->vlog = vlog_path(D) ? take(rows * D.n_ld * 4 * D.ndir) : 0;
+    L->vlog = (vlog_path(D) && !flash) ? take(rows * D.n_ld * 4 * D.ndir) : 0;
     L->total_bytes = off;
     return MARIUS_OK;
 }
@@ -1160,6 +1178,12 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
                                                                                      desc->src_neg, CN, D.d, D.ndir, y2);
         rc = check_launch("lp_negnorm");
         if (rc) return rc;
+    }
+
+    if (L->flash) {  // training-only path: operand records + SoftmaxCE row statistics, no score tensor (lp_flash.hip)
+        MARIUS_REQUIRE(kernel_level() == 2 && flash_applicable(desc, D), "lp_forward: the layout was planned for the flash path but the descriptor / environment no longer selects it");
+        float* S = (flash_store_scores(desc) && L->neg[0]) ? (float*)(ws + L->neg[0]) : nullptr;
+        return flash_forward(desc, D, pa.adj, ws + L->adjrec, ws + L->negrec, (float2*)(ws + L->fpart), S, st);
     }
 
     ScoreArgs sa;
@@ -1239,7 +1263,15 @@ extern "C" int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout
     {
         ProfScope ps(PROF_LP_LSE, st);
         float* dpos = (float*)(ws + L->dpos[0]);
-        if (D.loss != MARIUS_LOSS_SOFTMAX_CE) {
+        if (L->flash) {
+            const int64_t bpd = cdiv(D.Bp, 256);
+            float* blocksum = (float*)(ws + L->aux);
+            rc = flash_merge(D, (const float2*)(ws + L->fpart), (const float*)(ws + L->pos[0]), (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]),
+                             dpos, blocksum, ws + L->adjrec, st);
+            if (rc) return rc;
+            lp_loss_reduce_blocks_kernel<<<dim3(1), dim3(256), 0, st>>>(blocksum, bpd, D.ndir, D.gscale, (float*)(ws + L->loss));
+            return check_launch("lp_loss_reduce");
+        } else if (D.loss != MARIUS_LOSS_SOFTMAX_CE) {
             lp_loss_terms_kernel<<<dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st>>>((const float*)(ws + L->neg[0]), D.n_ld,
                                                                                      (const float*)(ws + L->pos[0]), rows, D.N, D.loss, D.margin,
                                                                                      D.gscale, (float*)(ws + L->lse[0]),
@@ -1311,7 +1343,12 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
         const char* sp = getenv("MARIUS_GRAD_SPLIT");  // 1 = separate launches for dAdj / dNeg (per-kernel timing)
         const bool split = sp && sp[0] == '1';
         bool done = false;
-        if (lvl == 2 && !split && scores_variant(desc, D) == 'b') {  // operand planes were produced by this step's forward
+        if (L->flash) {
+            rc = flash_backward(D, ws + L->adjrec, ws + L->negrec, ga.dadj, ga.gocc, ga.negocc_off, has_src_neg, st);
+            if (rc) return rc;
+            done = true;
+        }
+        if (!done && lvl == 2 && !split && scores_variant(desc, D) == 'b') {  // operand planes were produced by this step's forward
             const int64_t nocc = 2 * D.B + (int64_t)(desc->src_neg ? 2 : 1) * D.C * D.N;
             ProfScope ps(PROF_LP_GRAD_ADJ, st);
             done = launch_grad_b6(ga, ws + L->embp, nocc * L->kp, ws + L->adjp, D.Bp * D.ndir * L->kp, (int)L->kp, ws + L->negt, ws + L->adjt, st);

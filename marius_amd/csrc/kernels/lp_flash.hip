@@ -1,0 +1,584 @@
+// Flash-style CORRUPT_NODE training path on the BF16 matrix pipe: negative scores are never materialised.
+//
+// Reference path replaced (src/cpp/src): the negative half of nn/decoders/edge/decoder_methods.cpp:57-114 (node_corrupt_forward:
+// pad_and_reshape + bmm, comparators.cpp:7-41), nn/loss.cpp:50-67 (SoftmaxCrossEntropy) and their autograd backward (nn/model.cpp:324)
+// for the DotCompare decoders (DistMult, ComplEx) when the caller only trains (marius_lp_desc.flags & MARIUS_LP_TRAIN_ONLY: nobody
+// reads `neg`).  The materialised-score kernels (lp_res.hip) stay the API path of forward_lp / evaluate_batch.
+//
+// Why: on the FP32 matrix pipe the step is bound by 6e10 flop at ~50 % of 157 TF, and the 400 MB score tensor is written once and
+// read twice (1.2 GB of the step's 2.6 GB HBM traffic, profiles/r1h_pmc_traffic.json).  Here
+//   * every fp32 operand x is split once per step into two bf16 values x = h + l (h = bf16(x), l = bf16(x - h): 16 significand bits),
+//     and a product is taken as h.h' + (h.l' + l.h') on v_mfma_f32_32x32x16_bf16, accumulated in fp32.  Dropped: l.l' and the
+//     representation residuals, each <= 2^-18 |x y| with round-to-nearest splits, so
+//         |error of one contraction| <= 3 * 2^-18 * sum_k |a_k b_k|   (+ the usual fp32 accumulation error)
+//     — tested against exactly this bound (tests/test_gpu_flash.py) and inside the 1e-4 score contract;
+//   * forward keeps only the SoftmaxCE row statistics (running max / sum exp2, online softmax in registers);
+//   * backward recomputes the score tile, forms V = dL/dS = g exp(S - lse) in registers and feeds it straight back into the
+//     matrix pipe as the A operand of the gradient contraction (the accumulator layout of a 32x32 tile IS the A-operand layout of
+//     the next MFMA once the streamed rows are stored in a fixed permutation): dAdj = V Neg and dNeg = V^T adj are two launches of
+//     the same kernel with the roles of the two operands swapped.  5 contractions x 3 products = 3e11 bf16 flop per bench step.
+//
+// Operand records.  adj rows and negative rows are packed once per step (flash_pack_*_kernel) in OCCURRENCE order, one block of
+// XR = ceil32(rows) records per (direction, chunk):
+//     record = [ hi: KP bf16 | lo: KP bf16 | lsec: f32 | 12 B pad ]      KP = 16 ceil(d / 16),  pitch P = 4 KP + 16 bytes
+// P = 16 mod 32, so (a) the 16-B fragment reads of 16 consecutive records hit 16 distinct bank groups and (b) four records 4 apart
+// tile the 64 banks with their 64-B column windows, which is what ds_read_b64_tr_b16 (the hardware transpose read that yields the
+// k-major B operand of the gradient contraction from row-major records) needs.  Inside every 16-record group, logical row y sits at
+// physical slot rho(y) = 4 (y & 3) + (y >> 2) for that reason.  A streamed tile (32 records) is one contiguous 32 P byte run of
+// HBM: it is DMA'd into a 4-slot LDS ring by global_load_lds_dwordx4 (no VGPRs, no VALU), three tiles in flight.
+// `lsec` (adj records only) = lse log2(e) - log2(g), patched in by the merge kernel after the forward: V = exp2(S log2(e) - lsec).
+//
+// Work decomposition.  Items = (chunk-direction, 128-row tile of the stationary operand, 32-row block of the streamed operand),
+// streamed index fastest.  nwg persistent workgroups (2 per CU, 4 waves, a wave owns 32 stationary rows as MFMA fragments in
+// registers) each take a contiguous, XCD-local range of items, balanced to +-1 block, with nwg <= number of tiles so that a tile is
+// shared by at most two workgroups: the gradient of a split tile is accumulated with float atomics onto a zeroed output by exactly
+// two contributors, which is order-independent (a + b == b + a), so results stay bit-reproducible; the forward statistics of a split
+// tile go to two partial slots.
+#include <cstdlib>
+
+#include "lp_common.h"
+
+namespace marius {
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+enum { FLASH_FWD = 0, FLASH_DADJ = 1, FLASH_DNEG = 2 };
+
+constexpr int FL_WAVES = 4, FL_NT = 64 * FL_WAVES, FL_XT = 32 * FL_WAVES, FL_YB = 32, FL_SLOTS = 4;
+constexpr float FL_LOG2E = 1.4426950408889634f, FL_LN2 = 0.6931471805599453f;
+
+__host__ __device__ constexpr int fl_pitch(int KS) { return 64 * KS + 16; }                                    // bytes per record
+__host__ __device__ constexpr int fl_slot_bytes(int KS) { return (32 * fl_pitch(KS) + 4095) / 4096 * 4096; }   // DMA granule: 4 waves x 1 KB
+__host__ __device__ constexpr int fl_rho(int y) { return 4 * (y & 3) + ((y >> 2) & 3) + (y & ~15); }          // logical -> physical slot in a 16-group
+__host__ __device__ constexpr int fl_pi(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }         // swap bits 2 and 3
+
+struct FlashArgs {
+    const char* xrec;   // stationary operand records  [ncd][XR]
+    const char* yrec;   // streamed operand records    [ncd][YR]
+    int XR, YR;         // records per (chunk, direction) block, multiples of 32
+    int Xrows, Yrows;   // valid rows per block
+    int ncd, XT, YB, nwg;
+    int64_t total;      // ncd * XT * YB
+    int C, Bc, N, d;
+    int64_t Bp;
+    // FWD: SoftmaxCE partials [2][ndir * Bp] (m, l) with contribution l e^m; S (debug / parity only) [ndir][Bp][n_ld]
+    float2* part;
+    float* S;
+    int64_t n_ld;
+    // BWD: output rows [., out_ld]; DADJ: row = dir Bp + c Bc + x; DNEG: row = negocc_off[dir] + c N + x
+    float* out;
+    int64_t out_ld;
+    int64_t negocc_off[2];
+};
+
+// ---------------------------------------------------------------------------------------------------------------- pack kernels
+// fp32 row -> record.  One thread per 4 consecutive elements (8 B of hi, 8 B of lo); threads past d write the zero K padding.
+__device__ __forceinline__ void fl_write_piece(char* rec, int KP, int piece, float4 v) {
+#pragma clang fp contract(off)
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    v4bf H, L;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 h = (__bf16)x[j];
+        H[j] = h;
+        L[j] = (__bf16)(x[j] - (float)h);
+    }
+    *reinterpret_cast<v4bf*>(rec + piece * 8) = H;
+    *reinterpret_cast<v4bf*>(rec + 2 * KP + piece * 8) = L;
+}
+
+// adj [ndir][Bp][d_ld] fp32 (written by lp_prep*) -> adj records; chunk c of direction dir holds rows c Bc .. (c + 1) Bc of that direction
+__global__ __launch_bounds__(256) void flash_pack_adj_kernel(const float* __restrict__ adj, int64_t d_ld, int64_t Bp, int Bc, int C, int ndir, int d,
+                                                             int KP, int XR, char* __restrict__ rec) {
+    const int ppr = KP / 4 + 1;  // pieces per record (+1: the tail)
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nrec = (int64_t)ndir * C * XR;
+    if (idx >= nrec * ppr) return;
+    const int64_t r = idx / ppr;
+    const int piece = (int)(idx - r * ppr);
+    const int64_t cd = r / XR;
+    const int x = (int)(r - cd * XR);
+    const int P = 4 * KP + 16;
+    char* o = rec + (cd * XR + fl_rho(x)) * (int64_t)P;
+    if (piece == KP / 4) {  // tail: lsec of a padding record must be finite (V of a zero row is multiplied by zeros)
+        *reinterpret_cast<float4*>(o + 4 * KP) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x < Bc && 4 * piece < d) {
+        const int64_t dir = cd / C, c = cd - dir * C;
+        const float* src = adj + (dir * Bp + c * Bc + x) * d_ld + 4 * piece;
+        if (4 * piece + 3 < d) v = *reinterpret_cast<const float4*>(src);
+        else {
+            v.x = src[0];
+            if (4 * piece + 1 < d) v.y = src[1];
+            if (4 * piece + 2 < d) v.z = src[2];
+        }
+    }
+    fl_write_piece(o, KP, piece, v);
+}
+
+// negatives: record (dir, c, j) = emb[negmap[dir][c N + j]]; rows N .. NR are zero
+__global__ __launch_bounds__(256) void flash_pack_neg_kernel(const float* __restrict__ emb, int64_t emb_ld, const int64_t* __restrict__ neg0,
+                                                             const int64_t* __restrict__ neg1, int N, int C, int ndir, int d, int KP, int NR,
+                                                             int vec, char* __restrict__ rec) {
+    const int ppr = KP / 4 + 1;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nrec = (int64_t)ndir * C * NR;
+    if (idx >= nrec * ppr) return;
+    const int64_t r = idx / ppr;
+    const int piece = (int)(idx - r * ppr);
+    const int64_t cd = r / NR;
+    const int j = (int)(r - cd * NR);
+    const int P = 4 * KP + 16;
+    char* o = rec + (cd * NR + fl_rho(j)) * (int64_t)P;
+    if (piece == KP / 4) {
+        *reinterpret_cast<float4*>(o + 4 * KP) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < N && 4 * piece < d) {
+        const int64_t dir = cd / C, c = cd - dir * C;
+        const int64_t id = (dir ? neg1 : neg0)[c * N + j];
+        v = load_row4(emb + id * emb_ld, 4 * piece, d, vec);
+    }
+    fl_write_piece(o, KP, piece, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- the kernel
+__device__ __forceinline__ v16f fl_mfma(const v8bf& a, const v8bf& b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+template <int KS, int MODE, bool STORE_S>
+__global__ __launch_bounds__(FL_NT, 2) void flash_kernel(FlashArgs a) {
+    constexpr int KP = 16 * KS, P = fl_pitch(KS), SLOT = fl_slot_bytes(KS);
+    constexpr int NCT = (KP + 31) / 32;       // 32-column tiles of the gradient output
+    constexpr int DMA_PER_WAVE = SLOT / 4096;  // 1 KB wave-instructions per wave and tile
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5, t16 = lane & 15, c16 = (lane >> 4) & 1;
+
+    // ---- item range of this workgroup (contiguous per XCD: blockIdx % 8 is the XCD the block runs on).  total < 2^31 (checked on the host)
+    int wlin = blockIdx.x;
+    if ((a.nwg & 7) == 0) wlin = (int)(blockIdx.x & 7) * (a.nwg >> 3) + (int)(blockIdx.x >> 3);
+    const int it0 = (int)(a.total * wlin / a.nwg), it1 = (int)(a.total * (wlin + 1) / a.nwg);
+    if (it0 >= it1) return;
+
+    // ---- per-lane LDS offsets
+    // S-MFMA A operand: lane supplies C-row i = l31 of the streamed tile, i.e. logical row pi(i), physical slot rho(pi(i)); k = 16 ks + 8 h + e
+    const int a_off = fl_rho(fl_pi(l31)) * P + 16 * h;
+    // gradient-MFMA B operand through the transpose read: 16-lane group (c16, h) reads keys 4 apart; see the file header
+    const int tr_off = (4 * (t16 >> 2) + 2 * h) * P + 32 * c16 + 8 * (t16 & 3);
+
+    // ---- DMA: wave w moves the 1 KB pieces w, w + 4, ... of a tile's 32 P bytes (the tail of the last piece over-reads into the next tile).
+    // Issued from inline asm so that hipcc does not count it: with the builtin it drains vmcnt(0) before the first ds_read of every
+    // iteration (it cannot tell which slot a DMA writes), which serialises the ring.  M0 = LDS byte address of the piece.
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma = [&](int tile, int yb, int slot) {
+        const int cdp = tile / a.XT;
+        const char* src = a.yrec + (((int64_t)cdp * a.YR + (int64_t)yb * FL_YB) * P) + lane * 16 + wave_u * 1024;
+        const unsigned dst = lds_base + (unsigned)(slot * SLOT) + (unsigned)(wave_u * 1024);
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src + i * (FL_WAVES * 1024)), "s"(dst + (unsigned)(i * FL_WAVES * 1024))
+                         : "memory");
+        }
+    };
+
+    // stationary fragments (B operand of the S-MFMA): lane holds X[x = l31][k = 16 ks + 8 h .. + 7], hi and lo
+    v8bf xh[KS], xl[KS];
+    float lsec_x = 0.f;     // DADJ: lsec of the lane's own adj row
+    v16f out[MODE == FLASH_FWD ? 1 : NCT];
+    float m2 = -INFINITY, lsum = 0.f;  // FWD: running max of S log2(e) and sum of exp2 over this lane's columns
+
+    int cur_tile = -1;
+    int cd = 0, xt = 0, c_ = 0, dir = 0;
+    int y_first = 0;  // first streamed block of the current tile segment
+
+    auto load_x = [&](int tile) {
+        cd = tile / a.XT;
+        xt = tile - cd * a.XT;
+        dir = cd / a.C;
+        c_ = cd - dir * a.C;
+        const int x = xt * FL_XT + wave * 32 + l31;  // logical row inside the block; rows >= XR do not exist: clamp (never stored)
+        const int xc = x < a.XR ? x : a.XR - 1;
+        const char* r = a.xrec + ((int64_t)cd * a.XR + fl_rho(xc)) * P;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            xh[ks] = *reinterpret_cast<const v8bf*>(r + 32 * ks + 16 * h);
+            xl[ks] = *reinterpret_cast<const v8bf*>(r + 2 * KP + 32 * ks + 16 * h);
+        }
+        if (MODE == FLASH_DADJ) lsec_x = *reinterpret_cast<const float*>(r + 4 * KP);
+        // land the fragments HERE: hipcc's own wait for them would otherwise sit at their first use inside the item loop, and since
+        // it cannot see the DMAs of the asm statements it would read as vmcnt(0..3) there — draining the ring every iteration
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        if (MODE != FLASH_FWD) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r_ = 0; r_ < 16; ++r_) out[ct][r_] = 0.f;
+        } else {
+            m2 = -INFINITY;
+            lsum = 0.f;
+        }
+    };
+
+    auto flush = [&](int y_last_excl) {
+        const bool first = (y_first == 0), last = (y_last_excl == a.YB);
+        if (MODE == FLASH_FWD) {
+            // combine the two lane halves (disjoint columns of the same row), then one (m, l) pair per row
+            const float m_o = __shfl_xor(m2, 32, 64), l_o = __shfl_xor(lsum, 32, 64);
+            const float mm = fmaxf(m2, m_o);
+            const float ll = lsum * __builtin_amdgcn_exp2f(m2 - mm) + l_o * __builtin_amdgcn_exp2f(m_o - mm);
+            const int x = xt * FL_XT + wave * 32 + l31;
+            if (h == 0 && x < a.Xrows) {
+                const int64_t row = (int64_t)dir * a.Bp + (int64_t)c_ * a.Bc + x;
+                const int64_t prows = (a.ncd / a.C) * a.Bp;
+                const float2 v = make_float2(mm * FL_LN2, ll);
+                if (first) {
+                    a.part[row] = v;
+                    if (last) a.part[prows + row] = make_float2(-INFINITY, 0.f);
+                } else {
+                    a.part[prows + row] = v;
+                }
+            }
+        } else {
+            const bool sole = first && last;
+            const int64_t base = (MODE == FLASH_DADJ) ? ((int64_t)dir * a.Bp + (int64_t)c_ * a.Bc) : (a.negocc_off[dir] + (int64_t)c_ * a.N);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int col = 32 * ct + l31;
+#pragma unroll
+                for (int r_ = 0; r_ < 16; ++r_) {
+                    const int x = xt * FL_XT + wave * 32 + acc_row(r_, h);
+                    if (x < a.Xrows && col < a.d) {
+                        float* p = a.out + (base + x) * a.out_ld + col;
+                        if (sole) *p = out[ct][r_];
+                        else unsafeAtomicAdd(p, out[ct][r_]);
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- prologue: three tiles in flight.  (ptile, pyb) is the prefetch cursor; it stops at the last item of the range.
+    int tile = it0 / a.YB, yb = it0 - tile * a.YB;
+    int ptile = tile, pyb = yb, pit = it0;
+    auto padvance = [&]() {
+        if (pit + 1 < it1) {
+            ++pit;
+            if (++pyb == a.YB) { pyb = 0; ++ptile; }
+        }
+    };
+    dma(ptile, pyb, 0);
+    padvance();
+    dma(ptile, pyb, 1);
+    padvance();
+    dma(ptile, pyb, 2);
+    padvance();
+
+    for (int it = it0; it < it1; ++it) {
+        if (tile != cur_tile) {
+            if (cur_tile >= 0) flush(a.YB);
+            load_x(tile);
+            cur_tile = tile;
+            y_first = yb;
+        }
+        const int slot = (it - it0) & (FL_SLOTS - 1);
+        // tile `it` has landed once at most the two younger tiles' pieces are outstanding (loads retire in order; the x fragments
+        // loaded above are younger still, so this over-waits at a tile switch, never under-waits)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_WAVE) : "memory");
+        __builtin_amdgcn_s_barrier();
+        dma(ptile, pyb, (it - it0 + 3) & (FL_SLOTS - 1));
+        padvance();
+        const unsigned char* T = smem + slot * SLOT;
+
+        // ---- S tile: D[y][x] = sum_k Y[y][k] X[x][k], hi.hi in accM, the two cross products in accC
+        v16f accM, accC;
+#pragma unroll
+        for (int r_ = 0; r_ < 16; ++r_) accM[r_] = accC[r_] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const v8bf yh = *reinterpret_cast<const v8bf*>(T + a_off + 32 * ks);
+            const v8bf yl = *reinterpret_cast<const v8bf*>(T + a_off + 2 * KP + 32 * ks);
+            accM = fl_mfma(yh, xh[ks], accM);
+            accC = fl_mfma(yh, xl[ks], accC);
+            accC = fl_mfma(yl, xh[ks], accC);
+        }
+
+        if (MODE == FLASH_FWD) {
+            float t[16];
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) t[r_] = accM[r_] + accC[r_];
+            if (STORE_S) {  // parity / debug only: scattered 4-B stores
+                const int x = xt * FL_XT + wave * 32 + l31;
+#pragma unroll
+                for (int r_ = 0; r_ < 16; ++r_) {
+                    const int y = yb * FL_YB + 16 * (r_ >> 3) + 8 * h + (r_ & 7);
+                    if (x < a.Xrows && y < a.Yrows)
+                        a.S[((int64_t)dir * a.Bp + (int64_t)c_ * a.Bc + x) * a.n_ld + y] = t[r_];
+                }
+            }
+            if ((yb + 1) * FL_YB > a.Yrows) {  // last block of the chunk: columns past N do not exist
+#pragma unroll
+                for (int r_ = 0; r_ < 16; ++r_) {
+                    const int y = yb * FL_YB + 16 * (r_ >> 3) + 8 * h + (r_ & 7);
+                    if (y >= a.Yrows) t[r_] = -INFINITY;
+                }
+            }
+            float tm = t[0];
+#pragma unroll
+            for (int r_ = 1; r_ < 16; ++r_) tm = fmaxf(tm, t[r_]);
+            const float mn = fmaxf(m2, tm * FL_LOG2E);
+            float s0 = 0.f, s1 = 0.f;
+            if (mn > -INFINITY) {
+#pragma unroll
+                for (int r_ = 0; r_ < 16; r_ += 2) {
+                    s0 += __builtin_amdgcn_exp2f(fmaf(t[r_], FL_LOG2E, -mn));
+                    s1 += __builtin_amdgcn_exp2f(fmaf(t[r_ + 1], FL_LOG2E, -mn));
+                }
+                lsum = lsum * __builtin_amdgcn_exp2f(m2 - mn) + (s0 + s1);
+                m2 = mn;
+            }
+        } else {
+            // ---- V = exp2(S log2(e) - lsec) in the accumulator layout == A operand layout (k = 16 s + 8 h + e <-> reg 8 s + e)
+            v8bf wh[2], wl[2];
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r_ = 8 * s_ + e;
+                    float ls;
+                    if (MODE == FLASH_DADJ) ls = lsec_x;
+                    else ls = *reinterpret_cast<const float*>(T + (16 * s_ + fl_rho(8 * h + e)) * P + 4 * KP);
+                    const float w = __builtin_amdgcn_exp2f(fmaf(accM[r_] + accC[r_], FL_LOG2E, -ls));
+                    const __bf16 wh_ = (__bf16)w;
+                    wh[s_][e] = wh_;
+                    wl[s_][e] = (__bf16)(w - (float)wh_);
+                }
+            }
+            // ---- out[x][col] += sum_y V[y][x] Y[y][col]
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    const unsigned char* q = T + tr_off + (16 * s_) * P + 64 * ct;
+                    union { v4s p[2]; v8bf f; } bh, bl;
+                    bh.p[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q));
+                    bh.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + P));
+                    bl.p[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + 2 * KP));
+                    bl.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + 2 * KP + P));
+                    out[ct] = fl_mfma(wh[s_], bh.f, out[ct]);
+                    out[ct] = fl_mfma(wh[s_], bl.f, out[ct]);
+                    out[ct] = fl_mfma(wl[s_], bh.f, out[ct]);
+                }
+            }
+        }
+        if (++yb == a.YB) { yb = 0; ++tile; }
+    }
+    flush(yb == 0 ? a.YB : yb);
+    // drain the over-issued prefetches before the LDS allocation is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------- merge
+// lse = log(e^pos + sum over the (at most two) partials), row loss, dL/dpos, per-block loss sums; patches lsec into the adj records.
+__global__ __launch_bounds__(256) void flash_merge_kernel(const float2* __restrict__ part, const float* __restrict__ pos, int64_t rows, int64_t Bp,
+                                                          int Bc, int C, int XR, int KP, float* __restrict__ lse, float* __restrict__ rowloss,
+                                                          float* __restrict__ dpos, float gscale, float* __restrict__ blocksum, char* __restrict__ adjrec) {
+    __shared__ float red[256];
+    const int64_t bpd = (Bp + 255) / 256;
+    const int64_t dir = blockIdx.x / bpd, blk = blockIdx.x - dir * bpd;
+    const int64_t r = blk * 256 + threadIdx.x;
+    float mine = 0.f;
+    if (r < Bp) {
+        const int64_t row = dir * Bp + r;
+        const float p = pos[row];
+        const float2 v0 = part[row], v1 = part[rows + row];
+        const float m = fmaxf(p, fmaxf(v0.x, v1.x));
+        const float sneg = v0.y * __expf(v0.x - m) + v1.y * __expf(v1.x - m);
+        const float sum = __expf(p - m) + sneg;
+        const float l = m + __logf(sum);
+        lse[row] = l;
+        rowloss[row] = l - p;
+        // dL/dpos = p_pos - 1 = -(sum of the negatives' probabilities): the second form has no cancellation when p_pos -> 1
+        dpos[row] = -(sneg / sum) * gscale;
+        mine = l - p;
+        const int64_t c = r / Bc;
+        const int x = (int)(r - c * Bc);
+        const int P = 4 * KP + 16;
+        *reinterpret_cast<float*>(adjrec + ((dir * C + c) * XR + fl_rho(x)) * (int64_t)P + 4 * KP) = l * FL_LOG2E - log2f(gscale);
+    }
+    red[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = red[0];
+}
+
+// zero up to three float ranges (lengths are multiples of 4, bases 16-B aligned) in one launch
+__global__ __launch_bounds__(256) void flash_zero_kernel(float* a, int64_t na, float* b, int64_t nb, float* c, int64_t nc) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < na; i += stride) *reinterpret_cast<float4*>(a + i) = z;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < nb; i += stride) *reinterpret_cast<float4*>(b + i) = z;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < nc; i += stride) *reinterpret_cast<float4*>(c + i) = z;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- host side
+static int fl_ks(int d) { return (d + 15) / 16; }
+
+bool flash_applicable(const marius_lp_desc* desc, const LpDims& D) {
+    const char* e = getenv("MARIUS_FLASH");
+    if (e && e[0] == '0') return false;
+    if (!(desc->flags & MARIUS_LP_TRAIN_ONLY) && !(e && e[0] == 'f')) return false;  // MARIUS_FLASH=f: force (tests of the API path's numbers)
+    if (D.loss != MARIUS_LOSS_SOFTMAX_CE || D.cmp != MARIUS_CMP_DOT) return false;
+    if ((desc->dst_filter && desc->n_dst_filter > 0) || (desc->src_filter && desc->n_src_filter > 0)) return false;
+    const int ks = fl_ks(D.d);
+    if (!(ks == 4 || ks == 7 || ks == 8)) return false;  // instantiated K depths: d in (48, 64], (96, 112], (112, 128]
+    if (D.ndir == 2 && !desc->src_neg) return false;
+    return true;
+}
+
+size_t flash_adjrec_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.Bc + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)) + 8192; }
+size_t flash_negrec_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.N + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)) + 8192; }
+size_t flash_part_bytes(const LpDims& D) { return (size_t)2 * D.ndir * D.Bp * sizeof(float2); }
+
+static int fl_num_wg(int64_t tiles) {
+    int nwg = 512;  // 2 workgroups per CU
+    const char* e = getenv("MARIUS_FLASH_NWG");
+    if (e) nwg = atoi(e);
+    if (nwg > tiles) nwg = (int)tiles;
+    if (nwg >= 8) nwg &= ~7;  // XCD-local ranges need a multiple of 8
+    return nwg < 1 ? 1 : nwg;
+}
+
+template <int KS, int MODE, bool STORE_S>
+static int fl_launch(const FlashArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)FL_SLOTS * fl_slot_bytes(KS);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_kernel<KS, MODE, STORE_S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_last_error("flash: cannot raise the dynamic LDS limit to %zu", lds);
+            return MARIUS_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    flash_kernel<KS, MODE, STORE_S><<<dim3((unsigned)a.nwg), dim3(FL_NT), lds, st>>>(a);
+    return check_launch("flash_kernel");
+}
+
+template <int MODE, bool STORE_S>
+static int fl_dispatch(int ks, const FlashArgs& a, hipStream_t st) {
+    switch (ks) {
+        case 4: return fl_launch<4, MODE, STORE_S>(a, st);
+        case 7: return fl_launch<7, MODE, STORE_S>(a, st);
+        case 8: return fl_launch<8, MODE, STORE_S>(a, st);
+    }
+    set_last_error("flash: unsupported K depth %d", ks);
+    return MARIUS_ERR_UNSUPPORTED;
+}
+
+static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, char* negrec) {
+    const int XRa = (D.Bc + 31) / 32 * 32, NRn = (D.N + 31) / 32 * 32;
+    const bool xadj = (mode != FLASH_DNEG);
+    a.xrec = xadj ? adjrec : negrec;
+    a.yrec = xadj ? negrec : adjrec;
+    a.XR = xadj ? XRa : NRn;
+    a.YR = xadj ? NRn : XRa;
+    a.Xrows = xadj ? D.Bc : D.N;
+    a.Yrows = xadj ? D.N : D.Bc;
+    a.ncd = D.C * D.ndir;
+    a.XT = (a.Xrows + FL_XT - 1) / FL_XT;
+    a.YB = a.YR / FL_YB;
+    a.total = (int64_t)a.ncd * a.XT * a.YB;
+    a.nwg = fl_num_wg((int64_t)a.ncd * a.XT);
+    a.C = D.C;
+    a.Bc = D.Bc;
+    a.N = D.N;
+    a.d = D.d;
+    a.Bp = D.Bp;
+    a.part = nullptr;
+    a.S = nullptr;
+    a.n_ld = D.n_ld;
+    a.out = nullptr;
+    a.out_ld = 0;
+    a.negocc_off[0] = a.negocc_off[1] = 0;
+}
+
+// forward: pack both operands, row statistics (and, for parity tests only, the scores themselves)
+int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj, char* adjrec, char* negrec, float2* part, float* S, hipStream_t st) {
+    const int ks = fl_ks(D.d), KP = 16 * ks;
+    const int XR = (D.Bc + 31) / 32 * 32, NR = (D.N + 31) / 32 * 32;
+    const int ppr = KP / 4 + 1;
+    {
+        const int64_t n = (int64_t)D.ndir * D.C * XR * ppr;
+        flash_pack_adj_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(adj, D.d_ld, D.Bp, D.Bc, D.C, D.ndir, D.d, KP, XR, adjrec);
+    }
+    {
+        const int64_t n = (int64_t)D.ndir * D.C * NR * ppr;
+        flash_pack_neg_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(desc->emb, desc->emb_ld, desc->dst_neg, desc->src_neg, D.N, D.C, D.ndir,
+                                                                                 D.d, KP, NR, row_vec_width(desc->emb, desc->emb_ld, 4), negrec);
+    }
+    int rc = check_launch("flash_pack");
+    if (rc) return rc;
+    FlashArgs a;
+    fl_common(a, D, FLASH_FWD, adjrec, negrec);
+    a.part = part;
+    a.S = S;
+    ProfScope ps(PROF_LP_SCORES, st);
+    return S ? fl_dispatch<FLASH_FWD, true>(ks, a, st) : fl_dispatch<FLASH_FWD, false>(ks, a, st);
+}
+
+int flash_merge(const LpDims& D, const float2* part, const float* pos, float* lse, float* rowloss, float* dpos, float* blocksum, char* adjrec,
+                hipStream_t st) {
+    const int64_t bpd = cdiv(D.Bp, 256);
+    const int ks = fl_ks(D.d);
+    flash_merge_kernel<<<dim3((unsigned)(bpd * D.ndir)), dim3(256), 0, st>>>(part, pos, D.Bp * D.ndir, D.Bp, D.Bc, D.C, (D.Bc + 31) / 32 * 32, 16 * ks, lse,
+                                                                            rowloss, dpos, D.gscale, blocksum, adjrec);
+    return check_launch("flash_merge");
+}
+
+// backward contractions: dadj [ndir][Bp][d_ld] and the negatives' gocc rows.  Both outputs are zeroed first (split tiles accumulate).
+int flash_backward(const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2], bool has_src_neg, hipStream_t st) {
+    const int ks = fl_ks(D.d);
+    const int64_t CN = (int64_t)D.C * D.N;
+    {
+        const int64_t n0 = D.ndir * D.Bp * D.d_ld, n1 = CN * D.d_ld;
+        flash_zero_kernel<<<dim3(1024), dim3(256), 0, st>>>(dadj, n0, gocc + negocc_off[0] * D.d_ld, n1, D.ndir == 2 ? gocc + negocc_off[1] * D.d_ld : nullptr,
+                                                           D.ndir == 2 ? n1 : 0);
+        int rc0 = check_launch("flash_zero");
+        if (rc0) return rc0;
+    }
+    (void)has_src_neg;
+    FlashArgs a;
+    fl_common(a, D, FLASH_DADJ, adjrec, negrec);
+    a.out = dadj;
+    a.out_ld = D.d_ld;
+    int rc;
+    {
+        ProfScope ps(PROF_LP_GRAD_ADJ, st);
+        rc = fl_dispatch<FLASH_DADJ, false>(ks, a, st);
+    }
+    if (rc) return rc;
+    fl_common(a, D, FLASH_DNEG, adjrec, negrec);
+    a.out = gocc;
+    a.out_ld = D.d_ld;
+    a.negocc_off[0] = negocc_off[0];
+    a.negocc_off[1] = negocc_off[1];
+    {
+        ProfScope ps(PROF_LP_GRAD_NEG, st);
+        rc = fl_dispatch<FLASH_DNEG, false>(ks, a, st);
+    }
+    return rc;
+}
+
+}  // namespace marius

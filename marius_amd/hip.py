@@ -16,6 +16,7 @@ OP_HADAMARD, OP_COMPLEX_HADAMARD, OP_TRANSLATION, OP_NOOP = 0, 1, 2, 3
 CMP_DOT, CMP_L2, CMP_COSINE = 0, 1, 2
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 LOSS = {"SOFTMAX_CE": 0, "RANKING": 1, "CROSS_ENTROPY": 2, "BCE_AFTER_SIGMOID": 3, "BCE_WITH_LOGITS": 4, "MSE": 5, "SOFTPLUS": 6}
+LP_TRAIN_ONLY, LP_STORE_SCORES = 1, 2   # marius_lp_desc.flags
 MT_STATE_WORDS = 625
 
 
@@ -31,7 +32,7 @@ class LpDesc(C.Structure):
         ("edges", C.c_void_p), ("dst_neg", C.c_void_p), ("src_neg", C.c_void_p),
         ("rel", C.c_void_p), ("inv_rel", C.c_void_p), ("rel_ld", C.c_int64), ("R", C.c_int64),
         ("dst_filter", C.c_void_p), ("n_dst_filter", C.c_int64), ("src_filter", C.c_void_p), ("n_src_filter", C.c_int64),
-        ("loss", C.c_int32), ("margin", C.c_float),
+        ("loss", C.c_int32), ("margin", C.c_float), ("flags", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -41,7 +42,8 @@ class LpLayout(C.Structure):
         ("adj", C.c_size_t * 2), ("pos", C.c_size_t * 2), ("neg", C.c_size_t * 2), ("lse", C.c_size_t * 2),
         ("rowloss", C.c_size_t * 2), ("loss", C.c_size_t), ("dadj", C.c_size_t * 2), ("gocc", C.c_size_t),
         ("grel", C.c_size_t * 2), ("aux", C.c_size_t), ("lsepart", C.c_size_t), ("embp", C.c_size_t), ("adjp", C.c_size_t), ("kp", C.c_int64), ("negt", C.c_size_t), ("adjt", C.c_size_t), ("gradpart", C.c_size_t),
-        ("dpos", C.c_size_t * 2), ("vlog", C.c_size_t),
+        ("dpos", C.c_size_t * 2), ("vlog", C.c_size_t), ("adjrec", C.c_size_t), ("negrec", C.c_size_t), ("fpart", C.c_size_t),
+        ("flash", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -285,9 +287,9 @@ def owner_offsets(um, shard_rows, num_shards):
 class LpWorkspace:
     """marius_lp_desc + layout + workspace for one batch shape."""
 
-    def __init__(self, relop, cmp, d, B, C_, N, use_inverse, reduction, edge_cols, has_src_neg, device, loss=0, margin=0.0):
+    def __init__(self, relop, cmp, d, B, C_, N, use_inverse, reduction, edge_cols, has_src_neg, device, loss=0, margin=0.0, flags=0):
         self.desc = LpDesc()
-        self.desc.loss, self.desc.margin = loss, margin
+        self.desc.loss, self.desc.margin, self.desc.flags = loss, margin, flags
         self.desc.relop, self.desc.cmp, self.desc.d, self.desc.edge_cols = relop, cmp, d, edge_cols
         self.desc.B, self.desc.C, self.desc.N = B, C_, N
         self.desc.use_inverse, self.desc.reduction = int(use_inverse), reduction

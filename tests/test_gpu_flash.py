@@ -1,0 +1,241 @@
+"""GPU parity of the flash-style training path (marius_amd/csrc/kernels/lp_flash.hip; marius_lp_desc.flags & MARIUS_LP_TRAIN_ONLY).
+
+What the path claims, and what is asserted here:
+  * scores are computed from 2-way bf16 splits (x = h + l) with three products on the BF16 matrix pipe and fp32 accumulation:
+        |S_flash - S_exact| <= 3 * 2^-18 * sum_k |a_k n_k|  +  fp32 accumulation error (<= 2^-20 of the same sum at d <= 128)
+    checked entry by entry against the oracle evaluated in float64 (`test_flash_scores_obey_the_split_error_bound`), and inside the
+    1e-4 score contract in its (rtol |want| + rtol max|want|) form;
+  * loss, per-row lse, node / relation gradients match the oracle (reference arithmetic: fp32, comparators.cpp:22-28,
+    decoder_methods.cpp:57-114, loss.cpp:50-67) to the same tolerances as the materialised-score kernels;
+  * gradients are compared PER OCCURRENCE (the `gocc` rows, before the segmented sum) with the oracle evaluated in float64;
+  * tiles split between two workgroups (partial statistics, two-contributor atomics) are bit-reproducible run to run
+    (MARIUS_FLASH_NWG forces every split pattern at small shapes).
+"""
+import pytest
+import torch
+
+from oracle import lp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEC = {"DISTMULT": (0, 0), "COMPLEX": (1, 0)}
+
+
+@pytest.fixture(scope="module")
+def H():
+    from marius_amd import hip
+
+    hip.lib()
+    return hip
+
+
+def make_batch(decoder, B, C, N, d, U, R, seed, scale=0.5, zipf=False):
+    g = torch.Generator().manual_seed(seed)
+    emb = torch.randn(U, d, generator=g) * scale
+    if zipf:
+        src = (torch.rand(B, generator=g) ** 4 * U).long().clamp_(0, U - 1)
+        rel = (torch.rand(B, generator=g) ** 4 * R).long().clamp_(0, R - 1)
+    else:
+        src, rel = torch.randint(U, (B,), generator=g), torch.randint(R, (B,), generator=g)
+    edges = torch.stack([src, rel, torch.randint(U, (B,), generator=g)], 1)
+    dst_neg = torch.randint(U, (C, N), generator=g)
+    src_neg = torch.randint(U, (C, N), generator=g)
+    rel_t = O.init_relations(decoder, R, d) + 0.3 * torch.randn(R, d, generator=g)
+    inv_t = O.init_relations(decoder, R, d) + 0.3 * torch.randn(R, d, generator=g)
+    return emb, edges, dst_neg, src_neg, rel_t, inv_t
+
+
+def run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, store=True, reduction="sum"):
+    relop, cmp = DEC[decoder]
+    B, (C, N), d = edges.size(0), dst_neg.shape, emb.size(1)
+    flags = H.LP_TRAIN_ONLY | (H.LP_STORE_SCORES if store else 0)
+    W = H.LpWorkspace(relop, cmp, d, B, C, N, use_inverse, H.REDUCE_SUM if reduction == "sum" else H.REDUCE_MEAN, 3, True, dev, flags=flags)
+    assert W.layout.flash == 1, "the flash path was not selected"
+    t = lambda x: None if x is None else x.to(dev)
+    W.bind(t(emb), t(edges), t(dst_neg), t(src_neg), t(rel), t(inv) if use_inverse else None)
+    W.forward()
+    W.loss()
+    W.backward()
+    torch.cuda.synchronize()
+    return W
+
+
+def mixed_close(got, want, what, rtol=1e-4, ref32=None, scale=None):
+    """the contract's mixed form: |err| <= rtol |want| + rtol max|want|, plus the worst pure-relative error over entries >= 0.1 max.
+    For gradients `want` is the oracle evaluated in float64 and `ref32` the same oracle in the reference's fp32 arithmetic: its own
+    distance from the float64 result is printed next to ours (p - 1 with p -> 1, or sums of hundreds of +- terms, lose digits in
+    ANY fp32 evaluation)."""
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    mx = max(want.abs().max().item(), 1e-30)
+    if scale is not None:  # the magnitude of the terms an entry is summed from, when that is larger than the entries themselves
+        mx = max(mx, scale)
+    err = (got - want).abs()
+    ok = err <= rtol * mx + rtol * want.abs()
+    big = want.abs() >= 0.1 * mx
+    rel = (err[big] / want.abs()[big]).max().item() if bool(big.any()) else 0.0
+    extra = ""
+    if ref32 is not None:
+        e32 = (ref32.detach().cpu().double() - want).abs()
+        extra = "   [fp32 oracle vs fp64: err/max %.2e, rel %.2e]" % ((e32.max() / mx).item(), (e32[big] / want.abs()[big]).max().item() if bool(big.any()) else 0.0)
+    print("%-24s worst err / max %.2e   worst rel over entries >= 0.1 max %.2e   max %.3e%s" % (what, (err.max() / mx).item(), rel, mx, extra))
+    assert bool(ok.all()), "%s: max abs err %.3e vs max %.3e" % (what, err.max().item(), mx)
+    assert rel <= rtol, "%s: worst relative error %.3e over the large entries" % (what, rel)
+    return (err.max() / mx).item(), rel
+
+
+def oracle64(decoder, emb, U, d, edges, dst_neg, src_neg, rel, inv, reduction="sum"):
+    return O.train_batch(decoder, emb.double(), torch.zeros(U, d, dtype=torch.float64), edges, dst_neg, src_neg, rel.double(),
+                         None if inv is None else inv.double(), reduction=reduction)
+
+
+def node_grad_of(W, edges, src_neg, dst_neg, U, d):
+    occ_ids = torch.cat([edges[:, 0], edges[:, -1], src_neg.flatten(), dst_neg.flatten()])
+    return torch.zeros(U, d, dtype=torch.float64).index_add_(0, occ_ids, W.gocc()[:, :d].cpu().double())
+
+
+def occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction="sum", dtype=torch.float64):
+    """The oracle with every occurrence (src, dst, src negatives, dst negatives: map_tensors order, util.cpp:180-205) as its own
+    leaf row: its node gradient is the per-occurrence gradient the kernels write to `gocc`, before the segmented sum.  Comparing
+    there is the well-conditioned check: a node that is an endpoint AND its own negative gets +g and -g, and the sum cancels to
+    rounding noise in any arithmetic."""
+    B, (C, N), d = edges.size(0), dst_neg.shape, emb.size(1)
+    occ_ids = torch.cat([edges[:, 0], edges[:, -1], src_neg.flatten(), dst_neg.flatten()])
+    L = occ_ids.numel()
+    e2 = torch.stack([torch.arange(B), edges[:, 1], torch.arange(B) + B], 1)
+    sn2 = (torch.arange(C * N) + 2 * B).reshape(C, N)
+    dn2 = (torch.arange(C * N) + 2 * B + C * N).reshape(C, N)
+    cv = lambda t: None if t is None else t.to(dtype)
+    w = O.train_batch(decoder, emb[occ_ids].to(dtype), torch.zeros(L, d, dtype=dtype), e2, dn2, sn2, cv(rel), cv(inv), reduction=reduction)
+    return w, occ_ids
+
+
+def check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv, U, R, reduction="sum"):
+    d = emb.size(1)
+    w64, occ_ids = occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction)
+    w32, _ = occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction, dtype=torch.float32)
+    g = W.gocc()[:, :d].cpu().double()
+    if inv is None:  # src negatives take part in the unique map but get no gradient in a single-direction decoder
+        B, CN = edges.size(0), dst_neg.numel()
+        assert float(g[2 * B:2 * B + CN].abs().max()) == 0.0
+    mixed_close(g, w64["node_grad"], "per-occurrence node grad", ref32=w32["node_grad"])
+    # the segmented sum per node, on the scale of the occurrence gradients it is made of
+    scale = w64["node_grad"].abs().max().item()
+    ng = torch.zeros(U, d, dtype=torch.float64).index_add_(0, occ_ids, g)
+    ng64 = torch.zeros(U, d, dtype=torch.float64).index_add_(0, occ_ids, w64["node_grad"])
+    nerr = (ng - ng64).abs()
+    assert bool((nerr <= 1e-4 * ng64.abs() + 1e-4 * scale).all()), "node grad sum: %.3e vs scale %.3e" % (nerr.max().item(), scale)
+    rg = torch.zeros(R, d, dtype=torch.float64).index_add_(0, edges[:, 1], W.grel(0)[:, :d].cpu().double())
+    # a relation gradient is g o e with g = dpos dst + sum_j q_j n_j: when dst is its own negative the two parts cancel inside ONE
+    # edge, so the natural scale is that of the occurrence gradients (same g, other operand)
+    mixed_close(rg, w64["rel_grad"], "rel_grad", ref32=w32["rel_grad"], scale=scale)
+    if inv is not None:
+        ig = torch.zeros(R, d, dtype=torch.float64).index_add_(0, edges[:, 1], W.grel(1)[:, :d].cpu().double())
+        mixed_close(ig, w64["inv_rel_grad"], "inv_rel_grad", ref32=w32["inv_rel_grad"], scale=scale)
+
+
+SHAPES = [(6, 3, 5, 50), (100, 10, 50, 50), (1000, 10, 500, 100), (250, 7, 130, 100), (300, 4, 260, 128), (64, 2, 40, 64),
+          (5, 4, 6, 100), (2, 4, 64, 100), (1, 3, 33, 100), (777, 3, 1000, 112)]
+
+
+@pytest.mark.parametrize("decoder", ["DISTMULT", "COMPLEX"])
+@pytest.mark.parametrize("use_inverse", [True, False])
+@pytest.mark.parametrize("B,C,N,d", SHAPES)
+def test_flash_forward_loss_backward_match_oracle(H, dev, decoder, use_inverse, B, C, N, d):
+    U, R = max(40, B), 11
+    emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=B + d, zipf=(B == 250))
+    want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv if use_inverse else None)
+    W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse)
+    assert W.layout.Bp == want["pos"].numel()
+    mixed_close(W.pos(0), want["pos"], "pos")
+    mixed_close(W.neg(0), want["neg"], "neg (split scores)")
+    if use_inverse:
+        mixed_close(W.pos(1), want["inv_pos"], "inv_pos")
+        mixed_close(W.neg(1), want["inv_neg"], "inv_neg (split scores)")
+    mixed_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss")
+    lse_want = torch.logsumexp(torch.cat([want["pos"][:, None], want["neg"]], 1), 1)
+    mixed_close(W.lse(0), lse_want, "lse")
+    check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv if use_inverse else None, U, R)
+
+
+@pytest.mark.parametrize("decoder,B,C,N,d", [("COMPLEX", 4096, 4, 1000, 100), ("DISTMULT", 1000, 10, 500, 128), ("COMPLEX", 300, 3, 200, 64)])
+def test_flash_scores_obey_the_split_error_bound(H, dev, decoder, B, C, N, d):
+    """|S_flash - S_fp64| <= (3 * 2^-18 + 2^-20) * sum_k |adj_k| |neg_k|, entry by entry, both directions."""
+    U, R = 9000, 17
+    emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=5, scale=1.0)
+    W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True)
+    e64, r64, i64 = emb.double(), rel.double(), inv.double()
+    Bc = -(-B // C)
+    worst = 0.0
+    for dir_, (relt, head, negs) in enumerate([(r64, 0, dst_neg), (i64, 2, src_neg)]):
+        op = O.hadamard if decoder == "DISTMULT" else O.complex_hadamard
+        adj = op(e64[edges[:, head]], relt[edges[:, 1]])
+        adj = torch.cat([adj, torch.zeros(Bc * C - B, d, dtype=torch.float64)])
+        got = W.neg(dir_).cpu().double()
+        for c in range(C):
+            a = adj[c * Bc:(c + 1) * Bc]
+            n = e64[negs[c]]
+            exact = a @ n.t()
+            mag = a.abs() @ n.abs().t()
+            err = (got[c * Bc:(c + 1) * Bc] - exact).abs()
+            bound = (3 * 2.0 ** -18 + 2.0 ** -20) * mag + 1e-30
+            worst = max(worst, (err / bound).max().item())
+    print("worst |err| / bound = %.3f" % worst)
+    assert worst <= 1.0
+
+
+@pytest.mark.parametrize("nwg", ["1", "2", "3", "5", "8", "16", "24"])
+def test_flash_split_tiles_are_deterministic_and_consistent(H, dev, monkeypatch, nwg):
+    """Tiles shared by two workgroups (partial row statistics, two-contributor float atomics onto a zeroed output) are
+    bit-reproducible run to run — a + b == b + a — and agree with the unsplit distribution up to the association of the softmax sum."""
+    B, C, N, d, U, R = 700, 3, 300, 100, 900, 7
+    emb, edges, dst_neg, src_neg, rel, inv = make_batch("COMPLEX", B, C, N, d, U, R, seed=3)
+
+    def run():
+        W = run_flash(H, dev, "COMPLEX", emb, edges, dst_neg, src_neg, rel, inv, True, store=False)
+        return [t.clone() for t in (W.lse(0), W.lse(1), W.gocc(), W.dadj(0), W.dadj(1), W.loss_values())]
+
+    monkeypatch.setenv("MARIUS_FLASH_NWG", "512")   # clipped to the number of tiles: every tile has one owner
+    ref = run()
+    monkeypatch.setenv("MARIUS_FLASH_NWG", nwg)
+    got = [run() for _ in range(3)]
+    for other in got[1:]:
+        for a, b in zip(got[0], other):
+            assert torch.equal(a, b)
+    for a, b in zip(ref, got[0]):
+        assert torch.allclose(a, b, rtol=2e-5, atol=2e-6 * float(a.abs().max()))
+
+
+def test_flash_mean_reduction(H, dev):
+    B, C, N, d, U, R = 96, 4, 40, 100, 60, 5
+    emb, edges, dst_neg, src_neg, rel, inv = make_batch("DISTMULT", B, C, N, d, U, R, seed=77)
+    want = O.train_batch("DISTMULT", emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv, reduction="mean")
+    W = run_flash(H, dev, "DISTMULT", emb, edges, dst_neg, src_neg, rel, inv, True, reduction="mean")
+    mixed_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss (mean)")
+    check_gradients(W, "DISTMULT", emb, edges, dst_neg, src_neg, rel, inv, U, R, reduction="mean")
+
+
+def test_flash_not_selected_outside_its_domain(H, dev):
+    """TransE (L2), other losses, filters and unsupported d keep the materialised-score kernels even with TRAIN_ONLY set."""
+    mk = lambda **kw: H.LpWorkspace(kw.get("relop", 0), kw.get("cmp", 0), kw.get("d", 100), 64, 4, 32, True, H.REDUCE_SUM, 3, True, dev,
+                                    loss=kw.get("loss", 0), flags=H.LP_TRAIN_ONLY)
+    assert mk().layout.flash == 1
+    assert mk(relop=2, cmp=1).layout.flash == 0          # TransE
+    assert mk(loss=H.LOSS["RANKING"]).layout.flash == 0
+    assert mk(d=400).layout.flash == 0
+    assert mk(d=20).layout.flash == 0
+    assert H.LpWorkspace(0, 0, 100, 64, 4, 32, True, H.REDUCE_SUM, 3, True, dev).layout.flash == 0   # API contract: scores materialised
+
+
+def test_flash_bench_shape_matches_oracle(H, dev):
+    """cfg2's batch (B=50,000 C=50 N=1000 d=100 ComplEx + inverse) through the path bench.py times: no score tensor exists, so the
+    check is on the loss, the row statistics and every gradient."""
+    decoder, B, C, N, d, U, R = "COMPLEX", 50000, 50, 1000, 100, 200000, 1000
+    emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=2024)
+    want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv)
+    W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, store=False)
+    assert W.layout.neg[0] == 0 and W.layout.neg[1] == 0      # nothing score-shaped was allocated
+    mixed_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss")
+    mixed_close(W.lse(0), torch.logsumexp(torch.cat([want["pos"][:, None], want["neg"]], 1), 1), "lse")
+    mixed_close(W.lse(1), torch.logsumexp(torch.cat([want["inv_pos"][:, None], want["inv_neg"]], 1), 1), "inv lse")
+    check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv, U, R)
