@@ -284,7 +284,7 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_readonly("active_edges", &DataLoader::active_edges_)
         .def_readonly("graph", &DataLoader::graph_)
         .def_readonly("active_perm", &DataLoader::active_perm_)
-        .def_readonly("num_unique", &DataLoader::count_);
+        .def_readonly("num_unique", &DataLoader::last_num_unique_);
 
     py::class_<SynchronousTrainer, std::shared_ptr<SynchronousTrainer>>(m, "SynchronousTrainer")
         .def(py::init<std::shared_ptr<DataLoader>, std::shared_ptr<Model>>())

@@ -442,6 +442,20 @@ class DataLoader {
     shared_ptr<Batch> next_;
     bool next_exact_ = false;
     int64_t prepared_left_ = 0;
+    // Batch preparation ahead of the step runs on its own host thread (the reference's batch_loader_threads, pipeline.cpp:19-49):
+    // ~35 of a step's ~60 launches are the sampler / unique-map kernels of the NEXT batch, and issuing them from the training
+    // thread made the step launch-bound once the contraction kernels left the FP32 matrix pipe.
+    struct LoaderWorker;
+    LoaderWorker* worker_ = nullptr;
+    bool pending_ = false;  // a request has been posted and not yet taken
+    // Memory of a batch is allocated on the loader stream and read by the training stream.  The preparing thread may only reuse it for a
+    // batch whose loader-stream work waits for that training step, so a batch is released HERE, between taking the next prepared batch
+    // and posting the following request — never while a preparation is in flight on the other thread.
+    shared_ptr<Batch> held_;
+    Tensor last_num_unique_;  // device count of the batch getBatch returned last (count_ itself belongs to the preparing thread)
+    void post_prepare(bool exact_unique);
+    shared_ptr<Batch> take_prepared();
+    void drain_worker();
     ~DataLoader();
     shared_ptr<Batch> prepareBatch(bool exact_unique);  // the body of getBatch, on the current stream
 

@@ -47,7 +47,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 enum { FLASH_FWD = 0, FLASH_DADJ = 1, FLASH_DNEG = 2 };
 
-constexpr int FL_WAVES = 4, FL_NT = 64 * FL_WAVES, FL_XT = 32 * FL_WAVES, FL_YB = 32, FL_SLOTS = 4;
+constexpr int FL_WAVES = 4, FL_NT = 64 * FL_WAVES, FL_XT = 32 * FL_WAVES, FL_YB = 32;
+// LDS ring slots / workgroups per CU: the forward needs 122 VGPRs, so three workgroups fit a CU if each keeps to three slots
+#ifndef FL_FWD_SLOTS
+#define FL_FWD_SLOTS 3
+#endif
+__host__ __device__ constexpr int fl_slots(int mode) { return mode == 0 ? FL_FWD_SLOTS : 4; }
+__host__ __device__ constexpr int fl_wg_per_cu(int mode) { return mode == 0 ? (FL_FWD_SLOTS == 3 ? 3 : 2) : 2; }
 constexpr float FL_LOG2E = 1.4426950408889634f, FL_LN2 = 0.6931471805599453f;
 
 __host__ __device__ constexpr int fl_pitch(int KS) { return 64 * KS + 16; }                                    // bytes per record
@@ -151,9 +157,76 @@ __global__ __launch_bounds__(256) void flash_pack_neg_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------------------------- the kernel
 __device__ __forceinline__ v16f fl_mfma(const v8bf& a, const v8bf& b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
+// ---- the two matrix phases, shared by both kernels.  Operand fragments are read from LDS two steps ahead of the MFMAs that consume
+// them (a three-entry register ring): without the explicit distance hipcc emits read -> wait -> MFMA chains and every step pays the LDS
+// latency inside the matrix phase.
+template <int KS>
+__device__ __forceinline__ v16f fl_score_tile(const unsigned char* T, int a_off, const v8bf (&xh)[KS], const v8bf (&xl)[KS]) {
+    constexpr int KP = 16 * KS;
+    v16f accM, accC;
+#pragma unroll
+    for (int r_ = 0; r_ < 16; ++r_) accM[r_] = accC[r_] = 0.f;
+    v8bf yh[3], yl[3];
+#pragma unroll
+    for (int ks = 0; ks < 2 && ks < KS; ++ks) {
+        yh[ks] = *reinterpret_cast<const v8bf*>(T + a_off + 32 * ks);
+        yl[ks] = *reinterpret_cast<const v8bf*>(T + a_off + 2 * KP + 32 * ks);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 2 < KS) {
+            yh[(ks + 2) % 3] = *reinterpret_cast<const v8bf*>(T + a_off + 32 * (ks + 2));
+            yl[(ks + 2) % 3] = *reinterpret_cast<const v8bf*>(T + a_off + 2 * KP + 32 * (ks + 2));
+        }
+#ifdef FL_ONE_ACC
+        accM = fl_mfma(yl[ks % 3], xh[ks], accM);
+        accM = fl_mfma(yh[ks % 3], xl[ks], accM);
+        accM = fl_mfma(yh[ks % 3], xh[ks], accM);
+#else
+        accM = fl_mfma(yh[ks % 3], xh[ks], accM);
+        accC = fl_mfma(yh[ks % 3], xl[ks], accC);
+        accC = fl_mfma(yl[ks % 3], xh[ks], accC);
+#endif
+    }
+    v16f acc;
+#pragma unroll
+    for (int r_ = 0; r_ < 16; ++r_) acc[r_] = accM[r_] + accC[r_];
+    return acc;
+}
+
+struct FlTrFrag {
+    union { v4s p[2]; v8bf f; } h, l;
+};
+template <int KS>
+__device__ __forceinline__ FlTrFrag fl_tr_read(const unsigned char* T, int tr_off, int g) {  // g = 2 ct + s
+    constexpr int KP = 16 * KS, P = fl_pitch(KS);
+    const unsigned char* q = T + tr_off + (16 * (g & 1)) * P + 64 * (g >> 1);
+    FlTrFrag r;
+    r.h.p[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q));
+    r.h.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + P));
+    r.l.p[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + 2 * KP));
+    r.l.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + 2 * KP + P));
+    return r;
+}
+template <int KS, int NCT>
+__device__ __forceinline__ void fl_grad_tile(const unsigned char* T, int tr_off, const v8bf (&wh)[2], const v8bf (&wl)[2], v16f (&out)[NCT]) {
+    constexpr int G = 2 * NCT;
+    FlTrFrag b[3];
+#pragma unroll
+    for (int g = 0; g < 2 && g < G; ++g) b[g] = fl_tr_read<KS>(T, tr_off, g);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g + 2 < G) b[(g + 2) % 3] = fl_tr_read<KS>(T, tr_off, g + 2);
+        const int ct = g >> 1, s_ = g & 1;
+        out[ct] = fl_mfma(wh[s_], b[g % 3].h.f, out[ct]);
+        out[ct] = fl_mfma(wh[s_], b[g % 3].l.f, out[ct]);
+        out[ct] = fl_mfma(wl[s_], b[g % 3].h.f, out[ct]);
+    }
+}
+
 template <int KS, int MODE, bool STORE_S>
-__global__ __launch_bounds__(FL_NT, 2) void flash_kernel(FlashArgs a) {
-    constexpr int KP = 16 * KS, P = fl_pitch(KS), SLOT = fl_slot_bytes(KS);
+__global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashArgs a) {
+    constexpr int KP = 16 * KS, P = fl_pitch(KS), SLOT = fl_slot_bytes(KS), NSLOT = fl_slots(MODE);
     constexpr int NCT = (KP + 31) / 32;       // 32-column tiles of the gradient output
     constexpr int DMA_PER_WAVE = SLOT / 4096;  // 1 KB wave-instructions per wave and tile
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -276,13 +349,13 @@ __global__ __launch_bounds__(FL_NT, 2) void flash_kernel(FlashArgs a) {
             if (++pyb == a.YB) { pyb = 0; ++ptile; }
         }
     };
-    dma(ptile, pyb, 0);
-    padvance();
-    dma(ptile, pyb, 1);
-    padvance();
-    dma(ptile, pyb, 2);
-    padvance();
+#pragma unroll
+    for (int i = 0; i < NSLOT - 1; ++i) {
+        dma(ptile, pyb, i);
+        padvance();
+    }
 
+    int slot = 0, pslot = NSLOT - 1;  // ring positions of item `it` and of the tile the next DMA fills
     for (int it = it0; it < it1; ++it) {
         if (tile != cur_tile) {
             if (cur_tile >= 0) flush(a.YB);
@@ -290,32 +363,22 @@ __global__ __launch_bounds__(FL_NT, 2) void flash_kernel(FlashArgs a) {
             cur_tile = tile;
             y_first = yb;
         }
-        const int slot = (it - it0) & (FL_SLOTS - 1);
-        // tile `it` has landed once at most the two younger tiles' pieces are outstanding (loads retire in order; the x fragments
+        // tile `it` has landed once at most the NSLOT - 2 younger tiles' pieces are outstanding (loads retire in order; the x fragments
         // loaded above are younger still, so this over-waits at a tile switch, never under-waits)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_WAVE) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * DMA_PER_WAVE) : "memory");
         __builtin_amdgcn_s_barrier();
-        dma(ptile, pyb, (it - it0 + 3) & (FL_SLOTS - 1));
+        dma(ptile, pyb, pslot);
         padvance();
+        pslot = pslot + 1 == NSLOT ? 0 : pslot + 1;
         const unsigned char* T = smem + slot * SLOT;
 
-        // ---- S tile: D[y][x] = sum_k Y[y][k] X[x][k], hi.hi in accM, the two cross products in accC
-        v16f accM, accC;
-#pragma unroll
-        for (int r_ = 0; r_ < 16; ++r_) accM[r_] = accC[r_] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const v8bf yh = *reinterpret_cast<const v8bf*>(T + a_off + 32 * ks);
-            const v8bf yl = *reinterpret_cast<const v8bf*>(T + a_off + 2 * KP + 32 * ks);
-            accM = fl_mfma(yh, xh[ks], accM);
-            accC = fl_mfma(yh, xl[ks], accC);
-            accC = fl_mfma(yl, xh[ks], accC);
-        }
+        // ---- S tile: D[y][x] = sum_k Y[y][k] X[x][k]
+        const v16f accS = fl_score_tile<KS>(T, a_off, xh, xl);
 
         if (MODE == FLASH_FWD) {
             float t[16];
 #pragma unroll
-            for (int r_ = 0; r_ < 16; ++r_) t[r_] = accM[r_] + accC[r_];
+            for (int r_ = 0; r_ < 16; ++r_) t[r_] = accS[r_];
             if (STORE_S) {  // parity / debug only: scattered 4-B stores
                 const int x = xt * FL_XT + wave * 32 + l31;
 #pragma unroll
@@ -357,30 +420,17 @@ __global__ __launch_bounds__(FL_NT, 2) void flash_kernel(FlashArgs a) {
                     float ls;
                     if (MODE == FLASH_DADJ) ls = lsec_x;
                     else ls = *reinterpret_cast<const float*>(T + (16 * s_ + fl_rho(8 * h + e)) * P + 4 * KP);
-                    const float w = __builtin_amdgcn_exp2f(fmaf(accM[r_] + accC[r_], FL_LOG2E, -ls));
+                    const float w = __builtin_amdgcn_exp2f(fmaf(accS[r_], FL_LOG2E, -ls));
                     const __bf16 wh_ = (__bf16)w;
                     wh[s_][e] = wh_;
                     wl[s_][e] = (__bf16)(w - (float)wh_);
                 }
             }
             // ---- out[x][col] += sum_y V[y][x] Y[y][col]
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-#pragma unroll
-                for (int s_ = 0; s_ < 2; ++s_) {
-                    const unsigned char* q = T + tr_off + (16 * s_) * P + 64 * ct;
-                    union { v4s p[2]; v8bf f; } bh, bl;
-                    bh.p[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q));
-                    bh.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + P));
-                    bl.p[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + 2 * KP));
-                    bl.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + 2 * KP + P));
-                    out[ct] = fl_mfma(wh[s_], bh.f, out[ct]);
-                    out[ct] = fl_mfma(wh[s_], bl.f, out[ct]);
-                    out[ct] = fl_mfma(wl[s_], bh.f, out[ct]);
-                }
-            }
+            if constexpr (MODE != FLASH_FWD) fl_grad_tile<KS, NCT>(T, tr_off, wh, wl, out);
         }
         if (++yb == a.YB) { yb = 0; ++tile; }
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
     }
     flush(yb == 0 ? a.YB : yb);
     // drain the over-issued prefetches before the LDS allocation is released
@@ -448,12 +498,12 @@ bool flash_applicable(const marius_lp_desc* desc, const LpDims& D) {
     return true;
 }
 
-size_t flash_adjrec_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.Bc + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)) + 8192; }
-size_t flash_negrec_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.N + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)) + 8192; }
+size_t flash_adjrec_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.Bc + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)) + 32768; }
+size_t flash_negrec_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.N + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)) + 32768; }
 size_t flash_part_bytes(const LpDims& D) { return (size_t)2 * D.ndir * D.Bp * sizeof(float2); }
 
-static int fl_num_wg(int64_t tiles) {
-    int nwg = 512;  // 2 workgroups per CU
+static int fl_num_wg(int64_t tiles, int mode) {
+    int nwg = 256 * fl_wg_per_cu(mode);
     const char* e = getenv("MARIUS_FLASH_NWG");
     if (e) nwg = atoi(e);
     if (nwg > tiles) nwg = (int)tiles;
@@ -463,7 +513,7 @@ static int fl_num_wg(int64_t tiles) {
 
 template <int KS, int MODE, bool STORE_S>
 static int fl_launch(const FlashArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)FL_SLOTS * fl_slot_bytes(KS);
+    const size_t lds = (size_t)fl_slots(MODE) * fl_slot_bytes(KS);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_kernel<KS, MODE, STORE_S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -488,6 +538,7 @@ static int fl_dispatch(int ks, const FlashArgs& a, hipStream_t st) {
 }
 
 static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, char* negrec) {
+    const int xt_rows = FL_XT;
     const int XRa = (D.Bc + 31) / 32 * 32, NRn = (D.N + 31) / 32 * 32;
     const bool xadj = (mode != FLASH_DNEG);
     a.xrec = xadj ? adjrec : negrec;
@@ -497,10 +548,10 @@ static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, cha
     a.Xrows = xadj ? D.Bc : D.N;
     a.Yrows = xadj ? D.N : D.Bc;
     a.ncd = D.C * D.ndir;
-    a.XT = (a.Xrows + FL_XT - 1) / FL_XT;
+    a.XT = (a.Xrows + xt_rows - 1) / xt_rows;
     a.YB = a.YR / FL_YB;
     a.total = (int64_t)a.ncd * a.XT * a.YB;
-    a.nwg = fl_num_wg((int64_t)a.ncd * a.XT);
+    a.nwg = fl_num_wg((int64_t)a.ncd * a.XT, mode);
     a.C = D.C;
     a.Bc = D.Bc;
     a.N = D.N;
