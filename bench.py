@@ -4,8 +4,11 @@
     python bench.py --gpus N --steps K --warmup W [--workload freebase86m|fb15k237] [--num-nodes N] [--edge-dist zipf|uniform]
 
 A "step" is one pass of the whole hot path over one batch of synthetic Freebase86m-shaped input already resident in HBM:
-edge slice -> MT19937 negative sampling -> sort/unique map -> row gather -> ComplEx scores (FP32 MFMA) -> SoftmaxCE ->
-hand-derived backward -> dense Adagrad on the relation tables -> segmented-sum + sparse Adagrad scatter into the node table.
+edge slice -> MT19937 negative sampling -> sort/unique map -> row gather -> ComplEx negative scores -> SoftmaxCE ->
+hand-derived backward -> Adagrad on the relation tables -> segmented-sum + sparse Adagrad scatter into the node table.
+The contractions run flash-style (lp_flash.hip): fp32 operands split exactly once per step into two bf16 planes, three bf16 MFMA
+products per fp32 product with fp32 accumulation (error bound tested in tests/test_gpu_flash.py), score tiles recomputed in the
+backward instead of a 400 MB score tensor.  MARIUS_FLASH=0 selects the FP32-MFMA kernels with materialised scores.
 Prints ONE JSON line (rank 0).  The CPU baseline leg runs the oracle (a port of the reference's CPU path) on a bounded sample.
 """
 import argparse
@@ -32,6 +35,7 @@ WORKLOADS = {
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: FP32 matrix (v_mfma_f32_32x32x2_f32)
+MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: BF16 matrix, dense (v_mfma_f32_32x32x16_bf16)
 
 
 def synth_edges(num_nodes, num_relations, E, dist, device, seed=1):
@@ -183,10 +187,24 @@ def main():
     Bp = C * math.ceil(B / C)
     contraction_flops = 2.0 * Bp * N * d * ndir  # one [Bc x d] x [d x N] contraction per chunk and direction
     L = 2 * B + 2 * C * N
+    # does the library take the flash path for this descriptor?  (same predicate the trainer's plan call evaluates)
+    flash = False
+    if a.driver == "cpp" and a.loss.upper() == "SOFTMAX_CE":
+        import ctypes
+        relop, cmp_ = {"DISTMULT": (0, 0), "COMPLEX": (1, 0), "TRANSE": (2, 1)}[cfg["decoder"]]
+        desc, lay = H.LpDesc(), H.LpLayout()
+        desc.relop, desc.cmp, desc.d, desc.edge_cols, desc.B, desc.C, desc.N = relop if R > 1 else H.OP_NOOP, cmp_, d, 3 if R > 1 else 2, B, C, N
+        desc.use_inverse, desc.flags = int(R > 1), H.LP_TRAIN_ONLY
+        desc.src_neg = ctypes.c_void_p(1)
+        desc.inv_rel = ctypes.c_void_p(1) if R > 1 else None
+        flash = H.lib().marius_lp_plan(ctypes.byref(desc), ctypes.byref(lay)) == 0 and lay.flash == 1
+    # MFMA work per launch.  FP32-MFMA kernels: the fp32 flops of the contraction(s).  Flash kernels: the bf16 flops the split scheme
+    # needs for them — 3 bf16 products per fp32 product, and the two backward launches recompute the score tile before their
+    # gradient contraction (2 contractions each) — priced against the dense BF16 matrix peak.
     alg = {  # algorithmic work per launch
-        "lp_scores": ("mfma", contraction_flops),
-        "lp_grad_adj": ("mfma", contraction_flops),
-        "lp_grad_neg": ("mfma", contraction_flops),
+        "lp_scores": ("mfma_bf16", 3 * contraction_flops) if flash else ("mfma", contraction_flops),
+        "lp_grad_adj": ("mfma_bf16", 2 * 3 * contraction_flops) if flash else ("mfma", contraction_flops),
+        "lp_grad_neg": ("mfma_bf16", 2 * 3 * contraction_flops) if flash else ("mfma", contraction_flops),
         "gather_rows": ("hbm", U * d * 4.0 * 2 + U * 8.0),                    # read rows + write batch copy + ids
         "segment_adagrad_scatter": ("hbm", L * d * 4.0 + U * d * 4.0 * 4),    # occurrence grads + r/w of w and s
         "lp_lse": ("hbm", 2.0 * Bp * (math.ceil(math.ceil(N / 64) / 4) * 8.0 + 12.0)),  # fused SoftmaxCE: only the per-group partials are re-read
@@ -195,7 +213,7 @@ def main():
         "sort_unique": ("hbm", L * (8.0 + 4.0) * 2 * 4),
         "mt19937_fill": ("hbm", 2.0 * C * N * 4.0 * 2),
     }
-    if prof.get("lp_grad_neg", (0, 0))[1] == 0:  # both backward contractions ran as ONE launch, timed under lp_grad_adj
+    if not flash and prof.get("lp_grad_neg", (0, 0))[1] == 0:  # both backward contractions ran as ONE launch, timed under lp_grad_adj
         alg["lp_grad_adj"] = ("mfma", 2 * contraction_flops)
     kernels = {}
     for name, (ms, cnt) in prof.items():
@@ -205,6 +223,8 @@ def main():
         avg_ms = ms / cnt
         if bound == "mfma":
             ach, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
+        elif bound == "mfma_bf16":
+            ach, peak, unit, bound = work / (avg_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TF, "TFLOP/s", "mfma"
         else:
             ach, peak, unit = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         kernels[name] = {"bound": bound, "avg_ms": round(avg_ms, 4), "launches": cnt, "achieved": round(ach, 2), "peak": peak, "unit": unit,
@@ -221,17 +241,26 @@ def main():
         # HBM bytes per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
         # this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md) — only valid for the workload it was collected on
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r1h_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json" if flash else "r1h_pmc_traffic.json")
         if a.workload == "freebase86m" and not a.num_nodes and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))["kernels"]
-            key = {"lp_grad_adj": "lp_grad16_kernel", "lp_grad_neg": "lp_grad16_kernel", "lp_scores": "lp_scores_ap_kernel",
-                   "gather_rows": "gather_rows_kernel", "segment_adagrad_scatter": "adagrad_unique_rows_kernel"}.get(dom)
+            if flash:
+                key = {"lp_grad_adj": "flash_kernel<7, 1", "lp_grad_neg": "flash_kernel<7, 2", "lp_scores": "flash_kernel<7, 0",
+                       "gather_rows": "gather_rows_kernel", "segment_adagrad_scatter": "adagrad_unique_rows_kernel"}.get(dom)
+            else:
+                key = {"lp_grad_adj": "lp_grad16_kernel", "lp_grad_neg": "lp_grad16_kernel", "lp_scores": "lp_scores_ap_kernel",
+                       "gather_rows": "gather_rows_kernel", "segment_adagrad_scatter": "adagrad_unique_rows_kernel"}.get(dom)
             for name, v in pmc.items():
                 if key and name.startswith(key):
                     traffic = v["hbm_bytes"]
-        roofline = {"kernel": dom + (" (dAdj + dNeg contractions, one launch)" if dom == "lp_grad_adj" and prof.get("lp_grad_neg", (0, 0))[1] == 0 else ""),
+        roofline = {"kernel": dom + (" (dAdj + dNeg contractions, one launch)" if not flash and dom == "lp_grad_adj" and prof.get("lp_grad_neg", (0, 0))[1] == 0 else ""),
                     "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"], "frac": k["frac"],
                     "traffic": traffic, "avg_ms": k["avg_ms"]}
+        if flash and k["bound"] == "mfma":
+            ncon = 1 if dom == "lp_scores" else 2
+            roofline.update({"peak_is": "dense BF16 MFMA", "bf16_products_per_fp32_product": 3, "contractions_per_launch": ncon,
+                             "fp32_equivalent_tflops": round(k["achieved"] / 3, 2),
+                             "note": "achieved = contractions_per_launch x 3 products x 2 Bp N d ndir flop / launch time (score tile recomputed in the backward launches)"})
 
     # ---- CPU baseline: the oracle (port of the reference's CPU path) on a bounded sample, host cores of this box
     cpu = None
@@ -246,7 +275,7 @@ def main():
     out = {
         "metric": "edges/sec scored (pos+neg)", "value": round(scored_eps, 1), "unit": "scored edges/s",
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (contractions: 2-way bf16 split x 3 products, f32 accumulate)" if flash else "f32", "data": "synthetic",
         "config": {"workload": "%s %s d=%d in-memory, B=%d C=%d N=%d inverse_edges, SoftmaxCE SUM, Adagrad lr 0.1, %s edges" % (
             a.workload, cfg["decoder"], d, B, C, N, a.edge_dist), "num_nodes": num_nodes, "num_relations": R, "num_edges": cfg["num_edges"],
             "parallelism": "single GPU", "host": "C++ SynchronousTrainer (libtorch)" if a.driver == "cpp" else "python ctypes driver"},

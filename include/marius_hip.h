@@ -64,6 +64,11 @@ int marius_debug_set_timeline(unsigned long long* buf);
 int marius_gather_rows(const float* table, int64_t table_ld, const int64_t* ids, int64_t n, int32_t d,
                        float* out, int64_t out_ld, marius_stream_t stream);
 
+/* The same gather for a capacity-sized id list whose valid length lives on the device (the unique count of map_tensors, never read
+ * back by the fused training step): rows [*num_rows_dev, capacity) of `out` are left untouched. */
+int marius_gather_rows_counted(const float* table, int64_t table_ld, const int64_t* ids, int64_t capacity, const int64_t* num_rows_dev, int32_t d,
+                               float* out, int64_t out_ld, marius_stream_t stream);
+
 /* both node tables with one id list (embeddings + Adagrad state): DataLoader::loadGPUParameters
  * src/data/dataloader.cpp:529-548 */
 int marius_gather_rows2(const float* table_a, const float* table_b, int64_t table_ld, const int64_t* ids, int64_t n,

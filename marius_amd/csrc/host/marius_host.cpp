@@ -244,6 +244,15 @@ Tensor InMemory::indexRead(Tensor indices) {  // storage.cpp:606-649
     mcheck(marius_gather_rows(fp(data_), data_.stride(0), ip(indices), indices.size(0), (int32_t)dim1_size_, fp(out), out.stride(0), cur_stream()));
     return out;
 }
+Tensor InMemory::indexReadCounted(Tensor indices, Tensor count_dev) {
+    if (indices.sizes().size() != 1) throw std::runtime_error("");
+    require_device(data_, "indexRead");
+    require_device(indices, "indexRead");
+    Tensor out = torch::empty({indices.size(0), dim1_size_}, data_.options());
+    mcheck(marius_gather_rows_counted(fp(data_), data_.stride(0), ip(indices), indices.size(0), ip(count_dev), (int32_t)dim1_size_, fp(out), out.stride(0),
+                                      cur_stream()));
+    return out;
+}
 void InMemory::indexAdd(Tensor indices, Tensor values) {  // storage.cpp:651-673 (ids unique)
     if (!values.defined() || indices.sizes().size() != 1 || values.size(0) != indices.size(0) || data_.dim() != values.dim())
         throw std::runtime_error("");
@@ -1348,7 +1357,10 @@ void SynchronousTrainer::train_one(bool fused) {
     dataloader_->num_relations_ = fused ? model_->decoder_->num_relations_ : 0;
     if (fused) {
         auto batch = dataloader_->getBatch(/*exact_unique=*/false);  // no host sync anywhere in the step
-        batch->node_embeddings_ = dataloader_->node_embeddings_->indexRead(batch->unique_node_indices_);
+        // capacity-sized id list (no host sync on the unique count): gather the U real rows only
+        auto mem = std::dynamic_pointer_cast<InMemory>(dataloader_->node_embeddings_);
+        batch->node_embeddings_ = (mem && batch->num_unique_dev_.defined()) ? mem->indexReadCounted(batch->unique_node_indices_, batch->num_unique_dev_)
+                                                                              : dataloader_->node_embeddings_->indexRead(batch->unique_node_indices_);
         model_->backward_into_tables(batch, dataloader_->node_embeddings_->data_, dataloader_->node_embeddings_state_->data_);
     } else {  // API-granular path, call for call the reference's loop (trainer.cpp:106-138)
         auto batch = dataloader_->getBatch(true);

@@ -31,6 +31,11 @@ struct PrepArgs {
     float* adj;  // [ndir][Bp, d_ld]
     float* pos;  // [ndir][Bp]
     float* x2;   // [ndir][Bp] (L2) or null
+    // flash path (lp_flash.hip), fused into lp_prep2_kernel: adj operand records (hi | lo bf16 planes, permuted rows) and the zero fill
+    // of dadj that the two-contributor accumulation of the backward needs.  frec == nullptr: not the flash path.
+    char* frec;
+    int fKP, fXR;
+    float* fdadj;  // [ndir][Bp, d_ld]
     LpDims D;
 };
 
@@ -109,12 +114,74 @@ __device__ __forceinline__ float half_sum(float v) {
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+__device__ __forceinline__ unsigned prep_pack_bf16x2(float x, float y) {
+    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+    v2bf p;
+    p[0] = (__bf16)x;
+    p[1] = (__bf16)y;
+    return __builtin_bit_cast(unsigned, p);
+}
+// record of row i of direction dir: hi / lo pairs of the lane's four elements, zero K padding, zero tail; dadj row zeroed
+__device__ __forceinline__ void prep_flash_store(const PrepArgs& a, int dir, int64_t i, int l, int c0, int c1, const float (&v)[4], bool act) {
+#pragma clang fp contract(off)
+    const LpDims& D = a.D;
+    const int P = 4 * a.fKP + 16;
+    const int64_t c = i / D.Bc;
+    const int x = (int)(i - c * D.Bc);
+    const int xp = 4 * (x & 3) + ((x >> 2) & 3) + (x & ~15);  // fl_rho
+    char* rec = a.frec + (((int64_t)dir * D.C + c) * a.fXR + xp) * (int64_t)P;
+    if (act) {
+        float lo[4];
+        unsigned hi01, hi23;
+        {
+            typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+            v2bf h0, h1;
+            h0[0] = (__bf16)v[0]; h0[1] = (__bf16)v[1];
+            h1[0] = (__bf16)v[2]; h1[1] = (__bf16)v[3];
+            lo[0] = v[0] - (float)h0[0]; lo[1] = v[1] - (float)h0[1];
+            lo[2] = v[2] - (float)h1[0]; lo[3] = v[3] - (float)h1[1];
+            hi01 = __builtin_bit_cast(unsigned, h0);
+            hi23 = __builtin_bit_cast(unsigned, h1);
+        }
+        *reinterpret_cast<unsigned*>(rec + 2 * c0) = hi01;
+        *reinterpret_cast<unsigned*>(rec + 2 * c1) = hi23;
+        *reinterpret_cast<unsigned*>(rec + 2 * a.fKP + 2 * c0) = prep_pack_bf16x2(lo[0], lo[1]);
+        *reinterpret_cast<unsigned*>(rec + 2 * a.fKP + 2 * c1) = prep_pack_bf16x2(lo[2], lo[3]);
+        float* z = a.fdadj + ((int64_t)dir * D.Bp + i) * D.d_ld;
+        *reinterpret_cast<float2*>(z + c0) = make_float2(0.f, 0.f);
+        *reinterpret_cast<float2*>(z + c1) = make_float2(0.f, 0.f);
+    } else {
+        const int q = l - D.d / 4;             // idle lanes write the zero K padding, one element pair each
+        const int col = D.d + 2 * q;
+        if (col < a.fKP) {
+            *reinterpret_cast<unsigned*>(rec + 2 * col) = 0u;
+            *reinterpret_cast<unsigned*>(rec + 2 * a.fKP + 2 * col) = 0u;
+        }
+    }
+    if (l == 0) *reinterpret_cast<float4*>(rec + 4 * a.fKP) = make_float4(0.f, 0.f, 0.f, 0.f);  // lsec: patched in by the merge kernel
+}
+
 __global__ __launch_bounds__(256) void lp_prep2_kernel(PrepArgs a) {
 #pragma clang fp contract(off)
     const LpDims& D = a.D;
     const int l = threadIdx.x & 31;
     const int64_t i = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
-    if (i >= D.Bp) return;
+    if (i >= D.Bp) {
+        // flash path: blocks past the edge rows zero the records that pad every chunk block to a multiple of 32 rows
+        if (a.frec) {
+            const int64_t r = i - D.Bp;  // pad record index over (dir, chunk, x in [Bc, XR))
+            const int npad = a.fXR - D.Bc;
+            if (npad > 0 && r < (int64_t)D.ndir * D.C * npad) {
+                const int64_t cd = r / npad;
+                const int x = D.Bc + (int)(r - cd * npad);
+                const int xp = 4 * (x & 3) + ((x >> 2) & 3) + (x & ~15);
+                const int P = 4 * a.fKP + 16;
+                char* rec = a.frec + (cd * a.fXR + xp) * (int64_t)P;
+                for (int o = 16 * l; o < P; o += 16 * 32) *reinterpret_cast<float4*>(rec + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        return;
+    }
     const int h2 = D.d / 2;
     const bool act = 4 * l < D.d;          // lanes that own elements
     const int c0 = 2 * l, c1 = h2 + 2 * l;  // first-half pair, second-half pair
@@ -124,6 +191,10 @@ __global__ __launch_bounds__(256) void lp_prep2_kernel(PrepArgs a) {
             if (act) {
                 *reinterpret_cast<float2*>(adj + c0) = make_float2(0.f, 0.f);
                 *reinterpret_cast<float2*>(adj + c1) = make_float2(0.f, 0.f);
+            }
+            if (a.frec) {
+                const float zz[4] = {0.f, 0.f, 0.f, 0.f};
+                prep_flash_store(a, dir, i, l, c0, c1, zz, act);
             }
             if (l == 0) {
                 a.pos[(int64_t)dir * D.Bp + i] = 0.f;
@@ -202,6 +273,7 @@ __global__ __launch_bounds__(256) void lp_prep2_kernel(PrepArgs a) {
             *reinterpret_cast<float2*>(adj + c0) = make_float2(v[0], v[1]);
             *reinterpret_cast<float2*>(adj + c1) = make_float2(v[2], v[3]);
         }
+        if (a.frec) prep_flash_store(a, dir, i, l, c0, c1, v, act);
         acc = half_sum(acc);
         if (D.cmp == MARIUS_CMP_L2) {
             nrm = half_sum(nrm);
@@ -1159,14 +1231,27 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     pa.pos = (float*)(ws + L->pos[0]);
     pa.x2 = x2;
     pa.D = D;
+    pa.frec = nullptr;
+    pa.fKP = pa.fXR = 0;
+    pa.fdadj = nullptr;
+    bool flash_fused_prep = false;
     {
         ProfScope ps(PROF_LP_PREP, st);
         const char* pv = getenv("MARIUS_PREP");  // MARIUS_PREP=1: one-wave-per-row kernel (any shape)
         const bool vec_ok = (D.d % 4 == 0) && D.d <= 128 && (desc->emb_ld % 2 == 0) && (desc->rel_ld % 2 == 0 || !desc->rel) && (D.d == D.d_ld) &&
                             ((reinterpret_cast<uintptr_t>(desc->emb) & 7) == 0) && ((reinterpret_cast<uintptr_t>(desc->rel) & 7) == 0) &&
                             ((reinterpret_cast<uintptr_t>(desc->inv_rel) & 7) == 0) && !(pv && pv[0] == '1');
+        int64_t prep_rows = D.Bp;
+        if (vec_ok && L->flash) {  // the adj records and the dadj zero fill ride along (lp_flash.hip)
+            pa.fKP = (D.d + 15) / 16 * 16;
+            pa.fXR = (D.Bc + 31) / 32 * 32;
+            pa.frec = ws + L->adjrec;
+            pa.fdadj = (float*)(ws + L->dadj[0]);
+            prep_rows += (int64_t)D.ndir * D.C * (pa.fXR - D.Bc);  // one half-wave per chunk-padding record
+            flash_fused_prep = true;
+        }
         if (vec_ok)
-            lp_prep2_kernel<<<dim3((unsigned)cdiv(D.Bp, 8)), dim3(256), 0, st>>>(pa);
+            lp_prep2_kernel<<<dim3((unsigned)cdiv(prep_rows, 8)), dim3(256), 0, st>>>(pa);
         else
             lp_prep_kernel<<<dim3((unsigned)cdiv(D.Bp * D.ndir, 4)), dim3(256), 0, st>>>(pa);
     }
@@ -1183,7 +1268,10 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     if (L->flash) {  // training-only path: operand records + SoftmaxCE row statistics, no score tensor (lp_flash.hip)
         MARIUS_REQUIRE(kernel_level() == 2 && flash_applicable(desc, D), "lp_forward: the layout was planned for the flash path but the descriptor / environment no longer selects it");
         float* S = (flash_store_scores(desc) && L->neg[0]) ? (float*)(ws + L->neg[0]) : nullptr;
-        return flash_forward(desc, D, pa.adj, ws + L->adjrec, ws + L->negrec, (float2*)(ws + L->fpart), S, st);
+        const int64_t CNf = (int64_t)D.C * D.N;
+        const int64_t occ_off[2] = {2 * D.B + (desc->src_neg ? CNf : 0), 2 * D.B};  // gocc rows of the dst / src negatives (map_tensors order)
+        return flash_forward(desc, D, pa.adj, ws + L->adjrec, ws + L->negrec, (float2*)(ws + L->fpart), S, flash_fused_prep, (float*)(ws + L->gocc), occ_off,
+                             flash_fused_prep ? nullptr : (float*)(ws + L->dadj[0]), st);
     }
 
     ScoreArgs sa;
@@ -1344,7 +1432,7 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
         const bool split = sp && sp[0] == '1';
         bool done = false;
         if (L->flash) {
-            rc = flash_backward(D, ws + L->adjrec, ws + L->negrec, ga.dadj, ga.gocc, ga.negocc_off, has_src_neg, st);
+            rc = flash_backward(D, ws + L->adjrec, ws + L->negrec, ga.dadj, ga.gocc, ga.negocc_off, st);
             if (rc) return rc;
             done = true;
         }

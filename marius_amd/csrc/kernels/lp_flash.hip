@@ -80,6 +80,15 @@ struct FlashArgs {
     int64_t negocc_off[2];
 };
 
+// zero up to three float ranges (lengths are multiples of 4, bases 16-B aligned) in one launch
+__global__ __launch_bounds__(256) void flash_zero_kernel(float* a, int64_t na, float* b, int64_t nb, float* c, int64_t nc) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < na; i += stride) *reinterpret_cast<float4*>(a + i) = z;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < nb; i += stride) *reinterpret_cast<float4*>(b + i) = z;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < nc; i += stride) *reinterpret_cast<float4*>(c + i) = z;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- pack kernels
 // fp32 row -> record.  One thread per 4 consecutive elements (8 B of hi, 8 B of lo); threads past d write the zero K padding.
 __device__ __forceinline__ void fl_write_piece(char* rec, int KP, int piece, float4 v) {
@@ -130,7 +139,8 @@ __global__ __launch_bounds__(256) void flash_pack_adj_kernel(const float* __rest
 // negatives: record (dir, c, j) = emb[negmap[dir][c N + j]]; rows N .. NR are zero
 __global__ __launch_bounds__(256) void flash_pack_neg_kernel(const float* __restrict__ emb, int64_t emb_ld, const int64_t* __restrict__ neg0,
                                                              const int64_t* __restrict__ neg1, int N, int C, int ndir, int d, int KP, int NR,
-                                                             int vec, char* __restrict__ rec) {
+                                                             int vec, char* __restrict__ rec, float* __restrict__ gocc, int64_t d_ld, int64_t off0,
+                                                             int64_t off1) {
     const int ppr = KP / 4 + 1;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nrec = (int64_t)ndir * C * NR;
@@ -146,10 +156,14 @@ __global__ __launch_bounds__(256) void flash_pack_neg_kernel(const float* __rest
         return;
     }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < N && 4 * piece < d) {
+    if (j < N) {
         const int64_t dir = cd / C, c = cd - dir * C;
-        const int64_t id = (dir ? neg1 : neg0)[c * N + j];
-        v = load_row4(emb + id * emb_ld, 4 * piece, d, vec);
+        if (4 * piece < d) {
+            const int64_t id = (dir ? neg1 : neg0)[c * N + j];
+            v = load_row4(emb + id * emb_ld, 4 * piece, d, vec);
+        }
+        // the negative's gradient row is accumulated by at most two workgroups of the backward: it starts from zero
+        if (4 * piece < d_ld) *reinterpret_cast<float4*>(gocc + ((dir ? off1 : off0) + c * N + j) * d_ld + 4 * piece) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     fl_write_piece(o, KP, piece, v);
 }
@@ -474,15 +488,6 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(const float2* __restri
     if (threadIdx.x == 0) blocksum[blockIdx.x] = red[0];
 }
 
-// zero up to three float ranges (lengths are multiples of 4, bases 16-B aligned) in one launch
-__global__ __launch_bounds__(256) void flash_zero_kernel(float* a, int64_t na, float* b, int64_t nb, float* c, int64_t nc) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < na; i += stride) *reinterpret_cast<float4*>(a + i) = z;
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < nb; i += stride) *reinterpret_cast<float4*>(b + i) = z;
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < nc; i += stride) *reinterpret_cast<float4*>(c + i) = z;
-}
-
 // ---------------------------------------------------------------------------------------------------------------- host side
 static int fl_ks(int d) { return (d + 15) / 16; }
 
@@ -566,18 +571,21 @@ static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, cha
 }
 
 // forward: pack both operands, row statistics (and, for parity tests only, the scores themselves)
-int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj, char* adjrec, char* negrec, float2* part, float* S, hipStream_t st) {
+int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj, char* adjrec, char* negrec, float2* part, float* S, bool adj_packed,
+                  float* gocc, const int64_t negocc_off[2], float* dadj_zero, hipStream_t st) {
     const int ks = fl_ks(D.d), KP = 16 * ks;
     const int XR = (D.Bc + 31) / 32 * 32, NR = (D.N + 31) / 32 * 32;
     const int ppr = KP / 4 + 1;
-    {
+    if (!adj_packed) {
         const int64_t n = (int64_t)D.ndir * D.C * XR * ppr;
         flash_pack_adj_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(adj, D.d_ld, D.Bp, D.Bc, D.C, D.ndir, D.d, KP, XR, adjrec);
+        if (dadj_zero) flash_zero_kernel<<<dim3(1024), dim3(256), 0, st>>>(dadj_zero, D.ndir * D.Bp * D.d_ld, nullptr, 0, nullptr, 0);
     }
     {
         const int64_t n = (int64_t)D.ndir * D.C * NR * ppr;
         flash_pack_neg_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(desc->emb, desc->emb_ld, desc->dst_neg, desc->src_neg, D.N, D.C, D.ndir,
-                                                                                 D.d, KP, NR, row_vec_width(desc->emb, desc->emb_ld, 4), negrec);
+                                                                                 D.d, KP, NR, row_vec_width(desc->emb, desc->emb_ld, 4), negrec, gocc,
+                                                                                 D.d_ld, negocc_off[0], negocc_off[1]);
     }
     int rc = check_launch("flash_pack");
     if (rc) return rc;
@@ -599,17 +607,9 @@ int flash_merge(const LpDims& D, const float2* part, const float* pos, float* ls
 }
 
 // backward contractions: dadj [ndir][Bp][d_ld] and the negatives' gocc rows.  Both outputs are zeroed first (split tiles accumulate).
-int flash_backward(const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2], bool has_src_neg, hipStream_t st) {
+// dadj and the negatives' gocc rows were zeroed by the forward's pack kernels (split tiles accumulate onto them)
+int flash_backward(const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2], hipStream_t st) {
     const int ks = fl_ks(D.d);
-    const int64_t CN = (int64_t)D.C * D.N;
-    {
-        const int64_t n0 = D.ndir * D.Bp * D.d_ld, n1 = CN * D.d_ld;
-        flash_zero_kernel<<<dim3(1024), dim3(256), 0, st>>>(dadj, n0, gocc + negocc_off[0] * D.d_ld, n1, D.ndir == 2 ? gocc + negocc_off[1] * D.d_ld : nullptr,
-                                                           D.ndir == 2 ? n1 : 0);
-        int rc0 = check_launch("flash_zero");
-        if (rc0) return rc0;
-    }
-    (void)has_src_neg;
     FlashArgs a;
     fl_common(a, D, FLASH_DADJ, adjrec, negrec);
     a.out = dadj;

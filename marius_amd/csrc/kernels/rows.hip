@@ -36,9 +36,13 @@ template <int VEC, int NT, int GATHER_UNROLL>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ ta, const float* __restrict__ tb,
                                                           int64_t table_ld, const int64_t* __restrict__ ids, int64_t n,
                                                           int vpr, float* __restrict__ oa, float* __restrict__ ob,
-                                                          int64_t out_ld) {
+                                                          int64_t out_ld, const int64_t* __restrict__ n_dev) {
     using V = typename VecT<VEC>::type;
     const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
+    if (n_dev) {  // capacity-sized id list: only the first *n_dev entries are rows (the tail is padding)
+        const int64_t nd = *n_dev;
+        n = nd < n ? nd : n;
+    }
     int64_t rows[GATHER_UNROLL];
     int64_t src[GATHER_UNROLL];
 #pragma unroll
@@ -173,7 +177,7 @@ static void row_geometry(int vpr, dim3& block, int& rows_per_block, int unroll =
 
 template <int NT>
 static int launch_gather(const float* ta, const float* tb, int64_t table_ld, const int64_t* ids, int64_t n, int d,
-                         float* oa, float* ob, int64_t out_ld, hipStream_t st) {
+                         float* oa, float* ob, int64_t out_ld, hipStream_t st, const int64_t* n_dev = nullptr) {
     if (n == 0) return MARIUS_OK;
     int vec = row_vec_width(ta, table_ld, d);
     int v2 = row_vec_width(oa, out_ld, d);
@@ -191,13 +195,13 @@ static int launch_gather(const float* ta, const float* tb, int64_t table_ld, con
     dim3 grid((unsigned)cdiv(n, rpb));
     ProfScope ps(PROF_GATHER, st);
     if (vec == 4 && gu == 2)
-        gather_rows_kernel<4, NT, 2><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld);
+        gather_rows_kernel<4, NT, 2><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld, n_dev);
     else if (vec == 4)
-        gather_rows_kernel<4, NT, 4><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld);
+        gather_rows_kernel<4, NT, 4><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld, n_dev);
     else if (vec == 2)
-        gather_rows_kernel<2, NT, 4><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld);
+        gather_rows_kernel<2, NT, 4><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld, n_dev);
     else
-        gather_rows_kernel<1, NT, 4><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld);
+        gather_rows_kernel<1, NT, 4><<<grid, block, 0, st>>>(ta, tb, table_ld, ids, n, vpr, oa, ob, out_ld, n_dev);
     return check_launch("gather_rows");
 }
 
@@ -210,6 +214,13 @@ extern "C" int marius_gather_rows(const float* table, int64_t table_ld, const in
     MARIUS_REQUIRE(n >= 0 && d > 0 && table_ld >= d && out_ld >= d, "gather_rows: bad sizes n=%ld d=%d", (long)n, d);
     MARIUS_REQUIRE(n == 0 || (table && ids && out), "gather_rows: null pointer");
     return launch_gather<1>(table, nullptr, table_ld, ids, n, d, out, nullptr, out_ld, as_stream(stream));
+}
+
+extern "C" int marius_gather_rows_counted(const float* table, int64_t table_ld, const int64_t* ids, int64_t capacity, const int64_t* num_rows_dev,
+                                          int32_t d, float* out, int64_t out_ld, marius_stream_t stream) {
+    MARIUS_REQUIRE(capacity >= 0 && d > 0 && table_ld >= d && out_ld >= d, "gather_rows_counted: bad sizes n=%ld d=%d", (long)capacity, d);
+    MARIUS_REQUIRE(capacity == 0 || (table && ids && out && num_rows_dev), "gather_rows_counted: null pointer");
+    return launch_gather<1>(table, nullptr, table_ld, ids, capacity, d, out, nullptr, out_ld, as_stream(stream), num_rows_dev);
 }
 
 extern "C" int marius_gather_rows2(const float* table_a, const float* table_b, int64_t table_ld, const int64_t* ids,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "marius_hip_abi_version": (C.c_int, []),
     "marius_hip_last_error": (C.c_char_p, []),
     "marius_gather_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "marius_gather_rows_counted": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
     "marius_gather_rows2": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp]),
     "marius_scatter_add_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
     "marius_adagrad_rule": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp]),
@@ -141,6 +142,14 @@ def gather_rows(table, ids, out=None):
     if out is None:
         out = torch.empty((n, d), dtype=torch.float32, device=table.device)
     check(lib().marius_gather_rows(ptr(table), table.stride(0), ptr(ids), n, d, ptr(out), out.stride(0), stream_ptr()), "gather_rows")
+    return out
+
+
+def gather_rows_counted(table, ids, count_dev, out):
+    """capacity-sized id list, valid length on the device: rows past the count are not touched"""
+    _dev(table)
+    check(lib().marius_gather_rows_counted(ptr(table), table.stride(0), ptr(ids), ids.numel(), ptr(count_dev), table.size(1), ptr(out), out.stride(0),
+                                           stream_ptr()), "gather_rows_counted")
     return out
 
 
