@@ -33,7 +33,9 @@ DEFAULTS = {
     "training": {
         "batch_size": 1000,
         "negative_sampling": {"num_chunks": 1, "negatives_per_positive": 1000, "degree_fraction": 0.0, "filtered": False, "local_filter_mode": "DEG"},
-        "num_epochs": 10, "pipeline": {"sync": True}, "epochs_per_shuffle": 1, "logs_per_epoch": 10,
+        "num_epochs": 10, "epochs_per_shuffle": 1, "logs_per_epoch": 10,
+        # marius_config.py:664-682 (PipelineConfig): only sync / staleness_bound / gpu_sync_interval / gpu_model_average have a meaning on this path
+        "pipeline": {"sync": True, "staleness_bound": 16, "gpu_sync_interval": 16, "gpu_model_average": True},
         # marius_config.py:649-652, 734-735
         "save_model": True, "checkpoint": {"save_best": False, "interval": -1, "save_state": False}, "resume_training": False, "resume_from_checkpoint": "",
     },
@@ -60,8 +62,31 @@ def _merge(base, over, path=""):
     return out
 
 
-def load_config(path):
-    """Returns the full configuration dict (defaults merged, dataset stats filled in)."""
+def get_model_dir_path(dataset_dir):
+    """marius_config.py:47-56: the first free <dataset_dir>/model_<i>, i in 0..10; beyond that model_10 is overwritten."""
+    p = None
+    for i in range(11):
+        p = os.path.join(dataset_dir, "model_%d" % i)
+        if not os.path.exists(p):
+            return p
+    return p
+
+
+def infer_model_dir(cfg, auto):
+    """marius_config.py:875-896: a run that does not create a model directory (marius_eval, marius_predict, resume_training without
+    resume_from_checkpoint) uses model_dir as given when it already holds model.pt, else — for the automatic model_<i> name — the
+    latest existing model_<i-1>."""
+    mdir = cfg["storage"]["model_dir"]
+    if os.path.isdir(mdir) and os.path.exists(os.path.join(mdir, "model.pt")):
+        return
+    base = os.path.basename(os.path.normpath(mdir))
+    if auto and base.startswith("model_") and base[6:].isdigit() and int(base[6:]) >= 1:
+        cfg["storage"]["model_dir"] = os.path.join(os.path.dirname(os.path.normpath(mdir)), "model_%d" % (int(base[6:]) - 1))
+
+
+def load_config(path, train=True):
+    """Returns the full configuration dict (defaults merged, dataset stats filled in).  train=False: the caller evaluates (marius_eval):
+    the model directory is looked up, never created (marius_config.py:920-940)."""
     with open(path) as f:
         user = yaml.safe_load(f)
     cfg = _merge(DEFAULTS, user)
@@ -108,13 +133,16 @@ def load_config(path):
         emb["options"] = o
     elif emb["type"] not in ("DEVICE_MEMORY", "HOST_MEMORY"):
         raise NotImplementedError("storage.embeddings.type %s" % emb["type"])
-    if not cfg["training"]["pipeline"].get("sync", True):
-        warnings.warn("async pipeline is out of scope; running the synchronous trainer")
-    if cfg["storage"]["model_dir"] is None:
-        i = 0
-        while os.path.exists(os.path.join(ddir, "model_%d" % i)):
-            i += 1
-        cfg["storage"]["model_dir"] = os.path.join(ddir, "model_%d" % i)
+    if int(cfg["training"]["pipeline"].get("staleness_bound", 16)) < 1:
+        raise ValueError("training.pipeline.staleness_bound must be at least 1")
+    auto = cfg["storage"]["model_dir"] is None
+    if auto:
+        cfg["storage"]["model_dir"] = get_model_dir_path(ddir)
+    tr = cfg["training"]
+    creates = train and (bool(tr.get("resume_from_checkpoint")) or not tr.get("resume_training", False))  # marius_config.py:923-929
+    cfg["_creates_model_dir"] = creates
+    if not creates:
+        infer_model_dir(cfg, auto)
     return cfg
 
 

@@ -53,6 +53,7 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("write", &InMemory::write)
         .def("unload", &InMemory::unload, py::arg("perform_write") = false)
         .def("shuffle", &InMemory::shuffle)
+        .def("setGenerator", &InMemory::setGenerator, py::arg("generator"))
         .def("sort", &InMemory::sort, py::arg("src"));
 
     py::enum_<EdgeBucketOrdering>(m, "EdgeBucketOrdering")
@@ -167,12 +168,28 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("accumulateGradients", &Batch::accumulateGradients, py::arg("learning_rate"))
         .def("clear", &Batch::clear);
 
-    py::class_<RelationOperator, std::shared_ptr<RelationOperator>>(m, "RelationOperator")
+    // Python subclasses plug in exactly like C++ ones: override __call__ (test_nn.py-style user code); kind() stays -1, so a model that
+    // holds one trains through the generic autograd path
+    struct PyRelationOperator : RelationOperator {
+        using RelationOperator::RelationOperator;
+        torch::Tensor operator()(const torch::Tensor& e, const torch::Tensor& r) override {
+            PYBIND11_OVERRIDE_PURE_NAME(torch::Tensor, RelationOperator, "__call__", operator(), e, r);
+        }
+    };
+    struct PyComparator : Comparator {
+        using Comparator::Comparator;
+        torch::Tensor operator()(torch::Tensor s, torch::Tensor d) override { PYBIND11_OVERRIDE_PURE_NAME(torch::Tensor, Comparator, "__call__", operator(), s, d); }
+    };
+    py::class_<RelationOperator, PyRelationOperator, std::shared_ptr<RelationOperator>>(m, "RelationOperator")
+        .def(py::init<>())
         .def("__call__", [](RelationOperator& op, torch::Tensor e, torch::Tensor r) { return op(e, r); });
     py::class_<HadamardOperator, RelationOperator, std::shared_ptr<HadamardOperator>>(m, "HadamardOperator").def(py::init<>());
     py::class_<ComplexHadamardOperator, RelationOperator, std::shared_ptr<ComplexHadamardOperator>>(m, "ComplexHadamardOperator").def(py::init<>());
     py::class_<TranslationOperator, RelationOperator, std::shared_ptr<TranslationOperator>>(m, "TranslationOperator").def(py::init<>());
-    py::class_<Comparator, std::shared_ptr<Comparator>>(m, "Comparator").def("__call__", [](Comparator& c, torch::Tensor s, torch::Tensor d) { return c(s, d); });
+    py::class_<Comparator, PyComparator, std::shared_ptr<Comparator>>(m, "Comparator")
+        .def(py::init<>())
+        .def("__call__", [](Comparator& c, torch::Tensor s, torch::Tensor d) { return c(s, d); });
+    m.def("pad_and_reshape", &pad_and_reshape, py::arg("input"), py::arg("num_chunks"));
     py::class_<DotCompare, Comparator, std::shared_ptr<DotCompare>>(m, "DotCompare").def(py::init<>());
     py::class_<L2Compare, Comparator, std::shared_ptr<L2Compare>>(m, "L2Compare").def(py::init<>());
     py::class_<CosineCompare, Comparator, std::shared_ptr<CosineCompare>>(m, "CosineCompare").def(py::init<>());
@@ -245,10 +262,50 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("clear", &LinkPredictionReporter::clear)
         .def("report", &LinkPredictionReporter::report);
 
-    py::class_<Model, std::shared_ptr<Model>>(m, "Model")
+    // model_wrap.cpp:10-13 + a real trampoline: a Python subclass that overrides forward_lp is called by train_batch / evaluate_batch
+    struct PyModel : Model {
+        using Model::Model;
+        std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> forward_lp(std::shared_ptr<Batch> batch, bool train) override {
+            using Ret = std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>;
+            PYBIND11_OVERRIDE(Ret, Model, forward_lp, batch, train);
+        }
+        bool custom_forward() const override {
+            py::gil_scoped_acquire gil;
+            return static_cast<bool>(py::get_override(static_cast<const Model*>(this), "forward_lp"));
+        }
+    };
+    py::class_<ModelConfig>(m, "ModelConfig")
+        .def(py::init<>())
+        .def_readwrite("decoder", &ModelConfig::decoder)
+        .def_readwrite("embedding_dim", &ModelConfig::embedding_dim)
+        .def_readwrite("inverse_edges", &ModelConfig::inverse_edges)
+        .def_readwrite("decoder_method", &ModelConfig::decoder_method)
+        .def_readwrite("loss", &ModelConfig::loss)
+        .def_readwrite("loss_reduction", &ModelConfig::loss_reduction)
+        .def_readwrite("margin", &ModelConfig::margin)
+        .def_readwrite("dense_optimizer", &ModelConfig::dense_optimizer)
+        .def_readwrite("dense_lr", &ModelConfig::dense_lr)
+        .def_readwrite("eps", &ModelConfig::eps)
+        .def_readwrite("beta_1", &ModelConfig::beta_1)
+        .def_readwrite("beta_2", &ModelConfig::beta_2)
+        .def_readwrite("weight_decay", &ModelConfig::weight_decay)
+        .def_readwrite("amsgrad", &ModelConfig::amsgrad)
+        .def_readwrite("sparse_lr", &ModelConfig::sparse_lr);
+    m.def("initModelFromConfig", &initModelFromConfig, py::arg("model_config"), py::arg("devices"), py::arg("num_relations"), py::arg("train"));
+    py::class_<Model, PyModel, std::shared_ptr<Model>>(m, "Model", py::dynamic_attr())
         .def(py::init<std::shared_ptr<EdgeDecoder>, std::shared_ptr<LossFunction>, std::shared_ptr<LinkPredictionReporter>, torch::Device>(),
              py::arg("decoder"), py::arg("loss"), py::arg("reporter"), py::arg("device"))
-        .def("forward_lp", &Model::forward_lp, py::arg("batch"), py::arg("train") = true)
+        .def("forward_lp", [](Model& self, std::shared_ptr<Batch> b, bool train) { return self.Model::forward_lp(b, train); }, py::arg("batch"),
+             py::arg("train") = true)
+        .def("fused_ok", &Model::fused_ok)
+        .def("broadcast", &Model::broadcast, py::arg("devices"))
+        .def("all_reduce", &Model::all_reduce)
+        .def("set_process_group", &Model::set_process_group, py::arg("group_name"))
+        .def("named_parameters", [](Model& self) {
+            py::dict d;
+            for (auto& kv : self.named_parameters()) d[py::str(kv.key())] = kv.value();
+            return d;
+        })
         .def("train_batch", &Model::train_batch, py::arg("batch"), py::arg("call_step") = true)
         .def("evaluate_batch", &Model::evaluate_batch)
         .def("save", &Model::save, py::arg("directory"))
@@ -293,6 +350,14 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_readwrite("fused_update", &SynchronousTrainer::fused_update_)
         .def_readonly("last_epoch_seconds", &SynchronousTrainer::last_epoch_seconds_)
         .def_readonly("last_edges_per_second", &SynchronousTrainer::last_edges_per_second_);
+    py::class_<PipelineTrainer, std::shared_ptr<PipelineTrainer>>(m, "PipelineTrainer")
+        .def(py::init<std::shared_ptr<DataLoader>, std::shared_ptr<Model>, int, bool>(), py::arg("dataloader"), py::arg("model"),
+             py::arg("staleness_bound") = 16, py::arg("stale_parameters") = false)
+        .def("train", &PipelineTrainer::train, py::arg("num_epochs") = 1, py::call_guard<py::gil_scoped_release>())
+        .def_readonly("staleness_bound", &PipelineTrainer::staleness_bound_)
+        .def_readonly("stale_parameters", &PipelineTrainer::stale_parameters_)
+        .def_readonly("last_epoch_seconds", &PipelineTrainer::last_epoch_seconds_)
+        .def_readonly("last_edges_per_second", &PipelineTrainer::last_edges_per_second_);
     py::class_<ShardedTrainer, std::shared_ptr<ShardedTrainer>>(m, "ShardedTrainer")
         .def(py::init<std::shared_ptr<DataLoader>, std::shared_ptr<Model>, torch::Tensor, torch::Tensor, int, int, int64_t, std::string, std::string, int, int>(),
              py::arg("dataloader"), py::arg("model"), py::arg("shard_table"), py::arg("shard_state"), py::arg("rank"), py::arg("world"), py::arg("num_nodes"),

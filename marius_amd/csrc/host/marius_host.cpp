@@ -9,6 +9,8 @@
 #include "partition_buffer.h"
 
 #include <c10/hip/HIPStream.h>
+#include <torch/csrc/distributed/c10d/GroupRegistry.hpp>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 #include <c10/hip/HIPFunctions.h>
 #include <hip/hip_runtime_api.h>
 
@@ -182,12 +184,12 @@ Tensor MariusGenerator::raw_words(int64_t n, torch::Device dev) {
         if (!pools_[cur_].filled) fill_pool(cur_, dev);
         fill_pool(old, dev);  // becomes the pool after the one now current
     };
+    // A pool that the previous request exhausted exactly is handed back only NOW: its `done` event must follow the kernel that reads
+    // the view returned last time in stream order, and that kernel is enqueued by the caller after raw_words returns (recording the
+    // event right away let the producer overwrite the tail of the buffer under the consumer).
+    if (pools_[cur_].filled && pools_[cur_].used == pools_[cur_].size) advance();
     Pool& p = pools_[cur_];
-    if (p.size - p.used >= n) {
-        Tensor v = take(n);
-        if (p.used == p.size) advance();
-        return v;
-    }
+    if (p.size - p.used >= n) return take(n);
     // request straddles two pools
     const int64_t first = p.size - p.used;
     Tensor a = first > 0 ? take(first).clone() : Tensor();
@@ -281,13 +283,19 @@ static void permute_rows(Tensor& data, const std::vector<int64_t>& buckets, cons
         start += n;
     }
 }
-void InMemory::shuffle() {
+void InMemory::shuffle() {  // storage.cpp:709-737: randperm per edge bucket
     if (!loaded_) load();
-    permute_rows(data_, edge_bucket_sizes_, [](const Tensor& b) { return torch::randperm(b.size(0), torch::TensorOptions().dtype(torch::kInt64).device(b.device())); });
+    // the reference draws from the one global generator its whole run uses; here that stream is the MariusGenerator handed to
+    // setGenerator (host randperm, same MT19937 sequence as torch::randperm on the CPU); without one, torch's device generator
+    auto gen = generator_;
+    permute_rows(data_, edge_bucket_sizes_, [gen](const Tensor& b) {
+        if (gen) return gen->randperm(b.size(0)).to(b.device());
+        return torch::randperm(b.size(0), torch::TensorOptions().dtype(torch::kInt64).device(b.device()));
+    });
 }
-void InMemory::sort(bool src) {
+void InMemory::sort(bool src) {  // storage.cpp:739-766: stable, so equal keys keep their file order (reproducible bucket contents)
     if (!loaded_) load();
-    permute_rows(data_, edge_bucket_sizes_, [src](const Tensor& b) { return torch::argsort(b.select(1, src ? 0 : -1)); });
+    permute_rows(data_, edge_bucket_sizes_, [src](const Tensor& b) { return torch::argsort(b.select(1, src ? 0 : -1), /*stable=*/true, /*dim=*/0, /*descending=*/false); });
 }
 Tensor InMemory::range(int64_t offset, int64_t n) {
     if (!data_.defined()) throw std::runtime_error("");
@@ -317,6 +325,9 @@ std::tuple<Tensor, Tensor> CorruptNodeNegativeSampler::getNegatives(shared_ptr<M
         Tensor ids = torch::arange(num_nodes, i64(dev)).unsqueeze(0);
         return std::forward_as_tuple(ids, compute_filter_corruption_global(graph, edges, inverse));
     }
+    // negative.cpp:198-200, 295-301: on device edges only the DEG local filter exists; every other local mode ends in this exception
+    if (local_filter_mode_ != LocalFilterMode::DEG)
+        throw MariusRuntimeException("Local filtering against all edges in the batch not yet supported on GPU.");
     const int n_deg = (int)(num_negatives_ * degree_fraction_);
     const int64_t B = edges.size(0);
     const int64_t words = marius_negatives_raw_words(num_nodes, B, num_chunks_, num_negatives_, n_deg);
@@ -481,22 +492,26 @@ std::tuple<Tensor, Tensor> only_pos_forward(shared_ptr<EdgeDecoder> decoder, Ten
     return std::forward_as_tuple(pos, inv);
 }
 
-// API-level operator calls (not on the fused training path): expressed through the same fused forward so that they, too, run on
-// the HIP kernels only.
-Tensor RelationOperator::operator()(const Tensor& embs, const Tensor& rels) {
+// API-level operator calls (not on the fused training path).  Plain tensors: expressed through the same fused forward so that they,
+// too, run on the HIP kernels only.  Tensors that require grad (the generic path taken when a user plug-in is part of the model): the
+// reference's own libtorch expressions, so that autograd sees them.
+static Tensor relop_device(int kind, const Tensor& embs, const Tensor& rels) {
     if (!rels.defined()) return embs;
     require_device(embs, "RelationOperator");
     const int64_t B = embs.size(0);
     auto dev = embs.device();
     struct D : EdgeDecoder { void reset() override {} };
     auto dec = std::make_shared<D>();
-    dec->relation_operator_ = nullptr;
     dec->comparator_ = std::make_shared<DotCompare>();
     dec->relations_ = rels.contiguous();
     dec->use_inverse_relations_ = false;
-    struct Op : RelationOperator { int k; int kind() const override { return k; } };
+    struct Op : RelationOperator {
+        int k;
+        int kind() const override { return k; }
+        Tensor operator()(const Tensor& e, const Tensor&) override { return e; }
+    };
     auto op = std::make_shared<Op>();
-    op->k = kind();
+    op->k = kind;
     dec->relation_operator_ = op;
     Tensor idx = torch::arange(B, i64(dev));
     Tensor edges = torch::stack({idx, idx, idx}, 1);
@@ -505,17 +520,51 @@ Tensor RelationOperator::operator()(const Tensor& embs, const Tensor& rels) {
     node_corrupt_forward(dec, edges, embs.contiguous(), dummy, Tensor(), &ctx);
     return ctx.view(ctx.layout.adj[0], {B, embs.size(1)}, {ctx.layout.d_ld, 1}).clone();
 }
+static bool wants_grad(const Tensor& a, const Tensor& b) {
+    return torch::GradMode::is_enabled() && ((a.defined() && a.requires_grad()) || (b.defined() && b.requires_grad()));
+}
+Tensor HadamardOperator::operator()(const Tensor& embs, const Tensor& rels) {  // relation_operators.cpp:7-12
+    if (!rels.defined()) return embs;
+    return wants_grad(embs, rels) ? embs * rels : relop_device(kind(), embs, rels);
+}
+Tensor ComplexHadamardOperator::operator()(const Tensor& embs, const Tensor& rels) {  // relation_operators.cpp:14-34
+    if (!rels.defined()) return embs;
+    if (!wants_grad(embs, rels)) return relop_device(kind(), embs, rels);
+    const int64_t h = embs.size(1) / 2;
+    Tensor re = embs.narrow(1, 0, h), im = embs.narrow(1, h, h), rre = rels.narrow(1, 0, h), rim = rels.narrow(1, h, h);
+    return torch::cat({re * rre - im * rim, re * rim + im * rre}, 1);
+}
+Tensor TranslationOperator::operator()(const Tensor& embs, const Tensor& rels) {  // relation_operators.cpp:36-41
+    if (!rels.defined()) return embs;
+    return wants_grad(embs, rels) ? embs + rels : relop_device(kind(), embs, rels);
+}
+Tensor NoOp::operator()(const Tensor& embs, const Tensor&) { return embs; }
 
-Tensor Comparator::operator()(Tensor src, Tensor dst) {
+Tensor pad_and_reshape(Tensor input, int num_chunks) {  // comparators.cpp:7-20
+    const int64_t num_pos = input.size(0);
+    const int64_t per = (int64_t)std::ceil((float)num_pos / num_chunks);
+    if (per * num_chunks != num_pos) {
+        const int64_t new_size = per * num_chunks;
+        Tensor pad = torch::zeros({new_size - num_pos, input.size(1)}, input.options());
+        input = torch::cat({input, pad}, 0);
+    }
+    return input.view({num_chunks, per, input.size(1)});
+}
+
+static Tensor compare_device(int kind, Tensor src, Tensor dst) {
     if (!src.defined() || !dst.defined()) throw UndefinedTensorException();  // comparators.cpp:23-25
     require_device(src, "Comparator");
     auto dev = src.device();
     struct D : EdgeDecoder { void reset() override {} };
     auto dec = std::make_shared<D>();
     dec->relation_operator_ = std::make_shared<NoOp>();
-    struct Cmp : Comparator { int k; int kind() const override { return k; } };
+    struct Cmp : Comparator {
+        int k;
+        int kind() const override { return k; }
+        Tensor operator()(Tensor, Tensor) override { return Tensor(); }
+    };
     auto cmp = std::make_shared<Cmp>();
-    cmp->k = kind();
+    cmp->k = kind;
     dec->comparator_ = cmp;
     dec->use_inverse_relations_ = false;
     const int64_t B = src.size(0);
@@ -533,6 +582,29 @@ Tensor Comparator::operator()(Tensor src, Tensor dst) {
     Tensor negs = (torch::arange(C * N, i64(dev)) + B).reshape({C, N});
     auto t = node_corrupt_forward(dec, edges, emb, negs, Tensor(), nullptr);
     return std::get<1>(t);
+}
+Tensor DotCompare::operator()(Tensor src, Tensor dst) {  // comparators.cpp:22-28
+    if (!src.defined() || !dst.defined()) throw UndefinedTensorException();
+    if (!wants_grad(src, dst)) return compare_device(kind(), src, dst);
+    if (src.sizes() == dst.sizes()) return (src * dst).sum(-1);
+    Tensor s = pad_and_reshape(src, (int)dst.size(0));
+    return s.bmm(dst.transpose(-1, -2)).flatten(0, 1);
+}
+Tensor L2Compare::operator()(Tensor src, Tensor dst) {  // comparators.cpp:30-41
+    if (!src.defined() || !dst.defined()) throw UndefinedTensorException();
+    if (!wants_grad(src, dst)) return compare_device(kind(), src, dst);
+    if (src.sizes() == dst.sizes()) return torch::pairwise_distance(src, dst);
+    Tensor s = pad_and_reshape(src, (int)dst.size(0));
+    Tensor x2 = s.pow(2).sum(2).unsqueeze(2), y2 = dst.pow(2).sum(2).unsqueeze(1);
+    Tensor xy = s.bmm(dst.transpose(1, 2));
+    return torch::clamp_min(x2 + y2 - 2 * xy, 1e-8).sqrt().flatten(0, 1);
+}
+Tensor CosineCompare::operator()(Tensor src, Tensor dst) {  // comparators.cpp:43-60 (scores the tensors as given)
+    if (!src.defined() || !dst.defined()) throw UndefinedTensorException();
+    if (!wants_grad(src, dst)) return compare_device(kind(), src, dst);
+    if (src.sizes() == dst.sizes()) return (src * dst).sum(-1);
+    Tensor s = pad_and_reshape(src, (int)dst.size(0));
+    return s.bmm(dst.transpose(-1, -2)).flatten(0, 1);
 }
 
 // ------------------------------------------------------------------------------------------------ edge decoders
@@ -596,6 +668,46 @@ shared_ptr<EdgeDecoder> get_edge_decoder(DecoderType type, EdgeDecoderMethod met
 }
 
 // ------------------------------------------------------------------------------------------------ loss / optimizers / reporter
+// loss.cpp:37-187 as differentiable libtorch expressions (generic path only: a user plug-in elsewhere in the model)
+static Tensor loss_autograd(int kind, float margin, LossReduction red, Tensor pos, Tensor neg) {
+    namespace F = torch::nn::functional;
+    const bool mean = red == LossReduction::MEAN;
+    auto reduce = [&](Tensor t) { return mean ? t.mean() : t.sum(); };
+    auto scores_labels = [&]() {  // scores_to_labels, loss.cpp:37-48
+        Tensor y = torch::cat({pos, neg.flatten(0, 1)});
+        Tensor l = torch::cat({torch::ones_like(pos), torch::zeros_like(neg.flatten(0, 1))});
+        return std::make_pair(y, l);
+    };
+    switch (kind) {
+        case MARIUS_LOSS_SOFTMAX_CE:
+        case MARIUS_LOSS_CROSS_ENTROPY: {
+            Tensor scores = torch::cat({pos.unsqueeze(1), neg.logsumexp(1, true)}, 1);
+            Tensor labels = torch::zeros({pos.size(0)}, torch::TensorOptions().dtype(torch::kInt64).device(pos.device()));
+            if (mean) return F::cross_entropy(scores, labels, F::CrossEntropyFuncOptions().reduction(torch::kMean));
+            return F::cross_entropy(scores, labels, F::CrossEntropyFuncOptions().reduction(torch::kSum));
+        }
+        case MARIUS_LOSS_RANKING:
+            return reduce(torch::relu(neg - pos.unsqueeze(1) + margin));
+        case MARIUS_LOSS_BCE_AFTER_SIGMOID: {
+            auto yl = scores_labels();
+            return reduce(F::binary_cross_entropy(yl.first.sigmoid(), yl.second, F::BinaryCrossEntropyFuncOptions().reduction(torch::kNone)));
+        }
+        case MARIUS_LOSS_BCE_WITH_LOGITS: {
+            auto yl = scores_labels();
+            return reduce(F::binary_cross_entropy_with_logits(yl.first, yl.second, F::BinaryCrossEntropyWithLogitsFuncOptions().reduction(torch::kNone)));
+        }
+        case MARIUS_LOSS_MSE: {
+            auto yl = scores_labels();
+            return reduce((yl.first - yl.second).pow(2));
+        }
+        case MARIUS_LOSS_SOFTPLUS: {
+            auto yl = scores_labels();
+            return reduce(F::softplus(-(2 * yl.second - 1) * yl.first));
+        }
+    }
+    throw MariusRuntimeException("LossFunction: a user-defined loss must override operator()");
+}
+
 Tensor LossFunction::operator()(Tensor pos, Tensor neg, bool scores) {
     if (!scores) {
         if (kind() == MARIUS_LOSS_SOFTMAX_CE)
@@ -609,6 +721,7 @@ Tensor LossFunction::operator()(Tensor pos, Tensor neg, bool scores) {
     if (pos.dim() != 1) throw TensorSizeMismatchException(pos, "Positive scores should be 1-dimensional");
     if (neg.dim() != 2) throw TensorSizeMismatchException(neg, "Negative scores should be 2-dimensional");
     if (pos.size(0) != neg.size(0)) throw TensorSizeMismatchException(pos, "First dimension of pos_scores and neg_scores should match.");
+    if (wants_grad(pos, neg)) return loss_autograd(kind(), margin(), reduction_type_, pos, neg);
     require_device(pos, name());
     require_device(neg, name());
     Tensor n = neg;
@@ -728,6 +841,11 @@ Model::Model(shared_ptr<EdgeDecoder> decoder, shared_ptr<LossFunction> loss, sha
     : decoder_(decoder), loss_function_(loss), reporter_(reporter), device_(device) {
     if (decoder_->relations_.defined()) relations_grad_ = torch::zeros_like(decoder_->relations_);
     if (decoder_->inverse_relations_.defined()) inverse_relations_grad_ = torch::zeros_like(decoder_->inverse_relations_);
+    // torch::nn::Module view of the dense parameters under the reference's names (distmult.cpp:21-27); requires_grad stays off: the
+    // fused path updates them in place through the C-ABI, the generic path differentiates detached aliases
+    if (decoder_->relations_.defined()) register_parameter("relation_embeddings", decoder_->relations_, /*requires_grad=*/false);
+    if (decoder_->inverse_relations_.defined()) register_parameter("inverse_relation_embeddings", decoder_->inverse_relations_, /*requires_grad=*/false);
+    devices_ = {device};
 }
 void Model::setup_optimizers(float dense_lr) {
     std::vector<std::pair<Tensor, Tensor>> params;
@@ -805,8 +923,62 @@ void Model::step() {
     for (auto& o : optimizers_) o->step();
 }
 
+// decoder_methods.cpp:57-114 through the decoder's virtual operators, as differentiable libtorch ops: the path a user-defined comparator
+// or relation operator takes (and what autograd differentiates when any plug-in is part of the model)
+static std::tuple<Tensor, Tensor, Tensor, Tensor> node_corrupt_forward_generic(shared_ptr<EdgeDecoder> dec, Tensor edges, Tensor emb, Tensor dst_negs,
+                                                                               Tensor src_negs, Tensor dst_filter, Tensor src_filter) {
+    if (edges.dim() != 2 || (edges.size(1) != 3 && edges.size(1) != 2)) throw TensorSizeMismatchException(edges, "Edge list must be a 3 or 2 column tensor");
+    const bool has_rel = edges.size(1) == 3;
+    Tensor src = emb.index_select(0, edges.select(1, 0)), dst = emb.index_select(0, edges.select(1, -1));
+    Tensor rels, inv_rels;
+    if (has_rel) {
+        Tensor rel_ids = edges.select(1, 1);
+        rels = dec->relations_.index_select(0, rel_ids);
+        if (dec->use_inverse_relations_ && dec->inverse_relations_.defined()) inv_rels = dec->inverse_relations_.index_select(0, rel_ids);
+    }
+    auto neg_rows = [&](const Tensor& ids) { return emb.index_select(0, ids.flatten()).reshape({ids.size(0), ids.size(1), emb.size(1)}); };
+    auto filt = [](Tensor scores, const Tensor& f) {  // apply_score_filter, negative.cpp:306-311
+        if (f.defined() && f.numel() > 0) scores = scores.index_put({f.select(1, 0), f.select(1, 1)}, torch::full({}, -1e9, scores.options()));
+        return scores;
+    };
+    Tensor adj_src = dec->apply_relation(src, rels);
+    Tensor pos = dec->compute_scores(adj_src, dst);
+    Tensor neg = filt(dec->compute_scores(adj_src, neg_rows(dst_negs)), dst_filter);
+    Tensor inv_pos, inv_neg;
+    if (inv_rels.defined() && src_negs.defined()) {
+        Tensor adj_dst = dec->apply_relation(dst, inv_rels);
+        inv_pos = dec->compute_scores(adj_dst, src);
+        inv_neg = filt(dec->compute_scores(adj_dst, neg_rows(src_negs)), src_filter);
+    }
+    if (pos.size(0) != neg.size(0)) {  // decoder_methods.cpp:103-111: pos padded to the chunked row count
+        namespace F = torch::nn::functional;
+        const int64_t extra = neg.size(0) - pos.size(0);
+        pos = F::pad(pos, F::PadFuncOptions({0, extra}));
+        if (inv_pos.defined()) inv_pos = F::pad(inv_pos, F::PadFuncOptions({0, extra}));
+    }
+    return std::forward_as_tuple(pos, neg, inv_pos, inv_neg);
+}
+
+bool Model::fused_ok() const {
+    return !custom_forward() && decoder_ && decoder_->comparator_ && decoder_->relation_operator_ && decoder_->comparator_->kind() >= 0 &&
+           decoder_->relation_operator_->kind() >= 0 && (!loss_function_ || loss_function_->kind() >= 0);
+}
+
+void Model::broadcast(std::vector<torch::Device> devices) {  // model.cpp:136-147
+    if (devices.size() > 1)
+        throw MariusRuntimeException(
+            "Model::broadcast: this build runs one process per GPU (torch.distributed over RCCL); replicas live in the other ranks — "
+            "register the process group with set_process_group() and use all_reduce()");
+    devices_ = devices;
+}
+
 std::tuple<Tensor, Tensor, Tensor, Tensor> Model::forward_lp(shared_ptr<Batch> batch, bool train) {
     (void)train;  // evaluation also calls forward_lp(batch, true) in the reference (model.cpp:337)
+    const bool builtin = decoder_->comparator_->kind() >= 0 && decoder_->relation_operator_->kind() >= 0;
+    if (decoder_->decoder_method_ == EdgeDecoderMethod::CORRUPT_NODE &&
+        (!builtin || (torch::GradMode::is_enabled() && batch->node_embeddings_.requires_grad())))
+        return node_corrupt_forward_generic(decoder_, batch->edges_, batch->node_embeddings_, batch->dst_neg_indices_mapping_, batch->src_neg_indices_mapping_,
+                                            batch->dst_neg_filter_, batch->src_neg_filter_);
     if (decoder_->decoder_method_ == EdgeDecoderMethod::ONLY_POS) {
         auto t = only_pos_forward(decoder_, batch->edges_, batch->node_embeddings_);
         return std::forward_as_tuple(std::get<0>(t), Tensor(), std::get<1>(t), Tensor());
@@ -907,7 +1079,79 @@ static bool relation_step_sparse(Model& m, shared_ptr<Batch> batch) {
     return true;
 }
 
+// model.cpp:290-333 as written there: forward through the (possibly overridden) forward_lp and loss, loss.backward(), dense step,
+// sparse Adagrad rule.  Taken when a user plug-in is part of the model; the built-in configuration never comes here.
+void Model::train_batch_generic(shared_ptr<Batch> batch, bool call_step) {
+    if (call_step) clear_grad();
+    Tensor emb_plain = batch->node_embeddings_, rel_plain = decoder_->relations_, inv_plain = decoder_->inverse_relations_;
+    Tensor emb = emb_plain.detach().requires_grad_(true);
+    Tensor rel = rel_plain.defined() ? rel_plain.detach().requires_grad_(true) : Tensor();
+    Tensor inv = inv_plain.defined() ? inv_plain.detach().requires_grad_(true) : Tensor();
+    batch->node_embeddings_ = emb;
+    decoder_->relations_ = rel;
+    decoder_->inverse_relations_ = inv;
+    Tensor loss;
+    try {
+        auto t = forward_lp(batch, true);
+        if (!loss_function_) throw MariusRuntimeException("Model::train_batch: no loss function");
+        loss = (*loss_function_)(std::get<0>(t), std::get<1>(t), true);
+        Tensor rhs = loss, lhs;
+        if (std::get<3>(t).defined()) {
+            lhs = (*loss_function_)(std::get<2>(t), std::get<3>(t), true);
+            loss = lhs + rhs;  // model.cpp:309-312
+        }
+        if (!loss.requires_grad()) throw MariusRuntimeException("Model::train_batch: the loss does not depend on the parameters (forward_lp must return differentiable scores)");
+        loss.backward();
+        loss_ = torch::stack({loss.detach(), rhs.detach(), lhs.defined() ? lhs.detach() : torch::zeros_like(rhs.detach()), torch::zeros_like(rhs.detach())});
+    } catch (...) {
+        batch->node_embeddings_ = emb_plain;
+        decoder_->relations_ = rel_plain;
+        decoder_->inverse_relations_ = inv_plain;
+        throw;
+    }
+    batch->node_embeddings_ = emb_plain;
+    decoder_->relations_ = rel_plain;
+    decoder_->inverse_relations_ = inv_plain;
+    if (rel.defined()) relations_grad_.copy_(rel.grad().defined() ? rel.grad() : torch::zeros_like(rel_plain));
+    if (inv.defined() && inverse_relations_grad_.defined()) inverse_relations_grad_.copy_(inv.grad().defined() ? inv.grad() : torch::zeros_like(inv_plain));
+    batch->node_embeddings_grad_ = emb.grad().defined() ? emb.grad() : torch::zeros_like(emb_plain);
+    if (call_step) step();
+    if (batch->node_embeddings_.defined()) batch->accumulateGradients(sparse_lr_);
+}
+
+void Model::all_reduce() {  // model.cpp:149-159: sum of the dense gradients over the replicas
+    if (process_group_.empty()) return;  // a single process holds the only replica
+    auto pg = c10d::resolve_process_group(process_group_);
+    std::vector<Tensor> grads;
+    if (relations_grad_.defined()) grads.push_back(relations_grad_);
+    if (inverse_relations_grad_.defined()) grads.push_back(inverse_relations_grad_);
+    for (auto& g : grads) {
+        std::vector<Tensor> v{g};
+        pg->allreduce(v)->wait();
+    }
+}
+
+shared_ptr<Model> initModelFromConfig(const ModelConfig& c, std::vector<torch::Device> devices, int num_relations, bool train) {  // model.cpp:361-440
+    if (devices.empty()) throw MariusRuntimeException("initModelFromConfig: no device");
+    auto dev = devices[0];
+    auto opts = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
+    DecoderType dt;
+    if (c.decoder == "DISTMULT") dt = DecoderType::DISTMULT;
+    else if (c.decoder == "COMPLEX") dt = DecoderType::COMPLEX;
+    else if (c.decoder == "TRANSE") dt = DecoderType::TRANSE;
+    else throw MariusRuntimeException("Decoder currently not supported.");
+    EdgeDecoderMethod m = c.decoder_method == "ONLY_POS" ? EdgeDecoderMethod::ONLY_POS : EdgeDecoderMethod::CORRUPT_NODE;
+    auto decoder = get_edge_decoder(dt, m, num_relations, c.embedding_dim, opts, c.inverse_edges);
+    auto loss = getLossFunction(c.loss, c.loss_reduction == "MEAN" ? LossReduction::MEAN : LossReduction::SUM, c.margin);
+    auto model = std::make_shared<Model>(decoder, loss, std::make_shared<LinkPredictionReporter>(), dev);
+    model->sparse_lr_ = c.sparse_lr;
+    if (train) model->setup_optimizer(c.dense_optimizer, c.dense_lr, c.eps, c.beta_1, c.beta_2, c.weight_decay, c.amsgrad);
+    model->broadcast({dev});
+    return model;
+}
+
 void Model::train_batch(shared_ptr<Batch> batch, bool call_step) {
+    if (!fused_ok()) return train_batch_generic(batch, call_step);
     if (call_step) clear_grad();
     forward_lp_train(batch);
     model_backward(*this, batch);
@@ -1353,6 +1597,7 @@ void DataLoader::updateEmbeddings(shared_ptr<Batch> batch, bool gpu) {
 
 // ------------------------------------------------------------------------------------------------ trainer / evaluator
 void SynchronousTrainer::train_one(bool fused) {
+    fused = fused && model_->fused_ok();  // user plug-ins train through the API-granular path (virtual calls + autograd)
     dataloader_->run_ahead_ = fused;
     dataloader_->num_relations_ = fused ? model_->decoder_->num_relations_ : 0;
     if (fused) {
@@ -1393,6 +1638,41 @@ void SynchronousTrainer::train_steps(int64_t n) {
             dataloader_->initializeBatches(true);
         }
         train_one(fused_update_);
+    }
+}
+
+void PipelineTrainer::train(int num_epochs) {
+    if (!stale_parameters_) {  // device-resident parameters: gathered by the compute stage, i.e. the synchronous result; the loader runs ahead
+        SynchronousTrainer t(dataloader_, model_);
+        t.train(num_epochs);
+        last_epoch_seconds_ = t.last_epoch_seconds_;
+        last_edges_per_second_ = t.last_edges_per_second_;
+        return;
+    }
+    for (int epoch = 0; epoch < num_epochs; ++epoch) {
+        dataloader_->loadStorage();
+        dataloader_->initializeBatches(true);
+        c10::hip::getCurrentHIPStream().synchronize();
+        auto t0 = std::chrono::steady_clock::now();
+        dataloader_->run_ahead_ = false;
+        dataloader_->num_relations_ = 0;
+        std::deque<shared_ptr<Batch>> in_flight;
+        while (dataloader_->hasNextBatch() || !in_flight.empty()) {
+            while ((int)in_flight.size() < staleness_bound_ && dataloader_->hasNextBatch()) {  // LoadBatchWorker: admit, prepare, read parameters
+                auto b = dataloader_->getBatch(true);
+                dataloader_->loadGPUParameters(b);
+                in_flight.push_back(b);
+            }
+            auto b = in_flight.front();  // ComputeWorker + UpdateBatchWorker
+            in_flight.pop_front();
+            model_->train_batch(b);
+            dataloader_->updateEmbeddings(b, true);
+            b->clear();
+        }
+        c10::hip::getCurrentHIPStream().synchronize();
+        dataloader_->nextEpoch();
+        last_epoch_seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        last_edges_per_second_ = (double)dataloader_->edges_->dim0_size_ / last_epoch_seconds_;
     }
 }
 

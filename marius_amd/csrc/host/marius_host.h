@@ -16,6 +16,7 @@
 // There is no CPU fallback: tensors handed to these classes must live on the MI355X.
 #pragma once
 #include <torch/torch.h>
+#include <typeinfo>
 
 #include <memory>
 #include <string>
@@ -116,6 +117,9 @@ class InMemory : public Storage {
     InMemory(std::string filename, int64_t dim0_size, int64_t dim1_size, torch::Dtype dtype, torch::Device device);
     InMemory(Tensor data);  // tensor constructor (storage.cpp:538-545)
     Tensor indexRead(Tensor indices) override;
+    shared_ptr<MariusGenerator> generator_;  // stream shuffle() draws from (the run's global generator); null: torch's device generator
+    void setGenerator(shared_ptr<MariusGenerator> g) { generator_ = g; }
+    Tensor indexReadCounted(Tensor indices, Tensor count_dev);  // capacity-sized ids, valid length on the device (fused step: no host sync)
     void indexAdd(Tensor indices, Tensor values) override;
     Tensor range(int64_t offset, int64_t n) override;
     void indexPut(Tensor indices, Tensor values) override;
@@ -193,26 +197,44 @@ class Batch {
 };
 
 // ------------------------------------------------------------------------------------------------ decoder pieces
+// The reference's plug-in points (relation_operators.h:11-15, comparators.h:13-17): a virtual call operator on tensors.  The built-in
+// subclasses additionally report a kind(): when every component of a model reports one, training runs the fused HIP path keyed on it;
+// a user subclass (kind() == -1, the default) makes the model take the generic path through these virtual calls and libtorch
+// autograd, exactly as the reference does (nn/model.cpp:290-333).  The built-ins themselves run on the device kernels for plain
+// tensors and as differentiable libtorch ops when an argument requires grad (so they compose with user code on the generic path).
 class RelationOperator {
    public:
     virtual ~RelationOperator() = default;
-    virtual int kind() const = 0;  // MARIUS_OP_*
-    Tensor operator()(const Tensor& embs, const Tensor& rels);  // undefined rels => identity (relation_operators.cpp)
+    virtual int kind() const { return -1; }  // MARIUS_OP_* for the built-ins
+    virtual Tensor operator()(const Tensor& embs, const Tensor& rels) = 0;  // undefined rels => identity (relation_operators.cpp)
 };
-struct HadamardOperator : RelationOperator { int kind() const override { return MARIUS_OP_HADAMARD; } };
-struct ComplexHadamardOperator : RelationOperator { int kind() const override { return MARIUS_OP_COMPLEX_HADAMARD; } };
-struct TranslationOperator : RelationOperator { int kind() const override { return MARIUS_OP_TRANSLATION; } };
-struct NoOp : RelationOperator { int kind() const override { return MARIUS_OP_NOOP; } };
+#define MARIUS_RELOP(NAME, KIND)                                                \
+    struct NAME : RelationOperator {                                            \
+        int kind() const override { return KIND; }                              \
+        Tensor operator()(const Tensor& embs, const Tensor& rels) override;     \
+    }
+MARIUS_RELOP(HadamardOperator, MARIUS_OP_HADAMARD);
+MARIUS_RELOP(ComplexHadamardOperator, MARIUS_OP_COMPLEX_HADAMARD);
+MARIUS_RELOP(TranslationOperator, MARIUS_OP_TRANSLATION);
+MARIUS_RELOP(NoOp, MARIUS_OP_NOOP);
+#undef MARIUS_RELOP
 
 class Comparator {
    public:
     virtual ~Comparator() = default;
-    virtual int kind() const = 0;  // MARIUS_CMP_*
-    Tensor operator()(Tensor src, Tensor dst);  // dst [B,d] -> [B]; dst [C,N,d] -> [C*ceil(B/C), N]  (comparators.cpp)
+    virtual int kind() const { return -1; }  // MARIUS_CMP_* for the built-ins
+    virtual Tensor operator()(Tensor src, Tensor dst) = 0;  // dst [B,d] -> [B]; dst [C,N,d] -> [C*ceil(B/C), N]  (comparators.cpp)
 };
-struct DotCompare : Comparator { int kind() const override { return MARIUS_CMP_DOT; } };
-struct L2Compare : Comparator { int kind() const override { return MARIUS_CMP_L2; } };
-struct CosineCompare : Comparator { int kind() const override { return MARIUS_CMP_COSINE; } };
+#define MARIUS_CMP(NAME, KIND)                                   \
+    struct NAME : Comparator {                                   \
+        int kind() const override { return KIND; }               \
+        Tensor operator()(Tensor src, Tensor dst) override;      \
+    }
+MARIUS_CMP(DotCompare, MARIUS_CMP_DOT);
+MARIUS_CMP(L2Compare, MARIUS_CMP_L2);
+MARIUS_CMP(CosineCompare, MARIUS_CMP_COSINE);
+#undef MARIUS_CMP
+Tensor pad_and_reshape(Tensor input, int num_chunks);  // comparators.cpp:7-20
 
 class EdgeDecoder {
    public:
@@ -276,10 +298,10 @@ class LossFunction {  // loss.h:21-31; every subclass of loss.h:33-107 evaluates
    public:
     virtual ~LossFunction() = default;
     LossReduction reduction_type_ = LossReduction::SUM;
-    virtual int kind() const = 0;  // MARIUS_LOSS_*
+    virtual int kind() const { return -1; }  // MARIUS_LOSS_* for the built-ins; -1: user-defined (generic autograd path)
     virtual float margin() const { return 0.f; }
     virtual bool scores_only() const { return false; }  // SoftmaxCE / Ranking throw for classification input (loss.cpp:51-55, 72-74)
-    virtual const char* name() const = 0;
+    virtual const char* name() const { return "LossFunction"; }
     // (pos [B'], neg [B', N], scores = true) -> scalar loss.  scores = false (classification logits + labels) is outside the link-prediction path.
     virtual Tensor operator()(Tensor y_pred, Tensor targets, bool scores);
 };
@@ -369,8 +391,34 @@ class LinkPredictionReporter {  // reporting.cpp:11-57
 };
 
 // ------------------------------------------------------------------------------------------------ model (model.h:16-65)
-class Model {
+// What initModelFromConfig needs of the reference's ModelConfig (configuration/config.h) for an embedding-only link-prediction model.
+struct ModelConfig {
+    std::string decoder = "DISTMULT";            // model.decoder.type
+    int embedding_dim = 50;                      // model.encoder ... output_dim of the embedding layer
+    bool inverse_edges = true;                   // model.decoder.options.inverse_edges
+    std::string decoder_method = "CORRUPT_NODE"; // model.decoder.options.edge_decoder_method
+    std::string loss = "SOFTMAX_CE";             // model.loss.type
+    std::string loss_reduction = "SUM";          // model.loss.options.reduction
+    float margin = 0.1f;                         // model.loss.options.margin
+    std::string dense_optimizer = "ADAGRAD";     // model.dense_optimizer.type
+    float dense_lr = 0.1f, eps = 1e-10f, beta_1 = 0.9f, beta_2 = 0.999f, weight_decay = 0.f;
+    bool amsgrad = false;
+    float sparse_lr = 0.1f;                      // model.sparse_optimizer.options.learning_rate
+};
+
+class Model : public torch::nn::Module {
    public:
+    // Multi-GPU (model.h:33): the reference keeps one replica per device inside one process.  This build runs one process per GPU
+    // (torch.distributed over RCCL), so a process only ever holds its own replica; broadcast() records the device list and all_reduce()
+    // sums the dense (relation) gradients over the ranks of the registered process group.
+    std::vector<torch::Device> devices_;
+    std::string process_group_;  // c10d group name (torch.distributed: group.group_name); empty = single process
+    void broadcast(std::vector<torch::Device> devices);  // model.cpp:136-147
+    void all_reduce();                                    // model.cpp:149-159
+    void set_process_group(const std::string& name) { process_group_ = name; }
+    // true when every component is a built-in (kind() >= 0) and forward_lp is not overridden: the fused HIP training path applies
+    bool fused_ok() const;
+    virtual bool custom_forward() const { return typeid(*this) != typeid(Model); }
     shared_ptr<EdgeDecoder> decoder_;
     shared_ptr<LossFunction> loss_function_;
     shared_ptr<LinkPredictionReporter> reporter_;
@@ -385,10 +433,10 @@ class Model {
     void* side_stream_ = nullptr;  // relation-table update runs here, underneath the node-table update (backward_into_tables)
     void* ev_fork_ = nullptr;
     void* ev_join_ = nullptr;
-    ~Model();
+    virtual ~Model();
 
     Model(shared_ptr<EdgeDecoder> decoder, shared_ptr<LossFunction> loss, shared_ptr<LinkPredictionReporter> reporter, torch::Device device);
-    std::tuple<Tensor, Tensor, Tensor, Tensor> forward_lp(shared_ptr<Batch> batch, bool train);  // model.cpp:252-288
+    virtual std::tuple<Tensor, Tensor, Tensor, Tensor> forward_lp(shared_ptr<Batch> batch, bool train);  // model.cpp:252-288
     // the same forward for callers that only train (nobody reads the negative scores): lets the library take the flash-style path
     // (MARIUS_LP_TRAIN_ONLY, include/marius_hip.h); neg / inv_neg of the returned tuple are then undefined
     std::tuple<Tensor, Tensor, Tensor, Tensor> forward_lp_train(shared_ptr<Batch> batch);
@@ -410,7 +458,12 @@ class Model {
     // gpu_sync_interval steps); otherwise the dense gradients are left in relations_grad_ / inverse_relations_grad_ for an all-reduce + step()
     void backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step);
     std::vector<Tensor> dense_state();  // relation tables + their optimizer state (what gpu_model_average averages, pipeline_gpu.cpp:52-80)
+
+   private:
+    void train_batch_generic(shared_ptr<Batch> batch, bool call_step);  // the reference's autograd formulation, for user plug-ins
 };
+// model.cpp:361-440 for the embedding-only link-prediction models of this build
+shared_ptr<Model> initModelFromConfig(const ModelConfig& config, std::vector<torch::Device> devices, int num_relations, bool train);
 
 // ------------------------------------------------------------------------------------------------ dataloader (dataloader.h)
 class PartitionBufferStorage;  // partition_buffer.h
@@ -492,6 +545,26 @@ class SynchronousTrainer {  // trainer.cpp:94-161
     // run `n` batches of the current epoch (starting a new epoch when the batches run out); no host synchronisation inside
     void train_steps(int64_t n);
     void train_one(bool fused);
+};
+// PipelineTrainer::train (trainer.cpp:35-74) on one device: the reference's five worker stages (pipeline.cpp, pipeline_gpu.cpp) collapse
+// to "batches are admitted and prepared ahead of the training step".  Kept semantics:
+//   * admission control (pipeline.cpp:24-45): at most `staleness_bound` batches are in flight (admitted, not yet applied);
+//   * where the parameters of a batch are read: with device-resident storage the compute stage gathers them right before the step
+//     (pipeline_gpu.cpp:52 loadGPUParameters) — no staleness, only the sampler runs ahead, results equal the synchronous trainer; with
+//     host storage the LOADER stage gathers rows and optimizer state at admission (getBatch -> loadCPUParameters, dataloader.cpp:505-527)
+//     and the update lands later: rows are up to staleness_bound - 1 updates old.  `stale_parameters` selects the second behaviour
+//     (storage.embeddings.type: HOST_MEMORY in the YAML); this build admits deterministically, so the staleness is exactly
+//     min(staleness_bound, batches left) - 1 and runs are reproducible (the reference's thread interleaving is not).
+class PipelineTrainer {
+   public:
+    shared_ptr<DataLoader> dataloader_;
+    shared_ptr<Model> model_;
+    int staleness_bound_;
+    bool stale_parameters_;
+    double last_epoch_seconds_ = 0, last_edges_per_second_ = 0;
+    PipelineTrainer(shared_ptr<DataLoader> dataloader, shared_ptr<Model> model, int staleness_bound = 16, bool stale_parameters = false)
+        : dataloader_(dataloader), model_(model), staleness_bound_(staleness_bound < 1 ? 1 : staleness_bound), stale_parameters_(stale_parameters) {}
+    void train(int num_epochs = 1);
 };
 class SynchronousEvaluator {  // evaluator.cpp:58-97
    public:

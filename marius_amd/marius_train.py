@@ -35,7 +35,11 @@ def marius_train(cfg, log=print, train=True):
     dev = torch.device("cuda", 0)
     ds = cfg["storage"]["dataset"]
     ddir, mdir = ds["dataset_dir"], cfg["storage"]["model_dir"]
-    os.makedirs(mdir, exist_ok=True)
+    if cfg.get("_creates_model_dir", train):
+        os.makedirs(mdir, exist_ok=True)
+    elif not os.path.isdir(mdir):  # marius_eval / resume_training: the directory of an earlier run is looked up, never created
+        raise FileNotFoundError("model directory %s does not exist: nothing to %s (run marius_train first, or set storage.model_dir)" % (
+            mdir, "resume" if train else "evaluate"))
     if train:
         with open(os.path.join(mdir, "full_config.yaml"), "w") as f:
             yaml.safe_dump(cfg, f)
@@ -84,6 +88,11 @@ def marius_train(cfg, log=print, train=True):
                 shutil.copyfile(os.path.join(src_dir, name), os.path.join(mdir, name))
         resume = True
     epochs_processed = 0
+    if resume:  # Checkpointer::load needs these three (checkpointer.cpp:56-74): say which one is missing instead of a bare FileNotFoundError
+        missing = [n for n in ("metadata.csv", "model.pt", "embeddings.bin") if not os.path.exists(os.path.join(mdir, n))]
+        if missing:
+            raise FileNotFoundError("%s: cannot %s — %s missing (was a training run with save_model: true written here?)" % (
+                mdir, "resume training" if train else "evaluate", ", ".join(missing)))
     if resume and os.path.exists(os.path.join(mdir, "metadata.csv")):
         epochs_processed = int(open(os.path.join(mdir, "metadata.csv")).read().split("\n")[1])  # CheckpointMeta.num_epochs (marius.cpp:75)
     emb_cfg = cfg["storage"]["embeddings"]
@@ -116,7 +125,12 @@ def marius_train(cfg, log=print, train=True):
                     fe.write(torch.empty((n, d), dtype=torch.float32, device=dev).uniform_(-limit, limit).cpu().numpy().tobytes())
                     fs.write(bytes(4 * d * n))
         else:
+            meta = open(os.path.join(mdir, "metadata.csv")).read().split("\n")
+            if not int(meta[6]):
+                raise RuntimeError("checkpoint in %s has no model" % mdir)
             model.load(os.path.join(mdir, ""), train)
+            if int(meta[4]) and not os.path.exists(state_path):
+                raise FileNotFoundError("%s: metadata.csv says the optimizer state was saved, but embeddings_state.bin is missing" % mdir)
             if not os.path.exists(state_path):
                 with open(state_path, "wb") as fs:
                     fs.write(bytes(4 * d * num_nodes))
@@ -152,7 +166,13 @@ def marius_train(cfg, log=print, train=True):
                                             bool(ns["filtered"]), getattr(H.LocalFilterMode, ns.get("local_filter_mode", "DEG")), gen)
 
     loader = H.DataLoader(train_edges, emb, state, sampler(tr["negative_sampling"]), gen, int(tr["batch_size"]), True)
-    trainer = H.SynchronousTrainer(loader, model)
+    pipe = tr.get("pipeline", {})
+    if pipe.get("sync", True):
+        trainer = H.SynchronousTrainer(loader, model)
+    else:
+        # training.pipeline.sync: false (trainer.cpp:35-74): admission control with staleness_bound; parameters of host-resident tables are
+        # read at admission (stale by up to staleness_bound - 1 updates), device-resident ones by the compute stage (no staleness)
+        trainer = H.PipelineTrainer(loader, model, int(pipe.get("staleness_bound", 16)), emb_cfg["type"] == "HOST_MEMORY" and not partitioned)
     evals = {}
     eval_edges = {}
     for split, key in (("validation", "num_valid"), ("test", "num_test")):
@@ -252,7 +272,7 @@ def main(argv=None, train=True):
     if len(argv) != 1:
         print("usage: %s <config.yaml>" % ("marius_train" if train else "marius_eval"))
         return 2
-    marius_train(C.load_config(argv[0]), train=train)
+    marius_train(C.load_config(argv[0], train=train), train=train)
     return 0
 
 

@@ -82,3 +82,41 @@ def test_marius_train_refuses_cpu_device(tmp_path):
     with pytest.raises(Exception) as e:
         marius_train(C.load_config(path), log=lambda *a: None)
     assert "no CPU path" in str(e.value) or "MI355X" in str(e.value) or "HIP" in str(e.value) or "cuda" in str(e.value).lower()
+
+
+def test_model_dir_resolution_follows_the_reference(tmp_path):
+    """marius_config.py:47-56 (get_model_dir_path) and :875-896 (infer_model_dir): training creates the first free model_<i> (at most
+    model_10); marius_eval and resume_training without resume_from_checkpoint look the latest existing one up instead of creating one."""
+    path, ddir = write(tmp_path, {})
+    assert C.load_config(path, train=False)["storage"]["model_dir"] == os.path.join(ddir, "model_0")   # nothing to fall back to
+    os.makedirs(os.path.join(ddir, "model_0"))
+    os.makedirs(os.path.join(ddir, "model_1"))
+    assert C.load_config(path)["storage"]["model_dir"] == os.path.join(ddir, "model_2")               # a training run: fresh directory
+    cfg = C.load_config(path, train=False)                                                              # marius_eval: the latest existing
+    assert cfg["storage"]["model_dir"] == os.path.join(ddir, "model_1") and cfg["_creates_model_dir"] is False
+    rpath, _ = write(tmp_path, {"training": {"resume_training": True}})
+    assert C.load_config(rpath)["storage"]["model_dir"] == os.path.join(ddir, "model_1")               # resume without a checkpoint dir
+    cpath, _ = write(tmp_path, {"training": {"resume_training": True, "resume_from_checkpoint": str(tmp_path / "ckpt")}})
+    assert C.load_config(cpath)["storage"]["model_dir"] == os.path.join(ddir, "model_2")               # resume_from_checkpoint: a new directory
+    # an explicit model_dir holding model.pt is used as it is; the search stops at model_10
+    mdir = tmp_path / "mine"
+    mdir.mkdir()
+    (mdir / "model.pt").write_bytes(b"x")
+    upath, _ = write(tmp_path, {"storage": {"model_dir": str(mdir)}})
+    assert C.load_config(upath, train=False)["storage"]["model_dir"] == str(mdir)
+    for i in range(2, 11):
+        os.makedirs(os.path.join(ddir, "model_%d" % i))
+    path, _ = write(tmp_path, {})  # (write() reuses one file name)
+    assert C.load_config(path)["storage"]["model_dir"] == os.path.join(ddir, "model_10")
+
+
+def test_marius_eval_does_not_create_a_model_dir(tmp_path):
+    """marius_eval on a dataset nobody trained on reports the missing directory instead of creating model_0 (which would shift the index of
+    every later run)."""
+    from marius_amd.marius_train import marius_train
+
+    path, ddir = write(tmp_path, {})
+    cfg = C.load_config(path, train=False)
+    with pytest.raises(Exception):
+        marius_train(cfg, log=lambda *a: None, train=False)
+    assert not os.path.exists(cfg["storage"]["model_dir"])

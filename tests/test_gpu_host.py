@@ -120,9 +120,10 @@ def _setup(M, dev, decoder, num_nodes, R, d, B, C, N, E, seed, f=0.0):
     return table, edges_all, emb, state, loader, model
 
 
-@pytest.mark.parametrize("decoder,f,fused", [("COMPLEX", 0.0, True), ("COMPLEX", 0.0, False), ("DISTMULT", 0.5, True), ("TRANSE", 0.0, False)])
-def test_trainer_epoch_matches_cpu_reference_path(M, dev, decoder, f, fused):
-    num_nodes, R, d, B, C, N, E, seed = 4000, 11, 20, 250, 5, 40, 1000, 123
+@pytest.mark.parametrize("decoder,f,fused,d", [("COMPLEX", 0.0, True, 20), ("COMPLEX", 0.0, False, 20), ("DISTMULT", 0.5, True, 20), ("TRANSE", 0.0, False, 20),
+                                               ("COMPLEX", 0.0, True, 100), ("DISTMULT", 0.0, False, 64)])  # the last two: the flash training path
+def test_trainer_epoch_matches_cpu_reference_path(M, dev, decoder, f, fused, d):
+    num_nodes, R, B, C, N, E, seed = 4000, 11, 250, 5, 40, 1000, 123
     table, edges_all, emb, state, loader, model = _setup(M, dev, decoder, num_nodes, R, d, B, C, N, E, seed, f)
     trainer = M.SynchronousTrainer(loader, model)
     trainer.fused_update = fused
@@ -140,6 +141,129 @@ def test_trainer_epoch_matches_cpu_reference_path(M, dev, decoder, f, fused):
     close(model.decoder.relations, cpu.rel, rtol=3e-4)
     close(model.decoder.inverse_relations, cpu.inv_rel, rtol=3e-4)
     assert trainer.last_edges_per_second > 0
+
+
+def test_user_plugins_train_through_the_virtual_api(M, dev):
+    """The reference's plug-in points (comparators.h:13-17 virtual operator(), model.h forward_lp, test_nn.py:113-127): a Python subclass of
+    Comparator and a Python subclass of Model that overrides forward_lp are both picked up by the trainer.  Such models leave the fused
+    HIP path (fused_ok() is False) and train through the virtual calls + libtorch autograd, as the reference does; the result must agree
+    with the built-in DistMult run on the same seed."""
+    num_nodes, R, d, B, C, N, E, seed = 3000, 7, 64, 200, 4, 30, 800, 21
+
+    class MyDot(M.Comparator):
+        def __init__(self):
+            super().__init__()
+            self.calls = 0
+
+        def __call__(self, src, dst):
+            self.calls += 1
+            if src.shape == dst.shape:
+                return (src * dst).sum(-1)
+            return torch.bmm(M.pad_and_reshape(src, dst.shape[0]), dst.transpose(-1, -2)).flatten(0, 1)
+
+    class MyModel(M.Model):
+        def __init__(self, *a):
+            super().__init__(*a)
+            self.calls = 0
+
+        def forward_lp(self, batch, train):
+            self.calls += 1
+            return super().forward_lp(batch, train)
+
+    def run(kind):
+        table, edges_all, emb, state, loader, model = _setup(M, dev, "DISTMULT", num_nodes, R, d, B, C, N, E, seed)
+        probe = None
+        if kind == "comparator":
+            probe = MyDot()
+            model.decoder.comparator = probe
+            assert not model.fused_ok()
+        elif kind == "model":
+            model = MyModel(model.decoder, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+            model.setup_optimizers(0.1)
+            model.sparse_lr = 0.1
+            probe = model
+            assert not model.fused_ok()
+        else:
+            assert model.fused_ok()
+        trainer = M.SynchronousTrainer(loader, model)
+        trainer.train(1)
+        torch.cuda.synchronize()
+        return emb.data.cpu().clone(), state.data.cpu().clone(), model.decoder.relations.cpu().clone(), probe
+
+    ref = run("builtin")
+    for kind in ("comparator", "model"):
+        got = run(kind)
+        assert got[3].calls >= (E // B) * (4 if kind == "comparator" else 1)
+        for a, b in zip(got[:3], ref[:3]):
+            close(a, b, rtol=3e-4)
+    assert set(M.Model(M.DistMult(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE), M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+               .named_parameters().keys()) == {"relation_embeddings", "inverse_relation_embeddings"}
+    # initModelFromConfig (model.cpp:361-440) and the device-side LocalFilterMode contract (negative.cpp:295-301)
+    cfg = M.ModelConfig()
+    cfg.decoder, cfg.embedding_dim, cfg.loss = "COMPLEX", 64, "SOFTMAX_CE"
+    m2 = M.initModelFromConfig(cfg, [dev], R, True)
+    assert m2.fused_ok() and tuple(m2.decoder.relations.shape) == (R, 64)
+    with pytest.raises(Exception, match="one process per GPU"):
+        m2.broadcast([dev, dev])
+    m2.all_reduce()  # single process: the only replica, a no-op
+    gen = M.MariusGenerator(1)
+    bad = M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.ALL, gen)
+    edges = torch.zeros(4, 3, dtype=torch.int64, device=dev)
+    with pytest.raises(Exception, match="not yet supported on GPU"):
+        bad.getNegatives(M.MariusGraph(num_nodes), edges, False)
+
+
+@pytest.mark.parametrize("bound", [1, 3])
+def test_pipeline_trainer_bounded_staleness_matches_stale_oracle(M, dev, bound):
+    """training.pipeline.sync: false with host-resident parameters (pipeline.cpp:24-45 admission control, dataloader.cpp:505-527 parameters
+    read by the loader stage): rows and Adagrad state of a batch are gathered when it is admitted, `bound` batches in flight, and the
+    updates Batch::accumulateGradients computes from those stale copies (batch.cpp:62-79) are added later.  Same loop on the CPU oracle;
+    bound 1 is the synchronous trajectory."""
+    num_nodes, R, d, B, C, N, E, seed = 2500, 7, 32, 150, 3, 40, 1200, 9
+    table, edges_all, emb, state, loader, model = _setup(M, dev, "COMPLEX", num_nodes, R, d, B, C, N, E, seed)
+    trainer = M.PipelineTrainer(loader, model, bound, True)
+    trainer.train(1)
+    T, S = table.clone(), torch.zeros(num_nodes, d)
+    cpu = CpuLinkPredictionStep("COMPLEX", T, S, R, B, C, N)
+    torch.manual_seed(seed)
+    perm = torch.randperm(E)
+    steps = E // B
+
+    def admit(t):
+        e = edges_all[perm[t * B:(t + 1) * B]]
+        src_neg, _ = cpu.get_negatives(e, True)
+        dst_neg, _ = cpu.get_negatives(e, False)
+        uniq, mapped = O.map_tensors([e[:, 0], e[:, -1], src_neg.flatten(), dst_neg.flatten()])
+        return {"uniq": uniq, "el": torch.stack([mapped[0], e[:, 1], mapped[1]]).transpose(0, 1), "src_map": mapped[2].reshape(src_neg.shape),
+                "dst_map": mapped[3].reshape(dst_neg.shape), "emb": T[uniq].clone(), "state": S[uniq].clone()}
+
+    q, nxt = [], 0
+    while nxt < steps or q:
+        while len(q) < bound and nxt < steps:
+            q.append(admit(nxt))
+            nxt += 1
+        b = q.pop(0)
+        out = O.train_batch("COMPLEX", b["emb"], b["state"], b["el"], b["dst_map"], b["src_map"], cpu.rel, cpu.inv_rel)
+        O.dense_adagrad_step(cpu.rel, out["rel_grad"], cpu.rel_sum, 0.1)
+        O.dense_adagrad_step(cpu.inv_rel, out["inv_rel_grad"], cpu.inv_rel_sum, 0.1)
+        O.index_add(T, b["uniq"], out["dw"])
+        O.index_add(S, b["uniq"], out["ds"])
+    close(emb.data, T, rtol=3e-4)
+    close(state.data, S, rtol=3e-4)
+    close(model.decoder.relations, cpu.rel, rtol=3e-4)
+    if bound > 1:  # the stale trajectory really differs from the synchronous one
+        sync = CpuLinkPredictionStep("COMPLEX", table.clone(), torch.zeros(num_nodes, d), R, B, C, N)
+        torch.manual_seed(seed)
+        perm2 = torch.randperm(E)
+        for t in range(steps):
+            sync.step(edges_all[perm2[t * B:(t + 1) * B]])
+        assert not torch.allclose(sync.table, T, rtol=1e-4, atol=1e-6)
+    # device-resident parameters: the pipeline trainer is the synchronous trainer with the sampler running ahead
+    t2 = _setup(M, dev, "COMPLEX", num_nodes, R, d, B, C, N, E, seed)
+    M.PipelineTrainer(t2[4], t2[5], bound, False).train(1)
+    t3 = _setup(M, dev, "COMPLEX", num_nodes, R, d, B, C, N, E, seed)
+    M.SynchronousTrainer(t3[4], t3[5]).train(1)
+    assert torch.equal(t2[2].data, t3[2].data)
 
 
 def test_get_batch_matches_reference_dataloader(M, dev):
