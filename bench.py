@@ -57,6 +57,52 @@ def synth_edges(num_nodes, num_relations, E, dist, device, seed=1):
     return torch.stack([src, rel, dst], 1).to(torch.int32)
 
 
+def flash_selected(H, cfg, B, C, N):
+    """does the library take the flash path for this workload's descriptor?  (the predicate the trainer's plan call evaluates)"""
+    import ctypes
+    R, d = cfg["num_relations"], cfg["d"]
+    relop, cmp_ = {"DISTMULT": (0, 0), "COMPLEX": (1, 0), "TRANSE": (2, 1)}[cfg["decoder"]]
+    desc, lay = H.LpDesc(), H.LpLayout()
+    desc.relop, desc.cmp, desc.d, desc.edge_cols, desc.B, desc.C, desc.N = relop if R > 1 else H.OP_NOOP, cmp_, d, 3 if R > 1 else 2, B, C, N
+    desc.use_inverse, desc.flags = int(R > 1), H.LP_TRAIN_ONLY
+    desc.src_neg = ctypes.c_void_p(1)
+    desc.inv_rel = ctypes.c_void_p(1) if R > 1 else None
+    return H.lib().marius_lp_plan(ctypes.byref(desc), ctypes.byref(lay)) == 0 and lay.flash == 1
+
+
+def dominant_roofline(avg_ms, B, C, N, d, ndir, flash, pmc_ok, kernel="lp_grad_adj"):
+    """roofline object of a backward contraction launch timed at avg_ms (see the accounting notes in main())"""
+    Bp = C * math.ceil(B / C)
+    contraction_flops = 2.0 * Bp * N * d * ndir
+    if flash:
+        ach, peak = 2 * 3 * contraction_flops / (avg_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TF
+    else:
+        ach, peak = 2 * contraction_flops / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TF
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json" if flash else "r1h_pmc_traffic.json")
+    if pmc_ok and os.path.exists(pmc_path):
+        for name, v in json.load(open(pmc_path))["kernels"].items():
+            if name.startswith("flash_kernel<7, 1" if flash else "lp_grad16_kernel"):
+                traffic = v["hbm_bytes"]
+    out = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+           "avg_ms": round(avg_ms, 4)}
+    if flash:
+        out.update({"peak_is": "dense BF16 MFMA", "bf16_products_per_fp32_product": 3, "contractions_per_launch": 2, "fp32_equivalent_tflops": round(ach / 3, 2)})
+    return out
+
+
+def cpu_baseline_leg(cfg, B, C, N, edges_all, cpu_seconds):
+    from oracle.cpu_step import time_cpu_baseline
+    num_nodes, R, d = cfg["num_nodes"], cfg["num_relations"], cfg["d"]
+    ndir = 2 if R > 1 else 1
+    proxy = min(num_nodes, 10_000_000)
+    e_cpu = edges_all[: B * 16].cpu().long()
+    v, steps, threads = time_cpu_baseline(cfg["decoder"], proxy, num_nodes, R, d, B, C, N, e_cpu, max_seconds=cpu_seconds)
+    return {"value": round(v * ndir * (1 + N), 1), "unit": "scored edges/s", "positive_edges_per_s": round(v, 1), "cores": threads, "kind": "port",
+            "sample": "%d full steps (B=%d) of the same workload on a %d-row proxy table (the CPU box cannot hold the 34 GB table twice; a smaller "
+                      "table flatters the CPU gather), oracle/cpu_step.py, torch CPU ops" % (steps, B, proxy)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +115,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--strong", action="store_true", help="N > 1: strong scaling (the global batch stays B; default is weak scaling, B per GPU)")
     ap.add_argument("--loss", default="SOFTMAX_CE", help="model.loss.type (the headline metric is quoted on SOFTMAX_CE; others for exploration, C++ driver only)")
     a = ap.parse_args()
 
@@ -187,17 +234,7 @@ def main():
     Bp = C * math.ceil(B / C)
     contraction_flops = 2.0 * Bp * N * d * ndir  # one [Bc x d] x [d x N] contraction per chunk and direction
     L = 2 * B + 2 * C * N
-    # does the library take the flash path for this descriptor?  (same predicate the trainer's plan call evaluates)
-    flash = False
-    if a.driver == "cpp" and a.loss.upper() == "SOFTMAX_CE":
-        import ctypes
-        relop, cmp_ = {"DISTMULT": (0, 0), "COMPLEX": (1, 0), "TRANSE": (2, 1)}[cfg["decoder"]]
-        desc, lay = H.LpDesc(), H.LpLayout()
-        desc.relop, desc.cmp, desc.d, desc.edge_cols, desc.B, desc.C, desc.N = relop if R > 1 else H.OP_NOOP, cmp_, d, 3 if R > 1 else 2, B, C, N
-        desc.use_inverse, desc.flags = int(R > 1), H.LP_TRAIN_ONLY
-        desc.src_neg = ctypes.c_void_p(1)
-        desc.inv_rel = ctypes.c_void_p(1) if R > 1 else None
-        flash = H.lib().marius_lp_plan(ctypes.byref(desc), ctypes.byref(lay)) == 0 and lay.flash == 1
+    flash = a.driver == "cpp" and a.loss.upper() == "SOFTMAX_CE" and flash_selected(H, cfg, B, C, N)
     # MFMA work per launch.  FP32-MFMA kernels: the fp32 flops of the contraction(s).  Flash kernels: the bf16 flops the split scheme
     # needs for them — 3 bf16 products per fp32 product, and the two backward launches recompute the score tile before their
     # gradient contraction (2 contractions each) — priced against the dense BF16 matrix peak.
@@ -265,12 +302,7 @@ def main():
     # ---- CPU baseline: the oracle (port of the reference's CPU path) on a bounded sample, host cores of this box
     cpu = None
     if not a.no_cpu_baseline:
-        from oracle.cpu_step import time_cpu_baseline
-        proxy = min(num_nodes, 10_000_000)
-        e_cpu = edges_all[: B * 16].cpu().long()
-        v, steps, threads = time_cpu_baseline(cfg["decoder"], proxy, num_nodes, R, d, B, C, N, e_cpu, max_seconds=a.cpu_seconds)
-        cpu = {"value": round(v * ndir * (1 + N), 1), "unit": "scored edges/s", "positive_edges_per_s": round(v, 1), "cores": threads, "kind": "port",
-               "sample": "%d full steps (B=%d) of the same workload on a %d-row proxy table, oracle/cpu_step.py, torch CPU ops" % (steps, B, proxy)}
+        cpu = cpu_baseline_leg(cfg, B, C, N, edges_all, a.cpu_seconds)
 
     out = {
         "metric": "edges/sec scored (pos+neg)", "value": round(scored_eps, 1), "unit": "scored edges/s",

@@ -366,6 +366,10 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("train_steps", &ShardedTrainer::train_steps, py::arg("n"), py::call_guard<py::gil_scoped_release>())
         .def("finish", &ShardedTrainer::finish, py::call_guard<py::gil_scoped_release>())
         .def_readwrite("host_seconds", &ShardedTrainer::host_seconds_)
+        .def("ranks", &ShardedTrainer::ranks)
+        .def("backend", &ShardedTrainer::backend)
+        .def_property_readonly("exchange_bytes", [](ShardedTrainer& t) { return std::vector<int64_t>(t.exchange_bytes_, t.exchange_bytes_ + 3); })
+        .def("reset_exchange_bytes", [](ShardedTrainer& t) { t.exchange_bytes_[0] = t.exchange_bytes_[1] = t.exchange_bytes_[2] = 0; })
         .def_readonly("steps", &ShardedTrainer::steps_)
         .def_property_readonly("phase_seconds", [](ShardedTrainer& t) { return std::vector<double>(t.phase_seconds_, t.phase_seconds_ + 6); });
     m.def("c10d_exchange_selftest", &c10d_exchange_selftest, py::arg("group_name"), py::arg("send"), py::arg("send_counts"), py::arg("to_reduce"),

@@ -54,7 +54,7 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
     if (table_.size(0) != std::min<int64_t>(lo_ + S_, num_nodes_) - lo_) throw MariusRuntimeException("ShardedTrainer: shard has the wrong number of rows");
     d_ = (int)table_.size(1);
     pg_ = c10d::resolve_process_group(group_name);
-    if (world_ > 1) side_pg_ = c10d::resolve_process_group(side_group_name);
+    (void)side_group_name;  // kept in the signature: earlier builds exchanged the receive counts over a CPU (gloo) group
     if (pg_->getSize() != world_ || pg_->getRank() != rank_) throw MariusRuntimeException("ShardedTrainer: process group does not match rank / world");
     const auto dev = table_.device();
     {
@@ -76,6 +76,9 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
     for (auto& s : slots_) {
         s.offs_dev = torch::empty({world_ + 1}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
         s.offs_host = torch::empty({world_ + 1}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
+        s.cnt_send_dev = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
+        s.cnt_recv_dev = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
+        s.cnt_recv_host = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
         s.ready = new_event();
         s.fetched = new_event();
         s.computed = new_event();
@@ -116,9 +119,9 @@ void ShardedTrainer::prime() {
     pg_->alltoall_base(rows_out, rows, ones, ones)->wait();
     pg_->alltoall_base(ids_out, ids, ones, ones)->wait();
     if (world_ > 1) {
-        Tensor a = torch::zeros({world_}, torch::kInt64), b = torch::zeros({world_}, torch::kInt64);
+        Tensor a = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).device(dev)), b = torch::zeros_like(a);
         std::vector<int64_t> none;
-        side_pg_->alltoall_base(b, a, none, none)->wait();
+        pg_->alltoall_base(b, a, none, none)->wait();  // the equal-split form of the count exchange
     }
     strm(main_stream_).synchronize();
 }
@@ -167,6 +170,18 @@ void ShardedTrainer::prepare(int64_t t) {
         mcheck(marius_owner_offsets(s.batch->unique_node_indices_.data_ptr<int64_t>(), s.batch->num_unique_dev_.data_ptr<int64_t>(), S_, world_,
                                     s.offs_dev.data_ptr<int64_t>(), (marius_stream_t)prep.stream()));
         s.offs_host.copy_(s.offs_dev, /*non_blocking=*/true);
+        // The receive counts of the all-to-all(v) travel on the device as well: a `world`-integer all-to-all of the send counts on this
+        // (preparation) stream, read back together with the split points behind the same `ready` event.  No host round trip (the
+        // earlier form exchanged them over a gloo group from the host, one blocking call per step in the training loop).  Every rank
+        // issues its collectives in the same program order, which is all a communicator requires.
+        torch::sub_out(s.cnt_send_dev, s.offs_dev.narrow(0, 1, world_), s.offs_dev.narrow(0, 0, world_));
+        if (world_ > 1) {
+            std::vector<int64_t> none;
+            pg_->alltoall_base(s.cnt_recv_dev, s.cnt_send_dev, none, none)->wait();
+        } else {
+            s.cnt_recv_dev.copy_(s.cnt_send_dev);
+        }
+        s.cnt_recv_host.copy_(s.cnt_recv_dev, /*non_blocking=*/true);
     }
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.ready, prep.stream()));
     s.used = true;
@@ -187,15 +202,9 @@ void ShardedTrainer::fetch(int64_t t) {
     const int64_t* offs = s.offs_host.data_ptr<int64_t>();
     s.send_counts.assign(world_, 0);
     for (int i = 0; i < world_; ++i) s.send_counts[i] = offs[i + 1] - offs[i];
-    if (world_ > 1) {
-        // counts travel over the CPU (gloo) group: a second RCCL communicator on another stream could share a hardware queue with the
-        // main one and order differently on different ranks; `world` integers over loopback cost less than that risk
-        Tensor send = torch::from_blob(s.send_counts.data(), {world_}, torch::kInt64).clone(), recv = torch::empty({world_}, torch::kInt64);
-        std::vector<int64_t> none;
-        side_pg_->alltoall_base(recv, send, none, none)->wait();
-        s.recv_counts.assign(recv.data_ptr<int64_t>(), recv.data_ptr<int64_t>() + world_);
-    } else {
-        s.recv_counts = s.send_counts;
+    {
+        const int64_t* rc = s.cnt_recv_host.data_ptr<int64_t>();
+        s.recv_counts.assign(rc, rc + world_);
     }
     s.U = offs[world_];
     s.nrecv = 0;
@@ -215,6 +224,12 @@ void ShardedTrainer::fetch(int64_t t) {
         s.emb = a2a(rows, s.recv_counts, s.send_counts, view(emb_[k], s.U, {d_}, torch::kFloat32));
     }
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.fetched, xchg.stream()));
+    for (int q = 0; q < world_; ++q) {
+        if (q == rank_) continue;
+        exchange_bytes_[0] += s.send_counts[q] * 8;             // ids to the owners
+        exchange_bytes_[1] += s.recv_counts[q] * (int64_t)d_ * 4;  // rows served to the requesters
+        exchange_bytes_[2] += s.send_counts[q] * (int64_t)d_ * 4;  // gradients returned to the owners (update())
+    }
 }
 
 void ShardedTrainer::fetch_through(int64_t t) {

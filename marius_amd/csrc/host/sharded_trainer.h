@@ -31,6 +31,10 @@ class ShardedTrainer {
     void train_steps(int64_t n);
     void finish();  // drain the device (prefetched batches are dropped: preparation and fetch have no side effects)
     double host_seconds_ = 0;  // time spent issuing steps (diagnostic: the host must stay ahead of the GPU)
+    // bytes this rank put on the wire (to other ranks) in ids / rows served / gradients returned since the counters were last cleared
+    int64_t exchange_bytes_[3] = {0, 0, 0};
+    int ranks() const { return pg_ ? pg_->getSize() : 1; }
+    std::string backend() const { return pg_ ? pg_->getBackendName() : std::string("none"); }
     int64_t steps_ = 0;
     double phase_seconds_[6] = {0, 0, 0, 0, 0, 0};  // host time in: prepare, wait for split points, fetch, compute, update, dense
 
@@ -38,6 +42,7 @@ class ShardedTrainer {
     struct Slot {
         shared_ptr<Batch> batch;
         Tensor offs_dev, offs_host;  // [world + 1] split points of the batch's ascending unique ids by owner
+        Tensor cnt_send_dev, cnt_recv_dev, cnt_recv_host;  // [world] rows this rank asks of every owner / is asked for by every requester
         void* ready = nullptr;       // prep stream: batch prepared, split points on their way to the host
         void* fetched = nullptr;     // rows of this batch have arrived
         void* computed = nullptr;    // per-row gradients complete

@@ -539,6 +539,11 @@ def run_sharded_bench(a, cfg, rank, world, dev):
 
     sys_path_fix = None  # noqa: F841
     num_nodes, R, d, B, C, N = cfg["num_nodes"], cfg["num_relations"], cfg["d"], cfg["B"], cfg["C"], cfg["N"]
+    strong = bool(getattr(a, "strong", False))
+    if strong:  # fixed global batch: every rank trains B / world positives per step (chunks stay whole: C must divide)
+        if B % world or C % world:
+            raise SystemExit("--strong needs the batch size and the chunk count to be multiples of the number of GPUs")
+        B, C = B // world, C // world
     lo, hi = shard_range(num_nodes, rank, world)
     limit = math.sqrt(6.0 / (num_nodes + d))
     table = torch.empty((hi - lo, d), dtype=torch.float32, device=dev).uniform_(-limit, limit, generator=torch.Generator(device=dev).manual_seed(rank))
@@ -614,6 +619,7 @@ def run_sharded_bench(a, cfg, rank, world, dev):
         host_s[0] = 0.0
     if cpp_trainer is not None:
         cpp_trainer.host_seconds = 0.0
+        cpp_trainer.reset_exchange_bytes()
     H.profile_reset()
     H.profile_enable(True, only="lp_grad_adj")  # HIP events around the dominant kernel only (one pair per step)
     t0 = time.perf_counter()
@@ -626,18 +632,30 @@ def run_sharded_bench(a, cfg, rank, world, dev):
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
+    # wire bytes of the timed region, summed over ranks (ids to owners + rows served + gradients returned)
+    xb = torch.tensor(list(cpp_trainer.exchange_bytes) if cpp_trainer is not None else [0, 0, 0], dtype=torch.float64, device=dev)
+    dist.all_reduce(xb)
     if rank == 0:
         pos_eps = B * a.steps * world / dt
+        flash = bench_mod.flash_selected(H, cfg, B, C, N)
+        backend_name = cpp_trainer.backend() if cpp_trainer is not None else dist.get_backend()
         out = {
             "metric": "edges/sec scored (pos+neg)", "value": round(pos_eps * (2 + 2 * N), 1), "unit": "scored edges/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s %s d=%d, node table sharded by contiguous id range over %d GPUs, B=%d per GPU, C=%d N=%d, %s edges" % (
-                a.workload, cfg["decoder"], d, world, B, C, N, a.edge_dist), "num_nodes": num_nodes, "num_relations": R,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f32 (contractions: 2-way bf16 split x 3 products, f32 accumulate)" if flash else "f32", "data": "synthetic",
+            "config": {"workload": "%s %s d=%d, node table sharded by contiguous id range over %d GPUs, B=%d per GPU (%s), C=%d N=%d, %s edges" % (
+                a.workload, cfg["decoder"], d, world, B, "global batch fixed" if strong else "fixed per GPU", C, N, a.edge_dist),
+                "num_nodes": num_nodes, "num_relations": R,
                 "parallelism": "dp%d + sharded node table, RCCL all-to-all(v) row fetch / gradient return, relation tables averaged every %d steps, %s" % (
                     world, sync_interval, ("row exchange overlapped with scoring on a second stream (staleness 1 step; reference pipeline bound: 16)"
                                            if pipelined and staleness else "synchronous exchange"))},
             "positive_edges_per_s": round(pos_eps, 1), "roofline": None, "cpu_baseline": None,
+            # the communicator the exchange ran on: `rccl_ranks` ranks, one per GPU ("nccl" is RCCL on ROCm; "gloo" only in the
+            # single-GPU emulation of tests/test_gpu_sharded2.py)
+            "rccl_ranks": cpp_trainer.ranks() if cpp_trainer is not None else world, "collective_backend": backend_name,
+            "exchange_bytes_per_step": {"ids": round(float(xb[0]) / a.steps), "rows": round(float(xb[1]) / a.steps), "gradients": round(float(xb[2]) / a.steps),
+                                        "total": round(float(xb.sum()) / a.steps), "note": "all ranks, bytes that cross xGMI per step; counts ride a world-integer device all-to-all"},
         }
         host_total = cpp_trainer.host_seconds if cpp_trainer is not None else (host_s[0] if host_s is not None else None)
         if host_total is not None:  # how long the host needs to issue a step: it must stay below ms_per_step or the host is the bottleneck
@@ -647,12 +665,10 @@ def run_sharded_bench(a, cfg, rank, world, dev):
                 out["host_phase_ms_per_step"] = dict(zip(["prepare", "wait_split_points", "fetch", "compute", "update", "dense"],
                                                          [round(x / (a.steps + a.warmup) * 1e3, 4) for x in cpp_trainer.phase_seconds]))
         ms, cnt = prof.get("lp_grad_adj", (0.0, 0))
-        if cnt:  # rank 0's dominant kernel (both backward contractions in one launch), same accounting as the N = 1 line
-            Bp = C * math.ceil(B / C)
-            flops = 2.0 * Bp * N * d * 2 * 2
-            ach = flops / (ms / cnt * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "lp_grad_adj (dAdj + dNeg contractions, one launch; rank 0)", "bound": "mfma", "achieved": round(ach, 2),
-                               "peak": bench_mod.MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / bench_mod.MFMA_F32_PEAK_TF, 4), "traffic": None,
-                               "avg_ms": round(ms / cnt, 4)}
+        if cnt:  # rank 0's dominant kernel, same accounting as the N = 1 line
+            out["roofline"] = bench_mod.dominant_roofline(ms / cnt, B, C, N, d, 2, flash, a.workload == "freebase86m" and not a.num_nodes and not strong)
+            out["roofline"]["kernel"] += " (rank 0)"
+        if not a.no_cpu_baseline:  # rank 0 only: the same bounded CPU leg as the N = 1 line (per-rank workload)
+            out["cpu_baseline"] = bench_mod.cpu_baseline_leg(cfg, B, C, N, edges_all, a.cpu_seconds)
         print(json.dumps(out))
     dist.destroy_process_group()

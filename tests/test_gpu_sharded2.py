@@ -147,7 +147,8 @@ def test_bench_launch_contract_two_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MARIUS_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(47000 + os.getpid() % 2000), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--num-nodes", "2000000"]
+           str(47000 + os.getpid() % 2000), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--cpu-seconds", "3",
+           "--num-nodes", "2000000"]
     out = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -158,3 +159,16 @@ def test_bench_launch_contract_two_ranks():
         assert key in j, key
     assert j["n_gpus"] == 2 and j["steps"] == 6 and j["warmup"] == 2 and j["scaling"] == "weak" and j["value"] > 0
     assert "C++ ShardedTrainer" in j["config"]["host"]
+    # the N > 1 line is complete: bounded CPU leg, roofline of the dominant kernel, the communicator it ran on, bytes on the wire
+    assert j["cpu_baseline"] and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1 and j["cpu_baseline"]["kind"] == "port"
+    assert j["roofline"] and 0 < j["roofline"]["frac"] < 1 and j["roofline"]["bound"] == "mfma"
+    assert j["rccl_ranks"] == 2 and j["collective_backend"] == "gloo"
+    xb = j["exchange_bytes_per_step"]
+    assert xb["ids"] > 0 and xb["rows"] > 0 and xb["gradients"] == xb["rows"] and xb["total"] == xb["ids"] + xb["rows"] + xb["gradients"]
+    # strong scaling: the global batch stays B
+    cmd2 = cmd[:-2] + ["--num-nodes", "2000000", "--strong", "--no-cpu-baseline"]
+    cmd2[cmd2.index("--master-port") + 1] = str(49000 + os.getpid() % 2000)
+    out2 = subprocess.run(cmd2, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    j2 = json.loads([ln for ln in out2.stdout.splitlines() if ln.startswith("{")][0])
+    assert j2["scaling"] == "strong" and "B=25000 per GPU" in j2["config"]["workload"] and j2["cpu_baseline"] is None
