@@ -118,6 +118,7 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_property_readonly("swaps", [](PartitionBufferStorage& s) { return s.buffer_->swaps_; })
         .def_property_readonly("prefetch_hits", [](PartitionBufferStorage& s) { return s.buffer_->prefetch_hits_; })
         .def_property_readonly("swap_seconds", [](PartitionBufferStorage& s) { return s.buffer_->swap_seconds_; })
+        .def_property_readonly("drain_seconds", [](PartitionBufferStorage& s) { return s.buffer_->drain_seconds_; })
         .def_readonly("options", &PartitionBufferStorage::options_);
     m.def("getEdgeBucketOrdering", &getEdgeBucketOrdering, py::arg("edge_bucket_ordering"), py::arg("num_partitions"), py::arg("buffer_capacity"),
           py::arg("fine_to_coarse_ratio"), py::arg("num_cache_partitions"), py::arg("randomly_assign_edge_buckets"), py::arg("generator"));
@@ -347,6 +348,7 @@ PYBIND11_MODULE(_marius_host, m) {
         .def(py::init<std::shared_ptr<DataLoader>, std::shared_ptr<Model>>())
         .def("train", &SynchronousTrainer::train, py::arg("num_epochs") = 1, py::call_guard<py::gil_scoped_release>())
         .def("train_steps", &SynchronousTrainer::train_steps, py::arg("n"), py::call_guard<py::gil_scoped_release>())
+        .def("train_one", &SynchronousTrainer::train_one, py::arg("fused") = true, py::call_guard<py::gil_scoped_release>())
         .def_readwrite("fused_update", &SynchronousTrainer::fused_update_)
         .def_readonly("last_epoch_seconds", &SynchronousTrainer::last_epoch_seconds_)
         .def_readonly("last_edges_per_second", &SynchronousTrainer::last_edges_per_second_);

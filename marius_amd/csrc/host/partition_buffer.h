@@ -69,6 +69,7 @@ class PartitionBuffer {
     // counters for tests / reporting
     int64_t swaps_ = 0, prefetch_hits_ = 0;
     double swap_seconds_ = 0;
+    double drain_seconds_ = 0;  // host time spent at swap points waiting for the device to finish the batches of the ending buffer state
 
    private:
     int capacity_, num_partitions_, fine_to_coarse_ratio_, embedding_size_;

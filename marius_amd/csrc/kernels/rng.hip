@@ -189,8 +189,18 @@ extern "C" void marius_mt19937_fill_host(uint32_t* st, uint32_t* out, int64_t n)
 
 extern "C" int marius_mt19937_randperm_host(uint32_t* st, int64_t* out, int64_t n) {
     MARIUS_REQUIRE(n >= 0 && (n == 0 || out), "randperm: bad arguments");
-    // ATen switches to 64-bit draws for n >= 2^32 / 20; that path is not reproduced here.
-    MARIUS_REQUIRE((uint64_t)n < (0xffffffffull / 20ull), "randperm: n=%ld needs ATen's 64-bit path (unsupported)", (long)n);
+    // ATen (TensorFactories.cpp, randperm_cpu): Fisher-Yates with 32-bit draws below 2^32 / 20 elements; above, the inside-out variant
+    // with random64() = (first draw << 32) | second draw
+    if ((uint64_t)n >= (0xffffffffull / 20ull)) {
+        for (int64_t i = 0; i < n; i++) {
+            uint64_t r = host_next(st);
+            r = (r << 32) | (uint64_t)host_next(st);
+            const int64_t z = (int64_t)(r % (uint64_t)(i + 1));
+            out[i] = out[z];
+            out[z] = i;
+        }
+        return MARIUS_OK;
+    }
     for (int64_t i = 0; i < n; i++) out[i] = i;
     for (int64_t i = 0; i < n - 1; i++) {
         int64_t z = (int64_t)((uint64_t)host_next(st) % (uint64_t)(n - i));

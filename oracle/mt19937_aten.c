@@ -82,8 +82,17 @@ void mt_randint(mt_state* s, int64_t* out, int64_t n, uint64_t range, int64_t ba
     }
 }
 
-/* torch.randperm(n) on the CPU generator (n < 2^32 / 20 path: 32-bit draws) */
+/* torch.randperm(n) on the CPU generator (ATen/native/TensorFactories.cpp, randperm_cpu): Fisher-Yates with 32-bit draws for
+ * n < 2^32 / 20; above that the "inside-out" variant with random64() draws (r[i] = r[z]; r[z] = i, z = random64() % (i + 1)). */
 void mt_randperm(mt_state* s, int64_t* out, int64_t n) {
+    if ((uint64_t)n >= (0xffffffffull / 20ull)) {
+        for (int64_t i = 0; i < n; i++) {
+            int64_t z = (int64_t)(mt_random64(s) % (uint64_t)(i + 1));
+            out[i] = out[z];
+            out[z] = i;
+        }
+        return;
+    }
     for (int64_t i = 0; i < n; i++) out[i] = i;
     for (int64_t i = 0; i < n - 1; i++) {
         int64_t z = (int64_t)((uint64_t)mt_random(s) % (uint64_t)(n - i));

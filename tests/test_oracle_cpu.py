@@ -318,3 +318,23 @@ def test_cross_entropy_equals_softmax_ce_on_scores():
     pos, neg = torch.randn(50, generator=g), torch.randn(50, 30, generator=g)
     a, b = O.loss_function("CROSS_ENTROPY", pos, neg, "sum"), O.loss_function("SOFTMAX_CE", pos, neg, "sum")
     assert abs(a.item() - b.item()) <= 1e-5 * abs(b.item())
+
+
+def test_randperm_wide_path_matches_torch():
+    """n >= 2^32 / 20: ATen's randperm_cpu switches to the inside-out shuffle with random64() draws (an epoch over > 214.7 M training edges,
+    e.g. Twitter-2010 / Freebase86m at full size).  Oracle and library host function both reproduce torch.randperm bit for bit."""
+    import ctypes as C
+
+    from marius_amd import hip as H
+
+    n = 0xFFFFFFFF // 20 + 3
+    torch.manual_seed(77)
+    ref = torch.randperm(n)
+    og = OracleGenerator(77)
+    assert np.array_equal(og.randperm(n), ref.numpy())
+    L = H.lib()
+    st = torch.zeros(625, dtype=torch.int32)
+    L.marius_mt19937_seed_host(st.data_ptr(), 77)
+    out = torch.empty(n, dtype=torch.int64)
+    assert L.marius_mt19937_randperm_host(st.data_ptr(), out.data_ptr(), n) == 0
+    assert torch.equal(out, ref)

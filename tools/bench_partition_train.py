@@ -24,11 +24,13 @@ def main():
     ap.add_argument("--partitions", type=int, default=8)
     ap.add_argument("--capacity", type=int, default=4)
     ap.add_argument("--d", type=int, default=100)
-    ap.add_argument("--dir", default="/tmp")
+    ap.add_argument("--relations", type=int, default=14824, help="1: a single relation type, 2-column edges, one direction (cfg5: Twitter-2010)")
+    ap.add_argument("--dir", default="/tmp", help="/dev/shm keeps the partition files in host DRAM (cfg5's setting)")
+    ap.add_argument("--skip-device-memory", action="store_true")
     a = ap.parse_args()
     M = marius_amd.host()
     dev = torch.device("cuda", 0)
-    R, B, C, N, d, p = 14824, 50000, 50, 1000, a.d, a.partitions
+    R, B, C, N, d, p = a.relations, 50000, 50, 1000, a.d, a.partitions
     g = torch.Generator(device=dev).manual_seed(1)
     src = torch.randint(a.nodes, (a.edges,), generator=g, device=dev)
     dst = torch.randint(a.nodes, (a.edges,), generator=g, device=dev)
@@ -36,12 +38,12 @@ def main():
     ps = -(-a.nodes // p)
     bucket = (src // ps) * p + dst // ps                       # torch_partitioner.py:12-46 on the device: stable sort by edge bucket
     order = torch.sort(bucket, stable=True)[1]
-    edges = torch.stack([src, rel, dst], 1)[order].to(torch.int32)
+    edges = (torch.stack([src, rel, dst], 1) if R > 1 else torch.stack([src, dst], 1))[order].to(torch.int32)  # io.cpp:42-45: one relation type -> (src, dst)
     sizes = torch.bincount(bucket, minlength=p * p).tolist()
     del src, dst, rel, bucket, order
 
     def model():
-        dec = M.ComplEx(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+        dec = M.ComplEx(R, d, dev, R > 1, M.EdgeDecoderMethod.CORRUPT_NODE)
         m = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
         m.setup_optimizers(0.1)
         m.sparse_lr = 0.1
@@ -49,22 +51,26 @@ def main():
 
     out = {"nodes": a.nodes, "edges": a.edges, "d": d, "partitions": p, "capacity": a.capacity, "table_GB": round(a.nodes * d * 4 / 1e9, 2)}
     # ---- in memory
-    gen = M.MariusGenerator(7)
-    emb, st = M.InMemory(torch.zeros((a.nodes, d), device=dev).uniform_(-0.01, 0.01)), M.InMemory(torch.zeros((a.nodes, d), device=dev))
-    loader = M.DataLoader(M.InMemory(edges), emb, st, M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen), gen, B, True)
-    tr = M.SynchronousTrainer(loader, model())
-    tr.train(1)
-    out["device_memory_edges_per_s"] = round(tr.last_edges_per_second, 1)
-    del tr, loader, emb, st
-    torch.cuda.empty_cache()
+    if not a.skip_device_memory:
+        gen = M.MariusGenerator(7)
+        emb, st = M.InMemory(torch.zeros((a.nodes, d), device=dev).uniform_(-0.01, 0.01)), M.InMemory(torch.zeros((a.nodes, d), device=dev))
+        loader = M.DataLoader(M.InMemory(edges), emb, st, M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen), gen, B, True)
+        tr = M.SynchronousTrainer(loader, model())
+        tr.train(1)
+        out["device_memory_edges_per_s"] = round(tr.last_edges_per_second, 1)
+        out["device_memory_epoch_s"] = round(tr.last_epoch_seconds, 2)
+        del tr, loader, emb, st
+        torch.cuda.empty_cache()
     # ---- partition buffer
     paths = [os.path.join(a.dir, n) for n in ("pb_bench_embeddings.bin", "pb_bench_state.bin")]
     rows = 1 << 20
+    t_files = time.perf_counter()
     with open(paths[0], "wb") as fe, open(paths[1], "wb") as fs:
         for lo in range(0, a.nodes, rows):
             n = min(rows, a.nodes - lo)
             fe.write(torch.zeros((n, d), device=dev).uniform_(-0.01, 0.01).cpu().numpy().tobytes())
             fs.write(bytes(4 * d * n))
+    out["file_init_s"] = round(time.perf_counter() - t_files, 1)
     o = M.PartitionBufferOptions()
     o.num_partitions, o.buffer_capacity, o.prefetching, o.fine_to_coarse_ratio = p, a.capacity, True, 1
     o.edge_bucket_ordering = M.EdgeBucketOrdering.NEW_BETA
@@ -74,10 +80,35 @@ def main():
     est.edge_bucket_sizes = sizes
     loader = M.DataLoader(est, emb, st, M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen), gen, B, True)
     tr = M.SynchronousTrainer(loader, model())
+    # epoch by hand (== SynchronousTrainer::train(1)) so that the parts can be timed: per-state batch layout (host randperm of the state's
+    # edges + global -> buffer-local id remap), the training steps, the swaps, and the final write-back of the resident partitions
     t0 = time.perf_counter()
-    tr.train(1)
+    loader.loadStorage()
+    t_load = time.perf_counter() - t0
+    parts = {"load_first_state_s": round(t_load, 2)}
+    tl = time.perf_counter()
+    loader.initializeBatches(True)
+    torch.cuda.synchronize()
+    t_init0 = time.perf_counter() - tl
+    te = time.perf_counter()
+    steps = 0
+    while loader.hasNextBatch():
+        tr.train_one(True)
+        steps += 1
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - te
+    tw = time.perf_counter()
+    loader.nextEpoch(True)
+    t_unload = time.perf_counter() - tw
     wall = time.perf_counter() - t0
-    out.update({"partition_buffer_edges_per_s": round(tr.last_edges_per_second, 1), "epoch_wall_s_incl_load_and_writeback": round(wall, 2),
+    tr_last = a.edges / (t_train + t_unload)
+    parts.update({"first_state_batch_layout_s": round(t_init0, 2), "steps": steps, "train_loop_s_incl_swaps_and_layouts": round(t_train, 2),
+                  "final_write_back_s": round(t_unload, 2), "swap_exchange_s_embeddings": round(emb.swap_seconds, 3), "swap_exchange_s_state": round(st.swap_seconds, 3),
+                  "device_drain_at_swap_points_s": round(emb.drain_seconds + st.drain_seconds, 3)})
+    out["partition_buffer_breakdown"] = parts
+    out.update({"partition_buffer_edges_per_s": round(tr_last, 1), "partition_buffer_epoch_s": round(t_train + t_unload, 2),
+                "epoch_wall_s_incl_load_and_writeback": round(wall, 2), "parameters_GB": round(2 * a.nodes * d * 4 / 1e9, 1),
+                "resident_GB": round(2 * a.capacity * (-(-a.nodes // p)) * d * 4 / 1e9, 1), "swap_GB_each_way_per_swap": round(2 * (-(-a.nodes // p)) * d * 4 / 1e9, 2),
                 "swaps": emb.swaps, "prefetch_hits": emb.prefetch_hits, "swap_seconds_embeddings": round(emb.swap_seconds, 3),
                 "swap_seconds_state": round(st.swap_seconds, 3), "buffer_states": len(loader.buffer_states)})
     for pth in paths:
