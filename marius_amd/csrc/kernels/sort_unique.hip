@@ -7,6 +7,7 @@
 //   inverse[p]     index into uniq of input position p        (the mapped tensors of map_tensors)
 //   perm[k]        input position of the k-th sorted id       (stable: equal ids keep input order => deterministic sums)
 //   seg_offsets[u] first sorted position of run u, seg_offsets[U] = n
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -95,6 +96,242 @@ __global__ __launch_bounds__(256) void merge_rank_kernel(const int64_t* __restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ hand-written LSD radix sort
+// n is small (2e5 keys, 27 key bits: 2.4 MB of keys + positions), so the sort is latency- and launch-bound, not bandwidth-bound:
+// what matters is the number of dependent launches and how little each does.  "Onesweep" structure with 9-bit digits (3 passes for
+// 27 bits, 2 for the 14-bit relation ids):
+//   rs_ghist_kernel    ONE launch: the global digit histograms of all passes (key order does not matter for them); also zeroes the
+//                      granules and the output uniq[] (capacity-sized consumers read ids past the unique count as 0)
+//   rs_sweep_kernel    one launch per pass: a block ranks its tile stably (wave-level match on the digit + per-wave running counters),
+//                      publishes its per-digit counts as flagged 4-byte granules, sums the granules of the tiles before it (they were
+//                      dispatched earlier: a spin on a granule always ends) and scatters (key, position).  No per-tile histogram
+//                      pass, no scan launch.
+//   rs_emit_kernel     ONE launch: run heads -> unique index (same granule hand-off for the head counts of earlier tiles), uniq /
+//                      inverse / seg_offsets / count.
+// 1 + passes + 1 launches per call (5 for node ids), no memset, instead of rocPRIM's 14.
+constexpr int RS_BITS = 9, RS_RADIX = 1 << RS_BITS, RS_THREADS = 256, RS_WAVES = RS_THREADS / 64, RS_ITEMS = 16, RS_TILE = RS_THREADS * RS_ITEMS;
+constexpr int SW_THREADS = 512, SW_WAVES = SW_THREADS / 64, SW_ITEMS = RS_TILE / SW_THREADS;  // rs_sweep_kernel: two waves per SIMD share the ranking
+constexpr int RS_MAX_PASSES = 4, RS_MAX_KEY_BITS = RS_MAX_PASSES * RS_BITS;  // beyond that the rocPRIM path stays (never here: ids < 2^36)
+constexpr int RS_MAX_TILES = 512;  // every block reads the counts of the tiles before it: quadratic, the library sort takes over beyond 2M keys
+constexpr int EM_ITEMS = 4, EM_TILE = RS_THREADS * EM_ITEMS;  // rs_emit_kernel: small tiles, the whole chip
+constexpr uint32_t RS_FLAG = 0x80000000u;
+
+__device__ __forceinline__ void rs_publish(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v | RS_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t rs_poll(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ghist: [passes][RS_RADIX] global digit histograms.  Nothing is zeroed by a launch of its own: workgroup 0 zeroes ghist and then raises
+// `ready` to this call's ticket (a process-wide counter: no earlier call, no stale workspace content and no graph replay — rs_emit_kernel
+// puts 0 back — can hold the same value); the other workgroups build their LDS histograms meanwhile and wait for the ticket before their
+// global atomics.  Also zeroes what the later kernels expect to find zero: the granules of this tile (state: [passes][ntiles][RS_RADIX];
+// tile_state: EM tiles) and uniq[].
+__global__ __launch_bounds__(SW_THREADS) void rs_ghist_kernel(const uint64_t* __restrict__ keys, int64_t n, int passes, int ntiles, uint32_t* __restrict__ ghist,
+                                                              uint32_t* __restrict__ state, uint32_t* __restrict__ tile_state, int64_t* __restrict__ uniq,
+                                                              unsigned long long* __restrict__ ready, unsigned long long ticket) {
+    __shared__ uint32_t h[RS_MAX_PASSES][RS_RADIX];
+    const int tile = blockIdx.x;
+    if (tile == 0) {
+        for (int b = threadIdx.x; b < passes * RS_RADIX; b += SW_THREADS) __hip_atomic_store(ghist + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();  // every lane's stores are issued; the release below orders them before the ticket
+        if (threadIdx.x == 0) __hip_atomic_store(ready, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int b = threadIdx.x; b < RS_MAX_PASSES * RS_RADIX; b += SW_THREADS) (&h[0][0])[b] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)tile * RS_TILE;
+#pragma unroll
+    for (int r = 0; r < SW_ITEMS; ++r) {
+        const int64_t i = base + r * SW_THREADS + threadIdx.x;
+        if (i < n) {
+            const uint64_t k = keys[i];
+            uniq[i] = 0;
+            for (int ps = 0; ps < passes; ++ps) atomicAdd(&h[ps][(int)((k >> (ps * RS_BITS)) & (RS_RADIX - 1))], 1u);
+        }
+    }
+    if (threadIdx.x < RS_TILE / EM_TILE) tile_state[tile * (RS_TILE / EM_TILE) + threadIdx.x] = 0;
+    for (int ps = 0; ps < passes; ++ps) {
+        const size_t row = ((size_t)ps * ntiles + tile) * RS_RADIX;
+        for (int b = threadIdx.x; b < RS_RADIX; b += SW_THREADS) state[row + b] = 0;
+    }
+    if (tile != 0 && threadIdx.x == 0)
+        while (__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ticket) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < passes * RS_RADIX; b += SW_THREADS) {
+        const uint32_t v = (&h[0][0])[b];
+        if (v) atomicAdd(&ghist[b], v);
+    }
+}
+
+// pay_in == nullptr: the payload of key i is i (first pass).  ghist: this pass's global digit histogram; state: [ntiles][RS_RADIX]
+// granules of this pass (zero on entry).
+__global__ __launch_bounds__(SW_THREADS) void rs_sweep_kernel(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ pay_in, int64_t n, int shift,
+                                                              const uint32_t* __restrict__ ghist, uint32_t* __restrict__ state, uint64_t* __restrict__ keys_out,
+                                                              int32_t* __restrict__ pay_out) {
+    __shared__ int32_t off[RS_RADIX];            // global position of this tile's first key of each digit
+    __shared__ int32_t cw[SW_WAVES][RS_RADIX];   // per-wave running digit counts, then per-wave bases
+    __shared__ int32_t wsum[SW_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
+    const int64_t wbase_idx = (int64_t)tile * RS_TILE + (int64_t)wave * 64 * SW_ITEMS;
+    uint64_t key[SW_ITEMS];
+    int32_t pay[SW_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SW_ITEMS; ++r) {
+        const int64_t i = wbase_idx + r * 64 + lane;
+        key[r] = i < n ? keys_in[i] : 0ull;
+        pay[r] = (i < n && pay_in) ? pay_in[i] : (int32_t)i;
+    }
+    for (int b = tid; b < SW_WAVES * RS_RADIX; b += SW_THREADS) (&cw[0][0])[b] = 0;
+    __syncthreads();
+    // ---- stable ranking.  Wave w owns the contiguous keys [w * 64 * ITEMS, (w + 1) * 64 * ITEMS) of the tile, round r the 64 keys at
+    // r * 64: positions grow with (wave, round, lane), and so do the ranks handed out below.
+    int32_t rank[SW_ITEMS];
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < SW_ITEMS; ++r) {
+        const int64_t i = wbase_idx + r * 64 + lane;
+        const bool valid = i < n;
+        const int d = (int)((key[r] >> shift) & (RS_RADIX - 1));
+        uint64_t m = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+        for (int bit = 0; bit < RS_BITS; ++bit) {
+            const uint64_t bb = __builtin_amdgcn_ballot_w64((d >> bit) & 1);
+            m &= ((d >> bit) & 1) ? bb : ~bb;
+        }
+        const int before = __builtin_popcountll(m & lt), cnt = __builtin_popcountll(m);
+        int32_t prev = 0;
+        if (valid) prev = cw[wave][d];
+        __builtin_amdgcn_wave_barrier();  // every lane has read the counter before its group's leader advances it
+        if (valid && before == 0) cw[wave][d] = prev + cnt;
+        __builtin_amdgcn_wave_barrier();
+        rank[r] = prev + before;
+    }
+    __syncthreads();
+    // ---- thread t owns digit t: per-wave bases, then the tile's count is published (one flagged 4-byte granule) before anything waits
+    static_assert(RS_RADIX == SW_THREADS, "one digit per thread");
+    {
+        int32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < SW_WAVES; ++w) {
+            const int32_t c = cw[w][tid];
+            cw[w][tid] = run;
+            run += c;
+        }
+        rs_publish(state + (int64_t)tile * RS_RADIX + tid, (uint32_t)run);
+    }
+    // ---- keys of the digit in earlier tiles: their granules, RS_POLL in flight, re-polled until every flag is up
+    constexpr int RS_POLL = 24;
+    int32_t prefix = 0;
+    for (int t0 = 0; t0 < tile; t0 += RS_POLL) {
+        uint32_t v[RS_POLL];
+        bool done;
+        do {
+            done = true;
+#pragma unroll
+            for (int u = 0; u < RS_POLL; ++u) v[u] = (t0 + u < tile) ? rs_poll(state + (int64_t)(t0 + u) * RS_RADIX + tid) : RS_FLAG;
+#pragma unroll
+            for (int u = 0; u < RS_POLL; ++u) done = done && (v[u] & RS_FLAG);
+        } while (!done);
+#pragma unroll
+        for (int u = 0; u < RS_POLL; ++u) prefix += (int32_t)(v[u] & ~RS_FLAG);
+    }
+    // ---- exclusive scan of the global digit totals
+    {
+        const int32_t total = (int32_t)ghist[tid];
+        int32_t x = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int32_t before = x - total;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        off[tid] = before + prefix;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < SW_ITEMS; ++r) {
+        const int64_t i = wbase_idx + r * 64 + lane;
+        if (i < n) {
+            const int d = (int)((key[r] >> shift) & (RS_RADIX - 1));
+            const int64_t pos = (int64_t)off[d] + cw[wave][d] + rank[r];
+            keys_out[pos] = key[r];
+            pay_out[pos] = pay[r];
+        }
+    }
+}
+
+// unique index of every sorted position = heads in earlier tiles (granule hand-off) + inclusive scan inside the tile; emits uniq / inverse /
+// seg_offsets / count.  tile_state: [ntiles] granules, zero on entry.
+__global__ __launch_bounds__(RS_THREADS) void rs_emit_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ perm, int64_t n,
+                                                             uint32_t* __restrict__ tile_state, int64_t* __restrict__ uniq, int64_t* __restrict__ inverse,
+                                                             int32_t* __restrict__ seg_offsets, int64_t* __restrict__ num_unique, unsigned long long* __restrict__ ready) {
+    __shared__ int32_t red[RS_WAVES], wsum[RS_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
+    if (tile == 0 && tid == 0) *ready = 0ull;  // a replay of a captured call (same ticket) waits again
+    // thread t owns EM_ITEMS consecutive positions: local head count, block scan of the thread sums
+    const int64_t k0 = (int64_t)tile * EM_TILE + (int64_t)tid * EM_ITEMS;
+    uint64_t kk[EM_ITEMS];
+    int32_t pp[EM_ITEMS];
+    bool head[EM_ITEMS];
+    uint64_t prev = (k0 > 0 && k0 - 1 < n) ? keys[k0 - 1] : 0ull;
+    int32_t mine = 0;
+#pragma unroll
+    for (int r = 0; r < EM_ITEMS; ++r) {
+        const int64_t k = k0 + r;
+        kk[r] = k < n ? keys[k] : 0ull;
+        pp[r] = k < n ? perm[k] : 0;
+        head[r] = k < n && (k == 0 || kk[r] != prev);
+        prev = kk[r];
+        mine += head[r] ? 1 : 0;
+    }
+    int32_t x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int32_t tile_total = 0;
+    for (int w = 0; w < RS_WAVES; ++w) tile_total += wsum[w];
+    if (tid == 0) rs_publish(tile_state + tile, (uint32_t)tile_total);
+    // heads in earlier tiles
+    int32_t b = 0;
+    for (int t = tid; t < tile; t += RS_THREADS) {
+        uint32_t v;
+        do {
+            v = rs_poll(tile_state + t);
+        } while (!(v & RS_FLAG));
+        b += (int32_t)(v & ~RS_FLAG);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
+    if (lane == 0) red[wave] = b;
+    __syncthreads();
+    int32_t base = 0;
+    for (int w = 0; w < RS_WAVES; ++w) base += red[w];
+    int32_t before = base + x - mine;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    int32_t u = before - 1;  // unique index of the position before this thread's first one
+#pragma unroll
+    for (int r = 0; r < EM_ITEMS; ++r) {
+        const int64_t k = k0 + r;
+        if (k < n) {
+            if (head[r]) {
+                ++u;
+                uniq[u] = (int64_t)kk[r];
+                seg_offsets[u] = (int32_t)k;
+            }
+            inverse[pp[r]] = u;
+            if (k == n - 1) {
+                seg_offsets[u + 1] = (int32_t)n;
+                *num_unique = (int64_t)u + 1;
+            }
+        }
+    }
+}
+
 struct SortPlan {
     size_t keys_off, scan_off, temp_off, temp_bytes, total;
 };
@@ -115,6 +352,12 @@ static int make_plan(int64_t n, SortPlan& p) {
     p.scan_off = align_up((size_t)nn * 8, 256);
     p.temp_off = p.scan_off + align_up((size_t)nn * 4 * 2, 256);  // flags + scan
     p.temp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
+    {   // the hand-written sort: second key buffer, two payload buffers, histogram matrix, per-tile head counts
+        const size_t tiles = (size_t)(nn + RS_TILE - 1) / RS_TILE;
+        const size_t own = align_up((size_t)nn * 8, 256) + 2 * align_up((size_t)nn * 4, 256) +
+                           align_up(((size_t)RS_MAX_PASSES * RS_RADIX + (size_t)RS_MAX_PASSES * tiles * RS_RADIX + tiles * (RS_TILE / EM_TILE) + 4) * 4, 256);
+        if (tiles <= (size_t)RS_MAX_TILES && own > p.temp_bytes) p.temp_bytes = own;
+    }
     p.total = p.temp_off + align_up(p.temp_bytes, 256) + 256;
     return MARIUS_OK;
 }
@@ -147,17 +390,53 @@ extern "C" int marius_sort_unique(const int64_t* ids, int64_t n, int32_t key_bit
     }
     MARIUS_REQUIRE(workspace_bytes >= p.total, "sort_unique: workspace too small (%zu < %zu)", workspace_bytes, p.total);
     ProfScope ps(PROF_SORT_UNIQUE, st);
-    // uniq[U..n) reads as id 0 so that capacity-sized gathers downstream stay in bounds without a host sync on U
-    if (hipMemsetAsync(uniq, 0, (size_t)n * sizeof(int64_t), st) != hipSuccess) {
-        set_last_error("sort_unique: memset failed");
-        return MARIUS_ERR_HIP;
-    }
+    // uniq[U..n) reads as id 0 so that capacity-sized gathers downstream stay in bounds without a host sync on U (own path: zeroed by
+    // rs_ghist_kernel; library path: the memset below)
     char* ws = (char*)workspace;
     uint64_t* keys = (uint64_t*)(ws + p.keys_off);
     int32_t* flags = (int32_t*)(ws + p.scan_off);
     int32_t* scan = flags + n;
     void* tmp = ws + p.temp_off;
     size_t tmp_bytes = p.temp_bytes;
+    {
+        const char* lib = getenv("MARIUS_SORT");  // MARIUS_SORT=rocprim: the library chain (A/B runs)
+        if (key_bits <= RS_MAX_KEY_BITS && n <= (int64_t)RS_MAX_TILES * RS_TILE && !(lib && lib[0] == 'r')) {
+            const int ntiles = (int)cdiv(n, RS_TILE);
+            const int passes = (key_bits + RS_BITS - 1) / RS_BITS;
+            char* t = (char*)tmp;
+            uint64_t* keys2 = (uint64_t*)t;
+            t += align_up((size_t)n * 8, 256);
+            int32_t* payA = (int32_t*)t;
+            t += align_up((size_t)n * 4, 256);
+            int32_t* payB = (int32_t*)t;
+            t += align_up((size_t)n * 4, 256);
+            // [passes][RADIX] global histograms, [passes][ntiles][RADIX] granules, [etiles] head-count granules
+            uint32_t* ghist = (uint32_t*)t;
+            uint32_t* state = ghist + (size_t)RS_MAX_PASSES * RS_RADIX;
+            uint32_t* tile_state = state + (size_t)passes * ntiles * RS_RADIX;
+            static std::atomic<unsigned long long> tickets{1};
+            unsigned long long* ready = (unsigned long long*)(((uintptr_t)(tile_state + (size_t)ntiles * (RS_TILE / EM_TILE)) + 7) & ~(uintptr_t)7);
+            rs_ghist_kernel<<<dim3((unsigned)ntiles), dim3(SW_THREADS), 0, st>>>((const uint64_t*)ids, n, passes, ntiles, ghist, state, tile_state, uniq, ready, tickets.fetch_add(1));
+            // ping-pong so that the last pass lands in (keys, perm)
+            const uint64_t* kin = (const uint64_t*)ids;
+            const int32_t* pin = nullptr;
+            for (int ps_ = 0; ps_ < passes; ++ps_) {
+                const bool to_keys = ((passes - 1 - ps_) % 2) == 0;
+                uint64_t* kout = to_keys ? keys : keys2;
+                int32_t* pout = (ps_ == passes - 1) ? perm : (to_keys ? payA : payB);
+                rs_sweep_kernel<<<dim3((unsigned)ntiles), dim3(SW_THREADS), 0, st>>>(kin, pin, n, ps_ * RS_BITS, ghist + (size_t)ps_ * RS_RADIX,
+                                                                                     state + (size_t)ps_ * ntiles * RS_RADIX, kout, pout);
+                kin = kout;
+                pin = pout;
+            }
+            rs_emit_kernel<<<dim3((unsigned)cdiv(n, EM_TILE)), dim3(RS_THREADS), 0, st>>>(keys, perm, n, tile_state, uniq, inverse, seg_offsets, num_unique_dev, ready);
+            return check_launch("sort_unique");
+        }
+    }
+    if (hipMemsetAsync(uniq, 0, (size_t)n * sizeof(int64_t), st) != hipSuccess) {
+        set_last_error("sort_unique: memset failed");
+        return MARIUS_ERR_HIP;
+    }
     hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint64_t*)ids, keys, rocprim::counting_iterator<int32_t>(0),
                                              perm, (size_t)n, 0u, (unsigned)key_bits, st);
     if (e != hipSuccess) {

@@ -148,7 +148,8 @@ def test_select_edges(H, dev):
 
 
 # ------------------------------------------------------------------------------------------------ unique map
-@pytest.mark.parametrize("n,hi", [(1, 5), (12, 6), (12000, 14541), (200000, 86054151), (200000, 300)])
+@pytest.mark.parametrize("n,hi", [(1, 5), (12, 6), (12000, 14541), (200000, 86054151), (200000, 300), (4095, 1 << 20), (4096, 1 << 20), (4097, 1 << 20),
+                                  (16385, 1), (70001, (1 << 36) - 5), (70001, (1 << 40) + 3), (2200000, 86054151)])
 def test_sort_unique_matches_map_tensors(H, dev, n, hi):
     g = torch.Generator().manual_seed(n + hi)
     parts = [torch.randint(hi, (n // 4 + 1,), generator=g) for _ in range(4)]
@@ -165,6 +166,46 @@ def test_sort_unique_matches_map_tensors(H, dev, n, hi):
     sorted_ids = ids.cpu()[perm]
     assert torch.equal(sorted_ids, torch.sort(ids.cpu(), stable=True).values)
     assert torch.equal(perm, torch.sort(ids.cpu(), stable=True).indices)  # stable order
+
+
+def test_sort_unique_reuses_its_workspace_across_calls_and_sizes(H, dev):
+    """The hand-written sort keeps no state between calls: the same workspace sorts different inputs of different sizes back to back (the granule
+    arrays are re-zeroed by the call's first kernel, the histogram ticket is per call), and a call on another stream's workspace in between
+    does not disturb it."""
+    g = torch.Generator().manual_seed(99)
+    um, other = H.UniqueMap(150000, dev), H.UniqueMap(5000, dev)
+    for n, hi in ((150000, 1 << 27), (4097, 300), (150000, 1000), (1, 2), (90000, 1 << 27), (150000, 1 << 27)):
+        ids = torch.randint(hi, (n,), generator=g)
+        other.run(torch.randint(77, (5000,), generator=g).to(dev), 7)
+        um.run(ids.to(dev), 27)
+        u, inv = torch.unique(ids, return_inverse=True)
+        U = int(um.count.item())
+        assert U == u.numel() and torch.equal(um.uniq[:U].cpu(), u) and torch.equal(um.inverse[:n].cpu(), inv)
+        assert torch.equal(um.perm[:n].cpu().long(), torch.sort(ids, stable=True).indices)
+
+
+def test_sort_unique_replays_from_a_captured_graph(H, dev):
+    """A captured call carries its histogram ticket as a constant: the replay must still wait for the histogram to be zeroed (rs_emit_kernel puts
+    the ready word back to 0), so every replay of the graph sorts the then-current content of the input buffer."""
+    g = torch.Generator().manual_seed(5)
+    n = 50000
+    ids = torch.randint(1 << 27, (n,), generator=g).to(dev)
+    um = H.UniqueMap(n, dev)
+    um.run(ids, 27)  # warm
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(graph, stream=s):
+            um.run(ids, 27)
+    for trial in range(3):
+        fresh = torch.randint(1 << 27, (n,), generator=g)
+        ids.copy_(fresh.to(dev))
+        graph.replay()
+        torch.cuda.synchronize()
+        u, inv = torch.unique(fresh, return_inverse=True)
+        U = int(um.count.item())
+        assert U == u.numel() and torch.equal(um.uniq[:U].cpu(), u) and torch.equal(um.inverse[:n].cpu(), inv)
 
 
 def test_sort_unique_empty(H, dev):
