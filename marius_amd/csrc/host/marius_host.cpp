@@ -390,7 +390,7 @@ void Batch::accumulateGradients(float learning_rate) {
 }
 void Batch::clear() {
     unique_node_indices_ = node_embeddings_ = node_embeddings_grad_ = node_gradients_ = node_state_update_ = node_embeddings_state_ = Tensor();
-    edges_ = src_neg_indices_ = dst_neg_indices_ = src_neg_indices_mapping_ = dst_neg_indices_mapping_ = Tensor();
+    edges_ = global_edges_ = table_ = src_neg_indices_ = dst_neg_indices_ = src_neg_indices_mapping_ = dst_neg_indices_mapping_ = Tensor();
     src_neg_filter_ = dst_neg_filter_ = occ_perm_ = occ_inverse_ = occ_seg_offsets_ = num_unique_dev_ = Tensor();
     rel_uniq_ = rel_inverse_ = rel_perm_ = rel_seg_ = rel_count_ = Tensor();
 }
@@ -991,7 +991,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> Model::forward_lp(shared_ptr<Batch> b
 
 std::tuple<Tensor, Tensor, Tensor, Tensor> Model::forward_lp_train(shared_ptr<Batch> batch) {
     if (decoder_->decoder_method_ != EdgeDecoderMethod::CORRUPT_NODE) return forward_lp(batch, true);
-    return node_corrupt_forward(decoder_, batch->edges_, batch->node_embeddings_, batch->dst_neg_indices_mapping_, batch->src_neg_indices_mapping_, &ctx_,
+    const bool direct = batch->table_.defined();
+    return node_corrupt_forward(decoder_, direct ? batch->global_edges_ : batch->edges_, direct ? batch->table_ : batch->node_embeddings_,
+                                direct ? batch->dst_neg_indices_ : batch->dst_neg_indices_mapping_,
+                                direct ? batch->src_neg_indices_ : batch->src_neg_indices_mapping_, &ctx_,
                                 batch->dst_neg_filter_, batch->src_neg_filter_, loss_function_ ? loss_function_->reduction_type_ : LossReduction::SUM,
                                 loss_function_ ? loss_function_->kind() : MARIUS_LOSS_SOFTMAX_CE, loss_function_ ? loss_function_->margin() : 0.f,
                                 MARIUS_LP_TRAIN_ONLY);
@@ -1169,8 +1172,13 @@ void Model::train_batch(shared_ptr<Batch> batch, bool call_step) {
     if (batch->node_embeddings_.defined()) batch->accumulateGradients(sparse_lr_);
 }
 
-void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor state) {
+void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor state, bool table_direct) {
+    if (table_direct) {
+        if (!batch->global_edges_.defined()) throw MariusRuntimeException("backward_into_tables: table-direct step without the batch's global-id edges");
+        batch->table_ = table;
+    }
     forward_lp_train(batch);
+    batch->table_ = Tensor();
     model_backward(*this, batch);
     // The relation-table update (6 small, latency-bound launches) and the node-table update are independent: run the former on a side
     // stream underneath the latter and join before returning (the next forward reads the relation tables).
@@ -1551,6 +1559,7 @@ shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
     mcheck(marius_assemble_ids(ip(edges), B, cols, ip(batch->src_neg_indices_), ip(batch->dst_neg_indices_), CN, ip(all_ids_), st));
     mcheck(marius_sort_unique(ip(all_ids_), L, key_bits_, ip(uniq_), ip(inverse_), perm_.data_ptr<int32_t>(), seg_.data_ptr<int32_t>(), ip(count_),
                               sort_ws_.data_ptr(), (size_t)sort_ws_.numel(), st));
+    batch->global_edges_ = edges;
     batch->edges_ = torch::empty({B, cols}, i64(dev));
     mcheck(marius_remap_edges(ip(edges), ip(inverse_), B, cols, ip(batch->edges_), st));
     batch->src_neg_indices_mapping_ = inverse_.narrow(0, 2 * B, CN).view(batch->src_neg_indices_.sizes());
@@ -1604,9 +1613,14 @@ void SynchronousTrainer::train_one(bool fused) {
         auto batch = dataloader_->getBatch(/*exact_unique=*/false);  // no host sync anywhere in the step
         // capacity-sized id list (no host sync on the unique count): gather the U real rows only
         auto mem = std::dynamic_pointer_cast<InMemory>(dataloader_->node_embeddings_);
-        batch->node_embeddings_ = (mem && batch->num_unique_dev_.defined()) ? mem->indexReadCounted(batch->unique_node_indices_, batch->num_unique_dev_)
-                                                                              : dataloader_->node_embeddings_->indexRead(batch->unique_node_indices_);
-        model_->backward_into_tables(batch, dataloader_->node_embeddings_->data_, dataloader_->node_embeddings_state_->data_);
+        // A device-resident table is read in place by global id: no gathered [U, d] copy is written and re-read (MARIUS_TABLE_DIRECT=0: the
+        // gathered form, for A/B runs).  Buffer-backed storage addresses rows through its own map and keeps the gather.
+        static const bool direct_env = [] { const char* e = getenv("MARIUS_TABLE_DIRECT"); return !(e && e[0] == '0'); }();
+        const bool direct = mem && direct_env && mem->data_.is_cuda();
+        if (!direct)
+            batch->node_embeddings_ = (mem && batch->num_unique_dev_.defined()) ? mem->indexReadCounted(batch->unique_node_indices_, batch->num_unique_dev_)
+                                                                                  : dataloader_->node_embeddings_->indexRead(batch->unique_node_indices_);
+        model_->backward_into_tables(batch, dataloader_->node_embeddings_->data_, dataloader_->node_embeddings_state_->data_, direct);
     } else {  // API-granular path, call for call the reference's loop (trainer.cpp:106-138)
         auto batch = dataloader_->getBatch(true);
         dataloader_->loadGPUParameters(batch);

@@ -176,6 +176,8 @@ class Batch {
     int64_t start_idx_ = 0;
     int64_t batch_size_ = 0;
     Tensor edges_;                      // [B, 3|2] int64 (global ids before map, batch-local after)
+    Tensor global_edges_;               // [B, 3|2] int64 global ids, kept beside the batch-local copy (table-direct fused step)
+    Tensor table_;                      // defined: the fused step reads node rows straight from this table by global id (no gathered copy)
     Tensor unique_node_indices_;        // [U] ascending
     Tensor node_embeddings_;            // [U, d]
     Tensor node_embeddings_state_;      // [U, d]
@@ -452,7 +454,9 @@ class Model : public torch::nn::Module {
     // dense optimizer by name (ModelConfig::dense_optimizer, model.cpp:381-440): "ADAGRAD", "ADAM" or "SGD"
     void setup_optimizer(const std::string& type, float lr, float eps, float beta_1, float beta_2, float weight_decay, bool amsgrad);
     // fused tail used by the trainer for DEVICE_MEMORY tables: backward products -> table/state update in one call
-    void backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor state);
+    // table_direct: the decoder kernels index `table` by the batch's global ids (global_edges_, *_neg_indices_) instead of a gathered
+    // [U, d] copy by batch-local ids: the occurrence order, and with it every gradient and update, is unchanged
+    void backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor state, bool table_direct = false);
     // sharded node table (sharded_trainer.h): forward + loss + backward, then the per-unique-row gradient sums into grad_out [>= U, d] for
     // the owners of the rows.  local_relation_step: touched-rows Adagrad step on this replica's relation tables (replicas are averaged every
     // gpu_sync_interval steps); otherwise the dense gradients are left in relations_grad_ / inverse_relations_grad_ for an all-reduce + step()
