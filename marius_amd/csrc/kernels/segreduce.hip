@@ -232,33 +232,21 @@ __global__ __launch_bounds__(256) void adagrad_unique_rows_kernel(const float* _
                                                                   const int64_t* __restrict__ inverse, int64_t n, const int64_t* __restrict__ uniq,
                                                                   float* __restrict__ table, float* __restrict__ state, int64_t ld, int vpr,
                                                                   float lr, float eps, const float* __restrict__ occ, int64_t occ_ld,
-                                                                  const int32_t* __restrict__ seg_offsets, const float* __restrict__ carry, int dpad) {
+                                                                  const int32_t* __restrict__ seg_offsets) {
 #pragma clang fp contract(off)
     const int64_t U = inverse[perm[n - 1]] + 1;
     const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
     constexpr int UNR = 4;
     int64_t rows[UNR], ids[UNR];
     const float* grow[UNR];  // the row's gradient: the reduced sum, or (segment of one occurrence) that occurrence's row itself
-    int c0[UNR], c1[UNR], slot[UNR];  // a segment that crosses chunk boundaries: its carries live in chunks [c0, c1] (c1 < 0: not crossing)
 #pragma unroll
     for (int k = 0; k < UNR; ++k) {
         rows[k] = ((int64_t)blockIdx.x * UNR + k) * TY + ty;
         ids[k] = rows[k] < U ? uniq[rows[k]] : -1;
         grow[k] = g + rows[k] * g_ld;
-        c0[k] = 0;
-        c1[k] = -1;
-        slot[k] = 0;
-        if (ids[k] >= 0) {
+        if (ids[k] >= 0 && occ) {
             const int s0 = seg_offsets[rows[k]], s1 = seg_offsets[rows[k] + 1];
-            if (occ && s1 - s0 == 1) {
-                grow[k] = occ + (int64_t)perm[s0] * occ_ld;
-            } else if (s0 / SEG_R != (s1 - 1) / SEG_R) {
-                // what seg_fixup_kernel does for the stand-alone reduction, in the same order: the start chunk's partial (slot 1 unless the
-                // segment opens the chunk), then slot 0 of every following chunk up to the one holding the last occurrence
-                c0[k] = s0 / SEG_R;
-                c1[k] = (s1 - 1) / SEG_R;
-                slot[k] = (s0 % SEG_R) ? 1 : 0;
-            }
+            if (s1 - s0 == 1) grow[k] = occ + (int64_t)perm[s0] * occ_ld;
         }
     }
     for (int c = tx; c < vpr; c += TX) {
@@ -266,32 +254,9 @@ __global__ __launch_bounds__(256) void adagrad_unique_rows_kernel(const float* _
 #pragma unroll
         for (int k = 0; k < UNR; ++k) {
             if (ids[k] >= 0) {
-                if (c1[k] < 0) load_vec<VEC>(grow[k] + c * VEC, gv[k]);
+                load_vec<VEC>(grow[k] + c * VEC, gv[k]);
                 load_vec<VEC>(table + ids[k] * ld + c * VEC, wv[k]);
                 load_vec<VEC>(state + ids[k] * ld + c * VEC, sv[k]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < UNR; ++k) {
-            if (ids[k] >= 0 && c1[k] >= 0) {  // rare (hub rows): FIX_U carry loads in flight
-                constexpr int FIX_U = 8;
-                load_vec<VEC>(carry + ((int64_t)c0[k] * 2 + slot[k]) * dpad + c * VEC, gv[k]);
-                int ch = c0[k] + 1;
-                for (; ch + FIX_U - 1 <= c1[k]; ch += FIX_U) {
-                    float t[FIX_U][VEC];
-#pragma unroll
-                    for (int j = 0; j < FIX_U; ++j) load_vec<VEC>(carry + ((int64_t)(ch + j) * 2) * dpad + c * VEC, t[j]);
-#pragma unroll
-                    for (int j = 0; j < FIX_U; ++j)
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) gv[k][e] += t[j][e];
-                }
-                for (; ch <= c1[k]; ++ch) {
-                    float t[VEC];
-                    load_vec<VEC>(carry + ((int64_t)ch * 2) * dpad + c * VEC, t);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) gv[k][e] += t[e];
-                }
             }
         }
 #pragma unroll
@@ -316,14 +281,14 @@ __global__ __launch_bounds__(256) void adagrad_unique_rows_kernel(const float* _
 }
 
 template <class Apply>
-static int launch_seg(const SegArgs& a, const Apply& apply, int vec, hipStream_t st, bool fixup = true) {
+static int launch_seg(const SegArgs& a, const Apply& apply, int vec, hipStream_t st) {
     const int64_t nchunks = cdiv(a.n, SEG_R);
     dim3 grid((unsigned)cdiv(nchunks, 4)), block(256);
     const int per = cdiv(a.d, 64 * vec);  // column iterations per lane
 #define SEG_LAUNCH(V, N)                                             \
     do {                                                             \
         seg_reduce_kernel<V, N, Apply><<<grid, block, 0, st>>>(a, apply); \
-        if (fixup) seg_fixup_kernel<V, N, Apply><<<grid, block, 0, st>>>(a, apply);  \
+        seg_fixup_kernel<V, N, Apply><<<grid, block, 0, st>>>(a, apply);  \
     } while (0)
     if (vec == 4) {
         if (per <= 1) SEG_LAUNCH(4, 1);
@@ -413,8 +378,7 @@ extern "C" int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld
     const char* ns = getenv("MARIUS_SEG_NO_SKIP");
     const bool skip = !(ns && ns[0] == '1') && vec <= vsum;
     a.skip_singletons = skip ? 1 : 0;
-    // boundary-crossing segments are finished from the chunk carries by the update kernel itself: no fix-up launch
-    rc = launch_seg(a, ap, vsum, st, /*fixup=*/false);
+    rc = launch_seg(a, ap, vsum, st);
     if (rc) return rc;
     // (2) row-parallel Adagrad + scatter (ids ascending and unique: race-free, fully pipelined loads)
     const int vpr = d / vec;
@@ -424,10 +388,10 @@ extern "C" int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld
     dim3 block(tx, ty, 1), grid((unsigned)cdiv(n, (int64_t)ty * 4));
     const float* occ = skip ? rows : nullptr;
     if (vec == 4)
-        adagrad_unique_rows_kernel<4><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets, a.carry, a.dpad);
+        adagrad_unique_rows_kernel<4><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets);
     else if (vec == 2)
-        adagrad_unique_rows_kernel<2><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets, a.carry, a.dpad);
+        adagrad_unique_rows_kernel<2><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets);
     else
-        adagrad_unique_rows_kernel<1><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets, a.carry, a.dpad);
+        adagrad_unique_rows_kernel<1><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets);
     return check_launch("segment_adagrad_scatter");
 }
