@@ -47,17 +47,22 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 enum { FLASH_FWD = 0, FLASH_DADJ = 1, FLASH_DNEG = 2 };
 
-constexpr int FL_WAVES = 4, FL_NT = 64 * FL_WAVES, FL_XT = 32 * FL_WAVES, FL_YB = 32;
+// FL_WAVES_N=8 (256-row stationary tile, one workgroup per CU, six slots) halves the streamed bytes per flop; measured slower at the
+// bench shape (scores 82 vs 72 us, dAdj 141 vs 134, dNeg 148 vs 138): the streamed operand is not what the kernels wait for.
+#ifndef FL_WAVES_N
+#define FL_WAVES_N 4
+#endif
+constexpr int FL_WAVES = FL_WAVES_N, FL_NT = 64 * FL_WAVES, FL_XT = 32 * FL_WAVES, FL_YB = 32;
 // LDS ring slots / workgroups per CU: the forward needs 122 VGPRs, so three workgroups fit a CU if each keeps to three slots
 #ifndef FL_FWD_SLOTS
 #define FL_FWD_SLOTS 3
 #endif
-__host__ __device__ constexpr int fl_slots(int mode) { return mode == 0 ? FL_FWD_SLOTS : 4; }
-__host__ __device__ constexpr int fl_wg_per_cu(int mode) { return mode == 0 ? (FL_FWD_SLOTS == 3 ? 3 : 2) : 2; }
+__host__ __device__ constexpr int fl_slots(int mode) { return FL_WAVES == 8 ? 6 : (mode == 0 ? FL_FWD_SLOTS : 4); }
+__host__ __device__ constexpr int fl_wg_per_cu(int mode) { return FL_WAVES == 8 ? 1 : (mode == 0 ? (FL_FWD_SLOTS == 3 ? 3 : 2) : 2); }
 constexpr float FL_LOG2E = 1.4426950408889634f, FL_LN2 = 0.6931471805599453f;
 
 __host__ __device__ constexpr int fl_pitch(int KS) { return 64 * KS + 16; }                                    // bytes per record
-__host__ __device__ constexpr int fl_slot_bytes(int KS) { return (32 * fl_pitch(KS) + 4095) / 4096 * 4096; }   // DMA granule: 4 waves x 1 KB
+__host__ __device__ constexpr int fl_slot_bytes(int KS) { return (32 * fl_pitch(KS) + FL_WAVES * 1024 - 1) / (FL_WAVES * 1024) * (FL_WAVES * 1024); }   // DMA granule: 4 waves x 1 KB
 __host__ __device__ constexpr int fl_rho(int y) { return 4 * (y & 3) + ((y >> 2) & 3) + (y & ~15); }          // logical -> physical slot in a 16-group
 __host__ __device__ constexpr int fl_pi(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }         // swap bits 2 and 3
 
@@ -242,7 +247,7 @@ template <int KS, int MODE, bool STORE_S>
 __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashArgs a) {
     constexpr int KP = 16 * KS, P = fl_pitch(KS), SLOT = fl_slot_bytes(KS), NSLOT = fl_slots(MODE);
     constexpr int NCT = (KP + 31) / 32;       // 32-column tiles of the gradient output
-    constexpr int DMA_PER_WAVE = SLOT / 4096;  // 1 KB wave-instructions per wave and tile
+    constexpr int DMA_PER_WAVE = SLOT / (FL_WAVES * 1024);  // 1 KB wave-instructions per wave and tile
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5, t16 = lane & 15, c16 = (lane >> 4) & 1;
