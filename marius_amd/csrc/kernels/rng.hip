@@ -154,10 +154,38 @@ __global__ __launch_bounds__(256) void deg_filter_kernel(const int64_t* __restri
 }
 
 // ---- host-side generator (same stream; used for the per-epoch randperm, which is a serial swap chain) ----
+static inline uint32_t host_mix(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return c ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+}
+// in-place regeneration in three index ranges (no wrap-around arithmetic inside the loops: they vectorise)
 static void host_twist(uint32_t* p) {
-    for (int i = 0; i < MT_N; i++) {
-        uint32_t y = (p[i] & 0x80000000u) | (p[(i + 1) % MT_N] & 0x7fffffffu);
-        p[i] = p[(i + MT_M) % MT_N] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    int i = 0;
+    for (; i < MT_N - MT_M; i++) p[i] = host_mix(p[i], p[i + 1], p[i + MT_M]);
+    for (; i < MT_N - 1; i++) p[i] = host_mix(p[i], p[i + 1], p[i + MT_M - MT_N]);
+    p[MT_N - 1] = host_mix(p[MT_N - 1], p[0], p[MT_M - 1]);
+}
+static inline uint32_t host_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+// n tempered words into out, whole state blocks at a time
+static void host_fill(uint32_t* st, uint32_t* out, int64_t n) {
+    int64_t done = 0;
+    while (done < n) {
+        if (st[MT_N] >= (uint32_t)MT_N) {
+            host_twist(st);
+            st[MT_N] = 0;
+        }
+        const int idx = (int)st[MT_N];
+        int64_t take = MT_N - idx;
+        if (take > n - done) take = n - done;
+        for (int64_t j = 0; j < take; j++) out[done + j] = host_temper(st[idx + j]);
+        st[MT_N] = (uint32_t)(idx + take);
+        done += take;
     }
 }
 static inline uint32_t host_next(uint32_t* st) {
@@ -165,12 +193,7 @@ static inline uint32_t host_next(uint32_t* st) {
         host_twist(st);
         st[MT_N] = 0;
     }
-    uint32_t y = st[st[MT_N]++];
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return y;
+    return host_temper(st[st[MT_N]++]);
 }
 
 }  // namespace marius
@@ -183,30 +206,51 @@ extern "C" void marius_mt19937_seed_host(uint32_t* st, uint64_t seed) {
     st[MT_N] = MT_N;
 }
 
-extern "C" void marius_mt19937_fill_host(uint32_t* st, uint32_t* out, int64_t n) {
-    for (int64_t i = 0; i < n; i++) out[i] = host_next(st);
-}
+extern "C" void marius_mt19937_fill_host(uint32_t* st, uint32_t* out, int64_t n) { host_fill(st, out, n); }
 
 extern "C" int marius_mt19937_randperm_host(uint32_t* st, int64_t* out, int64_t n) {
     MARIUS_REQUIRE(n >= 0 && (n == 0 || out), "randperm: bad arguments");
     // ATen (TensorFactories.cpp, randperm_cpu): Fisher-Yates with 32-bit draws below 2^32 / 20 elements; above, the inside-out variant
     // with random64() = (first draw << 32) | second draw
+    // Both loops are chains of dependent random accesses into `out` (80 MB at 10 M edges: every access misses the caches).  The draws do not
+    // depend on the array, so they are generated a block ahead and their targets prefetched: same result, memory-level parallelism
+    // instead of one miss at a time.
+    constexpr int AHEAD = 512;
+    int64_t zs[AHEAD];
+    uint32_t w[2 * AHEAD];
     if ((uint64_t)n >= (0xffffffffull / 20ull)) {
-        for (int64_t i = 0; i < n; i++) {
-            uint64_t r = host_next(st);
-            r = (r << 32) | (uint64_t)host_next(st);
-            const int64_t z = (int64_t)(r % (uint64_t)(i + 1));
-            out[i] = out[z];
-            out[z] = i;
+        for (int64_t i0 = 0; i0 < n; i0 += AHEAD) {
+            const int m = (int)((n - i0) < AHEAD ? (n - i0) : AHEAD);
+            host_fill(st, w, 2 * (int64_t)m);
+            for (int j = 0; j < m; j++) {
+                const uint64_t r = ((uint64_t)w[2 * j] << 32) | (uint64_t)w[2 * j + 1];
+                zs[j] = (int64_t)(r % (uint64_t)(i0 + j + 1));
+                __builtin_prefetch(out + zs[j], 1);
+            }
+            for (int j = 0; j < m; j++) {
+                const int64_t i = i0 + j, z = zs[j];
+                out[i] = out[z];
+                out[z] = i;
+            }
         }
         return MARIUS_OK;
     }
     for (int64_t i = 0; i < n; i++) out[i] = i;
-    for (int64_t i = 0; i < n - 1; i++) {
-        int64_t z = (int64_t)((uint64_t)host_next(st) % (uint64_t)(n - i));
-        int64_t sav = out[i];
-        out[i] = out[z + i];
-        out[z + i] = sav;
+    const uint32_t n32 = (uint32_t)n;  // n < 2^32 / 20 here: 32-bit remainders
+    for (int64_t i0 = 0; i0 < n - 1; i0 += AHEAD) {
+        const int m = (int)((n - 1 - i0) < AHEAD ? (n - 1 - i0) : AHEAD);
+        host_fill(st, w, m);
+        for (int j = 0; j < m; j++) {
+            const uint32_t i = (uint32_t)(i0 + j);
+            zs[j] = (int64_t)(w[j] % (n32 - i)) + (int64_t)i;
+            __builtin_prefetch(out + zs[j], 1);
+        }
+        for (int j = 0; j < m; j++) {
+            const int64_t i = i0 + j;
+            const int64_t sav = out[i];
+            out[i] = out[zs[j]];
+            out[zs[j]] = sav;
+        }
     }
     return MARIUS_OK;
 }
