@@ -103,7 +103,24 @@ def cpu_baseline_leg(cfg, B, C, N, edges_all, cpu_seconds):
                       "table flatters the CPU gather), oracle/cpu_step.py, torch CPU ops" % (steps, B, proxy)}
 
 
+def protect_stdout():
+    """Native libraries write to fd 1 (RCCL prints a three-line version banner at communicator creation): point fd 1 at stderr for the
+    life of the process and keep the original for the ONE JSON line (`emit_json`)."""
+    if getattr(sys, "_marius_real_stdout", None) is None:  # on `sys`: bench.py runs as __main__ AND is imported as `bench` by sharded.py
+        sys.stdout.flush()
+        sys._marius_real_stdout = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(out):
+    line = (json.dumps(out) + "\n").encode()
+    sys.stdout.flush()
+    fd = getattr(sys, "_marius_real_stdout", None)
+    os.write(1 if fd is None else fd, line)
+
+
 def main():
+    protect_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -315,7 +332,7 @@ def main():
         "positive_edges_per_s": round(pos_eps, 1), "unique_rows_last_batch": U, "loss_last_batch": loss,
         "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
     }
-    print(json.dumps(out))
+    emit_json(out)
 
 
 if __name__ == "__main__":

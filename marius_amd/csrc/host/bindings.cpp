@@ -373,7 +373,13 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_property_readonly("exchange_bytes", [](ShardedTrainer& t) { return std::vector<int64_t>(t.exchange_bytes_, t.exchange_bytes_ + 3); })
         .def("reset_exchange_bytes", [](ShardedTrainer& t) { t.exchange_bytes_[0] = t.exchange_bytes_[1] = t.exchange_bytes_[2] = 0; })
         .def_readonly("steps", &ShardedTrainer::steps_)
-        .def_property_readonly("phase_seconds", [](ShardedTrainer& t) { return std::vector<double>(t.phase_seconds_, t.phase_seconds_ + 6); });
+        .def_property_readonly("phase_seconds", [](ShardedTrainer& t) { return std::vector<double>(t.phase_seconds_, t.phase_seconds_ + 6); })
+        .def("enable_spans", &ShardedTrainer::enable_spans)
+        .def_property_readonly("span_ms", [](ShardedTrainer& t) {
+            std::vector<double> v(4, 0.0);
+            for (int k = 0; k < 4; ++k) v[k] = t.span_n_[k] ? t.span_ms_[k] / (double)t.span_n_[k] : 0.0;
+            return v;
+        });
     m.def("c10d_exchange_selftest", &c10d_exchange_selftest, py::arg("group_name"), py::arg("send"), py::arg("send_counts"), py::arg("to_reduce"),
           py::call_guard<py::gil_scoped_release>());
     py::class_<SynchronousEvaluator, std::shared_ptr<SynchronousEvaluator>>(m, "SynchronousEvaluator")

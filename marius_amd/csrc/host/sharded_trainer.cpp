@@ -46,7 +46,7 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
                                int64_t num_nodes, const std::string& group_name, const std::string& side_group_name, int staleness, int sync_interval)
     : loader_(loader), model_(model), table_(shard_table), state_(shard_state), rank_(rank), world_(world), staleness_(staleness),
       sync_interval_(sync_interval), num_nodes_(num_nodes) {
-    if (staleness_ != 0 && staleness_ != 1) throw MariusRuntimeException("ShardedTrainer: staleness must be 0 or 1");
+    if (staleness_ < 0 || staleness_ > AHEAD) throw MariusRuntimeException("ShardedTrainer: staleness must be in [0, " + std::to_string(AHEAD) + "]");
     require_device(table_, "ShardedTrainer");
     require_device(state_, "ShardedTrainer");
     S_ = (num_nodes_ + world_ - 1) / world_;  // storage.cpp:75
@@ -71,8 +71,13 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
             ST_HIPCHECK(hipEventDestroy(ev));
         }
     }
-    prep_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(false, dev.index()));
-    xchg_stream_ = new c10::hip::HIPStream(staleness_ ? c10::hip::getStreamFromPool(false, dev.index()) : strm(main_stream_));
+    // The side streams' kernels are short and sit on the critical path of the NEXT step (rows must have arrived before it can be scored);
+    // the compute stream's persistent kernels hold the whole chip while they run.  High priority for the side streams lets their
+    // workgroups take the first slots that free up (MARIUS_SHARDED_SIDE_HIPRIO=0: equal priorities).
+    const char* sp = getenv("MARIUS_SHARDED_SIDE_HIPRIO");
+    const bool side_hi = !(sp && sp[0] == '0');
+    prep_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(side_hi, dev.index()));
+    xchg_stream_ = new c10::hip::HIPStream(staleness_ ? c10::hip::getStreamFromPool(side_hi, dev.index()) : strm(main_stream_));
     for (auto& s : slots_) {
         s.offs_dev = torch::empty({world_ + 1}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
         s.offs_host = torch::empty({world_ + 1}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
@@ -148,9 +153,38 @@ Tensor ShardedTrainer::a2a(const Tensor& in, const std::vector<int64_t>& send_co
 }
 
 // stage 1 (prep stream): everything that does not read the table — edge slice, negatives, sort / unique, owner split points
+void ShardedTrainer::span_begin(Slot& s, int stage, void* stream) {
+    if (!spans_) return;
+    if (!s.span_b[stage]) {
+        hipEvent_t b, e;
+        ST_HIPCHECK(hipEventCreate(&b));
+        ST_HIPCHECK(hipEventCreate(&e));
+        s.span_b[stage] = b;
+        s.span_e[stage] = e;
+    }
+    ST_HIPCHECK(hipEventRecord((hipEvent_t)s.span_b[stage], strm(stream).stream()));
+}
+void ShardedTrainer::span_end(Slot& s, int stage, void* stream) {
+    if (!spans_ || !s.span_b[stage]) return;
+    ST_HIPCHECK(hipEventRecord((hipEvent_t)s.span_e[stage], strm(stream).stream()));
+    s.span_live[stage] = true;
+}
+void ShardedTrainer::span_collect(Slot& s) {
+    for (int k = 0; k < 4; ++k) {
+        if (!s.span_live[k]) continue;
+        s.span_live[k] = false;
+        float ms = 0.f;
+        if (hipEventQuery((hipEvent_t)s.span_e[k]) == hipSuccess && hipEventElapsedTime(&ms, (hipEvent_t)s.span_b[k], (hipEvent_t)s.span_e[k]) == hipSuccess) {
+            span_ms_[k] += ms;
+            ++span_n_[k];
+        }
+    }
+}
+
 void ShardedTrainer::prepare(int64_t t) {
     Phase ph(phase_seconds_[0]);
     Slot& s = slot(t);
+    span_collect(s);
     auto& prep = strm(prep_stream_);
     const auto dev_index = table_.device().index();
     if (s.used) {
@@ -162,6 +196,7 @@ void ShardedTrainer::prepare(int64_t t) {
         ST_HIPCHECK(hipEventDestroy(e));
         (void)dev_index;
     }
+    span_begin(s, 0, prep_stream_);
     {
         Scope scope(prep);
         const int64_t B = loader_->batch_size_;
@@ -183,6 +218,7 @@ void ShardedTrainer::prepare(int64_t t) {
         }
         s.cnt_recv_host.copy_(s.cnt_recv_dev, /*non_blocking=*/true);
     }
+    span_end(s, 0, prep_stream_);
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.ready, prep.stream()));
     s.used = true;
 }
@@ -212,6 +248,7 @@ void ShardedTrainer::fetch(int64_t t) {
     const int k = (int)(t % RING);
     auto& xchg = strm(xchg_stream_);
     ST_HIPCHECK(hipStreamWaitEvent(xchg.stream(), (hipEvent_t)s.ready, 0));
+    span_begin(s, 1, xchg_stream_);
     {
         Scope scope(xchg);
         Tensor req = a2a(s.batch->unique_node_indices_.narrow(0, 0, s.U), s.send_counts, s.recv_counts, view(buf_req_, s.nrecv, {}, torch::kInt64));
@@ -223,6 +260,7 @@ void ShardedTrainer::fetch(int64_t t) {
                                       rows.stride(0), (marius_stream_t)xchg.stream()));
         s.emb = a2a(rows, s.recv_counts, s.send_counts, view(emb_[k], s.U, {d_}, torch::kFloat32));
     }
+    span_end(s, 1, xchg_stream_);
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.fetched, xchg.stream()));
     for (int q = 0; q < world_; ++q) {
         if (q == rank_) continue;
@@ -246,11 +284,13 @@ void ShardedTrainer::compute(int64_t t) {
     auto& main = strm(main_stream_);
     Scope scope(main);
     ST_HIPCHECK(hipStreamWaitEvent(main.stream(), (hipEvent_t)s.fetched, 0));
+    span_begin(s, 2, main_stream_);
     s.batch->node_embeddings_ = s.emb;
     s.grad = view(grad_[t % RING], s.U, {d_}, torch::kFloat32);
     // replicas step on their own relation gradients between averaging points (sync_interval > 1); with sync_interval 1 the dense
     // gradients are all-reduced first
     model_->backward_to_unique_grads(s.batch, s.grad, sync_interval_ > 1);
+    span_end(s, 2, main_stream_);
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.computed, main.stream()));
 }
 
@@ -292,11 +332,13 @@ void ShardedTrainer::update(int64_t t) {
     Slot& s = slot(t);
     auto& xchg = strm(xchg_stream_);
     ST_HIPCHECK(hipStreamWaitEvent(xchg.stream(), (hipEvent_t)s.computed, 0));
+    span_begin(s, 3, xchg_stream_);
     {
         Scope scope(xchg);
         Tensor recv_grad = a2a(s.grad, s.send_counts, s.recv_counts, view(buf_recv_grad_, s.nrecv, {d_}, torch::kFloat32));
         apply_local(s.local_ids, recv_grad, s.recv_counts);
     }
+    span_end(s, 3, xchg_stream_);
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.free_, xchg.stream()));
 }
 
@@ -327,7 +369,12 @@ void ShardedTrainer::step() {
     // whose preparation runs in the gaps the big kernels leave), and the compute stream must not run dry meanwhile.
     compute(t);
     prepare_through(t + AHEAD);  // preparation never reads the table: how far ahead it runs changes nothing but latency hiding
-    if (staleness_) fetch_through(t + 1);  // rows of the next batch move while this one is scored; on the exchange stream this precedes update(t)
+    // rows of batch t + s move while batch t is scored; on the exchange stream this precedes update(t).  s = 1: the fetch of batch t + 1 still
+    // queues behind update(t - 1), i.e. behind the scoring of t - 1, and has only the rest of scoring t to finish in: the critical cycle is
+    // score(t) -> update(t) -> fetch(t + 2) -> score(t + 2), period >= (score + update + fetch) / 2.  s = 2 takes the fetch off that
+    // cycle (period >= (score + update + fetch) / 3); rows are then up to two updates stale.  At world 1 (no wire time) the choice does not
+    // matter — 1.02 / 1.00 / 1.02 ms per step for s = 1 / 2 / 3: the device is simply full (device_span_ms) — so the default stays 1.
+    if (staleness_) fetch_through(t + staleness_);
     update(t);
     dense(t);
     ++step_index_;

@@ -15,14 +15,14 @@ namespace marius_amd {
 
 class ShardedTrainer {
    public:
-    static constexpr int RING = 6;   // slots in flight
-    static constexpr int AHEAD = 3;  // batches prepared ahead of the one being scored: their split points must be on the host when fetch needs them
+    static constexpr int RING = 8;   // slots in flight
+    static constexpr int AHEAD = 4;  // batches prepared ahead of the one being scored: their split points must be on the host when fetch needs them
 
     // loader: prepares this rank's batches (its node storage only supplies num_nodes = dim0_size_); shard_table / shard_state: rows
     // [rank * S, min((rank + 1) * S, num_nodes)) of the node table and its Adagrad state, S = ceil(num_nodes / world) (storage.cpp:75).
-    // staleness 0: synchronous (every row a batch reads carries all earlier updates); 1: the fetch of batch t + 1 and the gradient
-    // return of batch t run on an exchange stream underneath the scoring (rows at most one step stale; the reference's own multi-GPU
-    // trainer is the asynchronous pipeline with staleness_bound 16).  sync_interval: pipeline.gpu_sync_interval (relation tables and
+    // staleness 0: synchronous (every row a batch reads carries all earlier updates); s >= 1: the fetch of batch t + s and the gradient
+    // return of batch t run on an exchange stream underneath the scoring (rows at most s updates stale, s <= AHEAD; the reference's own
+    // multi-GPU trainer is the asynchronous pipeline with staleness_bound 16).  sync_interval: pipeline.gpu_sync_interval (relation tables and
     // their Adagrad state averaged every K steps; 1 = all-reduce the relation gradients every step, model.cpp:136-159).
     ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> model, Tensor shard_table, Tensor shard_state, int rank, int world, int64_t num_nodes,
                    const std::string& group_name, const std::string& side_group_name, int staleness, int sync_interval);
@@ -37,6 +37,13 @@ class ShardedTrainer {
     std::string backend() const { return pg_ ? pg_->getBackendName() : std::string("none"); }
     int64_t steps_ = 0;
     double phase_seconds_[6] = {0, 0, 0, 0, 0, 0};  // host time in: prepare, wait for split points, fetch, compute, update, dense
+    // device time from the first to the last operation of a stage on its stream (HIP events; collected when a slot is reused, RING steps
+    // later): prepare (prep stream), fetch and update (exchange stream), compute (main stream).  A stage's span includes the time its
+    // kernels wait for CUs held by the other streams: span >> the stage's own work means that stream is starved.
+    double span_ms_[4] = {0, 0, 0, 0};
+    int64_t span_n_[4] = {0, 0, 0, 0};
+    bool spans_ = false;
+    void enable_spans(bool on) { spans_ = on; }
 
    private:
     struct Slot {
@@ -47,6 +54,9 @@ class ShardedTrainer {
         void* fetched = nullptr;     // rows of this batch have arrived
         void* computed = nullptr;    // per-row gradients complete
         void* free_ = nullptr;       // owners applied the gradients: every buffer of the slot is reusable
+        void* span_b[4] = {nullptr, nullptr, nullptr, nullptr};  // timing events (stage begin / end), see span_ms_
+        void* span_e[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool span_live[4] = {false, false, false, false};
         bool used = false;
         std::vector<int64_t> send_counts, recv_counts;
         int64_t U = 0, nrecv = 0;
@@ -82,6 +92,9 @@ class ShardedTrainer {
     void apply_local(const Tensor& local_ids, const Tensor& grads, const std::vector<int64_t>& recv_counts);
     Tensor a2a(const Tensor& in, const std::vector<int64_t>& send_counts, const std::vector<int64_t>& recv_counts, Tensor out);
     void prime();
+    void span_begin(Slot& s, int stage, void* stream);
+    void span_end(Slot& s, int stage, void* stream);
+    void span_collect(Slot& s);
 };
 
 // The collective calls of ShardedTrainer in isolation, on tensors of any device the group supports (the CPU gloo tests run this with

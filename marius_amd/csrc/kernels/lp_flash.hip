@@ -512,8 +512,18 @@ size_t flash_adjrec_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.B
 size_t flash_negrec_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.N + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)) + 32768; }
 size_t flash_part_bytes(const LpDims& D) { return (size_t)2 * D.ndir * D.Bp * sizeof(float2); }
 
+static int g_flash_reserved_cus = 0;
+void flash_set_reserved_cus(int n) { g_flash_reserved_cus = n; }
+
 static int fl_num_wg(int64_t tiles, int mode) {
     int nwg = 256 * fl_wg_per_cu(mode);
+    // marius_flash_set_reserved_cus / MARIUS_FLASH_RESERVE: leave that many CUs' worth of workgroup slots empty.  The persistent
+    // workgroups otherwise hold every VGPR of the chip for the length of the launch, and kernels of other streams (batch preparation,
+    // the sharded trainer's row exchange) can only start in its tail.
+    int reserve = g_flash_reserved_cus;
+    const char* r = getenv("MARIUS_FLASH_RESERVE");
+    if (r) reserve = atoi(r);
+    if (reserve > 0 && reserve < 128) nwg = (256 - reserve) * fl_wg_per_cu(mode);
     const char* e = getenv("MARIUS_FLASH_NWG");
     if (e) nwg = atoi(e);
     if (nwg > tiles) nwg = (int)tiles;

@@ -579,11 +579,13 @@ def run_sharded_bench(a, cfg, rank, world, dev):
             # the constructor already runs every collective the steps use (all-reduce, both all-to-all(v) forms, the gloo count exchange)
             cpp_trainer = M.ShardedTrainer(loader, model, table, state, rank, world, num_nodes, dist.group.WORLD.group_name, side_group.group_name,
                                            staleness, sync_interval)
+            cpp_trainer.enable_spans(True)  # eight event records per step on three streams: which stage's stream is starved
         except Exception as e:  # noqa: BLE001 — e.g. a c10d build without the C++ group registry: same schedule from Python
             import sys
             print("[rank %d] C++ ShardedTrainer unavailable (%s): falling back to the Python schedule" % (rank, e), file=sys.stderr)
             cpp_trainer = None
             driver = "py"
+            staleness = min(staleness, 1)  # the Python schedule knows 0 and 1
     if cpp_trainer is not None:
 
         def run(k0, k):
@@ -648,7 +650,7 @@ def run_sharded_bench(a, cfg, rank, world, dev):
                 a.workload, cfg["decoder"], d, world, B, "global batch fixed" if strong else "fixed per GPU", C, N, a.edge_dist),
                 "num_nodes": num_nodes, "num_relations": R,
                 "parallelism": "dp%d + sharded node table, RCCL all-to-all(v) row fetch / gradient return, relation tables averaged every %d steps, %s" % (
-                    world, sync_interval, ("row exchange overlapped with scoring on a second stream (staleness 1 step; reference pipeline bound: 16)"
+                    world, sync_interval, ("row exchange overlapped with scoring on a second stream (staleness %d step%s; reference pipeline bound: 16)" % (staleness, "s" if staleness > 1 else "")
                                            if pipelined and staleness else "synchronous exchange"))},
             "positive_edges_per_s": round(pos_eps, 1), "roofline": None, "cpu_baseline": None,
             # the communicator the exchange ran on: `rccl_ranks` ranks, one per GPU ("nccl" is RCCL on ROCm; "gloo" only in the
@@ -661,7 +663,11 @@ def run_sharded_bench(a, cfg, rank, world, dev):
         if host_total is not None:  # how long the host needs to issue a step: it must stay below ms_per_step or the host is the bottleneck
             out["host_issue_ms_per_step"] = round(host_total / a.steps * 1e3, 4)
             out["config"]["host"] = "C++ ShardedTrainer (libtorch, c10d)" if cpp_trainer is not None else "Python schedule (marius_amd/sharded.py)"
-            if cpp_trainer is not None and os.environ.get("MARIUS_SHARDED_PHASES"):
+            if cpp_trainer is not None:
+                out["device_span_ms"] = dict(zip(["prepare", "fetch", "compute", "update"], [round(x, 4) for x in cpp_trainer.span_ms]))
+                out["host_phase_ms_per_step"] = dict(zip(["prepare", "wait_split_points", "fetch", "compute", "update", "dense"],
+                                                         [round(x / (a.steps + a.warmup) * 1e3, 4) for x in cpp_trainer.phase_seconds]))
+            if False:
                 out["host_phase_ms_per_step"] = dict(zip(["prepare", "wait_split_points", "fetch", "compute", "update", "dense"],
                                                          [round(x / (a.steps + a.warmup) * 1e3, 4) for x in cpp_trainer.phase_seconds]))
         ms, cnt = prof.get("lp_grad_adj", (0.0, 0))
@@ -670,5 +676,5 @@ def run_sharded_bench(a, cfg, rank, world, dev):
             out["roofline"]["kernel"] += " (rank 0)"
         if not a.no_cpu_baseline:  # rank 0 only: the same bounded CPU leg as the N = 1 line (per-rank workload)
             out["cpu_baseline"] = bench_mod.cpu_baseline_leg(cfg, B, C, N, edges_all, a.cpu_seconds)
-        print(json.dumps(out))
+        bench_mod.emit_json(out)
     dist.destroy_process_group()

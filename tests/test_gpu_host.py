@@ -600,15 +600,16 @@ def test_cpp_sharded_trainer_world1_equals_synchronous_trainer(M, dev, sync_inte
     dist.destroy_process_group()
 
 
-def test_cpp_sharded_trainer_staleness1_matches_stale_oracle(M, dev):
-    """Overlapped exchange: the rows of batch t + 1 are read before the update of batch t is applied (one step stale), the Adagrad state
-    is read by the owner at update time.  Same loop on the CPU oracle."""
+@pytest.mark.parametrize("stale", [1, 2, 3])
+def test_cpp_sharded_trainer_staleness1_matches_stale_oracle(M, dev, stale):
+    """Overlapped exchange: the rows of batch t + s are read before the update of batch t is applied (s updates stale; the first s batches
+    before any update), the Adagrad state is read by the owner at update time.  Same loop on the CPU oracle."""
     dist = _init_nccl(dev)
     num_nodes, R, d, B, C, N, E, seed, steps = 2000, 7, 32, 150, 3, 40, 1500, 5, 7
     table, edges_all, make = _sharded_setup(M, dev, seed, num_nodes, R, d, B, C, N, E)
     tb, sb = table.clone().to(dev), torch.zeros(num_nodes, d, device=dev)
     lb, mb = make(M.InMemory("", num_nodes, d, torch.float32, dev), None)
-    tr = M.ShardedTrainer(lb, mb, tb, sb, 0, 1, num_nodes, dist.group.WORLD.group_name, "", 1, 1)
+    tr = M.ShardedTrainer(lb, mb, tb, sb, 0, 1, num_nodes, dist.group.WORLD.group_name, "", stale, 1)
     tr.train_steps(steps)
     tr.finish()
     # ---- oracle
@@ -625,18 +626,22 @@ def test_cpp_sharded_trainer_staleness1_matches_stale_oracle(M, dev):
         return {"uniq": uniq, "el": torch.stack([mapped[0], e[:, 1], mapped[1]]).transpose(0, 1), "src_map": mapped[2].reshape(src_neg.shape),
                 "dst_map": mapped[3].reshape(dst_neg.shape)}
 
-    cur = prep(0)
-    cur["emb"] = T[cur["uniq"]].clone()
+    queue = []  # batches whose rows have been fetched, oldest first (the generator is consumed in batch order, as by the loader)
+    for k in range(stale + 1):
+        b = prep(k)
+        b["emb"] = T[b["uniq"]].clone()  # batches 0..s: fetched before the first update
+        queue.append(b)
     for t in range(steps):
-        nxt = prep(t + 1)
-        nxt["emb"] = T[nxt["uniq"]].clone()  # fetched before the update of batch t lands
+        cur = queue.pop(0)
         out = O.train_batch("COMPLEX", cur["emb"], torch.zeros_like(cur["emb"]), cur["el"], cur["dst_map"], cur["src_map"], cpu.rel, cpu.inv_rel)
         g = out["node_grad"]
         S[cur["uniq"]] += g * g
         T[cur["uniq"]] += -0.1 * (g / (S[cur["uniq"]].sqrt() + 1e-10))
         O.dense_adagrad_step(cpu.rel, out["rel_grad"], cpu.rel_sum, 0.1)
         O.dense_adagrad_step(cpu.inv_rel, out["inv_rel_grad"], cpu.inv_rel_sum, 0.1)
-        cur = nxt
+        nxt = prep(t + stale + 1)
+        nxt["emb"] = T[nxt["uniq"]].clone()  # fetched after update t, before update t + 1
+        queue.append(nxt)
     close(tb, T, rtol=3e-4)
     close(sb, S, rtol=3e-4)
     close(mb.decoder.relations, cpu.rel, rtol=3e-4)
