@@ -329,6 +329,10 @@ PYBIND11_MODULE(_marius_host, m) {
              py::arg("edges"), py::arg("node_embeddings"), py::arg("node_embeddings_state"), py::arg("negative_sampler"), py::arg("generator"),
              py::arg("batch_size"), py::arg("train") = true)
         .def("initializeBatches", &DataLoader::initializeBatches, py::arg("shuffle") = true)
+        .def_readonly("shuffle_ahead_hits", &DataLoader::shuffle_ahead_hits_)
+        .def_readonly("shuffle_ahead_misses", &DataLoader::shuffle_ahead_misses_)
+        .def_readwrite("full_batches_only", &DataLoader::full_batches_only_)
+        .def_readwrite("generator", &DataLoader::generator_)
         .def("hasNextBatch", &DataLoader::hasNextBatch)
         .def("getBatch", &DataLoader::getBatch, py::arg("exact_unique") = true)
         .def("loadGPUParameters", &DataLoader::loadGPUParameters)

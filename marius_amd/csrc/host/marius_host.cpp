@@ -1360,6 +1360,66 @@ bool DataLoader::hasNextBatch() {
     return batches_left_ > 0;
 }
 
+struct DataLoader::ShuffleAhead {
+    std::thread th;
+    std::vector<uint32_t> start, after;  // generator state the permutation was drawn from / left behind
+    Tensor perm;                         // pinned host int64 [n]
+    int64_t n = 0;
+    double seconds = 0;
+};
+
+void DataLoader::start_shuffle_ahead() {
+    const char* e0 = getenv("MARIUS_SHUFFLE_AHEAD");
+    const char* e1 = getenv("MARIUS_SHUFFLE_AHEAD_MIN");  // below this many edges the serial draw is cheaper than a thread (tests set 0)
+    const bool enabled = !(e0 && e0[0] == '0');
+    const int64_t min_edges = e1 ? (int64_t)atoll(e1) : (int64_t)200000;
+    if (!enabled || !train_ || partitioned() || num_edges_ < min_edges || !negative_sampler_ || negative_sampler_->num_negatives_ < 0) return;
+    if (negative_sampler_->local_filter_mode_ != LocalFilterMode::DEG) return;
+    // words this epoch's sampling will consume: two getNegatives per batch (dataloader.cpp:498-503), a fixed count per call
+    const int n_deg = (int)(negative_sampler_->num_negatives_ * negative_sampler_->degree_fraction_);
+    const int64_t batches = full_batches_only_ ? num_edges_ / batch_size_ : total_batches_;
+    const int64_t per_call = marius_negatives_raw_words(graph_->num_nodes_in_memory_, batch_size_, negative_sampler_->num_chunks_, negative_sampler_->num_negatives_, n_deg);
+    const int64_t words = 2 * per_call * batches;
+    generator_->to_host();  // right after this epoch's randperm: the state lives on the host
+    auto* a = new ShuffleAhead();
+    a->n = num_edges_;
+    a->start.assign((const uint32_t*)generator_->state_host_.data_ptr<int32_t>(), (const uint32_t*)generator_->state_host_.data_ptr<int32_t>() + MARIUS_MT_STATE_WORDS);
+    a->perm = torch::empty({num_edges_}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
+    int64_t* out = a->perm.data_ptr<int64_t>();
+    a->th = std::thread([a, words, out] {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<uint32_t> scratch(1 << 20);
+        for (int64_t done = 0; done < words;) {
+            const int64_t m = std::min<int64_t>(words - done, (int64_t)scratch.size());
+            marius_mt19937_fill_host(a->start.data(), scratch.data(), m);
+            done += m;
+        }
+        a->after = a->start;  // `start` now is the state at the epoch's end: where the next permutation begins
+        marius_mt19937_randperm_host(a->after.data(), out, a->n);
+        a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    });
+    ahead_ = a;
+}
+
+bool DataLoader::take_shuffle_ahead(Tensor& perm) {
+    if (!ahead_) return false;
+    ShuffleAhead* a = ahead_;
+    ahead_ = nullptr;
+    a->th.join();
+    bool hit = false;
+    if (a->n == num_edges_) {
+        generator_->to_host();
+        if (std::memcmp(generator_->state_host_.data_ptr<int32_t>(), a->start.data(), MARIUS_MT_STATE_WORDS * 4) == 0) {
+            std::memcpy(generator_->state_host_.data_ptr<int32_t>(), a->after.data(), MARIUS_MT_STATE_WORDS * 4);
+            perm = a->perm;
+            hit = true;
+        }
+    }
+    (hit ? shuffle_ahead_hits_ : shuffle_ahead_misses_)++;
+    delete a;
+    return hit;
+}
+
 void DataLoader::initializeBatches(bool shuffle) {
     drain_worker();  // nothing may be preparing while the generator draws the epoch permutation on this thread
     if (partitioned()) {
@@ -1367,15 +1427,28 @@ void DataLoader::initializeBatches(bool shuffle) {
         num_edges_ = active_edges_.size(0);
     }
     // setActiveEdges (dataloader.cpp:176-182): randperm over all edges on the generator stream, consumed even for evaluation
-    Tensor perm = num_edges_ > 0 ? generator_->randperm(num_edges_) : torch::empty({0}, torch::kInt64);
+    Tensor perm;
+    if (!(shuffle && take_shuffle_ahead(perm))) {
+        if (ahead_) {  // a permutation drawn ahead that this call cannot use (shuffle off): drop it
+            Tensor unused;
+            take_shuffle_ahead(unused);
+        }
+        perm = num_edges_ > 0 ? generator_->randperm(num_edges_) : torch::empty({0}, torch::kInt64);
+    }
     active_perm_ = shuffle ? perm.to(edges_->device_) : torch::arange(num_edges_, i64(edges_->device_));
     total_batches_ = (num_edges_ + batch_size_ - 1) / batch_size_;
     batches_left_ = total_batches_;
     prepared_left_ = total_batches_;
     batch_id_ = 0;
+    if (shuffle) start_shuffle_ahead();
 }
 
 DataLoader::~DataLoader() {
+    if (ahead_) {
+        ahead_->th.join();
+        delete ahead_;
+        ahead_ = nullptr;
+    }
     if (worker_) {
         {
             std::lock_guard<std::mutex> lk(worker_->m);

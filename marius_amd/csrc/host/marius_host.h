@@ -509,6 +509,18 @@ class DataLoader {
     // batch whose loader-stream work waits for that training step, so a batch is released HERE, between taking the next prepared batch
     // and posting the following request — never while a preparation is in flight on the other thread.
     shared_ptr<Batch> held_;
+    // The NEXT epoch's permutation, drawn by a host thread while this epoch trains (dataloader.cpp:176-182 puts a serial randperm of all
+    // edges between two epochs: 0.12 s at 10 M edges, seconds at Freebase86m's 338 M — as long as the epoch itself on this device).  The words
+    // an epoch's sampling draws from the generator are known in advance (two requests per batch, a fixed count each), so the thread advances a
+    // COPY of the state by that many words and draws the permutation from there.  At the epoch boundary the copy's starting point is compared
+    // with the generator's actual state: equal -> the permutation and the state after it are adopted (bit-identical to drawing it now);
+    // different (anything else consumed the generator) -> the permutation is drawn now as before.  MARIUS_SHUFFLE_AHEAD=0 disables it.
+    struct ShuffleAhead;
+    ShuffleAhead* ahead_ = nullptr;
+    bool full_batches_only_ = false;  // the caller wraps to the next epoch when fewer than batch_size_ edges remain (ShardedTrainer)
+    int64_t shuffle_ahead_hits_ = 0, shuffle_ahead_misses_ = 0;
+    void start_shuffle_ahead();
+    bool take_shuffle_ahead(Tensor& perm);
     Tensor last_num_unique_;  // device count of the batch getBatch returned last (count_ itself belongs to the preparing thread)
     void post_prepare(bool exact_unique);
     shared_ptr<Batch> take_prepared();

@@ -565,6 +565,43 @@ def _sharded_setup(M, dev, seed, num_nodes, R, d, B, C, N, E):
     return table, edges_all, make
 
 
+@pytest.mark.parametrize("E,B", [(1200, 200), (1130, 200)])
+def test_next_epoch_permutation_drawn_ahead_is_bit_identical(M, dev, monkeypatch, E, B):
+    """The next epoch's randperm is drawn by a host thread from a copy of the generator advanced by the words this epoch's sampling
+    will consume; at the boundary it is adopted only if the generator really is where the copy started.  Three epochs (incl. a ragged last
+    batch) must walk bit for bit the trajectory of the serial draw; a foreign draw between two epochs makes the prediction miss, and the
+    result is again that of the serial order."""
+    num_nodes, R, d, C, N, seed = 3000, 9, 64, 4, 60, 21
+    table, edges_all, make = _sharded_setup(M, dev, seed, num_nodes, R, d, B, C, N, E)
+    nb = (E + B - 1) // B
+
+    def run(ahead, foreign):
+        monkeypatch.setenv("MARIUS_SHUFFLE_AHEAD", "1" if ahead else "0")
+        monkeypatch.setenv("MARIUS_SHUFFLE_AHEAD_MIN", "0")
+        emb, st = M.InMemory(table.clone().to(dev)), M.InMemory(torch.zeros(num_nodes, d, device=dev))
+        loader, model = make(emb, st)
+        tr = M.SynchronousTrainer(loader, model)
+        loader.initializeBatches(True)
+        for epoch in range(3):
+            tr.train_steps(nb)
+            if foreign and epoch == 0:
+                loader.generator.randperm(7)  # somebody else consumes the stream: the copy's starting point is no longer the generator's
+            if epoch < 2:
+                loader.initializeBatches(True)
+        torch.cuda.synchronize()
+        return emb.data.clone(), st.data.clone(), loader.shuffle_ahead_hits, loader.shuffle_ahead_misses
+
+    ref = run(False, False)
+    got = run(True, False)
+    assert (ref[2], ref[3]) == (0, 0) and (got[2], got[3]) == (2, 0)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    ref_f = run(False, True)
+    got_f = run(True, True)
+    assert (got_f[2], got_f[3]) == (1, 1)
+    assert torch.equal(got_f[0], ref_f[0]) and torch.equal(got_f[1], ref_f[1])
+    assert not torch.equal(ref_f[0], ref[0])
+
+
 def _init_nccl(dev):
     import torch.distributed as dist
 
