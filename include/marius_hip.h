@@ -227,7 +227,8 @@ enum {
 typedef struct marius_lp_layout {
     int64_t Bp, n_ld, d_ld;
     size_t total_bytes;
-    size_t adj[2];    /* [Bp, d_ld]  op(src, rel) rows (zero rows for i >= B)                                   */
+    size_t adj[2];    /* [Bp, d_ld]  op(src, rel) rows (zero rows for i >= B); NOT written on the flash path (flash != 0 and
+                       *              no MARIUS_LP_STORE_SCORES): adj then exists as operand records only (adjrec)            */
     size_t pos[2];    /* [Bp]        positive scores (zero padded)  -> forward_lp pos / inv_pos                  */
     size_t neg[2];    /* [Bp, n_ld]  negative scores                -> forward_lp neg / inv_neg                  */
     size_t lse[2];    /* [Bp]        per-row scalar of the loss: SoftmaxCE log(e^pos + sum_j e^neg); Ranking pos - margin        */

@@ -161,6 +161,31 @@ __device__ __forceinline__ void prep_flash_store(const PrepArgs& a, int dir, int
     if (l == 0) *reinterpret_cast<float4*>(rec + 4 * a.fKP) = make_float4(0.f, 0.f, 0.f, 0.f);  // lsec: patched in by the merge kernel
 }
 
+// adj = op(e, r) on the four elements {c0, c0 + 1, c1, c1 + 1} a lane owns (ComplEx: (re, im) = (k, k + 2)); the SAME expressions, with
+// contraction off, in the forward (prep2) and — when the flash path does not keep an fp32 copy of adj — in the edge backward
+__device__ __forceinline__ void relop4(int relop, bool has_rel, const float (&e)[4], const float (&r)[4], float (&v)[4]) {
+#pragma clang fp contract(off)
+    if (!has_rel) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = e[k];
+    } else if (relop == MARIUS_OP_HADAMARD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = e[k] * r[k];
+    } else if (relop == MARIUS_OP_TRANSLATION) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = e[k] + r[k];
+    } else if (relop == MARIUS_OP_COMPLEX_HADAMARD) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            v[k] = (e[k] * r[k]) - (e[k + 2] * r[k + 2]);
+            v[k + 2] = (e[k] * r[k + 2]) + (e[k + 2] * r[k]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = e[k];
+    }
+}
+
 __global__ __launch_bounds__(256) void lp_prep2_kernel(PrepArgs a) {
 #pragma clang fp contract(off)
     const LpDims& D = a.D;
@@ -187,8 +212,8 @@ __global__ __launch_bounds__(256) void lp_prep2_kernel(PrepArgs a) {
     const int c0 = 2 * l, c1 = h2 + 2 * l;  // first-half pair, second-half pair
     if (i >= D.B) {  // pad_and_reshape zero rows; F.pad zero positives
         for (int dir = 0; dir < D.ndir; ++dir) {
-            float* adj = a.adj + ((int64_t)dir * D.Bp + i) * D.d_ld;
-            if (act) {
+            if (act && a.adj) {
+                float* adj = a.adj + ((int64_t)dir * D.Bp + i) * D.d_ld;
                 *reinterpret_cast<float2*>(adj + c0) = make_float2(0.f, 0.f);
                 *reinterpret_cast<float2*>(adj + c1) = make_float2(0.f, 0.f);
             }
@@ -237,24 +262,9 @@ __global__ __launch_bounds__(256) void lp_prep2_kernel(PrepArgs a) {
         const float* o = x[dir ^ 1];    // the other endpoint
         const bool hr = dir == 0 ? has_rel0 : has_rel1;
         float v[4];
-        if (!hr) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = e[k];
-        } else if (D.relop == MARIUS_OP_HADAMARD) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = e[k] * r[dir][k];
-        } else if (D.relop == MARIUS_OP_TRANSLATION) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = e[k] + r[dir][k];
-        } else if (D.relop == MARIUS_OP_COMPLEX_HADAMARD) {  // same expressions as relop_fwd, (re, im) = (k, k + 2)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                v[k] = (e[k] * r[dir][k]) - (e[k + 2] * r[dir][k + 2]);
-                v[k + 2] = (e[k] * r[dir][k + 2]) + (e[k + 2] * r[dir][k]);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = e[k];
+        {
+            const float ee[4] = {e[0], e[1], e[2], e[3]};
+            relop4(D.relop, hr, ee, r[dir], v);
         }
         float acc = 0.f, nrm = 0.f;
         if (act) {
@@ -269,9 +279,11 @@ __global__ __launch_bounds__(256) void lp_prep2_kernel(PrepArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) acc += v[k] * o[k];
             }
-            float* adj = a.adj + ((int64_t)dir * D.Bp + i) * D.d_ld;
-            *reinterpret_cast<float2*>(adj + c0) = make_float2(v[0], v[1]);
-            *reinterpret_cast<float2*>(adj + c1) = make_float2(v[2], v[3]);
+            if (a.adj) {  // null: the flash path keeps adj only as operand records (the edge backward recomputes it from the same rows)
+                float* adj = a.adj + ((int64_t)dir * D.Bp + i) * D.d_ld;
+                *reinterpret_cast<float2*>(adj + c0) = make_float2(v[0], v[1]);
+                *reinterpret_cast<float2*>(adj + c1) = make_float2(v[2], v[3]);
+            }
         }
         if (a.frec) prep_flash_store(a, dir, i, l, c0, c1, v, act);
         acc = half_sum(acc);
@@ -951,10 +963,12 @@ __global__ __launch_bounds__(256) void lp_edge_bwd2_kernel(EdgeBwdArgs a) {
         coef[dir] = posv[dir] = 0.f;
         if (dir >= D.ndir) continue;
         const int64_t rowoff = ((int64_t)dir * D.Bp + i) * D.d_ld;
-        ld4(a.adj + rowoff, av[dir]);
         ld4(a.dadj + rowoff, dv[dir]);
         has_rel[dir] = (D.edge_cols == 3) && (a.rel[dir] != nullptr);
         if (has_rel[dir]) ld4(a.rel[dir] + ed[1] * a.rel_ld, r[dir]);
+        else r[dir][0] = r[dir][1] = r[dir][2] = r[dir][3] = 0.f;
+        if (a.adj) ld4(a.adj + rowoff, av[dir]);
+        else relop4(D.relop, has_rel[dir], x[dir], r[dir], av[dir]);  // bit for bit what the forward packed into the operand records
         coef[dir] = a.dpos[(int64_t)dir * D.Bp + i];  // dL/dpos
         posv[dir] = a.pos[(int64_t)dir * D.Bp + i];
     }
@@ -1207,6 +1221,20 @@ extern "C" int marius_lp_plan(const marius_lp_desc* desc, marius_lp_layout* layo
     return make_layout(desc, D, layout);
 }
 
+// the half-wave-per-edge prep / edge-backward kernels need 8-B aligned rows and d <= 128 (MARIUS_PREP=1: the any-shape kernels)
+static bool lp_vec_ok(const marius_lp_desc* desc, const LpDims& D) {
+    const char* pv = getenv("MARIUS_PREP");
+    return (D.d % 4 == 0) && D.d <= 128 && (desc->emb_ld % 2 == 0) && (desc->rel_ld % 2 == 0 || !desc->rel) && (D.d == D.d_ld) &&
+           ((reinterpret_cast<uintptr_t>(desc->emb) & 7) == 0) && ((reinterpret_cast<uintptr_t>(desc->rel) & 7) == 0) &&
+           ((reinterpret_cast<uintptr_t>(desc->inv_rel) & 7) == 0) && !(pv && pv[0] == '1');
+}
+// Flash path with the fused prep: adj exists as operand records only; the edge backward recomputes the four elements it needs from the rows
+// it reads anyway (saves the 2 Bp d 4-byte store and its re-read).  MARIUS_FLASH_KEEP_ADJ=1 keeps the fp32 copy (layout.adj) as well.
+static bool flash_adj_elided(const marius_lp_desc* desc, const LpDims& D, const marius_lp_layout* L) {
+    const char* k = getenv("MARIUS_FLASH_KEEP_ADJ");
+    return L->flash && lp_vec_ok(desc, D) && !(desc->flags & MARIUS_LP_STORE_SCORES) && !(k && k[0] == '1');
+}
+
 extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_layout* L, void* workspace, marius_stream_t stream) {
     LpDims D;
     int rc = fill_dims(desc, D);
@@ -1220,6 +1248,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     float* x2 = l2 ? (float*)(ws + L->aux) : nullptr;
     float* y2 = l2 ? x2 + (size_t)D.Bp * D.ndir : nullptr;
 
+    const bool adj_elided = flash_adj_elided(desc, D, L);
     PrepArgs pa;
     pa.emb = desc->emb;
     pa.emb_ld = desc->emb_ld;
@@ -1227,7 +1256,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     pa.rel[0] = desc->rel;
     pa.rel[1] = desc->inv_rel;
     pa.rel_ld = desc->rel_ld;
-    pa.adj = (float*)(ws + L->adj[0]);
+    pa.adj = adj_elided ? nullptr : (float*)(ws + L->adj[0]);
     pa.pos = (float*)(ws + L->pos[0]);
     pa.x2 = x2;
     pa.D = D;
@@ -1237,10 +1266,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     bool flash_fused_prep = false;
     {
         ProfScope ps(PROF_LP_PREP, st);
-        const char* pv = getenv("MARIUS_PREP");  // MARIUS_PREP=1: one-wave-per-row kernel (any shape)
-        const bool vec_ok = (D.d % 4 == 0) && D.d <= 128 && (desc->emb_ld % 2 == 0) && (desc->rel_ld % 2 == 0 || !desc->rel) && (D.d == D.d_ld) &&
-                            ((reinterpret_cast<uintptr_t>(desc->emb) & 7) == 0) && ((reinterpret_cast<uintptr_t>(desc->rel) & 7) == 0) &&
-                            ((reinterpret_cast<uintptr_t>(desc->inv_rel) & 7) == 0) && !(pv && pv[0] == '1');
+        const bool vec_ok = lp_vec_ok(desc, D);
         int64_t prep_rows = D.Bp;
         if (vec_ok && L->flash) {  // the adj records and the dadj zero fill ride along (lp_flash.hip)
             pa.fKP = (D.d + 15) / 16 * 16;
@@ -1485,7 +1511,7 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     ea.rel[0] = desc->rel;
     ea.rel[1] = desc->inv_rel;
     ea.rel_ld = desc->rel_ld;
-    ea.adj = ga.adj;
+    ea.adj = flash_adj_elided(desc, D, L) ? nullptr : ga.adj;
     ea.pos = (const float*)(ws + L->pos[0]);
     ea.dpos = (const float*)(ws + L->dpos[0]);
     ea.dadj = ga.dadj;
@@ -1495,10 +1521,7 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     ea.D = D;
     {
         ProfScope ps(PROF_LP_EDGE_BWD, st);
-        const char* pv = getenv("MARIUS_PREP");  // MARIUS_PREP=1: one-wave-per-edge kernel (any shape)
-        const bool vec_ok = (D.d % 4 == 0) && D.d <= 128 && (desc->emb_ld % 2 == 0) && (desc->rel_ld % 2 == 0 || !desc->rel) && (D.d == D.d_ld) &&
-                            ((reinterpret_cast<uintptr_t>(desc->emb) & 7) == 0) && ((reinterpret_cast<uintptr_t>(desc->rel) & 7) == 0) &&
-                            ((reinterpret_cast<uintptr_t>(desc->inv_rel) & 7) == 0) && !(pv && pv[0] == '1');
+        const bool vec_ok = lp_vec_ok(desc, D);
         if (vec_ok)
             lp_edge_bwd2_kernel<<<dim3((unsigned)cdiv(D.B, 8)), dim3(256), 0, st>>>(ea);
         else
