@@ -301,6 +301,18 @@ int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld, const int
                                    const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* uniq_ids, float* table,
                                    float* state, int64_t table_ld, float lr, float eps, void* carry, marius_stream_t stream);
 
+/* The index work of the two calls above depends on perm / inverse / seg_offsets / uniq_ids only — known when the batch is prepared, a step
+ * before its gradients exist.  marius_segment_plan precomputes it (per sorted position: occurrence row, unique index, inside-one-chunk and
+ * singleton flags; per chunk: the boundary-crossing segment it owns; per unique row: table row id and the occurrence row of a singleton) on
+ * whatever stream prepares batches; marius_segment_adagrad_scatter_planned then runs the same three kernels with one coalesced load where
+ * the unplanned form walks a chain of dependent index loads.  Same results bit for bit.  plan: marius_segment_plan_bytes(n) bytes. */
+size_t marius_segment_plan_bytes(int64_t n);
+int marius_segment_plan(const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, const int64_t* uniq_ids, int64_t n, void* plan,
+                        marius_stream_t stream);
+int marius_segment_adagrad_scatter_planned(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
+                                           const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* uniq_ids, float* table, float* state,
+                                           int64_t table_ld, float lr, float eps, void* carry, const void* plan, marius_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

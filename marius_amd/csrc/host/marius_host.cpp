@@ -392,7 +392,7 @@ void Batch::clear() {
     unique_node_indices_ = node_embeddings_ = node_embeddings_grad_ = node_gradients_ = node_state_update_ = node_embeddings_state_ = Tensor();
     edges_ = global_edges_ = table_ = src_neg_indices_ = dst_neg_indices_ = src_neg_indices_mapping_ = dst_neg_indices_mapping_ = Tensor();
     src_neg_filter_ = dst_neg_filter_ = occ_perm_ = occ_inverse_ = occ_seg_offsets_ = num_unique_dev_ = Tensor();
-    rel_uniq_ = rel_inverse_ = rel_perm_ = rel_seg_ = rel_count_ = Tensor();
+    rel_uniq_ = rel_inverse_ = rel_perm_ = rel_seg_ = rel_count_ = occ_plan_ = rel_plan_ = Tensor();
 }
 
 // ------------------------------------------------------------------------------------------------ LP context / fused decoder calls
@@ -1020,12 +1020,14 @@ struct RelMap {
     const int64_t* inverse;
     const int32_t* perm;
     const int32_t* seg;
+    const void* plan = nullptr;  // marius_segment_plan of this map, when the loader prepared one
 };
 static RelMap relation_map(Model& m, shared_ptr<Batch> batch) {
     LpContext& c = m.ctx_;
     const int64_t B = c.desc.B;
     if (batch->rel_perm_.defined() && batch->rel_perm_.size(0) == B)
-        return {ip(batch->rel_uniq_), ip(batch->rel_inverse_), batch->rel_perm_.data_ptr<int32_t>(), batch->rel_seg_.data_ptr<int32_t>()};
+        return {ip(batch->rel_uniq_), ip(batch->rel_inverse_), batch->rel_perm_.data_ptr<int32_t>(), batch->rel_seg_.data_ptr<int32_t>(),
+                batch->rel_plan_.defined() ? batch->rel_plan_.data_ptr() : nullptr};
     auto dev = c.workspace.device();
     if (!m.rel_ids_.defined() || m.rel_ids_.size(0) != B) {
         m.rel_ids_ = torch::empty({B}, i64(dev));
@@ -1076,8 +1078,12 @@ static bool relation_step_sparse(Model& m, shared_ptr<Batch> batch) {
     for (int dir = 0; dir < ndir; ++dir) {
         Tensor& w = opt->params_[dir].first;
         const float* rows = (const float*)((const char*)c.workspace.data_ptr() + c.layout.grel[dir]);
-        mcheck(marius_segment_adagrad_scatter(rows, c.layout.d_ld, rm.perm, rm.inverse, rm.seg, B, c.desc.d, rm.uniq, fp(w), fp(opt->state_[dir]), w.stride(0),
-                                              opt->learning_rate_, opt->eps_, m.rel_carry_.data_ptr(), cur_stream()));
+        if (rm.plan)
+            mcheck(marius_segment_adagrad_scatter_planned(rows, c.layout.d_ld, rm.perm, rm.inverse, rm.seg, B, c.desc.d, rm.uniq, fp(w), fp(opt->state_[dir]),
+                                                          w.stride(0), opt->learning_rate_, opt->eps_, m.rel_carry_.data_ptr(), rm.plan, cur_stream()));
+        else
+            mcheck(marius_segment_adagrad_scatter(rows, c.layout.d_ld, rm.perm, rm.inverse, rm.seg, B, c.desc.d, rm.uniq, fp(w), fp(opt->state_[dir]), w.stride(0),
+                                                  opt->learning_rate_, opt->eps_, m.rel_carry_.data_ptr(), cur_stream()));
     }
     return true;
 }
@@ -1209,9 +1215,14 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
     const int64_t L = batch->occ_perm_.size(0);
     ensure(carry_, (int64_t)marius_segment_carry_bytes(L, ctx_.desc.d), device_);
     const float* gocc = (const float*)((const char*)ctx_.workspace.data_ptr() + ctx_.layout.gocc);
-    mcheck(marius_segment_adagrad_scatter(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
-                                          batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, ip(batch->unique_node_indices_), fp(table),
-                                          fp(state), table.stride(0), sparse_lr_, 1e-10f, carry_.data_ptr(), cur_stream()));
+    if (batch->occ_plan_.defined())
+        mcheck(marius_segment_adagrad_scatter_planned(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
+                                                      batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, ip(batch->unique_node_indices_), fp(table),
+                                                      fp(state), table.stride(0), sparse_lr_, 1e-10f, carry_.data_ptr(), batch->occ_plan_.data_ptr(), cur_stream()));
+    else
+        mcheck(marius_segment_adagrad_scatter(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
+                                              batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, ip(batch->unique_node_indices_), fp(table),
+                                              fp(state), table.stride(0), sparse_lr_, 1e-10f, carry_.data_ptr(), cur_stream()));
     HIPCHECK(hipStreamWaitEvent(main.stream(), (hipEvent_t)ev_join_, 0));
 }
 
@@ -1644,6 +1655,10 @@ shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
     batch->occ_inverse_ = inverse_;
     batch->occ_seg_offsets_ = seg_;
     batch->num_unique_dev_ = count_;
+    if (train_ && run_ahead_) {  // the fused update's index work, done here (this stream runs a step ahead of the gradients)
+        batch->occ_plan_ = torch::empty({(int64_t)marius_segment_plan_bytes(L)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+        mcheck(marius_segment_plan(perm_.data_ptr<int32_t>(), ip(inverse_), seg_.data_ptr<int32_t>(), ip(uniq_), L, batch->occ_plan_.data_ptr(), st));
+    }
     if (train_ && cols == 3 && num_relations_ > 0) {  // index_select backward into [R, d] wants the relation ids grouped: sort them here
         Tensor rel_ids = edges.select(1, 1).contiguous();
         batch->rel_uniq_ = torch::empty({B}, i64(dev));
@@ -1654,6 +1669,11 @@ shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
         mcheck(marius_sort_unique(ip(rel_ids), B, key_bits_for(num_relations_), ip(batch->rel_uniq_), ip(batch->rel_inverse_),
                                   batch->rel_perm_.data_ptr<int32_t>(), batch->rel_seg_.data_ptr<int32_t>(), ip(batch->rel_count_), sort_ws_.data_ptr(),
                                   (size_t)sort_ws_.numel(), st));
+        if (run_ahead_) {
+            batch->rel_plan_ = torch::empty({(int64_t)marius_segment_plan_bytes(B)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+            mcheck(marius_segment_plan(batch->rel_perm_.data_ptr<int32_t>(), ip(batch->rel_inverse_), batch->rel_seg_.data_ptr<int32_t>(), ip(batch->rel_uniq_), B,
+                                       batch->rel_plan_.data_ptr(), st));
+        }
     }
     return batch;
 }

@@ -189,6 +189,7 @@ class Batch {
     Tensor src_neg_filter_, dst_neg_filter_;                     // [F, 2]
     // device-side products of the unique map that the fused update consumes
     Tensor occ_perm_, occ_inverse_, occ_seg_offsets_, num_unique_dev_;
+    Tensor occ_plan_, rel_plan_;  // marius_segment_plan of the node / relation unique maps (prepared with the batch, off the critical path)
     // sorted-unique map of the batch's relation ids (column 1), prepared by the loader so the relation-gradient reduction needs no
     // sort on the compute stream: uniq [B] (zero tail), inverse [B], perm [B] int32, seg [B+1] int32
     Tensor rel_uniq_, rel_inverse_, rel_perm_, rel_seg_, rel_count_;

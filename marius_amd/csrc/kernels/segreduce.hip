@@ -28,6 +28,10 @@ struct SegArgs {
     float* carry;  // [nchunks][2][dpad]
     int dpad;
     int skip_singletons;  // 1: segments of length 1 are neither loaded nor written (their consumer reads the occurrence row itself)
+    // optional plan (marius_segment_plan): what the kernels otherwise derive through chains of dependent index loads, precomputed off the
+    // critical path (the ids are known a step before the gradients exist)
+    const int4* pos_plan;    // [n]        per sorted position: {occurrence row, unique index, complete-in-chunk, singleton}
+    const int4* chunk_plan;  // [nchunks]  per chunk: {owns a boundary-crossing segment, its unique index, carry slot of its first partial, last chunk}
 };
 
 struct ApplySum {
@@ -90,11 +94,19 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply)
     // lane r < cnt owns sorted position k0 + r: its occurrence row, its segment, and whether that segment lies inside the chunk
     int p = 0, u = -1, complete = 0, single = 0;
     if (lane < cnt) {
-        p = a.perm[k0 + lane];
-        u = (int)a.inverse[p];
-        const int s0 = a.seg_offsets[u], s1 = a.seg_offsets[u + 1];
-        complete = (s0 >= k0) && (s1 <= k1);
-        single = a.skip_singletons && (s1 - s0 == 1);
+        if (a.pos_plan) {
+            const int4 q = a.pos_plan[k0 + lane];
+            p = q.x;
+            u = q.y;
+            complete = q.z;
+            single = a.skip_singletons && q.w;
+        } else {
+            p = a.perm[k0 + lane];
+            u = (int)a.inverse[p];
+            const int s0 = a.seg_offsets[u], s1 = a.seg_offsets[u + 1];
+            complete = (s0 >= k0) && (s1 <= k1);
+            single = a.skip_singletons && (s1 - s0 == 1);
+        }
     }
     const int u_first = __shfl(u, 0, 64);
     float acc[NIT][VEC];
@@ -168,11 +180,21 @@ __global__ __launch_bounds__(256) void seg_fixup_kernel(SegArgs a, Apply apply) 
     const int64_t k0 = chunk * SEG_R;
     if (k0 >= a.n) return;
     const int64_t k1 = min(k0 + SEG_R, a.n);
-    const int u_first = (int)a.inverse[a.perm[k0]];
-    const int u_last = (int)a.inverse[a.perm[k1 - 1]];
-    const int64_t s0 = a.seg_offsets[u_last], s1 = a.seg_offsets[u_last + 1];
-    if (!(s0 >= k0 && s1 > k1)) return;  // not the owner of a crossing segment
-    const int64_t last_chunk = (s1 - 1) / SEG_R;
+    int u_first, u_last;
+    int64_t last_chunk;
+    if (a.chunk_plan) {
+        const int4 q = a.chunk_plan[chunk];
+        if (!q.x) return;  // not the owner of a crossing segment
+        u_last = q.y;
+        u_first = q.z ? -1 : q.y;  // only (u_last == u_first) is used below: slot 0 iff the segment opens the chunk
+        last_chunk = q.w;
+    } else {
+        u_first = (int)a.inverse[a.perm[k0]];
+        u_last = (int)a.inverse[a.perm[k1 - 1]];
+        const int64_t s0 = a.seg_offsets[u_last], s1 = a.seg_offsets[u_last + 1];
+        if (!(s0 >= k0 && s1 > k1)) return;  // not the owner of a crossing segment
+        last_chunk = (s1 - 1) / SEG_R;
+    }
     float acc[NIT][VEC];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -223,6 +245,32 @@ __global__ __launch_bounds__(256) void seg_fixup_kernel(SegArgs a, Apply apply) 
     }
 }
 
+// ---- plan: everything the three kernels derive from perm / inverse / seg_offsets alone
+// row_plan [n]: per unique row u < U {table row id (int64 split in two ints), occurrence row of a singleton or -1, unused}
+__global__ __launch_bounds__(256) void seg_plan_kernel(const int32_t* __restrict__ perm, const int64_t* __restrict__ inverse, const int32_t* __restrict__ seg_offsets,
+                                                       const int64_t* __restrict__ uniq, int64_t n, int4* __restrict__ pos_plan, int4* __restrict__ chunk_plan,
+                                                       int4* __restrict__ row_plan) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int64_t U = inverse[perm[n - 1]] + 1;
+    const int64_t k0 = k / SEG_R * SEG_R, k1 = min(k0 + SEG_R, n);
+    const int p = perm[k];
+    const int u = (int)inverse[p];
+    const int s0 = seg_offsets[u], s1 = seg_offsets[u + 1];
+    pos_plan[k] = make_int4(p, u, (s0 >= k0 && s1 <= k1) ? 1 : 0, (s1 - s0 == 1) ? 1 : 0);
+    if (k == k1 - 1) {  // last position of its chunk: does the chunk own a boundary-crossing segment (the one its last position belongs to)?
+        const bool owner = (s0 >= k0) && (s1 > k1);
+        chunk_plan[k / SEG_R] = make_int4(owner ? 1 : 0, u, (s0 != k0) ? 1 : 0, (int)((s1 - 1) / SEG_R));
+    }
+    if (k < U) {  // thread k also describes unique row k
+        const int64_t id = uniq[k];
+        const int t0 = seg_offsets[k], t1 = seg_offsets[k + 1];
+        row_plan[k] = make_int4((int)(id & 0xffffffffll), (int)(id >> 32), (t1 - t0 == 1) ? perm[t0] : -1, 0);
+    } else {
+        row_plan[k] = make_int4(-1, -1, -1, 0);
+    }
+}
+
 static inline int dpad_of(int d) { return (d + 3) / 4 * 4; }
 
 // Row-parallel sparse Adagrad over the per-unique-row gradients g[U, dpad] (U = inverse[perm[n-1]] + 1 read on the device):
@@ -232,9 +280,9 @@ __global__ __launch_bounds__(256) void adagrad_unique_rows_kernel(const float* _
                                                                   const int64_t* __restrict__ inverse, int64_t n, const int64_t* __restrict__ uniq,
                                                                   float* __restrict__ table, float* __restrict__ state, int64_t ld, int vpr,
                                                                   float lr, float eps, const float* __restrict__ occ, int64_t occ_ld,
-                                                                  const int32_t* __restrict__ seg_offsets) {
+                                                                  const int32_t* __restrict__ seg_offsets, const int4* __restrict__ row_plan) {
 #pragma clang fp contract(off)
-    const int64_t U = inverse[perm[n - 1]] + 1;
+    const int64_t U = row_plan ? n : inverse[perm[n - 1]] + 1;  // planned: rows past U carry id -1
     const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
     constexpr int UNR = 4;
     int64_t rows[UNR], ids[UNR];
@@ -242,11 +290,20 @@ __global__ __launch_bounds__(256) void adagrad_unique_rows_kernel(const float* _
 #pragma unroll
     for (int k = 0; k < UNR; ++k) {
         rows[k] = ((int64_t)blockIdx.x * UNR + k) * TY + ty;
-        ids[k] = rows[k] < U ? uniq[rows[k]] : -1;
         grow[k] = g + rows[k] * g_ld;
-        if (ids[k] >= 0 && occ) {
-            const int s0 = seg_offsets[rows[k]], s1 = seg_offsets[rows[k] + 1];
-            if (s1 - s0 == 1) grow[k] = occ + (int64_t)perm[s0] * occ_ld;
+        if (row_plan) {
+            ids[k] = -1;
+            if (rows[k] < U) {
+                const int4 q = row_plan[rows[k]];
+                ids[k] = ((int64_t)q.y << 32) | (int64_t)(uint32_t)q.x;
+                if (occ && q.z >= 0) grow[k] = occ + (int64_t)q.z * occ_ld;
+            }
+        } else {
+            ids[k] = rows[k] < U ? uniq[rows[k]] : -1;
+            if (ids[k] >= 0 && occ) {
+                const int s0 = seg_offsets[rows[k]], s1 = seg_offsets[rows[k] + 1];
+                if (s1 - s0 == 1) grow[k] = occ + (int64_t)perm[s0] * occ_ld;
+            }
         }
     }
     for (int c = tx; c < vpr; c += TX) {
@@ -324,6 +381,8 @@ static int fill_args(SegArgs& a, const float* rows, int64_t rows_ld, const int32
     a.carry = (float*)carry;
     a.dpad = dpad_of(d);
     a.skip_singletons = 0;
+    a.pos_plan = nullptr;
+    a.chunk_plan = nullptr;
     return MARIUS_OK;
 }
 
@@ -353,10 +412,42 @@ extern "C" int marius_segment_sum_rows(const float* rows, int64_t rows_ld, const
     return launch_seg(a, ap, vec, as_stream(stream));
 }
 
+static inline size_t plan_pos_bytes(int64_t n) { return ((size_t)(n > 0 ? n : 1) * sizeof(int4) + 255) / 256 * 256; }
+static inline size_t plan_chunk_bytes(int64_t n) { return ((size_t)cdiv(n > 0 ? n : 1, SEG_R) * sizeof(int4) + 255) / 256 * 256; }
+
+extern "C" size_t marius_segment_plan_bytes(int64_t n) { return 2 * plan_pos_bytes(n) + plan_chunk_bytes(n); }
+
+extern "C" int marius_segment_plan(const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, const int64_t* uniq_ids, int64_t n, void* plan,
+                                   marius_stream_t stream) {
+    MARIUS_REQUIRE(n >= 0 && (n == 0 || (perm && inverse && seg_offsets && uniq_ids && plan)), "segment_plan: bad arguments");
+    if (n == 0) return MARIUS_OK;
+    char* p = (char*)plan;
+    seg_plan_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream)>>>(perm, inverse, seg_offsets, uniq_ids, n, (int4*)p,
+                                                                                        (int4*)(p + plan_pos_bytes(n)), (int4*)(p + plan_pos_bytes(n) + plan_chunk_bytes(n)));
+    return check_launch("segment_plan");
+}
+
+static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, int64_t n,
+                                        int32_t d, const int64_t* uniq_ids, float* table, float* state, int64_t table_ld, float lr, float eps, void* carry,
+                                        const void* plan, marius_stream_t stream);
+
 extern "C" int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
                                               const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* uniq_ids,
                                               float* table, float* state, int64_t table_ld, float lr, float eps, void* carry,
                                               marius_stream_t stream) {
+    return segment_adagrad_scatter_impl(rows, rows_ld, perm, inverse, seg_offsets, n, d, uniq_ids, table, state, table_ld, lr, eps, carry, nullptr, stream);
+}
+
+extern "C" int marius_segment_adagrad_scatter_planned(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
+                                                      const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* uniq_ids, float* table, float* state,
+                                                      int64_t table_ld, float lr, float eps, void* carry, const void* plan, marius_stream_t stream) {
+    MARIUS_REQUIRE(plan || n == 0, "segment_adagrad_scatter_planned: null plan");
+    return segment_adagrad_scatter_impl(rows, rows_ld, perm, inverse, seg_offsets, n, d, uniq_ids, table, state, table_ld, lr, eps, carry, plan, stream);
+}
+
+static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, int64_t n,
+                                        int32_t d, const int64_t* uniq_ids, float* table, float* state, int64_t table_ld, float lr, float eps, void* carry,
+                                        const void* plan, marius_stream_t stream) {
     SegArgs a;
     int rc = fill_args(a, rows, rows_ld, perm, inverse, seg_offsets, n, d, carry);
     if (rc) return rc;
@@ -378,6 +469,13 @@ extern "C" int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld
     const char* ns = getenv("MARIUS_SEG_NO_SKIP");
     const bool skip = !(ns && ns[0] == '1') && vec <= vsum;
     a.skip_singletons = skip ? 1 : 0;
+    const int4* row_plan = nullptr;
+    if (plan) {
+        const char* pp = (const char*)plan;
+        a.pos_plan = (const int4*)pp;
+        a.chunk_plan = (const int4*)(pp + plan_pos_bytes(n));
+        row_plan = (const int4*)(pp + plan_pos_bytes(n) + plan_chunk_bytes(n));
+    }
     rc = launch_seg(a, ap, vsum, st);
     if (rc) return rc;
     // (2) row-parallel Adagrad + scatter (ids ascending and unique: race-free, fully pipelined loads)
@@ -388,10 +486,10 @@ extern "C" int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld
     dim3 block(tx, ty, 1), grid((unsigned)cdiv(n, (int64_t)ty * 4));
     const float* occ = skip ? rows : nullptr;
     if (vec == 4)
-        adagrad_unique_rows_kernel<4><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets);
+        adagrad_unique_rows_kernel<4><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets, row_plan);
     else if (vec == 2)
-        adagrad_unique_rows_kernel<2><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets);
+        adagrad_unique_rows_kernel<2><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets, row_plan);
     else
-        adagrad_unique_rows_kernel<1><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets);
+        adagrad_unique_rows_kernel<1><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets, row_plan);
     return check_launch("segment_adagrad_scatter");
 }

@@ -92,6 +92,9 @@ SIGNATURES = {
     "marius_segment_carry_bytes": (_sz, [_i64, _i32]),
     "marius_segment_sum_rows": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp]),
     "marius_segment_adagrad_scatter": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp]),
+    "marius_segment_plan_bytes": (C.c_size_t, [_i64]),
+    "marius_segment_plan": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "marius_segment_adagrad_scatter_planned": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -391,10 +394,22 @@ def segment_sum_rows(rows, um, n, d, out, out_rows=None, carry=None):
     return out
 
 
-def segment_adagrad_scatter(rows, um, n, d, table, state, lr, eps=1e-10, carry=None):
+def segment_plan(um, n):
+    """marius_segment_plan of a unique map: the index work of the fused update, precomputable as soon as the ids are sorted."""
+    plan = torch.empty(int(lib().marius_segment_plan_bytes(n)), dtype=torch.uint8, device=um.perm.device)
+    check(lib().marius_segment_plan(ptr(um.perm), ptr(um.inverse), ptr(um.seg), ptr(um.uniq), n, ptr(plan), stream_ptr()), "segment_plan")
+    return plan
+
+
+def segment_adagrad_scatter(rows, um, n, d, table, state, lr, eps=1e-10, carry=None, plan=None):
     _dev(rows)
     if carry is None:
         carry = segment_carry(n, d, rows.device)
+    if plan is not None:
+        check(lib().marius_segment_adagrad_scatter_planned(ptr(rows), rows.stride(0), ptr(um.perm), ptr(um.inverse), ptr(um.seg), n, d, ptr(um.uniq),
+                                                           ptr(table), ptr(state), table.stride(0), lr, eps, ptr(carry), ptr(plan), stream_ptr()),
+              "segment_adagrad_scatter_planned")
+        return
     check(lib().marius_segment_adagrad_scatter(ptr(rows), rows.stride(0), ptr(um.perm), ptr(um.inverse), ptr(um.seg), n, d, ptr(um.uniq),
                                                ptr(table), ptr(state), table.stride(0), lr, eps, ptr(carry), stream_ptr()),
           "segment_adagrad_scatter")

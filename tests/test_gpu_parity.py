@@ -389,6 +389,25 @@ def test_segment_adagrad_scatter_matches_reference_update(H, dev):
     assert_close(s_d, state, "state after update", rtol=1e-5)
 
 
+@pytest.mark.parametrize("n,num_nodes,power,d", [(8000, 3000, 3, 100), (200000, 86054151, 1, 100), (50000, 40, 4, 64), (33, 5, 1, 20), (1, 9, 1, 8)])
+def test_planned_segment_adagrad_scatter_is_bit_identical(H, dev, n, num_nodes, power, d):
+    """marius_segment_plan precomputes the index chains of the fused update; the planned call must leave exactly the bits of the unplanned one:
+    singletons only, hub rows spanning hundreds of chunks (40 ids over 50,000 occurrences), a single chunk, a single row."""
+    g = torch.Generator().manual_seed(n + d)
+    ids = (torch.rand(n, generator=g) ** power * num_nodes).long().clamp_(0, num_nodes - 1)
+    rows = (torch.randn(n, d, generator=g) * 0.1).to(dev)
+    rows_of_table = min(num_nodes, 200000)
+    ids = ids % rows_of_table
+    table, state = torch.randn(rows_of_table, d, generator=g), torch.rand(rows_of_table, d, generator=g)
+    um = H.UniqueMap(n, dev).run(ids.to(dev), key_bits=28)
+    ta, sa, tb, sb = table.to(dev), state.to(dev), table.to(dev), state.to(dev)
+    H.segment_adagrad_scatter(rows, um, n, d, ta, sa, lr=0.1)
+    plan = H.segment_plan(um, n)
+    H.segment_adagrad_scatter(rows, um, n, d, tb, sb, lr=0.1, plan=plan)
+    assert torch.equal(ta, tb) and torch.equal(sa, sb)
+    assert not torch.equal(ta.cpu(), table)
+
+
 # ------------------------------------------------------------------------------------------------ whole steps vs the CPU path
 @pytest.mark.parametrize("decoder,f", [("COMPLEX", 0.0), ("DISTMULT", 0.5), ("TRANSE", 0.0)])
 def test_train_steps_match_cpu_reference_path(H, dev, decoder, f):
