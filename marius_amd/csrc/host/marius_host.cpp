@@ -1395,7 +1395,12 @@ void DataLoader::start_shuffle_ahead() {
     auto* a = new ShuffleAhead();
     a->n = num_edges_;
     a->start.assign((const uint32_t*)generator_->state_host_.data_ptr<int32_t>(), (const uint32_t*)generator_->state_host_.data_ptr<int32_t>() + MARIUS_MT_STATE_WORDS);
-    a->perm = torch::empty({num_edges_}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
+    try {
+        a->perm = torch::empty({num_edges_}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
+    } catch (const std::exception&) {  // no room for a second (pinned) permutation: the serial draw at the boundary stays
+        delete a;
+        return;
+    }
     int64_t* out = a->perm.data_ptr<int64_t>();
     a->th = std::thread([a, words, out] {
         const auto t0 = std::chrono::steady_clock::now();

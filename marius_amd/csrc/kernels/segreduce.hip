@@ -174,9 +174,9 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply)
 
 // phase 2: the chunk in which a boundary-crossing segment STARTS finishes it from the carries
 template <int VEC, int NIT, class Apply>
-__global__ __launch_bounds__(256) void seg_fixup_kernel(SegArgs a, Apply apply) {
+__device__ __forceinline__ void seg_fixup_body(const SegArgs& a, const Apply& apply, int64_t block) {
     const int lane = threadIdx.x & 63;
-    const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t chunk = block * 4 + (threadIdx.x >> 6);
     const int64_t k0 = chunk * SEG_R;
     if (k0 >= a.n) return;
     const int64_t k1 = min(k0 + SEG_R, a.n);
@@ -245,8 +245,13 @@ __global__ __launch_bounds__(256) void seg_fixup_kernel(SegArgs a, Apply apply) 
     }
 }
 
+template <int VEC, int NIT, class Apply>
+__global__ __launch_bounds__(256) void seg_fixup_kernel(SegArgs a, Apply apply) {
+    seg_fixup_body<VEC, NIT, Apply>(a, apply, (int64_t)blockIdx.x);
+}
+
 // ---- plan: everything the three kernels derive from perm / inverse / seg_offsets alone
-// row_plan [n]: per unique row u < U {table row id (int64 split in two ints), occurrence row of a singleton or -1, unused}
+// row_plan [n]: per unique row u < U {table row id (int64 split in two ints), occurrence row of a singleton or -1, segment crosses a chunk boundary}
 __global__ __launch_bounds__(256) void seg_plan_kernel(const int32_t* __restrict__ perm, const int64_t* __restrict__ inverse, const int32_t* __restrict__ seg_offsets,
                                                        const int64_t* __restrict__ uniq, int64_t n, int4* __restrict__ pos_plan, int4* __restrict__ chunk_plan,
                                                        int4* __restrict__ row_plan) {
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256) void seg_plan_kernel(const int32_t* __restrict
     if (k < U) {  // thread k also describes unique row k
         const int64_t id = uniq[k];
         const int t0 = seg_offsets[k], t1 = seg_offsets[k + 1];
-        row_plan[k] = make_int4((int)(id & 0xffffffffll), (int)(id >> 32), (t1 - t0 == 1) ? perm[t0] : -1, 0);
+        row_plan[k] = make_int4((int)(id & 0xffffffffll), (int)(id >> 32), (t1 - t0 == 1) ? perm[t0] : -1, (t0 / SEG_R != (t1 - 1) / SEG_R) ? 1 : 0);
     } else {
         row_plan[k] = make_int4(-1, -1, -1, 0);
     }
@@ -275,21 +280,49 @@ static inline int dpad_of(int d) { return (d + 3) / 4 * 4; }
 
 // Row-parallel sparse Adagrad over the per-unique-row gradients g[U, dpad] (U = inverse[perm[n-1]] + 1 read on the device):
 //   ds = g*g; s = state[id] + ds; table[id] += -lr * (g / (sqrt(s) + eps)); state[id] = s        (batch.cpp:67-69 op order)
+struct AdagradRowsArgs {
+    const float* g;
+    int64_t g_ld;
+    const int32_t* perm;
+    const int64_t* inverse;
+    int64_t n;
+    const int64_t* uniq;
+    float* table;
+    float* state;
+    int64_t ld;
+    int vpr, tx_n;  // VEC-float pieces per row; threads along a row (power of two <= 64): 256 / tx_n rows per block pass
+    float lr, eps;
+    const float* occ;
+    int64_t occ_ld;
+    const int32_t* seg_offsets;
+    const int4* row_plan;
+    int skip_crossing;  // 1: rows whose segment crosses a chunk boundary are updated by the fix-up workgroups of the same launch
+};
+
 template <int VEC>
-__global__ __launch_bounds__(256) void adagrad_unique_rows_kernel(const float* __restrict__ g, int64_t g_ld, const int32_t* __restrict__ perm,
-                                                                  const int64_t* __restrict__ inverse, int64_t n, const int64_t* __restrict__ uniq,
-                                                                  float* __restrict__ table, float* __restrict__ state, int64_t ld, int vpr,
-                                                                  float lr, float eps, const float* __restrict__ occ, int64_t occ_ld,
-                                                                  const int32_t* __restrict__ seg_offsets, const int4* __restrict__ row_plan) {
+__device__ __forceinline__ void adagrad_rows_body(const AdagradRowsArgs& A, int64_t block) {
 #pragma clang fp contract(off)
+    const float* __restrict__ g = A.g;
+    const int64_t g_ld = A.g_ld, n = A.n, ld = A.ld, occ_ld = A.occ_ld;
+    const int32_t* __restrict__ perm = A.perm;
+    const int64_t* __restrict__ inverse = A.inverse;
+    const int64_t* __restrict__ uniq = A.uniq;
+    float* __restrict__ table = A.table;
+    float* __restrict__ state = A.state;
+    const int vpr = A.vpr;
+    const float lr = A.lr, eps = A.eps;
+    const float* __restrict__ occ = A.occ;
+    const int32_t* __restrict__ seg_offsets = A.seg_offsets;
+    const int4* __restrict__ row_plan = A.row_plan;
     const int64_t U = row_plan ? n : inverse[perm[n - 1]] + 1;  // planned: rows past U carry id -1
-    const int tx = threadIdx.x, ty = threadIdx.y, TX = blockDim.x, TY = blockDim.y;
+    const int TX = A.tx_n, TY = 256 / TX;
+    const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x / TX;
     constexpr int UNR = 4;
     int64_t rows[UNR], ids[UNR];
     const float* grow[UNR];  // the row's gradient: the reduced sum, or (segment of one occurrence) that occurrence's row itself
 #pragma unroll
     for (int k = 0; k < UNR; ++k) {
-        rows[k] = ((int64_t)blockIdx.x * UNR + k) * TY + ty;
+        rows[k] = (block * UNR + k) * TY + ty;
         grow[k] = g + rows[k] * g_ld;
         if (row_plan) {
             ids[k] = -1;
@@ -297,6 +330,7 @@ __global__ __launch_bounds__(256) void adagrad_unique_rows_kernel(const float* _
                 const int4 q = row_plan[rows[k]];
                 ids[k] = ((int64_t)q.y << 32) | (int64_t)(uint32_t)q.x;
                 if (occ && q.z >= 0) grow[k] = occ + (int64_t)q.z * occ_ld;
+                if (A.skip_crossing && q.w) ids[k] = -1;
             }
         } else {
             ids[k] = rows[k] < U ? uniq[rows[k]] : -1;
@@ -337,15 +371,31 @@ __global__ __launch_bounds__(256) void adagrad_unique_rows_kernel(const float* _
     }
 }
 
+template <int VEC>
+__global__ __launch_bounds__(256) void adagrad_unique_rows_kernel(AdagradRowsArgs A) {
+    adagrad_rows_body<VEC>(A, (int64_t)blockIdx.x);
+}
+
+// One launch, two kinds of workgroups (planned form): the first `nfix` finish the segments that cross chunk boundaries from their carries
+// and apply Adagrad to those rows themselves; the rest update every other row.  The two sets of rows are disjoint and both only need the
+// reduce launch before them, so the fix-up no longer stands between the reduction and the update.
+template <int VEC, int NIT>
+__global__ __launch_bounds__(256) void adagrad_with_fixup_kernel(SegArgs sa, ApplyAdagrad ap, AdagradRowsArgs A, int nfix) {
+    if ((int)blockIdx.x < nfix)
+        seg_fixup_body<VEC, NIT, ApplyAdagrad>(sa, ap, (int64_t)blockIdx.x);
+    else
+        adagrad_rows_body<VEC>(A, (int64_t)blockIdx.x - nfix);
+}
+
 template <class Apply>
-static int launch_seg(const SegArgs& a, const Apply& apply, int vec, hipStream_t st) {
+static int launch_seg(const SegArgs& a, const Apply& apply, int vec, hipStream_t st, bool fixup = true) {
     const int64_t nchunks = cdiv(a.n, SEG_R);
     dim3 grid((unsigned)cdiv(nchunks, 4)), block(256);
     const int per = cdiv(a.d, 64 * vec);  // column iterations per lane
 #define SEG_LAUNCH(V, N)                                             \
     do {                                                             \
         seg_reduce_kernel<V, N, Apply><<<grid, block, 0, st>>>(a, apply); \
-        seg_fixup_kernel<V, N, Apply><<<grid, block, 0, st>>>(a, apply);  \
+        if (fixup) seg_fixup_kernel<V, N, Apply><<<grid, block, 0, st>>>(a, apply);  \
     } while (0)
     if (vec == 4) {
         if (per <= 1) SEG_LAUNCH(4, 1);
@@ -476,20 +526,35 @@ static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, cons
         a.chunk_plan = (const int4*)(pp + plan_pos_bytes(n));
         row_plan = (const int4*)(pp + plan_pos_bytes(n) + plan_chunk_bytes(n));
     }
-    rc = launch_seg(a, ap, vsum, st);
-    if (rc) return rc;
-    // (2) row-parallel Adagrad + scatter (ids ascending and unique: race-free, fully pipelined loads)
     const int vpr = d / vec;
     int tx = 1;
     while (tx < vpr && tx < 64) tx <<= 1;
     const int ty = 256 / tx;
-    dim3 block(tx, ty, 1), grid((unsigned)cdiv(n, (int64_t)ty * 4));
+    const unsigned row_blocks = (unsigned)cdiv(n, (int64_t)ty * 4);
     const float* occ = skip ? rows : nullptr;
+    AdagradRowsArgs A{gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, tx, lr, eps, occ, rows_ld, seg_offsets, row_plan, 0};
+    const int per = cdiv(d, 64 * vec);
+    const char* fz = getenv("MARIUS_SEG_FUSED_FIXUP");  // 0: the fix-up as its own launch between reduction and update (A/B runs)
+    if (plan && vec == vsum && vec == 4 && per <= 2 && !(fz && fz[0] == '0')) {
+        rc = launch_seg(a, ap, vsum, st, /*fixup=*/false);
+        if (rc) return rc;
+        A.skip_crossing = 1;
+        ApplyAdagrad aa{uniq_ids, table, state, table_ld, lr, eps};
+        const unsigned nfix = (unsigned)cdiv(cdiv(n, SEG_R), 4);
+        dim3 grid(nfix + row_blocks), block(256);
+        if (per <= 1) adagrad_with_fixup_kernel<4, 1><<<grid, block, 0, st>>>(a, aa, A, (int)nfix);
+        else adagrad_with_fixup_kernel<4, 2><<<grid, block, 0, st>>>(a, aa, A, (int)nfix);
+        return check_launch("segment_adagrad_scatter");
+    }
+    rc = launch_seg(a, ap, vsum, st);
+    if (rc) return rc;
+    // (2) row-parallel Adagrad + scatter (ids ascending and unique: race-free, fully pipelined loads)
+    dim3 block(256), grid(row_blocks);
     if (vec == 4)
-        adagrad_unique_rows_kernel<4><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets, row_plan);
+        adagrad_unique_rows_kernel<4><<<grid, block, 0, st>>>(A);
     else if (vec == 2)
-        adagrad_unique_rows_kernel<2><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets, row_plan);
+        adagrad_unique_rows_kernel<2><<<grid, block, 0, st>>>(A);
     else
-        adagrad_unique_rows_kernel<1><<<grid, block, 0, st>>>(gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, lr, eps, occ, rows_ld, seg_offsets, row_plan);
+        adagrad_unique_rows_kernel<1><<<grid, block, 0, st>>>(A);
     return check_launch("segment_adagrad_scatter");
 }
