@@ -72,6 +72,7 @@ struct FlashArgs {
     int XR, YR;         // records per (chunk, direction) block, multiples of 32
     int Xrows, Yrows;   // valid rows per block
     int ncd, XT, YB, nwg;
+    int rotate;         // 1: rotated sweeps (see flash_kernel)
     int64_t total;      // ncd * XT * YB
     int C, Bc, N, d;
     int64_t Bp;
@@ -359,18 +360,46 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
         }
     };
 
+    // ---- order of the streamed blocks inside a tile segment.  A workgroup's range covers parts of up to three stationary tiles; within a
+    // segment (blocks [lo, lo + len) of one tile) the accumulation order is free, so the sweep is ROTATED to start at the block whose index
+    // equals the workgroup-local time: block = lo + ((tau - lo) mod len), tau = items done so far.  Workgroups start together and advance at
+    // the same rate, so the 5-6 workgroups of an XCD that sit on the same (chunk, direction) then stream the same block at the same time and
+    // share it in that XCD's L2 (unrotated, each starts its sweep where its range happens to start: a block's reuse distance exceeds the L2
+    // and every stationary tile re-fetches the whole streamed operand).  a.rotate = 0 (MARIUS_FLASH_ROTATE=0): natural order.
+    struct Seg {
+        int lo, len, r;
+    };
+    auto seg_init = [&](int tile_, int it_) {  // it_: first item of this workgroup inside tile_
+        Seg g;
+        g.lo = it_ - tile_ * a.YB;
+        const int hi = min(it1 - tile_ * a.YB, a.YB);
+        g.len = hi - g.lo;
+        g.r = 0;
+        if (a.rotate) {
+            g.r = ((it_ - it0) - g.lo) % g.len;
+            if (g.r < 0) g.r += g.len;
+        }
+        return g;
+    };
     // ---- prologue: three tiles in flight.  (ptile, pyb) is the prefetch cursor; it stops at the last item of the range.
     int tile = it0 / a.YB, yb = it0 - tile * a.YB;
     int ptile = tile, pyb = yb, pit = it0;
+    Seg ps = seg_init(ptile, pit), cs = ps;
     auto padvance = [&]() {
         if (pit + 1 < it1) {
             ++pit;
-            if (++pyb == a.YB) { pyb = 0; ++ptile; }
+            if (++pyb == a.YB) {
+                pyb = 0;
+                ++ptile;
+                ps = seg_init(ptile, pit);
+            } else {
+                ps.r = ps.r + 1 == ps.len ? 0 : ps.r + 1;
+            }
         }
     };
 #pragma unroll
     for (int i = 0; i < NSLOT - 1; ++i) {
-        dma(ptile, pyb, i);
+        dma(ptile, ps.lo + ps.r, i);
         padvance();
     }
 
@@ -381,12 +410,15 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
             load_x(tile);
             cur_tile = tile;
             y_first = yb;
+            cs = seg_init(tile, it);
         }
+        const int yph = cs.lo + cs.r;  // the streamed block this item multiplies (yb stays the position inside the segment's logical range)
+        cs.r = cs.r + 1 == cs.len ? 0 : cs.r + 1;
         // tile `it` has landed once at most the NSLOT - 2 younger tiles' pieces are outstanding (loads retire in order; the x fragments
         // loaded above are younger still, so this over-waits at a tile switch, never under-waits)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * DMA_PER_WAVE) : "memory");
         __builtin_amdgcn_s_barrier();
-        dma(ptile, pyb, pslot);
+        dma(ptile, ps.lo + ps.r, pslot);
         padvance();
         pslot = pslot + 1 == NSLOT ? 0 : pslot + 1;
         const unsigned char* T = smem + slot * SLOT;
@@ -402,15 +434,15 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
                 const int x = xt * FL_XT + wave * 32 + l31;
 #pragma unroll
                 for (int r_ = 0; r_ < 16; ++r_) {
-                    const int y = yb * FL_YB + 16 * (r_ >> 3) + 8 * h + (r_ & 7);
+                    const int y = yph * FL_YB + 16 * (r_ >> 3) + 8 * h + (r_ & 7);
                     if (x < a.Xrows && y < a.Yrows)
                         a.S[((int64_t)dir * a.Bp + (int64_t)c_ * a.Bc + x) * a.n_ld + y] = t[r_];
                 }
             }
-            if ((yb + 1) * FL_YB > a.Yrows) {  // last block of the chunk: columns past N do not exist
+            if ((yph + 1) * FL_YB > a.Yrows) {  // last block of the chunk: columns past N do not exist
 #pragma unroll
                 for (int r_ = 0; r_ < 16; ++r_) {
-                    const int y = yb * FL_YB + 16 * (r_ >> 3) + 8 * h + (r_ & 7);
+                    const int y = yph * FL_YB + 16 * (r_ >> 3) + 8 * h + (r_ & 7);
                     if (y >= a.Yrows) t[r_] = -INFINITY;
                 }
             }
@@ -572,6 +604,10 @@ static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, cha
     a.YB = a.YR / FL_YB;
     a.total = (int64_t)a.ncd * a.XT * a.YB;
     a.nwg = fl_num_wg((int64_t)a.ncd * a.XT, mode);
+    {
+        const char* ro = getenv("MARIUS_FLASH_ROTATE");
+        a.rotate = (ro && ro[0] == '0') ? 0 : 1;
+    }
     a.C = D.C;
     a.Bc = D.Bc;
     a.N = D.N;
