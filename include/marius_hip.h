@@ -216,7 +216,7 @@ enum {
     /* The caller trains and never reads `neg` (Model::train_batch, model.cpp:290-333, as opposed to forward_lp's return value):
      * the library may run the flash-style path (lp_flash.hip) that keeps only the SoftmaxCE row statistics and recomputes score
      * tiles in the backward; layout.neg is then not allocated.  Honoured for SoftmaxCE + DotCompare without score filters and
-     * d in (48, 64] or (96, 128]; every other case silently takes the materialised-score kernels. */
+     * d in (16, 128]; every other case silently takes the materialised-score kernels. */
     MARIUS_LP_TRAIN_ONLY = 1,
     /* with MARIUS_LP_TRAIN_ONLY: additionally store the recomputed scores into layout.neg (parity tests of the split arithmetic) */
     MARIUS_LP_STORE_SCORES = 2

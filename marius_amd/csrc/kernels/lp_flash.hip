@@ -535,7 +535,7 @@ bool flash_applicable(const marius_lp_desc* desc, const LpDims& D) {
     if (D.loss != MARIUS_LOSS_SOFTMAX_CE || D.cmp != MARIUS_CMP_DOT) return false;
     if ((desc->dst_filter && desc->n_dst_filter > 0) || (desc->src_filter && desc->n_src_filter > 0)) return false;
     const int ks = fl_ks(D.d);
-    if (!(ks == 4 || ks == 7 || ks == 8)) return false;  // instantiated K depths: d in (48, 64], (96, 112], (112, 128]
+    if (ks < 2 || ks > 8) return false;  // instantiated K depths: d in (16, 128]
     if (D.ndir == 2 && !desc->src_neg) return false;
     return true;
 }
@@ -581,7 +581,11 @@ static int fl_launch(const FlashArgs& a, hipStream_t st) {
 template <int MODE, bool STORE_S>
 static int fl_dispatch(int ks, const FlashArgs& a, hipStream_t st) {
     switch (ks) {
+        case 2: return fl_launch<2, MODE, STORE_S>(a, st);
+        case 3: return fl_launch<3, MODE, STORE_S>(a, st);
         case 4: return fl_launch<4, MODE, STORE_S>(a, st);
+        case 5: return fl_launch<5, MODE, STORE_S>(a, st);
+        case 6: return fl_launch<6, MODE, STORE_S>(a, st);
         case 7: return fl_launch<7, MODE, STORE_S>(a, st);
         case 8: return fl_launch<8, MODE, STORE_S>(a, st);
     }
