@@ -338,6 +338,13 @@ def main():
             roofline.update({"peak_is": "dense BF16 MFMA", "bf16_products_per_fp32_product": 3, "contractions_per_launch": ncon,
                              "fp32_equivalent_tflops": round(k["achieved"] / 3, 2),
                              "note": "achieved = contractions_per_launch x 3 products x 2 Bp N d ndir flop / launch time (score tile recomputed in the backward launches)"})
+        try:  # transparency only: `achieved` / `frac` stay on the uncorrected event figure (event vs rocprofv3)
+            ov = event_pair_overhead_ms()
+            net = max(k["avg_ms"] - 2.0 * ov, 1e-6)
+            roofline.update({"event_pair_overhead_ms": round(ov, 4), "avg_ms_minus_bracket": round(net, 4),
+                             "frac_minus_bracket": round(k["frac"] * k["avg_ms"] / net, 4)})
+        except Exception:  # noqa: BLE001
+            pass
 
     # ---- CPU baseline: the oracle (port of the reference's CPU path) on a bounded sample, host cores of this box
     cpu = None
