@@ -67,9 +67,13 @@ constexpr int MERGE_MAX_RUNS = 64;
 struct RunOffsets {
     int64_t off[MERGE_MAX_RUNS + 1];
 };
+// zero_uniq / zero_state (optional): what the emit launch that follows expects to find zero (uniq[] tail, head-count granules)
 __global__ __launch_bounds__(256) void merge_rank_kernel(const int64_t* __restrict__ ids, int64_t n, RunOffsets ro, int nruns, uint64_t* __restrict__ keys,
-                                                         int32_t* __restrict__ perm) {
+                                                         int32_t* __restrict__ perm, int64_t* __restrict__ zero_uniq, uint32_t* __restrict__ zero_state,
+                                                         int64_t nstate) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (zero_uniq) zero_uniq[i] = 0;
+        if (zero_state && i < nstate) zero_state[i] = 0u;
         int r = 0;
         while (r + 1 < nruns && i >= ro.off[r + 1]) ++r;
         const int64_t v = ids[i];
@@ -481,17 +485,28 @@ extern "C" int marius_merge_unique_runs(const int64_t* ids, int64_t n, const int
         MARIUS_REQUIRE(q == 0 || ro.off[q] >= ro.off[q - 1], "merge_unique_runs: run offsets must ascend");
     }
     ProfScope ps(PROF_SORT_UNIQUE, st);
-    if (hipMemsetAsync(uniq, 0, (size_t)n * sizeof(int64_t), st) != hipSuccess) {
-        set_last_error("merge_unique_runs: memset failed");
-        return MARIUS_ERR_HIP;
-    }
     char* ws = (char*)workspace;
     uint64_t* keys = (uint64_t*)(ws + p.keys_off);
     int32_t* flags = (int32_t*)(ws + p.scan_off);
     int32_t* scan = flags + n;
     int64_t blocks = cdiv(n, 256);
     if (blocks > 2048) blocks = 2048;
-    merge_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(ids, n, ro, num_runs, keys, perm);
+    {   // two launches: ranks by binary search (+ the zero fills), then the radix sort's emit kernel (heads, prefix by granule hand-off, outputs)
+        const char* lib = getenv("MARIUS_SORT");
+        const int64_t etiles = cdiv(n, EM_TILE);
+        if (n <= (int64_t)RS_MAX_TILES * RS_TILE && (size_t)(etiles + 4) * 4 <= p.temp_bytes && !(lib && lib[0] == 'r')) {
+            uint32_t* tile_state = (uint32_t*)(ws + p.temp_off);
+            unsigned long long* ready = (unsigned long long*)(((uintptr_t)(tile_state + etiles) + 7) & ~(uintptr_t)7);  // rs_emit_kernel clears it; unused here
+            merge_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(ids, n, ro, num_runs, keys, perm, uniq, tile_state, etiles);
+            rs_emit_kernel<<<dim3((unsigned)etiles), dim3(RS_THREADS), 0, st>>>(keys, perm, n, tile_state, uniq, inverse, seg_offsets, num_unique_dev, ready);
+            return check_launch("merge_unique_runs");
+        }
+    }
+    if (hipMemsetAsync(uniq, 0, (size_t)n * sizeof(int64_t), st) != hipSuccess) {
+        set_last_error("merge_unique_runs: memset failed");
+        return MARIUS_ERR_HIP;
+    }
+    merge_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(ids, n, ro, num_runs, keys, perm, nullptr, nullptr, 0);
     head_flags_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const int64_t*)keys, n, flags);
     size_t tmp_bytes = p.temp_bytes;
     hipError_t e = rocprim::inclusive_scan(ws + p.temp_off, tmp_bytes, flags, scan, (size_t)n, rocprim::plus<int32_t>(), st);
