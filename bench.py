@@ -141,6 +141,20 @@ def emit_json(out):
     os.write(1 if fd is None else fd, line)
 
 
+def _nccl_options():
+    """RCCL's internal stream at high priority (MARIUS_NCCL_HIPRIO=0: default priority): its kernels are short, sit on the critical cycle of the
+    sharded step, and otherwise queue behind whatever the compute stream has pending."""
+    import torch.distributed as dist
+    if os.environ.get("MARIUS_NCCL_HIPRIO", "1") == "0":
+        return None
+    try:
+        o = dist.ProcessGroupNCCL.Options()
+        o.is_high_priority_stream = True
+        return o
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     protect_stdout()
     ap = argparse.ArgumentParser()
@@ -176,7 +190,7 @@ def main():
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, pg_options=_nccl_options())
         else:
             dist.init_process_group(backend)
     assert a.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
@@ -195,7 +209,7 @@ def main():
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=_nccl_options())
         from marius_amd.sharded import run_sharded_bench
         return run_sharded_bench(a, cfg, rank, world, dev)
 

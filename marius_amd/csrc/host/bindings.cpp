@@ -380,8 +380,8 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_property_readonly("phase_seconds", [](ShardedTrainer& t) { return std::vector<double>(t.phase_seconds_, t.phase_seconds_ + 6); })
         .def("enable_spans", &ShardedTrainer::enable_spans)
         .def_property_readonly("span_ms", [](ShardedTrainer& t) {
-            std::vector<double> v(4, 0.0);
-            for (int k = 0; k < 4; ++k) v[k] = t.span_n_[k] ? t.span_ms_[k] / (double)t.span_n_[k] : 0.0;
+            std::vector<double> v(7, 0.0);
+            for (int k = 0; k < 7; ++k) v[k] = t.span_n_[k] ? t.span_ms_[k] / (double)t.span_n_[k] : 0.0;
             return v;
         });
     m.def("c10d_exchange_selftest", &c10d_exchange_selftest, py::arg("group_name"), py::arg("send"), py::arg("send_counts"), py::arg("to_reduce"),

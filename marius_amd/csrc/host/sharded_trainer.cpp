@@ -171,7 +171,7 @@ void ShardedTrainer::span_end(Slot& s, int stage, void* stream) {
     s.span_live[stage] = true;
 }
 void ShardedTrainer::span_collect(Slot& s) {
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 7; ++k) {
         if (!s.span_live[k]) continue;
         s.span_live[k] = false;
         float ms = 0.f;
@@ -252,14 +252,20 @@ void ShardedTrainer::fetch(int64_t t) {
     span_begin(s, 1, xchg_stream_);
     {
         Scope scope(xchg);
+        span_begin(s, 4, xchg_stream_);
         Tensor req = a2a(s.batch->unique_node_indices_.narrow(0, 0, s.U), s.send_counts, s.recv_counts, view(buf_req_, s.nrecv, {}, torch::kInt64));
+        span_end(s, 4, xchg_stream_);
+        span_begin(s, 5, xchg_stream_);
         s.local_ids = view(local_[k], s.nrecv, {}, torch::kInt64);
         torch::sub_out(s.local_ids, req, lo_);
         Tensor rows = view(buf_rows_, s.nrecv, {d_}, torch::kFloat32);
         if (s.nrecv > 0)
             mcheck(marius_gather_rows(table_.data_ptr<float>(), table_.stride(0), s.local_ids.data_ptr<int64_t>(), s.nrecv, d_, rows.data_ptr<float>(),
                                       rows.stride(0), (marius_stream_t)xchg.stream()));
+        span_end(s, 5, xchg_stream_);
+        span_begin(s, 6, xchg_stream_);
         s.emb = a2a(rows, s.recv_counts, s.send_counts, view(emb_[k], s.U, {d_}, torch::kFloat32));
+        span_end(s, 6, xchg_stream_);
     }
     span_end(s, 1, xchg_stream_);
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.fetched, xchg.stream()));

@@ -40,8 +40,8 @@ class ShardedTrainer {
     // device time from the first to the last operation of a stage on its stream (HIP events; collected when a slot is reused, RING steps
     // later): prepare (prep stream), fetch and update (exchange stream), compute (main stream).  A stage's span includes the time its
     // kernels wait for CUs held by the other streams: span >> the stage's own work means that stream is starved.
-    double span_ms_[4] = {0, 0, 0, 0};
-    int64_t span_n_[4] = {0, 0, 0, 0};
+    double span_ms_[7] = {0, 0, 0, 0, 0, 0, 0};  // 4..6: fetch split into ids all-to-all / owner gather / rows all-to-all
+    int64_t span_n_[7] = {0, 0, 0, 0, 0, 0, 0};
     bool spans_ = false;
     void enable_spans(bool on) { spans_ = on; }
 
@@ -54,9 +54,9 @@ class ShardedTrainer {
         void* fetched = nullptr;     // rows of this batch have arrived
         void* computed = nullptr;    // per-row gradients complete
         void* free_ = nullptr;       // owners applied the gradients: every buffer of the slot is reusable
-        void* span_b[4] = {nullptr, nullptr, nullptr, nullptr};  // timing events (stage begin / end), see span_ms_
-        void* span_e[4] = {nullptr, nullptr, nullptr, nullptr};
-        bool span_live[4] = {false, false, false, false};
+        void* span_b[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // timing events (stage begin / end), see span_ms_
+        void* span_e[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        bool span_live[7] = {false, false, false, false, false, false, false};
         bool used = false;
         std::vector<int64_t> send_counts, recv_counts;
         int64_t U = 0, nrecv = 0;

@@ -664,7 +664,7 @@ def run_sharded_bench(a, cfg, rank, world, dev):
             out["host_issue_ms_per_step"] = round(host_total / a.steps * 1e3, 4)
             out["config"]["host"] = "C++ ShardedTrainer (libtorch, c10d)" if cpp_trainer is not None else "Python schedule (marius_amd/sharded.py)"
             if cpp_trainer is not None:
-                out["device_span_ms"] = dict(zip(["prepare", "fetch", "compute", "update"], [round(x, 4) for x in cpp_trainer.span_ms]))
+                out["device_span_ms"] = dict(zip(["prepare", "fetch", "compute", "update", "fetch_ids_a2a", "fetch_owner_gather", "fetch_rows_a2a"], [round(x, 4) for x in cpp_trainer.span_ms]))
                 out["host_phase_ms_per_step"] = dict(zip(["prepare", "wait_split_points", "fetch", "compute", "update", "dense"],
                                                          [round(x / (a.steps + a.warmup) * 1e3, 4) for x in cpp_trainer.phase_seconds]))
             if False:
