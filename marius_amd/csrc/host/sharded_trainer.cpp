@@ -77,7 +77,9 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
     // workgroups take the first slots that free up (MARIUS_SHARDED_SIDE_HIPRIO=0: equal priorities).
     const char* sp = getenv("MARIUS_SHARDED_SIDE_HIPRIO");
     const bool side_hi = !(sp && sp[0] == '0');
-    prep_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(side_hi, dev.index()));
+    const char* pp = getenv("MARIUS_SHARDED_PREP_HIPRIO");  // preparation alone (it runs batches ahead: latency matters less than for the exchange)
+    const bool prep_hi = pp ? pp[0] != '0' : side_hi;
+    prep_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(prep_hi, dev.index()));
     xchg_stream_ = new c10::hip::HIPStream(staleness_ ? c10::hip::getStreamFromPool(side_hi, dev.index()) : strm(main_stream_));
     for (auto& s : slots_) {
         s.offs_dev = torch::empty({world_ + 1}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
