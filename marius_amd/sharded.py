@@ -562,7 +562,9 @@ def run_sharded_bench(a, cfg, rank, world, dev):
         # picks the interface by resolving the hostname, which containers do not always allow
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         side_group = dist.new_group(backend="gloo")
-        staleness = int(os.environ.get("MARIUS_SHARDED_STALENESS", "1"))
+        # rows of batch t + s are fetched while batch t is scored.  s = 2 keeps the fetch off the score -> update -> fetch -> score cycle
+        # (sharded_trainer.cpp: step()): no difference at world 1, one a2a round trip of slack per step once the exchange has wire time
+        staleness = int(os.environ.get("MARIUS_SHARDED_STALENESS", "2" if world > 1 else "1"))
     if pipelined and driver == "cpp":
         import marius_amd
 
