@@ -309,6 +309,9 @@ int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld, const int
 size_t marius_segment_plan_bytes(int64_t n);
 int marius_segment_plan(const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, const int64_t* uniq_ids, int64_t n, void* plan,
                         marius_stream_t stream);
+int marius_segment_sum_rows_planned(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets,
+                                    int64_t n, int32_t d, const int64_t* out_rows, float* out, int64_t out_ld, void* carry, const void* plan,
+                                    marius_stream_t stream);
 int marius_segment_adagrad_scatter_planned(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
                                            const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* uniq_ids, float* table, float* state,
                                            int64_t table_ld, float lr, float eps, void* carry, const void* plan, marius_stream_t stream);

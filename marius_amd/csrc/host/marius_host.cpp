@@ -1238,9 +1238,14 @@ void Model::backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, b
     const int64_t L = batch->occ_perm_.size(0);
     ensure(carry_, (int64_t)marius_segment_carry_bytes(L, ctx_.desc.d), device_);
     const float* gocc = (const float*)((const char*)ctx_.workspace.data_ptr() + ctx_.layout.gocc);
-    mcheck(marius_segment_sum_rows(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
-                                   batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, nullptr, fp(grad_out), grad_out.stride(0),
-                                   carry_.data_ptr(), cur_stream()));
+    if (batch->occ_plan_.defined())
+        mcheck(marius_segment_sum_rows_planned(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
+                                               batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, nullptr, fp(grad_out), grad_out.stride(0),
+                                               carry_.data_ptr(), batch->occ_plan_.data_ptr(), cur_stream()));
+    else
+        mcheck(marius_segment_sum_rows(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
+                                       batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, nullptr, fp(grad_out), grad_out.stride(0),
+                                       carry_.data_ptr(), cur_stream()));
 }
 
 std::vector<Tensor> Model::dense_state() {
@@ -1660,7 +1665,7 @@ shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
     batch->occ_inverse_ = inverse_;
     batch->occ_seg_offsets_ = seg_;
     batch->num_unique_dev_ = count_;
-    if (train_ && run_ahead_) {  // the fused update's index work, done here (this stream runs a step ahead of the gradients)
+    if (train_ && (run_ahead_ || plan_ahead_)) {  // the fused update's index work, done here (this stream runs a step ahead of the gradients)
         batch->occ_plan_ = torch::empty({(int64_t)marius_segment_plan_bytes(L)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
         mcheck(marius_segment_plan(perm_.data_ptr<int32_t>(), ip(inverse_), seg_.data_ptr<int32_t>(), ip(uniq_), L, batch->occ_plan_.data_ptr(), st));
     }
@@ -1674,7 +1679,7 @@ shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
         mcheck(marius_sort_unique(ip(rel_ids), B, key_bits_for(num_relations_), ip(batch->rel_uniq_), ip(batch->rel_inverse_),
                                   batch->rel_perm_.data_ptr<int32_t>(), batch->rel_seg_.data_ptr<int32_t>(), ip(batch->rel_count_), sort_ws_.data_ptr(),
                                   (size_t)sort_ws_.numel(), st));
-        if (run_ahead_) {
+        if (run_ahead_ || plan_ahead_) {
             batch->rel_plan_ = torch::empty({(int64_t)marius_segment_plan_bytes(B)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
             mcheck(marius_segment_plan(batch->rel_perm_.data_ptr<int32_t>(), ip(batch->rel_inverse_), batch->rel_seg_.data_ptr<int32_t>(), ip(batch->rel_uniq_), B,
                                        batch->rel_plan_.data_ptr(), st));

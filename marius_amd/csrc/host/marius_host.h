@@ -519,6 +519,7 @@ class DataLoader {
     struct ShuffleAhead;
     ShuffleAhead* ahead_ = nullptr;
     bool full_batches_only_ = false;  // the caller wraps to the next epoch when fewer than batch_size_ edges remain (ShardedTrainer)
+    bool plan_ahead_ = false;         // prepare marius_segment_plan of the node / relation maps with every batch even without run_ahead_ (ShardedTrainer)
     int64_t shuffle_ahead_hits_ = 0, shuffle_ahead_misses_ = 0;
     void start_shuffle_ahead();
     bool take_shuffle_ahead(Tensor& perm);

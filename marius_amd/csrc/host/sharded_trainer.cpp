@@ -54,6 +54,7 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
     if (table_.size(0) != std::min<int64_t>(lo_ + S_, num_nodes_) - lo_) throw MariusRuntimeException("ShardedTrainer: shard has the wrong number of rows");
     d_ = (int)table_.size(1);
     loader_->full_batches_only_ = true;  // prepare() wraps to the next epoch when fewer than a full batch remains
+    loader_->plan_ahead_ = true;         // the reductions' index work rides with the preparation (marius_segment_plan)
     pg_ = c10d::resolve_process_group(group_name);
     (void)side_group_name;  // kept in the signature: earlier builds exchanged the receive counts over a CPU (gloo) group
     if (pg_->getSize() != world_ || pg_->getRank() != rank_) throw MariusRuntimeException("ShardedTrainer: process group does not match rank / world");

@@ -447,19 +447,20 @@ extern "C" size_t marius_segment_carry_bytes(int64_t n, int32_t d) {
     return carry_only_bytes(n, d) + (size_t)(n > 0 ? n : 1) * dpad_of(d) * sizeof(float) + 256;
 }
 
+static int segment_sum_rows_impl(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, int64_t n, int32_t d,
+                                 const int64_t* out_rows, float* out, int64_t out_ld, void* carry, const void* plan, marius_stream_t stream);
+
 extern "C" int marius_segment_sum_rows(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
                                        const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* out_rows, float* out,
                                        int64_t out_ld, void* carry, marius_stream_t stream) {
-    SegArgs a;
-    int rc = fill_args(a, rows, rows_ld, perm, inverse, seg_offsets, n, d, carry);
-    if (rc) return rc;
-    if (n == 0) return MARIUS_OK;
-    MARIUS_REQUIRE(out && out_ld >= d, "segment_sum_rows: bad output");
-    int vec = row_vec_width(rows, rows_ld, d);
-    int v2 = row_vec_width(out, out_ld, d);
-    vec = vec < v2 ? vec : v2;
-    ApplySum ap{out, out_ld, out_rows};
-    return launch_seg(a, ap, vec, as_stream(stream));
+    return segment_sum_rows_impl(rows, rows_ld, perm, inverse, seg_offsets, n, d, out_rows, out, out_ld, carry, nullptr, stream);
+}
+
+extern "C" int marius_segment_sum_rows_planned(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
+                                               const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* out_rows, float* out,
+                                               int64_t out_ld, void* carry, const void* plan, marius_stream_t stream) {
+    MARIUS_REQUIRE(plan || n == 0, "segment_sum_rows_planned: null plan");
+    return segment_sum_rows_impl(rows, rows_ld, perm, inverse, seg_offsets, n, d, out_rows, out, out_ld, carry, plan, stream);
 }
 
 static inline size_t plan_pos_bytes(int64_t n) { return ((size_t)(n > 0 ? n : 1) * sizeof(int4) + 255) / 256 * 256; }
@@ -476,6 +477,26 @@ extern "C" int marius_segment_plan(const int32_t* perm, const int64_t* inverse, 
                                                                                         (int4*)(p + plan_pos_bytes(n)), (int4*)(p + plan_pos_bytes(n) + plan_chunk_bytes(n)));
     return check_launch("segment_plan");
 }
+
+static int segment_sum_rows_impl(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, int64_t n, int32_t d,
+                                 const int64_t* out_rows, float* out, int64_t out_ld, void* carry, const void* plan, marius_stream_t stream) {
+    SegArgs a;
+    int rc = fill_args(a, rows, rows_ld, perm, inverse, seg_offsets, n, d, carry);
+    if (rc) return rc;
+    if (n == 0) return MARIUS_OK;
+    MARIUS_REQUIRE(out && out_ld >= d, "segment_sum_rows: bad output");
+    int vec = row_vec_width(rows, rows_ld, d);
+    int v2 = row_vec_width(out, out_ld, d);
+    vec = vec < v2 ? vec : v2;
+    if (plan) {
+        const char* pp = (const char*)plan;
+        a.pos_plan = (const int4*)pp;
+        a.chunk_plan = (const int4*)(pp + plan_pos_bytes(n));
+    }
+    ApplySum ap{out, out_ld, out_rows};
+    return launch_seg(a, ap, vec, as_stream(stream));
+}
+
 
 static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, int64_t n,
                                         int32_t d, const int64_t* uniq_ids, float* table, float* state, int64_t table_ld, float lr, float eps, void* carry,

@@ -92,6 +92,7 @@ SIGNATURES = {
     "marius_segment_carry_bytes": (_sz, [_i64, _i32]),
     "marius_segment_sum_rows": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp]),
     "marius_segment_adagrad_scatter": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp]),
+    "marius_segment_sum_rows_planned": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
     "marius_segment_plan_bytes": (C.c_size_t, [_i64]),
     "marius_segment_plan": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "marius_segment_adagrad_scatter_planned": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp]),
@@ -385,10 +386,14 @@ def segment_carry(n, d, device):
     return torch.empty(lib().marius_segment_carry_bytes(n, d), dtype=torch.uint8, device=device)
 
 
-def segment_sum_rows(rows, um, n, d, out, out_rows=None, carry=None):
+def segment_sum_rows(rows, um, n, d, out, out_rows=None, carry=None, plan=None):
     _dev(rows)
     if carry is None:
         carry = segment_carry(n, d, rows.device)
+    if plan is not None:
+        check(lib().marius_segment_sum_rows_planned(ptr(rows), rows.stride(0), ptr(um.perm), ptr(um.inverse), ptr(um.seg), n, d, ptr(out_rows), ptr(out),
+                                                    out.stride(0), ptr(carry), ptr(plan), stream_ptr()), "segment_sum_rows_planned")
+        return out
     check(lib().marius_segment_sum_rows(ptr(rows), rows.stride(0), ptr(um.perm), ptr(um.inverse), ptr(um.seg), n, d, ptr(out_rows), ptr(out),
                                         out.stride(0), ptr(carry), stream_ptr()), "segment_sum_rows")
     return out

@@ -406,6 +406,11 @@ def test_planned_segment_adagrad_scatter_is_bit_identical(H, dev, n, num_nodes, 
     H.segment_adagrad_scatter(rows, um, n, d, tb, sb, lr=0.1, plan=plan)
     assert torch.equal(ta, tb) and torch.equal(sa, sb)
     assert not torch.equal(ta.cpu(), table)
+    U = int(um.count.item())
+    oa, ob = torch.zeros(n, d, device=dev), torch.zeros(n, d, device=dev)
+    H.segment_sum_rows(rows, um, n, d, oa)
+    H.segment_sum_rows(rows, um, n, d, ob, plan=plan)
+    assert torch.equal(oa[:U], ob[:U])
 
 
 # ------------------------------------------------------------------------------------------------ whole steps vs the CPU path
