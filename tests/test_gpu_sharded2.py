@@ -58,7 +58,7 @@ def worker(rank, world, port, outdir, sync_interval, staleness):
 def simulate(cfg, world=2, staleness=0):
     """Every rank reads the same table state, gradients are summed per node over all ranks' batches, Adagrad is applied once; relation
     gradients are summed (all-reduce) before the dense step.  Rank r's generator: seed + r, first draw = the epoch permutation.
-    staleness 1: the rows of step s + 1 (of every rank) are read before the update of step s is applied."""
+    staleness k: the rows of step s + k (of every rank) are read before the update of step s is applied."""
     table, edges = make_inputs(cfg, world)
     state = torch.zeros_like(table)
     steppers = []
@@ -87,10 +87,10 @@ def simulate(cfg, world=2, staleness=0):
             out.append((uniq, el, mapped[3].reshape(dst_neg.shape), mapped[2].reshape(src_neg.shape), O.index_read(table, uniq)))
         return out
 
-    ahead = fetch(0) if staleness else None
+    queue = [fetch(k) for k in range(staleness + 1)] if staleness else None  # batches 0..staleness are read before the first update
     for s in range(cfg["steps"]):
         if staleness:
-            cur, ahead = ahead, fetch(s + 1)  # the trainer prefetches one batch past the last step as well: same generator consumption
+            cur = queue.pop(0)
         else:
             cur = fetch(s)
         ids, gs, rg, ig = [], [], torch.zeros_like(rel), torch.zeros_like(inv)
@@ -108,10 +108,12 @@ def simulate(cfg, world=2, staleness=0):
         O.index_add(state, uniq, ds)
         O.dense_adagrad_step(rel, rg, rel_sum, cfg["lr"])
         O.dense_adagrad_step(inv, ig, inv_sum, cfg["lr"])
+        if staleness:
+            queue.append(fetch(s + staleness + 1))  # read after update s, before update s + 1 (the trainer runs `staleness` batches past the last step too)
     return table, state, rel, inv
 
 
-@pytest.mark.parametrize("world,staleness", [(2, 0), (2, 1), (8, 1)])
+@pytest.mark.parametrize("world,staleness", [(2, 0), (2, 1), (2, 2), (8, 1)])
 def test_cpp_sharded_trainer_ranks_equal_union_batch_update(world, staleness):
     from marius_amd.sharded import shard_range
 
