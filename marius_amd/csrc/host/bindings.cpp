@@ -333,6 +333,8 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_readonly("shuffle_ahead_misses", &DataLoader::shuffle_ahead_misses_)
         .def_readwrite("full_batches_only", &DataLoader::full_batches_only_)
         .def_readwrite("generator", &DataLoader::generator_)
+        .def_readwrite("words_between_epochs", &DataLoader::words_between_epochs_)
+        .def("wordsPerEpoch", &DataLoader::wordsPerEpoch, py::arg("with_permutation"))
         .def("hasNextBatch", &DataLoader::hasNextBatch)
         .def("getBatch", &DataLoader::getBatch, py::arg("exact_unique") = true)
         .def("loadGPUParameters", &DataLoader::loadGPUParameters)

@@ -1384,6 +1384,18 @@ struct DataLoader::ShuffleAhead {
     double seconds = 0;
 };
 
+int64_t DataLoader::wordsPerEpoch(bool with_permutation) {
+    int64_t words = 0;
+    if (with_permutation && num_edges_ > 0)  // ATen randperm_cpu: n - 1 32-bit draws below 2^32 / 20 elements, 2 n above (rng.hip)
+        words += ((uint64_t)num_edges_ >= (0xffffffffull / 20ull)) ? 2 * num_edges_ : num_edges_ - 1;
+    if (negative_sampler_ && negative_sampler_->num_negatives_ >= 0) {  // two getNegatives per batch (dataloader.cpp:498-503), a fixed count per call
+        const int n_deg = (int)(negative_sampler_->num_negatives_ * negative_sampler_->degree_fraction_);
+        const int64_t batches = full_batches_only_ ? num_edges_ / batch_size_ : (num_edges_ + batch_size_ - 1) / batch_size_;
+        words += 2 * batches * marius_negatives_raw_words(graph_->num_nodes_in_memory_, batch_size_, negative_sampler_->num_chunks_, negative_sampler_->num_negatives_, n_deg);
+    }
+    return words;
+}
+
 void DataLoader::start_shuffle_ahead() {
     const char* e0 = getenv("MARIUS_SHUFFLE_AHEAD");
     const char* e1 = getenv("MARIUS_SHUFFLE_AHEAD_MIN");  // below this many edges the serial draw is cheaper than a thread (tests set 0)
@@ -1391,11 +1403,8 @@ void DataLoader::start_shuffle_ahead() {
     const int64_t min_edges = e1 ? (int64_t)atoll(e1) : (int64_t)200000;
     if (!enabled || !train_ || partitioned() || num_edges_ < min_edges || !negative_sampler_ || negative_sampler_->num_negatives_ < 0) return;
     if (negative_sampler_->local_filter_mode_ != LocalFilterMode::DEG) return;
-    // words this epoch's sampling will consume: two getNegatives per batch (dataloader.cpp:498-503), a fixed count per call
-    const int n_deg = (int)(negative_sampler_->num_negatives_ * negative_sampler_->degree_fraction_);
-    const int64_t batches = full_batches_only_ ? num_edges_ / batch_size_ : total_batches_;
-    const int64_t per_call = marius_negatives_raw_words(graph_->num_nodes_in_memory_, batch_size_, negative_sampler_->num_chunks_, negative_sampler_->num_negatives_, n_deg);
-    const int64_t words = 2 * per_call * batches;
+    // words this epoch's sampling (and whoever else draws before the next epoch) will consume
+    const int64_t words = wordsPerEpoch(false) + words_between_epochs_;
     generator_->to_host();  // right after this epoch's randperm: the state lives on the host
     auto* a = new ShuffleAhead();
     a->n = num_edges_;

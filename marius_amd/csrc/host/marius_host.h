@@ -521,6 +521,10 @@ class DataLoader {
     bool full_batches_only_ = false;  // the caller wraps to the next epoch when fewer than batch_size_ edges remain (ShardedTrainer)
     bool plan_ahead_ = false;         // prepare marius_segment_plan of the node / relation maps with every batch even without run_ahead_ (ShardedTrainer)
     int64_t shuffle_ahead_hits_ = 0, shuffle_ahead_misses_ = 0;
+    // words other users of the same generator draw between two of this loader's epochs (e.g. the per-epoch evaluation passes: the sum of their
+    // wordsPerEpoch(true)); the permutation drawn ahead starts that much further down the stream
+    int64_t words_between_epochs_ = 0;
+    int64_t wordsPerEpoch(bool with_permutation);  // generator words one pass over this loader consumes (non-partitioned)
     void start_shuffle_ahead();
     bool take_shuffle_ahead(Tensor& perm);
     Tensor last_num_unique_;  // device count of the batch getBatch returned last (count_ itself belongs to the preparing thread)

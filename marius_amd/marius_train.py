@@ -187,6 +187,11 @@ def marius_train(cfg, log=print, train=True):
                 table_for_eval = H.PartitionBufferStorage(emb_path, num_nodes, d, pb_opts, dev)
             evals[split] = H.SynchronousEvaluator(H.DataLoader(eval_edges[split], table_for_eval, None, sampler(ev["negative_sampling"]), gen,
                                                                int(ev["batch_size"]), False), model)
+    if evals and int(ev.get("epochs_per_eval", 1)) == 1 and not partitioned:
+        # every epoch is followed by the evaluation passes, which draw from the same generator stream (their own permutation + their sampling):
+        # tell the training loader, so that the permutation it draws ahead for the next epoch starts where the generator will really be
+        # (a wrong count only costs the prediction: the loader verifies the generator state before adopting a permutation)
+        loader.words_between_epochs = sum(e.dataloader.wordsPerEpoch(True) for e in evals.values())
     f_train, f_eval = bool(tr["negative_sampling"].get("filtered", False)), bool(ev["negative_sampling"].get("filtered", False)) and bool(evals)
     if f_train or f_eval:
         # GraphModelStorage::sortAllEdges (graph_storage.cpp:745-777; dataloader.cpp:592-598 calls it for any filtered sampler): train +
@@ -241,6 +246,7 @@ def marius_train(cfg, log=print, train=True):
         if epoch % int(ev.get("epochs_per_eval", 1)) == 0:
             for split in evals:
                 run_eval(split, rec)
+        rec["shuffle_ahead"] = [int(loader.shuffle_ahead_hits), int(loader.shuffle_ahead_misses)]  # permutations adopted from the host thread / drawn serially
         results.append(rec)
         if save_model and interval > 0 and epoch % interval == 0 and epoch < int(tr["num_epochs"]):
             # Checkpointer::create_checkpoint (checkpointer.cpp:18-37): <model_dir>/checkpoint_<epochs>/ via a _tmp directory and a rename.  The

@@ -742,6 +742,46 @@ def test_marius_train_checkpoints_and_resume(M, dev, tmp_path):
     assert r4[0]["test"]["MRR"] > 0 and r5[0]["test"]["MRR"] > 0 and r4[0]["test"]["MRR"] != r5[0]["test"]["MRR"]
 
 
+def test_marius_train_draws_the_next_permutation_under_the_evaluation_pass(M, dev, tmp_path, monkeypatch):
+    """marius_train evaluates after every epoch; the evaluation loaders draw from the same generator stream.  The training loader is told how many
+    words they consume (wordsPerEpoch), so the permutation drawn ahead still starts where the generator really is: adopted at every boundary, and the
+    model directory is byte for byte that of the serial order."""
+    from marius_amd import config as C
+    from marius_amd.marius_train import marius_train
+
+    num_nodes, R, E = 200, 3, 3000
+    g = torch.Generator().manual_seed(0)
+    src = torch.randint(num_nodes, (E,), generator=g)
+    rel = torch.randint(R, (E,), generator=g)
+    edges = torch.stack([src, rel, (src * 5 + rel * 11 + 1) % num_nodes], 1).to(torch.int32)
+    ddir = tmp_path / "ds"
+    (ddir / "edges").mkdir(parents=True)
+    edges[:2200].numpy().tofile(str(ddir / "edges" / "train_edges.bin"))
+    edges[2200:2600].numpy().tofile(str(ddir / "edges" / "validation_edges.bin"))
+    edges[2600:].numpy().tofile(str(ddir / "edges" / "test_edges.bin"))
+    yaml.safe_dump({"dataset_dir": str(ddir), "num_edges": E, "num_nodes": num_nodes, "num_relations": R, "num_train": 2200, "num_valid": 400, "num_test": 400},
+                   open(ddir / "dataset.yaml", "w"))
+
+    def run(ahead, name):
+        monkeypatch.setenv("MARIUS_SHUFFLE_AHEAD", "1" if ahead else "0")
+        monkeypatch.setenv("MARIUS_SHUFFLE_AHEAD_MIN", "0")
+        user = {"model": {"random_seed": 5, "encoder": {"layers": [[{"type": "EMBEDDING", "output_dim": 16}]]}, "decoder": {"type": "DISTMULT"}},
+                "storage": {"device_type": "cuda", "dataset": {"dataset_dir": str(ddir)}, "model_dir": str(tmp_path / name)},
+                "training": {"batch_size": 500, "negative_sampling": {"num_chunks": 5, "negatives_per_positive": 50}, "num_epochs": 4},
+                "evaluation": {"batch_size": 300, "negative_sampling": {"num_chunks": 1, "negatives_per_positive": 100}}}
+        path = tmp_path / (name + ".yaml")
+        yaml.safe_dump(user, open(path, "w"))
+        res = marius_train(C.load_config(str(path)), log=lambda *x: None)
+        return res, np.fromfile(str(tmp_path / name / "embeddings.bin"), dtype=np.float32)
+
+    res0, e0 = run(False, "serial")
+    res1, e1 = run(True, "ahead")
+    assert res0[-1]["shuffle_ahead"] == [0, 0]
+    assert res1[-1]["shuffle_ahead"] == [3, 0]  # epochs 2, 3 and 4 started from a permutation drawn during the epoch + evaluation before them
+    assert np.array_equal(e0, e1)
+    assert [r["test"]["MRR"] for r in res0] == [r["test"]["MRR"] for r in res1]
+
+
 def test_marius_train_single_relation_dataset_uses_two_column_edges(M, dev, tmp_path):
     """num_relations == 1 (social graphs such as Twitter, cfg5): edges are stored as (src, dst) (io.cpp:42-45), the relation operator is
     skipped and only the dst direction is scored."""
