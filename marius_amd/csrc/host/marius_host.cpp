@@ -1401,16 +1401,32 @@ void DataLoader::start_shuffle_ahead() {
     const char* e1 = getenv("MARIUS_SHUFFLE_AHEAD_MIN");  // below this many edges the serial draw is cheaper than a thread (tests set 0)
     const bool enabled = !(e0 && e0[0] == '0');
     const int64_t min_edges = e1 ? (int64_t)atoll(e1) : (int64_t)200000;
-    if (!enabled || !train_ || partitioned() || num_edges_ < min_edges || !negative_sampler_ || negative_sampler_->num_negatives_ < 0) return;
+    if (!enabled || !train_ || num_edges_ < min_edges || !negative_sampler_ || negative_sampler_->num_negatives_ < 0) return;
     if (negative_sampler_->local_filter_mode_ != LocalFilterMode::DEG) return;
+    // how many edges the NEXT permutation covers: all of them, or (out-of-core) the edge buckets of the next buffer state — the layouts of
+    // all states are fixed when the epoch's ordering is drawn, so the count is known now (the state after the last one belongs to the next
+    // epoch, whose ordering has not been drawn yet: no prediction there)
+    int64_t next_n = num_edges_;
+    if (partitioned()) {
+        if (buffer_cursor_ + 1 >= (int64_t)edge_buckets_per_buffer_.size()) return;
+        const int64_t P = pb_embeddings_->options_->num_partitions;
+        Tensor buckets = edge_buckets_per_buffer_.at(buffer_cursor_ + 1);
+        auto b = buckets.accessor<int64_t, 2>();
+        next_n = 0;
+        for (int64_t i = 0; i < buckets.size(0); ++i) {
+            const int64_t id = b[i][0] * P + b[i][1];
+            next_n += edge_bucket_starts_[id + 1] - edge_bucket_starts_[id];
+        }
+        if (next_n <= 0) return;
+    }
     // words this epoch's sampling (and whoever else draws before the next epoch) will consume
     const int64_t words = wordsPerEpoch(false) + words_between_epochs_;
     generator_->to_host();  // right after this epoch's randperm: the state lives on the host
     auto* a = new ShuffleAhead();
-    a->n = num_edges_;
+    a->n = next_n;
     a->start.assign((const uint32_t*)generator_->state_host_.data_ptr<int32_t>(), (const uint32_t*)generator_->state_host_.data_ptr<int32_t>() + MARIUS_MT_STATE_WORDS);
     try {
-        a->perm = torch::empty({num_edges_}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
+        a->perm = torch::empty({next_n}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
     } catch (const std::exception&) {  // no room for a second (pinned) permutation: the serial draw at the boundary stays
         delete a;
         return;

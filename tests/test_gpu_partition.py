@@ -137,9 +137,12 @@ def _close(got, want, rtol=3e-4):
 
 @pytest.mark.parametrize("ordering,ratio,random_assign,prefetching,fused",
                          [("OLD_BETA", 1, False, False, True), ("COMET", 2, True, True, True), ("NEW_BETA", 1, True, True, False)])
-def test_partitioned_epochs_match_oracle(M, dev, tmp_path, ordering, ratio, random_assign, prefetching, fused):
+def test_partitioned_epochs_match_oracle(M, dev, tmp_path, monkeypatch, ordering, ratio, random_assign, prefetching, fused):
     """Two epochs of out-of-core training: ordering from the generator stream, per buffer state the assigned edge buckets with
-    buffer-local ids, negatives from the in-memory id range, swap, write-back — against the same loop on the CPU oracle."""
+    buffer-local ids, negatives from the in-memory id range, swap, write-back — against the same loop on the CPU oracle.  The
+    permutation of every buffer state but the first of an epoch is drawn ahead by the host thread (the sizes of all states are known once
+    the epoch's ordering is drawn) and must be the one the serial order draws."""
+    monkeypatch.setenv("MARIUS_SHUFFLE_AHEAD_MIN", "0")
     num_nodes, R, d, B, C, N, E, seed, p, c = 2003, 7, 16, 96, 4, 24, 3000, 99, 8, 4
     g = torch.Generator().manual_seed(1)
     table = (torch.rand(num_nodes, d, generator=g) - 0.5) * 0.6
@@ -169,6 +172,7 @@ def test_partitioned_epochs_match_oracle(M, dev, tmp_path, ordering, ratio, rand
     trainer.fused_update = fused
     trainer.train(2)
     assert emb.swaps > 0 and loader.graph.num_nodes_in_memory == c * (-(-num_nodes // p))
+    assert loader.shuffle_ahead_hits > 0 and loader.shuffle_ahead_misses == 0
     # ---- oracle: the same loop (trainer.cpp:94-161 with dataloader.cpp:120-183, 296-345, 566-600)
     ps = -(-num_nodes // p)
     o_emb = P.PartitionBufferOracle(c, p, ps, d, num_nodes, files["cpu"][0])
