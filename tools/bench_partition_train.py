@@ -41,6 +41,14 @@ def main():
     edges = (torch.stack([src, rel, dst], 1) if R > 1 else torch.stack([src, dst], 1))[order].to(torch.int32)  # io.cpp:42-45: one relation type -> (src, dst)
     sizes = torch.bincount(bucket, minlength=p * p).tolist()
     del src, dst, rel, bucket, order
+    trace = bool(os.environ.get("PB_TRACE"))
+    T0 = time.perf_counter()
+
+    def tr_print(*x):
+        if trace:
+            print("[%.1f s]" % (time.perf_counter() - T0), *x, file=sys.stderr, flush=True)
+
+    tr_print("edges built")
 
     def model():
         dec = M.ComplEx(R, d, dev, R > 1, M.EdgeDecoderMethod.CORRUPT_NODE)
@@ -71,6 +79,7 @@ def main():
             fe.write(torch.zeros((n, d), device=dev).uniform_(-0.01, 0.01).cpu().numpy().tobytes())
             fs.write(bytes(4 * d * n))
     out["file_init_s"] = round(time.perf_counter() - t_files, 1)
+    tr_print("files written")
     o = M.PartitionBufferOptions()
     o.num_partitions, o.buffer_capacity, o.prefetching, o.fine_to_coarse_ratio = p, a.capacity, True, 1
     o.edge_bucket_ordering = M.EdgeBucketOrdering.NEW_BETA
@@ -85,16 +94,21 @@ def main():
     t0 = time.perf_counter()
     loader.loadStorage()
     t_load = time.perf_counter() - t0
+    tr_print("loadStorage done")
     parts = {"load_first_state_s": round(t_load, 2)}
     tl = time.perf_counter()
     loader.initializeBatches(True)
     torch.cuda.synchronize()
     t_init0 = time.perf_counter() - tl
+    tr_print("first initializeBatches done")
     te = time.perf_counter()
     steps = 0
     while loader.hasNextBatch():
         tr.train_one(True)
         steps += 1
+        if trace and steps % 100 == 0:
+            torch.cuda.synchronize()
+            tr_print("steps", steps, "swaps", emb.swaps, "ahead hits/misses", loader.shuffle_ahead_hits, loader.shuffle_ahead_misses)
     torch.cuda.synchronize()
     t_train = time.perf_counter() - te
     tw = time.perf_counter()
