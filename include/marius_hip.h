@@ -42,7 +42,14 @@ enum {
     MARIUS_LOSS_SOFTPLUS = 6           /* softplus(-(2 y - 1) x)                                                                       */
 };
 
+/* Bumped whenever a struct of this header changes size or meaning, or an entry point changes its signature (3: marius_lp_desc.flags /
+ * reserved_, marius_lp_layout.adjrec / negrec / fpart / flash, planned segment update, zero-initialised sort workspace).  Every binder
+ * compares the value it was built against with what the loaded library returns and refuses to run on a mismatch: marius_amd/hip.py lib(),
+ * the host module's init (bindings.cpp), and the plug-in recipe of INTEGRATION.md. */
+#define MARIUS_HIP_ABI_VERSION 3
 int marius_hip_abi_version(void);
+/* sizeof(marius_lp_desc) / sizeof(marius_lp_layout) as the library was compiled: a second line of defence for ctypes mirrors */
+int marius_hip_struct_bytes(int which /* 0: marius_lp_desc, 1: marius_lp_layout */);
 const char* marius_hip_last_error(void);
 
 /* Optional HIP-event profiler (bench.py's roofline): when enabled, the library records hipEvents on the launch stream
@@ -154,6 +161,10 @@ int marius_remap_edges(const int64_t* edges, const int64_t* inverse, int64_t B, 
 
 /* ------------------------------------------------------------------------------------------------ unique map */
 
+/* Workspace contract: the first 256 bytes are the sort's control block (a hand-shake word and the tile counters its launches draw their
+ * tile ids from).  They must be ZERO the first time a workspace is used — allocate it zero-filled — and every call leaves them zero again, so
+ * a workspace can be reused for any n up to the one it was sized for, and a captured call can be replayed.  One workspace serves one
+ * stream at a time. */
 size_t marius_sort_unique_workspace_bytes(int64_t n);
 /* replaces map_tensors src/common/util.cpp:180-205 (_unique2 sorted + inverse).
  * ids[n] int64 (>= 0) -> uniq[<=n] ascending, inverse[n] (index into uniq per input position),

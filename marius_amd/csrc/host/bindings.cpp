@@ -12,6 +12,11 @@ using namespace marius_amd;
 PYBIND11_MODULE(_marius_host, m) {
     m.doc() = "MI355X-native host layer of the Marius link-prediction hot path (C++ on libtorch, kernels via libmarius_hip.so)";
     py::register_exception<MariusRuntimeException>(m, "MariusRuntimeException");
+    // the structs of include/marius_hip.h are passed by pointer: a library built from another revision of the header would read past them
+    if (marius_hip_abi_version() != MARIUS_HIP_ABI_VERSION || marius_hip_struct_bytes(0) != (int)sizeof(marius_lp_desc) ||
+        marius_hip_struct_bytes(1) != (int)sizeof(marius_lp_layout))
+        throw std::runtime_error("_marius_host was built against C-ABI version " + std::to_string(MARIUS_HIP_ABI_VERSION) + " of libmarius_hip.so, the loaded library reports " +
+                                 std::to_string(marius_hip_abi_version()) + ": rebuild both with `python -m marius_amd.build --host`");
 
     py::enum_<LossReduction>(m, "LossReduction").value("MEAN", LossReduction::MEAN).value("SUM", LossReduction::SUM);
     py::enum_<EdgeDecoderMethod>(m, "EdgeDecoderMethod")

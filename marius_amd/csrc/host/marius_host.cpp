@@ -1036,7 +1036,10 @@ static RelMap relation_map(Model& m, shared_ptr<Batch> batch) {
         m.rel_perm_ = torch::empty({B}, i32(dev));
         m.rel_seg_ = torch::empty({B + 1}, i32(dev));
         m.rel_count_ = torch::zeros({1}, i64(dev));
-        ensure(m.rel_ws_, (int64_t)marius_sort_unique_workspace_bytes(B), dev);
+        {   // zero-initialised: the sort's control block (include/marius_hip.h)
+            const int64_t wsb = (int64_t)marius_sort_unique_workspace_bytes(B);
+            if (!m.rel_ws_.defined() || m.rel_ws_.numel() < wsb || m.rel_ws_.device() != dev) m.rel_ws_ = torch::zeros({wsb}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+        }
     }
     m.rel_ids_.copy_(batch->edges_.select(1, 1));
     mcheck(marius_sort_unique(ip(m.rel_ids_), B, key_bits_for(c.desc.R), ip(m.rel_uniq_), ip(m.rel_inverse_), m.rel_perm_.data_ptr<int32_t>(),
@@ -1361,6 +1364,12 @@ void DataLoader::setActiveEdges() {
     std::vector<Tensor> columns{g2l.index_select(0, act.select(1, 0))};
     if (cols == 3) columns.push_back(act.select(1, 1));
     columns.push_back(g2l.index_select(0, act.select(1, -1)));
+    // Every edge of an active bucket must have both endpoints in the buffer.  An edge list that is not sorted by bucket (or bucket sizes that
+    // do not describe it) hands the batch rows of partitions that are on disk: the reference's index_select throws on the -1 such a node maps
+    // to; here the check is one reduction per buffer state, before any kernel sees the ids.
+    if (torch::minimum(columns.front().min(), columns.back().min()).item<int64_t>() < 0)
+        throw MariusRuntimeException("DataLoader: an edge of buffer state " + std::to_string(buffer_cursor_) +
+                                     " has an endpoint outside the partitions in memory (edge list not sorted by edge bucket, or wrong edge_bucket_sizes)");
     active_edges_ = torch::stack(columns, 1).contiguous();
 }
 
@@ -1674,7 +1683,7 @@ shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
     seg_ = torch::empty({L + 1}, i32(dev));
     count_ = torch::zeros({1}, i64(dev));
     const size_t wsb = marius_sort_unique_workspace_bytes(L);
-    if (!sort_ws_.defined() || (size_t)sort_ws_.numel() < wsb) sort_ws_ = torch::empty({(int64_t)wsb}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+    if (!sort_ws_.defined() || (size_t)sort_ws_.numel() < wsb) sort_ws_ = torch::zeros({(int64_t)wsb}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));  // zeroed: the sort's control block
     mcheck(marius_assemble_ids(ip(edges), B, cols, ip(batch->src_neg_indices_), ip(batch->dst_neg_indices_), CN, ip(all_ids_), st));
     mcheck(marius_sort_unique(ip(all_ids_), L, key_bits_, ip(uniq_), ip(inverse_), perm_.data_ptr<int32_t>(), seg_.data_ptr<int32_t>(), ip(count_),
                               sort_ws_.data_ptr(), (size_t)sort_ws_.numel(), st));

@@ -317,7 +317,7 @@ void ShardedTrainer::apply_local(const Tensor& local_ids, const Tensor& grads, c
         r_perm_ = torch::empty({r_cap_}, i32o);
         r_seg_ = torch::empty({r_cap_ + 1}, i32o);
         r_count_ = torch::zeros({1}, i64o);
-        r_ws_ = torch::empty({(int64_t)marius_sort_unique_workspace_bytes(r_cap_)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+        r_ws_ = torch::zeros({(int64_t)marius_sort_unique_workspace_bytes(r_cap_)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
         r_carry_ = torch::empty({(int64_t)marius_segment_carry_bytes(r_cap_, d_)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
     }
     auto st = cur_stream();

@@ -11,6 +11,9 @@
 namespace marius {
 
 void set_last_error(const char* fmt, ...);
+// MARIUS_SYNC_LAUNCH=1 (debugging): every C-ABI launch is named on stderr and followed by a device-wide synchronisation, so that a kernel
+// that never returns (or faults) is the last name printed.  Off: a single predictable branch.
+int launch_debug(const char* what);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
@@ -18,7 +21,7 @@ inline int check_launch(const char* what) {
         set_last_error("%s: %s", what, hipGetErrorString(e));
         return MARIUS_ERR_HIP;
     }
-    return MARIUS_OK;
+    return launch_debug(what);
 }
 
 #define MARIUS_REQUIRE(cond, ...)             \

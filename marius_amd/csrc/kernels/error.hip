@@ -1,4 +1,5 @@
 // Error string, ABI version and the optional per-kernel HIP-event profiler of libmarius_hip.so.
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -11,6 +12,19 @@ void set_last_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
     va_end(ap);
+}
+
+int launch_debug(const char* what) {
+    static const int mode = [] { const char* e = getenv("MARIUS_SYNC_LAUNCH"); return e ? atoi(e) : 0; }();
+    if (!mode) return MARIUS_OK;
+    if (mode >= 2) fprintf(stderr, "[launch] %s\n", what);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        set_last_error("%s: %s (reported by the synchronisation after the launch)", what, hipGetErrorString(e));
+        fprintf(stderr, "[launch] %s FAILED: %s\n", what, hipGetErrorString(e));
+        return MARIUS_ERR_HIP;
+    }
+    return MARIUS_OK;
 }
 
 // ---- HIP-event profiler: events are recorded on the launch stream around selected kernels (bench.py roofline) ----
@@ -46,7 +60,8 @@ void prof_end(hipStream_t st, ProfMark& m) {
 
 using namespace marius;
 
-extern "C" int marius_hip_abi_version(void) { return 1; }
+extern "C" int marius_hip_abi_version(void) { return MARIUS_HIP_ABI_VERSION; }
+extern "C" int marius_hip_struct_bytes(int which) { return which == 0 ? (int)sizeof(marius_lp_desc) : which == 1 ? (int)sizeof(marius_lp_layout) : -1; }
 extern "C" const char* marius_hip_last_error(void) { return marius::g_last_error; }
 
 extern "C" int marius_profile_enable(int on) {

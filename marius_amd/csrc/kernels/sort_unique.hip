@@ -121,6 +121,24 @@ constexpr int RS_MAX_TILES = 512;  // every block reads the counts of the tiles 
 constexpr int EM_ITEMS = 4, EM_TILE = RS_THREADS * EM_ITEMS;  // rs_emit_kernel: small tiles, the whole chip
 constexpr uint32_t RS_FLAG = 0x80000000u;
 
+// Control block at offset 0 of the workspace (zero when the workspace is first used; every call leaves it zero again):
+//   ready   the ticket hand-shake of rs_ghist_kernel
+//   ctr[k]  tile counter of the k-th launch of a call.  A workgroup's tile is the value it draws from the counter, not blockIdx: a tile
+//           then only ever waits for tiles whose workgroups have already started (HIP promises no dispatch order between workgroups, and
+//           these launches share the device with persistent kernels on other streams), which is what makes the spins below terminate.
+struct SortCtl {
+    unsigned long long ready;
+    uint32_t ctr[8];
+};
+constexpr size_t SORT_CTL_BYTES = 256;
+
+__device__ __forceinline__ int rs_draw_tile(uint32_t* ctr) {
+    __shared__ int s_tile;
+    if (threadIdx.x == 0) s_tile = (int)atomicAdd(ctr, 1u);
+    __syncthreads();
+    return s_tile;
+}
+
 __device__ __forceinline__ void rs_publish(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v | RS_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t rs_poll(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -131,10 +149,12 @@ __device__ __forceinline__ uint32_t rs_poll(const uint32_t* p) { return __hip_at
 // tile_state: EM tiles) and uniq[].
 __global__ __launch_bounds__(SW_THREADS) void rs_ghist_kernel(const uint64_t* __restrict__ keys, int64_t n, int passes, int ntiles, uint32_t* __restrict__ ghist,
                                                               uint32_t* __restrict__ state, uint32_t* __restrict__ tile_state, int64_t* __restrict__ uniq,
-                                                              unsigned long long* __restrict__ ready, unsigned long long ticket) {
+                                                              SortCtl* __restrict__ ctl, unsigned long long ticket) {
     __shared__ uint32_t h[RS_MAX_PASSES][RS_RADIX];
-    const int tile = blockIdx.x;
+    unsigned long long* ready = &ctl->ready;
+    const int tile = rs_draw_tile(&ctl->ctr[0]);
     if (tile == 0) {
+        if (threadIdx.x >= 1 && threadIdx.x < 8) ctl->ctr[threadIdx.x] = 0u;  // the later launches of this call start counting at 0
         for (int b = threadIdx.x; b < passes * RS_RADIX; b += SW_THREADS) __hip_atomic_store(ghist + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();  // every lane's stores are issued; the release below orders them before the ticket
         if (threadIdx.x == 0) __hip_atomic_store(ready, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -169,11 +189,11 @@ __global__ __launch_bounds__(SW_THREADS) void rs_ghist_kernel(const uint64_t* __
 // granules of this pass (zero on entry).
 __global__ __launch_bounds__(SW_THREADS) void rs_sweep_kernel(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ pay_in, int64_t n, int shift,
                                                               const uint32_t* __restrict__ ghist, uint32_t* __restrict__ state, uint64_t* __restrict__ keys_out,
-                                                              int32_t* __restrict__ pay_out) {
+                                                              int32_t* __restrict__ pay_out, uint32_t* __restrict__ tile_ctr) {
     __shared__ int32_t off[RS_RADIX];            // global position of this tile's first key of each digit
     __shared__ int32_t cw[SW_WAVES][RS_RADIX];   // per-wave running digit counts, then per-wave bases
     __shared__ int32_t wsum[SW_WAVES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = rs_draw_tile(tile_ctr);
     const int64_t wbase_idx = (int64_t)tile * RS_TILE + (int64_t)wave * 64 * SW_ITEMS;
     uint64_t key[SW_ITEMS];
     int32_t pay[SW_ITEMS];
@@ -210,6 +230,7 @@ __global__ __launch_bounds__(SW_THREADS) void rs_sweep_kernel(const uint64_t* __
     }
     __syncthreads();
     // ---- thread t owns digit t: per-wave bases, then the tile's count is published (one flagged 4-byte granule) before anything waits
+    static_assert(RS_MAX_PASSES + 2 <= 7 && sizeof(SortCtl) <= SORT_CTL_BYTES, "control block");
     static_assert(RS_RADIX == SW_THREADS, "one digit per thread");
     {
         int32_t run = 0;
@@ -269,10 +290,13 @@ __global__ __launch_bounds__(SW_THREADS) void rs_sweep_kernel(const uint64_t* __
 // seg_offsets / count.  tile_state: [ntiles] granules, zero on entry.
 __global__ __launch_bounds__(RS_THREADS) void rs_emit_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ perm, int64_t n,
                                                              uint32_t* __restrict__ tile_state, int64_t* __restrict__ uniq, int64_t* __restrict__ inverse,
-                                                             int32_t* __restrict__ seg_offsets, int64_t* __restrict__ num_unique, unsigned long long* __restrict__ ready) {
+                                                             int32_t* __restrict__ seg_offsets, int64_t* __restrict__ num_unique, SortCtl* __restrict__ ctl, int my_ctr) {
     __shared__ int32_t red[RS_WAVES], wsum[RS_WAVES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
-    if (tile == 0 && tid == 0) *ready = 0ull;  // a replay of a captured call (same ticket) waits again
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = rs_draw_tile(&ctl->ctr[my_ctr]);
+    if (tile == 0 && tid == 0) {  // last launch of a call: the control block returns to zero (a replay of a captured call waits and counts again);
+        ctl->ready = 0ull;        // this launch's own counter is still being drawn from: the last workgroup to finish clears it (below)
+        ctl->ctr[0] = 0u;
+    }
     // thread t owns EM_ITEMS consecutive positions: local head count, block scan of the thread sums
     const int64_t k0 = (int64_t)tile * EM_TILE + (int64_t)tid * EM_ITEMS;
     uint64_t kk[EM_ITEMS];
@@ -334,6 +358,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_emit_kernel(const uint64_t* __r
             }
         }
     }
+    // the workgroup that finishes last puts this launch's two counters back to zero (ctr[7] counts finished workgroups)
+    __syncthreads();
+    if (tid == 0 && atomicAdd(&ctl->ctr[7], 1u) + 1u == gridDim.x) {
+        ctl->ctr[7] = 0u;
+        ctl->ctr[my_ctr] = 0u;
+    }
 }
 
 struct SortPlan {
@@ -352,8 +382,8 @@ static int make_plan(int64_t n, SortPlan& p) {
     e = rocprim::inclusive_scan(nullptr, scan_tmp, (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)nn, rocprim::plus<int32_t>(),
                                 (hipStream_t)0);
     if (e != hipSuccess) return MARIUS_ERR_HIP;
-    p.keys_off = 0;
-    p.scan_off = align_up((size_t)nn * 8, 256);
+    p.keys_off = SORT_CTL_BYTES;  // [0, 256): SortCtl, at the same place whatever n a call has
+    p.scan_off = p.keys_off + align_up((size_t)nn * 8, 256);
     p.temp_off = p.scan_off + align_up((size_t)nn * 4 * 2, 256);  // flags + scan
     p.temp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
     {   // the hand-written sort: second key buffer, two payload buffers, histogram matrix, per-tile head counts
@@ -419,8 +449,8 @@ extern "C" int marius_sort_unique(const int64_t* ids, int64_t n, int32_t key_bit
             uint32_t* state = ghist + (size_t)RS_MAX_PASSES * RS_RADIX;
             uint32_t* tile_state = state + (size_t)passes * ntiles * RS_RADIX;
             static std::atomic<unsigned long long> tickets{1};
-            unsigned long long* ready = (unsigned long long*)(((uintptr_t)(tile_state + (size_t)ntiles * (RS_TILE / EM_TILE)) + 7) & ~(uintptr_t)7);
-            rs_ghist_kernel<<<dim3((unsigned)ntiles), dim3(SW_THREADS), 0, st>>>((const uint64_t*)ids, n, passes, ntiles, ghist, state, tile_state, uniq, ready, tickets.fetch_add(1));
+            SortCtl* ctl = (SortCtl*)ws;
+            rs_ghist_kernel<<<dim3((unsigned)ntiles), dim3(SW_THREADS), 0, st>>>((const uint64_t*)ids, n, passes, ntiles, ghist, state, tile_state, uniq, ctl, tickets.fetch_add(1));
             // ping-pong so that the last pass lands in (keys, perm)
             const uint64_t* kin = (const uint64_t*)ids;
             const int32_t* pin = nullptr;
@@ -429,11 +459,11 @@ extern "C" int marius_sort_unique(const int64_t* ids, int64_t n, int32_t key_bit
                 uint64_t* kout = to_keys ? keys : keys2;
                 int32_t* pout = (ps_ == passes - 1) ? perm : (to_keys ? payA : payB);
                 rs_sweep_kernel<<<dim3((unsigned)ntiles), dim3(SW_THREADS), 0, st>>>(kin, pin, n, ps_ * RS_BITS, ghist + (size_t)ps_ * RS_RADIX,
-                                                                                     state + (size_t)ps_ * ntiles * RS_RADIX, kout, pout);
+                                                                                     state + (size_t)ps_ * ntiles * RS_RADIX, kout, pout, &ctl->ctr[1 + ps_]);
                 kin = kout;
                 pin = pout;
             }
-            rs_emit_kernel<<<dim3((unsigned)cdiv(n, EM_TILE)), dim3(RS_THREADS), 0, st>>>(keys, perm, n, tile_state, uniq, inverse, seg_offsets, num_unique_dev, ready);
+            rs_emit_kernel<<<dim3((unsigned)cdiv(n, EM_TILE)), dim3(RS_THREADS), 0, st>>>(keys, perm, n, tile_state, uniq, inverse, seg_offsets, num_unique_dev, ctl, 1 + passes);
             return check_launch("sort_unique");
         }
     }
@@ -496,9 +526,8 @@ extern "C" int marius_merge_unique_runs(const int64_t* ids, int64_t n, const int
         const int64_t etiles = cdiv(n, EM_TILE);
         if (n <= (int64_t)RS_MAX_TILES * RS_TILE && (size_t)(etiles + 4) * 4 <= p.temp_bytes && !(lib && lib[0] == 'r')) {
             uint32_t* tile_state = (uint32_t*)(ws + p.temp_off);
-            unsigned long long* ready = (unsigned long long*)(((uintptr_t)(tile_state + etiles) + 7) & ~(uintptr_t)7);  // rs_emit_kernel clears it; unused here
             merge_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(ids, n, ro, num_runs, keys, perm, uniq, tile_state, etiles);
-            rs_emit_kernel<<<dim3((unsigned)etiles), dim3(RS_THREADS), 0, st>>>(keys, perm, n, tile_state, uniq, inverse, seg_offsets, num_unique_dev, ready);
+            rs_emit_kernel<<<dim3((unsigned)etiles), dim3(RS_THREADS), 0, st>>>(keys, perm, n, tile_state, uniq, inverse, seg_offsets, num_unique_dev, (SortCtl*)ws, 1);
             return check_launch("merge_unique_runs");
         }
     }

@@ -18,6 +18,7 @@ REDUCE_SUM, REDUCE_MEAN = 0, 1
 LOSS = {"SOFTMAX_CE": 0, "RANKING": 1, "CROSS_ENTROPY": 2, "BCE_AFTER_SIGMOID": 3, "BCE_WITH_LOGITS": 4, "MSE": 5, "SOFTPLUS": 6}
 LP_TRAIN_ONLY, LP_STORE_SCORES = 1, 2   # marius_lp_desc.flags
 MT_STATE_WORDS = 625
+ABI_VERSION = 3  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
 
 
 class MariusHipError(RuntimeError):
@@ -52,6 +53,7 @@ _i32, _i64, _f32, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_si
 # name -> (restype, argtypes); mirrors include/marius_hip.h one to one
 SIGNATURES = {
     "marius_hip_abi_version": (C.c_int, []),
+    "marius_hip_struct_bytes": (C.c_int, [C.c_int]),
     "marius_hip_last_error": (C.c_char_p, []),
     "marius_gather_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
     "marius_gather_rows_counted": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
@@ -114,6 +116,13 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        # include/marius_hip.h MARIUS_HIP_ABI_VERSION: a stale library (or stale struct mirrors here) would read fields past the caller's struct
+        got = L.marius_hip_abi_version()
+        if got != ABI_VERSION:
+            raise MariusHipError("libmarius_hip.so at %s has ABI version %d, this package was written against %d: rebuild with `python -m marius_amd.build`" % (path, got, ABI_VERSION))
+        for which, mirror in ((0, LpDesc), (1, LpLayout)):
+            if L.marius_hip_struct_bytes(which) != C.sizeof(mirror):
+                raise MariusHipError("%s is %d bytes in libmarius_hip.so and %d in marius_amd/hip.py" % (mirror.__name__, L.marius_hip_struct_bytes(which), C.sizeof(mirror)))
         _lib = L
     return _lib
 
@@ -280,7 +289,7 @@ class UniqueMap:
         self.ws_bytes = lib().marius_sort_unique_workspace_bytes(capacity)
         if self.ws_bytes == 0:
             raise MariusHipError("sort_unique workspace query failed")
-        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=device)  # zeroed once: the sort's control block (marius_hip.h)
 
     def run(self, ids, key_bits=63):
         n = ids.numel()

@@ -35,7 +35,8 @@ def marius_train(cfg, log=print, train=True):
     dev = torch.device("cuda", 0)
     ds = cfg["storage"]["dataset"]
     ddir, mdir = ds["dataset_dir"], cfg["storage"]["model_dir"]
-    if cfg.get("_creates_model_dir", train):
+    creates = cfg.pop("_creates_model_dir", train)  # run-mode state of load_config, not a key of the reference schema: never written to full_config.yaml
+    if creates:
         os.makedirs(mdir, exist_ok=True)
     elif not os.path.isdir(mdir):  # marius_eval / resume_training: the directory of an earlier run is looked up, never created
         raise FileNotFoundError("model directory %s does not exist: nothing to %s (run marius_train first, or set storage.model_dir)" % (

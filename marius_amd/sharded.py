@@ -655,9 +655,10 @@ def run_sharded_bench(a, cfg, rank, world, dev):
                     world, sync_interval, ("row exchange overlapped with scoring on a second stream (staleness %d step%s; reference pipeline bound: 16)" % (staleness, "s" if staleness > 1 else "")
                                            if pipelined and staleness else "synchronous exchange"))},
             "positive_edges_per_s": round(pos_eps, 1), "roofline": None, "cpu_baseline": None,
-            # the communicator the exchange ran on: `rccl_ranks` ranks, one per GPU ("nccl" is RCCL on ROCm; "gloo" only in the
-            # single-GPU emulation of tests/test_gpu_sharded2.py)
-            "rccl_ranks": cpp_trainer.ranks() if cpp_trainer is not None else world, "collective_backend": backend_name,
+            # the communicator the exchange ran on: `ranks` of `collective_backend` ("nccl" is RCCL on ROCm; "gloo" only in the single-GPU
+            # emulation of tests/test_gpu_sharded2.py).  `rccl_ranks` counts ranks of an RCCL communicator only: 0 when there is none.
+            "ranks": cpp_trainer.ranks() if cpp_trainer is not None else world, "collective_backend": backend_name,
+            "rccl_ranks": (cpp_trainer.ranks() if cpp_trainer is not None else world) if backend_name == "nccl" else 0,
             "exchange_bytes_per_step": {"ids": round(float(xb[0]) / a.steps), "rows": round(float(xb[1]) / a.steps), "gradients": round(float(xb[2]) / a.steps),
                                         "total": round(float(xb.sum()) / a.steps), "note": "all ranks, bytes that cross xGMI per step; counts ride a world-integer device all-to-all"},
         }

@@ -367,3 +367,89 @@ def test_marius_train_partitioned_evaluation_config(M, dev, tmp_path):
     assert res[-1]["validation"]["MRR"] > res[0]["validation"]["MRR"] and res[-1]["test"]["MRR"] > 0.2
     again = marius_eval(cfg, log=lambda *a: None)
     assert abs(again[0]["test"]["MRR"] - res[-1]["test"]["MRR"]) < 0.08  # a fresh ordering and fresh negatives, same table
+
+
+def _bucket_sorted_edges(num_nodes, E, p, dev, seed=3):
+    """Synthetic 2-column edge list sorted by edge bucket, built per bucket (no global sort), and the p * p bucket sizes."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    src = torch.randint(num_nodes, (E,), generator=g, device=dev)
+    dst = torch.randint(num_nodes, (E,), generator=g, device=dev)
+    ps = -(-num_nodes // p)
+    bucket = (src // ps) * p + dst // ps
+    parts, sizes = [], []
+    for k in range(p * p):
+        idx = (bucket == k).nonzero().flatten()
+        parts.append(torch.stack([src[idx], dst[idx]], 1))
+        sizes.append(int(idx.numel()))
+    return torch.cat(parts).to(torch.int32), sizes
+
+
+def test_one_buffer_state_with_ten_million_active_edges(M, dev, tmp_path, monkeypatch):
+    """>= 300 batches of ONE buffer state holding >= 10 M active edges, through the default training path (flash decoder,
+    planned update with the fix-up inside the Adagrad launch, loader stream, permutation ahead).  The round-2 'stall' at this scale was the
+    bench tool's edge list (not bucket-sorted above 10^8 rows: endpoints outside the buffer mapped to -1 and the fused fix-up, which does not
+    mask negative ids, faulted); this test pins the index ranges themselves: the epoch completes, touches only rows of resident partitions,
+    and the planned single-launch update leaves exactly the bits of the unplanned three-launch form over all 306 batches."""
+    num_nodes, d, B, C, N, E, p, c = 2_000_000, 32, 50_000, 10, 100, 15_300_000, 2, 2
+    edges, sizes = _bucket_sorted_edges(num_nodes, E, p, dev)
+    g = torch.Generator().manual_seed(11)
+    table = (torch.rand(num_nodes, d, generator=g) - 0.5) * 0.2
+    results = []
+    for tag, fused_fixup in (("a", "1"), ("b", "0")):
+        monkeypatch.setenv("MARIUS_SEG_FUSED_FIXUP", fused_fixup)
+        fe, fs = str(tmp_path / (tag + "_emb.bin")), str(tmp_path / (tag + "_state.bin"))
+        P.write_table(fe, table.numpy())
+        P.write_table(fs, np.zeros((num_nodes, d), dtype=np.float32))
+        o = M.PartitionBufferOptions()
+        o.num_partitions, o.buffer_capacity, o.prefetching, o.fine_to_coarse_ratio = p, c, True, 1
+        o.edge_bucket_ordering = M.EdgeBucketOrdering.NEW_BETA
+        emb, state = M.PartitionBufferStorage(fe, num_nodes, d, o, dev), M.PartitionBufferStorage(fs, num_nodes, d, o, dev)
+        gen = M.MariusGenerator(7)
+        est = M.InMemory(edges)
+        est.edge_bucket_sizes = sizes
+        loader = M.DataLoader(est, emb, state, M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen), gen, B, True)
+        dec = M.ComplEx(1, d, dev, False, M.EdgeDecoderMethod.CORRUPT_NODE)
+        model = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+        model.setup_optimizers(0.1)
+        model.sparse_lr = 0.1
+        trainer = M.SynchronousTrainer(loader, model)
+        loader.loadStorage()
+        loader.initializeBatches(True)
+        assert len(loader.buffer_states) == 1 and loader.active_edges.size(0) == E >= 10_000_000
+        assert int(loader.active_edges.min()) >= 0 and int(loader.active_edges.max()) < loader.graph.num_nodes_in_memory
+        steps = 0
+        while loader.hasNextBatch():
+            trainer.train_one(True)
+            steps += 1
+        torch.cuda.synchronize()
+        loader.nextEpoch(True)
+        assert steps == -(-E // B) >= 300
+        results.append((np.fromfile(fe, dtype=np.float32), np.fromfile(fs, dtype=np.float32)))
+        del trainer, loader, emb, state
+    (ea, sa), (eb, sb) = results
+    assert np.isfinite(ea).all() and not np.array_equal(ea, table.numpy().ravel())
+    assert (sa.reshape(num_nodes, d).max(1) > 0).mean() > 0.99          # every node is an endpoint or a negative somewhere in 15 M edges
+    assert np.array_equal(ea, eb) and np.array_equal(sa, sb)
+
+
+def test_edge_list_not_sorted_by_bucket_is_rejected(M, dev, tmp_path):
+    """An active bucket whose edges touch partitions that are on disk: the reference's index_select throws on the -1 row; here the loader
+    refuses the buffer state before any kernel sees the ids."""
+    num_nodes, d, p, c, E = 400, 8, 4, 2, 2000
+    edges, sizes = _bucket_sorted_edges(num_nodes, E, p, dev)
+    shuffled = edges[torch.randperm(E, generator=torch.Generator().manual_seed(0)).to(dev)]
+    fe, fs = str(tmp_path / "emb.bin"), str(tmp_path / "state.bin")
+    for f in (fe, fs):
+        P.write_table(f, np.zeros((num_nodes, d), dtype=np.float32))
+    o = M.PartitionBufferOptions()
+    o.num_partitions, o.buffer_capacity, o.prefetching, o.fine_to_coarse_ratio = p, c, False, 1
+    emb, state = M.PartitionBufferStorage(fe, num_nodes, d, o, dev), M.PartitionBufferStorage(fs, num_nodes, d, o, dev)
+    gen = M.MariusGenerator(7)
+    est = M.InMemory(shuffled)
+    est.edge_bucket_sizes = sizes
+    loader = M.DataLoader(est, emb, state, M.CorruptNodeNegativeSampler(2, 8, 0.0, False, M.LocalFilterMode.DEG, gen), gen, 64, True)
+    loader.loadStorage()
+    with pytest.raises(Exception, match="outside the partitions in memory"):
+        loader.initializeBatches(True)
+        while loader.hasNextBatch():   # the first state could by chance hold only resident endpoints; a later one cannot
+            loader.getBatch(False)

@@ -164,7 +164,7 @@ def test_bench_launch_contract_two_ranks():
     # the N > 1 line is complete: bounded CPU leg, roofline of the dominant kernel, the communicator it ran on, bytes on the wire
     assert j["cpu_baseline"] and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1 and j["cpu_baseline"]["kind"] == "port"
     assert j["roofline"] and 0 < j["roofline"]["frac"] < 1 and j["roofline"]["bound"] == "mfma"
-    assert j["rccl_ranks"] == 2 and j["collective_backend"] == "gloo"
+    assert j["ranks"] == 2 and j["collective_backend"] == "gloo" and j["rccl_ranks"] == 0  # no RCCL communicator in this emulation
     xb = j["exchange_bytes_per_step"]
     assert xb["ids"] > 0 and xb["rows"] > 0 and xb["gradients"] == xb["rows"] and xb["total"] == xb["ids"] + xb["rows"] + xb["gradients"]
     # strong scaling: the global batch stays B

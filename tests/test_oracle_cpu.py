@@ -4,6 +4,7 @@ import ctypes as C
 import json
 import math
 import os
+import re
 
 import numpy as np
 import pytest
@@ -199,7 +200,10 @@ def test_library_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(L, name), "libmarius_hip.so does not export %s" % name
     assert sorted(hip.SIGNATURES) == decl, set(hip.SIGNATURES) ^ set(decl)
-    assert L.marius_hip_abi_version() == 1
+    # the version the header states, the library returns and the ctypes mirror expects are one number (a stale build is refused by hip.lib())
+    hdr = open(os.path.join(ROOT, "include", "marius_hip.h")).read()
+    assert L.marius_hip_abi_version() == hip.ABI_VERSION == int(re.search(r"#define MARIUS_HIP_ABI_VERSION (\d+)", hdr).group(1))
+    assert L.marius_hip_struct_bytes(0) == C.sizeof(hip.LpDesc) and L.marius_hip_struct_bytes(1) == C.sizeof(hip.LpLayout)
 
 
 def test_host_generator_matches_golden(rnggold):
@@ -238,7 +242,7 @@ def test_lp_plan_validation_and_layout():
     d.B = 1005  # ceil(1005/10) = 101 -> Bp = 1010 (pad_and_reshape)
     assert hip.lib().marius_lp_plan(C.byref(d), C.byref(lay)) == 0 and lay.Bp == 1010
     d.edge_cols = 4
-    assert hip.lib().marius_lp_plan(C.byref(d), C.byref(lay)) == hip.lib().marius_hip_abi_version() * 1  # MARIUS_ERR_INVALID
+    assert hip.lib().marius_lp_plan(C.byref(d), C.byref(lay)) == 1  # MARIUS_ERR_INVALID
     assert b"3 or 2 column" in hip.lib().marius_hip_last_error()
     d.edge_cols, d.d = 3, 7  # ComplEx needs even d
     assert hip.lib().marius_lp_plan(C.byref(d), C.byref(lay)) != 0

@@ -17,6 +17,32 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import marius_amd  # noqa: E402
 
 
+def bucket_sort_edges(cols, src, dst, ps, p, piece=1 << 24):
+    """int32 edge list sorted (stably) by edge bucket (src // ps) * p + dst // ps, and the p * p bucket sizes.
+
+    Sorted piece by piece and stitched per bucket: on this stack one `torch.sort(stable=True)` + row gather over >= 10^8 rows returned a list
+    that was NOT bucket-sorted (tools/probe_torch_sort.py) — which is what the round-2 "stall" at 260 M edges was: edges whose endpoints
+    were not in the buffer.  The result is verified before it is handed out."""
+    E = src.numel()
+    pieces, counts = [], []
+    for lo in range(0, E, piece):
+        hi = min(E, lo + piece)
+        b = (src[lo:hi] // ps) * p + dst[lo:hi] // ps
+        order = torch.sort(b, stable=True)[1]
+        pieces.append(torch.stack([c[lo:hi] for c in cols], 1).index_select(0, order).to(torch.int32))
+        counts.append(torch.bincount(b, minlength=p * p))
+    counts_h = torch.stack(counts).cpu()                        # [pieces, p * p]
+    starts = torch.cumsum(counts_h, 1) - counts_h
+    parts = [pieces[i].narrow(0, int(starts[i, k]), int(counts_h[i, k])) for k in range(p * p) for i in range(len(pieces)) if counts_h[i, k] > 0]
+    edges = torch.cat(parts)
+    del pieces, parts
+    sizes = counts_h.sum(0).tolist()
+    eb = (edges[:, 0].long() // ps) * p + edges[:, -1].long() // ps
+    if not bool((eb[1:] >= eb[:-1]).all()) or torch.bincount(eb, minlength=p * p).tolist() != sizes:
+        raise RuntimeError("synthetic edge list is not bucket-sorted")
+    return edges, sizes
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nodes", type=int, default=10_000_000)
@@ -27,6 +53,9 @@ def main():
     ap.add_argument("--relations", type=int, default=14824, help="1: a single relation type, 2-column edges, one direction (cfg5: Twitter-2010)")
     ap.add_argument("--dir", default="/tmp", help="/dev/shm keeps the partition files in host DRAM (cfg5's setting)")
     ap.add_argument("--skip-device-memory", action="store_true")
+    ap.add_argument("--only-device-memory", action="store_true")
+    ap.add_argument("--prefetch", type=int, default=1)
+    ap.add_argument("--max-steps", type=int, default=0, help="stop the out-of-core epoch after this many steps (diagnosis runs)")
     a = ap.parse_args()
     M = marius_amd.host()
     dev = torch.device("cuda", 0)
@@ -36,13 +65,14 @@ def main():
     dst = torch.randint(a.nodes, (a.edges,), generator=g, device=dev)
     rel = torch.randint(R, (a.edges,), generator=g, device=dev)
     ps = -(-a.nodes // p)
-    bucket = (src // ps) * p + dst // ps                       # torch_partitioner.py:12-46 on the device: stable sort by edge bucket
-    order = torch.sort(bucket, stable=True)[1]
-    edges = (torch.stack([src, rel, dst], 1) if R > 1 else torch.stack([src, dst], 1))[order].to(torch.int32)  # io.cpp:42-45: one relation type -> (src, dst)
-    sizes = torch.bincount(bucket, minlength=p * p).tolist()
-    del src, dst, rel, bucket, order
+    cols = [src, rel, dst] if R > 1 else [src, dst]            # io.cpp:42-45: one relation type -> (src, dst)
+    edges, sizes = bucket_sort_edges(cols, src, dst, ps, p)    # torch_partitioner.py:12-46 on the device: stable sort by edge bucket
+    del src, dst, rel, cols
     trace = bool(os.environ.get("PB_TRACE"))
     T0 = time.perf_counter()
+    if trace:  # a run that stops making progress prints where every Python thread is
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("PB_TRACE_DUMP_AFTER", "45")), exit=False)
 
     def tr_print(*x):
         if trace:
@@ -69,6 +99,10 @@ def main():
         out["device_memory_epoch_s"] = round(tr.last_epoch_seconds, 2)
         del tr, loader, emb, st
         torch.cuda.empty_cache()
+        tr_print("device-memory epoch done", out["device_memory_edges_per_s"])
+    if a.only_device_memory:
+        print(json.dumps(out))
+        return
     # ---- partition buffer
     paths = [os.path.join(a.dir, n) for n in ("pb_bench_embeddings.bin", "pb_bench_state.bin")]
     rows = 1 << 20
@@ -81,7 +115,7 @@ def main():
     out["file_init_s"] = round(time.perf_counter() - t_files, 1)
     tr_print("files written")
     o = M.PartitionBufferOptions()
-    o.num_partitions, o.buffer_capacity, o.prefetching, o.fine_to_coarse_ratio = p, a.capacity, True, 1
+    o.num_partitions, o.buffer_capacity, o.prefetching, o.fine_to_coarse_ratio = p, a.capacity, bool(a.prefetch), 1
     o.edge_bucket_ordering = M.EdgeBucketOrdering.NEW_BETA
     emb, st = M.PartitionBufferStorage(paths[0], a.nodes, d, o, dev), M.PartitionBufferStorage(paths[1], a.nodes, d, o, dev)
     gen = M.MariusGenerator(7)
@@ -106,9 +140,11 @@ def main():
     while loader.hasNextBatch():
         tr.train_one(True)
         steps += 1
-        if trace and steps % 100 == 0:
+        if trace and (steps % 100 == 0 or steps <= 3):
             torch.cuda.synchronize()
             tr_print("steps", steps, "swaps", emb.swaps, "ahead hits/misses", loader.shuffle_ahead_hits, loader.shuffle_ahead_misses)
+        if a.max_steps and steps >= a.max_steps:
+            break
     torch.cuda.synchronize()
     t_train = time.perf_counter() - te
     tw = time.perf_counter()
