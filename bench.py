@@ -86,6 +86,15 @@ def event_pair_overhead_ms(k=100):
     return tot / k
 
 
+def pmc_traffic_file(flash):
+    """newest committed PMC traffic summary of the default bench command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.py)"""
+    names = ["r3_pmc_traffic.json", "r2_pmc_traffic.json"] if flash else ["r1h_pmc_traffic.json"]
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, "profiles", n)):
+            return os.path.join(ROOT, "profiles", n)
+    return None
+
+
 def dominant_roofline(avg_ms, B, C, N, d, ndir, flash, pmc_ok, kernel="lp_grad_adj"):
     """roofline object of a backward contraction launch timed at avg_ms (see the accounting notes in main())"""
     Bp = C * math.ceil(B / C)
@@ -95,12 +104,13 @@ def dominant_roofline(avg_ms, B, C, N, d, ndir, flash, pmc_ok, kernel="lp_grad_a
     else:
         ach, peak = 2 * contraction_flops / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TF
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json" if flash else "r1h_pmc_traffic.json")
-    if pmc_ok and os.path.exists(pmc_path):
+    pmc_path = pmc_traffic_file(flash)
+    if pmc_ok and pmc_path:
         for name, v in json.load(open(pmc_path))["kernels"].items():
             if name.startswith("flash_kernel<7, 1" if flash else "lp_grad16_kernel"):
                 traffic = v["hbm_bytes"]
     out = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+           "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command; a constant, NOT measured in this run)" % os.path.relpath(pmc_path, ROOT)) if traffic else None,
            "avg_ms": round(avg_ms, 4)}
     if flash:
         out.update({"peak_is": "dense BF16 MFMA", "bf16_products_per_fp32_product": 3, "contractions_per_launch": 2, "fp32_equivalent_tflops": round(ach / 3, 2)})
@@ -111,6 +121,49 @@ def dominant_roofline(avg_ms, B, C, N, d, ndir, flash, pmc_ok, kernel="lp_grad_a
     except Exception:  # noqa: BLE001
         pass
     return out
+
+
+def fp32_exact_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_flops, steps=20, warmup=5):
+    """ms per step and the dominant kernel's roofline with MARIUS_FLASH=0: every product an fp32 product (v_mfma_f32_32x32x2_f32), the
+    400 MB score tensor materialised and re-read by the merged backward launch — the round-1 path, parity-identical to the reference's
+    arithmetic up to summation order."""
+    R, d, B, C, N = cfg["num_relations"], cfg["d"], cfg["B"], cfg["C"], cfg["N"]
+    prev = os.environ.get("MARIUS_FLASH")
+    os.environ["MARIUS_FLASH"] = "0"
+    try:
+        gen = M.MariusGenerator(43)
+        loader = M.DataLoader(M.InMemory(edges_all), M.InMemory(table), M.InMemory(state), M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen), gen, B, True)
+        dec = {"DISTMULT": M.DistMult, "COMPLEX": M.ComplEx, "TRANSE": M.TransE}[cfg["decoder"]](R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+        model = M.Model(dec, M.getLossFunction("SOFTMAX_CE", "sum", 0.1), M.LinkPredictionReporter(), dev)
+        model.setup_optimizers(0.1)
+        model.sparse_lr = 0.1
+        trainer = M.SynchronousTrainer(loader, model)
+        loader.initializeBatches(True)
+        trainer.train_steps(warmup)
+        torch.cuda.synchronize()
+        assert not model.last_step_flash
+        H.profile_reset()
+        H.profile_enable(True, only="lp_grad_adj")
+        t0 = time.perf_counter()
+        trainer.train_steps(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        H.profile_enable(False)
+        ms, cnt = H.profile_read().get("lp_grad_adj", (0.0, 0))
+        out = {"ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup, "dtype": "f32 (v_mfma_f32_32x32x2_f32, fp32 products and accumulate)",
+               "loss_last_batch": float(model.loss[0].item()),
+               "note": "MARIUS_FLASH=0: the step in the reference's arithmetic (scores materialised); the headline value uses 16 significand bits per contraction operand"}
+        if cnt:
+            avg = ms / cnt
+            ach = 2 * contraction_flops / (avg * 1e-3) / 1e12
+            out.update({"kernel": "lp_grad16 (dAdj + dNeg contractions from the stored scores, one launch)", "kernel_avg_ms": round(avg, 4), "achieved": round(ach, 2),
+                        "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4)})
+        return out
+    finally:
+        if prev is None:
+            os.environ.pop("MARIUS_FLASH", None)
+        else:
+            os.environ["MARIUS_FLASH"] = prev
 
 
 def cpu_baseline_leg(cfg, B, C, N, edges_all, cpu_seconds):
@@ -167,6 +220,7 @@ def main():
     ap.add_argument("--driver", default="cpp", choices=["cpp", "py"], help="host loop: C++ SynchronousTrainer (default) or the ctypes step driver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-fp32-pass", action="store_true", help="skip the short MARIUS_FLASH=0 pass that reports the fp32-exact step time beside the headline number")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--strong", action="store_true", help="N > 1: strong scaling (the global batch stays B; default is weak scaling, B per GPU)")
     ap.add_argument("--loss", default="SOFTMAX_CE", help="model.loss.type (the headline metric is quoted on SOFTMAX_CE; others for exploration, C++ driver only)")
@@ -332,8 +386,8 @@ def main():
         # HBM bytes per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
         # this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md) — only valid for the workload it was collected on
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json" if flash else "r1h_pmc_traffic.json")
-        if a.workload == "freebase86m" and not a.num_nodes and os.path.exists(pmc_path):
+        pmc_path = pmc_traffic_file(flash)
+        if a.workload == "freebase86m" and not a.num_nodes and pmc_path:
             pmc = json.load(open(pmc_path))["kernels"]
             if flash:
                 key = {"lp_grad_adj": "flash_kernel<7, 1", "lp_grad_neg": "flash_kernel<7, 2", "lp_scores": "flash_kernel<7, 0",
@@ -346,7 +400,9 @@ def main():
                     traffic = v["hbm_bytes"]
         roofline = {"kernel": dom + (" (dAdj + dNeg contractions, one launch)" if not flash and dom == "lp_grad_adj" and prof.get("lp_grad_neg", (0, 0))[1] == 0 else ""),
                     "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"], "frac": k["frac"],
-                    "traffic": traffic, "avg_ms": k["avg_ms"]}
+                    "traffic": traffic,
+                    "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command; a constant, NOT measured in this run)" % os.path.relpath(pmc_path, ROOT)) if traffic else None,
+                    "avg_ms": k["avg_ms"]}
         if flash and k["bound"] == "mfma":
             ncon = 1 if dom == "lp_scores" else 2
             roofline.update({"peak_is": "dense BF16 MFMA", "bf16_products_per_fp32_product": 3, "contractions_per_launch": ncon,
@@ -359,6 +415,13 @@ def main():
                              "frac_minus_bracket": round(k["frac"] * k["avg_ms"] / net, 4)})
         except Exception:  # noqa: BLE001
             pass
+
+    # ---- the same step in the reference's own arithmetic: fp32 products on the FP32 matrix pipe, scores materialised
+    # (MARIUS_FLASH=0), a short pass after the timed region on a fresh Model / loader over the same tables — what the 16-bit-significand
+    # contraction of the headline number buys, stated next to it
+    fp32_exact = None
+    if flash and a.driver == "cpp" and not a.no_fp32_pass:
+        fp32_exact = fp32_exact_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_flops)
 
     # ---- CPU baseline: the oracle (port of the reference's CPU path) on a bounded sample, host cores of this box
     cpu = None
@@ -383,7 +446,7 @@ def main():
             a.workload, cfg["decoder"], d, B, C, N, a.edge_dist), "num_nodes": num_nodes, "num_relations": R, "num_edges": cfg["num_edges"],
             "parallelism": "single GPU", "host": "C++ SynchronousTrainer (libtorch)" if a.driver == "cpp" else "python ctypes driver"},
         "positive_edges_per_s": round(pos_eps, 1), "unique_rows_last_batch": U, "loss_last_batch": loss,
-        "roofline": roofline, "hbm_read_roofline_gather_score": gs, "kernels": kernels, "cpu_baseline": cpu,
+        "roofline": roofline, "fp32_exact": fp32_exact, "hbm_read_roofline_gather_score": gs, "kernels": kernels, "cpu_baseline": cpu,
     }
     emit_json(out)
 

@@ -158,30 +158,47 @@ def test_flash_forward_loss_backward_match_oracle(H, dev, decoder, use_inverse, 
     check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv if use_inverse else None, U, R)
 
 
-@pytest.mark.parametrize("decoder,B,C,N,d", [("COMPLEX", 4096, 4, 1000, 100), ("DISTMULT", 1000, 10, 500, 128), ("COMPLEX", 300, 3, 200, 64)])
+@pytest.mark.parametrize("decoder,B,C,N,d", [("COMPLEX", 4096, 4, 1000, 100), ("DISTMULT", 1000, 10, 500, 128), ("COMPLEX", 300, 3, 200, 64),
+                                             ("COMPLEX", 50000, 50, 1000, 100)])  # the last one: the bench shape (10^8 score entries, every one checked)
 def test_flash_scores_obey_the_split_error_bound(H, dev, decoder, B, C, N, d):
-    """|S_flash - S_fp64| <= (3 * 2^-18 + 2^-20) * sum_k |adj_k| |neg_k|, entry by entry, both directions."""
-    U, R = 9000, 17
+    """|S_flash - S_fp64| <= (3 * 2^-18 + 2^-20) * sum_k |adj_k| |neg_k|, entry by entry, both directions.  Also measured: the worst PURE
+    relative error over the entries with |S| >= 0.1 max|S| (asserted <= 1e-4, north_star's figure) and over |S| >= 1e-2 max|S| (the floor
+    close_report uses for the FP32 path; printed, asserted <= 1e-3).  The second figure is where a 16-bit-significand operand shows: the
+    error of an entry scales with sum|a_k n_k|, not with |S|, so entries a hundred times smaller than the largest — sums that mostly cancel —
+    carry up to a few 1e-4 of relative error (CPU emulation of the same split: 3.9e-4 over 1.6e7 entries at d = 100), where the fp32
+    kernels stay at <= 1e-4.  DESIGN.md section 4.1 states this next to the number."""
+    U, R = (9000, 17) if B < 50000 else (200000, 1000)
     emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=5, scale=1.0)
     W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True)
     e64, r64, i64 = emb.double(), rel.double(), inv.double()
     Bc = -(-B // C)
-    worst = 0.0
+    worst, worst_rel, worst_rel1 = 0.0, 0.0, 0.0
     for dir_, (relt, head, negs) in enumerate([(r64, 0, dst_neg), (i64, 2, src_neg)]):
         op = O.hadamard if decoder == "DISTMULT" else O.complex_hadamard
         adj = op(e64[edges[:, head]], relt[edges[:, 1]])
         adj = torch.cat([adj, torch.zeros(Bc * C - B, d, dtype=torch.float64)])
         got = W.neg(dir_).cpu().double()
+        exact_all = [adj[c * Bc:(c + 1) * Bc] @ e64[negs[c]].t() for c in range(C)]
+        smax = max(float(x.abs().max()) for x in exact_all)
         for c in range(C):
             a = adj[c * Bc:(c + 1) * Bc]
             n = e64[negs[c]]
-            exact = a @ n.t()
+            exact = exact_all[c]
             mag = a.abs() @ n.abs().t()
             err = (got[c * Bc:(c + 1) * Bc] - exact).abs()
             bound = (3 * 2.0 ** -18 + 2.0 ** -20) * mag + 1e-30
             worst = max(worst, (err / bound).max().item())
-    print("worst |err| / bound = %.3f" % worst)
+            for floor in (1e-1, 1e-2):
+                big = exact.abs() >= floor * smax
+                if bool(big.any()):
+                    r = (err[big] / exact.abs()[big]).max().item()
+                    if floor == 1e-1:
+                        worst_rel1 = max(worst_rel1, r)
+                    else:
+                        worst_rel = max(worst_rel, r)
+    print("worst |err| / bound = %.3f   worst pure-relative error over |S| >= 0.1 max|S| = %.2e, over |S| >= 1e-2 max|S| = %.2e" % (worst, worst_rel1, worst_rel))
     assert worst <= 1.0
+    assert worst_rel1 <= 1e-4 and worst_rel <= 1e-3
 
 
 @pytest.mark.parametrize("nwg", ["1", "2", "3", "5", "8", "16", "24"])
