@@ -107,7 +107,7 @@ def dominant_roofline(avg_ms, B, C, N, d, ndir, flash, pmc_ok, kernel="lp_grad_a
     pmc_path = pmc_traffic_file(flash)
     if pmc_ok and pmc_path:
         for name, v in json.load(open(pmc_path))["kernels"].items():
-            if name.startswith("flash_kernel<7, 1" if flash else "lp_grad16_kernel"):
+            if name.startswith(("flash_kernel<7, 3", "flash_kernel<7, 1") if flash else "lp_grad16_kernel"):
                 traffic = v["hbm_bytes"]
     out = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
            "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command; a constant, NOT measured in this run)" % os.path.relpath(pmc_path, ROOT)) if traffic else None,
@@ -348,7 +348,7 @@ def main():
     # gradient contraction (2 contractions each) — priced against the dense BF16 matrix peak.
     alg = {  # algorithmic work per launch
         "lp_scores": ("mfma_bf16", 3 * contraction_flops) if flash else ("mfma", contraction_flops),
-        "lp_grad_adj": ("mfma_bf16", 2 * 3 * contraction_flops) if flash else ("mfma", contraction_flops),
+        "lp_grad_adj": ("mfma_bf16", 2 * 3 * contraction_flops) if flash else ("mfma", contraction_flops),  # flash, fused form: the forward sweep (scores + V Neg)
         "lp_grad_neg": ("mfma_bf16", 2 * 3 * contraction_flops) if flash else ("mfma", contraction_flops),
         "gather_rows": ("hbm", U * d * 4.0 * 2 + U * 8.0),                    # read rows + write batch copy + ids
         "segment_adagrad_scatter": ("hbm", L * d * 4.0 + U * d * 4.0 * 4),    # occurrence grads + r/w of w and s
@@ -390,7 +390,7 @@ def main():
         if a.workload == "freebase86m" and not a.num_nodes and pmc_path:
             pmc = json.load(open(pmc_path))["kernels"]
             if flash:
-                key = {"lp_grad_adj": "flash_kernel<7, 1", "lp_grad_neg": "flash_kernel<7, 2", "lp_scores": "flash_kernel<7, 0",
+                key = {"lp_grad_adj": ("flash_kernel<7, 3", "flash_kernel<7, 1"), "lp_grad_neg": "flash_kernel<7, 2", "lp_scores": "flash_kernel<7, 0",
                        "gather_rows": "gather_rows_kernel", "segment_adagrad_scatter": "adagrad_unique_rows_kernel"}.get(dom)
             else:
                 key = {"lp_grad_adj": "lp_grad16_kernel", "lp_grad_neg": "lp_grad16_kernel", "lp_scores": "lp_scores_ap_kernel",
@@ -431,9 +431,11 @@ def main():
     # SURVEY 8(d) / north_star "fraction of the HBM-read roofline on gather + score": the bytes that MUST be read (every unique row once, the
     # edge triples, the negative ids) over the time of everything between the batch and its scores (row reads + operand packing + score launch)
     gs = None
-    if "lp_prep" in kernels and "lp_scores" in kernels:
+    if "lp_prep" in kernels and ("lp_scores" in kernels or (flash and "lp_grad_adj" in kernels)):
         gs_bytes = U * d * 4 + B * 12 + ndir * C * N * 8
-        gs_ms = kernels["lp_prep"]["avg_ms"] + kernels["lp_scores"]["avg_ms"] + (kernels["gather_rows"]["avg_ms"] if kernels.get("gather_rows", {}).get("launches") else 0.0)
+        # fused flash sweep (scores + dAdj in one launch): the score contraction is half of that launch's matrix work
+        score_ms = kernels["lp_scores"]["avg_ms"] if "lp_scores" in kernels else 0.5 * kernels["lp_grad_adj"]["avg_ms"]
+        gs_ms = kernels["lp_prep"]["avg_ms"] + score_ms + (kernels["gather_rows"]["avg_ms"] if kernels.get("gather_rows", {}).get("launches") else 0.0)
         gs = {"bytes": gs_bytes, "ms": round(gs_ms, 4), "achieved": round(gs_bytes / gs_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
               "frac": round(gs_bytes / gs_ms / 1e6 / HBM_PEAK_GBS, 4),
               "note": "U d 4 + B 12 + 2CN 8 bytes over (prep + pack + score launch): the score contraction is matrix-bound (roofline above), so the >= 0.70 of "

@@ -43,10 +43,11 @@ enum {
 };
 
 /* Bumped whenever a struct of this header changes size or meaning, or an entry point changes its signature (3: marius_lp_desc.flags /
- * reserved_, marius_lp_layout.adjrec / negrec / fpart / flash, planned segment update, zero-initialised sort workspace).  Every binder
+ * reserved_, marius_lp_layout.adjrec / negrec / fpart / flash, planned segment update, zero-initialised sort workspace; 4: MARIUS_LP_KEEP_DADJ,
+ * layout.dadj doubled on the flash path).  Every binder
  * compares the value it was built against with what the loaded library returns and refuses to run on a mismatch: marius_amd/hip.py lib(),
  * the host module's init (bindings.cpp), and the plug-in recipe of INTEGRATION.md. */
-#define MARIUS_HIP_ABI_VERSION 3
+#define MARIUS_HIP_ABI_VERSION 4
 int marius_hip_abi_version(void);
 /* sizeof(marius_lp_desc) / sizeof(marius_lp_layout) as the library was compiled: a second line of defence for ctypes mirrors */
 int marius_hip_struct_bytes(int which /* 0: marius_lp_desc, 1: marius_lp_layout */);
@@ -230,7 +231,10 @@ enum {
      * d in (16, 128]; every other case silently takes the materialised-score kernels. */
     MARIUS_LP_TRAIN_ONLY = 1,
     /* with MARIUS_LP_TRAIN_ONLY: additionally store the recomputed scores into layout.neg (parity tests of the split arithmetic) */
-    MARIUS_LP_STORE_SCORES = 2
+    MARIUS_LP_STORE_SCORES = 2,
+    /* flash path: layout.dadj must hold dL/dadj after marius_lp_backward (parity tests read it).  Without the flag the two blocks behind
+     * layout.dadj[0] hold the unnormalised partials of the forward sweep and the edge backward combines them on the fly. */
+    MARIUS_LP_KEEP_DADJ = 4
 };
 
 /* Workspace layout (all offsets in BYTES from the workspace base; dir 0 = (src,rel)->dst "rhs", dir 1 = inverse "lhs").
@@ -245,7 +249,7 @@ typedef struct marius_lp_layout {
     size_t lse[2];    /* [Bp]        per-row scalar of the loss: SoftmaxCE log(e^pos + sum_j e^neg); Ranking pos - margin        */
     size_t rowloss[2];/* [Bp]        per-row loss                                                                */
     size_t loss;      /* [4] floats: total, dir0, dir1, unused                                                   */
-    size_t dadj[2];   /* [Bp, d_ld]  dL/d adj (negative part)                                                    */
+    size_t dadj[2];   /* [Bp, d_ld]  dL/d adj (negative part); flash path: see MARIUS_LP_KEEP_DADJ                       */
     size_t gocc;      /* [2B + 2CN, d] occurrence gradients in map_tensors order (src, dst, src_neg, dst_neg)    */
     size_t grel[2];   /* [B, d]      per-edge relation gradients (dir 0 -> relations_, dir 1 -> inverse)         */
     size_t aux;       /* scratch (row norms etc.)                                                                */

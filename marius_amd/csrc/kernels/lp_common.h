@@ -201,8 +201,9 @@ size_t flash_negrec_bytes(const LpDims& D);
 size_t flash_part_bytes(const LpDims& D);
 // adj_packed: lp_prep2_kernel already wrote the adj records (and zeroed dadj); otherwise they are packed from `adj` here and dadj_zero
 // (if given) is zeroed.  The negatives' gocc rows are always zeroed by the negative pack kernel.
+bool flash_fused();  // forward statistics + dAdj in one sweep (default); false: MARIUS_FLASH_FUSED=0
 int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj, char* adjrec, char* negrec, float2* part, float* S, bool adj_packed,
-                  float* gocc, const int64_t negocc_off[2], float* dadj_zero, hipStream_t st);
+                  float* gocc, const int64_t negocc_off[2], float* dadj_zero, const float* pos, float* dadj, float* dadj2, hipStream_t st);
 int flash_merge(const LpDims& D, const float2* part, const float* pos, float* lse, float* rowloss, float* dpos, float* blocksum, char* adjrec,
                 hipStream_t st);
 void flash_set_reserved_cus(int n);

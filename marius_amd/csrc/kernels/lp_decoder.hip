@@ -147,9 +147,11 @@ __device__ __forceinline__ void prep_flash_store(const PrepArgs& a, int dir, int
         *reinterpret_cast<unsigned*>(rec + 2 * c1) = hi23;
         *reinterpret_cast<unsigned*>(rec + 2 * a.fKP + 2 * c0) = prep_pack_bf16x2(lo[0], lo[1]);
         *reinterpret_cast<unsigned*>(rec + 2 * a.fKP + 2 * c1) = prep_pack_bf16x2(lo[2], lo[3]);
-        float* z = a.fdadj + ((int64_t)dir * D.Bp + i) * D.d_ld;
-        *reinterpret_cast<float2*>(z + c0) = make_float2(0.f, 0.f);
-        *reinterpret_cast<float2*>(z + c1) = make_float2(0.f, 0.f);
+        if (a.fdadj) {
+            float* z = a.fdadj + ((int64_t)dir * D.Bp + i) * D.d_ld;
+            *reinterpret_cast<float2*>(z + c0) = make_float2(0.f, 0.f);
+            *reinterpret_cast<float2*>(z + c1) = make_float2(0.f, 0.f);
+        }
     } else {
         const int q = l - D.d / 4;             // idle lanes write the zero K padding, one element pair each
         const int col = D.d + 2 * q;
@@ -846,6 +848,13 @@ struct EdgeBwdArgs {
     const float* pos;
     const float* dpos;  // [ndir][Bp] dL/dpos (written by marius_lp_loss)
     const float* dadj;
+    // flash path, fused form (dadj2 != nullptr): dadj / dadj2 hold the UNNORMALISED partials of a row's (at most two) contributors, `part` their
+    // statistics (mref, sum V) [2][ndir Bp]: dL/dadj = g (exp(m0 - lse) O0 + exp(m1 - lse) O1).  keep_dadj: store that back into dadj.
+    const float* dadj2;
+    const float2* part;
+    const float* lse;
+    float gscale;
+    int keep_dadj;
     float* gocc;     // rows [0,B) = src occurrences, [B,2B) = dst occurrences
     float* grel[2];  // [B, d_ld]
     LpDims D;
@@ -889,6 +898,13 @@ __global__ __launch_bounds__(256) void lp_edge_bwd_kernel(EdgeBwdArgs a) {
                 const float av = a.adj[rowoff + cc];
                 const float ov = o[cc];
                 float g = a.dadj[rowoff + cc];
+                if (a.dadj2) {
+                    const int64_t row = (int64_t)dir * D.Bp + i, prows = (int64_t)D.ndir * D.Bp;
+                    const float2 p0 = a.part[row], p1 = a.part[prows + row];
+                    g *= a.gscale * __expf(p0.x - a.lse[row]);
+                    if (p1.y > 0.f) g += a.gscale * __expf(p1.x - a.lse[row]) * a.dadj2[rowoff + cc];
+                    if (a.keep_dadj) const_cast<float*>(a.dadj)[rowoff + cc] = g;
+                }
                 if (D.cmp == MARIUS_CMP_L2) {
                     const float df = (av - ov) + 1e-6f;
                     const float w = (posv[dir] > 0.f) ? coef[dir] * df / posv[dir] : 0.f;
@@ -964,6 +980,22 @@ __global__ __launch_bounds__(256) void lp_edge_bwd2_kernel(EdgeBwdArgs a) {
         if (dir >= D.ndir) continue;
         const int64_t rowoff = ((int64_t)dir * D.Bp + i) * D.d_ld;
         ld4(a.dadj + rowoff, dv[dir]);
+        if (a.dadj2) {  // fused flash sweep: combine the contributors' unnormalised partials
+            const int64_t row = (int64_t)dir * D.Bp + i, prows = (int64_t)D.ndir * D.Bp;
+            const float2 p0 = a.part[row], p1 = a.part[prows + row];
+            const float l_ = a.lse[row];
+            const float c0_ = a.gscale * __expf(p0.x - l_);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dv[dir][k] *= c0_;
+            if (p1.y > 0.f) {
+                const float c1_ = a.gscale * __expf(p1.x - l_);
+                float o1[4];
+                ld4(a.dadj2 + rowoff, o1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dv[dir][k] += c1_ * o1[k];
+            }
+            if (a.keep_dadj) st4(const_cast<float*>(a.dadj) + rowoff, dv[dir]);
+        }
         has_rel[dir] = (D.edge_cols == 3) && (a.rel[dir] != nullptr);
         if (has_rel[dir]) ld4(a.rel[dir] + ed[1] * a.rel_ld, r[dir]);
         else r[dir][0] = r[dir][1] = r[dir][2] = r[dir][3] = 0.f;
@@ -1176,7 +1208,8 @@ static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layou
     base = take(rows * 4 * D.ndir);
     for (int dir = 0; dir < D.ndir; ++dir) L->rowloss[dir] = base + (size_t)dir * rows * 4;
     L->loss = take(16);
-    base = take(rows * D.d_ld * 4 * D.ndir);
+    // flash path, fused form: a second [ndir][Bp, d_ld] block right behind the first holds the dAdj partial of a tile's second contributor
+    base = take(rows * D.d_ld * 4 * D.ndir * (flash ? 2 : 1));
     for (int dir = 0; dir < D.ndir; ++dir) L->dadj[dir] = base + (size_t)dir * rows * D.d_ld * 4;
     const size_t nocc = (size_t)2 * D.B + (size_t)(d->src_neg ? 2 : 1) * D.C * D.N;
     L->gocc = take(nocc * D.d_ld * 4);
@@ -1272,7 +1305,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
             pa.fKP = (D.d + 15) / 16 * 16;
             pa.fXR = (D.Bc + 31) / 32 * 32;
             pa.frec = ws + L->adjrec;
-            pa.fdadj = (float*)(ws + L->dadj[0]);
+            pa.fdadj = flash_fused() ? nullptr : (float*)(ws + L->dadj[0]);  // fused form: partials are stored, never accumulated
             prep_rows += (int64_t)D.ndir * D.C * (pa.fXR - D.Bc);  // one half-wave per chunk-padding record
             flash_fused_prep = true;
         }
@@ -1296,8 +1329,9 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
         float* S = (flash_store_scores(desc) && L->neg[0]) ? (float*)(ws + L->neg[0]) : nullptr;
         const int64_t CNf = (int64_t)D.C * D.N;
         const int64_t occ_off[2] = {2 * D.B + (desc->src_neg ? CNf : 0), 2 * D.B};  // gocc rows of the dst / src negatives (map_tensors order)
+        float* dadj0 = (float*)(ws + L->dadj[0]);
         return flash_forward(desc, D, pa.adj, ws + L->adjrec, ws + L->negrec, (float2*)(ws + L->fpart), S, flash_fused_prep, (float*)(ws + L->gocc), occ_off,
-                             flash_fused_prep ? nullptr : (float*)(ws + L->dadj[0]), st);
+                             (flash_fused_prep || flash_fused()) ? nullptr : dadj0, pa.pos, dadj0, dadj0 + (size_t)D.ndir * D.Bp * D.d_ld, st);
     }
 
     ScoreArgs sa;
@@ -1515,6 +1549,17 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     ea.pos = (const float*)(ws + L->pos[0]);
     ea.dpos = (const float*)(ws + L->dpos[0]);
     ea.dadj = ga.dadj;
+    ea.dadj2 = nullptr;
+    ea.part = nullptr;
+    ea.lse = nullptr;
+    ea.gscale = D.gscale;
+    ea.keep_dadj = 0;
+    if (L->flash && flash_fused()) {
+        ea.dadj2 = ga.dadj + (size_t)D.ndir * D.Bp * D.d_ld;
+        ea.part = (const float2*)(ws + L->fpart);
+        ea.lse = (const float*)(ws + L->lse[0]);
+        ea.keep_dadj = (desc->flags & MARIUS_LP_KEEP_DADJ) ? 1 : 0;
+    }
     ea.gocc = ga.gocc;
     ea.grel[0] = (float*)(ws + L->grel[0]);
     ea.grel[1] = D.ndir == 2 ? (float*)(ws + L->grel[1]) : nullptr;

@@ -45,7 +45,13 @@ typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-enum { FLASH_FWD = 0, FLASH_DADJ = 1, FLASH_DNEG = 2 };
+// FLASH_FDADJ (round 3, the default): forward statistics AND dAdj in one sweep, flash-attention style — V = exp2(S log2(e) - mref) against a
+// per-row reference mref that starts at the row's positive score and is raised (accumulators rescaled) only when a block's maximum
+// exceeds it by more than FL_TAU; the unnormalised sums leave the kernel as (mref, sum V) statistics plus the unnormalised dAdj partial of
+// every (tile, contributor), and the consumer (lp_edge_bwd*) scales by g exp(mref - lse).  One score contraction less per step (4 instead
+// of 5), no zero fill of dadj, no atomics.  FLASH_FWD + FLASH_DADJ remain as MARIUS_FLASH_FUSED=0 and for the score-storing parity runs.
+enum { FLASH_FWD = 0, FLASH_DADJ = 1, FLASH_DNEG = 2, FLASH_FDADJ = 3 };
+constexpr float FL_TAU = 8.f;  // log2 units: V <= 2^8 between raises (bf16 / fp32 share the exponent range: no overflow, no lost precision)
 
 // FL_WAVES_N=8 (256-row stationary tile, one workgroup per CU, six slots) halves the streamed bytes per flop; measured slower at the
 // bench shape (scores 82 vs 72 us, dAdj 141 vs 134, dNeg 148 vs 138): the streamed operand is not what the kernels wait for.
@@ -84,6 +90,9 @@ struct FlashArgs {
     float* out;
     int64_t out_ld;
     int64_t negocc_off[2];
+    // FDADJ: positive scores [ndir Bp] (initial reference of the online softmax); out = partial of a tile's first contributor, out2 = of its second
+    const float* pos;
+    float* out2;
 };
 
 // zero up to three float ranges (lengths are multiples of 4, bases 16-B aligned) in one launch
@@ -289,6 +298,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
     float lsec_x = 0.f;     // DADJ: lsec of the lane's own adj row
     v16f out[MODE == FLASH_FWD ? 1 : NCT];
     float m2 = -INFINITY, lsum = 0.f;  // FWD: running max of S log2(e) and sum of exp2 over this lane's columns
+    float mref = 0.f;                  // FDADJ: reference of the lane's own row x = l31 (log2 units; the same in both lane halves); lsum: this lane's share of sum V
 
     int cur_tile = -1;
     int cd = 0, xt = 0, c_ = 0, dir = 0;
@@ -308,6 +318,10 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
             xl[ks] = *reinterpret_cast<const v8bf*>(r + 2 * KP + 32 * ks + 16 * h);
         }
         if (MODE == FLASH_DADJ) lsec_x = *reinterpret_cast<const float*>(r + 4 * KP);
+        if (MODE == FLASH_FDADJ) {  // the row's positive score is a term of the same softmax: start from it (rows past Xrows are never stored)
+            mref = (x < a.Xrows) ? a.pos[(int64_t)dir * a.Bp + (int64_t)c_ * a.Bc + x] * FL_LOG2E : 0.f;
+            lsum = 0.f;
+        }
         // land the fragments HERE: hipcc's own wait for them would otherwise sit at their first use inside the item loop, and since
         // it cannot see the DMAs of the asm statements it would read as vmcnt(0..3) there — draining the ring every iteration
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -339,6 +353,32 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
                     if (last) a.part[prows + row] = make_float2(-INFINITY, 0.f);
                 } else {
                     a.part[prows + row] = v;
+                }
+            }
+        } else if (MODE == FLASH_FDADJ) {
+            // statistics (mref ln 2, sum V) and the unnormalised partial, slot 0 for the contributor that starts the tile, slot 1 for the other
+            const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+            const int xl = xt * FL_XT + wave * 32 + l31;
+            const int64_t prows = (a.ncd / a.C) * a.Bp;
+            if (h == 0 && xl < a.Xrows) {
+                const int64_t row = (int64_t)dir * a.Bp + (int64_t)c_ * a.Bc + xl;
+                const float2 v = make_float2(mref * FL_LN2, ltot);
+                if (first) {
+                    a.part[row] = v;
+                    if (last) a.part[prows + row] = make_float2(-INFINITY, 0.f);
+                } else {
+                    a.part[prows + row] = v;
+                }
+            }
+            float* dst = first ? a.out : a.out2;
+            const int64_t base = (int64_t)dir * a.Bp + (int64_t)c_ * a.Bc;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int col = 32 * ct + l31;
+#pragma unroll
+                for (int r_ = 0; r_ < 16; ++r_) {
+                    const int x = xt * FL_XT + wave * 32 + acc_row(r_, h);
+                    if (x < a.Xrows && col < a.d) dst[(base + x) * a.out_ld + col] = out[ct][r_];
                 }
             }
         } else {
@@ -461,6 +501,36 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
                 m2 = mn;
             }
         } else {
+            float t[16];
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) t[r_] = accS[r_];
+            if (MODE == FLASH_FDADJ) {
+                // streamed rows past N do not exist: they must not enter sum V (their records are zero rows: S = 0, not -inf)
+                if ((yph + 1) * FL_YB > a.Yrows) {
+#pragma unroll
+                    for (int r_ = 0; r_ < 16; ++r_) {
+                        const int y = yph * FL_YB + 16 * (r_ >> 3) + 8 * h + (r_ & 7);
+                        if (y >= a.Yrows) t[r_] = -INFINITY;
+                    }
+                }
+                float tm = t[0];
+#pragma unroll
+                for (int r_ = 1; r_ < 16; ++r_) tm = fmaxf(tm, t[r_]);
+                tm = fmaxf(tm, __shfl_xor(tm, 32, 64)) * FL_LOG2E;  // this block's maximum of row x = l31, both halves
+                const bool raise = tm > mref + FL_TAU;
+                if (__builtin_amdgcn_ballot_w64(raise) != 0ull) {    // rare: a reference moves, the row's sums are rescaled to it
+                    const float mnew = raise ? tm : mref;
+                    const float alpha = __builtin_amdgcn_exp2f(mref - mnew);
+                    lsum *= alpha;
+                    mref = mnew;
+#pragma unroll
+                    for (int r_ = 0; r_ < 16; ++r_) {
+                        const float ax = __shfl(alpha, acc_row(r_, h), 64);  // accumulator register r_ of this lane belongs to row acc_row(r_, h)
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) out[ct][r_] *= ax;
+                    }
+                }
+            }
             // ---- V = exp2(S log2(e) - lsec) in the accumulator layout == A operand layout (k = 16 s + 8 h + e <-> reg 8 s + e)
             v8bf wh[2], wl[2];
 #pragma unroll
@@ -470,8 +540,10 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
                     const int r_ = 8 * s_ + e;
                     float ls;
                     if (MODE == FLASH_DADJ) ls = lsec_x;
+                    else if (MODE == FLASH_FDADJ) ls = mref;
                     else ls = *reinterpret_cast<const float*>(T + (16 * s_ + fl_rho(8 * h + e)) * P + 4 * KP);
-                    const float w = __builtin_amdgcn_exp2f(fmaf(accS[r_], FL_LOG2E, -ls));
+                    const float w = __builtin_amdgcn_exp2f(fmaf(t[r_], FL_LOG2E, -ls));
+                    if (MODE == FLASH_FDADJ) lsum += w;
                     const __bf16 wh_ = (__bf16)w;
                     wh[s_][e] = wh_;
                     wl[s_][e] = (__bf16)(w - (float)wh_);
@@ -543,6 +615,11 @@ bool flash_applicable(const marius_lp_desc* desc, const LpDims& D) {
 size_t flash_adjrec_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.Bc + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)) + 32768; }
 size_t flash_negrec_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.N + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)) + 32768; }
 size_t flash_part_bytes(const LpDims& D) { return (size_t)2 * D.ndir * D.Bp * sizeof(float2); }
+// MARIUS_FLASH_FUSED=0: forward statistics and dAdj as two launches (the round-2 form; A/B runs)
+bool flash_fused() {
+    const char* e = getenv("MARIUS_FLASH_FUSED");
+    return !(e && e[0] == '0');
+}
 
 static int g_flash_reserved_cus = 0;
 void flash_set_reserved_cus(int n) { g_flash_reserved_cus = n; }
@@ -597,6 +674,8 @@ static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, cha
     const int xt_rows = FL_XT;
     const int XRa = (D.Bc + 31) / 32 * 32, NRn = (D.N + 31) / 32 * 32;
     const bool xadj = (mode != FLASH_DNEG);
+    a.pos = nullptr;
+    a.out2 = nullptr;
     a.xrec = xadj ? adjrec : negrec;
     a.yrec = xadj ? negrec : adjrec;
     a.XR = xadj ? XRa : NRn;
@@ -626,8 +705,9 @@ static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, cha
 }
 
 // forward: pack both operands, row statistics (and, for parity tests only, the scores themselves)
+// pos / dadj / dadj2: fused form only (flash_fused()): the sweep also leaves the unnormalised dAdj partials
 int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj, char* adjrec, char* negrec, float2* part, float* S, bool adj_packed,
-                  float* gocc, const int64_t negocc_off[2], float* dadj_zero, hipStream_t st) {
+                  float* gocc, const int64_t negocc_off[2], float* dadj_zero, const float* pos, float* dadj, float* dadj2, hipStream_t st) {
     const int ks = fl_ks(D.d), KP = 16 * ks;
     const int XR = (D.Bc + 31) / 32 * 32, NR = (D.N + 31) / 32 * 32;
     const int ppr = KP / 4 + 1;
@@ -645,11 +725,22 @@ int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj,
     int rc = check_launch("flash_pack");
     if (rc) return rc;
     FlashArgs a;
-    fl_common(a, D, FLASH_FWD, adjrec, negrec);
+    if (!flash_fused() || S) {  // statistics-only sweep: the unfused form, and the score-storing parity runs (its statistics are then rewritten below)
+        fl_common(a, D, FLASH_FWD, adjrec, negrec);
+        a.part = part;
+        a.S = S;
+        ProfScope ps(PROF_LP_SCORES, st);
+        rc = S ? fl_dispatch<FLASH_FWD, true>(ks, a, st) : fl_dispatch<FLASH_FWD, false>(ks, a, st);
+        if (rc || !flash_fused()) return rc;
+    }
+    fl_common(a, D, FLASH_FDADJ, adjrec, negrec);
     a.part = part;
-    a.S = S;
-    ProfScope ps(PROF_LP_SCORES, st);
-    return S ? fl_dispatch<FLASH_FWD, true>(ks, a, st) : fl_dispatch<FLASH_FWD, false>(ks, a, st);
+    a.pos = pos;
+    a.out = dadj;
+    a.out2 = dadj2;
+    a.out_ld = D.d_ld;
+    ProfScope ps(PROF_LP_GRAD_ADJ, st);  // accounted as the dAdj launch: 2 contractions (scores + V Neg)
+    return fl_dispatch<FLASH_FDADJ, false>(ks, a, st);
 }
 
 int flash_merge(const LpDims& D, const float2* part, const float* pos, float* lse, float* rowloss, float* dpos, float* blocksum, char* adjrec,
@@ -666,11 +757,11 @@ int flash_merge(const LpDims& D, const float2* part, const float* pos, float* ls
 int flash_backward(const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2], hipStream_t st) {
     const int ks = fl_ks(D.d);
     FlashArgs a;
-    fl_common(a, D, FLASH_DADJ, adjrec, negrec);
-    a.out = dadj;
-    a.out_ld = D.d_ld;
-    int rc;
-    {
+    int rc = MARIUS_OK;
+    if (!flash_fused()) {  // fused form: dAdj left the forward sweep as partials (flash_forward)
+        fl_common(a, D, FLASH_DADJ, adjrec, negrec);
+        a.out = dadj;
+        a.out_ld = D.d_ld;
         ProfScope ps(PROF_LP_GRAD_ADJ, st);
         rc = fl_dispatch<FLASH_DADJ, false>(ks, a, st);
     }

@@ -16,9 +16,9 @@ OP_HADAMARD, OP_COMPLEX_HADAMARD, OP_TRANSLATION, OP_NOOP = 0, 1, 2, 3
 CMP_DOT, CMP_L2, CMP_COSINE = 0, 1, 2
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 LOSS = {"SOFTMAX_CE": 0, "RANKING": 1, "CROSS_ENTROPY": 2, "BCE_AFTER_SIGMOID": 3, "BCE_WITH_LOGITS": 4, "MSE": 5, "SOFTPLUS": 6}
-LP_TRAIN_ONLY, LP_STORE_SCORES = 1, 2   # marius_lp_desc.flags
+LP_TRAIN_ONLY, LP_STORE_SCORES, LP_KEEP_DADJ = 1, 2, 4   # marius_lp_desc.flags
 MT_STATE_WORDS = 625
-ABI_VERSION = 3  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
+ABI_VERSION = 4  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
 
 
 class MariusHipError(RuntimeError):
@@ -311,7 +311,8 @@ class LpWorkspace:
 
     def __init__(self, relop, cmp, d, B, C_, N, use_inverse, reduction, edge_cols, has_src_neg, device, loss=0, margin=0.0, flags=0):
         self.desc = LpDesc()
-        self.desc.loss, self.desc.margin, self.desc.flags = loss, margin, flags
+        # this class serves tests and tools, which read dadj() back: ask the flash path to leave dL/dadj there (the C++ trainer does not)
+        self.desc.loss, self.desc.margin, self.desc.flags = loss, margin, (flags | LP_KEEP_DADJ) if (flags & LP_TRAIN_ONLY) else flags
         self.desc.relop, self.desc.cmp, self.desc.d, self.desc.edge_cols = relop, cmp, d, edge_cols
         self.desc.B, self.desc.C, self.desc.N = B, C_, N
         self.desc.use_inverse, self.desc.reduction = int(use_inverse), reduction

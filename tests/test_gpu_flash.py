@@ -158,6 +158,39 @@ def test_flash_forward_loss_backward_match_oracle(H, dev, decoder, use_inverse, 
     check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv if use_inverse else None, U, R)
 
 
+@pytest.mark.parametrize("scale,B,C,N,d", [(1.0, 700, 3, 1000, 100), (0.75, 260, 2, 300, 64), (0.05, 300, 3, 200, 100)])
+def test_flash_online_softmax_reference_moves(H, dev, scale, B, C, N, d):
+    """The fused sweep (FLASH_FDADJ) exponentiates against a per-row reference that starts at the positive score and is raised — with the
+    row's accumulators rescaled — whenever a block's maximum exceeds it by more than 2^8.  Large embeddings (score spread of tens of units,
+    sharply peaked softmax) make that happen on most rows, repeatedly, and at different times in a split tile's two contributors; tiny
+    embeddings never trigger it.  lse, loss and every gradient against the oracle either way.  (Scores of +-200 — scale 1.5 at d = 64 — leave
+    the 1e-4 gradient tolerance in ANY 16-bit-significand contraction: V = exp(S - lse) multiplies the score error; measured 1.6e-4.)"""
+    decoder, U, R = "COMPLEX", 900, 7
+    emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=17, scale=scale)
+    want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv)
+    W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, store=False)
+    spread = (want["neg"].max(1)[0] - want["pos"]).max().item()
+    print("largest (max negative - positive) over the rows: %.1f" % spread)
+    assert (spread > 8.0) if scale >= 0.5 else (spread < 5.0)   # a raise needs a block maximum more than 8 / log2(e) = 5.5 above the reference
+    mixed_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss")
+    mixed_close(W.lse(0), torch.logsumexp(torch.cat([want["pos"][:, None], want["neg"]], 1), 1), "lse")
+    mixed_close(W.lse(1), torch.logsumexp(torch.cat([want["inv_pos"][:, None], want["inv_neg"]], 1), 1), "inv lse")
+    check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv, U, R)
+
+
+@pytest.mark.parametrize("B,C,N,d", [(1000, 10, 500, 100), (300, 4, 260, 128)])
+def test_flash_unfused_form_still_matches_oracle(H, dev, monkeypatch, B, C, N, d):
+    """MARIUS_FLASH_FUSED=0: statistics sweep + dAdj launch + dNeg launch (the round-2 form, kept for A/B runs)."""
+    monkeypatch.setenv("MARIUS_FLASH_FUSED", "0")
+    decoder, U, R = "COMPLEX", max(40, B), 11
+    emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=B + d)
+    want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv)
+    W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True)
+    mixed_close(W.neg(0), want["neg"], "neg (split scores)")
+    mixed_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss")
+    check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv, U, R)
+
+
 @pytest.mark.parametrize("decoder,B,C,N,d", [("COMPLEX", 4096, 4, 1000, 100), ("DISTMULT", 1000, 10, 500, 128), ("COMPLEX", 300, 3, 200, 64),
                                              ("COMPLEX", 50000, 50, 1000, 100)])  # the last one: the bench shape (10^8 score entries, every one checked)
 def test_flash_scores_obey_the_split_error_bound(H, dev, decoder, B, C, N, d):
