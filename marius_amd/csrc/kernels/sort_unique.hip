@@ -70,7 +70,8 @@ struct RunOffsets {
 // zero_uniq / zero_state (optional): what the emit launch that follows expects to find zero (uniq[] tail, head-count granules)
 __global__ __launch_bounds__(256) void merge_rank_kernel(const int64_t* __restrict__ ids, int64_t n, RunOffsets ro, int nruns, uint64_t* __restrict__ keys,
                                                          int32_t* __restrict__ perm, int64_t* __restrict__ zero_uniq, uint32_t* __restrict__ zero_state,
-                                                         int64_t nstate) {
+                                                         int64_t nstate, uint32_t* __restrict__ zero_ctr) {
+    if (zero_ctr && blockIdx.x == 0 && threadIdx.x == 0) *zero_ctr = 0u;  // the tile counter the emit launch that follows draws from
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (zero_uniq) zero_uniq[i] = 0;
         if (zero_state && i < nstate) zero_state[i] = 0u;
@@ -121,7 +122,8 @@ constexpr int RS_MAX_TILES = 512;  // every block reads the counts of the tiles 
 constexpr int EM_ITEMS = 4, EM_TILE = RS_THREADS * EM_ITEMS;  // rs_emit_kernel: small tiles, the whole chip
 constexpr uint32_t RS_FLAG = 0x80000000u;
 
-// Control block at offset 0 of the workspace (zero when the workspace is first used; every call leaves it zero again):
+// Control block at offset 0 of the workspace (zero when the workspace is first used; every call leaves `ready` and ctr[0] zero again and
+// zeroes the other counters itself before its later launches draw from them):
 //   ready   the ticket hand-shake of rs_ghist_kernel
 //   ctr[k]  tile counter of the k-th launch of a call.  A workgroup's tile is the value it draws from the counter, not blockIdx: a tile
 //           then only ever waits for tiles whose workgroups have already started (HIP promises no dispatch order between workgroups, and
@@ -293,9 +295,9 @@ __global__ __launch_bounds__(RS_THREADS) void rs_emit_kernel(const uint64_t* __r
                                                              int32_t* __restrict__ seg_offsets, int64_t* __restrict__ num_unique, SortCtl* __restrict__ ctl, int my_ctr) {
     __shared__ int32_t red[RS_WAVES], wsum[RS_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = rs_draw_tile(&ctl->ctr[my_ctr]);
-    if (tile == 0 && tid == 0) {  // last launch of a call: the control block returns to zero (a replay of a captured call waits and counts again);
-        ctl->ready = 0ull;        // this launch's own counter is still being drawn from: the last workgroup to finish clears it (below)
-        ctl->ctr[0] = 0u;
+    if (tile == 0 && tid == 0) {  // last launch of a call: hand-shake word and the first launch's counter return to zero (a replay of a captured
+        ctl->ready = 0ull;        // call waits and counts again).  This launch's own counter, like those of the sweeps, is zeroed by the FIRST launch
+        ctl->ctr[0] = 0u;         // of the next call that uses the workspace (rs_ghist_kernel / merge_rank_kernel), before anything draws from it.
     }
     // thread t owns EM_ITEMS consecutive positions: local head count, block scan of the thread sums
     const int64_t k0 = (int64_t)tile * EM_TILE + (int64_t)tid * EM_ITEMS;
@@ -357,12 +359,6 @@ __global__ __launch_bounds__(RS_THREADS) void rs_emit_kernel(const uint64_t* __r
                 *num_unique = (int64_t)u + 1;
             }
         }
-    }
-    // the workgroup that finishes last puts this launch's two counters back to zero (ctr[7] counts finished workgroups)
-    __syncthreads();
-    if (tid == 0 && atomicAdd(&ctl->ctr[7], 1u) + 1u == gridDim.x) {
-        ctl->ctr[7] = 0u;
-        ctl->ctr[my_ctr] = 0u;
     }
 }
 
@@ -526,7 +522,7 @@ extern "C" int marius_merge_unique_runs(const int64_t* ids, int64_t n, const int
         const int64_t etiles = cdiv(n, EM_TILE);
         if (n <= (int64_t)RS_MAX_TILES * RS_TILE && (size_t)(etiles + 4) * 4 <= p.temp_bytes && !(lib && lib[0] == 'r')) {
             uint32_t* tile_state = (uint32_t*)(ws + p.temp_off);
-            merge_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(ids, n, ro, num_runs, keys, perm, uniq, tile_state, etiles);
+            merge_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(ids, n, ro, num_runs, keys, perm, uniq, tile_state, etiles, &((SortCtl*)ws)->ctr[1]);
             rs_emit_kernel<<<dim3((unsigned)etiles), dim3(RS_THREADS), 0, st>>>(keys, perm, n, tile_state, uniq, inverse, seg_offsets, num_unique_dev, (SortCtl*)ws, 1);
             return check_launch("merge_unique_runs");
         }
@@ -535,7 +531,7 @@ extern "C" int marius_merge_unique_runs(const int64_t* ids, int64_t n, const int
         set_last_error("merge_unique_runs: memset failed");
         return MARIUS_ERR_HIP;
     }
-    merge_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(ids, n, ro, num_runs, keys, perm, nullptr, nullptr, 0);
+    merge_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(ids, n, ro, num_runs, keys, perm, nullptr, nullptr, 0, nullptr);
     head_flags_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const int64_t*)keys, n, flags);
     size_t tmp_bytes = p.temp_bytes;
     hipError_t e = rocprim::inclusive_scan(ws + p.temp_off, tmp_bytes, flags, scan, (size_t)n, rocprim::plus<int32_t>(), st);
