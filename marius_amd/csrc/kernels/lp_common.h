@@ -207,6 +207,7 @@ int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj,
 int flash_merge(const LpDims& D, const float2* part, const float* pos, float* lse, float* rowloss, float* dpos, float* blocksum, char* adjrec,
                 hipStream_t st);
 void flash_set_reserved_cus(int n);
-int flash_backward(const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2], hipStream_t st);
+int flash_backward(const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2], const float2* part, bool filtered,
+                   hipStream_t st);
 
 }  // namespace marius

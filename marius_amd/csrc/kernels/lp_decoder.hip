@@ -1492,7 +1492,8 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
         const bool split = sp && sp[0] == '1';
         bool done = false;
         if (L->flash) {
-            rc = flash_backward(D, ws + L->adjrec, ws + L->negrec, ga.dadj, ga.gocc, ga.negocc_off, st);
+            const bool filtered = (desc->dst_filter && desc->n_dst_filter > 0) || (D.ndir == 2 && desc->src_filter && desc->n_src_filter > 0);
+            rc = flash_backward(D, ws + L->adjrec, ws + L->negrec, ga.dadj, ga.gocc, ga.negocc_off, (const float2*)(ws + L->fpart), filtered, st);
             if (rc) return rc;
             done = true;
         }

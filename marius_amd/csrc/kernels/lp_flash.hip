@@ -93,6 +93,11 @@ struct FlashArgs {
     // FDADJ: positive scores [ndir Bp] (initial reference of the online softmax); out = partial of a tile's first contributor, out2 = of its second
     const float* pos;
     float* out2;
+    // score filter (apply_score_filter, negative.cpp:306-311: listed (row, column) scores count as -1e9): entries bucketed by item,
+    // foff[item] .. foff[item + 1] into fent; an entry = (stationary row inside the 128-row tile) << 5 | (streamed row inside the block).
+    // nullptr: no filter.
+    const uint32_t* foff;
+    const uint16_t* fent;
 };
 
 // zero up to three float ranges (lengths are multiples of 4, bases 16-B aligned) in one launch
@@ -181,6 +186,73 @@ __global__ __launch_bounds__(256) void flash_pack_neg_kernel(const float* __rest
         if (4 * piece < d_ld) *reinterpret_cast<float4*>(gocc + ((dir ? off1 : off0) + c * N + j) * d_ld + 4 * piece) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     fl_write_piece(o, KP, piece, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- score filter index
+// One workgroup per orientation (0: adj rows stationary — the forward + dAdj sweep; 1: negatives stationary — dNeg) buckets the filter
+// entries (row in [0, B), column in [0, N)) of both directions by the item that holds their score: counts, exclusive scan and scatter all in
+// LDS.  The order of the entries inside an item is whatever the atomics give: masking is idempotent, results do not depend on it.
+__global__ __launch_bounds__(1024) void flash_filter_index_kernel(const int64_t* __restrict__ f0, int64_t n0, const int64_t* __restrict__ f1, int64_t n1,
+                                                                  int Bc, int C, int ndir, int XTa, int YBa, int XTn, int YBn, int nkeys_max,
+                                                                  uint32_t* __restrict__ foff, uint16_t* __restrict__ fent, int64_t ent_cap) {
+    extern __shared__ uint32_t cnt[];  // [nkeys + 1]
+    __shared__ uint32_t wsum[16];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const int XT = o == 0 ? XTa : XTn, YB = o == 0 ? YBa : YBn;
+    const int nkeys = ndir * C * XT * YB;
+    uint32_t* off_out = foff + (size_t)o * (nkeys_max + 1);
+    uint16_t* ent_out = fent + (size_t)o * ent_cap;
+    for (int k = tid; k <= nkeys; k += 1024) cnt[k] = 0u;
+    __syncthreads();
+    auto key_of = [&](int dir, int64_t row, int64_t col, int& ent) {
+        const int c = (int)(row / Bc), x = (int)(row - (int64_t)c * Bc);
+        const int cd = dir * C + c;
+        if (o == 0) {
+            ent = ((x & 127) << 5) | (int)(col & 31);
+            return (cd * XT + (x >> 7)) * YB + (int)(col >> 5);
+        }
+        ent = (((int)col & 127) << 5) | (x & 31);
+        return (cd * XT + (int)(col >> 7)) * YB + (x >> 5);
+    };
+    const int64_t n = n0 + n1;
+    for (int64_t i = tid; i < n; i += 1024) {
+        const int dir = i < n0 ? 0 : 1;
+        const int64_t* e = dir == 0 ? f0 + 2 * i : f1 + 2 * (i - n0);
+        int ent;
+        atomicAdd(&cnt[key_of(dir, e[0], e[1], ent)], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0 .. nkeys]: thread t owns a contiguous slice
+    const int per = (nkeys + 1 + 1023) / 1024;
+    const int lo = tid * per, hi = min(lo + per, nkeys + 1);
+    uint32_t s_ = 0;
+    for (int k = lo; k < hi; ++k) s_ += cnt[k];
+    uint32_t x_ = s_;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int d_ = 1; d_ < 64; d_ <<= 1) {
+        const uint32_t y_ = __shfl_up(x_, d_, 64);
+        if (lane >= d_) x_ += y_;
+    }
+    if (lane == 63) wsum[wave] = x_;
+    __syncthreads();
+    uint32_t base = x_ - s_;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    for (int k = lo; k < hi; ++k) {
+        const uint32_t c_ = cnt[k];
+        cnt[k] = base;
+        off_out[k] = base;
+        base += c_;
+    }
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += 1024) {
+        const int dir = i < n0 ? 0 : 1;
+        const int64_t* e = dir == 0 ? f0 + 2 * i : f1 + 2 * (i - n0);
+        int ent;
+        const int k = key_of(dir, e[0], e[1], ent);
+        const uint32_t slot = atomicAdd(&cnt[k], 1u);
+        if ((int64_t)slot < ent_cap) ent_out[slot] = (uint16_t)ent;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- the kernel
@@ -462,6 +534,12 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
         padvance();
         pslot = pslot + 1 == NSLOT ? 0 : pslot + 1;
         const unsigned char* T = smem + slot * SLOT;
+        uint32_t fo0 = 0u, fo1 = 0u;  // filter entries of this item (loaded ahead of the matrix phase that hides the latency)
+        if (MODE != FLASH_FWD && a.foff) {
+            const int64_t key = ((int64_t)cd * a.XT + xt) * a.YB + yph;
+            fo0 = a.foff[key];
+            fo1 = a.foff[key + 1];
+        }
 
         // ---- S tile: D[y][x] = sum_k Y[y][k] X[x][k]
         const v16f accS = fl_score_tile<KS>(T, a_off, xh, xl);
@@ -504,6 +582,17 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
             float t[16];
 #pragma unroll
             for (int r_ = 0; r_ < 16; ++r_) t[r_] = accS[r_];
+            if (fo1 != fo0) {  // filtered scores of this item: the reference overwrites them with -1e9 before the loss
+                for (uint32_t q = fo0; q < fo1; ++q) {
+                    const int ent = a.fent[q];
+                    const int xl = ent >> 5, yl = ent & 31;
+                    const bool mine = (wave == (xl >> 5)) && (l31 == (xl & 31)) && (h == ((yl >> 3) & 1));
+                    const int reg = 8 * (yl >> 4) + (yl & 7);
+#pragma unroll
+                    for (int r_ = 0; r_ < 16; ++r_)
+                        if (mine && r_ == reg) t[r_] = -1e9f;
+                }
+            }
             if (MODE == FLASH_FDADJ) {
                 // streamed rows past N do not exist: they must not enter sum V (their records are zero rows: S = 0, not -inf)
                 if ((yph + 1) * FL_YB > a.Yrows) {
@@ -600,12 +689,41 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(const float2* __restri
 // ---------------------------------------------------------------------------------------------------------------- host side
 static int fl_ks(int d) { return (d + 15) / 16; }
 
+// score-filter index (flash_filter_index_kernel): item counts of the two orientations, entry capacity, bytes behind the statistics in `fpart`
+struct FlFilterDims {
+    int XTa, YBa, XTn, YBn, nkeys_max;
+    int64_t ent_cap;
+    size_t off_bytes, bytes;
+};
+static FlFilterDims fl_filter_dims(const LpDims& D) {
+    FlFilterDims f;
+    const int XRa = (D.Bc + 31) / 32 * 32, NRn = (D.N + 31) / 32 * 32;
+    f.XTa = (D.Bc + FL_XT - 1) / FL_XT;
+    f.YBa = NRn / FL_YB;
+    f.XTn = (D.N + FL_XT - 1) / FL_XT;
+    f.YBn = XRa / FL_YB;
+    const int64_t ka = (int64_t)D.ndir * D.C * f.XTa * f.YBa, kn = (int64_t)D.ndir * D.C * f.XTn * f.YBn;
+    f.nkeys_max = (int)(ka > kn ? ka : kn);
+    f.ent_cap = (int64_t)D.ndir * D.C * D.N;  // a DEG filter has at most one entry per (direction, chunk, negative column) (negative.cpp:21-39)
+    f.off_bytes = ((size_t)2 * (f.nkeys_max + 1) * 4 + 255) / 256 * 256;
+    f.bytes = f.off_bytes + ((size_t)2 * f.ent_cap * 2 + 255) / 256 * 256;
+    return f;
+}
+constexpr size_t FL_FILTER_LDS_MAX = 150 * 1024;
+
 bool flash_applicable(const marius_lp_desc* desc, const LpDims& D) {
     const char* e = getenv("MARIUS_FLASH");
     if (e && e[0] == '0') return false;
     if (!(desc->flags & MARIUS_LP_TRAIN_ONLY) && !(e && e[0] == 'f')) return false;  // MARIUS_FLASH=f: force (tests of the API path's numbers)
     if (D.loss != MARIUS_LOSS_SOFTMAX_CE || D.cmp != MARIUS_CMP_DOT) return false;
-    if ((desc->dst_filter && desc->n_dst_filter > 0) || (desc->src_filter && desc->n_src_filter > 0)) return false;
+    if ((desc->dst_filter && desc->n_dst_filter > 0) || (desc->src_filter && desc->n_src_filter > 0)) {
+        // score filters (training: the DEG filter of degree-based negatives) are honoured by the fused sweep and dNeg through a per-item index;
+        // not by the round-2 three-launch form, not together with stored scores, and only for lists a DEG filter can produce
+        const FlFilterDims f = fl_filter_dims(D);
+        if (!flash_fused() || (desc->flags & MARIUS_LP_STORE_SCORES) || (size_t)(f.nkeys_max + 1) * 4 > FL_FILTER_LDS_MAX ||
+            desc->n_dst_filter + desc->n_src_filter > f.ent_cap)
+            return false;
+    }
     const int ks = fl_ks(D.d);
     if (ks < 2 || ks > 8) return false;  // instantiated K depths: d in (16, 128]
     if (D.ndir == 2 && !desc->src_neg) return false;
@@ -614,7 +732,9 @@ bool flash_applicable(const marius_lp_desc* desc, const LpDims& D) {
 
 size_t flash_adjrec_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.Bc + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)) + 32768; }
 size_t flash_negrec_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.N + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)) + 32768; }
-size_t flash_part_bytes(const LpDims& D) { return (size_t)2 * D.ndir * D.Bp * sizeof(float2); }
+static size_t fl_stats_bytes(const LpDims& D) { return ((size_t)2 * D.ndir * D.Bp * sizeof(float2) + 255) / 256 * 256; }
+// [statistics | filter index (offsets of both orientations, entries of both orientations)]
+size_t flash_part_bytes(const LpDims& D) { return fl_stats_bytes(D) + fl_filter_dims(D).bytes; }
 // MARIUS_FLASH_FUSED=0: forward statistics and dAdj as two launches (the round-2 form; A/B runs)
 bool flash_fused() {
     const char* e = getenv("MARIUS_FLASH_FUSED");
@@ -676,6 +796,8 @@ static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, cha
     const bool xadj = (mode != FLASH_DNEG);
     a.pos = nullptr;
     a.out2 = nullptr;
+    a.foff = nullptr;
+    a.fent = nullptr;
     a.xrec = xadj ? adjrec : negrec;
     a.yrec = xadj ? negrec : adjrec;
     a.XR = xadj ? XRa : NRn;
@@ -739,6 +861,29 @@ int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj,
     a.out = dadj;
     a.out2 = dadj2;
     a.out_ld = D.d_ld;
+    const int64_t nf0 = desc->dst_filter ? desc->n_dst_filter : 0, nf1 = (D.ndir == 2 && desc->src_filter) ? desc->n_src_filter : 0;
+    if (nf0 + nf1 > 0) {
+        const FlFilterDims f = fl_filter_dims(D);
+        MARIUS_REQUIRE(nf0 + nf1 <= f.ent_cap, "flash: the score filter has %ld entries, more than a DEG filter of this batch shape can (%ld)", (long)(nf0 + nf1), (long)f.ent_cap);
+        char* fbase = (char*)part + fl_stats_bytes(D);
+        uint32_t* foff = (uint32_t*)fbase;
+        uint16_t* fent = (uint16_t*)(fbase + f.off_bytes);
+        const size_t lds = (size_t)(f.nkeys_max + 1) * 4;
+        static bool fattr = false;
+        if (!fattr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_filter_index_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL_FILTER_LDS_MAX) != hipSuccess) {
+                set_last_error("flash: cannot raise the dynamic LDS limit of the filter index kernel");
+                return MARIUS_ERR_HIP;
+            }
+            fattr = true;
+        }
+        flash_filter_index_kernel<<<dim3(2), dim3(1024), lds, st>>>(desc->dst_filter, nf0, desc->src_filter, nf1, D.Bc, D.C, D.ndir, f.XTa, f.YBa, f.XTn, f.YBn,
+                                                                   f.nkeys_max, foff, fent, f.ent_cap);
+        rc = check_launch("flash_filter_index");
+        if (rc) return rc;
+        a.foff = foff;
+        a.fent = fent;
+    }
     ProfScope ps(PROF_LP_GRAD_ADJ, st);  // accounted as the dAdj launch: 2 contractions (scores + V Neg)
     return fl_dispatch<FLASH_FDADJ, false>(ks, a, st);
 }
@@ -754,7 +899,9 @@ int flash_merge(const LpDims& D, const float2* part, const float* pos, float* ls
 
 // backward contractions: dadj [ndir][Bp][d_ld] and the negatives' gocc rows.  Both outputs are zeroed first (split tiles accumulate).
 // dadj and the negatives' gocc rows were zeroed by the forward's pack kernels (split tiles accumulate onto them)
-int flash_backward(const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2], hipStream_t st) {
+// part / filtered: fused form with a score filter — the index the forward built (orientation 1) sits behind the statistics
+int flash_backward(const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2], const float2* part, bool filtered,
+                   hipStream_t st) {
     const int ks = fl_ks(D.d);
     FlashArgs a;
     int rc = MARIUS_OK;
@@ -771,6 +918,12 @@ int flash_backward(const LpDims& D, char* adjrec, char* negrec, float* dadj, flo
     a.out_ld = D.d_ld;
     a.negocc_off[0] = negocc_off[0];
     a.negocc_off[1] = negocc_off[1];
+    if (filtered && part) {
+        const FlFilterDims f = fl_filter_dims(D);
+        const char* fbase = (const char*)part + fl_stats_bytes(D);
+        a.foff = (const uint32_t*)fbase + (f.nkeys_max + 1);
+        a.fent = (const uint16_t*)(fbase + f.off_bytes) + f.ent_cap;
+    }
     {
         ProfScope ps(PROF_LP_GRAD_NEG, st);
         rc = fl_dispatch<FLASH_DNEG, false>(ks, a, st);

@@ -45,14 +45,14 @@ def make_batch(decoder, B, C, N, d, U, R, seed, scale=0.5, zipf=False):
     return emb, edges, dst_neg, src_neg, rel_t, inv_t
 
 
-def run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, store=True, reduction="sum"):
+def run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, store=True, reduction="sum", dst_filter=None, src_filter=None):
     relop, cmp = DEC[decoder]
     B, (C, N), d = edges.size(0), dst_neg.shape, emb.size(1)
     flags = H.LP_TRAIN_ONLY | (H.LP_STORE_SCORES if store else 0)
     W = H.LpWorkspace(relop, cmp, d, B, C, N, use_inverse, H.REDUCE_SUM if reduction == "sum" else H.REDUCE_MEAN, 3, True, dev, flags=flags)
     assert W.layout.flash == 1, "the flash path was not selected"
     t = lambda x: None if x is None else x.to(dev)
-    W.bind(t(emb), t(edges), t(dst_neg), t(src_neg), t(rel), t(inv) if use_inverse else None)
+    W.bind(t(emb), t(edges), t(dst_neg), t(src_neg), t(rel), t(inv) if use_inverse else None, t(dst_filter), t(src_filter))
     W.forward()
     W.loss()
     W.backward()
@@ -94,7 +94,7 @@ def node_grad_of(W, edges, src_neg, dst_neg, U, d):
     return torch.zeros(U, d, dtype=torch.float64).index_add_(0, occ_ids, W.gocc()[:, :d].cpu().double())
 
 
-def occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction="sum", dtype=torch.float64):
+def occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction="sum", dtype=torch.float64, dst_filter=None, src_filter=None):
     """The oracle with every occurrence (src, dst, src negatives, dst negatives: map_tensors order, util.cpp:180-205) as its own
     leaf row: its node gradient is the per-occurrence gradient the kernels write to `gocc`, before the segmented sum.  Comparing
     there is the well-conditioned check: a node that is an endpoint AND its own negative gets +g and -g, and the sum cancels to
@@ -106,14 +106,14 @@ def occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction
     sn2 = (torch.arange(C * N) + 2 * B).reshape(C, N)
     dn2 = (torch.arange(C * N) + 2 * B + C * N).reshape(C, N)
     cv = lambda t: None if t is None else t.to(dtype)
-    w = O.train_batch(decoder, emb[occ_ids].to(dtype), torch.zeros(L, d, dtype=dtype), e2, dn2, sn2, cv(rel), cv(inv), reduction=reduction)
+    w = O.train_batch(decoder, emb[occ_ids].to(dtype), torch.zeros(L, d, dtype=dtype), e2, dn2, sn2, cv(rel), cv(inv), dst_filter, src_filter, reduction=reduction)
     return w, occ_ids
 
 
-def check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv, U, R, reduction="sum"):
+def check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv, U, R, reduction="sum", dst_filter=None, src_filter=None):
     d = emb.size(1)
-    w64, occ_ids = occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction)
-    w32, _ = occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction, dtype=torch.float32)
+    w64, occ_ids = occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction, dst_filter=dst_filter, src_filter=src_filter)
+    w32, _ = occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction, dtype=torch.float32, dst_filter=dst_filter, src_filter=src_filter)
     g = W.gocc()[:, :d].cpu().double()
     if inv is None:  # src negatives take part in the unique map but get no gradient in a single-direction decoder
         B, CN = edges.size(0), dst_neg.numel()
@@ -176,6 +176,34 @@ def test_flash_online_softmax_reference_moves(H, dev, scale, B, C, N, d):
     mixed_close(W.lse(0), torch.logsumexp(torch.cat([want["pos"][:, None], want["neg"]], 1), 1), "lse")
     mixed_close(W.lse(1), torch.logsumexp(torch.cat([want["inv_pos"][:, None], want["inv_neg"]], 1), 1), "inv lse")
     check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv, U, R)
+
+
+@pytest.mark.parametrize("use_inverse", [True, False])
+@pytest.mark.parametrize("B,C,N,d,F", [(1000, 10, 500, 100, 400), (700, 3, 1000, 64, 3000), (5, 4, 6, 100, 3), (4096, 4, 1000, 100, 4000)])
+def test_flash_score_filter_matches_oracle(H, dev, use_inverse, B, C, N, d, F):
+    """apply_score_filter (negative.cpp:306-311; in training the DEG filter of degree-based negatives, :21-39) on the flash path: listed
+    (row, column) scores count as -1e9 in the loss, i.e. leave the softmax and get no gradient — in the fused sweep and in dNeg, through the
+    per-item index flash_filter_index_kernel builds each step.  Random lists: several entries per item, items without any, up to C N entries
+    per direction (the most a DEG filter can have: one per chunk and degree-sampled column — the capacity the index is planned for), both
+    directions; loss, lse and every gradient against the oracle."""
+    decoder, U, R = "COMPLEX", max(40, B), 11
+    emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=B + F)
+    g = torch.Generator().manual_seed(F)
+
+    def mk():
+        flat = torch.randperm(B * N, generator=g)[:F]
+        return torch.stack([flat // N, flat % N], 1)
+
+    dst_filter, src_filter = mk(), mk()
+    inv_u = inv if use_inverse else None
+    want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv_u, dst_filter, src_filter if use_inverse else None)
+    W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, store=False, dst_filter=dst_filter, src_filter=src_filter if use_inverse else None)
+    assert float((want["neg"] == -1e9).sum()) == F
+    mixed_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss")
+    mixed_close(W.lse(0), torch.logsumexp(torch.cat([want["pos"][:, None], want["neg"]], 1), 1), "lse")
+    if use_inverse:
+        mixed_close(W.lse(1), torch.logsumexp(torch.cat([want["inv_pos"][:, None], want["inv_neg"]], 1), 1), "inv lse")
+    check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv_u, U, R, dst_filter=dst_filter, src_filter=src_filter if use_inverse else None)
 
 
 @pytest.mark.parametrize("B,C,N,d", [(1000, 10, 500, 100), (300, 4, 260, 128)])
@@ -266,7 +294,7 @@ def test_flash_mean_reduction(H, dev):
 
 
 def test_flash_not_selected_outside_its_domain(H, dev):
-    """TransE (L2), other losses, filters and unsupported d keep the materialised-score kernels even with TRAIN_ONLY set."""
+    """TransE (L2), other losses and unsupported d keep the materialised-score kernels even with TRAIN_ONLY set."""
     mk = lambda **kw: H.LpWorkspace(kw.get("relop", 0), kw.get("cmp", 0), kw.get("d", 100), 64, 4, 32, True, H.REDUCE_SUM, 3, True, dev,
                                     loss=kw.get("loss", 0), flags=H.LP_TRAIN_ONLY)
     assert mk().layout.flash == 1

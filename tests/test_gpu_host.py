@@ -121,7 +121,8 @@ def _setup(M, dev, decoder, num_nodes, R, d, B, C, N, E, seed, f=0.0):
 
 
 @pytest.mark.parametrize("decoder,f,fused,d", [("COMPLEX", 0.0, True, 20), ("COMPLEX", 0.0, False, 20), ("DISTMULT", 0.5, True, 20), ("TRANSE", 0.0, False, 20),
-                                               ("COMPLEX", 0.0, True, 100), ("DISTMULT", 0.0, False, 64)])  # the last two: the flash training path
+                                               ("COMPLEX", 0.0, True, 100), ("DISTMULT", 0.0, False, 64),    # these two: the flash training path
+                                               ("COMPLEX", 0.5, True, 100)])                                 # flash path with the DEG score filter
 def test_trainer_epoch_matches_cpu_reference_path(M, dev, decoder, f, fused, d):
     num_nodes, R, B, C, N, E, seed = 4000, 11, 250, 5, 40, 1000, 123
     table, edges_all, emb, state, loader, model = _setup(M, dev, decoder, num_nodes, R, d, B, C, N, E, seed, f)
