@@ -223,6 +223,8 @@ def main():
     ap.add_argument("--no-fp32-pass", action="store_true", help="skip the short MARIUS_FLASH=0 pass that reports the fp32-exact step time beside the headline number")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--strong", action="store_true", help="N > 1: strong scaling (the global batch stays B; default is weak scaling, B per GPU)")
+    ap.add_argument("--degree-fraction", type=float, default=0.0, help="fraction of every chunk's negatives drawn from the batch's own endpoints (the headline "
+                    "metric is quoted on 0; SURVEY 8 names 0.5 as the secondary configuration: the DEG score filter is then live), C++ driver only")
     ap.add_argument("--loss", default="SOFTMAX_CE", help="model.loss.type (the headline metric is quoted on SOFTMAX_CE; others for exploration, C++ driver only)")
     a = ap.parse_args()
 
@@ -278,7 +280,7 @@ def main():
         import marius_amd
         M = marius_amd.host()
         gen = M.MariusGenerator(42)
-        sampler = M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen)
+        sampler = M.CorruptNodeNegativeSampler(C, N, a.degree_fraction, False, M.LocalFilterMode.DEG, gen)
         loader = M.DataLoader(M.InMemory(edges_all), M.InMemory(table), M.InMemory(state), sampler, gen, B, True)
         dec = {"DISTMULT": M.DistMult, "COMPLEX": M.ComplEx, "TRANSE": M.TransE}[cfg["decoder"]](R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
         model = M.Model(dec, M.getLossFunction(a.loss.upper(), "sum", 0.1), M.LinkPredictionReporter(), dev)
@@ -343,6 +345,8 @@ def main():
     contraction_flops = 2.0 * Bp * N * d * ndir  # one [Bc x d] x [d x N] contraction per chunk and direction
     L = 2 * B + 2 * C * N
     flash = a.driver == "cpp" and a.loss.upper() == "SOFTMAX_CE" and flash_selected(H, cfg, B, C, N)
+    if a.driver == "cpp" and flash != bool(model.last_step_flash):
+        raise SystemExit("bench.py: the flash predicate (%s) and the path the trainer took (%s) disagree" % (flash, model.last_step_flash))
     # MFMA work per launch.  FP32-MFMA kernels: the fp32 flops of the contraction(s).  Flash kernels: the bf16 flops the split scheme
     # needs for them — 3 bf16 products per fp32 product, and the two backward launches recompute the score tile before their
     # gradient contraction (2 contractions each) — priced against the dense BF16 matrix peak.
@@ -444,8 +448,8 @@ def main():
         "metric": "edges/sec scored (pos+neg)", "value": round(scored_eps, 1), "unit": "scored edges/s",
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "host_issue_ms_per_step": round(host_issue / a.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32 (contractions: 2-way bf16 split x 3 products, f32 accumulate)" if flash else "f32", "data": "synthetic",
-        "config": {"workload": "%s %s d=%d in-memory, B=%d C=%d N=%d inverse_edges, SoftmaxCE SUM, Adagrad lr 0.1, %s edges" % (
-            a.workload, cfg["decoder"], d, B, C, N, a.edge_dist), "num_nodes": num_nodes, "num_relations": R, "num_edges": cfg["num_edges"],
+        "config": {"workload": "%s %s d=%d in-memory, B=%d C=%d N=%d%s inverse_edges, SoftmaxCE SUM, Adagrad lr 0.1, %s edges" % (
+            a.workload, cfg["decoder"], d, B, C, N, (" degree_fraction %.2f" % a.degree_fraction) if a.degree_fraction else "", a.edge_dist), "num_nodes": num_nodes, "num_relations": R, "num_edges": cfg["num_edges"],
             "parallelism": "single GPU", "host": "C++ SynchronousTrainer (libtorch)" if a.driver == "cpp" else "python ctypes driver"},
         "positive_edges_per_s": round(pos_eps, 1), "unique_rows_last_batch": U, "loss_last_batch": loss,
         "roofline": roofline, "fp32_exact": fp32_exact, "hbm_read_roofline_gather_score": gs, "kernels": kernels, "cpu_baseline": cpu,

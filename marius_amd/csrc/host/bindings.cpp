@@ -211,8 +211,7 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_readonly("embedding_size", &EdgeDecoder::embedding_size_)
         .def("apply_relation", &EdgeDecoder::apply_relation)
         .def("compute_scores", &EdgeDecoder::compute_scores)
-        .def("select_relations", &EdgeDecoder::select_relations, py::arg("indices"), py::arg("inverse") = false)
-        .def("reset", &EdgeDecoder::reset);
+        .def("select_relations", &EdgeDecoder::select_relations, py::arg("indices"), py::arg("inverse") = false);
     auto dec_init = [](auto tag) {
         using T = decltype(tag);
         return py::init([](int num_relations, int embedding_dim, torch::Device device, bool use_inverse_relations, EdgeDecoderMethod method) {
@@ -227,7 +226,14 @@ PYBIND11_MODULE(_marius_host, m) {
                                                use_inverse_relations, method);                                                                     \
              }),                                                                                                                                   \
              py::arg("num_relations"), py::arg("embedding_dim"), py::arg("device"), py::arg("use_inverse_relations") = true,                       \
-             py::arg("decoder_method") = EdgeDecoderMethod::CORRUPT_NODE)
+             py::arg("decoder_method") = EdgeDecoderMethod::CORRUPT_NODE)                                                                          \
+        .def("reset", [](NAME& self) { self.reset(); })                                                                                           \
+        .def("named_parameters", [](NAME& self) {                                                                                                  \
+            py::dict d;                                                                                                                            \
+            for (auto& kv : self.named_parameters()) d[py::str(kv.key())] = kv.value();                                                            \
+            return d;                                                                                                                              \
+        })                                                                                                                                         \
+        .def("clone", [](NAME& self) { return std::dynamic_pointer_cast<NAME>(self.clone()); })
     MARIUS_DECODER(DistMult);
     MARIUS_DECODER(ComplEx);
     MARIUS_DECODER(TransE);
@@ -297,7 +303,8 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_readwrite("weight_decay", &ModelConfig::weight_decay)
         .def_readwrite("amsgrad", &ModelConfig::amsgrad)
         .def_readwrite("sparse_lr", &ModelConfig::sparse_lr);
-    m.def("initModelFromConfig", &initModelFromConfig, py::arg("model_config"), py::arg("devices"), py::arg("num_relations"), py::arg("train"));
+    m.def("initModelFromConfig", static_cast<std::shared_ptr<Model> (*)(const ModelConfig&, std::vector<torch::Device>, int, bool)>(&initModelFromConfig),
+          py::arg("model_config"), py::arg("devices"), py::arg("num_relations"), py::arg("train"));
     py::class_<Model, PyModel, std::shared_ptr<Model>>(m, "Model", py::dynamic_attr())
         .def(py::init<std::shared_ptr<EdgeDecoder>, std::shared_ptr<LossFunction>, std::shared_ptr<LinkPredictionReporter>, torch::Device>(),
              py::arg("decoder"), py::arg("loss"), py::arg("reporter"), py::arg("device"))
@@ -316,7 +323,8 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("evaluate_batch", &Model::evaluate_batch)
         .def("save", &Model::save, py::arg("directory"))
         .def("load", &Model::load, py::arg("directory"), py::arg("train") = true)
-        .def("setup_optimizers", &Model::setup_optimizers, py::arg("dense_lr"))
+        .def("setup_optimizers", static_cast<void (Model::*)(float)>(&Model::setup_optimizers), py::arg("dense_lr"))
+        .def("setup_optimizers", [](Model& self, const ModelConfig& c) { self.setup_optimizers(std::make_shared<ModelConfig>(c)); }, py::arg("model_config"))
         .def("setup_optimizer", &Model::setup_optimizer, py::arg("type"), py::arg("lr"), py::arg("eps") = 1e-10f, py::arg("beta_1") = 0.9f,
              py::arg("beta_2") = 0.999f, py::arg("weight_decay") = 0.f, py::arg("amsgrad") = false)
         .def("step", &Model::step)

@@ -500,7 +500,7 @@ static Tensor relop_device(int kind, const Tensor& embs, const Tensor& rels) {
     require_device(embs, "RelationOperator");
     const int64_t B = embs.size(0);
     auto dev = embs.device();
-    struct D : EdgeDecoder { void reset() override {} };
+    struct D : EdgeDecoder {};
     auto dec = std::make_shared<D>();
     dec->comparator_ = std::make_shared<DotCompare>();
     dec->relations_ = rels.contiguous();
@@ -555,7 +555,7 @@ static Tensor compare_device(int kind, Tensor src, Tensor dst) {
     if (!src.defined() || !dst.defined()) throw UndefinedTensorException();  // comparators.cpp:23-25
     require_device(src, "Comparator");
     auto dev = src.device();
-    struct D : EdgeDecoder { void reset() override {} };
+    struct D : EdgeDecoder {};
     auto dec = std::make_shared<D>();
     dec->relation_operator_ = std::make_shared<NoOp>();
     struct Cmp : Comparator {
@@ -623,6 +623,7 @@ static void init_decoder(EdgeDecoder* d, int num_relations, int dim, torch::Tens
     d->tensor_options_ = opts;
     d->use_inverse_relations_ = inv;
     d->decoder_method_ = m;
+    d->learning_task_ = LearningTask::LINK_PREDICTION;
 }
 DistMult::DistMult(int num_relations, int embedding_dim, torch::TensorOptions o, bool inv, EdgeDecoderMethod m) {
     comparator_ = std::make_shared<DotCompare>();
@@ -631,8 +632,9 @@ DistMult::DistMult(int num_relations, int embedding_dim, torch::TensorOptions o,
     reset();
 }
 void DistMult::reset() {  // distmult.cpp:21-27
-    relations_ = torch::ones({num_relations_, embedding_size_}, tensor_options_);
-    if (use_inverse_relations_) inverse_relations_ = torch::ones({num_relations_, embedding_size_}, tensor_options_);
+    relations_ = register_parameter("relation_embeddings", torch::ones({num_relations_, embedding_size_}, tensor_options_), /*requires_grad=*/false);
+    if (use_inverse_relations_)
+        inverse_relations_ = register_parameter("inverse_relation_embeddings", torch::ones({num_relations_, embedding_size_}, tensor_options_), /*requires_grad=*/false);
 }
 ComplEx::ComplEx(int num_relations, int embedding_dim, torch::TensorOptions o, bool inv, EdgeDecoderMethod m) {
     comparator_ = std::make_shared<DotCompare>();
@@ -641,11 +643,13 @@ ComplEx::ComplEx(int num_relations, int embedding_dim, torch::TensorOptions o, b
     reset();
 }
 void ComplEx::reset() {  // complex.cpp:21-29
-    relations_ = torch::zeros({num_relations_, embedding_size_}, tensor_options_);
-    relations_.narrow(1, 0, embedding_size_ / 2).fill_(1);
+    Tensor r = torch::zeros({num_relations_, embedding_size_}, tensor_options_);
+    r.narrow(1, 0, embedding_size_ / 2).fill_(1);
+    relations_ = register_parameter("relation_embeddings", r, /*requires_grad=*/false);
     if (use_inverse_relations_) {
-        inverse_relations_ = torch::zeros({num_relations_, embedding_size_}, tensor_options_);
-        inverse_relations_.narrow(1, 0, embedding_size_ / 2).fill_(1);
+        Tensor ir = torch::zeros({num_relations_, embedding_size_}, tensor_options_);
+        ir.narrow(1, 0, embedding_size_ / 2).fill_(1);
+        inverse_relations_ = register_parameter("inverse_relation_embeddings", ir, /*requires_grad=*/false);
     }
 }
 TransE::TransE(int num_relations, int embedding_dim, torch::TensorOptions o, bool inv, EdgeDecoderMethod m) {
@@ -655,8 +659,9 @@ TransE::TransE(int num_relations, int embedding_dim, torch::TensorOptions o, boo
     reset();
 }
 void TransE::reset() {  // transe.cpp:21-28
-    relations_ = torch::zeros({num_relations_, embedding_size_}, tensor_options_);
-    if (use_inverse_relations_) inverse_relations_ = torch::zeros({num_relations_, embedding_size_}, tensor_options_);
+    relations_ = register_parameter("relation_embeddings", torch::zeros({num_relations_, embedding_size_}, tensor_options_), /*requires_grad=*/false);
+    if (use_inverse_relations_)
+        inverse_relations_ = register_parameter("inverse_relation_embeddings", torch::zeros({num_relations_, embedding_size_}, tensor_options_), /*requires_grad=*/false);
 }
 shared_ptr<EdgeDecoder> get_edge_decoder(DecoderType type, EdgeDecoderMethod method, int num_relations, int dim, torch::TensorOptions opts, bool inv) {
     switch (type) {  // model_helpers.h:23-38
@@ -841,11 +846,36 @@ Model::Model(shared_ptr<EdgeDecoder> decoder, shared_ptr<LossFunction> loss, sha
     : decoder_(decoder), loss_function_(loss), reporter_(reporter), device_(device) {
     if (decoder_->relations_.defined()) relations_grad_ = torch::zeros_like(decoder_->relations_);
     if (decoder_->inverse_relations_.defined()) inverse_relations_grad_ = torch::zeros_like(decoder_->inverse_relations_);
-    // torch::nn::Module view of the dense parameters under the reference's names (distmult.cpp:21-27); requires_grad stays off: the
-    // fused path updates them in place through the C-ABI, the generic path differentiates detached aliases
-    if (decoder_->relations_.defined()) register_parameter("relation_embeddings", decoder_->relations_, /*requires_grad=*/false);
-    if (decoder_->inverse_relations_.defined()) register_parameter("inverse_relation_embeddings", decoder_->inverse_relations_, /*requires_grad=*/false);
+    // model.cpp:52-57: the decoder is the submodule "decoder" (its reset() registered relation_embeddings / inverse_relation_embeddings).
+    // A user decoder that is not a torch module keeps the round-2 form: its tables as parameters of the model itself.
+    if (auto mod = std::dynamic_pointer_cast<torch::nn::Module>(decoder_)) {
+        register_module("decoder", mod);
+    } else {
+        if (decoder_->relations_.defined()) register_parameter("relation_embeddings", decoder_->relations_, /*requires_grad=*/false);
+        if (decoder_->inverse_relations_.defined()) register_parameter("inverse_relation_embeddings", decoder_->inverse_relations_, /*requires_grad=*/false);
+    }
+    learning_task_ = decoder_->learning_task_;
     devices_ = {device};
+}
+static shared_ptr<EdgeDecoder> as_edge_decoder(shared_ptr<Decoder> d) {
+    auto e = std::dynamic_pointer_cast<EdgeDecoder>(d);
+    if (!e) throw MariusRuntimeException("Decoder currently not supported.");  // this build: edge decoders (link prediction) only
+    return e;
+}
+Model::Model(shared_ptr<GeneralEncoder> encoder, shared_ptr<Decoder> decoder, shared_ptr<LossFunction> loss, shared_ptr<Reporter> reporter,
+             std::vector<shared_ptr<Optimizer>> optimizers)
+    : Model(as_edge_decoder(decoder), loss,
+            reporter ? std::dynamic_pointer_cast<LinkPredictionReporter>(reporter) : std::make_shared<LinkPredictionReporter>(),
+            as_edge_decoder(decoder)->tensor_options_.device()) {
+    if (!reporter_) throw MariusRuntimeException("Reporter must be specified for this learning task.");  // model.cpp:44: not a link-prediction reporter
+    if (encoder && !encoder->parameters().empty()) throw MariusRuntimeException("Model: this build trains embedding-only models (the encoder must be a pass-through)");
+    encoder_ = encoder;
+    if (encoder_) register_module("encoder", encoder_);
+    optimizers_ = optimizers;
+}
+void Model::setup_optimizers(shared_ptr<ModelConfig> c) {  // model.cpp:161-250 for the decoder's parameters
+    if (!c) throw MariusRuntimeException("Model::setup_optimizers: null model configuration");  // UnexpectedNullPtrException in the reference
+    setup_optimizer(c->dense_optimizer, c->dense_lr, c->eps, c->beta_1, c->beta_2, c->weight_decay, c->amsgrad);
 }
 void Model::setup_optimizers(float dense_lr) {
     std::vector<std::pair<Tensor, Tensor>> params;
@@ -1143,6 +1173,10 @@ void Model::all_reduce() {  // model.cpp:149-159: sum of the dense gradients ove
     }
 }
 
+shared_ptr<Model> initModelFromConfig(shared_ptr<ModelConfig> c, std::vector<torch::Device> devices, int num_relations, bool train) {
+    if (!c) throw MariusRuntimeException("initModelFromConfig: null model configuration");
+    return initModelFromConfig(*c, std::move(devices), num_relations, train);
+}
 shared_ptr<Model> initModelFromConfig(const ModelConfig& c, std::vector<torch::Device> devices, int num_relations, bool train) {  // model.cpp:361-440
     if (devices.empty()) throw MariusRuntimeException("initModelFromConfig: no device");
     auto dev = devices[0];

@@ -239,9 +239,16 @@ MARIUS_CMP(CosineCompare, MARIUS_CMP_COSINE);
 #undef MARIUS_CMP
 Tensor pad_and_reshape(Tensor input, int num_chunks);  // comparators.cpp:7-20
 
-class EdgeDecoder {
+// options.h:12, nn/decoders/decoder.h:12-17
+enum class LearningTask { NODE_CLASSIFICATION, LINK_PREDICTION, ENCODE };
+class Decoder {
    public:
-    virtual ~EdgeDecoder() = default;
+    LearningTask learning_task_ = LearningTask::LINK_PREDICTION;
+    virtual ~Decoder() {}
+};
+
+class EdgeDecoder : public Decoder {  // edge_decoder.h:13-31
+   public:
     shared_ptr<Comparator> comparator_;
     shared_ptr<RelationOperator> relation_operator_;
     Tensor relations_;
@@ -255,23 +262,26 @@ class EdgeDecoder {
     Tensor apply_relation(Tensor nodes, Tensor relations);
     Tensor compute_scores(Tensor src, Tensor dst);
     Tensor select_relations(Tensor indices, bool inverse = false);
-    virtual void reset() = 0;
 };
-class DistMult : public EdgeDecoder {
+// distmult.h:10-16, complex.h, transe.h: torch::nn::Cloneable modules whose reset() (re)creates the relation tables and registers them as
+// `relation_embeddings` / `inverse_relation_embeddings` (distmult.cpp:21-27).  One deviation, by design: the parameters are registered with
+// requires_grad = false — the fused path updates them in place through the C-ABI, the generic (plug-in) path differentiates detached
+// aliases (Model::train_batch_generic) — where the reference sets requires_grad(true) for its autograd-only training.
+class DistMult : public EdgeDecoder, public torch::nn::Cloneable<DistMult> {
    public:
-    DistMult(int num_relations, int embedding_dim, torch::TensorOptions tensor_options, bool use_inverse_relations = true,
+    DistMult(int num_relations, int embedding_dim, torch::TensorOptions tensor_options = torch::TensorOptions(), bool use_inverse_relations = true,
              EdgeDecoderMethod decoder_method = EdgeDecoderMethod::CORRUPT_NODE);
     void reset() override;
 };
-class ComplEx : public EdgeDecoder {
+class ComplEx : public EdgeDecoder, public torch::nn::Cloneable<ComplEx> {
    public:
-    ComplEx(int num_relations, int embedding_dim, torch::TensorOptions tensor_options, bool use_inverse_relations = true,
+    ComplEx(int num_relations, int embedding_dim, torch::TensorOptions tensor_options = torch::TensorOptions(), bool use_inverse_relations = true,
             EdgeDecoderMethod decoder_method = EdgeDecoderMethod::CORRUPT_NODE);
     void reset() override;
 };
-class TransE : public EdgeDecoder {
+class TransE : public EdgeDecoder, public torch::nn::Cloneable<TransE> {
    public:
-    TransE(int num_relations, int embedding_dim, torch::TensorOptions tensor_options, bool use_inverse_relations = true,
+    TransE(int num_relations, int embedding_dim, torch::TensorOptions tensor_options = torch::TensorOptions(), bool use_inverse_relations = true,
            EdgeDecoderMethod decoder_method = EdgeDecoderMethod::CORRUPT_NODE);
     void reset() override;
 };
@@ -383,7 +393,11 @@ class SGDOptimizer : public Optimizer {  // optim.cpp:59-79
     void step() override;
 };
 
-class LinkPredictionReporter {  // reporting.cpp:11-57
+class Reporter {  // reporting.h:58-76 (metrics are fixed to the link-prediction set of model.cpp:28-38 in this build)
+   public:
+    virtual ~Reporter() = default;
+};
+class LinkPredictionReporter : public Reporter {  // reporting.cpp:11-57
    public:
     std::vector<Tensor> ranks_;
     Tensor computeRanks(Tensor pos_scores, Tensor neg_scores);
@@ -409,8 +423,15 @@ struct ModelConfig {
     float sparse_lr = 0.1f;                      // model.sparse_optimizer.options.learning_rate
 };
 
+// encoder.h: the general encoder.  This build trains embedding-only models, whose encoder is a pass-through (encoder.cpp:195-257 with a
+// single embedding layer): the class exists so that code written against model.h:28-33 compiles; any non-null encoder with parameters
+// is rejected by Model's constructor.
+class GeneralEncoder : public torch::nn::Module {};
+
 class Model : public torch::nn::Module {
    public:
+    shared_ptr<GeneralEncoder> encoder_;  // nullptr or parameter-less (embedding-only)
+    LearningTask learning_task_ = LearningTask::LINK_PREDICTION;
     // Multi-GPU (model.h:33): the reference keeps one replica per device inside one process.  This build runs one process per GPU
     // (torch.distributed over RCCL), so a process only ever holds its own replica; broadcast() records the device list and all_reduce()
     // sums the dense (relation) gradients over the ranks of the registered process group.
@@ -439,6 +460,9 @@ class Model : public torch::nn::Module {
     virtual ~Model();
 
     Model(shared_ptr<EdgeDecoder> decoder, shared_ptr<LossFunction> loss, shared_ptr<LinkPredictionReporter> reporter, torch::Device device);
+    // the reference's constructor (model.h:33, model.cpp:18-58): the device is the decoder's, a null reporter becomes the link-prediction one
+    Model(shared_ptr<GeneralEncoder> encoder, shared_ptr<Decoder> decoder, shared_ptr<LossFunction> loss, shared_ptr<Reporter> reporter = nullptr,
+          std::vector<shared_ptr<Optimizer>> optimizers = {});
     virtual std::tuple<Tensor, Tensor, Tensor, Tensor> forward_lp(shared_ptr<Batch> batch, bool train);  // model.cpp:252-288
     // the same forward for callers that only train (nobody reads the negative scores): lets the library take the flash-style path
     // (MARIUS_LP_TRAIN_ONLY, include/marius_hip.h); neg / inv_neg of the returned tuple are then undefined
@@ -448,6 +472,7 @@ class Model : public torch::nn::Module {
     void clear_grad();
     void step();
     void setup_optimizers(float dense_lr);
+    void setup_optimizers(shared_ptr<ModelConfig> model_config);  // model.h:58, model.cpp:161-250: the dense optimizer of the configuration
     // model.cpp:82-134: model.pt (encoder + decoder parameters) and model_state.pt (optimizer state) as torch::serialize archives with
     // the reference's key structure, so a model directory written here loads in the reference and vice versa
     void save(const std::string& directory);
@@ -469,6 +494,7 @@ class Model : public torch::nn::Module {
 };
 // model.cpp:361-440 for the embedding-only link-prediction models of this build
 shared_ptr<Model> initModelFromConfig(const ModelConfig& config, std::vector<torch::Device> devices, int num_relations, bool train);
+shared_ptr<Model> initModelFromConfig(shared_ptr<ModelConfig> model_config, std::vector<torch::Device> devices, int num_relations, bool train);  // model.h:65
 
 // ------------------------------------------------------------------------------------------------ dataloader (dataloader.h)
 class PartitionBufferStorage;  // partition_buffer.h

@@ -197,8 +197,17 @@ def test_user_plugins_train_through_the_virtual_api(M, dev):
         assert got[3].calls >= (E // B) * (4 if kind == "comparator" else 1)
         for a, b in zip(got[:3], ref[:3]):
             close(a, b, rtol=3e-4)
-    assert set(M.Model(M.DistMult(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE), M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
-               .named_parameters().keys()) == {"relation_embeddings", "inverse_relation_embeddings"}
+    # the decoders are torch::nn::Cloneable modules whose reset() registers the relation tables (distmult.h:10-16, distmult.cpp:21-27) and the
+    # model holds the decoder as its submodule "decoder" (model.cpp:52-57)
+    dm = M.DistMult(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+    assert set(dm.named_parameters().keys()) == {"relation_embeddings", "inverse_relation_embeddings"}
+    assert set(M.Model(dm, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev).named_parameters().keys()) == {
+        "decoder.relation_embeddings", "decoder.inverse_relation_embeddings"}
+    dm.relations.fill_(3.0)
+    cl = dm.clone()
+    assert cl.relations.data_ptr() != dm.relations.data_ptr() and torch.equal(cl.relations, dm.relations)   # Cloneable: a deep copy
+    dm.reset()
+    assert float(dm.relations.min()) == 1.0 and float(cl.relations.min()) == 3.0
     # initModelFromConfig (model.cpp:361-440) and the device-side LocalFilterMode contract (negative.cpp:295-301)
     cfg = M.ModelConfig()
     cfg.decoder, cfg.embedding_dim, cfg.loss = "COMPLEX", 64, "SOFTMAX_CE"
