@@ -631,10 +631,17 @@ DistMult::DistMult(int num_relations, int embedding_dim, torch::TensorOptions o,
     init_decoder(this, num_relations, embedding_dim, o, inv, m);
     reset();
 }
+// register_parameter the first time (the constructor; Cloneable::clone() clears the dictionaries first), replace the tensor on a repeated
+// reset() — the reference's reset() throws "Parameter already defined" there; re-initialising is the more useful superset
+#define MARIUS_SET_PARAM(FIELD, NAME, VALUE)                                                     \
+    do {                                                                                          \
+        Tensor v_ = (VALUE);                                                                      \
+        if (parameters_.contains(NAME)) FIELD = parameters_[NAME] = v_;                           \
+        else FIELD = register_parameter(NAME, v_, /*requires_grad=*/false);                       \
+    } while (0)
 void DistMult::reset() {  // distmult.cpp:21-27
-    relations_ = register_parameter("relation_embeddings", torch::ones({num_relations_, embedding_size_}, tensor_options_), /*requires_grad=*/false);
-    if (use_inverse_relations_)
-        inverse_relations_ = register_parameter("inverse_relation_embeddings", torch::ones({num_relations_, embedding_size_}, tensor_options_), /*requires_grad=*/false);
+    MARIUS_SET_PARAM(relations_, "relation_embeddings", torch::ones({num_relations_, embedding_size_}, tensor_options_));
+    if (use_inverse_relations_) MARIUS_SET_PARAM(inverse_relations_, "inverse_relation_embeddings", torch::ones({num_relations_, embedding_size_}, tensor_options_));
 }
 ComplEx::ComplEx(int num_relations, int embedding_dim, torch::TensorOptions o, bool inv, EdgeDecoderMethod m) {
     comparator_ = std::make_shared<DotCompare>();
@@ -645,11 +652,11 @@ ComplEx::ComplEx(int num_relations, int embedding_dim, torch::TensorOptions o, b
 void ComplEx::reset() {  // complex.cpp:21-29
     Tensor r = torch::zeros({num_relations_, embedding_size_}, tensor_options_);
     r.narrow(1, 0, embedding_size_ / 2).fill_(1);
-    relations_ = register_parameter("relation_embeddings", r, /*requires_grad=*/false);
+    MARIUS_SET_PARAM(relations_, "relation_embeddings", r);
     if (use_inverse_relations_) {
         Tensor ir = torch::zeros({num_relations_, embedding_size_}, tensor_options_);
         ir.narrow(1, 0, embedding_size_ / 2).fill_(1);
-        inverse_relations_ = register_parameter("inverse_relation_embeddings", ir, /*requires_grad=*/false);
+        MARIUS_SET_PARAM(inverse_relations_, "inverse_relation_embeddings", ir);
     }
 }
 TransE::TransE(int num_relations, int embedding_dim, torch::TensorOptions o, bool inv, EdgeDecoderMethod m) {
@@ -659,10 +666,10 @@ TransE::TransE(int num_relations, int embedding_dim, torch::TensorOptions o, boo
     reset();
 }
 void TransE::reset() {  // transe.cpp:21-28
-    relations_ = register_parameter("relation_embeddings", torch::zeros({num_relations_, embedding_size_}, tensor_options_), /*requires_grad=*/false);
-    if (use_inverse_relations_)
-        inverse_relations_ = register_parameter("inverse_relation_embeddings", torch::zeros({num_relations_, embedding_size_}, tensor_options_), /*requires_grad=*/false);
+    MARIUS_SET_PARAM(relations_, "relation_embeddings", torch::zeros({num_relations_, embedding_size_}, tensor_options_));
+    if (use_inverse_relations_) MARIUS_SET_PARAM(inverse_relations_, "inverse_relation_embeddings", torch::zeros({num_relations_, embedding_size_}, tensor_options_));
 }
+#undef MARIUS_SET_PARAM
 shared_ptr<EdgeDecoder> get_edge_decoder(DecoderType type, EdgeDecoderMethod method, int num_relations, int dim, torch::TensorOptions opts, bool inv) {
     switch (type) {  // model_helpers.h:23-38
         case DecoderType::DISTMULT: return std::make_shared<DistMult>(num_relations, dim, opts, inv, method);
@@ -1704,7 +1711,10 @@ shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
         mcheck(marius_select_edges(active_edges_.data_ptr(), 1, cols, ip(active_perm_), batch->start_idx_, B, ip(edges), st));
     else
         mcheck(marius_select_edges(edges_->data_.data_ptr(), edges_->dtype_ == torch::kInt64 ? 1 : 0, cols, ip(active_perm_), batch->start_idx_, B, ip(edges), st));
-    // negativeSample (dataloader.cpp:498-503): inverse (src corruption) first, then dst
+    // negativeSample (dataloader.cpp:498-503): inverse (src corruption) first, then dst.  The reference's filter tensor (rows in nonzero() order)
+    // needs its size on the host — a stream drain; the fused step keeps the uncompacted [C * n_deg, 2] form instead, whose (-1, -1) rows every
+    // consumer behind the C-ABI ignores (measured at degree_fraction 0.5: 0.82 -> ms per step with the two drains per batch gone: see DESIGN)
+    negative_sampler_->compact_filter_ = exact_unique;
     std::tie(batch->src_neg_indices_, batch->src_neg_filter_) = negative_sampler_->getNegatives(graph_, edges, true);
     std::tie(batch->dst_neg_indices_, batch->dst_neg_filter_) = negative_sampler_->getNegatives(graph_, edges, false);
     const int64_t CN = batch->dst_neg_indices_.numel();

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void flash_pack_neg_kernel(const float* __rest
 // entries (row in [0, B), column in [0, N)) of both directions by the item that holds their score: counts, exclusive scan and scatter all in
 // LDS.  The order of the entries inside an item is whatever the atomics give: masking is idempotent, results do not depend on it.
 __global__ __launch_bounds__(1024) void flash_filter_index_kernel(const int64_t* __restrict__ f0, int64_t n0, const int64_t* __restrict__ f1, int64_t n1,
-                                                                  int Bc, int C, int ndir, int XTa, int YBa, int XTn, int YBn, int nkeys_max,
+                                                                  int Bc, int C, int N, int ndir, int XTa, int YBa, int XTn, int YBn, int nkeys_max,
                                                                   uint32_t* __restrict__ foff, uint16_t* __restrict__ fent, int64_t ent_cap) {
     extern __shared__ uint32_t cnt[];  // [nkeys + 1]
     __shared__ uint32_t wsum[16];
@@ -215,11 +215,13 @@ __global__ __launch_bounds__(1024) void flash_filter_index_kernel(const int64_t*
         return (cd * XT + (int)(col >> 7)) * YB + (x >> 5);
     };
     const int64_t n = n0 + n1;
+    // rows of (-1, -1) are the slots of an uncompacted DEG filter (marius_deg_filter): ignored, like anything outside the score matrix
+    auto valid = [&](const int64_t* e) { return e[0] >= 0 && e[0] < (int64_t)Bc * C && e[1] >= 0 && e[1] < N; };
     for (int64_t i = tid; i < n; i += 1024) {
         const int dir = i < n0 ? 0 : 1;
         const int64_t* e = dir == 0 ? f0 + 2 * i : f1 + 2 * (i - n0);
         int ent;
-        atomicAdd(&cnt[key_of(dir, e[0], e[1], ent)], 1u);
+        if (valid(e)) atomicAdd(&cnt[key_of(dir, e[0], e[1], ent)], 1u);
     }
     __syncthreads();
     // exclusive scan of cnt[0 .. nkeys]: thread t owns a contiguous slice
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(1024) void flash_filter_index_kernel(const int64_t*
         const int dir = i < n0 ? 0 : 1;
         const int64_t* e = dir == 0 ? f0 + 2 * i : f1 + 2 * (i - n0);
         int ent;
+        if (!valid(e)) continue;
         const int k = key_of(dir, e[0], e[1], ent);
         const uint32_t slot = atomicAdd(&cnt[k], 1u);
         if ((int64_t)slot < ent_cap) ent_out[slot] = (uint16_t)ent;
@@ -877,7 +880,7 @@ int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj,
             }
             fattr = true;
         }
-        flash_filter_index_kernel<<<dim3(2), dim3(1024), lds, st>>>(desc->dst_filter, nf0, desc->src_filter, nf1, D.Bc, D.C, D.ndir, f.XTa, f.YBa, f.XTn, f.YBn,
+        flash_filter_index_kernel<<<dim3(2), dim3(1024), lds, st>>>(desc->dst_filter, nf0, desc->src_filter, nf1, D.Bc, D.C, D.N, D.ndir, f.XTa, f.YBa, f.XTn, f.YBn,
                                                                    f.nkeys_max, foff, fent, f.ent_cap);
         rc = check_launch("flash_filter_index");
         if (rc) return rc;
