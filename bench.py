@@ -447,7 +447,8 @@ def main():
     out = {
         "metric": "edges/sec scored (pos+neg)", "value": round(scored_eps, 1), "unit": "scored edges/s",
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "host_issue_ms_per_step": round(host_issue / a.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (contractions: 2-way bf16 split x 3 products, f32 accumulate)" if flash else "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": ("f32 (contractions: 2-way %s split x 3 products, f32 accumulate)" % (
+            "fp16 [22 significand bits per operand]" if (a.driver == "cpp" and model.ranges_valid) else "bf16 [16 significand bits per operand]")) if flash else "f32", "data": "synthetic",
         "config": {"workload": "%s %s d=%d in-memory, B=%d C=%d N=%d%s inverse_edges, SoftmaxCE SUM, Adagrad lr 0.1, %s edges" % (
             a.workload, cfg["decoder"], d, B, C, N, (" degree_fraction %.2f" % a.degree_fraction) if a.degree_fraction else "", a.edge_dist), "num_nodes": num_nodes, "num_relations": R, "num_edges": cfg["num_edges"],
             "parallelism": "single GPU", "host": "C++ SynchronousTrainer (libtorch)" if a.driver == "cpp" else "python ctypes driver"},

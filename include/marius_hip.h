@@ -44,10 +44,10 @@ enum {
 
 /* Bumped whenever a struct of this header changes size or meaning, or an entry point changes its signature (3: marius_lp_desc.flags /
  * reserved_, marius_lp_layout.adjrec / negrec / fpart / flash, planned segment update, zero-initialised sort workspace; 4: MARIUS_LP_KEEP_DADJ,
- * layout.dadj doubled on the flash path).  Every binder
+ * layout.dadj doubled on the flash path; 5: marius_lp_desc.absmax, marius_table_absmax, the *_tracked update entry points).  Every binder
  * compares the value it was built against with what the loaded library returns and refuses to run on a mismatch: marius_amd/hip.py lib(),
  * the host module's init (bindings.cpp), and the plug-in recipe of INTEGRATION.md. */
-#define MARIUS_HIP_ABI_VERSION 4
+#define MARIUS_HIP_ABI_VERSION 5
 int marius_hip_abi_version(void);
 /* sizeof(marius_lp_desc) / sizeof(marius_lp_layout) as the library was compiled: a second line of defence for ctypes mirrors */
 int marius_hip_struct_bytes(int which /* 0: marius_lp_desc, 1: marius_lp_layout */);
@@ -221,6 +221,12 @@ typedef struct marius_lp_desc {
     float margin;         /* RankingLoss margin (loss.h:43-55) */
     int32_t flags;        /* MARIUS_LP_* (0 = the API contract: adj / pos / neg are all materialised) */
     int32_t reserved_;
+    /* Optional, flash path only: DEVICE float[2] = { bound on |entries of the node table the batch rows come from|, bound on |entries of the
+     * relation tables| } (any upper bound; marius_table_absmax computes one, the *_tracked Adagrad entry points keep it current).  When
+     * given, the operand records hold fp16 halves of power-of-two scaled rows (22 significand bits per operand) instead of bf16 halves
+     * (16 bits): same speed, split error 3 2^-24 instead of 3 2^-18 of sum|a_k b_k|.  NULL: bf16 records.  The kernels read the bounds on
+     * the device when they run: no host read-back, and the values must not change between marius_lp_forward and marius_lp_backward. */
+    const float* absmax;
 } marius_lp_desc;
 
 /* marius_lp_desc.flags */
@@ -330,6 +336,12 @@ int marius_segment_sum_rows_planned(const float* rows, int64_t rows_ld, const in
 int marius_segment_adagrad_scatter_planned(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
                                            const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* uniq_ids, float* table, float* state,
                                            int64_t table_ld, float lr, float eps, void* carry, const void* plan, marius_stream_t stream);
+/* The same update (plan may be NULL: the unplanned form) that also keeps *absmax (device float) >= every |w| it writes: marius_lp_desc.absmax
+ * stays a valid bound without a pass over the table.  marius_table_absmax max'es max |x| of a whole table into *absmax (zero it first). */
+int marius_segment_adagrad_scatter_tracked(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
+                                           const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* uniq_ids, float* table, float* state,
+                                           int64_t table_ld, float lr, float eps, void* carry, const void* plan, float* absmax, marius_stream_t stream);
+int marius_table_absmax(const float* table, int64_t rows, int64_t ld, int32_t d, float* absmax, marius_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -334,6 +334,10 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_readwrite("reporter", &Model::reporter_)
         .def_readonly("loss", &Model::loss_)
         .def("dense_state", &Model::dense_state)  // [parameters..., optimizer state tensors...] of the dense (relation-table) optimizers, aliased
+        .def_readonly("ranges_valid", &Model::ranges_valid_)  // the flash path packs fp16 operand halves (table magnitude bounds are tracked)
+        .def_readonly("range_state", &Model::range_state_)
+        .def("track_ranges", &Model::track_ranges, py::arg("table"))
+        .def("drop_ranges", &Model::drop_ranges)
         .def_property_readonly("last_step_flash", [](Model& self) { return self.ctx_.layout.flash != 0; })  // did the last fused step take the flash decoder path
         .def_readonly("relations_grad", &Model::relations_grad_)
         .def_readonly("inverse_relations_grad", &Model::inverse_relations_grad_);

@@ -429,6 +429,7 @@ static void lp_setup(LpContext& ctx, shared_ptr<EdgeDecoder> dec, const Tensor& 
     d.loss = loss_kind;
     d.margin = margin;
     d.flags = lp_flags;
+    d.absmax = (ctx.absmax.defined() && (lp_flags & MARIUS_LP_TRAIN_ONLY)) ? ctx.absmax.data_ptr<float>() : nullptr;
     Tensor e = edges.contiguous(), dn = dst_negs.contiguous(), sn = src_negs.defined() ? src_negs.contiguous() : Tensor();
     d.emb = fp(emb);
     d.emb_ld = emb.stride(0);
@@ -1118,7 +1119,11 @@ static bool relation_step_sparse(Model& m, shared_ptr<Batch> batch) {
     for (int dir = 0; dir < ndir; ++dir) {
         Tensor& w = opt->params_[dir].first;
         const float* rows = (const float*)((const char*)c.workspace.data_ptr() + c.layout.grel[dir]);
-        if (rm.plan)
+        if (m.ranges_valid_)
+            mcheck(marius_segment_adagrad_scatter_tracked(rows, c.layout.d_ld, rm.perm, rm.inverse, rm.seg, B, c.desc.d, rm.uniq, fp(w), fp(opt->state_[dir]),
+                                                          w.stride(0), opt->learning_rate_, opt->eps_, m.rel_carry_.data_ptr(), rm.plan, m.range_state_.data_ptr<float>() + 1,
+                                                          cur_stream()));
+        else if (rm.plan)
             mcheck(marius_segment_adagrad_scatter_planned(rows, c.layout.d_ld, rm.perm, rm.inverse, rm.seg, B, c.desc.d, rm.uniq, fp(w), fp(opt->state_[dir]),
                                                           w.stride(0), opt->learning_rate_, opt->eps_, m.rel_carry_.data_ptr(), rm.plan, cur_stream()));
         else
@@ -1255,11 +1260,21 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
         clear_grad();
         relation_grads_dense(*this, batch);
         step();
+        if (ranges_valid_) {  // a dense optimizer step (Adam, SGD, weight decay) moved the relation tables: refresh their bound (two small tables)
+            for (auto& o : optimizers_)
+                for (auto& p : o->params_)
+                    mcheck(marius_table_absmax(fp(p.first), p.first.size(0), p.first.stride(0), (int32_t)p.first.size(1), range_state_.data_ptr<float>() + 1, cur_stream()));
+        }
     }
     const int64_t L = batch->occ_perm_.size(0);
     ensure(carry_, (int64_t)marius_segment_carry_bytes(L, ctx_.desc.d), device_);
     const float* gocc = (const float*)((const char*)ctx_.workspace.data_ptr() + ctx_.layout.gocc);
-    if (batch->occ_plan_.defined())
+    if (ranges_valid_)
+        mcheck(marius_segment_adagrad_scatter_tracked(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
+                                                      batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, ip(batch->unique_node_indices_), fp(table),
+                                                      fp(state), table.stride(0), sparse_lr_, 1e-10f, carry_.data_ptr(),
+                                                      batch->occ_plan_.defined() ? batch->occ_plan_.data_ptr() : nullptr, range_state_.data_ptr<float>(), cur_stream()));
+    else if (batch->occ_plan_.defined())
         mcheck(marius_segment_adagrad_scatter_planned(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
                                                       batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, ip(batch->unique_node_indices_), fp(table),
                                                       fp(state), table.stride(0), sparse_lr_, 1e-10f, carry_.data_ptr(), batch->occ_plan_.data_ptr(), cur_stream()));
@@ -1290,6 +1305,19 @@ void Model::backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, b
         mcheck(marius_segment_sum_rows(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
                                        batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, nullptr, fp(grad_out), grad_out.stride(0),
                                        carry_.data_ptr(), cur_stream()));
+}
+
+void Model::track_ranges(Tensor table) {
+    range_state_ = torch::zeros({2}, f32(device_));
+    mcheck(marius_table_absmax(fp(table), table.size(0), table.stride(0), (int32_t)table.size(1), range_state_.data_ptr<float>(), cur_stream()));
+    for (Tensor* r : {&decoder_->relations_, &decoder_->inverse_relations_})
+        if (r->defined()) mcheck(marius_table_absmax(fp(*r), r->size(0), r->stride(0), (int32_t)r->size(1), range_state_.data_ptr<float>() + 1, cur_stream()));
+    ctx_.absmax = range_state_;
+    ranges_valid_ = true;
+}
+void Model::drop_ranges() {
+    ranges_valid_ = false;
+    ctx_.absmax = Tensor();
 }
 
 std::vector<Tensor> Model::dense_state() {
@@ -1798,11 +1826,17 @@ void SynchronousTrainer::train_one(bool fused) {
         // gathered form, for A/B runs).  Buffer-backed storage addresses rows through its own map and keeps the gather.
         static const bool direct_env = [] { const char* e = getenv("MARIUS_TABLE_DIRECT"); return !(e && e[0] == '0'); }();
         const bool direct = mem && direct_env && mem->data_.is_cuda();
+        // fp16 operand records need magnitude bounds of the tables: one pass over the table the first time, kept current by the fused update
+        // from then on (MARIUS_FLASH_F16=0: bf16 records).  Only for a device-resident table updated by this trainer alone.
+        static const bool f16_env = [] { const char* e = getenv("MARIUS_FLASH_F16"); return !(e && e[0] == '0'); }();
+        if (direct && f16_env && !model_->ranges_valid_) model_->track_ranges(mem->data_);
+        if (!direct && model_->ranges_valid_) model_->drop_ranges();
         if (!direct)
             batch->node_embeddings_ = (mem && batch->num_unique_dev_.defined()) ? mem->indexReadCounted(batch->unique_node_indices_, batch->num_unique_dev_)
                                                                                   : dataloader_->node_embeddings_->indexRead(batch->unique_node_indices_);
         model_->backward_into_tables(batch, dataloader_->node_embeddings_->data_, dataloader_->node_embeddings_state_->data_, direct);
     } else {  // API-granular path, call for call the reference's loop (trainer.cpp:106-138)
+        if (model_->ranges_valid_) model_->drop_ranges();  // updateEmbeddings writes the table without tracking its magnitude
         auto batch = dataloader_->getBatch(true);
         dataloader_->loadGPUParameters(batch);
         model_->train_batch(batch);

@@ -295,6 +295,7 @@ struct LpContext {
     Tensor workspace;
     std::vector<Tensor> keep;  // tensors whose pointers sit in desc
     bool has_loss = false;
+    Tensor absmax;             // optional device float[2] (marius_lp_desc.absmax): set by Model::track_ranges, used only with MARIUS_LP_TRAIN_ONLY
     Tensor view(size_t off, std::vector<int64_t> shape, std::vector<int64_t> strides = {}) const;
 };
 
@@ -488,6 +489,14 @@ class Model : public torch::nn::Module {
     // gpu_sync_interval steps); otherwise the dense gradients are left in relations_grad_ / inverse_relations_grad_ for an all-reduce + step()
     void backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step);
     std::vector<Tensor> dense_state();  // relation tables + their optimizer state (what gpu_model_average averages, pipeline_gpu.cpp:52-80)
+    // Magnitude bounds of the node table and the relation tables on the device (marius_lp_desc.absmax): with them the flash path packs fp16
+    // operand halves (22 significand bits per operand) instead of bf16 ones (16).  track_ranges(table) computes the bounds once (one pass
+    // over the table, no temporary) and the fused update keeps them current (marius_segment_adagrad_scatter_tracked); anything that writes
+    // the tables behind the model's back calls drop_ranges() and the path falls back to bf16 records until the next track_ranges().
+    Tensor range_state_;
+    bool ranges_valid_ = false;
+    void track_ranges(Tensor table);
+    void drop_ranges();
 
    private:
     void train_batch_generic(shared_ptr<Batch> batch, bool call_step);  // the reference's autograd formulation, for user plug-ins

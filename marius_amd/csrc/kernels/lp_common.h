@@ -207,7 +207,75 @@ int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj,
 int flash_merge(const LpDims& D, const float2* part, const float* pos, float* lse, float* rowloss, float* dpos, float* blocksum, char* adjrec,
                 hipStream_t st);
 void flash_set_reserved_cus(int n);
-int flash_backward(const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2], const float2* part, bool filtered,
-                   hipStream_t st);
+int flash_backward(const marius_lp_desc* desc, const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2],
+                   const float2* part, bool filtered, hipStream_t st);
+// fp16 operand records (lp_flash.hip): the scale an operand set is packed with, derived on the device from marius_lp_desc.absmax
+struct FlRange {
+    const float* absmax;  // nullptr: bf16 records, scales 1
+    int has_rel, relop_k;
+};
+FlRange flash_range(const marius_lp_desc* desc, const LpDims& D);
+template <bool F16>
+__device__ __forceinline__ unsigned short fl_cvt16(float x) {
+    if constexpr (F16) {
+        const float c = fminf(fmaxf(x, -65504.f), 65504.f);
+        return __builtin_bit_cast(unsigned short, (_Float16)c);
+    } else {
+        return __builtin_bit_cast(unsigned short, (__bf16)x);
+    }
+}
+// two values at once, no saturation (for magnitudes known to fit: the V factors of the flash kernels are <= 2^14 by construction):
+// v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round to nearest even
+template <bool F16>
+__device__ __forceinline__ unsigned fl_cvt16x2(float x, float y) {
+    typedef float f2_ __attribute__((ext_vector_type(2)));
+    const f2_ v = {x, y};
+    if constexpr (F16) {
+        typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2_));
+    } else {
+        typedef __bf16 b2_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2_));
+    }
+}
+// (w0, w1) - (the two 16-bit values packed in `hi`): the low halves of a split.  With fp16 halves one v_fma_mix_f32 each — an fp32 FMA that reads
+// its fp16 operand straight from either half of the packed register — instead of a conversion and a subtraction (hipcc does not form it itself).
+template <bool F16>
+__device__ __forceinline__ void fl_lo_pair(float w0, float w1, unsigned hi, float& lo0, float& lo1) {
+    if constexpr (F16) {
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo0) : "v"(hi), "v"(w0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo1) : "v"(hi), "v"(w1));
+    } else {
+        lo0 = w0 - __builtin_bit_cast(float, hi << 16);
+        lo1 = w1 - __builtin_bit_cast(float, hi & 0xffff0000u);
+    }
+}
+template <bool F16>
+__device__ __forceinline__ float fl_back16(unsigned short b) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, b);
+    else return (float)__builtin_bit_cast(__bf16, b);
+}
+// power-of-two scale that puts a magnitude bound M at [2^11, 2^12); 1 for M == 0 (or a non-finite bound)
+__host__ __device__ __forceinline__ float fl_scale_of(float M) {
+    if (!(M > 0.f) || !(M < 3.0e38f)) return 1.f;
+    int e;
+    (void)frexpf(M, &e);  // M = m 2^e, m in [0.5, 1)
+    return ldexpf(1.f, 12 - e);
+}
+struct FlScales {
+    float s_adj, s_neg;  // operand scales of the adj records and of the negative-row records (1, 1 on the bf16 path)
+};
+// absmax: device float[2] = {bound on |node table entries|, bound on |relation table entries|}; relop_k: how much the relation operator can
+// amplify (|e o r| <= k M_e M_r): 2 for ComplEx, 1 for the Hadamard product, and the bound is M_e alone without relations
+__device__ __forceinline__ FlScales fl_scales(const float* absmax, int has_rel, int relop_k) {
+    FlScales f;
+    f.s_adj = f.s_neg = 1.f;
+    if (absmax) {
+        const float me = absmax[0], mr = absmax[1];
+        f.s_neg = fl_scale_of(me);
+        f.s_adj = fl_scale_of(has_rel ? me * mr * (float)relop_k : me);
+    }
+    return f;
+}
 
 }  // namespace marius

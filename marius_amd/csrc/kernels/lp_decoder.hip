@@ -36,6 +36,7 @@ struct PrepArgs {
     char* frec;
     int fKP, fXR;
     float* fdadj;  // [ndir][Bp, d_ld]
+    FlRange frg;   // fp16 records: the adj scale is derived from it (lp_common.h); absmax == nullptr: bf16 records
     LpDims D;
 };
 
@@ -131,22 +132,28 @@ __device__ __forceinline__ void prep_flash_store(const PrepArgs& a, int dir, int
     const int xp = 4 * (x & 3) + ((x >> 2) & 3) + (x & ~15);  // fl_rho
     char* rec = a.frec + (((int64_t)dir * D.C + c) * a.fXR + xp) * (int64_t)P;
     if (act) {
-        float lo[4];
-        unsigned hi01, hi23;
-        {
-            typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
-            v2bf h0, h1;
-            h0[0] = (__bf16)v[0]; h0[1] = (__bf16)v[1];
-            h1[0] = (__bf16)v[2]; h1[1] = (__bf16)v[3];
-            lo[0] = v[0] - (float)h0[0]; lo[1] = v[1] - (float)h0[1];
-            lo[2] = v[2] - (float)h1[0]; lo[3] = v[3] - (float)h1[1];
-            hi01 = __builtin_bit_cast(unsigned, h0);
-            hi23 = __builtin_bit_cast(unsigned, h1);
+        // x s = h + l with both halves in the record's element type (fp16 when the caller gave magnitude bounds — s = the adj scale, a power
+        // of two — else bf16 with s = 1): the same split flash_pack_adj_kernel makes (fl_write_piece)
+        unsigned short H[4], L[4];
+        if (a.frg.absmax) {
+            const float sc = fl_scales(a.frg.absmax, a.frg.has_rel, a.frg.relop_k).s_adj;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xs = v[k] * sc;
+                H[k] = fl_cvt16<true>(xs);
+                L[k] = fl_cvt16<true>(xs - fl_back16<true>(H[k]));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                H[k] = fl_cvt16<false>(v[k]);
+                L[k] = fl_cvt16<false>(v[k] - fl_back16<false>(H[k]));
+            }
         }
-        *reinterpret_cast<unsigned*>(rec + 2 * c0) = hi01;
-        *reinterpret_cast<unsigned*>(rec + 2 * c1) = hi23;
-        *reinterpret_cast<unsigned*>(rec + 2 * a.fKP + 2 * c0) = prep_pack_bf16x2(lo[0], lo[1]);
-        *reinterpret_cast<unsigned*>(rec + 2 * a.fKP + 2 * c1) = prep_pack_bf16x2(lo[2], lo[3]);
+        *reinterpret_cast<unsigned*>(rec + 2 * c0) = (unsigned)H[0] | ((unsigned)H[1] << 16);
+        *reinterpret_cast<unsigned*>(rec + 2 * c1) = (unsigned)H[2] | ((unsigned)H[3] << 16);
+        *reinterpret_cast<unsigned*>(rec + 2 * a.fKP + 2 * c0) = (unsigned)L[0] | ((unsigned)L[1] << 16);
+        *reinterpret_cast<unsigned*>(rec + 2 * a.fKP + 2 * c1) = (unsigned)L[2] | ((unsigned)L[3] << 16);
         if (a.fdadj) {
             float* z = a.fdadj + ((int64_t)dir * D.Bp + i) * D.d_ld;
             *reinterpret_cast<float2*>(z + c0) = make_float2(0.f, 0.f);
@@ -1296,6 +1303,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     pa.frec = nullptr;
     pa.fKP = pa.fXR = 0;
     pa.fdadj = nullptr;
+    pa.frg = FlRange{nullptr, 0, 1};
     bool flash_fused_prep = false;
     {
         ProfScope ps(PROF_LP_PREP, st);
@@ -1305,6 +1313,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
             pa.fKP = (D.d + 15) / 16 * 16;
             pa.fXR = (D.Bc + 31) / 32 * 32;
             pa.frec = ws + L->adjrec;
+            pa.frg = flash_range(desc, D);
             pa.fdadj = flash_fused() ? nullptr : (float*)(ws + L->dadj[0]);  // fused form: partials are stored, never accumulated
             prep_rows += (int64_t)D.ndir * D.C * (pa.fXR - D.Bc);  // one half-wave per chunk-padding record
             flash_fused_prep = true;
@@ -1493,7 +1502,7 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
         bool done = false;
         if (L->flash) {
             const bool filtered = (desc->dst_filter && desc->n_dst_filter > 0) || (D.ndir == 2 && desc->src_filter && desc->n_src_filter > 0);
-            rc = flash_backward(D, ws + L->adjrec, ws + L->negrec, ga.dadj, ga.gocc, ga.negocc_off, (const float2*)(ws + L->fpart), filtered, st);
+            rc = flash_backward(desc, D, ws + L->adjrec, ws + L->negrec, ga.dadj, ga.gocc, ga.negocc_off, (const float2*)(ws + L->fpart), filtered, st);
             if (rc) return rc;
             done = true;
         }

@@ -42,6 +42,16 @@ namespace marius {
 
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+// ---- operand element type.  Round 2: bf16 (x = h + l carries 16 significand bits).  Round 3: fp16 when the caller supplies the magnitude
+// bounds of its tables (marius_lp_desc.absmax): x 2^k = h + l with both halves fp16 carries 22 bits — the split error drops from 3 2^-18 to
+// 3 2^-24 of sum|a_k b_k|, the class of the fp32 accumulation itself — at the same MFMA rate.  fp16's narrow exponent is what the bounds
+// are for: every operand set is scaled by a power of two that puts its largest possible magnitude at [2^11, 2^12) (a factor 16 below
+// overflow; conversions saturate anyway), so elements down to 2^-15 of the maximum keep all 22 bits and smaller ones lose low bits of an
+// already negligible contribution.  Records, fragments and LDS traffic are bit patterns either way (the v8bf type below is storage only): the
+// element type shows up in exactly two places, the conversion and the MFMA opcode.
+// (fl_cvt16 / fl_back16 / fl_scale_of / fl_scales: lp_common.h — the prep kernel of lp_decoder.hip packs adj records with them too)
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -93,6 +103,7 @@ struct FlashArgs {
     // FDADJ: positive scores [ndir Bp] (initial reference of the online softmax); out = partial of a tile's first contributor, out2 = of its second
     const float* pos;
     float* out2;
+    FlRange rg;  // operand scales (fp16 records) are derived from it by every kernel of the step
     // score filter (apply_score_filter, negative.cpp:306-311: listed (row, column) scores count as -1e9): entries bucketed by item,
     // foff[item] .. foff[item + 1] into fent; an entry = (stationary row inside the 128-row tile) << 5 | (streamed row inside the block).
     // nullptr: no filter.
@@ -111,23 +122,23 @@ __global__ __launch_bounds__(256) void flash_zero_kernel(float* a, int64_t na, f
 
 // ---------------------------------------------------------------------------------------------------------------- pack kernels
 // fp32 row -> record.  One thread per 4 consecutive elements (8 B of hi, 8 B of lo); threads past d write the zero K padding.
-__device__ __forceinline__ void fl_write_piece(char* rec, int KP, int piece, float4 v) {
+template <bool F16>
+__device__ __forceinline__ void fl_write_piece(char* rec, int KP, int piece, float4 v, float scale) {
 #pragma clang fp contract(off)
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    v4bf H, L;
+    const float x[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};  // scale is a power of two: exact
+    unsigned short H[4], L[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const __bf16 h = (__bf16)x[j];
-        H[j] = h;
-        L[j] = (__bf16)(x[j] - (float)h);
+        H[j] = fl_cvt16<F16>(x[j]);
+        L[j] = fl_cvt16<F16>(x[j] - fl_back16<F16>(H[j]));
     }
-    *reinterpret_cast<v4bf*>(rec + piece * 8) = H;
-    *reinterpret_cast<v4bf*>(rec + 2 * KP + piece * 8) = L;
+    *reinterpret_cast<uint2*>(rec + piece * 8) = make_uint2((unsigned)H[0] | ((unsigned)H[1] << 16), (unsigned)H[2] | ((unsigned)H[3] << 16));
+    *reinterpret_cast<uint2*>(rec + 2 * KP + piece * 8) = make_uint2((unsigned)L[0] | ((unsigned)L[1] << 16), (unsigned)L[2] | ((unsigned)L[3] << 16));
 }
 
 // adj [ndir][Bp][d_ld] fp32 (written by lp_prep*) -> adj records; chunk c of direction dir holds rows c Bc .. (c + 1) Bc of that direction
 __global__ __launch_bounds__(256) void flash_pack_adj_kernel(const float* __restrict__ adj, int64_t d_ld, int64_t Bp, int Bc, int C, int ndir, int d,
-                                                             int KP, int XR, char* __restrict__ rec) {
+                                                             int KP, int XR, char* __restrict__ rec, FlRange rg) {
     const int ppr = KP / 4 + 1;  // pieces per record (+1: the tail)
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nrec = (int64_t)ndir * C * XR;
@@ -153,14 +164,15 @@ __global__ __launch_bounds__(256) void flash_pack_adj_kernel(const float* __rest
             if (4 * piece + 2 < d) v.z = src[2];
         }
     }
-    fl_write_piece(o, KP, piece, v);
+    if (rg.absmax) fl_write_piece<true>(o, KP, piece, v, fl_scales(rg.absmax, rg.has_rel, rg.relop_k).s_adj);
+    else fl_write_piece<false>(o, KP, piece, v, 1.f);
 }
 
 // negatives: record (dir, c, j) = emb[negmap[dir][c N + j]]; rows N .. NR are zero
 __global__ __launch_bounds__(256) void flash_pack_neg_kernel(const float* __restrict__ emb, int64_t emb_ld, const int64_t* __restrict__ neg0,
                                                              const int64_t* __restrict__ neg1, int N, int C, int ndir, int d, int KP, int NR,
                                                              int vec, char* __restrict__ rec, float* __restrict__ gocc, int64_t d_ld, int64_t off0,
-                                                             int64_t off1) {
+                                                             int64_t off1, FlRange rg) {
     const int ppr = KP / 4 + 1;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nrec = (int64_t)ndir * C * NR;
@@ -185,7 +197,8 @@ __global__ __launch_bounds__(256) void flash_pack_neg_kernel(const float* __rest
         // the negative's gradient row is accumulated by at most two workgroups of the backward: it starts from zero
         if (4 * piece < d_ld) *reinterpret_cast<float4*>(gocc + ((dir ? off1 : off0) + c * N + j) * d_ld + 4 * piece) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    fl_write_piece(o, KP, piece, v);
+    if (rg.absmax) fl_write_piece<true>(o, KP, piece, v, fl_scales(rg.absmax, rg.has_rel, rg.relop_k).s_neg);
+    else fl_write_piece<false>(o, KP, piece, v, 1.f);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- score filter index
@@ -259,12 +272,16 @@ __global__ __launch_bounds__(1024) void flash_filter_index_kernel(const int64_t*
 }
 
 // ---------------------------------------------------------------------------------------------------------------- the kernel
-__device__ __forceinline__ v16f fl_mfma(const v8bf& a, const v8bf& b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+template <bool F16>
+__device__ __forceinline__ v16f fl_mfma(const v8bf& a, const v8bf& b, v16f c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 // ---- the two matrix phases, shared by both kernels.  Operand fragments are read from LDS two steps ahead of the MFMAs that consume
 // them (a three-entry register ring): without the explicit distance hipcc emits read -> wait -> MFMA chains and every step pays the LDS
 // latency inside the matrix phase.
-template <int KS>
+template <int KS, bool F16>
 __device__ __forceinline__ v16f fl_score_tile(const unsigned char* T, int a_off, const v8bf (&xh)[KS], const v8bf (&xl)[KS]) {
     constexpr int KP = 16 * KS;
     v16f accM, accC;
@@ -283,13 +300,13 @@ __device__ __forceinline__ v16f fl_score_tile(const unsigned char* T, int a_off,
             yl[(ks + 2) % 3] = *reinterpret_cast<const v8bf*>(T + a_off + 2 * KP + 32 * (ks + 2));
         }
 #ifdef FL_ONE_ACC
-        accM = fl_mfma(yl[ks % 3], xh[ks], accM);
-        accM = fl_mfma(yh[ks % 3], xl[ks], accM);
-        accM = fl_mfma(yh[ks % 3], xh[ks], accM);
+        accM = fl_mfma<F16>(yl[ks % 3], xh[ks], accM);
+        accM = fl_mfma<F16>(yh[ks % 3], xl[ks], accM);
+        accM = fl_mfma<F16>(yh[ks % 3], xh[ks], accM);
 #else
-        accM = fl_mfma(yh[ks % 3], xh[ks], accM);
-        accC = fl_mfma(yh[ks % 3], xl[ks], accC);
-        accC = fl_mfma(yl[ks % 3], xh[ks], accC);
+        accM = fl_mfma<F16>(yh[ks % 3], xh[ks], accM);
+        accC = fl_mfma<F16>(yh[ks % 3], xl[ks], accC);
+        accC = fl_mfma<F16>(yl[ks % 3], xh[ks], accC);
 #endif
     }
     v16f acc;
@@ -312,7 +329,7 @@ __device__ __forceinline__ FlTrFrag fl_tr_read(const unsigned char* T, int tr_of
     r.l.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + 2 * KP + P));
     return r;
 }
-template <int KS, int NCT>
+template <int KS, int NCT, bool F16>
 __device__ __forceinline__ void fl_grad_tile(const unsigned char* T, int tr_off, const v8bf (&wh)[2], const v8bf (&wl)[2], v16f (&out)[NCT]) {
     constexpr int G = 2 * NCT;
     FlTrFrag b[3];
@@ -322,15 +339,23 @@ __device__ __forceinline__ void fl_grad_tile(const unsigned char* T, int tr_off,
     for (int g = 0; g < G; ++g) {
         if (g + 2 < G) b[(g + 2) % 3] = fl_tr_read<KS>(T, tr_off, g + 2);
         const int ct = g >> 1, s_ = g & 1;
-        out[ct] = fl_mfma(wh[s_], b[g % 3].h.f, out[ct]);
-        out[ct] = fl_mfma(wh[s_], b[g % 3].l.f, out[ct]);
-        out[ct] = fl_mfma(wl[s_], b[g % 3].h.f, out[ct]);
+        out[ct] = fl_mfma<F16>(wh[s_], b[g % 3].h.f, out[ct]);
+        out[ct] = fl_mfma<F16>(wh[s_], b[g % 3].l.f, out[ct]);
+        out[ct] = fl_mfma<F16>(wl[s_], b[g % 3].h.f, out[ct]);
     }
 }
 
-template <int KS, int MODE, bool STORE_S>
+template <int KS, int MODE, bool STORE_S, bool F16>
 __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashArgs a) {
     constexpr int KP = 16 * KS, P = fl_pitch(KS), SLOT = fl_slot_bytes(KS), NSLOT = fl_slots(MODE);
+    // ---- scales (all powers of two).  Accumulated scores carry s_x s_y; V = exp2(...) is formed VSH binades up so that its fp16 halves keep
+    // their bits (V <= 2^FL_TAU in the fused sweep, <= 1 where lse is known); the outputs are scaled back when they leave the registers.
+    const FlScales sc_ = fl_scales(F16 ? a.rg.absmax : nullptr, a.rg.has_rel, a.rg.relop_k);
+    const float s_y = (MODE == FLASH_DNEG) ? sc_.s_adj : sc_.s_neg;
+    const float inv_xy = 1.f / (sc_.s_adj * sc_.s_neg);
+    const float c_s = FL_LOG2E * inv_xy;          // accumulator -> score in log2 units
+    constexpr float VSH = !F16 ? 0.f : (MODE == FLASH_FDADJ ? 6.f : (MODE == FLASH_FWD ? 0.f : 14.f));
+    const float out_unscale = __builtin_amdgcn_exp2f(-VSH) / s_y;
     constexpr int NCT = (KP + 31) / 32;       // 32-column tiles of the gradient output
     constexpr int DMA_PER_WAVE = SLOT / (FL_WAVES * 1024);  // 1 KB wave-instructions per wave and tile
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -432,7 +457,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
             }
         } else if (MODE == FLASH_FDADJ) {
             // statistics (mref ln 2, sum V) and the unnormalised partial, slot 0 for the contributor that starts the tile, slot 1 for the other
-            const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+            const float ltot = (lsum + __shfl_xor(lsum, 32, 64)) * __builtin_amdgcn_exp2f(-VSH);
             const int xl = xt * FL_XT + wave * 32 + l31;
             const int64_t prows = (a.ncd / a.C) * a.Bp;
             if (h == 0 && xl < a.Xrows) {
@@ -453,7 +478,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
 #pragma unroll
                 for (int r_ = 0; r_ < 16; ++r_) {
                     const int x = xt * FL_XT + wave * 32 + acc_row(r_, h);
-                    if (x < a.Xrows && col < a.d) dst[(base + x) * a.out_ld + col] = out[ct][r_];
+                    if (x < a.Xrows && col < a.d) dst[(base + x) * a.out_ld + col] = out[ct][r_] * out_unscale;
                 }
             }
         } else {
@@ -467,8 +492,8 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
                     const int x = xt * FL_XT + wave * 32 + acc_row(r_, h);
                     if (x < a.Xrows && col < a.d) {
                         float* p = a.out + (base + x) * a.out_ld + col;
-                        if (sole) *p = out[ct][r_];
-                        else unsafeAtomicAdd(p, out[ct][r_]);
+                        if (sole) *p = out[ct][r_] * out_unscale;
+                        else unsafeAtomicAdd(p, out[ct][r_] * out_unscale);
                     }
                 }
             }
@@ -545,7 +570,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
         }
 
         // ---- S tile: D[y][x] = sum_k Y[y][k] X[x][k]
-        const v16f accS = fl_score_tile<KS>(T, a_off, xh, xl);
+        const v16f accS = fl_score_tile<KS, F16>(T, a_off, xh, xl);
 
         if (MODE == FLASH_FWD) {
             float t[16];
@@ -557,7 +582,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
                 for (int r_ = 0; r_ < 16; ++r_) {
                     const int y = yph * FL_YB + 16 * (r_ >> 3) + 8 * h + (r_ & 7);
                     if (x < a.Xrows && y < a.Yrows)
-                        a.S[((int64_t)dir * a.Bp + (int64_t)c_ * a.Bc + x) * a.n_ld + y] = t[r_];
+                        a.S[((int64_t)dir * a.Bp + (int64_t)c_ * a.Bc + x) * a.n_ld + y] = t[r_] * inv_xy;
                 }
             }
             if ((yph + 1) * FL_YB > a.Yrows) {  // last block of the chunk: columns past N do not exist
@@ -570,13 +595,13 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
             float tm = t[0];
 #pragma unroll
             for (int r_ = 1; r_ < 16; ++r_) tm = fmaxf(tm, t[r_]);
-            const float mn = fmaxf(m2, tm * FL_LOG2E);
+            const float mn = fmaxf(m2, tm * c_s);
             float s0 = 0.f, s1 = 0.f;
             if (mn > -INFINITY) {
 #pragma unroll
                 for (int r_ = 0; r_ < 16; r_ += 2) {
-                    s0 += __builtin_amdgcn_exp2f(fmaf(t[r_], FL_LOG2E, -mn));
-                    s1 += __builtin_amdgcn_exp2f(fmaf(t[r_ + 1], FL_LOG2E, -mn));
+                    s0 += __builtin_amdgcn_exp2f(fmaf(t[r_], c_s, -mn));
+                    s1 += __builtin_amdgcn_exp2f(fmaf(t[r_ + 1], c_s, -mn));
                 }
                 lsum = lsum * __builtin_amdgcn_exp2f(m2 - mn) + (s0 + s1);
                 m2 = mn;
@@ -593,7 +618,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
                     const int reg = 8 * (yl >> 4) + (yl & 7);
 #pragma unroll
                     for (int r_ = 0; r_ < 16; ++r_)
-                        if (mine && r_ == reg) t[r_] = -1e9f;
+                        if (mine && r_ == reg) t[r_] = -INFINITY;  // exp(-1e9 - lse) is exactly 0 in the reference's fp32 as well
                 }
             }
             if (MODE == FLASH_FDADJ) {
@@ -608,7 +633,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
                 float tm = t[0];
 #pragma unroll
                 for (int r_ = 1; r_ < 16; ++r_) tm = fmaxf(tm, t[r_]);
-                tm = fmaxf(tm, __shfl_xor(tm, 32, 64)) * FL_LOG2E;  // this block's maximum of row x = l31, both halves
+                tm = fmaxf(tm, __shfl_xor(tm, 32, 64)) * c_s;  // this block's maximum of row x = l31, both halves (log2 units)
                 const bool raise = tm > mref + FL_TAU;
                 if (__builtin_amdgcn_ballot_w64(raise) != 0ull) {    // rare: a reference moves, the row's sums are rescaled to it
                     const float mnew = raise ? tm : mref;
@@ -623,26 +648,36 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
                     }
                 }
             }
-            // ---- V = exp2(S log2(e) - lsec) in the accumulator layout == A operand layout (k = 16 s + 8 h + e <-> reg 8 s + e)
-            v8bf wh[2], wl[2];
+            // ---- V = exp2(S log2(e) - lsec) in the accumulator layout == A operand layout (k = 16 s + 8 h + e <-> reg 8 s + e).  V <= 2^14 by
+            // construction (the reference of the fused sweep, lse elsewhere), so the packed conversions need no saturation.
+            union { v8bf v; unsigned u[4]; } wh[2], wl[2];
 #pragma unroll
             for (int s_ = 0; s_ < 2; ++s_) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int r_ = 8 * s_ + e;
-                    float ls;
-                    if (MODE == FLASH_DADJ) ls = lsec_x;
-                    else if (MODE == FLASH_FDADJ) ls = mref;
-                    else ls = *reinterpret_cast<const float*>(T + (16 * s_ + fl_rho(8 * h + e)) * P + 4 * KP);
-                    const float w = __builtin_amdgcn_exp2f(fmaf(t[r_], FL_LOG2E, -ls));
-                    if (MODE == FLASH_FDADJ) lsum += w;
-                    const __bf16 wh_ = (__bf16)w;
-                    wh[s_][e] = wh_;
-                    wl[s_][e] = (__bf16)(w - (float)wh_);
+                for (int e = 0; e < 8; e += 2) {
+                    float w2[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int r_ = 8 * s_ + e + q;
+                        float ls;
+                        if (MODE == FLASH_DADJ) ls = lsec_x;
+                        else if (MODE == FLASH_FDADJ) ls = mref;
+                        else ls = *reinterpret_cast<const float*>(T + (16 * s_ + fl_rho(8 * h + e + q)) * P + 4 * KP);
+                        w2[q] = __builtin_amdgcn_exp2f(fmaf(t[r_], c_s, VSH - ls));
+                        if (MODE == FLASH_FDADJ) lsum += w2[q];
+                    }
+                    const unsigned hi = fl_cvt16x2<F16>(w2[0], w2[1]);
+                    wh[s_].u[e >> 1] = hi;
+                    float lo0, lo1;
+                    fl_lo_pair<F16>(w2[0], w2[1], hi, lo0, lo1);
+                    wl[s_].u[e >> 1] = fl_cvt16x2<F16>(lo0, lo1);
                 }
             }
             // ---- out[x][col] += sum_y V[y][x] Y[y][col]
-            if constexpr (MODE != FLASH_FWD) fl_grad_tile<KS, NCT>(T, tr_off, wh, wl, out);
+            if constexpr (MODE != FLASH_FWD) {
+                const v8bf whv[2] = {wh[0].v, wh[1].v}, wlv[2] = {wl[0].v, wl[1].v};
+                fl_grad_tile<KS, NCT, F16>(T, tr_off, whv, wlv, out);
+            }
         }
         if (++yb == a.YB) { yb = 0; ++tile; }
         slot = slot + 1 == NSLOT ? 0 : slot + 1;
@@ -763,19 +798,23 @@ static int fl_num_wg(int64_t tiles, int mode) {
     return nwg < 1 ? 1 : nwg;
 }
 
-template <int KS, int MODE, bool STORE_S>
-static int fl_launch(const FlashArgs& a, hipStream_t st) {
+template <int KS, int MODE, bool STORE_S, bool F16>
+static int fl_launch_t(const FlashArgs& a, hipStream_t st) {
     const size_t lds = (size_t)fl_slots(MODE) * fl_slot_bytes(KS);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_kernel<KS, MODE, STORE_S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_kernel<KS, MODE, STORE_S, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             set_last_error("flash: cannot raise the dynamic LDS limit to %zu", lds);
             return MARIUS_ERR_HIP;
         }
         attr_done = true;
     }
-    flash_kernel<KS, MODE, STORE_S><<<dim3((unsigned)a.nwg), dim3(FL_NT), lds, st>>>(a);
+    flash_kernel<KS, MODE, STORE_S, F16><<<dim3((unsigned)a.nwg), dim3(FL_NT), lds, st>>>(a);
     return check_launch("flash_kernel");
+}
+template <int KS, int MODE, bool STORE_S>
+static int fl_launch(const FlashArgs& a, hipStream_t st) {
+    return a.rg.absmax ? fl_launch_t<KS, MODE, STORE_S, true>(a, st) : fl_launch_t<KS, MODE, STORE_S, false>(a, st);
 }
 
 template <int MODE, bool STORE_S>
@@ -793,7 +832,20 @@ static int fl_dispatch(int ks, const FlashArgs& a, hipStream_t st) {
     return MARIUS_ERR_UNSUPPORTED;
 }
 
-static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, char* negrec) {
+static FlRange g_no_range = {nullptr, 0, 1};
+// magnitude bounds of the caller's tables -> fp16 records (marius_lp_desc.absmax); MARIUS_FLASH_F16=0 keeps the bf16 records
+FlRange flash_range(const marius_lp_desc* desc, const LpDims& D) {
+    FlRange r = g_no_range;
+    const char* e = getenv("MARIUS_FLASH_F16");
+    if (desc->absmax && !(e && e[0] == '0')) {
+        r.absmax = desc->absmax;
+        r.has_rel = (D.edge_cols == 3 && desc->rel) ? 1 : 0;
+        r.relop_k = D.relop == MARIUS_OP_COMPLEX_HADAMARD ? 2 : 1;
+    }
+    return r;
+}
+static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, char* negrec, const FlRange& rg) {
+    a.rg = rg;
     const int xt_rows = FL_XT;
     const int XRa = (D.Bc + 31) / 32 * 32, NRn = (D.N + 31) / 32 * 32;
     const bool xadj = (mode != FLASH_DNEG);
@@ -833,32 +885,33 @@ static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, cha
 // pos / dadj / dadj2: fused form only (flash_fused()): the sweep also leaves the unnormalised dAdj partials
 int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj, char* adjrec, char* negrec, float2* part, float* S, bool adj_packed,
                   float* gocc, const int64_t negocc_off[2], float* dadj_zero, const float* pos, float* dadj, float* dadj2, hipStream_t st) {
+    const FlRange rg = flash_range(desc, D);
     const int ks = fl_ks(D.d), KP = 16 * ks;
     const int XR = (D.Bc + 31) / 32 * 32, NR = (D.N + 31) / 32 * 32;
     const int ppr = KP / 4 + 1;
     if (!adj_packed) {
         const int64_t n = (int64_t)D.ndir * D.C * XR * ppr;
-        flash_pack_adj_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(adj, D.d_ld, D.Bp, D.Bc, D.C, D.ndir, D.d, KP, XR, adjrec);
+        flash_pack_adj_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(adj, D.d_ld, D.Bp, D.Bc, D.C, D.ndir, D.d, KP, XR, adjrec, rg);
         if (dadj_zero) flash_zero_kernel<<<dim3(1024), dim3(256), 0, st>>>(dadj_zero, D.ndir * D.Bp * D.d_ld, nullptr, 0, nullptr, 0);
     }
     {
         const int64_t n = (int64_t)D.ndir * D.C * NR * ppr;
         flash_pack_neg_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(desc->emb, desc->emb_ld, desc->dst_neg, desc->src_neg, D.N, D.C, D.ndir,
                                                                                  D.d, KP, NR, row_vec_width(desc->emb, desc->emb_ld, 4), negrec, gocc,
-                                                                                 D.d_ld, negocc_off[0], negocc_off[1]);
+                                                                                 D.d_ld, negocc_off[0], negocc_off[1], rg);
     }
     int rc = check_launch("flash_pack");
     if (rc) return rc;
     FlashArgs a;
     if (!flash_fused() || S) {  // statistics-only sweep: the unfused form, and the score-storing parity runs (its statistics are then rewritten below)
-        fl_common(a, D, FLASH_FWD, adjrec, negrec);
+        fl_common(a, D, FLASH_FWD, adjrec, negrec, rg);
         a.part = part;
         a.S = S;
         ProfScope ps(PROF_LP_SCORES, st);
         rc = S ? fl_dispatch<FLASH_FWD, true>(ks, a, st) : fl_dispatch<FLASH_FWD, false>(ks, a, st);
         if (rc || !flash_fused()) return rc;
     }
-    fl_common(a, D, FLASH_FDADJ, adjrec, negrec);
+    fl_common(a, D, FLASH_FDADJ, adjrec, negrec, rg);
     a.part = part;
     a.pos = pos;
     a.out = dadj;
@@ -903,20 +956,21 @@ int flash_merge(const LpDims& D, const float2* part, const float* pos, float* ls
 // backward contractions: dadj [ndir][Bp][d_ld] and the negatives' gocc rows.  Both outputs are zeroed first (split tiles accumulate).
 // dadj and the negatives' gocc rows were zeroed by the forward's pack kernels (split tiles accumulate onto them)
 // part / filtered: fused form with a score filter — the index the forward built (orientation 1) sits behind the statistics
-int flash_backward(const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2], const float2* part, bool filtered,
-                   hipStream_t st) {
+int flash_backward(const marius_lp_desc* desc, const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2],
+                   const float2* part, bool filtered, hipStream_t st) {
+    const FlRange rg = flash_range(desc, D);
     const int ks = fl_ks(D.d);
     FlashArgs a;
     int rc = MARIUS_OK;
     if (!flash_fused()) {  // fused form: dAdj left the forward sweep as partials (flash_forward)
-        fl_common(a, D, FLASH_DADJ, adjrec, negrec);
+        fl_common(a, D, FLASH_DADJ, adjrec, negrec, rg);
         a.out = dadj;
         a.out_ld = D.d_ld;
         ProfScope ps(PROF_LP_GRAD_ADJ, st);
         rc = fl_dispatch<FLASH_DADJ, false>(ks, a, st);
     }
     if (rc) return rc;
-    fl_common(a, D, FLASH_DNEG, adjrec, negrec);
+    fl_common(a, D, FLASH_DNEG, adjrec, negrec, rg);
     a.out = gocc;
     a.out_ld = D.d_ld;
     a.negocc_off[0] = negocc_off[0];

@@ -38,6 +38,7 @@ struct ApplySum {
     float* out;
     int64_t out_ld;
     const int64_t* out_rows;  // optional row indirection
+    __device__ __forceinline__ void finish() const {}
     template <int VEC>
     __device__ __forceinline__ void operator()(int u, int col, const float (&g)[VEC]) const {
         const int64_t r = out_rows ? out_rows[u] : (int64_t)u;
@@ -46,12 +47,22 @@ struct ApplySum {
     }
 };
 
+// Optional magnitude tracking (marius_lp_desc.absmax): *absmax >= every |w| the update has written.  The bound is monotone, so a racy read
+// filters almost every lane out once it has settled and the atomic (non-negative floats order like their bit patterns) is rare.
+__device__ __forceinline__ void track_absmax(float* absmax, float mx) {
+    if (!absmax) return;
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0 && mx > *reinterpret_cast<volatile float*>(absmax)) atomicMax(reinterpret_cast<unsigned int*>(absmax), __float_as_uint(mx));
+}
+
 struct ApplyAdagrad {
     const int64_t* uniq;
     float* table;
     float* state;
     int64_t ld;
     float lr, eps;
+    float* absmax;  // optional: see track_absmax (the caller reduces over the wave)
+    mutable float seen = 0.f;
     template <int VEC>
     __device__ __forceinline__ void operator()(int u, int col, const float (&g)[VEC]) const {
 #pragma clang fp contract(off)
@@ -64,9 +75,12 @@ struct ApplyAdagrad {
             const float sn = s[e] + ds;
             const float dw = -lr * (g[e] / (sqrtf(sn) + eps));
             s[e] = sn;
-            w[e] = w[e] + dw;
+            const float wn = w[e] + dw;
+            w[e] = wn;
+            seen = fmaxf(seen, fabsf(wn));
         }
     }
+    __device__ __forceinline__ void finish() const { track_absmax(absmax, seen); }
 };
 
 template <int VEC>
@@ -243,6 +257,7 @@ __device__ __forceinline__ void seg_fixup_body(const SegArgs& a, const Apply& ap
         const int col = (lane + it * 64) * VEC;
         if (col < a.d) apply.template operator()<VEC>(u_last, col, acc[it]);
     }
+    apply.finish();
 }
 
 template <int VEC, int NIT, class Apply>
@@ -297,6 +312,7 @@ struct AdagradRowsArgs {
     const int32_t* seg_offsets;
     const int4* row_plan;
     int skip_crossing;  // 1: rows whose segment crosses a chunk boundary are updated by the fix-up workgroups of the same launch
+    float* absmax;      // optional: track_absmax
 };
 
 template <int VEC>
@@ -340,6 +356,7 @@ __device__ __forceinline__ void adagrad_rows_body(const AdagradRowsArgs& A, int6
             }
         }
     }
+    float seen = 0.f;
     for (int c = tx; c < vpr; c += TX) {
         float gv[UNR][VEC], wv[UNR][VEC], sv[UNR][VEC];
 #pragma unroll
@@ -360,6 +377,7 @@ __device__ __forceinline__ void adagrad_rows_body(const AdagradRowsArgs& A, int6
                     const float dw = -lr * (gv[k][e] / (sqrtf(sn) + eps));
                     sv[k][e] = sn;
                     wv[k][e] = wv[k][e] + dw;
+                    seen = fmaxf(seen, fabsf(wv[k][e]));
                 }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
@@ -369,6 +387,7 @@ __device__ __forceinline__ void adagrad_rows_body(const AdagradRowsArgs& A, int6
             }
         }
     }
+    track_absmax(A.absmax, seen);
 }
 
 template <int VEC>
@@ -500,25 +519,51 @@ static int segment_sum_rows_impl(const float* rows, int64_t rows_ld, const int32
 
 static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, int64_t n,
                                         int32_t d, const int64_t* uniq_ids, float* table, float* state, int64_t table_ld, float lr, float eps, void* carry,
-                                        const void* plan, marius_stream_t stream);
+                                        const void* plan, float* absmax, marius_stream_t stream);
 
 extern "C" int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
                                               const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* uniq_ids,
                                               float* table, float* state, int64_t table_ld, float lr, float eps, void* carry,
                                               marius_stream_t stream) {
-    return segment_adagrad_scatter_impl(rows, rows_ld, perm, inverse, seg_offsets, n, d, uniq_ids, table, state, table_ld, lr, eps, carry, nullptr, stream);
+    return segment_adagrad_scatter_impl(rows, rows_ld, perm, inverse, seg_offsets, n, d, uniq_ids, table, state, table_ld, lr, eps, carry, nullptr, nullptr, stream);
 }
 
 extern "C" int marius_segment_adagrad_scatter_planned(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
                                                       const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* uniq_ids, float* table, float* state,
                                                       int64_t table_ld, float lr, float eps, void* carry, const void* plan, marius_stream_t stream) {
     MARIUS_REQUIRE(plan || n == 0, "segment_adagrad_scatter_planned: null plan");
-    return segment_adagrad_scatter_impl(rows, rows_ld, perm, inverse, seg_offsets, n, d, uniq_ids, table, state, table_ld, lr, eps, carry, plan, stream);
+    return segment_adagrad_scatter_impl(rows, rows_ld, perm, inverse, seg_offsets, n, d, uniq_ids, table, state, table_ld, lr, eps, carry, plan, nullptr, stream);
+}
+
+extern "C" int marius_segment_adagrad_scatter_tracked(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
+                                                      const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* uniq_ids, float* table, float* state,
+                                                      int64_t table_ld, float lr, float eps, void* carry, const void* plan, float* absmax, marius_stream_t stream) {
+    return segment_adagrad_scatter_impl(rows, rows_ld, perm, inverse, seg_offsets, n, d, uniq_ids, table, state, table_ld, lr, eps, carry, plan, absmax, stream);
+}
+
+// max |x| over a [rows, d] table (row pitch ld), max'ed into *absmax (the caller zero-initialises it): the starting point of marius_lp_desc.absmax
+__global__ __launch_bounds__(256) void table_absmax_kernel(const float* __restrict__ t, int64_t rows, int64_t ld, int d, float* __restrict__ absmax) {
+    float mx = 0.f;
+    const int64_t n = rows * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / d;
+        mx = fmaxf(mx, fabsf(t[r * ld + (i - r * d)]));
+    }
+    track_absmax(absmax, mx);
+}
+extern "C" int marius_table_absmax(const float* table, int64_t rows, int64_t ld, int32_t d, float* absmax, marius_stream_t stream) {
+    MARIUS_REQUIRE(rows >= 0 && d > 0 && ld >= d && absmax && (rows == 0 || table), "table_absmax: bad arguments");
+    if (rows == 0) return MARIUS_OK;
+    int64_t blocks = cdiv(rows * d, 256 * 16);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    table_absmax_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(table, rows, ld, d, absmax);
+    return check_launch("table_absmax");
 }
 
 static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, int64_t n,
                                         int32_t d, const int64_t* uniq_ids, float* table, float* state, int64_t table_ld, float lr, float eps, void* carry,
-                                        const void* plan, marius_stream_t stream) {
+                                        const void* plan, float* absmax, marius_stream_t stream) {
     SegArgs a;
     int rc = fill_args(a, rows, rows_ld, perm, inverse, seg_offsets, n, d, carry);
     if (rc) return rc;
@@ -553,14 +598,14 @@ static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, cons
     const int ty = 256 / tx;
     const unsigned row_blocks = (unsigned)cdiv(n, (int64_t)ty * 4);
     const float* occ = skip ? rows : nullptr;
-    AdagradRowsArgs A{gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, tx, lr, eps, occ, rows_ld, seg_offsets, row_plan, 0};
+    AdagradRowsArgs A{gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, tx, lr, eps, occ, rows_ld, seg_offsets, row_plan, 0, absmax};
     const int per = cdiv(d, 64 * vec);
     const char* fz = getenv("MARIUS_SEG_FUSED_FIXUP");  // 0: the fix-up as its own launch between reduction and update (A/B runs)
     if (plan && vec == vsum && vec == 4 && per <= 2 && !(fz && fz[0] == '0')) {
         rc = launch_seg(a, ap, vsum, st, /*fixup=*/false);
         if (rc) return rc;
         A.skip_crossing = 1;
-        ApplyAdagrad aa{uniq_ids, table, state, table_ld, lr, eps};
+        ApplyAdagrad aa{uniq_ids, table, state, table_ld, lr, eps, absmax};
         const unsigned nfix = (unsigned)cdiv(cdiv(n, SEG_R), 4);
         dim3 grid(nfix + row_blocks), block(256);
         if (per <= 1) adagrad_with_fixup_kernel<4, 1><<<grid, block, 0, st>>>(a, aa, A, (int)nfix);

@@ -45,14 +45,19 @@ def make_batch(decoder, B, C, N, d, U, R, seed, scale=0.5, zipf=False):
     return emb, edges, dst_neg, src_neg, rel_t, inv_t
 
 
-def run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, store=True, reduction="sum", dst_filter=None, src_filter=None):
+def run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, store=True, reduction="sum", dst_filter=None, src_filter=None, f16=False):
     relop, cmp = DEC[decoder]
     B, (C, N), d = edges.size(0), dst_neg.shape, emb.size(1)
     flags = H.LP_TRAIN_ONLY | (H.LP_STORE_SCORES if store else 0)
     W = H.LpWorkspace(relop, cmp, d, B, C, N, use_inverse, H.REDUCE_SUM if reduction == "sum" else H.REDUCE_MEAN, 3, True, dev, flags=flags)
     assert W.layout.flash == 1, "the flash path was not selected"
     t = lambda x: None if x is None else x.to(dev)
-    W.bind(t(emb), t(edges), t(dst_neg), t(src_neg), t(rel), t(inv) if use_inverse else None, t(dst_filter), t(src_filter))
+    absmax = None
+    if f16:  # magnitude bounds of the tables -> fp16 operand halves (22 significand bits) instead of bf16 ones (16); computed by the library itself
+        tabs = [t(rel)] + ([t(inv)] if use_inverse else [])
+        absmax = torch.cat([H.table_absmax(t(emb)), H.table_absmax(*tabs)])
+        assert float(absmax[0]) == float(emb.abs().max()) and float(absmax[1]) == float(torch.stack([x.abs().max() for x in tabs]).max().cpu())
+    W.bind(t(emb), t(edges), t(dst_neg), t(src_neg), t(rel), t(inv) if use_inverse else None, t(dst_filter), t(src_filter), absmax=absmax)
     W.forward()
     W.loss()
     W.backward()
@@ -138,14 +143,15 @@ SHAPES = [(6, 3, 5, 50), (100, 10, 50, 50), (1000, 10, 500, 100), (250, 7, 130, 
           (5, 4, 6, 100), (2, 4, 64, 100), (1, 3, 33, 100), (777, 3, 1000, 112), (200, 4, 96, 20), (300, 5, 70, 40), (260, 2, 300, 80), (130, 3, 64, 96)]
 
 
+@pytest.mark.parametrize("f16", [False, True])
 @pytest.mark.parametrize("decoder", ["DISTMULT", "COMPLEX"])
 @pytest.mark.parametrize("use_inverse", [True, False])
 @pytest.mark.parametrize("B,C,N,d", SHAPES)
-def test_flash_forward_loss_backward_match_oracle(H, dev, decoder, use_inverse, B, C, N, d):
+def test_flash_forward_loss_backward_match_oracle(H, dev, decoder, use_inverse, B, C, N, d, f16):
     U, R = max(40, B), 11
     emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=B + d, zipf=(B == 250))
     want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv if use_inverse else None)
-    W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse)
+    W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, f16=f16)
     assert W.layout.Bp == want["pos"].numel()
     mixed_close(W.pos(0), want["pos"], "pos")
     mixed_close(W.neg(0), want["neg"], "neg (split scores)")
@@ -221,7 +227,8 @@ def test_flash_unfused_form_still_matches_oracle(H, dev, monkeypatch, B, C, N, d
 
 @pytest.mark.parametrize("decoder,B,C,N,d", [("COMPLEX", 4096, 4, 1000, 100), ("DISTMULT", 1000, 10, 500, 128), ("COMPLEX", 300, 3, 200, 64),
                                              ("COMPLEX", 50000, 50, 1000, 100)])  # the last one: the bench shape (10^8 score entries, every one checked)
-def test_flash_scores_obey_the_split_error_bound(H, dev, decoder, B, C, N, d):
+@pytest.mark.parametrize("f16", [False, True])
+def test_flash_scores_obey_the_split_error_bound(H, dev, decoder, B, C, N, d, f16):
     """|S_flash - S_fp64| <= (3 * 2^-18 + 2^-20) * sum_k |adj_k| |neg_k|, entry by entry, both directions.  Also measured: the worst PURE
     relative error over the entries with |S| >= 0.1 max|S| (asserted <= 1e-4, north_star's figure) and over |S| >= 1e-2 max|S| (the floor
     close_report uses for the FP32 path; printed, asserted <= 1e-3).  The second figure is where a 16-bit-significand operand shows: the
@@ -230,7 +237,22 @@ def test_flash_scores_obey_the_split_error_bound(H, dev, decoder, B, C, N, d):
     kernels stay at <= 1e-4.  DESIGN.md section 4.1 states this next to the number."""
     U, R = (9000, 17) if B < 50000 else (200000, 1000)
     emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=5, scale=1.0)
-    W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True)
+    if f16:  # rows of very different magnitude under ONE table-wide scale: a tenth of the nodes 2^-9 of the rest, a few 2^-18
+        emb[::10] *= 2.0 ** -9
+        emb[5::97] *= 2.0 ** -18
+    W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, f16=f16)
+    # split error: bf16 halves 3 * 2^-18, fp16 halves 3 * 2^-22 of sum|a_k n_k| (half an ulp of an 8- / 11-bit significand, twice), plus the
+    # fp32 accumulation term
+    split = 3 * 2.0 ** -22 if f16 else 3 * 2.0 ** -18
+    # fp16 has a floor as well: below 2^-14 in scaled units a half is subnormal (quantum 2^-24), so an operand element is off by at most
+    # max(2^-22 |x|, 2^-25 / s) — the second term, 2^-37 of the table's magnitude bound, is what rows 2^-18 smaller than the rest run into
+    import math
+    qa = qn = 0.0
+    if f16:
+        scale_of = lambda M: 2.0 ** (12 - math.frexp(M)[1])
+        m_e, m_r = float(emb.abs().max()), float(torch.maximum(rel.abs().max(), inv.abs().max()))
+        qn = 2.0 ** -25 / scale_of(m_e)
+        qa = 2.0 ** -25 / scale_of(m_e * m_r * (2 if decoder == "COMPLEX" else 1))
     e64, r64, i64 = emb.double(), rel.double(), inv.double()
     Bc = -(-B // C)
     worst, worst_rel, worst_rel1 = 0.0, 0.0, 0.0
@@ -247,7 +269,7 @@ def test_flash_scores_obey_the_split_error_bound(H, dev, decoder, B, C, N, d):
             exact = exact_all[c]
             mag = a.abs() @ n.abs().t()
             err = (got[c * Bc:(c + 1) * Bc] - exact).abs()
-            bound = (3 * 2.0 ** -18 + 2.0 ** -20) * mag + 1e-30
+            bound = (split + 2.0 ** -20) * mag + qa * n.abs().sum(1)[None, :] + qn * a.abs().sum(1)[:, None] + 1e-30
             worst = max(worst, (err / bound).max().item())
             for floor in (1e-1, 1e-2):
                 big = exact.abs() >= floor * smax
@@ -259,6 +281,8 @@ def test_flash_scores_obey_the_split_error_bound(H, dev, decoder, B, C, N, d):
                         worst_rel = max(worst_rel, r)
     print("worst |err| / bound = %.3f   worst pure-relative error over |S| >= 0.1 max|S| = %.2e, over |S| >= 1e-2 max|S| = %.2e" % (worst, worst_rel1, worst_rel))
     assert worst <= 1.0
+    if f16 and B >= 1000:   # 22-bit operands: north_star's 1e-4 holds in the form the FP32-MFMA path is held to (pure relative, floor 1e-2 max)
+        assert worst_rel <= 1e-4
     assert worst_rel1 <= 1e-4 and worst_rel <= 1e-3
 
 

@@ -279,14 +279,14 @@ def test_cpp_trainer_flash_pipeline_bench_shape_matches_cpu_step(H, dev):
     trainer.train_steps(steps)
     torch.cuda.synchronize()
     assert model.last_step_flash, "the bench pipeline is the flash path"
+    assert model.ranges_valid and float(model.range_state[0]) >= float(t_d.abs().max()), "magnitude bound of the node table lost track"
     changed = (s_d != s0_d).any(1).nonzero().flatten().cpu()
     assert torch.equal(changed, rows), (changed.numel(), rows.numel())
     close_report(model.loss[0:1], want["loss"].reshape(1), "loss of step %d" % (steps - 1))
     for got, ref, what in ((t_d[rows.to(dev)], cpu.table[rows], "touched table rows"), (s_d[rows.to(dev)], cpu.state[rows], "touched state rows"),
                            (dec.relations, cpu.rel, "relations"), (dec.inverse_relations, cpu.inv_rel, "inverse relations")):
-        # tier 1 is north_star's figure.  Tier 2 is wider than on the FP32-MFMA path (3e-4 / 3e-6 in test_train_step_bench_shape_matches_cpu_step):
-        # the flash contractions carry 16 significand bits per operand, so an accumulated gradient's error scales with sum|a_k b_k| rather
-        # than with the entry, and entries 10-100x below the largest inherit up to ~6e-4 of relative error through the Adagrad step
-        # (measured: 5.6e-4 - 5.8e-4 on the touched table rows, 1.4e-5 of the maximum below the floor).  tests/test_gpu_flash.py states the same for the scores themselves.
+        # the same three tiers as the FP32-MFMA path (test_train_step_bench_shape_matches_cpu_step): the trainer tracks the tables' magnitude
+        # bounds, so the flash contractions run on fp16 halves (22 significand bits per operand; measured here: 8.7e-5 at the 1e-2 floor,
+        # 1.6e-6 of the maximum below it).  With bf16 halves (MARIUS_FLASH_F16=0) the second tier reads 5.6e-4 / 1.4e-5.
         close_report(got, ref, what, floor=0.1, atol_frac=1.0)
-        close_report(got, ref, what, rtol=1e-3, floor=0.01, atol_frac=3e-5)
+        close_report(got, ref, what, rtol=3e-4, floor=0.01, atol_frac=3e-6)

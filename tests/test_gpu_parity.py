@@ -413,6 +413,25 @@ def test_planned_segment_adagrad_scatter_is_bit_identical(H, dev, n, num_nodes, 
     assert torch.equal(oa[:U], ob[:U])
 
 
+@pytest.mark.parametrize("n,rows_of_table,d,planned", [(8000, 3000, 100, True), (50000, 40, 64, True), (33, 5, 20, False), (200000, 200000, 100, True)])
+def test_tracked_update_keeps_the_magnitude_bound(H, dev, n, rows_of_table, d, planned):
+    """marius_segment_adagrad_scatter_tracked: the same bits as the untracked update, and *absmax >= every |w| in the table afterwards, starting
+    from marius_table_absmax — the bound marius_lp_desc.absmax needs for fp16 operand records, kept without a pass over the table."""
+    g = torch.Generator().manual_seed(n + d)
+    ids = (torch.rand(n, generator=g) ** 2 * rows_of_table).long().clamp_(0, rows_of_table - 1)
+    rows = (torch.randn(n, d, generator=g) * 0.1).to(dev)
+    table, state = torch.randn(rows_of_table, d, generator=g) * 1e-3, torch.zeros(rows_of_table, d)   # fresh rows: the first Adagrad step moves them by lr
+    um = H.UniqueMap(n, dev).run(ids.to(dev), key_bits=28)
+    plan = H.segment_plan(um, n) if planned else None
+    ta, sa, tb, sb = table.to(dev), state.to(dev), table.to(dev), state.to(dev)
+    bound = H.table_absmax(tb)
+    assert float(bound) == float(table.abs().max())
+    H.segment_adagrad_scatter(rows, um, n, d, ta, sa, lr=0.1, plan=plan)
+    H.segment_adagrad_scatter(rows, um, n, d, tb, sb, lr=0.1, plan=plan, absmax=bound)
+    assert torch.equal(ta, tb) and torch.equal(sa, sb)
+    assert float(bound) == float(tb.abs().max()) > 0.05           # grew with the update (1e-3 -> ~lr), and is exact here: nothing shrank
+
+
 # ------------------------------------------------------------------------------------------------ whole steps vs the CPU path
 @pytest.mark.parametrize("decoder,f", [("COMPLEX", 0.0), ("DISTMULT", 0.5), ("TRANSE", 0.0)])
 def test_train_steps_match_cpu_reference_path(H, dev, decoder, f):
