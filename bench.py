@@ -429,7 +429,7 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference's CPU path) on a bounded sample, host cores of this box
     cpu = None
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and R > 1:  # the oracle step restates the 3-column (src, rel, dst) path the metric is quoted on
         cpu = cpu_baseline_leg(cfg, B, C, N, edges_all, a.cpu_seconds)
 
     # SURVEY 8(d) / north_star "fraction of the HBM-read roofline on gather + score": the bytes that MUST be read (every unique row once, the

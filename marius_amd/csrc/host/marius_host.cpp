@@ -1828,7 +1828,7 @@ void SynchronousTrainer::train_one(bool fused) {
         const bool direct = mem && direct_env && mem->data_.is_cuda();
         // fp16 operand records need magnitude bounds of the tables: one pass over the table the first time, kept current by the fused update
         // from then on (MARIUS_FLASH_F16=0: bf16 records).  Only for a device-resident table updated by this trainer alone.
-        static const bool f16_env = [] { const char* e = getenv("MARIUS_FLASH_F16"); return !(e && e[0] == '0'); }();
+        const bool f16_env = [] { const char* e = getenv("MARIUS_FLASH_F16"); return !(e && e[0] == '0'); }();
         if (direct && f16_env && !model_->ranges_valid_) model_->track_ranges(mem->data_);
         if (!direct && model_->ranges_valid_) model_->drop_ranges();
         if (!direct)

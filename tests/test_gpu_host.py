@@ -102,9 +102,9 @@ def test_storage_roundtrip_and_index_ops(M, dev, tmp_path):
         st.indexRead(torch.zeros(2, 2, dtype=torch.int64, device=dev))
 
 
-def _setup(M, dev, decoder, num_nodes, R, d, B, C, N, E, seed, f=0.0):
+def _setup(M, dev, decoder, num_nodes, R, d, B, C, N, E, seed, f=0.0, init=0.6):
     g = torch.Generator().manual_seed(1)
-    table = (torch.rand(num_nodes, d, generator=g) - 0.5) * 0.6
+    table = (torch.rand(num_nodes, d, generator=g) - 0.5) * init
     edges_all = torch.stack([torch.randint(num_nodes, (E,), generator=g), torch.randint(R, (E,), generator=g),
                              torch.randint(num_nodes, (E,), generator=g)], 1)
     gen = M.MariusGenerator(seed)
@@ -142,6 +142,32 @@ def test_trainer_epoch_matches_cpu_reference_path(M, dev, decoder, f, fused, d):
     close(model.decoder.relations, cpu.rel, rtol=3e-4)
     close(model.decoder.inverse_relations, cpu.inv_rel, rtol=3e-4)
     assert trainer.last_edges_per_second > 0
+
+
+def test_trainer_tracks_table_magnitude_through_a_thousandfold_growth(M, dev):
+    """fp16 operand records are packed with a power-of-two scale derived from a bound on the table's magnitude.  A freshly initialised table
+    (+-1.3e-4, Freebase86m's glorot limit) whose rows jump to +-0.1 the first time Adagrad touches them — a factor 1000 inside one step — is the
+    case that bound exists for: it must follow the update (marius_segment_adagrad_scatter_tracked) or the next step's records overflow.  Two
+    epochs against the CPU reference path, and the bound is checked against the table itself."""
+    num_nodes, R, d, B, C, N, E, seed = 4000, 11, 100, 250, 5, 40, 1000, 77
+    table, edges_all, emb, state, loader, model = _setup(M, dev, "COMPLEX", num_nodes, R, d, B, C, N, E, seed, init=2.6e-4)
+    trainer = M.SynchronousTrainer(loader, model)
+    trainer.train(2)
+    assert model.last_step_flash and model.ranges_valid
+    bound = model.range_state.cpu()
+    assert float(bound[0]) >= float(emb.data.abs().max()) > 0.05 and float(bound[1]) >= float(model.decoder.relations.abs().max())
+    cpu = CpuLinkPredictionStep("COMPLEX", table.clone(), torch.zeros(num_nodes, d), R, B, C, N)
+    torch.manual_seed(seed)
+    for epoch in range(2):
+        perm = torch.randperm(E)
+        for s in range(E // B):
+            cpu.step(edges_all[perm[s * B:(s + 1) * B]])
+    # Adagrad from an all-zero state moves a weight by lr * sign(g): two correct fp32 evaluations can differ by 2 lr where g is rounding noise
+    # around 0.  Compare where the CPU path's accumulated state says the gradients were not noise.
+    solid = cpu.state > 1e-8
+    assert float(solid.float().mean()) > 0.05
+    close(emb.data.cpu()[solid], cpu.table[solid], rtol=3e-4)
+    close(state.data.cpu()[solid], cpu.state[solid], rtol=3e-4)
 
 
 def test_user_plugins_train_through_the_virtual_api(M, dev):
@@ -623,9 +649,12 @@ def _init_nccl(dev):
 
 
 @pytest.mark.parametrize("sync_interval", [1, 16])
-def test_cpp_sharded_trainer_world1_equals_synchronous_trainer(M, dev, sync_interval):
+def test_cpp_sharded_trainer_world1_equals_synchronous_trainer(M, dev, sync_interval, monkeypatch):
     """ShardedTrainer (owner split points, all-to-all(v) through c10d, owner-side dedupe + Adagrad, prepared one step ahead) at world
-    size 1 and staleness 0 walks the same trajectory as the fused single-GPU trainer — across an epoch boundary (new permutation)."""
+    size 1 and staleness 0 walks the same trajectory as the fused single-GPU trainer — across an epoch boundary (new permutation).
+    Same arithmetic on both sides: the sharded trainer packs bf16 operand halves (a rank sees only its shard's magnitudes), so the fused
+    trainer is held to them too (MARIUS_FLASH_F16=0) — from an all-zero Adagrad state any difference in rounding flips lr-sized steps."""
+    monkeypatch.setenv("MARIUS_FLASH_F16", "0")
     dist = _init_nccl(dev)
     num_nodes, R, d, B, C, N, E, seed, steps = 3000, 9, 100, 200, 4, 60, 1200, 21, 9
     table, edges_all, make = _sharded_setup(M, dev, seed, num_nodes, R, d, B, C, N, E)
