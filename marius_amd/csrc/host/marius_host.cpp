@@ -1235,6 +1235,7 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
     forward_lp_train(batch);
     batch->table_ = Tensor();
     model_backward(*this, batch);
+    if (ev_grads_) HIPCHECK(hipEventRecord((hipEvent_t)ev_grads_, c10::hip::getCurrentHIPStream(device_.index()).stream()));
     // The relation-table update (6 small, latency-bound launches) and the node-table update are independent: run the former on a side
     // stream underneath the latter and join before returning (the next forward reads the relation tables).
     const auto dev_index = device_.index();
@@ -1442,6 +1443,15 @@ void DataLoader::setActiveEdges() {
     active_edges_ = torch::stack(columns, 1).contiguous();
 }
 
+void* DataLoader::gate_event() {
+    if (!gate_event_) {
+        hipEvent_t e;
+        HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        gate_event_ = e;
+    }
+    return gate_event_;
+}
+
 bool DataLoader::hasNextBatch() {
     if (batches_left_ > 0 || !partitioned()) return batches_left_ > 0;
     // dataloader.cpp:308-340: all batches of this buffer state are done -> swap and lay out the next state's batches
@@ -1588,6 +1598,7 @@ DataLoader::~DataLoader() {
         if (e) (void)hipEventDestroy((hipEvent_t)e);
     for (auto& e : ev_main_)
         if (e) (void)hipEventDestroy((hipEvent_t)e);
+    if (gate_event_) (void)hipEventDestroy((hipEvent_t)gate_event_);
     delete (c10::hip::HIPStream*)loader_stream_;
 }
 
@@ -1599,7 +1610,9 @@ void DataLoader::post_prepare(bool exact_unique) {
     // safe (blocks freed by the previous batch return to the loader stream's pool while that step may still be executing).
     hipEvent_t em = (hipEvent_t)ev_main_[ev_main_next_];
     ev_main_next_ = (ev_main_next_ + 1) & 3;
-    HIPCHECK(hipEventRecord(em, main.stream()));
+    static const bool gate_env = [] { const char* e = getenv("MARIUS_LOADER_GATE"); return !(e && e[0] == '0'); }();
+    if (gate_env && gate_valid_ && gate_event_ && !worker_) em = (hipEvent_t)gate_event_;  // the previous step's gradients exist: early enough (see header)
+    else HIPCHECK(hipEventRecord(em, main.stream()));
     prepared_left_--;
     pending_ = true;
     next_exact_ = exact_unique;
@@ -1651,7 +1664,9 @@ void DataLoader::drain_worker() {
         }
     }
     held_.reset();
+    held_prev_.reset();
     next_.reset();
+    gate_valid_ = false;  // an epoch boundary uploads a new permutation on the training stream: the next preparation waits for all of it
 }
 
 shared_ptr<Batch> DataLoader::getBatch(bool exact_unique) {
@@ -1717,7 +1732,8 @@ shared_ptr<Batch> DataLoader::getBatch(bool exact_unique) {
     shared_ptr<Batch> batch = take_prepared();
     batches_left_--;
     last_num_unique_ = batch->num_unique_dev_;
-    held_ = batch;  // releases the previous batch: no preparation is in flight right now
+    held_prev_ = held_;  // the batch before the previous one is released here: the updates of the previous step may still be reading its maps
+    held_ = batch;
     if (run_ahead_ && prepared_left_ > 0) post_prepare(exact_unique);
     HIPCHECK(hipStreamWaitEvent(main.stream(), (hipEvent_t)batch->ready_, 0));
     return batch;
@@ -1834,7 +1850,15 @@ void SynchronousTrainer::train_one(bool fused) {
         if (!direct)
             batch->node_embeddings_ = (mem && batch->num_unique_dev_.defined()) ? mem->indexReadCounted(batch->unique_node_indices_, batch->num_unique_dev_)
                                                                                   : dataloader_->node_embeddings_->indexRead(batch->unique_node_indices_);
-        model_->backward_into_tables(batch, dataloader_->node_embeddings_->data_, dataloader_->node_embeddings_state_->data_, direct);
+        model_->ev_grads_ = dataloader_->gate_event();
+        try {
+            model_->backward_into_tables(batch, dataloader_->node_embeddings_->data_, dataloader_->node_embeddings_state_->data_, direct);
+        } catch (...) {
+            model_->ev_grads_ = nullptr;
+            throw;
+        }
+        model_->ev_grads_ = nullptr;
+        dataloader_->gate_valid_ = true;
     } else {  // API-granular path, call for call the reference's loop (trainer.cpp:106-138)
         if (model_->ranges_valid_) model_->drop_ranges();  // updateEmbeddings writes the table without tracking its magnitude
         auto batch = dataloader_->getBatch(true);

@@ -458,6 +458,8 @@ class Model : public torch::nn::Module {
     void* side_stream_ = nullptr;  // relation-table update runs here, underneath the node-table update (backward_into_tables)
     void* ev_fork_ = nullptr;
     void* ev_join_ = nullptr;
+    void* ev_grads_ = nullptr;  // caller-owned hipEvent_t (the data loader's gate): recorded on the training stream when a step's gradients exist, i.e.
+                                // after the edge backward and before the updates; set around one backward_into_tables call, never owned here
     virtual ~Model();
 
     Model(shared_ptr<EdgeDecoder> decoder, shared_ptr<LossFunction> loss, shared_ptr<LinkPredictionReporter> reporter, torch::Device device);
@@ -545,6 +547,15 @@ class DataLoader {
     // batch whose loader-stream work waits for that training step, so a batch is released HERE, between taking the next prepared batch
     // and posting the following request — never while a preparation is in flight on the other thread.
     shared_ptr<Batch> held_;
+    // Early gate (MARIUS_LOADER_GATE=0 disables it): the preparation of batch t + 1 may start as soon as the GRADIENTS of step t - 1 exist
+    // (gate_event_, recorded by the model) instead of when that step has finished: its two hundred microseconds of small kernels then run
+    // underneath the HBM-bound tail of step t - 1 (segmented sums, Adagrad) and the row packing of step t, and are mostly gone when the
+    // persistent matrix launches of step t need every CU.  Preparation never reads the tables; what it must not do is reuse memory the
+    // running updates still read, so a batch is kept one step longer (held_prev_).
+    void* gate_event_ = nullptr;  // owned here (created on first use, destroyed with the loader)
+    bool gate_valid_ = false;
+    void* gate_event();
+    shared_ptr<Batch> held_prev_;
     // The NEXT epoch's permutation, drawn by a host thread while this epoch trains (dataloader.cpp:176-182 puts a serial randperm of all
     // edges between two epochs: 0.12 s at 10 M edges, seconds at Freebase86m's 338 M — as long as the epoch itself on this device).  The words
     // an epoch's sampling draws from the generator are known in advance (two requests per batch, a fixed count each), so the thread advances a
