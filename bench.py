@@ -6,9 +6,11 @@
 A "step" is one pass of the whole hot path over one batch of synthetic Freebase86m-shaped input already resident in HBM:
 edge slice -> MT19937 negative sampling -> sort/unique map -> row gather -> ComplEx negative scores -> SoftmaxCE ->
 hand-derived backward -> Adagrad on the relation tables -> segmented-sum + sparse Adagrad scatter into the node table.
-The contractions run flash-style (lp_flash.hip): fp32 operands split exactly once per step into two bf16 planes, three bf16 MFMA
-products per fp32 product with fp32 accumulation (error bound tested in tests/test_gpu_flash.py), score tiles recomputed in the
-backward instead of a 400 MB score tensor.  MARIUS_FLASH=0 selects the FP32-MFMA kernels with materialised scores.
+The contractions run flash-style (lp_flash.hip): fp32 operands split once per step into two 16-bit halves (fp16 halves of power-of-two
+scaled rows — 22 significand bits per operand — when the trainer tracks the tables' magnitude bounds, which it does here; bf16 halves
+otherwise), three MFMA products per fp32 product with fp32 accumulation (error bound tested in tests/test_gpu_flash.py); forward statistics
+and dAdj are one sweep (online softmax), dNeg recomputes its score tiles: 4 contractions per step, no 400 MB score tensor.
+MARIUS_FLASH=0 selects the FP32-MFMA kernels with materialised scores (reported beside the headline number as `fp32_exact`).
 Prints ONE JSON line (rank 0).  The CPU baseline leg runs the oracle (a port of the reference's CPU path) on a bounded sample.
 """
 import argparse
@@ -113,7 +115,7 @@ def dominant_roofline(avg_ms, B, C, N, d, ndir, flash, pmc_ok, kernel="lp_grad_a
            "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command; a constant, NOT measured in this run)" % os.path.relpath(pmc_path, ROOT)) if traffic else None,
            "avg_ms": round(avg_ms, 4)}
     if flash:
-        out.update({"peak_is": "dense BF16 MFMA", "bf16_products_per_fp32_product": 3, "contractions_per_launch": 2, "fp32_equivalent_tflops": round(ach / 3, 2)})
+        out.update({"peak_is": "dense 16-bit MFMA (bf16 and fp16 run at the same rate)", "bf16_products_per_fp32_product": 3, "contractions_per_launch": 2, "fp32_equivalent_tflops": round(ach / 3, 2)})
     try:  # transparency only: `achieved` / `frac` stay on the uncorrected event figure
         ov = event_pair_overhead_ms()
         net = max(avg_ms - 2.0 * ov, 1e-6)
@@ -409,9 +411,9 @@ def main():
                     "avg_ms": k["avg_ms"]}
         if flash and k["bound"] == "mfma":
             ncon = 1 if dom == "lp_scores" else 2
-            roofline.update({"peak_is": "dense BF16 MFMA", "bf16_products_per_fp32_product": 3, "contractions_per_launch": ncon,
+            roofline.update({"peak_is": "dense 16-bit MFMA (bf16 and fp16 run at the same rate)", "bf16_products_per_fp32_product": 3, "contractions_per_launch": ncon,
                              "fp32_equivalent_tflops": round(k["achieved"] / 3, 2),
-                             "note": "achieved = contractions_per_launch x 3 products x 2 Bp N d ndir flop / launch time (score tile recomputed in the backward launches)"})
+                             "note": "achieved = contractions_per_launch x 3 products x 2 Bp N d ndir flop / launch time (lp_grad_adj = the fused forward sweep: scores + V Neg; lp_grad_neg recomputes the scores)"})
         try:  # transparency only: `achieved` / `frac` stay on the uncorrected event figure (event vs rocprofv3)
             ov = event_pair_overhead_ms()
             net = max(k["avg_ms"] - 2.0 * ov, 1e-6)
