@@ -364,6 +364,16 @@ def main():
         "sort_unique": ("hbm", L * (8.0 + 4.0) * 2 * 4),
         "mt19937_fill": ("hbm", 2.0 * C * N * 4.0 * 2),
     }
+    wide = flash and d > 128
+    if wide:
+        # rows wider than 128 columns (cfg5's d = 400): the contraction index is cut into nch column chunks, the fp32 scores ARE stored (tile
+        # order) and every launch streams them — these launches are bound by that traffic, not by the matrix pipe:
+        # forward = nch launches timed as one (first stores, the others read-modify-write); backward = one (dAdj, dNeg) launch pair per chunk
+        nch = math.ceil(d / 128)
+        s_bytes = 4.0 * ndir * Bp * N
+        alg["lp_scores"] = ("hbm", (2 * nch - 1) * s_bytes)
+        alg["lp_grad_adj"] = ("hbm", s_bytes)
+        alg["lp_grad_neg"] = ("hbm", s_bytes)
     if not flash and prof.get("lp_grad_neg", (0, 0))[1] == 0:  # both backward contractions ran as ONE launch, timed under lp_grad_adj
         alg["lp_grad_adj"] = ("mfma", 2 * contraction_flops)
     kernels = {}
@@ -409,6 +419,9 @@ def main():
                     "traffic": traffic,
                     "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command; a constant, NOT measured in this run)" % os.path.relpath(pmc_path, ROOT)) if traffic else None,
                     "avg_ms": k["avg_ms"]}
+        if wide:
+            roofline["note"] = ("rows wider than 128 columns: %d column chunks over stored fp32 scores in tile order; achieved = score bytes a launch streams "
+                                "(4 ndir Bp N per pass; the forward = 2 nch - 1 passes) / launch time") % math.ceil(d / 128)
         if flash and k["bound"] == "mfma":
             ncon = 1 if dom == "lp_scores" else 2
             roofline.update({"peak_is": "dense 16-bit MFMA (bf16 and fp16 run at the same rate)", "bf16_products_per_fp32_product": 3, "contractions_per_launch": ncon,

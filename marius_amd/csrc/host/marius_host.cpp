@@ -931,6 +931,7 @@ void Model::save(const std::string& directory) {  // model.cpp:82-106
     state_archive.save_to(directory + "model_state.pt");
 }
 void Model::load(const std::string& directory, bool train) {  // model.cpp:108-134
+    if (ranges_valid_) drop_ranges();  // the relation tables are about to be overwritten
     torch::serialize::InputArchive model_archive, state_archive;
     model_archive.load_from(directory + "model.pt");
     const auto keys = decoder_param_keys(*this);
@@ -1209,6 +1210,7 @@ shared_ptr<Model> initModelFromConfig(const ModelConfig& c, std::vector<torch::D
 }
 
 void Model::train_batch(shared_ptr<Batch> batch, bool call_step) {
+    if (ranges_valid_) drop_ranges();  // the caller applies the update itself (updateEmbeddings / indexAdd): nothing tracks the tables' magnitude
     if (!fused_ok()) return train_batch_generic(batch, call_step);
     if (call_step) clear_grad();
     forward_lp_train(batch);
@@ -1287,6 +1289,7 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
 }
 
 void Model::backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step) {
+    if (ranges_valid_) drop_ranges();  // sharded table: the rows come from other ranks' shards, whose magnitudes this rank does not track
     forward_lp_train(batch);
     model_backward(*this, batch);
     bool done = false;

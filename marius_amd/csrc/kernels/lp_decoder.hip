@@ -1206,8 +1206,10 @@ static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layou
     const bool flash = kernel_level() == 2 && flash_applicable(d, D);
     L->flash = flash ? 1 : 0;
     L->reserved_ = 0;
-    if (!flash || flash_store_scores(d)) {  // the flash path never materialises the scores
-        base = take(rows * D.n_ld * 4 * D.ndir);
+    if (!flash || flash_store_scores(d) || flash_chunked(D.d)) {  // the flash path never materialises the scores — except for rows wider than 128 columns
+        size_t sbytes = rows * D.n_ld * 4 * D.ndir;
+        if (flash && flash_chunked(D.d) && flash_tiled_scores_bytes(D) > sbytes) sbytes = flash_tiled_scores_bytes(D);  // tile order needs whole tiles
+        base = take(sbytes);
         for (int dir = 0; dir < D.ndir; ++dir) L->neg[dir] = base + (size_t)dir * rows * D.n_ld * 4;
     }
     base = take(rows * 4 * D.ndir);
@@ -1335,7 +1337,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
 
     if (L->flash) {  // training-only path: operand records + SoftmaxCE row statistics, no score tensor (lp_flash.hip)
         MARIUS_REQUIRE(kernel_level() == 2 && flash_applicable(desc, D), "lp_forward: the layout was planned for the flash path but the descriptor / environment no longer selects it");
-        float* S = (flash_store_scores(desc) && L->neg[0]) ? (float*)(ws + L->neg[0]) : nullptr;
+        float* S = ((flash_store_scores(desc) || flash_chunked(D.d)) && L->neg[0]) ? (float*)(ws + L->neg[0]) : nullptr;
         const int64_t CNf = (int64_t)D.C * D.N;
         const int64_t occ_off[2] = {2 * D.B + (desc->src_neg ? CNf : 0), 2 * D.B};  // gocc rows of the dst / src negatives (map_tensors order)
         float* dadj0 = (float*)(ws + L->dadj[0]);
@@ -1502,7 +1504,8 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
         bool done = false;
         if (L->flash) {
             const bool filtered = (desc->dst_filter && desc->n_dst_filter > 0) || (D.ndir == 2 && desc->src_filter && desc->n_src_filter > 0);
-            rc = flash_backward(desc, D, ws + L->adjrec, ws + L->negrec, ga.dadj, ga.gocc, ga.negocc_off, (const float2*)(ws + L->fpart), filtered, st);
+            rc = flash_backward(desc, D, ws + L->adjrec, ws + L->negrec, ga.dadj, ga.gocc, ga.negocc_off, (const float2*)(ws + L->fpart), filtered,
+                                flash_chunked(D.d) ? (float*)(ws + L->neg[0]) : nullptr, st);
             if (rc) return rc;
             done = true;
         }
@@ -1564,7 +1567,7 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     ea.lse = nullptr;
     ea.gscale = D.gscale;
     ea.keep_dadj = 0;
-    if (L->flash && flash_fused()) {
+    if (L->flash && flash_fused() && !flash_chunked(D.d)) {  // (rows wider than 128 take the stored-score launches: dadj is final there)
         ea.dadj2 = ga.dadj + (size_t)D.ndir * D.Bp * D.d_ld;
         ea.part = (const float2*)(ws + L->fpart);
         ea.lse = (const float*)(ws + L->lse[0]);

@@ -60,7 +60,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // exceeds it by more than FL_TAU; the unnormalised sums leave the kernel as (mref, sum V) statistics plus the unnormalised dAdj partial of
 // every (tile, contributor), and the consumer (lp_edge_bwd*) scales by g exp(mref - lse).  One score contraction less per step (4 instead
 // of 5), no zero fill of dadj, no atomics.  FLASH_FWD + FLASH_DADJ remain as MARIUS_FLASH_FUSED=0 and for the score-storing parity runs.
-enum { FLASH_FWD = 0, FLASH_DADJ = 1, FLASH_DNEG = 2, FLASH_FDADJ = 3 };
+// d > 128 (round 3; cfg5's d = 400): the stationary operand of a tile no longer fits the register file, so the contraction index is cut into
+// nch equal column chunks of <= 128 (400 = 4 x 100) with one operand-record set per chunk, and the scores ARE materialised (fp32 [Bp, n_ld]):
+//   FLASH_FWDS   one launch per chunk: S += adj_c . neg_c^T (the first chunk stores, the last also leaves the SoftmaxCE row statistics);
+//   FLASH_DADJS / FLASH_DNEGS   one launch per chunk: V = exp(S - lse) from the stored scores, dAdj[:, chunk] = V neg_c, dNeg[:, chunk] = V^T adj_c.
+// Same tiles, ring and MFMA phases as the d <= 128 kernels; what replaces the FP32-MFMA kernels' 1.6 ms of matrix time is 3 x 16-bit products.
+// The stored scores live in tile order and travel through a second LDS ring (DMA, two items ahead, same counted waits as the blocks): with the
+// tile fetched by ordinary loads one item ahead these launches were latency-bound (4.9 us per item, cfg5 step 2.18 ms = no faster than the
+// FP32 path); with the ring 1.78 ms.  Three slots + two score tiles = 80 KB at KS >= 7, so two workgroups still share a CU (four + three
+// slots at one workgroup per CU: 1.91 ms).
+enum { FLASH_FWD = 0, FLASH_DADJ = 1, FLASH_DNEG = 2, FLASH_FDADJ = 3, FLASH_FWDS = 4, FLASH_DADJS = 5, FLASH_DNEGS = 6 };
+__host__ __device__ constexpr int fl_base(int mode) { return mode == FLASH_FWDS ? FLASH_FWD : mode == FLASH_DADJS ? FLASH_DADJ : mode == FLASH_DNEGS ? FLASH_DNEG : mode; }
 constexpr float FL_TAU = 8.f;  // log2 units: V <= 2^8 between raises (bf16 / fp32 share the exponent range: no overflow, no lost precision)
 
 // FL_WAVES_N=8 (256-row stationary tile, one workgroup per CU, six slots) halves the streamed bytes per flop; measured slower at the
@@ -73,8 +83,17 @@ constexpr int FL_WAVES = FL_WAVES_N, FL_NT = 64 * FL_WAVES, FL_XT = 32 * FL_WAVE
 #ifndef FL_FWD_SLOTS
 #define FL_FWD_SLOTS 3
 #endif
-__host__ __device__ constexpr int fl_slots(int mode) { return FL_WAVES == 8 ? 6 : (mode == 0 ? FL_FWD_SLOTS : 4); }
-__host__ __device__ constexpr int fl_wg_per_cu(int mode) { return FL_WAVES == 8 ? 1 : (mode == 0 ? (FL_FWD_SLOTS == 3 ? 3 : 2) : 2); }
+// FL_S_DEEP=1: four block slots + three score-tile slots, one workgroup per CU; 0: three + two (both two items ahead), two workgroups per CU
+#ifndef FL_S_DEEP
+#define FL_S_DEEP 0
+#endif
+__host__ __device__ constexpr int fl_slots(int mode) { return FL_WAVES == 8 ? 6 : (mode == 0 ? FL_FWD_SLOTS : (mode >= 4 && !FL_S_DEEP) ? 3 : 4); }
+// the stored-score modes (d > 128) keep a second ring beside the streamed blocks — the 16 KB score tile of every item in flight — and
+// run one workgroup per CU for it
+constexpr int FL_STILE = FL_XT * FL_YB * 4;
+__host__ __device__ constexpr int fl_sslots(int mode) { return mode >= 4 ? (FL_S_DEEP ? 3 : 2) : 0; }
+__host__ __device__ constexpr int fl_sring_bytes(int mode) { return fl_sslots(mode) * FL_STILE; }
+__host__ __device__ constexpr int fl_wg_per_cu(int mode) { return (FL_WAVES == 8 || (mode >= 4 && FL_S_DEEP)) ? 1 : (mode == 0 ? (FL_FWD_SLOTS == 3 ? 3 : 2) : 2); }
 constexpr float FL_LOG2E = 1.4426950408889634f, FL_LN2 = 0.6931471805599453f;
 
 __host__ __device__ constexpr int fl_pitch(int KS) { return 64 * KS + 16; }                                    // bytes per record
@@ -103,6 +122,8 @@ struct FlashArgs {
     // FDADJ: positive scores [ndir Bp] (initial reference of the online softmax); out = partial of a tile's first contributor, out2 = of its second
     const float* pos;
     float* out2;
+    int chunk_first, chunk_last;  // FWDS: this launch handles the first / last column chunk of the contraction index
+    int s_tiled;                  // stored scores in tile order [chunk-direction][128-row adj tile][32-column block][128][32] (internal) instead of [Bp, n_ld]
     FlRange rg;  // operand scales (fp16 records) are derived from it by every kernel of the step
     // score filter (apply_score_filter, negative.cpp:306-311: listed (row, column) scores count as -1e9): entries bucketed by item,
     // foff[item] .. foff[item + 1] into fent; an entry = (stationary row inside the 128-row tile) << 5 | (streamed row inside the block).
@@ -137,8 +158,9 @@ __device__ __forceinline__ void fl_write_piece(char* rec, int KP, int piece, flo
 }
 
 // adj [ndir][Bp][d_ld] fp32 (written by lp_prep*) -> adj records; chunk c of direction dir holds rows c Bc .. (c + 1) Bc of that direction
+// d = columns of this record set, taken from column col0 on (one set per column chunk when the rows are wider than 128)
 __global__ __launch_bounds__(256) void flash_pack_adj_kernel(const float* __restrict__ adj, int64_t d_ld, int64_t Bp, int Bc, int C, int ndir, int d,
-                                                             int KP, int XR, char* __restrict__ rec, FlRange rg) {
+                                                             int KP, int XR, char* __restrict__ rec, FlRange rg, int col0) {
     const int ppr = KP / 4 + 1;  // pieces per record (+1: the tail)
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nrec = (int64_t)ndir * C * XR;
@@ -156,7 +178,7 @@ __global__ __launch_bounds__(256) void flash_pack_adj_kernel(const float* __rest
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (x < Bc && 4 * piece < d) {
         const int64_t dir = cd / C, c = cd - dir * C;
-        const float* src = adj + (dir * Bp + c * Bc + x) * d_ld + 4 * piece;
+        const float* src = adj + (dir * Bp + c * Bc + x) * d_ld + col0 + 4 * piece;
         if (4 * piece + 3 < d) v = *reinterpret_cast<const float4*>(src);
         else {
             v.x = src[0];
@@ -172,7 +194,7 @@ __global__ __launch_bounds__(256) void flash_pack_adj_kernel(const float* __rest
 __global__ __launch_bounds__(256) void flash_pack_neg_kernel(const float* __restrict__ emb, int64_t emb_ld, const int64_t* __restrict__ neg0,
                                                              const int64_t* __restrict__ neg1, int N, int C, int ndir, int d, int KP, int NR,
                                                              int vec, char* __restrict__ rec, float* __restrict__ gocc, int64_t d_ld, int64_t off0,
-                                                             int64_t off1, FlRange rg) {
+                                                             int64_t off1, FlRange rg, int col0) {
     const int ppr = KP / 4 + 1;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nrec = (int64_t)ndir * C * NR;
@@ -192,10 +214,10 @@ __global__ __launch_bounds__(256) void flash_pack_neg_kernel(const float* __rest
         const int64_t dir = cd / C, c = cd - dir * C;
         if (4 * piece < d) {
             const int64_t id = (dir ? neg1 : neg0)[c * N + j];
-            v = load_row4(emb + id * emb_ld, 4 * piece, d, vec);
+            v = load_row4(emb + id * emb_ld + col0, 4 * piece, d, vec);
         }
         // the negative's gradient row is accumulated by at most two workgroups of the backward: it starts from zero
-        if (4 * piece < d_ld) *reinterpret_cast<float4*>(gocc + ((dir ? off1 : off0) + c * N + j) * d_ld + 4 * piece) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col0 + 4 * piece < d_ld) *reinterpret_cast<float4*>(gocc + ((dir ? off1 : off0) + c * N + j) * d_ld + col0 + 4 * piece) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (rg.absmax) fl_write_piece<true>(o, KP, piece, v, fl_scales(rg.absmax, rg.has_rel, rg.relop_k).s_neg);
     else fl_write_piece<false>(o, KP, piece, v, 1.f);
@@ -351,10 +373,12 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
     // ---- scales (all powers of two).  Accumulated scores carry s_x s_y; V = exp2(...) is formed VSH binades up so that its fp16 halves keep
     // their bits (V <= 2^FL_TAU in the fused sweep, <= 1 where lse is known); the outputs are scaled back when they leave the registers.
     const FlScales sc_ = fl_scales(F16 ? a.rg.absmax : nullptr, a.rg.has_rel, a.rg.relop_k);
-    const float s_y = (MODE == FLASH_DNEG) ? sc_.s_adj : sc_.s_neg;
+    constexpr int BASE = fl_base(MODE);                                      // which of the d <= 128 kernels this launch is shaped like
+    constexpr bool SACC = (MODE == FLASH_FWDS), SLOAD = (MODE == FLASH_DADJS || MODE == FLASH_DNEGS);
+    const float s_y = (BASE == FLASH_DNEG) ? sc_.s_adj : sc_.s_neg;
     const float inv_xy = 1.f / (sc_.s_adj * sc_.s_neg);
-    const float c_s = FL_LOG2E * inv_xy;          // accumulator -> score in log2 units
-    constexpr float VSH = !F16 ? 0.f : (MODE == FLASH_FDADJ ? 6.f : (MODE == FLASH_FWD ? 0.f : 14.f));
+    const float c_s = (SACC || SLOAD) ? FL_LOG2E : FL_LOG2E * inv_xy;        // t[] -> score in log2 units (stored scores are in true units)
+    constexpr float VSH = !F16 ? 0.f : (MODE == FLASH_FDADJ ? 6.f : (BASE == FLASH_FWD ? 0.f : 14.f));
     const float out_unscale = __builtin_amdgcn_exp2f(-VSH) / s_y;
     constexpr int NCT = (KP + 31) / 32;       // 32-column tiles of the gradient output
     constexpr int DMA_PER_WAVE = SLOT / (FL_WAVES * 1024);  // 1 KB wave-instructions per wave and tile
@@ -393,10 +417,67 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
         }
     };
 
+    // stored-score modes, tile order: the score tile of an item travels with its streamed block, straight into LDS (a register prefetch cannot
+    // be three items deep without the compiler moving half-loaded registers about; one item of distance leaves HBM latency exposed: 4.9 us
+    // per item at cfg5's shape).  A wave's part of a tile is one contiguous 4 KB run in both layouts: forward / dAdj — rows 32 wave .. + 31 of
+    // the item's own [128][32] tile; dNeg — rows (32 yph & 127) .. + 31 of tile (adj tile yph / 4, negative block 4 xt + wave).  The wave that
+    // fetches a part is the only one that reads it.
+    constexpr int S_DMA = 4;  // 1 KB wave-instructions per wave and score tile
+    constexpr int SSLOTS = fl_sslots(MODE) > 0 ? fl_sslots(MODE) : 1;  // score tiles in flight = the distance of the block ring (NSLOT - 1)
+    auto dma_s = [&](int tile_, int yph_, int slot_) {
+        const int cd_ = tile_ / a.XT, xt_ = tile_ - cd_ * a.XT;
+        const float* src;
+        if (BASE != FLASH_DNEG) {
+            src = a.S + ((((int64_t)cd_ * a.XT + xt_) * a.YB + yph_) * FL_XT + wave * 32) * FL_YB;
+        } else {
+            const int nta = (a.Yrows + FL_XT - 1) / FL_XT, nnb = (a.Xrows + FL_YB - 1) / FL_YB;
+            const int nb = min(xt_ * 4 + wave, nnb - 1);
+            const int y0 = yph_ * FL_YB;
+            src = a.S + ((((int64_t)cd_ * nta + (y0 >> 7)) * nnb + nb) * FL_XT + (y0 & 127)) * FL_YB;
+        }
+        const char* sp = reinterpret_cast<const char*>(src) + lane * 16;
+        const unsigned dst = lds_base + (unsigned)(NSLOT * SLOT) + (unsigned)(slot_ * FL_STILE) + (unsigned)(wave_u * 4096);
+#pragma unroll
+        for (int i = 0; i < S_DMA; ++i) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(sp + i * 1024), "s"(dst + (unsigned)(i * 1024))
+                         : "memory");
+        }
+    };
+    auto s_take = [&](int xt_, int yph_, int slot_, float (&v)[16]) {  // this lane's sixteen scores of the item out of the LDS tile; outside the matrix: -inf
+        const unsigned char* base = smem + NSLOT * SLOT + slot_ * FL_STILE + wave * 4096;
+        const int xq = xt_ * FL_XT + wave * 32 + l31;
+        if (BASE != FLASH_DNEG) {
+            const float* row = reinterpret_cast<const float*>(base) + l31 * FL_YB + 8 * h;
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float4 f = *reinterpret_cast<const float4*>(row + 16 * s_ + 4 * q);
+                    v[8 * s_ + 4 * q] = f.x;
+                    v[8 * s_ + 4 * q + 1] = f.y;
+                    v[8 * s_ + 4 * q + 2] = f.z;
+                    v[8 * s_ + 4 * q + 3] = f.w;
+                }
+            }
+        } else {
+            const float* col = reinterpret_cast<const float*>(base) + l31;
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) v[r_] = col[(16 * (r_ >> 3) + 8 * h + (r_ & 7)) * FL_YB];
+        }
+#pragma unroll
+        for (int r_ = 0; r_ < 16; ++r_) {
+            const int yq = yph_ * FL_YB + 16 * (r_ >> 3) + 8 * h + (r_ & 7);
+            if (!(xq < a.Xrows && yq < a.Yrows)) v[r_] = -INFINITY;
+        }
+    };
+
     // stationary fragments (B operand of the S-MFMA): lane holds X[x = l31][k = 16 ks + 8 h .. + 7], hi and lo
     v8bf xh[KS], xl[KS];
     float lsec_x = 0.f;     // DADJ: lsec of the lane's own adj row
-    v16f out[MODE == FLASH_FWD ? 1 : NCT];
+    v16f out[BASE == FLASH_FWD ? 1 : NCT];
     float m2 = -INFINITY, lsum = 0.f;  // FWD: running max of S log2(e) and sum of exp2 over this lane's columns
     float mref = 0.f;                  // FDADJ: reference of the lane's own row x = l31 (log2 units; the same in both lane halves); lsum: this lane's share of sum V
 
@@ -417,7 +498,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
             xh[ks] = *reinterpret_cast<const v8bf*>(r + 32 * ks + 16 * h);
             xl[ks] = *reinterpret_cast<const v8bf*>(r + 2 * KP + 32 * ks + 16 * h);
         }
-        if (MODE == FLASH_DADJ) lsec_x = *reinterpret_cast<const float*>(r + 4 * KP);
+        if (BASE == FLASH_DADJ) lsec_x = *reinterpret_cast<const float*>(r + 4 * KP);
         if (MODE == FLASH_FDADJ) {  // the row's positive score is a term of the same softmax: start from it (rows past Xrows are never stored)
             mref = (x < a.Xrows) ? a.pos[(int64_t)dir * a.Bp + (int64_t)c_ * a.Bc + x] * FL_LOG2E : 0.f;
             lsum = 0.f;
@@ -425,7 +506,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
         // land the fragments HERE: hipcc's own wait for them would otherwise sit at their first use inside the item loop, and since
         // it cannot see the DMAs of the asm statements it would read as vmcnt(0..3) there — draining the ring every iteration
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        if (MODE != FLASH_FWD) {
+        if (BASE != FLASH_FWD) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -438,7 +519,8 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
 
     auto flush = [&](int y_last_excl) {
         const bool first = (y_first == 0), last = (y_last_excl == a.YB);
-        if (MODE == FLASH_FWD) {
+        if (SACC && !a.chunk_last) return;  // the statistics exist only once the last column chunk has been added
+        if (BASE == FLASH_FWD) {
             // combine the two lane halves (disjoint columns of the same row), then one (m, l) pair per row
             const float m_o = __shfl_xor(m2, 32, 64), l_o = __shfl_xor(lsum, 32, 64);
             const float mm = fmaxf(m2, m_o);
@@ -483,7 +565,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
             }
         } else {
             const bool sole = first && last;
-            const int64_t base = (MODE == FLASH_DADJ) ? ((int64_t)dir * a.Bp + (int64_t)c_ * a.Bc) : (a.negocc_off[dir] + (int64_t)c_ * a.N);
+            const int64_t base = (BASE == FLASH_DADJ) ? ((int64_t)dir * a.Bp + (int64_t)c_ * a.Bc) : (a.negocc_off[dir] + (int64_t)c_ * a.N);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const int col = 32 * ct + l31;
@@ -496,6 +578,84 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
                         else unsafeAtomicAdd(p, out[ct][r_] * out_unscale);
                     }
                 }
+            }
+        }
+    };
+
+    // ---- stored scores (d > 128 modes): the [Bp, n_ld] fp32 matrix S, read / written in this lane's accumulator layout.  Register 8 s + e of
+    // lane (l31, h) is S[adj row][neg column] with (adj row, neg column) = (x, y) when the adj rows are stationary and (y, x) in dNeg, where
+    // x = 128 xt + 32 wave + l31 and y = 32 yph + 16 s + 8 h + e: 8 consecutive columns of one row (two 16-B accesses) in the first case, one
+    // element of 16 different rows — 32 lanes side by side along a row — in the second.  Entries outside the matrix read as -inf (V = 0).
+    auto s_tile = [&](int tile_, int yph_, float (&v)[16], bool store) {
+        const int cd_ = tile_ / a.XT, xt_ = tile_ - cd_ * a.XT;
+        const int dir_ = cd_ / a.C, cc_ = cd_ - dir_ * a.C;
+        const int xq = xt_ * FL_XT + wave * 32 + l31;
+        if (a.s_tiled) {
+            // tile order: the 128 x 32 scores of (adj tile ta, negative block nb) of a chunk-direction are one contiguous 16 KB run, row-major
+            // inside.  Forward / dAdj (adj rows stationary): this item IS such a run — a wave's access is 4 KB contiguous.  dNeg (negative
+            // columns stationary): lane l31 is column l31 of negative block (4 xt + wave), register r_ is adj row 32 yph + 16 (r_ >> 3) + 8 h +
+            // (r_ & 7) of adj tile yph / 4 — 32 lanes read one 128-B line, the lines of consecutive rows are adjacent.
+            if (BASE != FLASH_DNEG) {
+                const int nta = a.XT, nnb = a.YB;
+                float* base = a.S + ((((int64_t)cd_ * nta + xt_) * nnb + yph_) * FL_XT + wave * 32 + l31) * FL_YB;
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int yl = 16 * s_ + 8 * h + 4 * q;
+                        const int yq = yph_ * FL_YB + yl;
+                        if (store) {
+                            *reinterpret_cast<float4*>(base + yl) = make_float4(v[8 * s_ + 4 * q], v[8 * s_ + 4 * q + 1], v[8 * s_ + 4 * q + 2], v[8 * s_ + 4 * q + 3]);
+                        } else {
+                            const float4 f = *reinterpret_cast<const float4*>(base + yl);
+                            const bool xo = xq < a.Xrows;
+                            v[8 * s_ + 4 * q] = (xo && yq < a.Yrows) ? f.x : -INFINITY;
+                            v[8 * s_ + 4 * q + 1] = (xo && yq + 1 < a.Yrows) ? f.y : -INFINITY;
+                            v[8 * s_ + 4 * q + 2] = (xo && yq + 2 < a.Yrows) ? f.z : -INFINITY;
+                            v[8 * s_ + 4 * q + 3] = (xo && yq + 3 < a.Yrows) ? f.w : -INFINITY;
+                        }
+                    }
+                }
+            } else {
+                // adj tiles / negative blocks as the forward numbered them (here Yrows = adj rows per chunk, Xrows = negatives per chunk)
+                const int nta = (a.Yrows + FL_XT - 1) / FL_XT, nnb = (a.Xrows + FL_YB - 1) / FL_YB;
+                const int nb = min(xt_ * 4 + wave, nnb - 1);  // clamped: every lane issues every load (the counted waits below rely on it)
+#pragma unroll
+                for (int r_ = 0; r_ < 16; ++r_) {
+                    const int yrow = yph_ * FL_YB + 16 * (r_ >> 3) + 8 * h + (r_ & 7);
+                    const bool ok = xq < a.Xrows && yrow < a.Yrows;
+                    v[r_] = ok ? a.S[((((int64_t)cd_ * nta + (yrow >> 7)) * nnb + nb) * FL_XT + (yrow & 127)) * FL_YB + l31] : -INFINITY;
+                }
+            }
+            return;
+        }
+        if (BASE != FLASH_DNEG) {
+            float* row = a.S + ((int64_t)dir_ * a.Bp + (int64_t)cc_ * a.Bc + xq) * a.n_ld;
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const int y0 = yph_ * FL_YB + 16 * s_ + 8 * h;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int yq = y0 + 4 * q;
+                    const bool ok = xq < a.Xrows && yq + 3 < (int)a.n_ld;
+                    if (store) {
+                        if (ok) *reinterpret_cast<float4*>(row + yq) = make_float4(v[8 * s_ + 4 * q], v[8 * s_ + 4 * q + 1], v[8 * s_ + 4 * q + 2], v[8 * s_ + 4 * q + 3]);
+                    } else {
+                        float4 f = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                        if (ok) f = *reinterpret_cast<const float4*>(row + yq);
+                        v[8 * s_ + 4 * q] = yq < a.Yrows ? f.x : -INFINITY;
+                        v[8 * s_ + 4 * q + 1] = yq + 1 < a.Yrows ? f.y : -INFINITY;
+                        v[8 * s_ + 4 * q + 2] = yq + 2 < a.Yrows ? f.z : -INFINITY;
+                        v[8 * s_ + 4 * q + 3] = yq + 3 < a.Yrows ? f.w : -INFINITY;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) {
+                const int yrow = yph_ * FL_YB + 16 * (r_ >> 3) + 8 * h + (r_ & 7);
+                const bool ok = xq < a.Xrows && yrow < a.Yrows;
+                v[r_] = ok ? a.S[((int64_t)dir_ * a.Bp + (int64_t)cc_ * a.Bc + yrow) * a.n_ld + xq] : -INFINITY;
             }
         }
     };
@@ -537,13 +697,25 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
             }
         }
     };
+    const bool s_loads = SLOAD || (SACC && !a.chunk_first);
+    const bool s_lds = (SACC || SLOAD) && a.s_tiled && SSLOTS == NSLOT - 1;
 #pragma unroll
     for (int i = 0; i < NSLOT - 1; ++i) {
+        if constexpr (SACC || SLOAD) {
+            if (s_lds && s_loads) dma_s(ptile, ps.lo + ps.r, i % SSLOTS);
+        }
         dma(ptile, ps.lo + ps.r, i);
         padvance();
     }
 
+    // row-major scores (MARIUS_LP_STORE_SCORES, parity runs): the next item's tile through ordinary loads, one item ahead
+    float tnext[16];
+    if constexpr (SACC || SLOAD) {
+        if (!s_lds && s_loads) s_tile(tile, cs.lo + cs.r, tnext, false);
+    }
+
     int slot = 0, pslot = NSLOT - 1;  // ring positions of item `it` and of the tile the next DMA fills
+    int sslot = 0;                    // score-tile ring position of item `it` (read out at the top of the item, refilled at once)
     for (int it = it0; it < it1; ++it) {
         if (tile != cur_tile) {
             if (cur_tile >= 0) flush(a.YB);
@@ -556,26 +728,78 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
         cs.r = cs.r + 1 == cs.len ? 0 : cs.r + 1;
         // tile `it` has landed once at most the NSLOT - 2 younger tiles' pieces are outstanding (loads retire in order; the x fragments
         // loaded above are younger still, so this over-waits at a tile switch, never under-waits)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * DMA_PER_WAVE) : "memory");
-        __builtin_amdgcn_s_barrier();
+        float tcur[16];
+        if constexpr (SACC || SLOAD) {
+            if (s_lds) {
+                // issued after this item's requests (its score tile, then its block): the requests of the NSLOT - 2 items behind it and the
+                // score stores of the (at most NSLOT - 1) items finished since; in-order retirement turns `at most that many outstanding` into
+                // `this item has landed`
+                constexpr int AHEAD = NSLOT - 2;  // whole items requested after this one
+                const int k = SACC ? min(it - it0, NSLOT - 1) : 0;
+                if (s_loads) {
+                    if (k == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * (S_DMA + DMA_PER_WAVE)) : "memory");
+                    else if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * (S_DMA + DMA_PER_WAVE) + 4) : "memory");
+                    else if (k == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * (S_DMA + DMA_PER_WAVE) + 8) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * (S_DMA + DMA_PER_WAVE) + 12) : "memory");
+                } else {
+                    if (k == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * DMA_PER_WAVE) : "memory");
+                    else if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * DMA_PER_WAVE + 4) : "memory");
+                    else if (k == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * DMA_PER_WAVE + 8) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * DMA_PER_WAVE + 12) : "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                if (s_loads) {
+                    s_take(xt, yph, sslot, tcur);
+                    dma_s(ptile, ps.lo + ps.r, sslot);  // the slot just read out takes the tile of the item the block DMA below fetches
+                    sslot = sslot + 1 == SSLOTS ? 0 : sslot + 1;
+                }
+            } else {
+                // ordinary loads one item ahead; everything (this item's streamed block included) is drained at the top
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (s_loads) {
+#pragma unroll
+                    for (int r_ = 0; r_ < 16; ++r_) tcur[r_] = tnext[r_];
+                    if (it + 1 < it1) {  // next item: same tile (cs has already advanced) or the first block of the next tile's segment
+                        int n_tile = tile, n_yb = yb + 1;
+                        if (n_yb == a.YB) ++n_tile;
+                        const Seg ns = (n_tile != tile) ? seg_init(n_tile, it + 1) : cs;
+                        s_tile(n_tile, ns.lo + ns.r, tnext, false);
+                    }
+                }
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * DMA_PER_WAVE) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         dma(ptile, ps.lo + ps.r, pslot);
         padvance();
         pslot = pslot + 1 == NSLOT ? 0 : pslot + 1;
         const unsigned char* T = smem + slot * SLOT;
         uint32_t fo0 = 0u, fo1 = 0u;  // filter entries of this item (loaded ahead of the matrix phase that hides the latency)
-        if (MODE != FLASH_FWD && a.foff) {
+        if (BASE != FLASH_FWD && a.foff) {
             const int64_t key = ((int64_t)cd * a.XT + xt) * a.YB + yph;
             fo0 = a.foff[key];
             fo1 = a.foff[key + 1];
         }
 
         // ---- S tile: D[y][x] = sum_k Y[y][k] X[x][k]
-        const v16f accS = fl_score_tile<KS, F16>(T, a_off, xh, xl);
+        v16f accS;
+        if constexpr (!SLOAD) accS = fl_score_tile<KS, F16>(T, a_off, xh, xl);
 
-        if (MODE == FLASH_FWD) {
+        if (BASE == FLASH_FWD) {
             float t[16];
 #pragma unroll
             for (int r_ = 0; r_ < 16; ++r_) t[r_] = accS[r_];
+            if constexpr (SACC) {  // S (true units) = what the earlier chunks left + this chunk's part; every chunk but the last only stores it
+                const float invs = 1.f / (sc_.s_adj * sc_.s_neg);
+#pragma unroll
+                for (int r_ = 0; r_ < 16; ++r_) t[r_] = a.chunk_first ? t[r_] * invs : fmaf(t[r_], invs, tcur[r_] == -INFINITY ? 0.f : tcur[r_]);
+                s_tile(tile, yph, t, true);
+            }
+            if (SACC && !a.chunk_last) {
+                // nothing else to do for this item
+            } else {
             if (STORE_S) {  // parity / debug only: scattered 4-B stores
                 const int x = xt * FL_XT + wave * 32 + l31;
 #pragma unroll
@@ -606,10 +830,11 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
                 lsum = lsum * __builtin_amdgcn_exp2f(m2 - mn) + (s0 + s1);
                 m2 = mn;
             }
+            }
         } else {
             float t[16];
 #pragma unroll
-            for (int r_ = 0; r_ < 16; ++r_) t[r_] = accS[r_];
+            for (int r_ = 0; r_ < 16; ++r_) t[r_] = SLOAD ? tcur[r_] : accS[r_];
             if (fo1 != fo0) {  // filtered scores of this item: the reference overwrites them with -1e9 before the loss
                 for (uint32_t q = fo0; q < fo1; ++q) {
                     const int ent = a.fent[q];
@@ -660,7 +885,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
                     for (int q = 0; q < 2; ++q) {
                         const int r_ = 8 * s_ + e + q;
                         float ls;
-                        if (MODE == FLASH_DADJ) ls = lsec_x;
+                        if (BASE == FLASH_DADJ) ls = lsec_x;
                         else if (MODE == FLASH_FDADJ) ls = mref;
                         else ls = *reinterpret_cast<const float*>(T + (16 * s_ + fl_rho(8 * h + e + q)) * P + 4 * KP);
                         w2[q] = __builtin_amdgcn_exp2f(fmaf(t[r_], c_s, VSH - ls));
@@ -674,7 +899,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
                 }
             }
             // ---- out[x][col] += sum_y V[y][x] Y[y][col]
-            if constexpr (MODE != FLASH_FWD) {
+            if constexpr (BASE != FLASH_FWD) {
                 const v8bf whv[2] = {wh[0].v, wh[1].v}, wlv[2] = {wl[0].v, wl[1].v};
                 fl_grad_tile<KS, NCT, F16>(T, tr_off, whv, wlv, out);
             }
@@ -691,7 +916,8 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
 // lse = log(e^pos + sum over the (at most two) partials), row loss, dL/dpos, per-block loss sums; patches lsec into the adj records.
 __global__ __launch_bounds__(256) void flash_merge_kernel(const float2* __restrict__ part, const float* __restrict__ pos, int64_t rows, int64_t Bp,
                                                           int Bc, int C, int XR, int KP, float* __restrict__ lse, float* __restrict__ rowloss,
-                                                          float* __restrict__ dpos, float gscale, float* __restrict__ blocksum, char* __restrict__ adjrec) {
+                                                          float* __restrict__ dpos, float gscale, float* __restrict__ blocksum, char* __restrict__ adjrec,
+                                                          int nsets, int64_t set_bytes) {
     __shared__ float red[256];
     const int64_t bpd = (Bp + 255) / 256;
     const int64_t dir = blockIdx.x / bpd, blk = blockIdx.x - dir * bpd;
@@ -713,7 +939,8 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(const float2* __restri
         const int64_t c = r / Bc;
         const int x = (int)(r - c * Bc);
         const int P = 4 * KP + 16;
-        *reinterpret_cast<float*>(adjrec + ((dir * C + c) * XR + fl_rho(x)) * (int64_t)P + 4 * KP) = l * FL_LOG2E - log2f(gscale);
+        for (int q = 0; q < nsets; ++q)  // every column chunk's record set carries the row's lsec
+            *reinterpret_cast<float*>(adjrec + q * set_bytes + ((dir * C + c) * XR + fl_rho(x)) * (int64_t)P + 4 * KP) = l * FL_LOG2E - log2f(gscale);
     }
     red[threadIdx.x] = mine;
     __syncthreads();
@@ -725,7 +952,25 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(const float2* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------- host side
-static int fl_ks(int d) { return (d + 15) / 16; }
+// column chunks of the contraction index: one for d <= 128, ceil(d / 128) equal ones above (each a multiple of 4 columns: 400 = 4 x 100);
+// 0 = this d cannot be cut that way
+int flash_chunks(int d) {
+    if (d <= 128) return 1;
+    const char* e = getenv("MARIUS_FLASH_WIDE");  // 0: rows wider than 128 columns stay on the FP32 matrix path (A/B runs)
+    if (e && e[0] == '0') return 0;
+    const int n = (d + 127) / 128;
+    return (d % (4 * n) == 0 && d <= 1024) ? n : 0;
+}
+static int fl_kc(int d) { const int n = flash_chunks(d); return n > 0 ? d / n : d; }  // columns per chunk
+static int fl_ks(int d) { return (fl_kc(d) + 15) / 16; }
+bool flash_chunked(int d) { return flash_chunks(d) > 1; }
+// bytes of the stored scores in tile order (see s_tile in flash_kernel): whole 128 x 32 tiles
+size_t flash_tiled_scores_bytes(const LpDims& D) {
+    const size_t xt = (D.Bc + FL_XT - 1) / FL_XT, yb = ((D.N + 31) / 32 * 32) / FL_YB;
+    return (size_t)D.ndir * D.C * xt * yb * FL_XT * FL_YB * sizeof(float);
+}
+static size_t fl_adjset_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.Bc + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)); }
+static size_t fl_negset_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.N + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)); }
 
 // score-filter index (flash_filter_index_kernel): item counts of the two orientations, entry capacity, bytes behind the statistics in `fpart`
 struct FlFilterDims {
@@ -768,8 +1013,8 @@ bool flash_applicable(const marius_lp_desc* desc, const LpDims& D) {
     return true;
 }
 
-size_t flash_adjrec_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.Bc + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)) + 32768; }
-size_t flash_negrec_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.N + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)) + 32768; }
+size_t flash_adjrec_bytes(const LpDims& D) { return fl_adjset_bytes(D) * flash_chunks(D.d) + 32768; }   // one record set per column chunk
+size_t flash_negrec_bytes(const LpDims& D) { return fl_negset_bytes(D) * flash_chunks(D.d) + 32768; }
 static size_t fl_stats_bytes(const LpDims& D) { return ((size_t)2 * D.ndir * D.Bp * sizeof(float2) + 255) / 256 * 256; }
 // [statistics | filter index (offsets of both orientations, entries of both orientations)]
 size_t flash_part_bytes(const LpDims& D) { return fl_stats_bytes(D) + fl_filter_dims(D).bytes; }
@@ -800,7 +1045,7 @@ static int fl_num_wg(int64_t tiles, int mode) {
 
 template <int KS, int MODE, bool STORE_S, bool F16>
 static int fl_launch_t(const FlashArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)fl_slots(MODE) * fl_slot_bytes(KS);
+    const size_t lds = (size_t)fl_slots(MODE) * fl_slot_bytes(KS) + fl_sring_bytes(MODE);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_kernel<KS, MODE, STORE_S, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -848,9 +1093,11 @@ static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, cha
     a.rg = rg;
     const int xt_rows = FL_XT;
     const int XRa = (D.Bc + 31) / 32 * 32, NRn = (D.N + 31) / 32 * 32;
-    const bool xadj = (mode != FLASH_DNEG);
+    const bool xadj = (fl_base(mode) != FLASH_DNEG);
     a.pos = nullptr;
     a.out2 = nullptr;
+    a.chunk_first = a.chunk_last = 1;
+    a.s_tiled = 0;
     a.foff = nullptr;
     a.fent = nullptr;
     a.xrec = xadj ? adjrec : negrec;
@@ -885,24 +1132,41 @@ static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, cha
 // pos / dadj / dadj2: fused form only (flash_fused()): the sweep also leaves the unnormalised dAdj partials
 int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj, char* adjrec, char* negrec, float2* part, float* S, bool adj_packed,
                   float* gocc, const int64_t negocc_off[2], float* dadj_zero, const float* pos, float* dadj, float* dadj2, hipStream_t st) {
+    const bool s_tiled = flash_chunked(D.d) && !(desc->flags & MARIUS_LP_STORE_SCORES);  // nobody outside reads the scores: keep them in tile order
     const FlRange rg = flash_range(desc, D);
     const int ks = fl_ks(D.d), KP = 16 * ks;
     const int XR = (D.Bc + 31) / 32 * 32, NR = (D.N + 31) / 32 * 32;
     const int ppr = KP / 4 + 1;
-    if (!adj_packed) {
-        const int64_t n = (int64_t)D.ndir * D.C * XR * ppr;
-        flash_pack_adj_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(adj, D.d_ld, D.Bp, D.Bc, D.C, D.ndir, D.d, KP, XR, adjrec, rg);
-        if (dadj_zero) flash_zero_kernel<<<dim3(1024), dim3(256), 0, st>>>(dadj_zero, D.ndir * D.Bp * D.d_ld, nullptr, 0, nullptr, 0);
-    }
-    {
+    const int nch = flash_chunks(D.d), kc = fl_kc(D.d);  // column chunks of the contraction index (1 for d <= 128) and their width
+    const size_t adjset = fl_adjset_bytes(D), negset = fl_negset_bytes(D);
+    MARIUS_REQUIRE(nch == 1 || (!adj_packed && adj && S), "flash: rows wider than 128 need the fp32 adj rows and the score matrix");
+    for (int c = 0; c < nch; ++c) {
+        if (!adj_packed) {
+            const int64_t n = (int64_t)D.ndir * D.C * XR * ppr;
+            flash_pack_adj_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(adj, D.d_ld, D.Bp, D.Bc, D.C, D.ndir, kc, KP, XR, adjrec + c * adjset, rg, c * kc);
+        }
         const int64_t n = (int64_t)D.ndir * D.C * NR * ppr;
         flash_pack_neg_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(desc->emb, desc->emb_ld, desc->dst_neg, desc->src_neg, D.N, D.C, D.ndir,
-                                                                                 D.d, KP, NR, row_vec_width(desc->emb, desc->emb_ld, 4), negrec, gocc,
-                                                                                 D.d_ld, negocc_off[0], negocc_off[1], rg);
+                                                                                 kc, KP, NR, row_vec_width(desc->emb, desc->emb_ld, 4), negrec + c * negset, gocc,
+                                                                                 D.d_ld, negocc_off[0], negocc_off[1], rg, c * kc);
     }
+    if (!adj_packed && (dadj_zero || nch > 1)) flash_zero_kernel<<<dim3(1024), dim3(256), 0, st>>>(nch > 1 ? dadj : dadj_zero, D.ndir * D.Bp * D.d_ld, nullptr, 0, nullptr, 0);
     int rc = check_launch("flash_pack");
     if (rc) return rc;
     FlashArgs a;
+    if (nch > 1) {  // S += adj_c neg_c^T chunk by chunk; the last launch also leaves the row statistics
+        ProfScope ps(PROF_LP_SCORES, st);
+        for (int c = 0; c < nch && !rc; ++c) {
+            fl_common(a, D, FLASH_FWDS, adjrec + c * adjset, negrec + c * negset, rg);
+            a.part = part;
+            a.S = S;
+            a.chunk_first = c == 0;
+            a.chunk_last = c == nch - 1;
+            a.s_tiled = s_tiled ? 1 : 0;
+            rc = fl_dispatch<FLASH_FWDS, false>(ks, a, st);
+        }
+        return rc;
+    }
     if (!flash_fused() || S) {  // statistics-only sweep: the unfused form, and the score-storing parity runs (its statistics are then rewritten below)
         fl_common(a, D, FLASH_FWD, adjrec, negrec, rg);
         a.part = part;
@@ -949,7 +1213,7 @@ int flash_merge(const LpDims& D, const float2* part, const float* pos, float* ls
     const int64_t bpd = cdiv(D.Bp, 256);
     const int ks = fl_ks(D.d);
     flash_merge_kernel<<<dim3((unsigned)(bpd * D.ndir)), dim3(256), 0, st>>>(part, pos, D.Bp * D.ndir, D.Bp, D.Bc, D.C, (D.Bc + 31) / 32 * 32, 16 * ks, lse,
-                                                                            rowloss, dpos, D.gscale, blocksum, adjrec);
+                                                                            rowloss, dpos, D.gscale, blocksum, adjrec, flash_chunks(D.d), (int64_t)fl_adjset_bytes(D));
     return check_launch("flash_merge");
 }
 
@@ -957,11 +1221,40 @@ int flash_merge(const LpDims& D, const float2* part, const float* pos, float* ls
 // dadj and the negatives' gocc rows were zeroed by the forward's pack kernels (split tiles accumulate onto them)
 // part / filtered: fused form with a score filter — the index the forward built (orientation 1) sits behind the statistics
 int flash_backward(const marius_lp_desc* desc, const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2],
-                   const float2* part, bool filtered, hipStream_t st) {
+                   const float2* part, bool filtered, float* S, hipStream_t st) {
     const FlRange rg = flash_range(desc, D);
     const int ks = fl_ks(D.d);
     FlashArgs a;
     int rc = MARIUS_OK;
+    if (flash_chunked(D.d)) {  // V = exp(S - lse) from the stored scores; one (dAdj, dNeg) pair of launches per column chunk, each writing its columns
+        MARIUS_REQUIRE(S, "flash: rows wider than 128 need the score matrix");
+        const int nch = flash_chunks(D.d), kc = fl_kc(D.d);
+        const size_t adjset = fl_adjset_bytes(D), negset = fl_negset_bytes(D);
+        for (int c = 0; c < nch && !rc; ++c) {
+            fl_common(a, D, FLASH_DADJS, adjrec + c * adjset, negrec + c * negset, rg);
+            a.S = S;
+            a.s_tiled = (desc->flags & MARIUS_LP_STORE_SCORES) ? 0 : 1;
+            a.d = kc;
+            a.out = dadj + c * kc;
+            a.out_ld = D.d_ld;
+            {
+                ProfScope ps(PROF_LP_GRAD_ADJ, st);
+                rc = fl_dispatch<FLASH_DADJS, false>(ks, a, st);
+            }
+            if (rc) break;
+            fl_common(a, D, FLASH_DNEGS, adjrec + c * adjset, negrec + c * negset, rg);
+            a.S = S;
+            a.s_tiled = (desc->flags & MARIUS_LP_STORE_SCORES) ? 0 : 1;
+            a.d = kc;
+            a.out = gocc + c * kc;
+            a.out_ld = D.d_ld;
+            a.negocc_off[0] = negocc_off[0];
+            a.negocc_off[1] = negocc_off[1];
+            ProfScope ps(PROF_LP_GRAD_NEG, st);
+            rc = fl_dispatch<FLASH_DNEGS, false>(ks, a, st);
+        }
+        return rc;
+    }
     if (!flash_fused()) {  // fused form: dAdj left the forward sweep as partials (flash_forward)
         fl_common(a, D, FLASH_DADJ, adjrec, negrec, rg);
         a.out = dadj;

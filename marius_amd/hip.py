@@ -367,6 +367,14 @@ class LpWorkspace:
         return self._view(self.layout.pos[dir_], (self.layout.Bp,))
 
     def neg(self, dir_):
+        d = self.desc
+        if self.layout.flash and d.d > 128 and not (d.flags & LP_STORE_SCORES):
+            # rows wider than 128 columns: the flash path keeps its stored scores in tile order [chunk-direction][adj tile][negative block][128][32]
+            Bc = -(-d.B // d.C)
+            XT, YB = -(-Bc // 128), -(-d.N // 32)
+            per_dir = d.C * XT * YB * 128 * 32
+            t = self._view(self.layout.neg[0] + 4 * per_dir * dir_, (d.C, XT, YB, 128, 32))
+            return t.permute(0, 1, 3, 2, 4).reshape(d.C, XT * 128, YB * 32)[:, :Bc, : d.N].reshape(d.C * Bc, d.N)
         return self._view(self.layout.neg[dir_], (self.layout.Bp, self.layout.n_ld))[:, : self.desc.N]
 
     def lse(self, dir_):

@@ -212,6 +212,33 @@ def test_flash_score_filter_matches_oracle(H, dev, use_inverse, B, C, N, d, F):
     check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv_u, U, R, dst_filter=dst_filter, src_filter=src_filter if use_inverse else None)
 
 
+@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("decoder,use_inverse,B,C,N,d", [("COMPLEX", True, 1000, 4, 500, 400), ("COMPLEX", False, 2048, 4, 512, 400), ("DISTMULT", True, 700, 3, 1000, 256),
+                                                      ("COMPLEX", True, 260, 2, 300, 200), ("COMPLEX", True, 5, 4, 6, 400)])
+def test_flash_wide_rows_in_column_chunks_match_oracle(H, dev, decoder, use_inverse, B, C, N, d, f16):
+    """d > 128 (cfg5: Twitter ComplEx d = 400): the contraction index is cut into ceil(d / 128) equal column chunks with one operand-record set
+    each; the scores are accumulated chunk by chunk into an fp32 matrix (FLASH_FWDS: the last launch leaves the SoftmaxCE statistics) and the two
+    gradient contractions take V = exp(S - lse) from it, one (dAdj, dNeg) pair of launches per chunk of output columns.  Scores, loss, lse and
+    every gradient against the oracle; bf16 and fp16 operand halves."""
+    U, R = max(40, B), 11
+    emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=B + d, scale=0.3)
+    inv_u = inv if use_inverse else None
+    want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv_u)
+    W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, store=False, f16=f16)
+    assert W.layout.neg[0] != 0                          # the score matrix exists on this path (in tile order: LpWorkspace.neg un-tiles it)
+    mixed_close(W.neg(0), want["neg"], "neg (stored scores)")
+    if use_inverse:
+        mixed_close(W.neg(1), want["inv_neg"], "inv_neg (stored scores)")
+        mixed_close(W.lse(1), torch.logsumexp(torch.cat([want["inv_pos"][:, None], want["inv_neg"]], 1), 1), "inv lse")
+    mixed_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss")
+    mixed_close(W.lse(0), torch.logsumexp(torch.cat([want["pos"][:, None], want["neg"]], 1), 1), "lse")
+    check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv_u, U, R)
+    if B == 260:  # the same with the scores asked for in the API's row-major [Bp, n_ld] form (MARIUS_LP_STORE_SCORES)
+        W2 = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, store=True, f16=f16)
+        mixed_close(W2.neg(0), want["neg"], "neg (row-major)")
+        assert torch.equal(W2.gocc(), W.gocc()) and torch.equal(W2.lse(0), W.lse(0))
+
+
 @pytest.mark.parametrize("B,C,N,d", [(1000, 10, 500, 100), (300, 4, 260, 128)])
 def test_flash_unfused_form_still_matches_oracle(H, dev, monkeypatch, B, C, N, d):
     """MARIUS_FLASH_FUSED=0: statistics sweep + dAdj launch + dNeg launch (the round-2 form, kept for A/B runs)."""
@@ -324,7 +351,8 @@ def test_flash_not_selected_outside_its_domain(H, dev):
     assert mk().layout.flash == 1
     assert mk(relop=2, cmp=1).layout.flash == 0          # TransE
     assert mk(loss=H.LOSS["RANKING"]).layout.flash == 0
-    assert mk(d=400).layout.flash == 0
+    assert mk(d=400).layout.flash == 1          # round 3: four column chunks of 100 with stored scores
+    assert mk(d=132).layout.flash == 0          # 2 chunks of 66: not a multiple of 4 columns
     assert mk(d=12).layout.flash == 0
     assert H.LpWorkspace(0, 0, 100, 64, 4, 32, True, H.REDUCE_SUM, 3, True, dev).layout.flash == 0   # API contract: scores materialised
 
