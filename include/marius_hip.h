@@ -47,10 +47,10 @@ enum {
  * layout.dadj doubled on the flash path; 5: marius_lp_desc.absmax, marius_table_absmax, the *_tracked update entry points).  Every binder
  * compares the value it was built against with what the loaded library returns and refuses to run on a mismatch: marius_amd/hip.py lib(),
  * the host module's init (bindings.cpp), and the plug-in recipe of INTEGRATION.md. */
-#define MARIUS_HIP_ABI_VERSION 5
+#define MARIUS_HIP_ABI_VERSION 6
 int marius_hip_abi_version(void);
 /* sizeof(marius_lp_desc) / sizeof(marius_lp_layout) as the library was compiled: a second line of defence for ctypes mirrors */
-int marius_hip_struct_bytes(int which /* 0: marius_lp_desc, 1: marius_lp_layout */);
+int marius_hip_struct_bytes(int which /* 0: marius_lp_desc, 1: marius_lp_layout, 2: marius_segment_update */);
 const char* marius_hip_last_error(void);
 
 /* Optional HIP-event profiler (bench.py's roofline): when enabled, the library records hipEvents on the launch stream
@@ -341,6 +341,30 @@ int marius_segment_adagrad_scatter_planned(const float* rows, int64_t rows_ld, c
 int marius_segment_adagrad_scatter_tracked(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
                                            const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* uniq_ids, float* table, float* state,
                                            int64_t table_ld, float lr, float eps, void* carry, const void* plan, float* absmax, marius_stream_t stream);
+
+/* The update of several independent tables — one training step's node table and relation tables (dataloader.cpp:550-564 for the former,
+ * the optimizer step over model parameters, model.cpp:328-331, restricted to touched rows for the latter) — as ONE pair of launches instead of
+ * one pair per table.  Every job carries the arguments of marius_segment_adagrad_scatter_tracked (plan and absmax may be NULL); results per
+ * table are those of the separate calls, bit for bit.  Up to four jobs, all planned with 16-byte-aligned rows of the same width class, run
+ * grouped; anything else falls back to the separate calls on the same stream. */
+typedef struct marius_segment_update {
+    const float* rows;
+    int64_t rows_ld;
+    const int32_t* perm;
+    const int64_t* inverse;
+    const int32_t* seg_offsets;
+    int64_t n;
+    int32_t d;
+    const int64_t* uniq_ids;
+    float* table;
+    float* state;
+    int64_t table_ld;
+    float lr, eps;
+    void* carry;
+    const void* plan;
+    float* absmax;
+} marius_segment_update;
+int marius_segment_adagrad_scatter_group(const marius_segment_update* jobs, int32_t njobs, marius_stream_t stream);
 int marius_table_absmax(const float* table, int64_t rows, int64_t ld, int32_t d, float* absmax, marius_stream_t stream);
 
 #ifdef __cplusplus

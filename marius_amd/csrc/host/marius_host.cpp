@@ -1102,6 +1102,43 @@ static void relation_grads_dense(Model& m, shared_ptr<Batch> batch) {
     }
 }
 
+// the sparse relation step below as jobs of marius_segment_adagrad_scatter_group (one per direction); false: not expressible (see there)
+static bool relation_step_jobs(Model& m, shared_ptr<Batch> batch, marius_segment_update* jobs, int& njobs) {
+    LpContext& c = m.ctx_;
+    if (c.desc.edge_cols != 3) return true;
+    if (m.optimizers_.size() != 1) return false;
+    auto* opt = dynamic_cast<AdagradOptimizer*>(m.optimizers_[0].get());
+    if (!opt || opt->weight_decay_ != 0.f) return false;
+    const int ndir = c.desc.use_inverse ? 2 : 1;
+    if ((int)opt->params_.size() != ndir) return false;
+    if (!(batch->rel_perm_.defined() && batch->rel_perm_.size(0) == c.desc.B && batch->rel_plan_.defined())) return false;  // the loader's map + plan only
+    const int64_t B = c.desc.B;
+    RelMap rm = relation_map(m, batch);
+    const int64_t one = (int64_t)marius_segment_carry_bytes(B, c.desc.d);
+    ensure(m.rel_carry_, ndir * one, c.workspace.device());  // the directions run side by side: a carry each
+    for (int dir = 0; dir < ndir; ++dir) {
+        Tensor& w = opt->params_[dir].first;
+        marius_segment_update& u = jobs[njobs++];
+        u.rows = (const float*)((const char*)c.workspace.data_ptr() + c.layout.grel[dir]);
+        u.rows_ld = c.layout.d_ld;
+        u.perm = rm.perm;
+        u.inverse = rm.inverse;
+        u.seg_offsets = rm.seg;
+        u.n = B;
+        u.d = c.desc.d;
+        u.uniq_ids = rm.uniq;
+        u.table = fp(w);
+        u.state = fp(opt->state_[dir]);
+        u.table_ld = w.stride(0);
+        u.lr = opt->learning_rate_;
+        u.eps = opt->eps_;
+        u.carry = (char*)m.rel_carry_.data_ptr() + dir * one;
+        u.plan = rm.plan;
+        u.absmax = m.ranges_valid_ ? m.range_state_.data_ptr<float>() + 1 : nullptr;
+    }
+    return true;
+}
+
 // Dense Adagrad step on the relation tables restricted to the rows the batch touched.  A row with zero gradient is a fixed point of
 // the dense rule (sum += 0; w -= lr*0/(sqrt(sum)+eps)), so this equals AdagradOptimizer::step() on the dense gradient bit for bit
 // while skipping the [R, d] zero-fill, the dense scatter target and the full-table pass.  Returns false if the optimizer is not
@@ -1238,9 +1275,43 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
     batch->table_ = Tensor();
     model_backward(*this, batch);
     if (ev_grads_) HIPCHECK(hipEventRecord((hipEvent_t)ev_grads_, c10::hip::getCurrentHIPStream(device_.index()).stream()));
-    // The relation-table update (6 small, latency-bound launches) and the node-table update are independent: run the former on a side
-    // stream underneath the latter and join before returning (the next forward reads the relation tables).
     const auto dev_index = device_.index();
+    const int64_t L = batch->occ_perm_.size(0);
+    ensure(carry_, (int64_t)marius_segment_carry_bytes(L, ctx_.desc.d), device_);
+    const float* gocc = (const float*)((const char*)ctx_.workspace.data_ptr() + ctx_.layout.gocc);
+    // The node-table update and the relation-table updates are independent.  With the loader's plans at hand all of them are ONE pair of
+    // launches (marius_segment_adagrad_scatter_group); the side stream the relation step used to run on, its fork / join events and four
+    // launches are gone from the step's tail.
+    if (batch->occ_plan_.defined()) {
+        // relation jobs first: a hub relation's segment spans hundreds of chunks and is finished by ONE wave, so those workgroups should start
+        // at the head of the launch, with the node table's many short ones filling in behind them
+        marius_segment_update jobs[3];
+        int njobs = 0;
+        const bool rel_ok = relation_step_jobs(*this, batch, jobs, njobs);
+        marius_segment_update& u = jobs[njobs++];
+        u.rows = gocc;
+        u.rows_ld = ctx_.layout.d_ld;
+        u.perm = batch->occ_perm_.data_ptr<int32_t>();
+        u.inverse = ip(batch->occ_inverse_);
+        u.seg_offsets = batch->occ_seg_offsets_.data_ptr<int32_t>();
+        u.n = L;
+        u.d = ctx_.desc.d;
+        u.uniq_ids = ip(batch->unique_node_indices_);
+        u.table = fp(table);
+        u.state = fp(state);
+        u.table_ld = table.stride(0);
+        u.lr = sparse_lr_;
+        u.eps = 1e-10f;
+        u.carry = carry_.data_ptr();
+        u.plan = batch->occ_plan_.data_ptr();
+        u.absmax = ranges_valid_ ? range_state_.data_ptr<float>() : nullptr;
+        if (rel_ok) {
+            mcheck(marius_segment_adagrad_scatter_group(jobs, njobs, cur_stream()));
+            return;
+        }
+    }
+    // otherwise: the relation step (6 small, latency-bound launches) on a side stream underneath the node-table update, joined before
+    // returning (the next forward reads the relation tables)
     c10::hip::HIPStream main = c10::hip::getCurrentHIPStream(dev_index);
     if (!side_stream_) {
         side_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(false, dev_index));
@@ -1269,9 +1340,6 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
                     mcheck(marius_table_absmax(fp(p.first), p.first.size(0), p.first.stride(0), (int32_t)p.first.size(1), range_state_.data_ptr<float>() + 1, cur_stream()));
         }
     }
-    const int64_t L = batch->occ_perm_.size(0);
-    ensure(carry_, (int64_t)marius_segment_carry_bytes(L, ctx_.desc.d), device_);
-    const float* gocc = (const float*)((const char*)ctx_.workspace.data_ptr() + ctx_.layout.gocc);
     if (ranges_valid_)
         mcheck(marius_segment_adagrad_scatter_tracked(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
                                                       batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, ip(batch->unique_node_indices_), fp(table),

@@ -61,7 +61,7 @@ void prof_end(hipStream_t st, ProfMark& m) {
 using namespace marius;
 
 extern "C" int marius_hip_abi_version(void) { return MARIUS_HIP_ABI_VERSION; }
-extern "C" int marius_hip_struct_bytes(int which) { return which == 0 ? (int)sizeof(marius_lp_desc) : which == 1 ? (int)sizeof(marius_lp_layout) : -1; }
+extern "C" int marius_hip_struct_bytes(int which) { return which == 0 ? (int)sizeof(marius_lp_desc) : which == 1 ? (int)sizeof(marius_lp_layout) : which == 2 ? (int)sizeof(marius_segment_update) : -1; }
 extern "C" const char* marius_hip_last_error(void) { return marius::g_last_error; }
 
 extern "C" int marius_profile_enable(int on) {

@@ -98,9 +98,9 @@ __device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC]) {
 
 // phase 1: one wave per chunk
 template <int VEC, int NIT, class Apply>
-__global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply) {
+__device__ __forceinline__ void seg_reduce_body(const SegArgs& a, const Apply& apply, int64_t block) {
     const int lane = threadIdx.x & 63;
-    const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t chunk = block * 4 + (threadIdx.x >> 6);
     const int64_t k0 = chunk * SEG_R;
     if (k0 >= a.n) return;
     const int cnt = (int)min((int64_t)SEG_R, a.n - k0);
@@ -184,6 +184,11 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply)
         }
     }
     flush(cur, cur_complete, cur_single);
+}
+
+template <int VEC, int NIT, class Apply>
+__global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a, Apply apply) {
+    seg_reduce_body<VEC, NIT, Apply>(a, apply, (int64_t)blockIdx.x);
 }
 
 // phase 2: the chunk in which a boundary-crossing segment STARTS finishes it from the carries
@@ -406,6 +411,50 @@ __global__ __launch_bounds__(256) void adagrad_with_fixup_kernel(SegArgs sa, App
         adagrad_rows_body<VEC>(A, (int64_t)blockIdx.x - nfix);
 }
 
+// Several independent tables (the node table and the relation tables of one training step) in ONE pair of launches: workgroup ranges
+// select the job.  Per job the work and its order are those of the single-table launches above, so the results are theirs bit for bit; what
+// goes away are four launches, the side stream they ran on and its fork / join events (13 + 18 us of the step's tail, trace in DESIGN.md 5).
+constexpr int SEG_GROUP_MAX = 4;
+struct SegJob {
+    SegArgs sa;
+    ApplySum sum;
+    ApplyAdagrad ada;
+    AdagradRowsArgs A;
+    unsigned red0, upd0, nfix;  // first workgroup of the job in the reduce / update grid; fix-up workgroups at the head of its update range
+};
+struct SegGroup {
+    SegJob job[SEG_GROUP_MAX];
+    int njobs;
+};
+// (the job is picked by static index under uniform branches: indexing the kernel argument with a run-time value makes the compiler copy
+// the whole group into scratch — the grouped launches then took 0.8 ms instead of 0.13)
+template <int VEC, int NIT>
+__global__ __launch_bounds__(256) void seg_reduce_group_kernel(SegGroup G) {
+    const unsigned b = blockIdx.x;
+#define SEG_JOB(J)                                                                                          \
+    if (J == G.njobs - 1 || b < G.job[J + 1 < SEG_GROUP_MAX ? J + 1 : J].red0) {                              \
+        seg_reduce_body<VEC, NIT, ApplySum>(G.job[J].sa, G.job[J].sum, (int64_t)(b - G.job[J].red0));        \
+        return;                                                                                             \
+    }
+    SEG_JOB(0) SEG_JOB(1) SEG_JOB(2) SEG_JOB(3)
+#undef SEG_JOB
+}
+template <int VEC, int NIT>
+__global__ __launch_bounds__(256) void adagrad_with_fixup_group_kernel(SegGroup G) {
+    const unsigned b0 = blockIdx.x;
+#define SEG_JOB(J)                                                                                          \
+    if (J == G.njobs - 1 || b0 < G.job[J + 1 < SEG_GROUP_MAX ? J + 1 : J].upd0) {                             \
+        const unsigned b = b0 - G.job[J].upd0;                                                              \
+        if (b < G.job[J].nfix)                                                                              \
+            seg_fixup_body<VEC, NIT, ApplyAdagrad>(G.job[J].sa, G.job[J].ada, (int64_t)b);                   \
+        else                                                                                                \
+            adagrad_rows_body<VEC>(G.job[J].A, (int64_t)(b - G.job[J].nfix));                                \
+        return;                                                                                             \
+    }
+    SEG_JOB(0) SEG_JOB(1) SEG_JOB(2) SEG_JOB(3)
+#undef SEG_JOB
+}
+
 template <class Apply>
 static int launch_seg(const SegArgs& a, const Apply& apply, int vec, hipStream_t st, bool fixup = true) {
     const int64_t nchunks = cdiv(a.n, SEG_R);
@@ -623,4 +672,69 @@ static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, cons
     else
         adagrad_unique_rows_kernel<1><<<grid, block, 0, st>>>(A);
     return check_launch("segment_adagrad_scatter");
+}
+
+extern "C" int marius_segment_adagrad_scatter_group(const marius_segment_update* jobs, int32_t njobs, marius_stream_t stream) {
+    MARIUS_REQUIRE(jobs && njobs >= 1, "segment_adagrad_scatter_group: no jobs");
+    hipStream_t st = as_stream(stream);
+    const char* ge = getenv("MARIUS_SEG_GROUP");  // 0: one launch pair per table (A/B runs)
+    bool grouped = njobs <= SEG_GROUP_MAX && !(ge && ge[0] == '0');
+    const char* ns = getenv("MARIUS_SEG_NO_SKIP");
+    int per0 = 0;
+    for (int j = 0; j < njobs && grouped; ++j) {  // the single-launch planned form's conditions (segment_adagrad_scatter_impl), for every job
+        const marius_segment_update& u = jobs[j];
+        if (!(u.n > 0 && u.plan && u.d > 0 && u.d <= 512 && u.rows && u.perm && u.inverse && u.seg_offsets && u.carry && u.uniq_ids && u.table && u.state &&
+              u.rows_ld >= u.d && u.table_ld >= u.d)) { grouped = false; break; }
+        const int v = row_vec_width(u.rows, u.rows_ld, u.d), v2 = row_vec_width(u.table, u.table_ld, u.d), v3 = row_vec_width(u.state, u.table_ld, u.d);
+        const int per = cdiv(u.d, 256);
+        if (v != 4 || v2 != 4 || v3 != 4 || per > 2 || (j > 0 && per != per0) || (ns && ns[0] == '1')) grouped = false;
+        per0 = per;
+    }
+    if (!grouped) {
+        for (int j = 0; j < njobs; ++j) {
+            const marius_segment_update& u = jobs[j];
+            int rc = segment_adagrad_scatter_impl(u.rows, u.rows_ld, u.perm, u.inverse, u.seg_offsets, u.n, u.d, u.uniq_ids, u.table, u.state, u.table_ld, u.lr, u.eps,
+                                                  u.carry, u.plan, u.absmax, stream);
+            if (rc) return rc;
+        }
+        return MARIUS_OK;
+    }
+    ProfScope ps(PROF_SEG_ADAGRAD, st);
+    SegGroup G;
+    G.njobs = njobs;
+    unsigned red = 0, upd = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const marius_segment_update& u = jobs[j];
+        SegJob& J = G.job[j];
+        int rc = fill_args(J.sa, u.rows, u.rows_ld, u.perm, u.inverse, u.seg_offsets, u.n, u.d, u.carry);
+        if (rc) return rc;
+        float* gsum = (float*)((char*)u.carry + carry_only_bytes(u.n, u.d));
+        const int64_t g_ld = dpad_of(u.d);
+        J.sum = ApplySum{gsum, g_ld, nullptr};
+        J.sa.skip_singletons = 1;
+        const char* pp = (const char*)u.plan;
+        J.sa.pos_plan = (const int4*)pp;
+        J.sa.chunk_plan = (const int4*)(pp + plan_pos_bytes(u.n));
+        const int4* row_plan = (const int4*)(pp + plan_pos_bytes(u.n) + plan_chunk_bytes(u.n));
+        const int vpr = u.d / 4;
+        int tx = 1;
+        while (tx < vpr && tx < 64) tx <<= 1;
+        const int ty = 256 / tx;
+        const unsigned row_blocks = (unsigned)cdiv(u.n, (int64_t)ty * 4);
+        J.A = AdagradRowsArgs{gsum, g_ld, u.perm, u.inverse, u.n, u.uniq_ids, u.table, u.state, u.table_ld, vpr, tx, u.lr, u.eps, u.rows, u.rows_ld, u.seg_offsets, row_plan, 1, u.absmax};
+        J.ada = ApplyAdagrad{u.uniq_ids, u.table, u.state, u.table_ld, u.lr, u.eps, u.absmax};
+        J.nfix = (unsigned)cdiv(cdiv(u.n, SEG_R), 4);
+        J.red0 = red;
+        J.upd0 = upd;
+        red += J.nfix;  // the reduce grid has one workgroup per four chunks too
+        upd += J.nfix + row_blocks;
+    }
+    if (per0 <= 1) {
+        seg_reduce_group_kernel<4, 1><<<dim3(red), dim3(256), 0, st>>>(G);
+        adagrad_with_fixup_group_kernel<4, 1><<<dim3(upd), dim3(256), 0, st>>>(G);
+    } else {
+        seg_reduce_group_kernel<4, 2><<<dim3(red), dim3(256), 0, st>>>(G);
+        adagrad_with_fixup_group_kernel<4, 2><<<dim3(upd), dim3(256), 0, st>>>(G);
+    }
+    return check_launch("segment_adagrad_scatter_group");
 }

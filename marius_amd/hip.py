@@ -18,7 +18,7 @@ REDUCE_SUM, REDUCE_MEAN = 0, 1
 LOSS = {"SOFTMAX_CE": 0, "RANKING": 1, "CROSS_ENTROPY": 2, "BCE_AFTER_SIGMOID": 3, "BCE_WITH_LOGITS": 4, "MSE": 5, "SOFTPLUS": 6}
 LP_TRAIN_ONLY, LP_STORE_SCORES, LP_KEEP_DADJ = 1, 2, 4   # marius_lp_desc.flags
 MT_STATE_WORDS = 625
-ABI_VERSION = 5  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
+ABI_VERSION = 6  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
 
 
 class MariusHipError(RuntimeError):
@@ -100,6 +100,7 @@ SIGNATURES = {
     "marius_segment_plan": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "marius_segment_adagrad_scatter_planned": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp]),
     "marius_segment_adagrad_scatter_tracked": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "marius_segment_adagrad_scatter_group": (C.c_int, [_vp, _i32, _vp]),
     "marius_table_absmax": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
 }
 
@@ -123,7 +124,7 @@ def lib():
         got = L.marius_hip_abi_version()
         if got != ABI_VERSION:
             raise MariusHipError("libmarius_hip.so at %s has ABI version %d, this package was written against %d: rebuild with `python -m marius_amd.build`" % (path, got, ABI_VERSION))
-        for which, mirror in ((0, LpDesc), (1, LpLayout)):
+        for which, mirror in ((0, LpDesc), (1, LpLayout), (2, SegmentUpdate)):
             if L.marius_hip_struct_bytes(which) != C.sizeof(mirror):
                 raise MariusHipError("%s is %d bytes in libmarius_hip.so and %d in marius_amd/hip.py" % (mirror.__name__, L.marius_hip_struct_bytes(which), C.sizeof(mirror)))
         _lib = L
@@ -455,6 +456,31 @@ def segment_adagrad_scatter(rows, um, n, d, table, state, lr, eps=1e-10, carry=N
     check(lib().marius_segment_adagrad_scatter(ptr(rows), rows.stride(0), ptr(um.perm), ptr(um.inverse), ptr(um.seg), n, d, ptr(um.uniq),
                                                ptr(table), ptr(state), table.stride(0), lr, eps, ptr(carry), stream_ptr()),
           "segment_adagrad_scatter")
+
+
+class SegmentUpdate(C.Structure):
+    """marius_segment_update (include/marius_hip.h): one table's job of marius_segment_adagrad_scatter_group"""
+    _fields_ = [("rows", C.c_void_p), ("rows_ld", C.c_int64), ("perm", C.c_void_p), ("inverse", C.c_void_p), ("seg_offsets", C.c_void_p), ("n", C.c_int64),
+                ("d", C.c_int32), ("uniq_ids", C.c_void_p), ("table", C.c_void_p), ("state", C.c_void_p), ("table_ld", C.c_int64), ("lr", C.c_float),
+                ("eps", C.c_float), ("carry", C.c_void_p), ("plan", C.c_void_p), ("absmax", C.c_void_p)]
+
+
+def segment_adagrad_scatter_group(jobs):
+    """jobs: list of dicts with the keyword arguments of segment_adagrad_scatter (rows, um, n, d, table, state, lr [, eps, carry, plan, absmax]);
+    all tables updated by one pair of launches"""
+    arr = (SegmentUpdate * len(jobs))()
+    keep = []
+    for a, j in zip(arr, jobs):
+        rows, um, n, d = j["rows"], j["um"], j["n"], j["d"]
+        _dev(rows)
+        carry = j.get("carry")
+        if carry is None:
+            carry = segment_carry(n, d, rows.device)
+        keep.append(carry)
+        a.rows, a.rows_ld, a.perm, a.inverse, a.seg_offsets, a.n, a.d = ptr(rows), rows.stride(0), ptr(um.perm), ptr(um.inverse), ptr(um.seg), n, d
+        a.uniq_ids, a.table, a.state, a.table_ld = ptr(um.uniq), ptr(j["table"]), ptr(j["state"]), j["table"].stride(0)
+        a.lr, a.eps, a.carry, a.plan, a.absmax = j["lr"], j.get("eps", 1e-10), ptr(carry), ptr(j.get("plan")), ptr(j.get("absmax"))
+    check(lib().marius_segment_adagrad_scatter_group(C.cast(arr, C.c_void_p), len(jobs), stream_ptr()), "segment_adagrad_scatter_group")
 
 
 def profile_enable(on=True, only=None):

@@ -432,6 +432,41 @@ def test_tracked_update_keeps_the_magnitude_bound(H, dev, n, rows_of_table, d, p
     assert float(bound) == float(tb.abs().max()) > 0.05           # grew with the update (1e-3 -> ~lr), and is exact here: nothing shrank
 
 
+@pytest.mark.parametrize("planned", [True, False])
+def test_grouped_update_of_three_tables_equals_the_separate_updates(H, dev, planned):
+    """marius_segment_adagrad_scatter_group: a step's node table + both relation tables in one launch pair (the relation tables share one
+    id map, as the two directions of a batch do) — every table and state bit-identical to its own marius_segment_adagrad_scatter_tracked call,
+    magnitude bounds included; unplanned jobs take the documented fallback (separate launches) with the same result."""
+    g = torch.Generator().manual_seed(7)
+    d = 100
+    shapes = [(200000, 150000), (50000, 3000)]   # (occurrences, table rows): the bench's node and relation shapes (a Zipf hub spans hundreds of chunks)
+    maps, plans = [], []
+    for n, nrows in shapes:
+        ids = (torch.rand(n, generator=g) ** 3 * nrows).long().clamp_(0, nrows - 1)
+        um = H.UniqueMap(n, dev).run(ids.to(dev), key_bits=28)
+        maps.append(um)
+        plans.append(H.segment_plan(um, n) if planned else None)
+    jobs_src = [(0, 0.1), (1, 0.1), (1, 0.05)]
+    want, got, jobs, bounds_w, bounds_g = [], [], [], [], []
+    for which, lr in jobs_src:
+        n, nrows = shapes[which]
+        rows = (torch.randn(n, d, generator=g) * 0.1).to(dev)
+        table, state = (torch.randn(nrows, d, generator=g) * 1e-3), torch.rand(nrows, d, generator=g) * 1e-4
+        tw, sw, tg, sg = table.to(dev), state.to(dev), table.to(dev), state.to(dev)
+        bw, bg = H.table_absmax(tw), H.table_absmax(tg)
+        H.segment_adagrad_scatter(rows, maps[which], n, d, tw, sw, lr=lr, plan=plans[which], absmax=bw)
+        want.append((tw, sw))
+        got.append((tg, sg))
+        bounds_w.append(bw)
+        bounds_g.append(bg)
+        jobs.append(dict(rows=rows, um=maps[which], n=n, d=d, table=tg, state=sg, lr=lr, plan=plans[which], absmax=bg))
+    H.segment_adagrad_scatter_group(jobs)
+    torch.cuda.synchronize()
+    for (tw, sw), (tg, sg), bw, bg in zip(want, got, bounds_w, bounds_g):
+        assert torch.equal(tw, tg) and torch.equal(sw, sg)
+        assert float(bw) == float(bg) == float(tg.abs().max())
+
+
 # ------------------------------------------------------------------------------------------------ whole steps vs the CPU path
 @pytest.mark.parametrize("decoder,f", [("COMPLEX", 0.0), ("DISTMULT", 0.5), ("TRANSE", 0.0)])
 def test_train_steps_match_cpu_reference_path(H, dev, decoder, f):
