@@ -1004,7 +1004,7 @@ bool flash_applicable(const marius_lp_desc* desc, const LpDims& D) {
         // not by the round-2 three-launch form, not together with stored scores, and only for lists a DEG filter can produce
         const FlFilterDims f = fl_filter_dims(D);
         if (!flash_fused() || (desc->flags & MARIUS_LP_STORE_SCORES) || (size_t)(f.nkeys_max + 1) * 4 > FL_FILTER_LDS_MAX ||
-            desc->n_dst_filter + desc->n_src_filter > f.ent_cap)
+            desc->n_dst_filter + desc->n_src_filter > f.ent_cap || flash_chunked(D.d))  // (the column-chunked launches of d > 128 do not look filters up)
             return false;
     }
     const int ks = fl_ks(D.d);

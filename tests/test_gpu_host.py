@@ -122,7 +122,9 @@ def _setup(M, dev, decoder, num_nodes, R, d, B, C, N, E, seed, f=0.0, init=0.6):
 
 @pytest.mark.parametrize("decoder,f,fused,d", [("COMPLEX", 0.0, True, 20), ("COMPLEX", 0.0, False, 20), ("DISTMULT", 0.5, True, 20), ("TRANSE", 0.0, False, 20),
                                                ("COMPLEX", 0.0, True, 100), ("DISTMULT", 0.0, False, 64),    # these two: the flash training path
-                                               ("COMPLEX", 0.5, True, 100)])                                 # flash path with the DEG score filter
+                                               ("COMPLEX", 0.5, True, 100),                                  # flash path with the DEG score filter
+                                               ("COMPLEX", 0.0, True, 200),                                  # rows wider than 128: column-chunked flash path
+                                               ("COMPLEX", 0.5, True, 200)])                                 # ... which does not look filters up: FP32 kernels
 def test_trainer_epoch_matches_cpu_reference_path(M, dev, decoder, f, fused, d):
     num_nodes, R, B, C, N, E, seed = 4000, 11, 250, 5, 40, 1000, 123
     table, edges_all, emb, state, loader, model = _setup(M, dev, decoder, num_nodes, R, d, B, C, N, E, seed, f)
@@ -142,6 +144,8 @@ def test_trainer_epoch_matches_cpu_reference_path(M, dev, decoder, f, fused, d):
     close(model.decoder.relations, cpu.rel, rtol=3e-4)
     close(model.decoder.inverse_relations, cpu.inv_rel, rtol=3e-4)
     assert trainer.last_edges_per_second > 0
+    if fused and d == 200:
+        assert bool(model.last_step_flash) == (f == 0.0)   # a DEG filter on wide rows must NOT take the chunked launches (they would ignore it)
 
 
 def test_trainer_tracks_table_magnitude_through_a_thousandfold_growth(M, dev):
