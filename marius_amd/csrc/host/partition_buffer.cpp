@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 namespace marius_amd {
 
@@ -35,7 +36,8 @@ static void full_io(int fd, char* buf, int64_t n, int64_t off, bool write_) {
     const int64_t nslices = (n + slice - 1) / slice;
     int failed = 0;
     int err_no = 0;
-    const int nthreads = (int)std::min<int64_t>(nslices, 8);
+    static const int max_threads = [] { const char* e = getenv("MARIUS_PB_IO_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();
+    const int nthreads = (int)std::min<int64_t>(nslices, max_threads);
 #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1) if (nslices > 1)
     for (int64_t sidx = 0; sidx < nslices; ++sidx) {
         int64_t o = sidx * slice, left = std::min<int64_t>(slice, n - o);
@@ -116,6 +118,20 @@ void PartitionBuffer::alloc_staging() {
     swap_stream_ = s;
     PB_HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     swap_stream2_ = s;
+    static const bool dev_env = [] { const char* e = getenv("MARIUS_PB_DEVICE_STAGING"); return !(e && e[0] == '0'); }();
+    if (prefetching_ && dev_env && buffer_states_.size() > 1) {
+        dev_admit_.assign(lanes_, nullptr);
+        dev_evict_.assign(lanes_, nullptr);
+        for (int i = 0; i < lanes_; ++i) {
+            PB_HIPCHECK(hipMalloc(&dev_admit_[i], (size_t)slot_bytes()));
+            PB_HIPCHECK(hipMalloc(&dev_evict_[i], (size_t)slot_bytes()));
+        }
+        hipEvent_t e;
+        PB_HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_compute_ = e;
+        PB_HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_swapped_ = e;
+        PB_HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_evict_host_ = e;
+        PB_HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_admit_ready_ = e;
+    }
 }
 
 void PartitionBuffer::free_staging() {
@@ -125,6 +141,16 @@ void PartitionBuffer::free_staging() {
         if (m) (void)hipHostFree(m);
     admit_mem_.clear();
     evict_mem_.clear();
+    for (auto m : dev_admit_)
+        if (m) (void)hipFree(m);
+    for (auto m : dev_evict_)
+        if (m) (void)hipFree(m);
+    dev_admit_.clear();
+    dev_evict_.clear();
+    for (void** e : {&ev_compute_, &ev_swapped_, &ev_evict_host_, &ev_admit_ready_}) {
+        if (*e) (void)hipEventDestroy((hipEvent_t)*e);
+        *e = nullptr;
+    }
     if (swap_stream_) (void)hipStreamDestroy((hipStream_t)swap_stream_);
     if (swap_stream2_) (void)hipStreamDestroy((hipStream_t)swap_stream2_);
     swap_stream_ = swap_stream2_ = nullptr;
@@ -163,6 +189,12 @@ void PartitionBuffer::load() {  // buffer.cpp:372-418
             staged_admits_ = next;
             io_submit([this, next] {
                 for (size_t i = 0; i < next.size(); ++i) file_->readPartition(admit_mem_[i], partition_table_[next[i]]);
+                if (dev_staging()) {
+                    hipStream_t s2 = (hipStream_t)swap_stream2_;
+                    for (size_t i = 0; i < next.size(); ++i)
+                        PB_HIPCHECK(hipMemcpyAsync(dev_admit_[i], admit_mem_[i], (size_t)partition_table_[next[i]].total_size_, hipMemcpyHostToDevice, s2));
+                    PB_HIPCHECK(hipEventRecord((hipEvent_t)ev_admit_ready_, s2));
+                }
             });
         }
     }
@@ -173,14 +205,35 @@ void PartitionBuffer::sync() {
     if (prefetching_) io_wait();
     hipStream_t s = (hipStream_t)swap_stream_;
     c10::hip::getCurrentHIPStream(device_.index()).synchronize();  // every update enqueued so far has landed in the slab
+    PB_HIPCHECK(hipStreamSynchronize(s));
+    if (swap_stream2_) PB_HIPCHECK(hipStreamSynchronize((hipStream_t)swap_stream2_));
+    // two staging buffers (nothing is being admitted any more: the admit lane is free): partition k + 1 comes off the device while partition k
+    // is written to its file
+    void* stage[2] = {evict_mem_[0], admit_mem_[0]};
+    std::thread writer;
+    std::string werr;
+    int k = 0;
     for (auto& p : partition_table_) {
         if (!p.present_) continue;
-        PB_HIPCHECK(hipMemcpyAsync(evict_mem_[0], slot_ptr(p.buffer_idx_), (size_t)p.total_size_, hipMemcpyDeviceToHost, s));
+        void* buf = stage[k & 1];
+        PB_HIPCHECK(hipMemcpyAsync(buf, slot_ptr(p.buffer_idx_), (size_t)p.total_size_, hipMemcpyDeviceToHost, s));
         PB_HIPCHECK(hipStreamSynchronize(s));
-        file_->writePartition(evict_mem_[0], p);
+        if (writer.joinable()) writer.join();  // the other buffer's write; this one's buffer was released by the join before it
+        if (!werr.empty()) throw MariusRuntimeException(werr);
+        Partition* pp = &p;
+        writer = std::thread([this, buf, pp, &werr] {
+            try {
+                file_->writePartition(buf, *pp);
+            } catch (const std::exception& e) {
+                werr = e.what();
+            }
+        });
         p.present_ = false;
         p.buffer_idx_ = -1;
+        ++k;
     }
+    if (writer.joinable()) writer.join();
+    if (!werr.empty()) throw MariusRuntimeException(werr);
 }
 
 void PartitionBuffer::unload(bool write) {  // buffer.cpp:420-439
@@ -249,6 +302,10 @@ std::vector<int> PartitionBuffer::getNextEvict() {  // buffer.cpp:569-585: in th
 void PartitionBuffer::performNextSwap() {  // buffer.cpp:501-547 (+ evict :637-652, admit :654-686)
     if (buffer_state_.empty() || !hasSwap()) return;
     if (!loaded_) throw MariusRuntimeException("performNextSwap: buffer not loaded");
+    if (dev_staging()) {
+        perform_next_swap_staged();
+        return;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<int> evict = getNextEvict(), admit = getNextAdmit();
     if (admit.size() > evict.size() || (int)evict.size() > lanes_) throw std::runtime_error("");
@@ -326,6 +383,69 @@ void PartitionBuffer::performNextSwap() {  // buffer.cpp:501-547 (+ evict :637-6
     swap_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
 }
 
+// The same exchange with the PCIe transfers moved off the swap point (see the header): at the swap the device copies the evicted partitions into
+// dev_evict_ and the staged admissions out of dev_admit_ (two HBM-to-HBM copies, ~1 ms per GB), the next state's batches wait for exactly that, and
+// the evicted data goes to the host, into its file, and the FOLLOWING admission from its file onto the device while those batches run.  The host
+// never waits for the device here; it is throttled by io_wait() to at most one buffer state ahead of the IO thread.
+void PartitionBuffer::perform_next_swap_staged() {
+    const auto t1 = std::chrono::steady_clock::now();
+    std::vector<int> evict = getNextEvict(), admit = getNextAdmit();
+    if (admit.size() > evict.size() || (int)evict.size() > lanes_) throw std::runtime_error("");
+    std::vector<int64_t> slots;
+    for (int e : evict) slots.push_back(partition_table_[e].buffer_idx_);
+    hipStream_t s = (hipStream_t)swap_stream_, s2 = (hipStream_t)swap_stream2_;
+    hipStream_t compute = c10::hip::getCurrentHIPStream(device_.index()).stream();
+    io_wait();  // the previous swap's write-back and this swap's look-ahead (file -> pinned -> dev_admit_, enqueued on s2) are done / enqueued
+    const bool staged = staged_admits_ == admit;
+    if (staged) ++prefetch_hits_;
+    if (!staged) {  // an ordering the look-ahead did not predict (setBufferOrdering in between): read and stage now
+        PB_HIPCHECK(hipStreamSynchronize(s2));
+        for (size_t i = 0; i < admit.size(); ++i) {
+            file_->readPartition(admit_mem_[i], partition_table_[admit[i]]);
+            PB_HIPCHECK(hipMemcpyAsync(dev_admit_[i], admit_mem_[i], (size_t)partition_table_[admit[i]].total_size_, hipMemcpyHostToDevice, s2));
+        }
+        PB_HIPCHECK(hipEventRecord((hipEvent_t)ev_admit_ready_, s2));
+    }
+    PB_HIPCHECK(hipEventRecord((hipEvent_t)ev_compute_, compute));
+    PB_HIPCHECK(hipStreamWaitEvent(s, (hipEvent_t)ev_compute_, 0));        // the ending state's batches have updated the slab
+    if (!admit.empty()) PB_HIPCHECK(hipStreamWaitEvent(s, (hipEvent_t)ev_admit_ready_, 0));
+    for (size_t i = 0; i < evict.size(); ++i) {
+        const Partition& pe = partition_table_[evict[i]];
+        PB_HIPCHECK(hipMemcpyAsync(dev_evict_[i], slot_ptr(slots[i]), (size_t)pe.total_size_, hipMemcpyDeviceToDevice, s));
+        if (i < admit.size()) {
+            const Partition& pa = partition_table_[admit[i]];
+            PB_HIPCHECK(hipMemcpyAsync(slot_ptr(slots[i]), dev_admit_[i], (size_t)pa.total_size_, hipMemcpyDeviceToDevice, s));
+            if (pa.total_size_ < slot_bytes()) PB_HIPCHECK(hipMemsetAsync(slot_ptr(slots[i]) + pa.total_size_, 0, (size_t)(slot_bytes() - pa.total_size_), s));
+        }
+    }
+    PB_HIPCHECK(hipEventRecord((hipEvent_t)ev_swapped_, s));
+    PB_HIPCHECK(hipStreamWaitEvent(compute, (hipEvent_t)ev_swapped_, 0));  // the next state's first batch
+    for (size_t i = 0; i < evict.size(); ++i)
+        PB_HIPCHECK(hipMemcpyAsync(evict_mem_[i], dev_evict_[i], (size_t)partition_table_[evict[i]].total_size_, hipMemcpyDeviceToHost, s));
+    PB_HIPCHECK(hipEventRecord((hipEvent_t)ev_evict_host_, s));
+    for (int e : evict) partition_table_[e].present_ = false;  // buffer_idx_ stays, as in the reference
+    for (size_t i = 0; i < admit.size(); ++i) {
+        partition_table_[admit[i]].present_ = true;
+        partition_table_[admit[i]].buffer_idx_ = (int)slots[i];
+    }
+    buffer_state_ = buffer_states_[next_state_++];
+    std::vector<int> next = getNextAdmit();
+    staged_admits_ = next;
+    io_submit([this, evict, next] {
+        hipStream_t s2 = (hipStream_t)swap_stream2_;
+        PB_HIPCHECK(hipEventSynchronize((hipEvent_t)ev_evict_host_));  // (also: ev_swapped_ has passed, i.e. dev_admit_ was consumed)
+        for (size_t i = 0; i < evict.size(); ++i) file_->writePartition(evict_mem_[i], partition_table_[evict[i]]);
+        if (next.empty()) return;
+        PB_HIPCHECK(hipStreamSynchronize(s2));  // the previous look-ahead's copies have left admit_mem_
+        for (size_t i = 0; i < next.size(); ++i) file_->readPartition(admit_mem_[i], partition_table_[next[i]]);
+        for (size_t i = 0; i < next.size(); ++i)
+            PB_HIPCHECK(hipMemcpyAsync(dev_admit_[i], admit_mem_[i], (size_t)partition_table_[next[i]].total_size_, hipMemcpyHostToDevice, s2));
+        PB_HIPCHECK(hipEventRecord((hipEvent_t)ev_admit_ready_, s2));
+    });
+    ++swaps_;
+    swap_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+}
+
 Tensor PartitionBuffer::getGlobalToLocalMap(bool get_current) {  // buffer.cpp:587-635
     Tensor map = torch::full({total_embeddings_}, -1, torch::kInt64);
     int64_t* m = map.data_ptr<int64_t>();
@@ -381,6 +501,7 @@ Tensor PartitionBuffer::getRandomIds(int64_t size) {  // buffer.cpp:450: over th
 }
 
 void PartitionBuffer::io_loop() {
+    (void)hipSetDevice(device_.index());  // the look-ahead enqueues copies from this thread
     for (;;) {
         std::function<void()> job;
         {

@@ -91,6 +91,16 @@ class PartitionBuffer {
     void* swap_stream_ = nullptr;   // evictions (D2H), initial load
     void* swap_stream2_ = nullptr;  // admissions (H2D) during a swap
     std::vector<int> staged_admits_;  // partition ids currently (being) read into admit_mem_ by the IO thread
+    // Device-side staging (prefetching mode; 288 GB of HBM make two more slot-sized buffers per lane a rounding error): the next admission is
+    // already ON the device when its swap comes, and the eviction leaves its slot by a device-to-device copy — the PCIe transfers of a swap run
+    // under the compute of the neighbouring buffer states instead of between them.
+    std::vector<void*> dev_admit_, dev_evict_;
+    void* ev_compute_ = nullptr;      // the ending state's last batch (compute stream)
+    void* ev_swapped_ = nullptr;      // slots exchanged (swap stream): the next state's first batch waits for it
+    void* ev_evict_host_ = nullptr;   // evicted partitions have reached the pinned buffers
+    void* ev_admit_ready_ = nullptr;  // the staged admissions have reached dev_admit_
+    bool dev_staging() const { return prefetching_ && !dev_admit_.empty(); }
+    void perform_next_swap_staged();
 
     // one FIFO IO thread
     std::thread io_thread_;
