@@ -122,9 +122,18 @@ void PartitionBuffer::alloc_staging() {
     if (prefetching_ && dev_env && buffer_states_.size() > 1) {
         dev_admit_.assign(lanes_, nullptr);
         dev_evict_.assign(lanes_, nullptr);
-        for (int i = 0; i < lanes_; ++i) {
-            PB_HIPCHECK(hipMalloc(&dev_admit_[i], (size_t)slot_bytes()));
-            PB_HIPCHECK(hipMalloc(&dev_evict_[i], (size_t)slot_bytes()));
+        bool ok = true;
+        for (int i = 0; i < lanes_ && ok; ++i)
+            ok = hipMalloc(&dev_admit_[i], (size_t)slot_bytes()) == hipSuccess && hipMalloc(&dev_evict_[i], (size_t)slot_bytes()) == hipSuccess;
+        if (!ok) {  // HBM is full of slab: keep the exchange at the swap point (the path below)
+            (void)hipGetLastError();
+            for (auto m : dev_admit_)
+                if (m) (void)hipFree(m);
+            for (auto m : dev_evict_)
+                if (m) (void)hipFree(m);
+            dev_admit_.clear();
+            dev_evict_.clear();
+            return;
         }
         hipEvent_t e;
         PB_HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_compute_ = e;
