@@ -442,11 +442,38 @@ void PartitionBuffer::perform_next_swap_staged() {
     staged_admits_ = next;
     io_submit([this, evict, next] {
         hipStream_t s2 = (hipStream_t)swap_stream2_;
-        PB_HIPCHECK(hipEventSynchronize((hipEvent_t)ev_evict_host_));  // (also: ev_swapped_ has passed, i.e. dev_admit_ was consumed)
-        for (size_t i = 0; i < evict.size(); ++i) file_->writePartition(evict_mem_[i], partition_table_[evict[i]]);
+        // the look-ahead read does not have to queue behind the write-back (different partitions, different pinned buffers): side by side,
+        // unless a partition leaving now is the one coming back next (then the file must have it first)
+        bool overlap = !next.empty();
+        for (int n : next)
+            if (std::find(evict.begin(), evict.end(), n) != evict.end()) overlap = false;
+        std::string rerr;
+        std::thread reader;
+        auto read_next = [this, &next, s2] {
+            PB_HIPCHECK(hipStreamSynchronize(s2));  // the previous look-ahead's copies have left admit_mem_ (dev_admit_ was consumed before ev_swapped_)
+            for (size_t i = 0; i < next.size(); ++i) file_->readPartition(admit_mem_[i], partition_table_[next[i]]);
+        };
+        if (overlap)
+            reader = std::thread([this, &rerr, &read_next] {
+                try {
+                    (void)hipSetDevice(device_.index());
+                    read_next();
+                } catch (const std::exception& e) {
+                    rerr = e.what();
+                }
+            });
+        try {
+            PB_HIPCHECK(hipEventSynchronize((hipEvent_t)ev_evict_host_));  // (also: ev_swapped_ has passed, i.e. dev_admit_ was consumed)
+            for (size_t i = 0; i < evict.size(); ++i) file_->writePartition(evict_mem_[i], partition_table_[evict[i]]);
+        } catch (...) {
+            if (reader.joinable()) reader.join();
+            throw;
+        }
+        if (reader.joinable()) reader.join();
+        if (!rerr.empty()) throw MariusRuntimeException(rerr);
         if (next.empty()) return;
-        PB_HIPCHECK(hipStreamSynchronize(s2));  // the previous look-ahead's copies have left admit_mem_
-        for (size_t i = 0; i < next.size(); ++i) file_->readPartition(admit_mem_[i], partition_table_[next[i]]);
+        if (!overlap) read_next();
+        PB_HIPCHECK(hipEventSynchronize((hipEvent_t)ev_evict_host_));
         for (size_t i = 0; i < next.size(); ++i)
             PB_HIPCHECK(hipMemcpyAsync(dev_admit_[i], admit_mem_[i], (size_t)partition_table_[next[i]].total_size_, hipMemcpyHostToDevice, s2));
         PB_HIPCHECK(hipEventRecord((hipEvent_t)ev_admit_ready_, s2));
