@@ -357,7 +357,9 @@ def main():
         "lp_grad_adj": ("mfma_bf16", 2 * 3 * contraction_flops) if flash else ("mfma", contraction_flops),  # flash, fused form: the forward sweep (scores + V Neg)
         "lp_grad_neg": ("mfma_bf16", 2 * 3 * contraction_flops) if flash else ("mfma", contraction_flops),
         "gather_rows": ("hbm", U * d * 4.0 * 2 + U * 8.0),                    # read rows + write batch copy + ids
-        "segment_adagrad_scatter": ("hbm", L * d * 4.0 + U * d * 4.0 * 4),    # occurrence grads + r/w of w and s
+        # occurrence grads + r/w of w and s; since round 3 the launch pair also updates both relation tables (their 2 B occurrence rows are
+        # counted, their few thousand touched table rows are not)
+        "segment_adagrad_scatter": ("hbm", L * d * 4.0 + U * d * 4.0 * 4 + (2.0 * B * d * 4.0 if R > 1 else 0.0)),
         "lp_lse": ("hbm", 2.0 * Bp * (math.ceil(math.ceil(N / 64) / 4) * 8.0 + 12.0)),  # fused SoftmaxCE: only the per-group partials are re-read
         "lp_prep": ("hbm", 2.0 * Bp * d * 4.0 * 4),
         "lp_edge_bwd": ("hbm", 2.0 * B * d * 4.0 * 6),

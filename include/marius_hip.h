@@ -345,8 +345,9 @@ int marius_segment_adagrad_scatter_tracked(const float* rows, int64_t rows_ld, c
 /* The update of several independent tables — one training step's node table and relation tables (dataloader.cpp:550-564 for the former,
  * the optimizer step over model parameters, model.cpp:328-331, restricted to touched rows for the latter) — as ONE pair of launches instead of
  * one pair per table.  Every job carries the arguments of marius_segment_adagrad_scatter_tracked (plan and absmax may be NULL); results per
- * table are those of the separate calls, bit for bit.  Up to four jobs, all planned with 16-byte-aligned rows of the same width class, run
- * grouped; anything else falls back to the separate calls on the same stream. */
+ * table are those of the separate calls, bit for bit.  Up to four jobs, all planned with 16-byte-aligned rows of the same width class and with
+ * distinct tables, states and carry buffers, run grouped (side by side); anything else falls back to the separate calls, one after the other, on
+ * the same stream. */
 typedef struct marius_segment_update {
     const float* rows;
     int64_t rows_ld;

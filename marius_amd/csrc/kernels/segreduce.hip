@@ -688,6 +688,8 @@ extern "C" int marius_segment_adagrad_scatter_group(const marius_segment_update*
         const int v = row_vec_width(u.rows, u.rows_ld, u.d), v2 = row_vec_width(u.table, u.table_ld, u.d), v3 = row_vec_width(u.state, u.table_ld, u.d);
         const int per = cdiv(u.d, 256);
         if (v != 4 || v2 != 4 || v3 != 4 || per > 2 || (j > 0 && per != per0) || (ns && ns[0] == '1')) grouped = false;
+        for (int i = 0; i < j; ++i)  // jobs run side by side: a shared scratch or a shared table would race
+            if (jobs[i].carry == u.carry || jobs[i].table == u.table || jobs[i].state == u.state) grouped = false;
         per0 = per;
     }
     if (!grouped) {
