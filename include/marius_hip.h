@@ -44,10 +44,12 @@ enum {
 
 /* Bumped whenever a struct of this header changes size or meaning, or an entry point changes its signature (3: marius_lp_desc.flags /
  * reserved_, marius_lp_layout.adjrec / negrec / fpart / flash, planned segment update, zero-initialised sort workspace; 4: MARIUS_LP_KEEP_DADJ,
- * layout.dadj doubled on the flash path; 5: marius_lp_desc.absmax, marius_table_absmax, the *_tracked update entry points).  Every binder
+ * layout.dadj doubled on the flash path; 5: marius_lp_desc.absmax, marius_table_absmax, the *_tracked update entry points; 6:
+ * marius_segment_update, marius_segment_adagrad_scatter_group, marius_hip_struct_bytes(2); 7: marius_lp_desc.absmax_rel,
+ * marius_table_absmax_counted).  Every binder
  * compares the value it was built against with what the loaded library returns and refuses to run on a mismatch: marius_amd/hip.py lib(),
  * the host module's init (bindings.cpp), and the plug-in recipe of INTEGRATION.md. */
-#define MARIUS_HIP_ABI_VERSION 6
+#define MARIUS_HIP_ABI_VERSION 7
 int marius_hip_abi_version(void);
 /* sizeof(marius_lp_desc) / sizeof(marius_lp_layout) as the library was compiled: a second line of defence for ctypes mirrors */
 int marius_hip_struct_bytes(int which /* 0: marius_lp_desc, 1: marius_lp_layout, 2: marius_segment_update */);
@@ -227,6 +229,10 @@ typedef struct marius_lp_desc {
      * (16 bits): same speed, split error 3 2^-24 instead of 3 2^-18 of sum|a_k b_k|.  NULL: bf16 records.  The kernels read the bounds on
      * the device when they run: no host read-back, and the values must not change between marius_lp_forward and marius_lp_backward. */
     const float* absmax;
+    /* Optional: DEVICE float[1], the relation-table bound when it does not live behind the node bound (then absmax is float[1] too).  A
+     * caller whose batch rows are a gathered copy (sharded table, partition buffer, Model::train_batch) bounds the rows it gathered —
+     * marius_table_absmax over the copy — while the relation bound belongs to the model.  NULL: absmax[1]. */
+    const float* absmax_rel;
 } marius_lp_desc;
 
 /* marius_lp_desc.flags */
@@ -367,6 +373,9 @@ typedef struct marius_segment_update {
 } marius_segment_update;
 int marius_segment_adagrad_scatter_group(const marius_segment_update* jobs, int32_t njobs, marius_stream_t stream);
 int marius_table_absmax(const float* table, int64_t rows, int64_t ld, int32_t d, float* absmax, marius_stream_t stream);
+/* The same over the first *num_rows_dev rows (a device count: the unique count of map_tensors) of a capacity-sized row buffer. */
+int marius_table_absmax_counted(const float* table, int64_t capacity, const int64_t* num_rows_dev, int64_t ld, int32_t d, float* absmax,
+                                marius_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -79,7 +79,7 @@ def build_host(force=False, verbose=True):
                                                    "-I" + HOST_DIR, "-I/opt/rocm/include"]
     abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
     cflags = ["-O2", "-std=c++17", "-fPIC", "-fopenmp", "-D_GLIBCXX_USE_CXX11_ABI=%d" % abi, "-DTORCH_EXTENSION_NAME=_marius_host",
-              "-DTORCH_API_INCLUDE_EXTENSION_H", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-Wno-deprecated-declarations"]
+              "-DTORCH_API_INCLUDE_EXTENSION_H", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-Wno-deprecated-declarations", "-Wno-attributes"]
     jobs, objs = [], []
     for src in srcs:
         obj = os.path.join(OBJ_DIR, "host_" + os.path.basename(src)[:-4] + ".o")

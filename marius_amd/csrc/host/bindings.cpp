@@ -14,7 +14,7 @@ PYBIND11_MODULE(_marius_host, m) {
     py::register_exception<MariusRuntimeException>(m, "MariusRuntimeException");
     // the structs of include/marius_hip.h are passed by pointer: a library built from another revision of the header would read past them
     if (marius_hip_abi_version() != MARIUS_HIP_ABI_VERSION || marius_hip_struct_bytes(0) != (int)sizeof(marius_lp_desc) ||
-        marius_hip_struct_bytes(1) != (int)sizeof(marius_lp_layout))
+        marius_hip_struct_bytes(1) != (int)sizeof(marius_lp_layout) || marius_hip_struct_bytes(2) != (int)sizeof(marius_segment_update))
         throw std::runtime_error("_marius_host was built against C-ABI version " + std::to_string(MARIUS_HIP_ABI_VERSION) + " of libmarius_hip.so, the loaded library reports " +
                                  std::to_string(marius_hip_abi_version()) + ": rebuild both with `python -m marius_amd.build --host`");
 
@@ -99,6 +99,8 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("getNumInMemory", &PartitionBuffer::getNumInMemory)
         .def_readonly("swaps", &PartitionBuffer::swaps_)
         .def_readonly("prefetch_hits", &PartitionBuffer::prefetch_hits_)
+        .def("enable_absmax", &PartitionBuffer::enable_absmax)
+        .def_readonly("absmax", &PartitionBuffer::absmax_)  // running bound on |slab entries| (device float[1]); undefined until enabled
         .def_readonly("buffer_tensor_view", &PartitionBuffer::buffer_tensor_view_);
     py::class_<PartitionBufferStorage, Storage, std::shared_ptr<PartitionBufferStorage>>(m, "PartitionBufferStorage")
         .def(py::init<std::string, int64_t, int64_t, std::shared_ptr<PartitionBufferOptions>, torch::Device>(), py::arg("filename"), py::arg("dim0_size"),
@@ -124,6 +126,7 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_property_readonly("prefetch_hits", [](PartitionBufferStorage& s) { return s.buffer_->prefetch_hits_; })
         .def_property_readonly("swap_seconds", [](PartitionBufferStorage& s) { return s.buffer_->swap_seconds_; })
         .def_property_readonly("drain_seconds", [](PartitionBufferStorage& s) { return s.buffer_->drain_seconds_; })
+        .def_property_readonly("absmax", [](PartitionBufferStorage& s) { return s.buffer_->absmax_; })
         .def_readonly("options", &PartitionBufferStorage::options_);
     m.def("getEdgeBucketOrdering", &getEdgeBucketOrdering, py::arg("edge_bucket_ordering"), py::arg("num_partitions"), py::arg("buffer_capacity"),
           py::arg("fine_to_coarse_ratio"), py::arg("num_cache_partitions"), py::arg("randomly_assign_edge_buckets"), py::arg("generator"));
@@ -338,6 +341,12 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_readonly("range_state", &Model::range_state_)
         .def("track_ranges", &Model::track_ranges, py::arg("table"))
         .def("drop_ranges", &Model::drop_ranges)
+        .def_readonly("rel_ranges_valid", &Model::rel_ranges_valid_)
+        .def_readonly("row_bound", &Model::row_bound_)  // running bound of the rows of gathered batches (Model::bind_ranges)
+        .def("tracks", &Model::tracks, py::arg("table"))
+        .def("touch_relations", &Model::touch_relations)  // call after writing the relation tables through a raw pointer (ATen writes are seen by their version)
+        // what the last training forward packed its operand records with: "fp16" (22 significand bits per operand) or "bf16" (16)
+        .def_property_readonly("last_step_records", [](Model& self) { return std::string(self.ctx_.layout.flash ? (self.ctx_.desc.absmax ? "fp16" : "bf16") : "none"); })
         .def_property_readonly("last_step_flash", [](Model& self) { return self.ctx_.layout.flash != 0; })  // did the last fused step take the flash decoder path
         .def_readonly("relations_grad", &Model::relations_grad_)
         .def_readonly("inverse_relations_grad", &Model::inverse_relations_grad_);

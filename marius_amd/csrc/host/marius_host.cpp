@@ -393,6 +393,7 @@ void Batch::clear() {
     edges_ = global_edges_ = table_ = src_neg_indices_ = dst_neg_indices_ = src_neg_indices_mapping_ = dst_neg_indices_mapping_ = Tensor();
     src_neg_filter_ = dst_neg_filter_ = occ_perm_ = occ_inverse_ = occ_seg_offsets_ = num_unique_dev_ = Tensor();
     rel_uniq_ = rel_inverse_ = rel_perm_ = rel_seg_ = rel_count_ = occ_plan_ = rel_plan_ = Tensor();
+    row_bound_ = table_to_update_ = Tensor();
 }
 
 // ------------------------------------------------------------------------------------------------ LP context / fused decoder calls
@@ -430,6 +431,7 @@ static void lp_setup(LpContext& ctx, shared_ptr<EdgeDecoder> dec, const Tensor& 
     d.margin = margin;
     d.flags = lp_flags;
     d.absmax = (ctx.absmax.defined() && (lp_flags & MARIUS_LP_TRAIN_ONLY)) ? ctx.absmax.data_ptr<float>() : nullptr;
+    d.absmax_rel = (d.absmax && ctx.absmax_rel.defined()) ? ctx.absmax_rel.data_ptr<float>() : nullptr;
     Tensor e = edges.contiguous(), dn = dst_negs.contiguous(), sn = src_negs.defined() ? src_negs.contiguous() : Tensor();
     d.emb = fp(emb);
     d.emb_ld = emb.stride(0);
@@ -931,7 +933,7 @@ void Model::save(const std::string& directory) {  // model.cpp:82-106
     state_archive.save_to(directory + "model_state.pt");
 }
 void Model::load(const std::string& directory, bool train) {  // model.cpp:108-134
-    if (ranges_valid_) drop_ranges();  // the relation tables are about to be overwritten
+    touch_relations();  // the relation tables are about to be overwritten: their bound is rescanned before the next training forward
     torch::serialize::InputArchive model_archive, state_archive;
     model_archive.load_from(directory + "model.pt");
     const auto keys = decoder_param_keys(*this);
@@ -960,6 +962,7 @@ void Model::clear_grad() {
 }
 void Model::step() {
     for (auto& o : optimizers_) o->step();
+    touch_relations();  // a dense step moved the relation tables without tracking their magnitude
 }
 
 // decoder_methods.cpp:57-114 through the decoder's virtual operators, as differentiable libtorch ops: the path a user-defined comparator
@@ -1031,6 +1034,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> Model::forward_lp(shared_ptr<Batch> b
 std::tuple<Tensor, Tensor, Tensor, Tensor> Model::forward_lp_train(shared_ptr<Batch> batch) {
     if (decoder_->decoder_method_ != EdgeDecoderMethod::CORRUPT_NODE) return forward_lp(batch, true);
     const bool direct = batch->table_.defined();
+    bind_ranges(batch, direct);
     return node_corrupt_forward(decoder_, direct ? batch->global_edges_ : batch->edges_, direct ? batch->table_ : batch->node_embeddings_,
                                 direct ? batch->dst_neg_indices_ : batch->dst_neg_indices_mapping_,
                                 direct ? batch->src_neg_indices_ : batch->src_neg_indices_mapping_, &ctx_,
@@ -1134,7 +1138,7 @@ static bool relation_step_jobs(Model& m, shared_ptr<Batch> batch, marius_segment
         u.eps = opt->eps_;
         u.carry = (char*)m.rel_carry_.data_ptr() + dir * one;
         u.plan = rm.plan;
-        u.absmax = m.ranges_valid_ ? m.range_state_.data_ptr<float>() + 1 : nullptr;
+        u.absmax = m.relation_bound();
     }
     return true;
 }
@@ -1157,9 +1161,9 @@ static bool relation_step_sparse(Model& m, shared_ptr<Batch> batch) {
     for (int dir = 0; dir < ndir; ++dir) {
         Tensor& w = opt->params_[dir].first;
         const float* rows = (const float*)((const char*)c.workspace.data_ptr() + c.layout.grel[dir]);
-        if (m.ranges_valid_)
+        if (m.rel_ranges_valid_)
             mcheck(marius_segment_adagrad_scatter_tracked(rows, c.layout.d_ld, rm.perm, rm.inverse, rm.seg, B, c.desc.d, rm.uniq, fp(w), fp(opt->state_[dir]),
-                                                          w.stride(0), opt->learning_rate_, opt->eps_, m.rel_carry_.data_ptr(), rm.plan, m.range_state_.data_ptr<float>() + 1,
+                                                          w.stride(0), opt->learning_rate_, opt->eps_, m.rel_carry_.data_ptr(), rm.plan, m.relation_bound(),
                                                           cur_stream()));
         else if (rm.plan)
             mcheck(marius_segment_adagrad_scatter_planned(rows, c.layout.d_ld, rm.perm, rm.inverse, rm.seg, B, c.desc.d, rm.uniq, fp(w), fp(opt->state_[dir]),
@@ -1247,7 +1251,6 @@ shared_ptr<Model> initModelFromConfig(const ModelConfig& c, std::vector<torch::D
 }
 
 void Model::train_batch(shared_ptr<Batch> batch, bool call_step) {
-    if (ranges_valid_) drop_ranges();  // the caller applies the update itself (updateEmbeddings / indexAdd): nothing tracks the tables' magnitude
     if (!fused_ok()) return train_batch_generic(batch, call_step);
     if (call_step) clear_grad();
     forward_lp_train(batch);
@@ -1304,7 +1307,7 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
         u.eps = 1e-10f;
         u.carry = carry_.data_ptr();
         u.plan = batch->occ_plan_.data_ptr();
-        u.absmax = ranges_valid_ ? range_state_.data_ptr<float>() : nullptr;
+        u.absmax = node_track_;
         if (rel_ok) {
             mcheck(marius_segment_adagrad_scatter_group(jobs, njobs, cur_stream()));
             return;
@@ -1333,18 +1336,13 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
     if (!sparse_ok) {
         clear_grad();
         relation_grads_dense(*this, batch);
-        step();
-        if (ranges_valid_) {  // a dense optimizer step (Adam, SGD, weight decay) moved the relation tables: refresh their bound (two small tables)
-            for (auto& o : optimizers_)
-                for (auto& p : o->params_)
-                    mcheck(marius_table_absmax(fp(p.first), p.first.size(0), p.first.stride(0), (int32_t)p.first.size(1), range_state_.data_ptr<float>() + 1, cur_stream()));
-        }
+        step();  // (Adam, SGD, weight decay: the relation bound is rescanned before the next forward — touch_relations())
     }
-    if (ranges_valid_)
+    if (node_track_)
         mcheck(marius_segment_adagrad_scatter_tracked(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
                                                       batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, ip(batch->unique_node_indices_), fp(table),
                                                       fp(state), table.stride(0), sparse_lr_, 1e-10f, carry_.data_ptr(),
-                                                      batch->occ_plan_.defined() ? batch->occ_plan_.data_ptr() : nullptr, range_state_.data_ptr<float>(), cur_stream()));
+                                                      batch->occ_plan_.defined() ? batch->occ_plan_.data_ptr() : nullptr, node_track_, cur_stream()));
     else if (batch->occ_plan_.defined())
         mcheck(marius_segment_adagrad_scatter_planned(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
                                                       batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, ip(batch->unique_node_indices_), fp(table),
@@ -1357,8 +1355,7 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
 }
 
 void Model::backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step) {
-    if (ranges_valid_) drop_ranges();  // sharded table: the rows come from other ranks' shards, whose magnitudes this rank does not track
-    forward_lp_train(batch);
+    forward_lp_train(batch);  // (sharded table: the rows came from other ranks' shards; the bound is the one of the gathered copy itself, Batch::row_bound_)
     model_backward(*this, batch);
     bool done = false;
     if (local_relation_step) done = relation_step_sparse(*this, batch);
@@ -1379,17 +1376,76 @@ void Model::backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, b
                                        carry_.data_ptr(), cur_stream()));
 }
 
+static bool flash_f16_env() {
+    static const bool on = [] { const char* e = getenv("MARIUS_FLASH_F16"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+void Model::ensure_relation_ranges() {
+    Tensor* rels[2] = {&decoder_->relations_, &decoder_->inverse_relations_};
+    bool same = rel_ranges_valid_;
+    for (int i = 0; i < 2 && same; ++i) same = rels[i]->defined() ? tracked_rel_[i].is(*rels[i]) : tracked_rel_[i].ptr == nullptr;
+    if (same) return;
+    if (!range_state_.defined()) range_state_ = torch::zeros({2}, f32(device_));
+    else range_state_.narrow(0, 1, 1).zero_();
+    for (int i = 0; i < 2; ++i) {
+        tracked_rel_[i] = Scanned{};
+        if (!rels[i]->defined()) continue;
+        require_device(*rels[i], "Model::ensure_relation_ranges");
+        mcheck(marius_table_absmax(fp(*rels[i]), rels[i]->size(0), rels[i]->stride(0), (int32_t)rels[i]->size(1), range_state_.data_ptr<float>() + 1, cur_stream()));
+        tracked_rel_[i].set(*rels[i]);
+    }
+    rel_ranges_valid_ = true;
+}
+
 void Model::track_ranges(Tensor table) {
-    range_state_ = torch::zeros({2}, f32(device_));
+    if (!range_state_.defined()) range_state_ = torch::zeros({2}, f32(device_));
+    else range_state_.narrow(0, 0, 1).zero_();
     mcheck(marius_table_absmax(fp(table), table.size(0), table.stride(0), (int32_t)table.size(1), range_state_.data_ptr<float>(), cur_stream()));
-    for (Tensor* r : {&decoder_->relations_, &decoder_->inverse_relations_})
-        if (r->defined()) mcheck(marius_table_absmax(fp(*r), r->size(0), r->stride(0), (int32_t)r->size(1), range_state_.data_ptr<float>() + 1, cur_stream()));
-    ctx_.absmax = range_state_;
+    tracked_table_.set(table);
     ranges_valid_ = true;
+    ensure_relation_ranges();
 }
 void Model::drop_ranges() {
     ranges_valid_ = false;
-    ctx_.absmax = Tensor();
+    tracked_table_ = Scanned{};
+    ctx_.absmax = ctx_.absmax_rel = Tensor();
+    node_track_ = nullptr;
+}
+
+void Model::bind_ranges(shared_ptr<Batch> batch, bool direct) {
+    ctx_.absmax = ctx_.absmax_rel = Tensor();
+    node_track_ = nullptr;
+    if (!flash_f16_env()) return;
+    if (direct) {
+        if (external_node_bound_.defined()) {  // partition-buffer slab: the buffer's running bound
+            ensure_relation_ranges();
+            ctx_.absmax = external_node_bound_;
+            ctx_.absmax_rel = range_state_.narrow(0, 1, 1);
+            node_track_ = external_node_bound_.data_ptr<float>();
+        } else if (tracks(batch->table_)) {
+            ensure_relation_ranges();
+            ctx_.absmax = range_state_;
+            node_track_ = range_state_.data_ptr<float>();
+        }  // else nobody scanned this table: bf16 records
+        return;
+    }
+    // a gathered copy: bound the rows the decoder is about to read — by the gatherer's scan, or here
+    const Tensor& emb = batch->node_embeddings_;
+    if (!emb.defined() || !emb.is_cuda() || emb.dim() != 2 || emb.scalar_type() != torch::kFloat32 || emb.requires_grad()) return;
+    Tensor nb = batch->row_bound_;
+    if (!nb.defined()) {
+        if (!row_bound_.defined()) row_bound_ = torch::zeros({1}, f32(device_));
+        if (batch->num_unique_dev_.defined() && batch->num_unique_dev_.is_cuda())  // capacity-sized copies carry their row count on the device
+            mcheck(marius_table_absmax_counted(fp(emb), emb.size(0), ip(batch->num_unique_dev_), emb.stride(0), (int32_t)emb.size(1), row_bound_.data_ptr<float>(), cur_stream()));
+        else
+            mcheck(marius_table_absmax(fp(emb), emb.size(0), emb.stride(0), (int32_t)emb.size(1), row_bound_.data_ptr<float>(), cur_stream()));
+        nb = row_bound_;
+    }
+    ensure_relation_ranges();
+    ctx_.absmax = nb;
+    ctx_.absmax_rel = range_state_.narrow(0, 1, 1);
+    if (tracks(batch->table_to_update_)) node_track_ = range_state_.data_ptr<float>();  // gathered A/B form of the fused step on a tracked table
 }
 
 std::vector<Tensor> Model::dense_state() {
@@ -1940,11 +1996,18 @@ void SynchronousTrainer::train_one(bool fused) {
         // negatives drawn from the rows in memory), and the slab stays where it is across swaps.
         auto pbs = std::dynamic_pointer_cast<PartitionBufferStorage>(dataloader_->node_embeddings_);
         const bool direct = direct_env && ((mem && mem->data_.is_cuda()) || (pbs && pbs->data_.defined() && pbs->data_.is_cuda()));
-        // fp16 operand records need magnitude bounds of the tables: one pass over the table the first time, kept current by the fused update
-        // from then on (MARIUS_FLASH_F16=0: bf16 records).  Only for a device-resident table updated by this trainer alone.
-        const bool f16_env = [] { const char* e = getenv("MARIUS_FLASH_F16"); return !(e && e[0] == '0'); }();
-        if (direct && mem && f16_env && !model_->ranges_valid_) model_->track_ranges(mem->data_);
-        if ((!direct || !mem) && model_->ranges_valid_) model_->drop_ranges();  // (a swap brings rows in whose magnitudes nobody tracked: bf16 records)
+        // fp16 operand records need magnitude bounds (Model::bind_ranges): a device-resident table is scanned the first time the trainer meets it
+        // and kept current by the fused update; the partition buffer keeps its own running bound of the slab (MARIUS_FLASH_F16=0: bf16 records)
+        if (flash_f16_env()) {
+            if (mem && mem->data_.is_cuda() && !model_->tracks(mem->data_)) model_->track_ranges(mem->data_);
+            if (pbs && direct) {
+                pbs->buffer_->enable_absmax();
+                model_->external_node_bound_ = pbs->buffer_->absmax_;
+            } else {
+                model_->external_node_bound_ = Tensor();
+            }
+        }
+        batch->table_to_update_ = dataloader_->node_embeddings_->data_;
         if (!direct)
             batch->node_embeddings_ = (mem && batch->num_unique_dev_.defined()) ? mem->indexReadCounted(batch->unique_node_indices_, batch->num_unique_dev_)
                                                                                   : dataloader_->node_embeddings_->indexRead(batch->unique_node_indices_);
@@ -1958,8 +2021,8 @@ void SynchronousTrainer::train_one(bool fused) {
         model_->ev_grads_ = nullptr;
         dataloader_->gate_valid_ = true;
     } else {  // API-granular path, call for call the reference's loop (trainer.cpp:106-138)
-        if (model_->ranges_valid_) model_->drop_ranges();  // updateEmbeddings writes the table without tracking its magnitude
-        auto batch = dataloader_->getBatch(true);
+        if (model_->ranges_valid_) model_->drop_ranges();  // updateEmbeddings writes the table without tracking its magnitude: the table-wide bound is void
+        auto batch = dataloader_->getBatch(true);               // (the step itself bounds the rows it gathers: Model::bind_ranges)
         dataloader_->loadGPUParameters(batch);
         model_->train_batch(batch);
         dataloader_->updateEmbeddings(batch, true);

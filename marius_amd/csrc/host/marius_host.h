@@ -193,6 +193,8 @@ class Batch {
     // sorted-unique map of the batch's relation ids (column 1), prepared by the loader so the relation-gradient reduction needs no
     // sort on the compute stream: uniq [B] (zero tail), inverse [B], perm [B] int32, seg [B+1] int32
     Tensor rel_uniq_, rel_inverse_, rel_perm_, rel_seg_, rel_count_;
+    Tensor table_to_update_; // the table the fused update of this batch writes (set by the trainer; lets the model recognise a table it tracks)
+    Tensor row_bound_;       // optional device float[1] >= every |x| of node_embeddings_ (whoever gathered the rows scanned them: ShardedTrainer)
     void* ready_ = nullptr;  // hipEvent_t recorded on the loader stream when the batch was prepared ahead (DataLoader owns it)
 
     void accumulateGradients(float learning_rate);  // batch.cpp:62-79
@@ -295,7 +297,8 @@ struct LpContext {
     Tensor workspace;
     std::vector<Tensor> keep;  // tensors whose pointers sit in desc
     bool has_loss = false;
-    Tensor absmax;             // optional device float[2] (marius_lp_desc.absmax): set by Model::track_ranges, used only with MARIUS_LP_TRAIN_ONLY
+    Tensor absmax;             // optional device float (marius_lp_desc.absmax): bound on the node rows the step reads; set per step by Model::bind_ranges, used only with MARIUS_LP_TRAIN_ONLY
+    Tensor absmax_rel;         // optional device float[1] (marius_lp_desc.absmax_rel); undefined: absmax is float[2] and holds both
     Tensor view(size_t off, std::vector<int64_t> shape, std::vector<int64_t> strides = {}) const;
 };
 
@@ -491,14 +494,39 @@ class Model : public torch::nn::Module {
     // gpu_sync_interval steps); otherwise the dense gradients are left in relations_grad_ / inverse_relations_grad_ for an all-reduce + step()
     void backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step);
     std::vector<Tensor> dense_state();  // relation tables + their optimizer state (what gpu_model_average averages, pipeline_gpu.cpp:52-80)
-    // Magnitude bounds of the node table and the relation tables on the device (marius_lp_desc.absmax): with them the flash path packs fp16
-    // operand halves (22 significand bits per operand) instead of bf16 ones (16).  track_ranges(table) computes the bounds once (one pass
-    // over the table, no temporary) and the fused update keeps them current (marius_segment_adagrad_scatter_tracked); anything that writes
-    // the tables behind the model's back calls drop_ranges() and the path falls back to bf16 records until the next track_ranges().
-    Tensor range_state_;
-    bool ranges_valid_ = false;
+    // Magnitude bounds on the device (marius_lp_desc.absmax / absmax_rel): with them the flash path packs fp16 operand halves (22 significand
+    // bits per operand) instead of bf16 ones (16).  Three sources for the bound on the node rows a step reads, one per way the rows reach it:
+    //   * a device-resident table read in place: track_ranges(table) scans it once (one pass, no temporary) and the fused update keeps the bound
+    //     current (marius_segment_adagrad_scatter_tracked); the scan remembers WHICH table it saw (pointer, rows, ATen version) and is redone
+    //     when the trainer meets another one or an ATen op wrote it in between;
+    //   * a partition-buffer slab read in place: the buffer's own running bound (PartitionBuffer::absmax — initial fill, every admitted
+    //     partition at its swap, every tracked update);
+    //   * a gathered copy [U, d] (sharded table, Model::train_batch, gathered fused step): the copy itself is scanned — exact, local, no
+    //     collective — into Batch::row_bound_ (the sharded trainer does it on its exchange stream) or the model's own running row_bound_.
+    // The relation bound (range_state_[1]) belongs to the model: the touched-rows update tracks it, everything else that writes the relation
+    // tables (dense optimizer steps, load, replica averaging) calls touch_relations() and the bound is rescanned (two small tables) before
+    // the next training forward.
+    Tensor range_state_;  // device float[2]: [0] bound on the tracked table, [1] bound on the relation tables
+    Tensor row_bound_;    // device float[1]: running bound on the rows of gathered batches (monotone: every batch is max'ed in)
+    bool ranges_valid_ = false, rel_ranges_valid_ = false;
+    struct Scanned {
+        const void* ptr = nullptr;
+        int64_t rows = 0;
+        uint32_t version = 0;
+        bool is(const Tensor& t) const { return t.defined() && t.data_ptr() == ptr && t.size(0) == rows && t._version() == version; }
+        void set(const Tensor& t) { ptr = t.data_ptr(); rows = t.size(0); version = t._version(); }
+    };
+    Scanned tracked_table_, tracked_rel_[2];
+    Tensor external_node_bound_;  // set by the trainer for a partition-buffer slab (the buffer keeps it current)
+    float* node_track_ = nullptr; // the bound the node-table update of this step must keep current (set by bind_ranges; nullptr: none)
     void track_ranges(Tensor table);
+    bool tracks(const Tensor& table) const { return ranges_valid_ && tracked_table_.is(table); }
     void drop_ranges();
+    void touch_relations() { rel_ranges_valid_ = false; }
+    void ensure_relation_ranges();
+    float* relation_bound() { return rel_ranges_valid_ ? range_state_.data_ptr<float>() + 1 : nullptr; }
+    // chooses the bounds of one training forward (ctx_.absmax / absmax_rel); direct: the batch reads batch->table_ in place
+    void bind_ranges(shared_ptr<Batch> batch, bool direct);
 
    private:
     void train_batch_generic(shared_ptr<Batch> batch, bool call_step);  // the reference's autograd formulation, for user plug-ins

@@ -172,6 +172,19 @@ void PartitionBuffer::stage_in(const Partition& p, int64_t slot, void* staging) 
         PB_HIPCHECK(hipMemsetAsync(slot_ptr(slot) + p.total_size_, 0, (size_t)(slot_bytes() - p.total_size_), s));
 }
 
+void PartitionBuffer::scan_slot(int64_t slot, void* stream) {
+    if (!absmax_.defined() || dtype_ != torch::kFloat32) return;
+    mcheck(marius_table_absmax((const float*)slot_ptr(slot), partition_size_, embedding_size_, embedding_size_, absmax_.data_ptr<float>(), (marius_stream_t)stream));
+}
+
+void PartitionBuffer::enable_absmax() {
+    if (absmax_.defined() || dtype_ != torch::kFloat32) return;
+    absmax_ = torch::zeros({1}, torch::TensorOptions().dtype(torch::kFloat32).device(device_));
+    if (!loaded_) return;
+    // the slab as it is now, on the caller's stream (updates and swaps so far are ordered before it; what follows keeps the bound current)
+    for (int64_t slot = 0; slot < capacity_; ++slot) scan_slot(slot, c10::hip::getCurrentHIPStream(device_.index()).stream());
+}
+
 void PartitionBuffer::load() {  // buffer.cpp:372-418
     if (loaded_) return;
     if (buffer_state_.empty()) throw MariusRuntimeException("PartitionBuffer::load: setBufferOrdering first");
@@ -184,6 +197,7 @@ void PartitionBuffer::load() {  // buffer.cpp:372-418
         if (i >= (size_t)lanes_) PB_HIPCHECK(hipStreamSynchronize((hipStream_t)swap_stream_));  // staging lane still in flight
         file_->readPartition(st, p);
         stage_in(p, (int64_t)i, st);
+        scan_slot((int64_t)i, swap_stream_);
         p.present_ = true;
         p.buffer_idx_ = (int)i;
     }
@@ -222,24 +236,29 @@ void PartitionBuffer::sync() {
     std::thread writer;
     std::string werr;
     int k = 0;
-    for (auto& p : partition_table_) {
-        if (!p.present_) continue;
-        void* buf = stage[k & 1];
-        PB_HIPCHECK(hipMemcpyAsync(buf, slot_ptr(p.buffer_idx_), (size_t)p.total_size_, hipMemcpyDeviceToHost, s));
-        PB_HIPCHECK(hipStreamSynchronize(s));
-        if (writer.joinable()) writer.join();  // the other buffer's write; this one's buffer was released by the join before it
-        if (!werr.empty()) throw MariusRuntimeException(werr);
-        Partition* pp = &p;
-        writer = std::thread([this, buf, pp, &werr] {
-            try {
-                file_->writePartition(buf, *pp);
-            } catch (const std::exception& e) {
-                werr = e.what();
-            }
-        });
-        p.present_ = false;
-        p.buffer_idx_ = -1;
-        ++k;
+    try {
+        for (auto& p : partition_table_) {
+            if (!p.present_) continue;
+            void* buf = stage[k & 1];
+            PB_HIPCHECK(hipMemcpyAsync(buf, slot_ptr(p.buffer_idx_), (size_t)p.total_size_, hipMemcpyDeviceToHost, s));
+            PB_HIPCHECK(hipStreamSynchronize(s));
+            if (writer.joinable()) writer.join();  // the other buffer's write; this one's buffer was released by the join before it
+            if (!werr.empty()) throw MariusRuntimeException(werr);
+            Partition* pp = &p;
+            writer = std::thread([this, buf, pp, &werr] {
+                try {
+                    file_->writePartition(buf, *pp);
+                } catch (const std::exception& e) {
+                    werr = e.what();
+                }
+            });
+            p.present_ = false;
+            p.buffer_idx_ = -1;
+            ++k;
+        }
+    } catch (...) {  // a HIP error while a write-back is in flight: unwinding past a joinable std::thread would terminate the process
+        if (writer.joinable()) writer.join();
+        throw;
     }
     if (writer.joinable()) writer.join();
     if (!werr.empty()) throw MariusRuntimeException(werr);
@@ -368,6 +387,7 @@ void PartitionBuffer::performNextSwap() {  // buffer.cpp:501-547 (+ evict :637-6
             events.push_back(e);
             PB_HIPCHECK(hipMemsetAsync(slot_ptr(slots[i]) + pa->total_size_, 0, (size_t)(slot_bytes() - pa->total_size_), s2));
         }
+        if (pa) scan_slot(slots[i], s2);
     }
     PB_HIPCHECK(hipStreamSynchronize(s));
     PB_HIPCHECK(hipStreamSynchronize(s2));
@@ -425,6 +445,7 @@ void PartitionBuffer::perform_next_swap_staged() {
             const Partition& pa = partition_table_[admit[i]];
             PB_HIPCHECK(hipMemcpyAsync(slot_ptr(slots[i]), dev_admit_[i], (size_t)pa.total_size_, hipMemcpyDeviceToDevice, s));
             if (pa.total_size_ < slot_bytes()) PB_HIPCHECK(hipMemsetAsync(slot_ptr(slots[i]) + pa.total_size_, 0, (size_t)(slot_bytes() - pa.total_size_), s));
+            scan_slot(slots[i], s);  // ahead of ev_swapped_: the next state's first batch reads a bound that covers the admitted rows
         }
     }
     PB_HIPCHECK(hipEventRecord((hipEvent_t)ev_swapped_, s));

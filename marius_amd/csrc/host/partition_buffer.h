@@ -65,6 +65,11 @@ class PartitionBuffer {
     std::vector<int64_t> getBufferState() const { return buffer_state_; }
 
     Tensor buffer_tensor_view_;  // [capacity * partition_size, d] on the device
+    // Running bound on |entries of the slab| (device float[1]; marius_lp_desc.absmax of the table-direct training step): the whole slab once
+    // when enabled / loaded, every admitted partition right behind the copy that fills its slot (same stream, ahead of the event the next buffer
+    // state's first batch waits for), and the fused update's own tracking.  Never lowered: evictions only make it looser.
+    Tensor absmax_;
+    void enable_absmax();
     std::vector<Partition> partition_table_;
     // counters for tests / reporting
     int64_t swaps_ = 0, prefetch_hits_ = 0;
@@ -116,6 +121,7 @@ class PartitionBuffer {
     int64_t slot_bytes() const { return partition_size_ * embedding_size_ * dtype_size_; }
     char* slot_ptr(int64_t slot) const;
     void stage_in(const Partition& p, int64_t slot, void* staging);  // staging (already filled) -> slot, zero tail
+    void scan_slot(int64_t slot, void* stream);  // max |x| of one slot into absmax_ (no-op unless enabled)
     void alloc_staging();
     void free_staging();
 };

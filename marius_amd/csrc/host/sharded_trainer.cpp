@@ -88,6 +88,7 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
         s.cnt_send_dev = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
         s.cnt_recv_dev = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
         s.cnt_recv_host = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
+        s.row_bound = torch::zeros({1}, torch::TensorOptions().dtype(torch::kFloat32).device(dev));
         s.ready = new_event();
         s.fetched = new_event();
         s.computed = new_event();
@@ -122,6 +123,7 @@ void ShardedTrainer::prime() {
         pg_->allreduce(v)->wait();
         t.div_((double)world_);
     }
+    model_->touch_relations();
     std::vector<int64_t> ones(world_, 1);
     Tensor rows = torch::zeros({world_, d_}, torch::TensorOptions().dtype(torch::kFloat32).device(dev)), rows_out = torch::empty_like(rows);
     Tensor ids = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).device(dev)), ids_out = torch::empty_like(ids);
@@ -269,6 +271,12 @@ void ShardedTrainer::fetch(int64_t t) {
         span_begin(s, 6, xchg_stream_);
         s.emb = a2a(rows, s.recv_counts, s.send_counts, view(emb_[k], s.U, {d_}, torch::kFloat32));
         span_end(s, 6, xchg_stream_);
+        // Magnitude bound of the rows this batch will read (marius_lp_desc.absmax: fp16 operand halves on the flash path).  The rows come from
+        // every rank's shard, so no rank's own table bound covers them — but the requester holds all of them right here: one pass over the
+        // gathered copy (80 MB at the bench shape, on this stream, underneath the scoring of the previous batch) is exact and needs no
+        // collective.  One float per slot: the scoring of batch t reads its slot's bound while batch t + 1's is being written.
+        if (s.U > 0)
+            mcheck(marius_table_absmax(s.emb.data_ptr<float>(), s.U, s.emb.stride(0), d_, s.row_bound.data_ptr<float>(), (marius_stream_t)xchg.stream()));
     }
     span_end(s, 1, xchg_stream_);
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.fetched, xchg.stream()));
@@ -296,6 +304,7 @@ void ShardedTrainer::compute(int64_t t) {
     ST_HIPCHECK(hipStreamWaitEvent(main.stream(), (hipEvent_t)s.fetched, 0));
     span_begin(s, 2, main_stream_);
     s.batch->node_embeddings_ = s.emb;
+    s.batch->row_bound_ = s.row_bound;
     s.grad = view(grad_[t % RING], s.U, {d_}, torch::kFloat32);
     // replicas step on their own relation gradients between averaging points (sync_interval > 1); with sync_interval 1 the dense
     // gradients are all-reduced first
@@ -368,6 +377,7 @@ void ShardedTrainer::dense(int64_t t) {
             pg_->allreduce(v)->wait();
             tt.div_((double)world_);
         }
+        model_->touch_relations();  // the averaged tables are not the ones whose magnitude the local steps tracked
     }
 }
 

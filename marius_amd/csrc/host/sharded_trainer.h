@@ -61,6 +61,7 @@ class ShardedTrainer {
         std::vector<int64_t> send_counts, recv_counts;
         int64_t U = 0, nrecv = 0;
         Tensor emb, grad, local_ids;
+        Tensor row_bound;  // device float[1] >= every |x| of the rows this slot's batches gathered (Batch::row_bound_; max'ed in on the exchange stream)
     };
     shared_ptr<DataLoader> loader_;
     shared_ptr<Model> model_;

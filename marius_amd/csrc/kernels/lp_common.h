@@ -214,9 +214,13 @@ bool flash_chunked(int d); // d > 128: stored scores + per-chunk launches
 size_t flash_tiled_scores_bytes(const LpDims& D);  // the stored scores in tile order (internal layout; row-major [Bp, n_ld] with MARIUS_LP_STORE_SCORES)
 // fp16 operand records (lp_flash.hip): the scale an operand set is packed with, derived on the device from marius_lp_desc.absmax
 struct FlRange {
-    const float* absmax;  // nullptr: bf16 records, scales 1
-    int has_rel, relop_k;
+    const float* absmax;      // bound on |node rows|; nullptr: bf16 records, scales 1
+    const float* absmax_rel;  // bound on |relation rows| (marius_lp_desc.absmax_rel, or absmax + 1)
+    int adj_bound;            // FL_ADJ_*: how the bound on |adj| = |op(e, r)| follows from the two
 };
+// |op(e, r)| per relation operator (relation_operators.cpp:7-42): no relation / NoOp: M_e; Hadamard: M_e M_r; ComplexHadamard: each output
+// is a sum or difference of two products: 2 M_e M_r; Translation: M_e + M_r
+enum { FL_ADJ_NODE = 0, FL_ADJ_PRODUCT = 1, FL_ADJ_PRODUCT2 = 2, FL_ADJ_SUM = 3 };
 FlRange flash_range(const marius_lp_desc* desc, const LpDims& D);
 template <bool F16>
 __device__ __forceinline__ unsigned short fl_cvt16(float x) {
@@ -268,15 +272,19 @@ __host__ __device__ __forceinline__ float fl_scale_of(float M) {
 struct FlScales {
     float s_adj, s_neg;  // operand scales of the adj records and of the negative-row records (1, 1 on the bf16 path)
 };
-// absmax: device float[2] = {bound on |node table entries|, bound on |relation table entries|}; relop_k: how much the relation operator can
-// amplify (|e o r| <= k M_e M_r): 2 for ComplEx, 1 for the Hadamard product, and the bound is M_e alone without relations
-__device__ __forceinline__ FlScales fl_scales(const float* absmax, int has_rel, int relop_k) {
+// the scales every kernel of a step derives, on the device, from the same two bounds (so they agree without a host read-back)
+__device__ __forceinline__ FlScales fl_scales(const FlRange& rg) {
     FlScales f;
     f.s_adj = f.s_neg = 1.f;
-    if (absmax) {
-        const float me = absmax[0], mr = absmax[1];
+    if (rg.absmax) {
+        const float me = rg.absmax[0];
         f.s_neg = fl_scale_of(me);
-        f.s_adj = fl_scale_of(has_rel ? me * mr * (float)relop_k : me);
+        float ma = me;
+        if (rg.adj_bound != FL_ADJ_NODE) {
+            const float mr = rg.absmax_rel[0];
+            ma = rg.adj_bound == FL_ADJ_SUM ? me + mr : me * mr * (rg.adj_bound == FL_ADJ_PRODUCT2 ? 2.f : 1.f);
+        }
+        f.s_adj = fl_scale_of(ma);
     }
     return f;
 }

@@ -136,7 +136,7 @@ __device__ __forceinline__ void prep_flash_store(const PrepArgs& a, int dir, int
         // of two — else bf16 with s = 1): the same split flash_pack_adj_kernel makes (fl_write_piece)
         unsigned short H[4], L[4];
         if (a.frg.absmax) {
-            const float sc = fl_scales(a.frg.absmax, a.frg.has_rel, a.frg.relop_k).s_adj;
+            const float sc = fl_scales(a.frg).s_adj;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float xs = v[k] * sc;
@@ -1305,7 +1305,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     pa.frec = nullptr;
     pa.fKP = pa.fXR = 0;
     pa.fdadj = nullptr;
-    pa.frg = FlRange{nullptr, 0, 1};
+    pa.frg = FlRange{nullptr, nullptr, FL_ADJ_NODE};
     bool flash_fused_prep = false;
     {
         ProfScope ps(PROF_LP_PREP, st);

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void flash_pack_adj_kernel(const float* __rest
             if (4 * piece + 2 < d) v.z = src[2];
         }
     }
-    if (rg.absmax) fl_write_piece<true>(o, KP, piece, v, fl_scales(rg.absmax, rg.has_rel, rg.relop_k).s_adj);
+    if (rg.absmax) fl_write_piece<true>(o, KP, piece, v, fl_scales(rg).s_adj);
     else fl_write_piece<false>(o, KP, piece, v, 1.f);
 }
 
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void flash_pack_neg_kernel(const float* __rest
         // the negative's gradient row is accumulated by at most two workgroups of the backward: it starts from zero
         if (col0 + 4 * piece < d_ld) *reinterpret_cast<float4*>(gocc + ((dir ? off1 : off0) + c * N + j) * d_ld + col0 + 4 * piece) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (rg.absmax) fl_write_piece<true>(o, KP, piece, v, fl_scales(rg.absmax, rg.has_rel, rg.relop_k).s_neg);
+    if (rg.absmax) fl_write_piece<true>(o, KP, piece, v, fl_scales(rg).s_neg);
     else fl_write_piece<false>(o, KP, piece, v, 1.f);
 }
 
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashA
     constexpr int KP = 16 * KS, P = fl_pitch(KS), SLOT = fl_slot_bytes(KS), NSLOT = fl_slots(MODE);
     // ---- scales (all powers of two).  Accumulated scores carry s_x s_y; V = exp2(...) is formed VSH binades up so that its fp16 halves keep
     // their bits (V <= 2^FL_TAU in the fused sweep, <= 1 where lse is known); the outputs are scaled back when they leave the registers.
-    const FlScales sc_ = fl_scales(F16 ? a.rg.absmax : nullptr, a.rg.has_rel, a.rg.relop_k);
+    const FlScales sc_ = F16 ? fl_scales(a.rg) : FlScales{1.f, 1.f};
     constexpr int BASE = fl_base(MODE);                                      // which of the d <= 128 kernels this launch is shaped like
     constexpr bool SACC = (MODE == FLASH_FWDS), SLOAD = (MODE == FLASH_DADJS || MODE == FLASH_DNEGS);
     const float s_y = (BASE == FLASH_DNEG) ? sc_.s_adj : sc_.s_neg;
@@ -1077,15 +1077,19 @@ static int fl_dispatch(int ks, const FlashArgs& a, hipStream_t st) {
     return MARIUS_ERR_UNSUPPORTED;
 }
 
-static FlRange g_no_range = {nullptr, 0, 1};
+static FlRange g_no_range = {nullptr, nullptr, FL_ADJ_NODE};
 // magnitude bounds of the caller's tables -> fp16 records (marius_lp_desc.absmax); MARIUS_FLASH_F16=0 keeps the bf16 records
 FlRange flash_range(const marius_lp_desc* desc, const LpDims& D) {
     FlRange r = g_no_range;
     const char* e = getenv("MARIUS_FLASH_F16");
     if (desc->absmax && !(e && e[0] == '0')) {
         r.absmax = desc->absmax;
-        r.has_rel = (D.edge_cols == 3 && desc->rel) ? 1 : 0;
-        r.relop_k = D.relop == MARIUS_OP_COMPLEX_HADAMARD ? 2 : 1;
+        r.absmax_rel = desc->absmax_rel ? desc->absmax_rel : desc->absmax + 1;
+        const bool has_rel = D.edge_cols == 3 && desc->rel;
+        r.adj_bound = !has_rel ? FL_ADJ_NODE
+                      : D.relop == MARIUS_OP_HADAMARD ? FL_ADJ_PRODUCT
+                      : D.relop == MARIUS_OP_COMPLEX_HADAMARD ? FL_ADJ_PRODUCT2
+                      : D.relop == MARIUS_OP_TRANSLATION ? FL_ADJ_SUM : FL_ADJ_NODE;
     }
     return r;
 }

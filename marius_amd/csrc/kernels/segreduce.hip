@@ -590,24 +590,55 @@ extern "C" int marius_segment_adagrad_scatter_tracked(const float* rows, int64_t
     return segment_adagrad_scatter_impl(rows, rows_ld, perm, inverse, seg_offsets, n, d, uniq_ids, table, state, table_ld, lr, eps, carry, plan, absmax, stream);
 }
 
-// max |x| over a [rows, d] table (row pitch ld), max'ed into *absmax (the caller zero-initialises it): the starting point of marius_lp_desc.absmax
-__global__ __launch_bounds__(256) void table_absmax_kernel(const float* __restrict__ t, int64_t rows, int64_t ld, int d, float* __restrict__ absmax) {
+// max |x| over a [rows, d] table (row pitch ld), max'ed into *absmax (the caller zero-initialises it, or keeps a running bound): the starting
+// point of marius_lp_desc.absmax.  HBM-bound: contiguous rows (ld == d, 16-B aligned) are read as one flat float4 stream, four loads in flight
+// per lane; rows_dev (optional) = device count that replaces `rows`.
+template <bool FLAT>
+__global__ __launch_bounds__(256) void table_absmax_kernel(const float* __restrict__ t, int64_t rows, const int64_t* __restrict__ rows_dev, int64_t ld, int d,
+                                                           float* __restrict__ absmax) {
+    if (rows_dev) rows = min(rows, *rows_dev);
     float mx = 0.f;
-    const int64_t n = rows * d;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / d;
-        mx = fmaxf(mx, fabsf(t[r * ld + (i - r * d)]));
+    const int64_t n = rows * d, stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (FLAT) {
+        const int64_t n4 = n >> 2;
+        const float4* t4 = reinterpret_cast<const float4*>(t);
+        int64_t i = i0;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const float4 a = t4[i], b = t4[i + stride], c = t4[i + 2 * stride], e = t4[i + 3 * stride];
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))), fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))), fmaxf(fmaxf(fabsf(e.x), fabsf(e.y)), fmaxf(fabsf(e.z), fabsf(e.w)))));
+        }
+        for (; i < n4; i += stride) {
+            const float4 a = t4[i];
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        }
+        for (int64_t k = (n4 << 2) + i0; k < n; k += stride) mx = fmaxf(mx, fabsf(t[k]));
+    } else {
+        for (int64_t i = i0; i < n; i += stride) {
+            const int64_t r = i / d;
+            mx = fmaxf(mx, fabsf(t[r * ld + (i - r * d)]));
+        }
     }
     track_absmax(absmax, mx);
 }
-extern "C" int marius_table_absmax(const float* table, int64_t rows, int64_t ld, int32_t d, float* absmax, marius_stream_t stream) {
+static int table_absmax_launch(const float* table, int64_t rows, const int64_t* rows_dev, int64_t ld, int32_t d, float* absmax, marius_stream_t stream) {
     MARIUS_REQUIRE(rows >= 0 && d > 0 && ld >= d && absmax && (rows == 0 || table), "table_absmax: bad arguments");
     if (rows == 0) return MARIUS_OK;
+    const bool flat = ld == d && (reinterpret_cast<uintptr_t>(table) & 15) == 0;
     int64_t blocks = cdiv(rows * d, 256 * 16);
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    table_absmax_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(table, rows, ld, d, absmax);
+    if (flat) table_absmax_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(table, rows, rows_dev, ld, d, absmax);
+    else table_absmax_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(table, rows, rows_dev, ld, d, absmax);
     return check_launch("table_absmax");
+}
+extern "C" int marius_table_absmax(const float* table, int64_t rows, int64_t ld, int32_t d, float* absmax, marius_stream_t stream) {
+    return table_absmax_launch(table, rows, nullptr, ld, d, absmax, stream);
+}
+extern "C" int marius_table_absmax_counted(const float* table, int64_t capacity, const int64_t* num_rows_dev, int64_t ld, int32_t d, float* absmax,
+                                           marius_stream_t stream) {
+    MARIUS_REQUIRE(num_rows_dev, "table_absmax_counted: the device row count is required");
+    return table_absmax_launch(table, capacity, num_rows_dev, ld, d, absmax, stream);
 }
 
 static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, int64_t n,

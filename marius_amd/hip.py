@@ -18,7 +18,7 @@ REDUCE_SUM, REDUCE_MEAN = 0, 1
 LOSS = {"SOFTMAX_CE": 0, "RANKING": 1, "CROSS_ENTROPY": 2, "BCE_AFTER_SIGMOID": 3, "BCE_WITH_LOGITS": 4, "MSE": 5, "SOFTPLUS": 6}
 LP_TRAIN_ONLY, LP_STORE_SCORES, LP_KEEP_DADJ = 1, 2, 4   # marius_lp_desc.flags
 MT_STATE_WORDS = 625
-ABI_VERSION = 6  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
+ABI_VERSION = 7  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
 
 
 class MariusHipError(RuntimeError):
@@ -34,7 +34,7 @@ class LpDesc(C.Structure):
         ("rel", C.c_void_p), ("inv_rel", C.c_void_p), ("rel_ld", C.c_int64), ("R", C.c_int64),
         ("dst_filter", C.c_void_p), ("n_dst_filter", C.c_int64), ("src_filter", C.c_void_p), ("n_src_filter", C.c_int64),
         ("loss", C.c_int32), ("margin", C.c_float), ("flags", C.c_int32), ("reserved_", C.c_int32),
-        ("absmax", C.c_void_p),
+        ("absmax", C.c_void_p), ("absmax_rel", C.c_void_p),
     ]
 
 
@@ -102,6 +102,7 @@ SIGNATURES = {
     "marius_segment_adagrad_scatter_tracked": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
     "marius_segment_adagrad_scatter_group": (C.c_int, [_vp, _i32, _vp]),
     "marius_table_absmax": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp]),
+    "marius_table_absmax_counted": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
 }
 
 _lib = None
@@ -329,11 +330,13 @@ class LpWorkspace:
         self.device = device
         self._keep = None
 
-    def bind(self, emb, edges, dst_neg, src_neg, rel, inv_rel, dst_filter=None, src_filter=None, absmax=None):
-        """absmax: optional device float[2] (bound on |node rows|, bound on |relation rows|): fp16 operand records on the flash path"""
+    def bind(self, emb, edges, dst_neg, src_neg, rel, inv_rel, dst_filter=None, src_filter=None, absmax=None, absmax_rel=None):
+        """absmax: optional device float[2] (bound on |node rows|, bound on |relation rows|): fp16 operand records on the flash path;
+        absmax_rel: optional device float[1], the relation bound kept apart from the node bound (absmax is then float[1])"""
         d = self.desc
         d.absmax = absmax.data_ptr() if absmax is not None else None
-        self._absmax = absmax
+        d.absmax_rel = absmax_rel.data_ptr() if absmax_rel is not None else None
+        self._absmax = (absmax, absmax_rel)
         d.emb, d.emb_ld, d.U = emb.data_ptr(), emb.stride(0), emb.size(0)
         d.edges, d.dst_neg = edges.data_ptr(), dst_neg.data_ptr()
         d.src_neg = src_neg.data_ptr() if src_neg is not None else None
@@ -431,11 +434,16 @@ def segment_plan(um, n):
     return plan
 
 
-def table_absmax(*tables):
-    """device float[1]: max |x| over the given [rows, d] tables (marius_table_absmax)"""
-    out = torch.zeros(1, dtype=torch.float32, device=tables[0].device)
+def table_absmax(*tables, out=None, count=None):
+    """device float[1]: max |x| over the given [rows, d] tables (marius_table_absmax), max'ed into `out` when given; count: device int64
+    holding the number of valid rows of a capacity-sized buffer (marius_table_absmax_counted)"""
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float32, device=tables[0].device)
     for t in tables:
-        check(lib().marius_table_absmax(ptr(t), t.size(0), t.stride(0), t.size(1), ptr(out), stream_ptr()), "table_absmax")
+        if count is not None:
+            check(lib().marius_table_absmax_counted(ptr(t), t.size(0), ptr(count), t.stride(0), t.size(1), ptr(out), stream_ptr()), "table_absmax_counted")
+        else:
+            check(lib().marius_table_absmax(ptr(t), t.size(0), t.stride(0), t.size(1), ptr(out), stream_ptr()), "table_absmax")
     return out
 
 

@@ -18,7 +18,7 @@ from oracle import lp_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-DEC = {"DISTMULT": (0, 0), "COMPLEX": (1, 0)}
+DEC = {"DISTMULT": (0, 0), "COMPLEX": (1, 0), "TRANSLATION_DOT": (2, 0)}
 
 
 @pytest.fixture(scope="module")
@@ -162,6 +162,31 @@ def test_flash_forward_loss_backward_match_oracle(H, dev, decoder, use_inverse, 
     lse_want = torch.logsumexp(torch.cat([want["pos"][:, None], want["neg"]], 1), 1)
     mixed_close(W.lse(0), lse_want, "lse")
     check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv if use_inverse else None, U, R)
+
+
+@pytest.mark.parametrize("me,mr", [(0.05, 0.05), (0.5, 0.02), (2e-3, 1.5), (1.0, 1.0)])
+def test_flash_translation_operator_scales_adj_by_the_sum_of_the_bounds(H, dev, monkeypatch, me, mr):
+    """EdgeDecoder.relation_operator / comparator are writable, so TranslationOperator + DotCompare + SoftmaxCE reaches the flash
+    path.  Its adj rows are e + r, bounded by M_e + M_r — not by the product M_e M_r the Hadamard operators allow: with M_e = M_r = 0.05 the
+    product bound would scale the fp16 adj records by 2^20 and clamp every |adj| > 0.0625 silently.  Scores, loss and every gradient against the
+    oracle with fp16 records at magnitudes on both sides of 1."""
+    monkeypatch.setitem(O.DECODERS, "TRANSLATION_DOT", ("translation", "dot"))
+    decoder, B, C, N, d, U, R = "TRANSLATION_DOT", 300, 3, 200, 100, 400, 7
+    g = torch.Generator().manual_seed(11)
+    emb = (torch.rand(U, d, generator=g) * 2 - 1) * me
+    emb[0, 0] = me   # the bounds are attained
+    rel, inv = (torch.rand(R, d, generator=g) * 2 - 1) * mr, (torch.rand(R, d, generator=g) * 2 - 1) * mr
+    rel[0, 0] = mr
+    edges = torch.stack([torch.randint(U, (B,), generator=g), torch.randint(R, (B,), generator=g), torch.randint(U, (B,), generator=g)], 1)
+    edges[0] = torch.tensor([0, 0, 1])   # an adj row that reaches M_e + M_r in its first column
+    dst_neg, src_neg = torch.randint(U, (C, N), generator=g), torch.randint(U, (C, N), generator=g)
+    want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv)
+    W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, f16=True)
+    mixed_close(W.neg(0), want["neg"], "neg (split scores)")
+    mixed_close(W.neg(1), want["inv_neg"], "inv_neg (split scores)")
+    mixed_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss")
+    mixed_close(W.lse(0), torch.logsumexp(torch.cat([want["pos"][:, None], want["neg"]], 1), 1), "lse")
+    check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv, U, R)
 
 
 @pytest.mark.parametrize("scale,B,C,N,d", [(1.0, 700, 3, 1000, 100), (0.75, 260, 2, 300, 64), (0.05, 300, 3, 200, 100)])

@@ -20,24 +20,7 @@ from oracle import lp_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-RTOL = 1e-4
-FLOOR = 1e-2
-
-
-def close_report(got, want, what, rtol=RTOL, floor=FLOOR, atol_frac=None):
-    """worst pure-relative error above floor*max, worst absolute error (as a fraction of max) below it."""
-    got, want = got.detach().cpu().double().flatten(), want.detach().cpu().double().flatten()
-    assert got.shape == want.shape, (what, got.shape, want.shape)
-    mx = max(want.abs().max().item(), 1e-30)
-    err = (got - want).abs()
-    big = want.abs() >= floor * mx
-    rel = (err[big] / want.abs()[big]).max().item() if bool(big.any()) else 0.0
-    small = (err[~big].max().item() / mx) if bool((~big).any()) else 0.0
-    atol_frac = rtol * floor if atol_frac is None else atol_frac
-    print("%-28s worst rel (|want| >= %.0e max) %.2e   worst abs/max below %.2e   max %.3e" % (what, floor, rel, small, mx))
-    assert rel <= rtol, "%s: worst relative error %.3e > %.1e over entries >= %.0e x max" % (what, rel, rtol, floor)
-    assert small <= atol_frac, "%s: worst small-entry error %.3e x max > %.1e x max" % (what, small, atol_frac)
-    return rel, small
+from tolerance import FLOOR, RTOL, close_report  # noqa: F401  (tests/tolerance.py)
 
 
 @pytest.fixture(scope="module")

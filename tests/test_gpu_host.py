@@ -144,6 +144,8 @@ def test_trainer_epoch_matches_cpu_reference_path(M, dev, decoder, f, fused, d):
     close(model.decoder.relations, cpu.rel, rtol=3e-4)
     close(model.decoder.inverse_relations, cpu.inv_rel, rtol=3e-4)
     assert trainer.last_edges_per_second > 0
+    if model.last_step_flash:  # every way the rows reach the decoder carries a magnitude bound (table scan + tracked update when fused, the gathered
+        assert model.last_step_records == "fp16"  # copy's own bound on the API-granular path): 22-significand-bit operand halves, never bf16
     if fused and d == 200:
         assert bool(model.last_step_flash) == (f == 0.0)   # a DEG filter on wide rows must NOT take the chunked launches (they would ignore it)
 

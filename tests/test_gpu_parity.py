@@ -432,6 +432,38 @@ def test_tracked_update_keeps_the_magnitude_bound(H, dev, n, rows_of_table, d, p
     assert float(bound) == float(tb.abs().max()) > 0.05           # grew with the update (1e-3 -> ~lr), and is exact here: nothing shrank
 
 
+@pytest.mark.parametrize("rows,d,ld", [(200000, 100, 100), (1000, 100, 100), (777, 50, 50), (513, 33, 33), (4096, 100, 112), (3, 7, 7), (40000, 400, 400)])
+def test_table_absmax_flat_strided_and_counted(H, dev, rows, d, ld):
+    """marius_table_absmax / _counted: the bound marius_lp_desc.absmax starts from — exact max |x| for contiguous rows (flat float4 stream), padded
+    row pitch (the padding is NOT read: it holds larger values here), sizes that leave a ragged float4 tail, a running bound that is only ever
+    raised, and a capacity-sized buffer of which only the first *count rows are valid (the rest holds NaN / huge garbage)."""
+    g = torch.Generator().manual_seed(rows + d)
+    buf = torch.full((rows, ld), 1e30)
+    buf[:, :d] = torch.randn(rows, d, generator=g)
+    r0, c0 = int(torch.randint(rows, (1,), generator=g)), int(torch.randint(d, (1,), generator=g))
+    buf[r0, c0] = -7.5   # the maximum, negative, at an arbitrary place
+    t = buf.to(dev)[:, :d] if ld != d else buf[:, :d].contiguous().to(dev)
+    assert t.stride(0) == ld
+    out = H.table_absmax(t)
+    assert float(out) == 7.5
+    H.table_absmax(t * 0.5, out=out)   # running bound: a smaller table does not lower it
+    assert float(out) == 7.5
+    H.table_absmax(t * 2.0, out=out)
+    assert float(out) == 15.0
+    # counted: rows [count, capacity) are garbage
+    count = max(1, rows // 3)
+    cap = t.clone() if ld == d else t
+    garbage = cap.clone()
+    garbage[count:] = 1e30
+    garbage[count::2] = float("nan")
+    if count > 1:
+        garbage[count - 1, 0] = 3.25
+    want = float(garbage[:count].abs().max())
+    cnt = torch.tensor([count], dtype=torch.int64, device=dev)
+    assert float(H.table_absmax(garbage, count=cnt)) == want
+    assert float(H.table_absmax(garbage, count=torch.tensor([rows + 5], dtype=torch.int64, device=dev) * 0)) == 0.0   # zero valid rows
+
+
 @pytest.mark.parametrize("planned", [True, False])
 def test_grouped_update_of_three_tables_equals_the_separate_updates(H, dev, planned):
     """marius_segment_adagrad_scatter_group: a step's node table + both relation tables in one launch pair (the relation tables share one

@@ -128,22 +128,21 @@ def test_random_ordering_with_updates_matches_oracle(M, dev, tmp_path, prefetchi
     assert not np.array_equal(a.reshape(total, d), table.numpy())
 
 
-def _close(got, want, rtol=3e-4):
-    got, want = torch.as_tensor(got).double(), torch.as_tensor(want).double()
-    atol = rtol * max(want.abs().max().item(), 1e-30)
-    assert got.shape == want.shape
-    assert bool(((got - want).abs() <= atol + rtol * want.abs()).all()), (got - want).abs().max().item()
-
-
-@pytest.mark.parametrize("ordering,ratio,random_assign,prefetching,fused",
-                         [("OLD_BETA", 1, False, False, True), ("COMET", 2, True, True, True), ("NEW_BETA", 1, True, True, False)])
-def test_partitioned_epochs_match_oracle(M, dev, tmp_path, monkeypatch, ordering, ratio, random_assign, prefetching, fused):
+@pytest.mark.parametrize("ordering,ratio,random_assign,prefetching,fused,d",
+                         [("OLD_BETA", 1, False, False, True, 16), ("COMET", 2, True, True, True, 16), ("NEW_BETA", 1, True, True, False, 16),
+                          ("COMET", 2, True, True, True, 32), ("OLD_BETA", 1, False, False, True, 32), ("NEW_BETA", 1, True, True, False, 32)])
+def test_partitioned_epochs_match_oracle(M, dev, tmp_path, monkeypatch, ordering, ratio, random_assign, prefetching, fused, d):
     """Two epochs of out-of-core training: ordering from the generator stream, per buffer state the assigned edge buckets with
     buffer-local ids, negatives from the in-memory id range, swap, write-back — against the same loop on the CPU oracle.  The
     permutation of every buffer state but the first of an epoch is drawn ahead by the host thread (the sizes of all states are known once
-    the epoch's ordering is drawn) and must be the one the serial order draws."""
+    the epoch's ordering is drawn) and must be the one the serial order draws.
+    d = 32 puts the step on the flash decoder path, whose operand records must carry fp16 halves (22 significand bits) here too: the slab's
+    running magnitude bound (initial fill + every admitted partition + the tracked update) for the fused step that reads the slab in place, the
+    bound of the gathered copy for the API-granular step.  Tolerance: the tiers of the single-GPU training path (tests/tolerance.py)."""
+    from tolerance import tiers
+
     monkeypatch.setenv("MARIUS_SHUFFLE_AHEAD_MIN", "0")
-    num_nodes, R, d, B, C, N, E, seed, p, c = 2003, 7, 16, 96, 4, 24, 3000, 99, 8, 4
+    num_nodes, R, B, C, N, E, seed, p, c = 2003, 7, 96, 4, 24, 3000, 99, 8, 4
     g = torch.Generator().manual_seed(1)
     table = (torch.rand(num_nodes, d, generator=g) - 0.5) * 0.6
     raw = torch.stack([torch.randint(num_nodes, (E,), generator=g), torch.randint(R, (E,), generator=g), torch.randint(num_nodes, (E,), generator=g)], 1)
@@ -171,6 +170,9 @@ def test_partitioned_epochs_match_oracle(M, dev, tmp_path, monkeypatch, ordering
     trainer = M.SynchronousTrainer(loader, model)
     trainer.fused_update = fused
     trainer.train(2)
+    assert bool(model.last_step_flash) == (d > 16)
+    if d > 16:
+        assert model.last_step_records == "fp16", "the partitioned step fell back to bf16 operand halves"
     assert emb.swaps > 0 and loader.graph.num_nodes_in_memory == c * (-(-num_nodes // p))
     assert loader.shuffle_ahead_hits > 0 and loader.shuffle_ahead_misses == 0
     # ---- oracle: the same loop (trainer.cpp:94-161 with dataloader.cpp:120-183, 296-345, 566-600)
@@ -206,10 +208,12 @@ def test_partitioned_epochs_match_oracle(M, dev, tmp_path, monkeypatch, ordering
     got_emb, want_emb = (np.fromfile(files[k][0], dtype=np.float32).reshape(num_nodes, d) for k in ("dev", "cpu"))
     got_st, want_st = (np.fromfile(files[k][1], dtype=np.float32).reshape(num_nodes, d) for k in ("dev", "cpu"))
     assert not np.allclose(want_emb, table.numpy())
-    _close(got_emb, want_emb)
-    _close(got_st, want_st)
-    _close(model.decoder.relations.cpu(), cpu.rel)
-    _close(model.decoder.inverse_relations.cpu(), cpu.inv_rel)
+    touched = (want_st > 0).any(1)
+    assert np.array_equal(touched, (got_st > 0).any(1)) and np.array_equal(got_emb[~touched], want_emb[~touched])
+    tiers(torch.from_numpy(got_emb[touched]), torch.from_numpy(want_emb[touched]), "node rows after two partitioned epochs")
+    tiers(torch.from_numpy(got_st[touched]), torch.from_numpy(want_st[touched]), "Adagrad state after two partitioned epochs")
+    tiers(model.decoder.relations.cpu(), cpu.rel, "relations")
+    tiers(model.decoder.inverse_relations.cpu(), cpu.inv_rel, "inverse relations")
 
 
 def test_marius_train_with_partition_buffer_config(M, dev, tmp_path):

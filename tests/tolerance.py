@@ -1,0 +1,30 @@
+"""Tolerance reports shared by the GPU parity tests.
+
+`close_report` asserts the worst PURE relative error over every entry with |want| >= floor x max|want| against rtol and an absolute error of
+atol_frac x max|want| below that, and prints the numbers so the claim is checkable.  `tiers` is the three-tier bound the single-GPU training
+path is held to (tests/test_gpu_fullshape.py): 1e-4 over entries >= 0.1 max, 3e-4 over entries >= 0.01 max, 3e-6 x max below — north_star's
+"within 1e-4 relative on float scores" carried through accumulated gradients and updated parameters."""
+
+RTOL = 1e-4
+FLOOR = 1e-2
+
+
+def close_report(got, want, what, rtol=RTOL, floor=FLOOR, atol_frac=None):
+    """worst pure-relative error above floor*max, worst absolute error (as a fraction of max) below it."""
+    got, want = got.detach().cpu().double().flatten(), want.detach().cpu().double().flatten()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    mx = max(want.abs().max().item(), 1e-30)
+    err = (got - want).abs()
+    big = want.abs() >= floor * mx
+    rel = (err[big] / want.abs()[big]).max().item() if bool(big.any()) else 0.0
+    small = (err[~big].max().item() / mx) if bool((~big).any()) else 0.0
+    atol_frac = rtol * floor if atol_frac is None else atol_frac
+    print("%-28s worst rel (|want| >= %.0e max) %.2e   worst abs/max below %.2e   max %.3e" % (what, floor, rel, small, mx))
+    assert rel <= rtol, "%s: worst relative error %.3e > %.1e over entries >= %.0e x max" % (what, rel, rtol, floor)
+    assert small <= atol_frac, "%s: worst small-entry error %.3e x max > %.1e x max" % (what, small, atol_frac)
+    return rel, small
+
+
+def tiers(got, want, what):
+    close_report(got, want, what, floor=0.1, atol_frac=1.0)
+    close_report(got, want, what, rtol=3e-4, floor=0.01, atol_frac=3e-6)
