@@ -125,13 +125,59 @@ def dominant_roofline(avg_ms, B, C, N, d, ndir, flash, pmc_ok, kernel="lp_grad_a
     return out
 
 
-def fp32_exact_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_flops, steps=20, warmup=5):
-    """ms per step and the dominant kernel's roofline with MARIUS_FLASH=0: every product an fp32 product (v_mfma_f32_32x32x2_f32), the
-    400 MB score tensor materialised and re-read by the merged backward launch — the round-1 path, parity-identical to the reference's
-    arithmetic up to summation order."""
+def arith_check_leg(H, cfg, B, C, N, dev, seed=4242):
+    """CHECKER leg (oracle/arith_check.py; like cpu_baseline, the only other place bench.py touches oracle/): one batch of the workload's shape
+    through the flash decoder path on the device, through the reference's op sequence in float32 (torch CPU: the ATen calls of
+    comparators.cpp:62-73, loss.cpp:50-67, autograd) and in float64; per quantity the max / RMS error of the device path and of the reference's
+    own fp32 evaluation against float64, and their ratio.  `ok` = every ratio <= 1: the split arithmetic is then no worse than the reference's
+    fp32 and carries the headline; otherwise the headline is measured with MARIUS_FLASH=0 (fp32 products) and the split path is `fast_path`."""
+    from oracle import lp_oracle as O
+    from oracle.arith_check import error_pairs
+
+    decoder, d = cfg["decoder"], cfg["d"]
+    relop, cmp_ = {"DISTMULT": (0, 0), "COMPLEX": (1, 0)}[decoder]
+    U, R = 4 * B, min(cfg["num_relations"], 1000)
+    g = torch.Generator().manual_seed(seed)
+    emb = torch.randn(U, d, generator=g) * 0.5
+    edges = torch.stack([torch.randint(U, (B,), generator=g), torch.randint(R, (B,), generator=g), torch.randint(U, (B,), generator=g)], 1)
+    dst_neg, src_neg = torch.randint(U, (C, N), generator=g), torch.randint(U, (C, N), generator=g)
+    rel = O.init_relations(decoder, R, d) + 0.3 * torch.randn(R, d, generator=g)
+    inv = O.init_relations(decoder, R, d) + 0.3 * torch.randn(R, d, generator=g)
+    t0 = time.perf_counter()
+    W = H.LpWorkspace(relop, cmp_, d, B, C, N, True, H.REDUCE_SUM, 3, True, dev, flags=H.LP_TRAIN_ONLY | H.LP_STORE_SCORES)
+    if W.layout.flash != 1:
+        return None
+    t = lambda x: x.to(dev)  # noqa: E731
+    absmax = torch.cat([H.table_absmax(t(emb)), H.table_absmax(t(rel), t(inv))])
+    W.bind(t(emb), t(edges), t(dst_neg), t(src_neg), t(rel), t(inv), absmax=absmax)
+    W.forward()
+    W.loss()
+    W.backward()
+    torch.cuda.synchronize()
+    got = {"neg": W.neg(0).cpu(), "inv_neg": W.neg(1).cpu(), "lse": W.lse(0).cpu(), "inv_lse": W.lse(1).cpu(), "rowloss": W.rowloss(0).cpu(),
+           "inv_rowloss": W.rowloss(1).cpu(), "loss": W.loss_values()[0:1].cpu(), "gocc": W.gocc()[:, :d].cpu(), "grel": W.grel(0)[:B, :d].cpu(),
+           "inv_grel": W.grel(1)[:B, :d].cpu()}
+    del W
+    pairs = error_pairs(decoder, emb, edges, dst_neg, src_neg, rel, inv, got)
+    asserted = ("scores", "lse", "row_loss", "occ_grad", "rel_grad")
+    ok = all(pairs[q]["ratio_max"] <= 1.0 and pairs[q]["ratio_rms"] <= 1.0 for q in asserted)
+    rnd = lambda p: {k: float("%.3g" % v) for k, v in p.items()}  # noqa: E731
+    return {"ok": ok, "quantities": {q: rnd(p) for q, p in pairs.items()}, "asserted": list(asserted),
+            "what": "error against the float64 oracle of (device) the flash path [fp16-half split x 3 products] and (fp32) the reference's own float32 "
+                    "evaluation [ATen CPU ops] on one batch of the workload's shape: max |err| / max |want| and rms err / rms want; ratio = device / fp32; "
+                    "`loss` is one number per batch (reported, not asserted)",
+            "inputs": "B=%d C=%d N=%d d=%d, %d candidate rows ~ N(0, 0.5^2), %d relations, seed %d" % (B, C, N, d, U, R, seed),
+            "seconds": round(time.perf_counter() - t0, 1)}
+
+
+def alt_arithmetic_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_flops, flash_env, steps=20, warmup=5):
+    """ms per step and the dominant kernel's roofline of the OTHER arithmetic, measured after the timed region on a fresh Model / loader over
+    the same tables.  flash_env "0": every product an fp32 product (v_mfma_f32_32x32x2_f32), the 400 MB score tensor materialised and re-read by
+    the merged backward launch — the round-1 path, the reference's arithmetic up to summation order (`fp32_exact`).  flash_env "1": the flash
+    path (`fast_path`), when the headline had to be measured in fp32."""
     R, d, B, C, N = cfg["num_relations"], cfg["d"], cfg["B"], cfg["C"], cfg["N"]
     prev = os.environ.get("MARIUS_FLASH")
-    os.environ["MARIUS_FLASH"] = "0"
+    os.environ["MARIUS_FLASH"] = flash_env
     try:
         gen = M.MariusGenerator(43)
         loader = M.DataLoader(M.InMemory(edges_all), M.InMemory(table), M.InMemory(state), M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen), gen, B, True)
@@ -143,7 +189,7 @@ def fp32_exact_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_flop
         loader.initializeBatches(True)
         trainer.train_steps(warmup)
         torch.cuda.synchronize()
-        assert not model.last_step_flash
+        assert bool(model.last_step_flash) == (flash_env != "0")
         H.profile_reset()
         H.profile_enable(True, only="lp_grad_adj")
         t0 = time.perf_counter()
@@ -152,14 +198,25 @@ def fp32_exact_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_flop
         dt = time.perf_counter() - t0
         H.profile_enable(False)
         ms, cnt = H.profile_read().get("lp_grad_adj", (0.0, 0))
-        out = {"ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup, "dtype": "f32 (v_mfma_f32_32x32x2_f32, fp32 products and accumulate)",
-               "loss_last_batch": float(model.loss[0].item()),
-               "note": "MARIUS_FLASH=0: the step in the reference's arithmetic (scores materialised); the headline value uses 16 significand bits per contraction operand"}
-        if cnt:
-            avg = ms / cnt
-            ach = 2 * contraction_flops / (avg * 1e-3) / 1e12
-            out.update({"kernel": "lp_grad16 (dAdj + dNeg contractions from the stored scores, one launch)", "kernel_avg_ms": round(avg, 4), "achieved": round(ach, 2),
-                        "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4)})
+        ndir = 2 if R > 1 else 1
+        out = {"ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup, "value": round(B * steps / dt * ndir * (1 + N), 1), "unit": "scored edges/s",
+               "loss_last_batch": float(model.loss[0].item())}
+        if flash_env == "0":
+            out.update({"dtype": "f32 (v_mfma_f32_32x32x2_f32, fp32 products and accumulate)",
+                        "note": "MARIUS_FLASH=0: the step with every contraction product an fp32 product on the FP32 matrix pipe (scores materialised)"})
+            if cnt:
+                avg = ms / cnt
+                ach = 2 * contraction_flops / (avg * 1e-3) / 1e12
+                out.update({"kernel": "lp_grad16 (dAdj + dNeg contractions from the stored scores, one launch)", "kernel_avg_ms": round(avg, 4), "achieved": round(ach, 2),
+                            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4)})
+        else:
+            out.update({"dtype": "f32 (contractions: 2-way %s split x 3 products, f32 accumulate)" % model.last_step_records,
+                        "note": "the flash path: NOT the headline because arith_check.ok is false"})
+            if cnt:
+                avg = ms / cnt
+                ach = 2 * 3 * contraction_flops / (avg * 1e-3) / 1e12
+                out.update({"kernel": "flash fused sweep (scores + V Neg)", "kernel_avg_ms": round(avg, 4), "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": round(ach / MFMA_BF16_PEAK_TF, 4)})
         return out
     finally:
         if prev is None:
@@ -222,7 +279,8 @@ def main():
     ap.add_argument("--driver", default="cpp", choices=["cpp", "py"], help="host loop: C++ SynchronousTrainer (default) or the ctypes step driver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--no-fp32-pass", action="store_true", help="skip the short MARIUS_FLASH=0 pass that reports the fp32-exact step time beside the headline number")
+    ap.add_argument("--no-fp32-pass", action="store_true", help="skip the short pass that reports the step time of the other arithmetic (fp32_exact / fast_path) beside the headline number")
+    ap.add_argument("--no-arith-check", action="store_true", help="skip the arithmetic check (flash path vs the reference's fp32 evaluation vs float64) that decides which path carries the headline")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--strong", action="store_true", help="N > 1: strong scaling (the global batch stays B; default is weak scaling, B per GPU)")
     ap.add_argument("--degree-fraction", type=float, default=0.0, help="fraction of every chunk's negatives drawn from the batch's own endpoints (the headline "
@@ -261,6 +319,19 @@ def main():
     if a.num_nodes:
         cfg["num_nodes"] = a.num_nodes
     num_nodes, R, d, B, C, N = cfg["num_nodes"], cfg["num_relations"], cfg["d"], cfg["B"], cfg["C"], cfg["N"]
+
+    # ---- which arithmetic carries the headline: the flash path only if it is no worse than the reference's own fp32 evaluation
+    arith = None
+    if rank == 0 and not a.no_arith_check and a.loss.upper() == "SOFTMAX_CE" and cfg["decoder"] in ("DISTMULT", "COMPLEX") and R > 1 and \
+            os.environ.get("MARIUS_FLASH", "1") != "0" and flash_selected(H, cfg, B, C, N) and d <= 128:
+        arith = arith_check_leg(H, cfg, B, C, N, dev)
+    demote = torch.tensor([1 if (arith is not None and not arith["ok"]) else 0], device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.broadcast(demote, 0)
+    if int(demote.item()):
+        os.environ["MARIUS_FLASH"] = "0"  # every rank: the timed region runs fp32 products
+    a.arith_check = arith
 
     if world > 1 or os.environ.get("MARIUS_FORCE_SHARDED") == "1":
         if world == 1:  # exercise the N>1 code path on a single GPU (tests / profiling)
@@ -440,9 +511,12 @@ def main():
     # ---- the same step in the reference's own arithmetic: fp32 products on the FP32 matrix pipe, scores materialised
     # (MARIUS_FLASH=0), a short pass after the timed region on a fresh Model / loader over the same tables — what the 16-bit-significand
     # contraction of the headline number buys, stated next to it
-    fp32_exact = None
-    if flash and a.driver == "cpp" and not a.no_fp32_pass:
-        fp32_exact = fp32_exact_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_flops)
+    fp32_exact = fast_path = None
+    if a.driver == "cpp" and not a.no_fp32_pass and a.loss.upper() == "SOFTMAX_CE":
+        if flash:
+            fp32_exact = alt_arithmetic_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_flops, "0")
+        elif arith is not None and not arith["ok"]:
+            fast_path = alt_arithmetic_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_flops, "1")
 
     # ---- CPU baseline: the oracle (port of the reference's CPU path) on a bounded sample, host cores of this box
     cpu = None
@@ -465,12 +539,12 @@ def main():
         "metric": "edges/sec scored (pos+neg)", "value": round(scored_eps, 1), "unit": "scored edges/s",
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "host_issue_ms_per_step": round(host_issue / a.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": ("f32 (contractions: 2-way %s split x 3 products, f32 accumulate)" % (
-            "fp16 [22 significand bits per operand]" if (a.driver == "cpp" and model.ranges_valid) else "bf16 [16 significand bits per operand]")) if flash else "f32", "data": "synthetic",
+            "fp16 [22 significand bits per operand]" if (a.driver == "cpp" and model.last_step_records == "fp16") else "bf16 [16 significand bits per operand]")) if flash else "f32", "data": "synthetic",
         "config": {"workload": "%s %s d=%d in-memory, B=%d C=%d N=%d%s inverse_edges, SoftmaxCE SUM, Adagrad lr 0.1, %s edges" % (
             a.workload, cfg["decoder"], d, B, C, N, (" degree_fraction %.2f" % a.degree_fraction) if a.degree_fraction else "", a.edge_dist), "num_nodes": num_nodes, "num_relations": R, "num_edges": cfg["num_edges"],
             "parallelism": "single GPU", "host": "C++ SynchronousTrainer (libtorch)" if a.driver == "cpp" else "python ctypes driver"},
         "positive_edges_per_s": round(pos_eps, 1), "unique_rows_last_batch": U, "loss_last_batch": loss,
-        "roofline": roofline, "fp32_exact": fp32_exact, "hbm_read_roofline_gather_score": gs, "kernels": kernels, "cpu_baseline": cpu,
+        "roofline": roofline, "arith_check": arith, "fp32_exact": fp32_exact, "fast_path": fast_path, "hbm_read_roofline_gather_score": gs, "kernels": kernels, "cpu_baseline": cpu,
     }
     emit_json(out)
 

@@ -46,7 +46,7 @@ enum {
  * reserved_, marius_lp_layout.adjrec / negrec / fpart / flash, planned segment update, zero-initialised sort workspace; 4: MARIUS_LP_KEEP_DADJ,
  * layout.dadj doubled on the flash path; 5: marius_lp_desc.absmax, marius_table_absmax, the *_tracked update entry points; 6:
  * marius_segment_update, marius_segment_adagrad_scatter_group, marius_hip_struct_bytes(2); 7: marius_lp_desc.absmax_rel,
- * marius_table_absmax_counted).  Every binder
+ * marius_table_absmax_counted; marius_lp_layout lost the operand planes of the removed bf16x6 kernels and the stream-K partials).  Every binder
  * compares the value it was built against with what the loaded library returns and refuses to run on a mismatch: marius_amd/hip.py lib(),
  * the host module's init (bindings.cpp), and the plug-in recipe of INTEGRATION.md. */
 #define MARIUS_HIP_ABI_VERSION 7
@@ -266,12 +266,6 @@ typedef struct marius_lp_layout {
     size_t grel[2];   /* [B, d]      per-edge relation gradients (dir 0 -> relations_, dir 1 -> inverse)         */
     size_t aux;       /* scratch (row norms etc.)                                                                */
     size_t lsepart;   /* [groups][ndir][Bp][2] partial (max, sum exp) of the score epilogue (fused SoftmaxCE)                */
-    size_t embp;      /* [3][2B + 2CN][kp] bf16: exact 3-way split (hi, mid, lo) of the batch rows, kp = 16 ceil(d/16)          */
-    size_t adjp;      /* [3][ndir Bp][kp]  bf16: the same split of adj (operands of the bf16-split contraction kernels)        */
-    int64_t kp;
-    size_t negt;      /* [ncd][3][kp][N  rounded to 32] bf16: negatives of each chunk-direction, contraction-major                */
-    size_t adjt;      /* [ncd][3][kp][Bc rounded to 32] bf16: adj rows of each chunk-direction, contraction-major                 */
-    size_t gradpart;  /* partial accumulators of the stream-K backward launch (two tiles per persistent workgroup)               */
     size_t dpos[2];   /* [Bp]        dL/d pos, written by marius_lp_loss, read by the edge backward                               */
     size_t vlog;      /* [ndir][Bp, n_ld] log(dL/dneg / scale) for the non-negative-gradient losses (0 = not allocated)            */
     size_t adjrec;    /* flash path: adj operand records      [ndir C][Bc rounded to 32][4 kp + 16 B] (hi | lo | lsec)             */

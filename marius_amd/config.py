@@ -112,8 +112,9 @@ def load_config(path, train=True):
     if cfg["model"]["learning_task"] != "LINK_PREDICTION":
         raise NotImplementedError("only LINK_PREDICTION is in scope (SURVEY.md §8)")
     layers = cfg["model"]["encoder"]["layers"]
-    if len(layers) != 1 or len(layers[0]) != 1 or layers[0][0]["type"] != "EMBEDDING":
+    if len(layers) != 1 or len(layers[0]) != 1 or str(layers[0][0].get("type", "")).upper() != "EMBEDDING":
         raise NotImplementedError("only the embedding-only encoder is on the link-prediction hot path")
+    layers[0][0] = check_embedding_layer(layers[0][0])
     # filtered (config.cpp:365-376): num_chunks = 1, negatives = -1 (every node), scores of true edges masked (negative.cpp:212-311);
     # marius_train sorts train + validation + test edges (GraphModelStorage::sortAllEdges) for every filtered sampler, training included
     for section in ("training", "evaluation"):
@@ -144,6 +145,83 @@ def load_config(path, train=True):
     if not creates:
         infer_model_dir(cfg, auto)
     return cfg
+
+
+# LayerConfig (marius_config.py:190-199) of the one embedding layer.  What the layer's post-hook would add (Layer::post_hook, layer.cpp:9-16:
+# `+ bias`, then the activation) is NOT implemented on the device path, so asking for it is an error here — never a silently different model.
+INIT_TYPES = {"GLOROT_UNIFORM": {}, "GLOROT_NORMAL": {}, "UNIFORM": {"scale_factor": 1.0}, "NORMAL": {"mean": 0.0, "std": 1.0}, "ZEROS": {}, "ONES": {},
+              "CONSTANT": {"constant": 0.0}}  # InitConfig / *InitOptions (marius_config.py:96-160), initialization.cpp:67-95
+
+
+def check_init(init, where):
+    init = dict(init or {"type": "GLOROT_UNIFORM"})
+    kind = str(init.get("type", "GLOROT_UNIFORM")).upper()
+    if kind not in INIT_TYPES:
+        raise ValueError("%s: unknown init type %r (one of %s)" % (where, init.get("type"), ", ".join(sorted(INIT_TYPES))))
+    opts = dict(init.get("options") or {})
+    unknown = set(opts) - set(INIT_TYPES[kind])
+    if unknown:
+        raise ValueError("%s: init type %s takes no option(s) %s" % (where, kind, ", ".join(sorted(unknown))))
+    return {"type": kind, "options": {**INIT_TYPES[kind], **{k: float(v) for k, v in opts.items()}}}
+
+
+def check_embedding_layer(layer):
+    known = {"type", "options", "input_dim", "output_dim", "init", "optimizer", "bias", "bias_init", "activation"}
+    unknown = set(layer) - known
+    if unknown:
+        raise ValueError("model.encoder.layers[0][0]: unknown key(s) %s" % ", ".join(sorted(unknown)))
+    out = dict(layer)
+    out["type"] = "EMBEDDING"
+    if int(out.get("output_dim", 50)) < 1:
+        raise ValueError("model.encoder.layers[0][0].output_dim must be positive")
+    out["output_dim"] = int(out.get("output_dim", 50))
+    if int(out.get("input_dim", -1)) not in (-1, out["output_dim"]):
+        raise ValueError("model.encoder.layers[0][0]: an embedding layer has no input (input_dim must be -1 or equal to output_dim)")
+    if out.get("options"):
+        raise NotImplementedError("model.encoder.layers[0][0].options: an EMBEDDING layer takes none (LayerOptions, marius_config.py:163-187)")
+    if bool(out.get("bias", False)):
+        raise NotImplementedError("model.encoder.layers[0][0].bias: true — the embedding layer's bias (Layer::post_hook, layer.cpp:9-16) is not implemented on "
+                                  "the MI355X path; remove the key (the reference's default is false)")
+    if str(out.get("activation", "NONE")).upper() != "NONE":
+        raise NotImplementedError("model.encoder.layers[0][0].activation: %s — the embedding layer's activation (Layer::post_hook, layer.cpp:9-16) is not "
+                                  "implemented on the MI355X path; use NONE (the reference's default)" % out["activation"])
+    opt = out.get("optimizer")
+    if opt and str(opt.get("type", "DEFAULT")).upper() != "DEFAULT":
+        raise NotImplementedError("model.encoder.layers[0][0].optimizer: node embeddings are trained by model.sparse_optimizer (ADAGRAD)")
+    out["init"] = check_init(out.get("init"), "model.encoder.layers[0][0].init")
+    return out
+
+
+def initialize_rows(init, rows, d, fans, device, generator=None):
+    """initialize_subtensor (initialization.cpp:98-119) for `rows` rows of the [fans[0], d] node table: the scale of the GLOROT forms comes from
+    the FULL table shape (fan_in = num_nodes, fan_out = d)."""
+    import math
+
+    import torch
+
+    kind, o = init["type"], init["options"]
+    shape = (rows, d)
+    kw = dict(dtype=torch.float32, device=device)
+    if kind == "GLOROT_UNIFORM":
+        limit = math.sqrt(6.0 / (fans[0] + fans[1]))
+        return torch.empty(shape, **kw).uniform_(-limit, limit, generator=generator)
+    if kind == "GLOROT_NORMAL":
+        return torch.empty(shape, **kw).normal_(0.0, math.sqrt(2.0 / (fans[0] + fans[1])), generator=generator)
+    if kind == "UNIFORM":
+        return torch.empty(shape, **kw).uniform_(-o["scale_factor"], o["scale_factor"], generator=generator)
+    if kind == "NORMAL":
+        return torch.empty(shape, **kw).normal_(o["mean"], o["std"], generator=generator)
+    if kind == "ZEROS":
+        return torch.zeros(shape, **kw)
+    if kind == "ONES":
+        return torch.ones(shape, **kw)
+    if kind == "CONSTANT":
+        return torch.full(shape, o["constant"], **kw)
+    raise ValueError(kind)
+
+
+def embedding_init(cfg):
+    return cfg["model"]["encoder"]["layers"][0][0]["init"]
 
 
 def embedding_dim(cfg):

@@ -639,8 +639,9 @@ DistMult::DistMult(int num_relations, int embedding_dim, torch::TensorOptions o,
 #define MARIUS_SET_PARAM(FIELD, NAME, VALUE)                                                     \
     do {                                                                                          \
         Tensor v_ = (VALUE);                                                                      \
+        v_.set_requires_grad(true);                                                               \
         if (parameters_.contains(NAME)) FIELD = parameters_[NAME] = v_;                           \
-        else FIELD = register_parameter(NAME, v_, /*requires_grad=*/false);                       \
+        else FIELD = register_parameter(NAME, v_, /*requires_grad=*/true);                        \
     } while (0)
 void DistMult::reset() {  // distmult.cpp:21-27
     MARIUS_SET_PARAM(relations_, "relation_embeddings", torch::ones({num_relations_, embedding_size_}, tensor_options_));
@@ -829,6 +830,7 @@ SGDOptimizer::SGDOptimizer(std::vector<std::pair<Tensor, Tensor>> params, float 
     learning_rate_ = lr;
 }
 void SGDOptimizer::step() {  // optim.cpp:59-79: param -= lr * grad (plain libtorch elementwise op, as in the reference)
+    torch::NoGradGuard ng;  // the parameters are leaves that require grad (distmult.cpp:21-27): in-place steps belong outside autograd
     for (auto& pg : params_) pg.first.add_(pg.second, -learning_rate_);
 }
 
@@ -861,8 +863,8 @@ Model::Model(shared_ptr<EdgeDecoder> decoder, shared_ptr<LossFunction> loss, sha
     if (auto mod = std::dynamic_pointer_cast<torch::nn::Module>(decoder_)) {
         register_module("decoder", mod);
     } else {
-        if (decoder_->relations_.defined()) register_parameter("relation_embeddings", decoder_->relations_, /*requires_grad=*/false);
-        if (decoder_->inverse_relations_.defined()) register_parameter("inverse_relation_embeddings", decoder_->inverse_relations_, /*requires_grad=*/false);
+        if (decoder_->relations_.defined()) register_parameter("relation_embeddings", decoder_->relations_, /*requires_grad=*/true);
+        if (decoder_->inverse_relations_.defined()) register_parameter("inverse_relation_embeddings", decoder_->inverse_relations_, /*requires_grad=*/true);
     }
     learning_task_ = decoder_->learning_task_;
     devices_ = {device};
@@ -961,6 +963,7 @@ void Model::clear_grad() {
     for (auto& o : optimizers_) o->clear_grad();
 }
 void Model::step() {
+    torch::NoGradGuard ng;
     for (auto& o : optimizers_) o->step();
     touch_relations();  // a dense step moved the relation tables without tracking their magnitude
 }
@@ -1211,8 +1214,17 @@ void Model::train_batch_generic(shared_ptr<Batch> batch, bool call_step) {
     if (rel.defined()) relations_grad_.copy_(rel.grad().defined() ? rel.grad() : torch::zeros_like(rel_plain));
     if (inv.defined() && inverse_relations_grad_.defined()) inverse_relations_grad_.copy_(inv.grad().defined() ? inv.grad() : torch::zeros_like(inv_plain));
     batch->node_embeddings_grad_ = emb.grad().defined() ? emb.grad() : torch::zeros_like(emb_plain);
+    publish_grads();
     if (call_step) step();
     if (batch->node_embeddings_.defined()) batch->accumulateGradients(sparse_lr_);
+}
+
+// model.cpp:324 leaves relations_.grad() / inverse_relations_.grad() for whoever steps the parameters (the model's optimizers, or a user's
+// optimizer over named_parameters() after train_batch(batch, false)): the hand-derived backward writes relations_grad_ /
+// inverse_relations_grad_, which are made the parameters' .grad() here (aliases: clear_grad() zeroes both views of the same memory)
+void Model::publish_grads() {
+    if (decoder_->relations_.defined() && relations_grad_.defined()) decoder_->relations_.mutable_grad() = relations_grad_;
+    if (decoder_->inverse_relations_.defined() && inverse_relations_grad_.defined()) decoder_->inverse_relations_.mutable_grad() = inverse_relations_grad_;
 }
 
 void Model::all_reduce() {  // model.cpp:149-159: sum of the dense gradients over the replicas
@@ -1265,6 +1277,7 @@ void Model::train_batch(shared_ptr<Batch> batch, bool call_step) {
     mcheck(marius_segment_sum_rows(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
                                    batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, nullptr, fp(batch->node_embeddings_grad_),
                                    batch->node_embeddings_grad_.stride(0), carry_.data_ptr(), cur_stream()));
+    publish_grads();
     if (call_step) step();
     if (batch->node_embeddings_.defined()) batch->accumulateGradients(sparse_lr_);
 }

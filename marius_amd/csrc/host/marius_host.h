@@ -266,9 +266,9 @@ class EdgeDecoder : public Decoder {  // edge_decoder.h:13-31
     Tensor select_relations(Tensor indices, bool inverse = false);
 };
 // distmult.h:10-16, complex.h, transe.h: torch::nn::Cloneable modules whose reset() (re)creates the relation tables and registers them as
-// `relation_embeddings` / `inverse_relation_embeddings` (distmult.cpp:21-27).  One deviation, by design: the parameters are registered with
-// requires_grad = false — the fused path updates them in place through the C-ABI, the generic (plug-in) path differentiates detached
-// aliases (Model::train_batch_generic) — where the reference sets requires_grad(true) for its autograd-only training.
+// `relation_embeddings` / `inverse_relation_embeddings` with requires_grad(true) (distmult.cpp:21-27).  The fused path updates them in place
+// through the C-ABI (raw pointers: outside autograd); Model::train_batch leaves the hand-derived gradients in their .grad(), so an optimizer a
+// user builds over named_parameters() steps them as in the reference; the generic (plug-in) path differentiates detached aliases.
 class DistMult : public EdgeDecoder, public torch::nn::Cloneable<DistMult> {
    public:
     DistMult(int num_relations, int embedding_dim, torch::TensorOptions tensor_options = torch::TensorOptions(), bool use_inverse_relations = true,
@@ -527,6 +527,8 @@ class Model : public torch::nn::Module {
     float* relation_bound() { return rel_ranges_valid_ ? range_state_.data_ptr<float>() + 1 : nullptr; }
     // chooses the bounds of one training forward (ctx_.absmax / absmax_rel); direct: the batch reads batch->table_ in place
     void bind_ranges(shared_ptr<Batch> batch, bool direct);
+
+    void publish_grads();  // relations_.grad() / inverse_relations_.grad() = the gradients of the last backward (model.cpp:324)
 
    private:
     void train_batch_generic(shared_ptr<Batch> batch, bool call_step);  // the reference's autograd formulation, for user plug-ins

@@ -116,6 +116,7 @@ ShardedTrainer::~ShardedTrainer() {
 // RCCL sets a collective up lazily on its first use per communicator (tens of milliseconds for the first all-reduce); the relation-table
 // averaging only happens every sync_interval steps, so without this its one-time cost would land in the middle of a run.
 void ShardedTrainer::prime() {
+    torch::NoGradGuard ng;  // the relation tables are leaves that require grad: averaging them in place is not an autograd operation
     const auto dev = table_.device();
     Scope scope(strm(main_stream_));
     for (auto& t : model_->dense_state()) {  // every replica starts from the same tables and zero sums: sum / world leaves them unchanged
@@ -363,6 +364,7 @@ void ShardedTrainer::update(int64_t t) {
 
 void ShardedTrainer::dense(int64_t t) {
     Phase ph(phase_seconds_[5]);
+    torch::NoGradGuard ng;
     Scope scope(strm(main_stream_));
     if (sync_interval_ <= 1) {  // model.cpp:136-159: all-reduce the relation gradients, every replica takes the same dense step
         for (Tensor* g : {&model_->relations_grad_, &model_->inverse_relations_grad_}) {

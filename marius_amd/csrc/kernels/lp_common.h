@@ -59,12 +59,6 @@ struct ScoreArgs {
     int ablate;  // debug only (MARIUS_ABLATE): 1 = skip S stores, 2 = skip MFMAs, 4 = skip negative-tile staging
     unsigned long long* dbg;  // debug only: per-phase s_memtime stamps of the first workgroups (MARIUS_DBG_TIMELINE)
     float* lse_part;  // optional [ngroups][ndir][Bp][2]: per (negative-tile group, row) running (max, sum exp) from the score epilogue
-    // bf16-split operand planes (lp_split.hip): [3][rows][kp] bf16, plane stride in elements
-    const void* embp;
-    int64_t embp_plane;
-    const void* adjp;
-    int64_t adjp_plane;
-    int kp;
     LpDims D;
 };
 
@@ -168,31 +162,13 @@ inline void scores_res_geometry(int N, int& ntpg, int& ngroups) {
     ngroups = (ntiles + ntpg - 1) / ntpg;
 }
 bool scores_res_applicable(const float* emb, int64_t emb_ld, int d);
-// adj-in-registers score kernel: 32-column negative tiles, 4 tiles (128 columns) per workgroup
-inline void scores_a_geometry(int N, int& ntpg, int& ngroups) {
-    const int ntiles = (N + 31) / 32;
-    ntpg = ntiles >= 8 ? 4 : ntiles;
-    ngroups = (ntiles + ntpg - 1) / ntpg;
-}
 bool scores_a_applicable(const float* emb, int64_t emb_ld, int d);
-// persistent variant of the same kernel: units of two 32-column tiles, one SoftmaxCE partial per (row, unit)
+// adj-in-registers score kernel, persistent workgroups: units of two 32-column tiles, one SoftmaxCE partial per (row, unit)
 inline int scores_ap_groups(int N) { return ((N + 31) / 32 + 1) / 2; }
 bool launch_scores_ap(const ScoreArgs& a, bool l2, hipStream_t st);
-// same structure on the BF16 matrix pipe with exact 3-way operand splitting (lp_split.hip)
-bool scores_b6_applicable(const float* emb, int64_t emb_ld, int d);
-// rows[n][ld] fp32 -> planes[3][n][kp] bf16 (exact hi/mid/lo split, zero K padding)
-// backward contractions of the same scheme (lp_split_grad.hip); builds the contraction-major operand copies negT / adjT first
-bool launch_grad_b6(const GradArgs& ga, const void* embp, int64_t embp_plane, const void* adjp, int64_t adjp_plane, int kp, void* negT, void* adjT,
-                    hipStream_t st);
-int launch_split_rows(const float* src, int64_t ld, int64_t rows, int d, int kp, void* planes, int64_t plane_elems, hipStream_t st);
-bool launch_scores_b6(const ScoreArgs& a, bool l2, hipStream_t st);
-bool launch_scores_a(const ScoreArgs& a, bool l2, hipStream_t st);
 // resident-operand / 16x16x4 variants (lp_res.hip): additionally d <= 128 for the score kernel
 bool launch_scores_res(const ScoreArgs& a, bool l2, hipStream_t st);
 bool launch_grad16(const GradArgs& a, bool l2, int which, hipStream_t st);  // which: 0 both (one launch), 1 dAdj, 2 dNeg
-size_t grad16_sk_part_bytes();
-bool launch_grad16_sk(const GradArgs& a, bool l2, float* part, hipStream_t st);
-bool launch_grad16_hy(const GradArgs& a, bool l2, float* part, hipStream_t st);  // both contractions, whole tiles + K-split tiles for the last round  // both contractions, stream-K balanced persistent launch
 
 // flash-style training path (lp_flash.hip): operand records, SoftmaxCE row statistics, recomputing backward
 bool flash_applicable(const marius_lp_desc* desc, const LpDims& D);

@@ -1101,14 +1101,13 @@ static int kernel_level();
 static unsigned long long* g_dbg_timeline = nullptr;
 // SoftmaxCE partial (max, sum exp) per (row, negative-tile group) come out of the score kernel's epilogue when nothing can change
 // the scores afterwards (no score filter) and the resident-operand kernel runs; marius_lp_loss then only merges the partials.
-// which level-2 score kernel runs: 'p' (adj fragments in registers, persistent workgroups; default), 'a' (same, one workgroup per
-// 128x128 unit; MARIUS_SCORES=a), 'b' (bf16x6 split on the BF16 matrix pipe; MARIUS_SCORES=b) or 'r' (adj tile in LDS; MARIUS_SCORES=res)
+// which level-2 score kernel runs: 'p' (adj fragments in registers, persistent workgroups: d / 4 in {8, 16, 25, 32}) or 'r' (adj tile in LDS,
+// persistent workgroups: every other d <= 128 with d % 4 == 0; MARIUS_SCORES=res forces it where 'p' would apply — tests of that kernel at
+// the bench shape).  The one-workgroup-per-unit forms and the bf16x6 split planes of rounds 1-2 lost their A/B runs and are gone.
 static char scores_variant(const marius_lp_desc* d, const LpDims& D) {
     const char* v = getenv("MARIUS_SCORES");
     const bool want_res = v && v[0] == 'r';
-    if (v && v[0] == 'b' && scores_b6_applicable(d->emb, d->emb_ld, D.d) && d->U <= 2 * D.B + (int64_t)(d->src_neg ? 2 : 1) * D.C * D.N)
-        return 'b';  // bf16x6 split (lp_split.hip); the plane buffers hold at most 2B + 2CN rows
-    if (!want_res && scores_a_applicable(d->emb, d->emb_ld, D.d)) return (v && v[0] == 'a') ? 'a' : 'p';  // default 'p': persistent variant
+    if (!want_res && scores_a_applicable(d->emb, d->emb_ld, D.d)) return 'p';
     if (scores_res_applicable(d->emb, d->emb_ld, D.d)) return 'r';
     return 0;
 }
@@ -1121,8 +1120,7 @@ static int lse_fused_groups(const marius_lp_desc* d, const LpDims& D) {
     if ((d->dst_filter && d->n_dst_filter > 0) || (d->src_filter && d->n_src_filter > 0)) return 0;
     int ntpg, ng;
     const char v = scores_variant(d, D);
-    if (v == 'a') scores_a_geometry(D.N, ntpg, ng);
-    else if (v == 'p' || v == 'b') ng = scores_ap_groups(D.N);
+    if (v == 'p') ng = scores_ap_groups(D.N);
     else if (v == 'r') scores_res_geometry(D.N, ntpg, ng);
     else return 0;
     return ng;
@@ -1229,19 +1227,11 @@ static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layou
         const size_t ng = (size_t)(D.N + 63) / 64 + 1;  // upper bound over the score-kernel variants (finest: one partial per 64 columns)
         L->lsepart = take(rows * ng * 2 * 4 * D.ndir);
     }
-    L->kp = (D.d + 15) / 16 * 16;
-    L->embp = L->adjp = L->negt = L->adjt = L->gradpart = 0;
     L->adjrec = L->negrec = L->fpart = 0;
     if (flash) {
         L->adjrec = take(flash_adjrec_bytes(D));
         L->negrec = take(flash_negrec_bytes(D));
         L->fpart = take(flash_part_bytes(D));
-    } else {
-        L->embp = take(nocc * (size_t)L->kp * 2 * 3);
-        L->adjp = take(rows * D.ndir * (size_t)L->kp * 2 * 3);
-        L->negt = take((size_t)D.C * D.ndir * 3 * L->kp * ((D.N + 31) / 32 * 32) * 2);
-        L->adjt = take((size_t)D.C * D.ndir * 3 * L->kp * ((D.Bc + 31) / 32 * 32) * 2);
-        L->gradpart = take(grad16_sk_part_bytes());
     }
     base = take(rows * 4 * D.ndir);
     L->dpos[0] = L->dpos[1] = 0;
@@ -1346,9 +1336,6 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     }
 
     ScoreArgs sa;
-    sa.embp = sa.adjp = nullptr;
-    sa.embp_plane = sa.adjp_plane = 0;
-    sa.kp = (int)L->kp;
     sa.adj = pa.adj;
     sa.emb = desc->emb;
     sa.emb_ld = desc->emb_ld;
@@ -1368,24 +1355,10 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     sa.dbg = getenv("MARIUS_TIMELINE_GRADS") ? nullptr : g_dbg_timeline;
     dim3 grid((unsigned)cdiv(D.N, F_TN), (unsigned)cdiv(D.Bc, F_TM), (unsigned)(D.C * D.ndir));
     size_t lds = (size_t)(F_TM + F_TN) * sa.KS * sizeof(float);
-    if (kernel_level() == 2 && scores_variant(desc, D) == 'b') {
-        const int64_t nocc = 2 * D.B + (int64_t)(desc->src_neg ? 2 : 1) * D.C * D.N;
-        const int64_t erows = desc->U < nocc ? desc->U : nocc;
-        sa.embp = ws + L->embp;
-        sa.embp_plane = nocc * L->kp;
-        sa.adjp = ws + L->adjp;
-        sa.adjp_plane = D.Bp * D.ndir * L->kp;
-        rc = launch_split_rows(desc->emb, desc->emb_ld, erows, D.d, (int)L->kp, ws + L->embp, sa.embp_plane, st);
-        if (rc) return rc;
-        rc = launch_split_rows(pa.adj, D.d_ld, D.Bp * D.ndir, D.d, (int)L->kp, ws + L->adjp, sa.adjp_plane, st);
-        if (rc) return rc;
-    }
     {
         ProfScope ps(PROF_LP_SCORES, st);
         const int lvl = kernel_level();
-        if (!((lvl == 2 && scores_variant(desc, D) == 'b' && launch_scores_b6(sa, l2, st)) ||
-              (lvl == 2 && scores_variant(desc, D) == 'p' && launch_scores_ap(sa, l2, st)) ||
-              (lvl == 2 && scores_variant(desc, D) == 'a' && launch_scores_a(sa, l2, st)) ||
+        if (!((lvl == 2 && scores_variant(desc, D) == 'p' && launch_scores_ap(sa, l2, st)) ||
               (lvl >= 2 && launch_scores_res(sa, l2, st)) || (lvl >= 1 && launch_scores_fast(sa, l2, st)))) {
             if (l2)
                 lp_scores_kernel<true><<<grid, dim3(256), lds, st>>>(sa);
@@ -1509,15 +1482,9 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
             if (rc) return rc;
             done = true;
         }
-        if (!done && lvl == 2 && !split && scores_variant(desc, D) == 'b') {  // operand planes were produced by this step's forward
-            const int64_t nocc = 2 * D.B + (int64_t)(desc->src_neg ? 2 : 1) * D.C * D.N;
-            ProfScope ps(PROF_LP_GRAD_ADJ, st);
-            done = launch_grad_b6(ga, ws + L->embp, nocc * L->kp, ws + L->adjp, D.Bp * D.ndir * L->kp, (int)L->kp, ws + L->negt, ws + L->adjt, st);
-        }
         if (!done && lvl >= 2 && !split) {
             ProfScope ps(PROF_LP_GRAD_ADJ, st);  // merged launch is accounted under lp_grad_adj (both contractions)
-            done = launch_grad16_sk(ga, l2, (float*)(ws + L->gradpart), st) || launch_grad16_hy(ga, l2, (float*)(ws + L->gradpart), st) ||
-                   launch_grad16(ga, l2, 0, st);
+            done = launch_grad16(ga, l2, 0, st);
         }
         if (!done) {
             {

@@ -59,7 +59,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // per-row reference mref that starts at the row's positive score and is raised (accumulators rescaled) only when a block's maximum
 // exceeds it by more than FL_TAU; the unnormalised sums leave the kernel as (mref, sum V) statistics plus the unnormalised dAdj partial of
 // every (tile, contributor), and the consumer (lp_edge_bwd*) scales by g exp(mref - lse).  One score contraction less per step (4 instead
-// of 5), no zero fill of dadj, no atomics.  FLASH_FWD + FLASH_DADJ remain as MARIUS_FLASH_FUSED=0 and for the score-storing parity runs.
+// of 5), no zero fill of dadj, no atomics.  FLASH_FWD remains for the score-storing parity runs; FLASH_DADJ only as the base of the stored-score mode FLASH_DADJS.
 // d > 128 (round 3; cfg5's d = 400): the stationary operand of a tile no longer fits the register file, so the contraction index is cut into
 // nch equal column chunks of <= 128 (400 = 4 x 100) with one operand-record set per chunk, and the scores ARE materialised (fp32 [Bp, n_ld]):
 //   FLASH_FWDS   one launch per chunk: S += adj_c . neg_c^T (the first chunk stores, the last also leaves the SoftmaxCE row statistics);
@@ -1003,7 +1003,7 @@ bool flash_applicable(const marius_lp_desc* desc, const LpDims& D) {
         // score filters (training: the DEG filter of degree-based negatives) are honoured by the fused sweep and dNeg through a per-item index;
         // not by the round-2 three-launch form, not together with stored scores, and only for lists a DEG filter can produce
         const FlFilterDims f = fl_filter_dims(D);
-        if (!flash_fused() || (desc->flags & MARIUS_LP_STORE_SCORES) || (size_t)(f.nkeys_max + 1) * 4 > FL_FILTER_LDS_MAX ||
+        if ((desc->flags & MARIUS_LP_STORE_SCORES) || (size_t)(f.nkeys_max + 1) * 4 > FL_FILTER_LDS_MAX ||
             desc->n_dst_filter + desc->n_src_filter > f.ent_cap || flash_chunked(D.d))  // (the column-chunked launches of d > 128 do not look filters up)
             return false;
     }
@@ -1018,11 +1018,8 @@ size_t flash_negrec_bytes(const LpDims& D) { return fl_negset_bytes(D) * flash_c
 static size_t fl_stats_bytes(const LpDims& D) { return ((size_t)2 * D.ndir * D.Bp * sizeof(float2) + 255) / 256 * 256; }
 // [statistics | filter index (offsets of both orientations, entries of both orientations)]
 size_t flash_part_bytes(const LpDims& D) { return fl_stats_bytes(D) + fl_filter_dims(D).bytes; }
-// MARIUS_FLASH_FUSED=0: forward statistics and dAdj as two launches (the round-2 form; A/B runs)
-bool flash_fused() {
-    const char* e = getenv("MARIUS_FLASH_FUSED");
-    return !(e && e[0] == '0');
-}
+// forward statistics and dAdj are one sweep (FLASH_FDADJ); the two-launch form of round 2 lost its A/B run (0.726 vs 0.653 ms per step) and is gone
+bool flash_fused() { return true; }
 
 static int g_flash_reserved_cus = 0;
 void flash_set_reserved_cus(int n) { g_flash_reserved_cus = n; }
@@ -1171,13 +1168,13 @@ int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj,
         }
         return rc;
     }
-    if (!flash_fused() || S) {  // statistics-only sweep: the unfused form, and the score-storing parity runs (its statistics are then rewritten below)
+    if (S) {  // statistics-only sweep of the score-storing parity runs (its statistics are then rewritten below)
         fl_common(a, D, FLASH_FWD, adjrec, negrec, rg);
         a.part = part;
         a.S = S;
         ProfScope ps(PROF_LP_SCORES, st);
         rc = S ? fl_dispatch<FLASH_FWD, true>(ks, a, st) : fl_dispatch<FLASH_FWD, false>(ks, a, st);
-        if (rc || !flash_fused()) return rc;
+        if (rc) return rc;
     }
     fl_common(a, D, FLASH_FDADJ, adjrec, negrec, rg);
     a.part = part;
@@ -1259,14 +1256,7 @@ int flash_backward(const marius_lp_desc* desc, const LpDims& D, char* adjrec, ch
         }
         return rc;
     }
-    if (!flash_fused()) {  // fused form: dAdj left the forward sweep as partials (flash_forward)
-        fl_common(a, D, FLASH_DADJ, adjrec, negrec, rg);
-        a.out = dadj;
-        a.out_ld = D.d_ld;
-        ProfScope ps(PROF_LP_GRAD_ADJ, st);
-        rc = fl_dispatch<FLASH_DADJ, false>(ks, a, st);
-    }
-    if (rc) return rc;
+    (void)dadj;  // dAdj left the forward sweep as partials (flash_forward)
     fl_common(a, D, FLASH_DNEG, adjrec, negrec, rg);
     a.out = gocc;
     a.out_ld = D.d_ld;

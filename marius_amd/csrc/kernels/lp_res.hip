@@ -35,211 +35,6 @@ __device__ __forceinline__ float4 mul4(const float4& v, float m) { return make_f
 constexpr int R_T = 64;  // output tile 64 x 64 per iteration; 4 waves as 2 x 2, one 32x32 MFMA tile each
 
 // NQ = d / 4 as a compile-time constant (fully unrolled, software-pipelined MFMA chain) or 0 for a runtime K loop
-template <bool L2, int NQ>
-__global__ __launch_bounds__(256, 2) void lp_scores_res_kernel(ScoreArgs a, int ngroups, int nt_per_group, int units_per_cd) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const LpDims& D = a.D;
-    int cd, unit;
-    if (!decode_block2(blockIdx.x, units_per_cd, D.C * D.ndir, cd, unit)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // debug timeline: entry stamp + 5 stamps per tile for the first 256 workgroups of XCD 0 (wave 0 and wave 3 only)
-    unsigned long long* dbg = (a.dbg && blockIdx.x < 2048 && (blockIdx.x & 7) == 0 && lane == 0 && (wave == 0 || wave == 3))
-                                  ? a.dbg + ((size_t)(blockIdx.x >> 3) * 2 + (wave ? 1 : 0)) * 64 : nullptr;
-    int dbi = 0;
-#define STAMP() do { if (dbg && dbi < 64) dbg[dbi++] = __builtin_readcyclecounter(); } while (0)
-    STAMP();
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int dir = cd / D.C, c = cd - dir * D.C;
-    const int mt = unit / ngroups, ng = unit - mt * ngroups;
-    const int m0 = mt * R_T;
-    const int ntiles = (D.N + R_T - 1) / R_T;
-    const int nt0 = ng * nt_per_group;
-    const int T = min(nt_per_group, ntiles - nt0);
-    if (T <= 0) return;
-    const int KS = a.KS;  // d + 2
-    float* As = smem;
-    float* Bs0 = smem + R_T * KS;
-    float* Bs1 = Bs0 + R_T * KS;
-    const float* adj = a.adj + ((int64_t)dir * D.Bp + (int64_t)c * D.Bc) * D.d_ld;
-    const int64_t* negmap = a.negmap[dir] + (int64_t)c * D.N;
-
-    const int piece = tid & 31, row = tid >> 5;  // 32 threads x 16 B cover up to 128 columns; 8 rows per pass, 8 passes
-    const bool col_ok = 4 * piece < D.d;
-    const int colc = col_ok ? 4 * piece : 0;
-
-    float4 vb[8];
-    int64_t ids[8];
-    auto load_ids = [&](int t) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int n = (nt0 + t) * R_T + row + 8 * it;
-            ids[it] = negmap[n < D.N ? n : 0];
-        }
-    };
-    auto issue_b = [&]() {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) vb[it] = *reinterpret_cast<const float4*>(a.emb + ids[it] * a.emb_ld + colc);
-    };
-    auto write_b = [&](float* buf, int t) {
-        if (col_ok) {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int n = (nt0 + t) * R_T + row + 8 * it;
-                lds_store4x(buf + (row + 8 * it) * KS + 4 * piece, mul4(vb[it], n < D.N ? 1.f : 0.f));
-            }
-        }
-    };
-
-    // ---- prologue: adj tile + negative tile 0 into LDS, tile 1 in flight
-    load_ids(0);
-    {
-        float4 va[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int m = m0 + row + 8 * it;
-            va[it] = *reinterpret_cast<const float4*>(adj + (int64_t)(m < D.Bc ? m : 0) * D.d_ld + colc);
-        }
-        issue_b();
-        if (col_ok) {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int m = m0 + row + 8 * it;
-                lds_store4x(As + (row + 8 * it) * KS + 4 * piece, mul4(va[it], m < D.Bc ? 1.f : 0.f));
-            }
-        }
-    }
-    write_b(Bs0, 0);
-    if (T > 1) {
-        load_ids(1);
-        issue_b();
-    }
-    if (T > 2) load_ids(2);
-    __syncthreads();
-
-    float* S = a.S + ((int64_t)dir * D.Bp + (int64_t)c * D.Bc) * D.n_ld;
-    const float* ap = As + (wm * 32 + l31) * KS + 2 * h;
-    const int nq = D.d >> 2;
-    float run_m = -3.0e38f, run_l = 0.f;  // running (max, sum exp) of this lane's row over the unit's columns
-    STAMP();
-    for (int t = 0; t < T; ++t) {
-        const float* bp = ((t & 1) ? Bs1 : Bs0) + (wn * 32 + l31) * KS + 2 * h;
-        v16f acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        if constexpr (NQ > 0) {
-            // operands of step q+1 are read from LDS before the two MFMAs of step q issue (sched_barrier pins that order: left to
-            // itself the compiler re-uses one register pair and waits lgkmcnt(0) before every MFMA pair, exposing the LDS latency)
-            float2 av[2], bv[2];
-            av[0] = *reinterpret_cast<const float2*>(ap);
-            bv[0] = *reinterpret_cast<const float2*>(bp);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (q + 1 < NQ) {
-                    av[(q + 1) & 1] = *reinterpret_cast<const float2*>(ap + 4 * (q + 1));
-                    bv[(q + 1) & 1] = *reinterpret_cast<const float2*>(bp + 4 * (q + 1));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                acc = mfma32(bv[q & 1].x, av[q & 1].x, acc);  // swapped: D[n][m], a lane owns ONE row m and 16 columns n
-                acc = mfma32(bv[q & 1].y, av[q & 1].y, acc);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            for (int q = 0; q < nq; ++q) {
-                const float2 a2 = *reinterpret_cast<const float2*>(ap + 4 * q);
-                const float2 b2 = *reinterpret_cast<const float2*>(bp + 4 * q);
-                acc = mfma32(b2.x, a2.x, acc);
-                acc = mfma32(b2.y, a2.y, acc);
-            }
-        }
-        STAMP();  // after the MFMA chain issued
-        // tile t+1 (in registers since the previous iteration) -> the other LDS buffer; then put tile t+2 in flight
-        if (t + 1 < T && !(a.ablate & 4)) write_b((t & 1) ? Bs0 : Bs1, t + 1);
-        STAMP();  // after LDS writes (includes the wait for the loads issued one tile ago)
-        if (t + 2 < T && !(a.ablate & 4)) {
-            issue_b();  // uses ids of tile t+2
-            if (t + 3 < T) load_ids(t + 3);
-        }
-        STAMP();  // after issuing the next loads
-        // epilogue of tile t: lane (m = l31, h) holds S[m][nb + 8q + 4h + e] in acc[4q + e]: four 16-B stores per lane, and the
-        // row-wise (max, sum exp) of the SoftmaxCE is lane-local (no cross-lane traffic until the end of the unit)
-        {
-            const int m = m0 + wm * 32 + l31;
-            const int nb = (nt0 + t) * R_T + wn * 32 + 4 * h;
-            float xx = 0.f;
-            if (L2 && m < D.Bc) xx = a.x2[(int64_t)dir * D.Bp + (int64_t)c * D.Bc + m];
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                v[r] = acc[r];
-                if (L2) {
-#pragma clang fp contract(off)
-                    const int n = nb + 8 * (r >> 2) + (r & 3);
-                    const float yy = (n < D.N) ? a.y2[(int64_t)dir * D.C * D.N + (int64_t)c * D.N + n] : 0.f;
-                    const float tt = (xx + yy) - 2.f * v[r];
-                    v[r] = sqrtf(fmaxf(tt, 1e-8f));
-                }
-            }
-            if (m < D.Bc && !(a.ablate & 1)) {
-                float* srow = S + (int64_t)m * D.n_ld;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = nb + 8 * q;
-                    if (n + 3 < D.N) {
-                        *reinterpret_cast<float4*>(srow + n) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < D.N) srow[n + e] = v[4 * q + e];
-                    }
-                }
-            }
-            if (a.lse_part) {
-                float tmax = -3.0e38f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = nb + 8 * (r >> 2) + (r & 3);
-                    if (n < D.N) tmax = fmaxf(tmax, v[r]);
-                }
-                const float mnew = fmaxf(run_m, tmax);
-                float sum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = nb + 8 * (r >> 2) + (r & 3);
-                    if (n < D.N) sum += __expf(v[r] - mnew);
-                }
-                run_l = run_l * __expf(run_m - mnew) + sum;
-                run_m = mnew;
-            }
-        }
-        STAMP();  // after stores + partial LSE
-        __syncthreads();
-        STAMP();  // after the barrier
-    }
-#undef STAMP
-    if (a.lse_part) {
-        // combine the two half-waves (columns +0..3 / +4..7 of every 8), then the two waves that cover the 64-column tile
-        const float m2 = __shfl_xor(run_m, 32, 64), l2 = __shfl_xor(run_l, 32, 64);
-        const float mm = fmaxf(run_m, m2);
-        const float ll = run_l * __expf(run_m - mm) + l2 * __expf(m2 - mm);
-        float* red = smem;  // LDS is free after the last barrier of the tile loop
-        if (h == 0) {
-            red[((wm * 2 + wn) * 32 + l31) * 2] = mm;
-            red[((wm * 2 + wn) * 32 + l31) * 2 + 1] = ll;
-        }
-        __syncthreads();
-        const int m = m0 + wm * 32 + l31;
-        if (wn == 0 && h == 0 && m < D.Bc) {
-            const float ma = red[((wm * 2) * 32 + l31) * 2], la = red[((wm * 2) * 32 + l31) * 2 + 1];
-            const float mb = red[((wm * 2 + 1) * 32 + l31) * 2], lb = red[((wm * 2 + 1) * 32 + l31) * 2 + 1];
-            const float mx = fmaxf(ma, mb);
-            float* out = a.lse_part + ((int64_t)ng * D.ndir * D.Bp + (int64_t)dir * D.Bp + (int64_t)c * D.Bc + m) * 2;  // [group][row][2]: rows of a wave are contiguous
-            out[0] = mx;
-            out[1] = la * __expf(ma - mx) + lb * __expf(mb - mx);
-        }
-    }
-}
-
 // =========================================================================================== scores, persistent workgroups
 // Timeline stamps of lp_scores_res_kernel (tools/timeline_scores.py) showed that a workgroup spends ~8.3k cycles per 64x64 tile
 // (3.7k of them in the MFMA chain) but ~24k cycles per 4-tile unit in launch + prologue (negative ids -> rows -> LDS is two
@@ -514,186 +309,6 @@ __global__ __launch_bounds__(256, 2) void lp_scores_ps_kernel(ScoreArgs a, int n
 //   * fits 3 workgroups per CU (40 kB LDS, <= 168 VGPRs), which breaks the two-workgroup lockstep.
 // Each wave owns its rows for every column, so the SoftmaxCE partial needs no cross-wave exchange.
 constexpr int A_TM = 128, A_TN = 32, A_SLOTS = 3;
-
-template <bool L2, int NQ>
-__global__ __launch_bounds__(256, 3) void lp_scores_a_kernel(ScoreArgs a, int ngroups, int ntpg, int units_per_cd) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const LpDims& D = a.D;
-    int cd, unit;
-    if (!decode_block2(blockIdx.x, units_per_cd, D.C * D.ndir, cd, unit)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long* dbg = (a.dbg && blockIdx.x < 2048 && (blockIdx.x & 7) == 0 && lane == 0 && (wave == 0 || wave == 3))
-                                  ? a.dbg + ((size_t)(blockIdx.x >> 3) * 2 + (wave ? 1 : 0)) * 64 : nullptr;
-    int dbi = 0;
-#define STAMP() do { if (dbg && dbi < 64) dbg[dbi++] = __builtin_readcyclecounter(); } while (0)
-    STAMP();
-    const int l31 = lane & 31, h = lane >> 5;
-    const int dir = cd / D.C, c = cd - dir * D.C;
-    const int mt = unit / ngroups, ng = unit - mt * ngroups;
-    const int ntiles = (D.N + A_TN - 1) / A_TN;
-    const int nt0 = ng * ntpg;
-    const int T = min(ntpg, ntiles - nt0);
-    if (T <= 0) return;
-    const int KS = a.KS;
-    const int m_row = mt * A_TM + wave * 32 + l31;
-    const bool m_ok = m_row < D.Bc;
-    const int64_t rowbase = (int64_t)dir * D.Bp + (int64_t)c * D.Bc;
-    const int64_t* negmap = a.negmap[dir] + (int64_t)c * D.N;
-
-    // adj fragments of this lane: A[m_row][4q + 2h .. +1]
-    float2 af[NQ];
-    {
-        const float* arow = a.adj + (rowbase + (m_ok ? m_row : 0)) * D.d_ld + 2 * h;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) af[q] = *reinterpret_cast<const float2*>(arow + 4 * q);
-        if (!m_ok) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) af[q] = make_float2(0.f, 0.f);
-        }
-    }
-
-    const int piece = tid & 31, row = tid >> 5;  // 32 thr x 16 B per row, 8 rows per pass, 4 passes = 32 rows
-    const bool col_ok = 4 * piece < D.d;
-    const int colc = col_ok ? 4 * piece : 0;
-    int64_t ids0[4], ids1[4];
-    float4 vb0[4], vb1[4];
-    auto load_ids = [&](int t, int64_t(&ids)[4]) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int n = (nt0 + t) * A_TN + row + 8 * it;
-            ids[it] = negmap[(t < T && n < D.N) ? n : 0];
-        }
-    };
-    auto issue = [&](const int64_t(&ids)[4], float4(&vb)[4]) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) vb[it] = *reinterpret_cast<const float4*>(a.emb + ids[it] * a.emb_ld + colc);
-    };
-    auto write = [&](int t, const float4(&vb)[4]) {
-        if (t < T && col_ok) {
-            float* buf = smem + (t % A_SLOTS) * (A_TN * KS);
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int n = (nt0 + t) * A_TN + row + 8 * it;
-                lds_store4x(buf + (row + 8 * it) * KS + 4 * piece, mul4(vb[it], n < D.N ? 1.f : 0.f));
-            }
-        }
-    };
-
-    // ---- prologue: tiles 0,1 -> LDS, tiles 2,3 in flight (sets 0,1), ids of tiles 4,5 loaded
-    load_ids(0, ids0);
-    load_ids(1, ids1);
-    issue(ids0, vb0);
-    issue(ids1, vb1);
-    load_ids(2, ids0);
-    load_ids(3, ids1);
-    write(0, vb0);
-    write(1, vb1);
-    issue(ids0, vb0);  // tile 2
-    issue(ids1, vb1);  // tile 3
-    load_ids(4, ids0);
-    load_ids(5, ids1);
-    // land the adj fragments before the step loop: a wait at their first use inside the loop is merged conservatively at the loop
-    // header and drains younger loads on every step (see lp_split.hip)
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(af[q].x), "+v"(af[q].y));
-    __syncthreads();
-    STAMP();
-
-    float* srow = a.S + (rowbase + (m_ok ? m_row : 0)) * D.n_ld;
-    float xx = 0.f;
-    if (L2 && m_ok) xx = a.x2[rowbase + m_row];
-    float run_m = -3.0e38f, run_l = 0.f;
-
-    auto step = [&](int t, const int64_t(&ids)[4], float4(&vb)[4]) {
-        // on entry: LDS holds tiles t, t+1; `vb` holds tile t+2 (issued two steps ago); `ids` holds the ids of tile t+4
-        const float* bp = smem + (t % A_SLOTS) * (A_TN * KS) + l31 * KS + 2 * h;
-        v16f acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        float2 bv[2];
-        bv[0] = *reinterpret_cast<const float2*>(bp);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (q + 1 < NQ) bv[(q + 1) & 1] = *reinterpret_cast<const float2*>(bp + 4 * (q + 1));
-            __builtin_amdgcn_sched_barrier(0);
-            acc = mfma32(bv[q & 1].x, af[q].x, acc);  // D[n][m]: the lane owns row m and 16 columns n
-            acc = mfma32(bv[q & 1].y, af[q].y, acc);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        STAMP();
-        write(t + 2, vb);                 // slot (t+2) % 3 was last read in step t-1
-        STAMP();
-        if (t + 4 < T) issue(ids, vb);    // tile t+4 into the register set just freed
-        STAMP();
-        // epilogue of tile t
-        const int nb = (nt0 + t) * A_TN + 4 * h;
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            v[r] = acc[r];
-            if (L2) {
-#pragma clang fp contract(off)
-                const int n = nb + 8 * (r >> 2) + (r & 3);
-                const float yy = (n < D.N) ? a.y2[(int64_t)dir * D.C * D.N + (int64_t)c * D.N + n] : 0.f;
-                const float tt = (xx + yy) - 2.f * v[r];
-                v[r] = sqrtf(fmaxf(tt, 1e-8f));
-            }
-        }
-        if (m_ok && !(a.ablate & 1)) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = nb + 8 * q;
-                if (n + 3 < D.N) {
-                    *reinterpret_cast<float4*>(srow + n) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < D.N) srow[n + e] = v[4 * q + e];
-                }
-            }
-        }
-        if (a.lse_part && !(a.ablate & 8)) {
-            float tmax = -3.0e38f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = nb + 8 * (r >> 2) + (r & 3);
-                if (n < D.N) tmax = fmaxf(tmax, v[r]);
-            }
-            const float mnew = fmaxf(run_m, tmax);
-            float sum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = nb + 8 * (r >> 2) + (r & 3);
-                if (n < D.N) sum += __expf(v[r] - mnew);
-            }
-            run_l = run_l * __expf(run_m - mnew) + sum;
-            run_m = mnew;
-        }
-        STAMP();
-        __syncthreads();
-        STAMP();
-    };
-
-    for (int t = 0; t < T; t += 2) {
-        step(t, ids0, vb0);
-        load_ids(t + 6, ids0);
-        if (t + 1 < T) {
-            step(t + 1, ids1, vb1);
-            load_ids(t + 7, ids1);
-        }
-    }
-    if (a.lse_part) {
-        const float m2 = __shfl_xor(run_m, 32, 64), l2 = __shfl_xor(run_l, 32, 64);
-        const float mm = fmaxf(run_m, m2);
-        const float ll = run_l * __expf(run_m - mm) + l2 * __expf(m2 - mm);
-        if (h == 0 && m_ok) {
-            float* out = a.lse_part + ((int64_t)ng * D.ndir * D.Bp + rowbase + m_row) * 2;
-            out[0] = mm;
-            out[1] = ll;
-        }
-    }
-#undef STAMP
-}
 
 // =========================================================================================== scores, adj in registers, persistent
 // lp_scores_a_kernel spends 28 % of a workgroup's life in its prologue (ids -> rows -> LDS, adj fragments) for only four 32-column
@@ -1354,176 +969,6 @@ __global__ __launch_bounds__(256, 3) void lp_grad16_kernel(GradArgs a, int tiles
         grad_neg16_body<L2, NT>(a, cd, unit - units_adj, tiles_neg, smem);
 }
 
-// ---- stream-K launch of the same two bodies (Dot comparator); an experiment against the idea that 3200 equal tiles over 768 resident
-// workgroups lose a partly filled fifth round (they do not: measured slower, see launch_grad16_sk / launch_grad16_hy).  768 persistent workgroups split the flat list of (tile, K chunk) units evenly (+-1 chunk): a workgroup finishes
-// the tail of the tile its predecessor started, a few whole tiles, and the head of one more.  Partial accumulators (at most two per
-// workgroup; a tile is shared by at most two workgroups because every range is longer than a tile's K loop) go to `part`, and
-// lp_grad16_fixup_kernel adds the two halves in a fixed order and stores the tile: deterministic, no atomics.
-struct SkUnit {
-    int cd, kind, tile, chunk, nch;  // kind 0 = dAdj tile, 1 = dNeg tile
-};
-__device__ __forceinline__ SkUnit sk_decode(int u, int tiles_adj, int tiles_neg, int nch_adj, int nch_neg) {
-    const int per_cd = tiles_adj * nch_adj + tiles_neg * nch_neg;
-    SkUnit k;
-    k.cd = u / per_cd;
-    int r = u - k.cd * per_cd;
-    if (r < tiles_adj * nch_adj) {
-        k.kind = 0;
-        k.nch = nch_adj;
-    } else {
-        r -= tiles_adj * nch_adj;
-        k.kind = 1;
-        k.nch = nch_neg;
-    }
-    k.tile = r / k.nch;
-    k.chunk = r - k.tile * k.nch;
-    return k;
-}
-__device__ __forceinline__ int sk_wlin(int b, int nwg) { return (nwg & 7) ? b : (b & 7) * (nwg >> 3) + (b >> 3); }  // XCD-major when possible
-
-template <int NT>
-__global__ __launch_bounds__(256, 3) void lp_grad16_sk_kernel(GradArgs a, int tiles_adj, int tiles_neg, int nch_adj, int nch_neg, int total_units, int nwg,
-                                                              float* part) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int wlin = sk_wlin((int)blockIdx.x, nwg);
-    int u = (int)((int64_t)wlin * total_units / nwg);
-    const int u1 = (int)((int64_t)(wlin + 1) * total_units / nwg);
-    while (u < u1) {
-        const SkUnit k = sk_decode(u, tiles_adj, tiles_neg, nch_adj, nch_neg);
-        const int c0 = k.chunk;
-        const int c1 = min(k.nch, c0 + (u1 - u));
-        const bool full = c0 == 0 && c1 == k.nch;
-        // slot 0: tail of a tile the predecessor started (c0 > 0); slot 1: head of a tile the successor finishes
-        float* p = full ? nullptr : part + ((size_t)wlin * 2 + (c0 > 0 ? 0 : 1)) * (NT * 4 * 256);
-        __syncthreads();  // the previous segment's last LDS reads are done before this segment's prologue overwrites the buffers
-        if (k.kind == 0)
-            grad_adj16_body<false, NT>(a, k.cd, k.tile, tiles_adj, smem, c0, c1, p);
-        else
-            grad_neg16_body<false, NT>(a, k.cd, k.tile, tiles_neg, smem, c0, c1, p);
-        u += c1 - c0;
-    }
-}
-
-template <int NT>
-__global__ __launch_bounds__(256) void lp_grad16_fixup_kernel(GradArgs a, int tiles_adj, int tiles_neg, int nch_adj, int nch_neg, int total_units, int nwg,
-                                                              const float* part) {
-    const int b = blockIdx.x;  // boundary between workgroup ranges b and b + 1
-    const int ub = (int)((int64_t)(b + 1) * total_units / nwg);
-    if (ub >= total_units) return;
-    const SkUnit k = sk_decode(ub, tiles_adj, tiles_neg, nch_adj, nch_neg);
-    if (k.chunk == 0) return;  // the boundary coincides with a tile boundary: nothing was split
-    const LpDims& D = a.D;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, kq = lane >> 4;
-    const float* p0 = part + ((size_t)b * 2 + 1) * (NT * 4 * 256);        // head part (workgroup b)
-    const float* p1 = part + ((size_t)(b + 1) * 2 + 0) * (NT * 4 * 256);  // tail part (workgroup b + 1)
-    const int dir = k.cd / D.C, c = k.cd - dir * D.C;
-    const int64_t rowbase = (int64_t)dir * D.Bp + (int64_t)c * D.Bc;
-    const int m0 = k.tile * H_TM;
-    float* out = k.kind == 0 ? a.dadj + rowbase * D.d_ld : a.gocc + (a.negocc_off[dir] + (int64_t)c * D.N) * D.d_ld;
-    const int mlimit = k.kind == 0 ? D.Bc : D.N;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n = 16 * t + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wave * 16 + 4 * kq + r;
-            const int e = (t * 4 + r) * 256 + tid;
-            if (m < mlimit && n < D.d) out[(int64_t)m * D.d_ld + n] = p0[e] + p1[e];
-        }
-    }
-}
-
-// ---- tail-split launch of the same two bodies (Dot comparator).  Whole tiles keep the plain one-workgroup-per-tile dynamic dispatch
-// for as many FULL rounds of the resident slots as there are; only the tiles of the last, partly filled round are cut along their K
-// loop into `sp` pieces so that this round also fills every slot, with pieces 1/sp as long.  Each XCD owns a contiguous range of
-// tiles (Tx), Wx of them whole, the other Tx - Wx split; blocks are numbered so that block b runs on XCD b % 8 for both kinds.
-// Pieces write their accumulators to `part`; lp_grad16_hyfix_kernel adds the sp pieces of a tile in index order (deterministic).
-constexpr int HY_SLOTS = 96;  // resident workgroups per XCD: 32 CUs x 3 (launch bounds of the grad16 kernels)
-
-struct HyTile {
-    int t, piece;  // tile index (< 0: nothing to do), piece (-1 = whole tile)
-    int slot;      // index of the split tile among all split tiles (part buffer addressing)
-};
-__device__ __forceinline__ HyTile hy_decode(int b, int T, int Tx, int Wx, int sp) {
-    HyTile h;
-    h.piece = -1;
-    h.slot = 0;
-    const int nwhole = 8 * Wx;
-    int xcd;
-    if (b < nwhole) {
-        xcd = b & 7;
-        h.t = xcd * Tx + (b >> 3);
-    } else {
-        const int q = b - nwhole;
-        xcd = q & 7;
-        const int r = q >> 3;
-        const int tt = r / sp;
-        h.piece = r - tt * sp;
-        h.t = xcd * Tx + Wx + tt;
-        h.slot = xcd * (Tx - Wx) + tt;
-    }
-    const int end = min(T, (xcd + 1) * Tx);
-    if (h.t >= end) h.t = -1;
-    return h;
-}
-
-template <int NT>
-__global__ __launch_bounds__(256, 3) void lp_grad16_hy_kernel(GradArgs a, int tiles_adj, int tiles_neg, int nch_adj, int nch_neg, int T, int Tx, int Wx, int sp,
-                                                              float* part) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const HyTile h = hy_decode((int)blockIdx.x, T, Tx, Wx, sp);
-    if (h.t < 0) return;
-    const int per = tiles_adj + tiles_neg;
-    const int cd = h.t / per, unit = h.t - cd * per;
-    const bool adj = unit < tiles_adj;
-    int c0 = 0, c1 = -1;
-    float* p = nullptr;
-    if (h.piece >= 0 && sp > 1) {
-        const int nch = adj ? nch_adj : nch_neg;
-        c0 = nch * h.piece / sp;
-        c1 = nch * (h.piece + 1) / sp;
-        p = part + ((size_t)h.slot * sp + h.piece) * (NT * 4 * 256);
-    }
-    if (adj)
-        grad_adj16_body<false, NT>(a, cd, unit, tiles_adj, smem, c0, c1, p);
-    else
-        grad_neg16_body<false, NT>(a, cd, unit - tiles_adj, tiles_neg, smem, c0, c1, p);
-}
-
-template <int NT>
-__global__ __launch_bounds__(256) void lp_grad16_hyfix_kernel(GradArgs a, int tiles_adj, int tiles_neg, int T, int Tx, int Wx, int sp, const float* part) {
-    const int rx = Tx - Wx;
-    const int xcd = (int)blockIdx.x / rx, tt = (int)blockIdx.x - xcd * rx;
-    const int t = xcd * Tx + Wx + tt;
-    if (t >= min(T, (xcd + 1) * Tx)) return;
-    const LpDims& D = a.D;
-    const int per = tiles_adj + tiles_neg;
-    const int cd = t / per, unit = t - cd * per;
-    const bool adj = unit < tiles_adj;
-    const int tile = adj ? unit : unit - tiles_adj;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, kq = lane >> 4;
-    const float* p = part + (size_t)blockIdx.x * sp * (NT * 4 * 256);
-    const int dir = cd / D.C, c = cd - dir * D.C;
-    const int64_t rowbase = (int64_t)dir * D.Bp + (int64_t)c * D.Bc;
-    const int m0 = tile * H_TM;
-    float* out = adj ? a.dadj + rowbase * D.d_ld : a.gocc + (a.negocc_off[dir] + (int64_t)c * D.N) * D.d_ld;
-    const int mlimit = adj ? D.Bc : D.N;
-#pragma unroll
-    for (int tc = 0; tc < NT; ++tc) {
-        const int n = 16 * tc + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wave * 16 + 4 * kq + r;
-            const int e = (tc * 4 + r) * 256 + tid;
-            float acc = p[e];
-            for (int j = 1; j < sp; ++j) acc += p[(size_t)j * (NT * 4 * 256) + e];
-            if (m < mlimit && n < D.d) out[(int64_t)m * D.d_ld + n] = acc;
-        }
-    }
-}
-
 // =========================================================================================== launchers
 static bool res_ok(const float* emb, int64_t emb_ld, int d) {
     return (d % 4 == 0) && (emb_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(emb) & 15) == 0);
@@ -1564,35 +1009,6 @@ bool launch_scores_ap(const ScoreArgs& a_in, bool l2, hipStream_t st) {
     return true;
 }
 
-bool launch_scores_a(const ScoreArgs& a_in, bool l2, hipStream_t st) {
-    if (!scores_a_applicable(a_in.emb, a_in.emb_ld, a_in.D.d)) return false;
-    ScoreArgs a = a_in;
-    a.KS = a.D.d + 2;
-    int ntpg, ngroups;
-    scores_a_geometry(a.D.N, ntpg, ngroups);
-    const int mtiles = (int)cdiv(a.D.Bc, A_TM);
-    const int units = mtiles * ngroups;
-    const size_t lds = (size_t)A_SLOTS * A_TN * a.KS * sizeof(float);
-    dim3 grid(xcd_grid2(units, a.D.C * a.D.ndir));
-#define SCORES_A_LAUNCH(L2V, NQV) lp_scores_a_kernel<L2V, NQV><<<grid, dim3(256), lds, st>>>(a, ngroups, ntpg, units)
-#define SCORES_A_DISPATCH(L2V)                         \
-    do {                                               \
-        switch (a.D.d / 4) {                           \
-            case 8: SCORES_A_LAUNCH(L2V, 8); break;    \
-            case 16: SCORES_A_LAUNCH(L2V, 16); break;  \
-            case 25: SCORES_A_LAUNCH(L2V, 25); break;  \
-            default: SCORES_A_LAUNCH(L2V, 32); break;  \
-        }                                              \
-    } while (0)
-    if (l2)
-        SCORES_A_DISPATCH(true);
-    else
-        SCORES_A_DISPATCH(false);
-#undef SCORES_A_DISPATCH
-#undef SCORES_A_LAUNCH
-    return true;
-}
-
 bool launch_scores_res(const ScoreArgs& a_in, bool l2, hipStream_t st) {
     if (!scores_res_applicable(a_in.emb, a_in.emb_ld, a_in.D.d)) return false;
     ScoreArgs a = a_in;
@@ -1602,60 +1018,20 @@ bool launch_scores_res(const ScoreArgs& a_in, bool l2, hipStream_t st) {
     scores_res_geometry(a.D.N, nt_per_group, ngroups);
     const int units = mtiles * ngroups;
     const size_t lds = (size_t)3 * R_T * a.KS * sizeof(float);
-    dim3 grid(xcd_grid2(units, a.D.C * a.D.ndir));
-    const char* pse = getenv("MARIUS_SCORES_PS");
-    const bool use_ps = !(pse && pse[0] == '0');
-    if (use_ps) {  // persistent workgroups (default)
-        const int ncd = a.D.C * a.D.ndir;
-        const int units_x = (int)cdiv(ncd, 8) * units;
-        int wg_per_xcd = 64;  // 2 resident workgroups on each of the XCD's 32 CUs
-        if (units_x < wg_per_xcd) wg_per_xcd = units_x;
-        const size_t lds_ps = lds + 256 * sizeof(float);
-        dim3 pgrid((unsigned)(8 * wg_per_xcd));
-#define SCORES_PS_LAUNCH(L2V, NQV)                                                                                                       \
-    do {                                                                                                                                   \
-        if (lds_ps > 65536) hipFuncSetAttribute((const void*)lp_scores_ps_kernel<L2V, NQV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ps); \
-        lp_scores_ps_kernel<L2V, NQV><<<pgrid, dim3(256), lds_ps, st>>>(a, ngroups, nt_per_group, units, wg_per_xcd);                         \
-    } while (0)
-#define SCORES_PS_DISPATCH(L2V)                          \
-    do {                                                 \
-        switch (a.D.d / 4) {                             \
-            case 8: SCORES_PS_LAUNCH(L2V, 8); break;     \
-            case 16: SCORES_PS_LAUNCH(L2V, 16); break;   \
-            case 25: SCORES_PS_LAUNCH(L2V, 25); break;   \
-            case 32: SCORES_PS_LAUNCH(L2V, 32); break;   \
-            default: SCORES_PS_LAUNCH(L2V, 0); break;    \
-        }                                                \
-    } while (0)
-        if (l2)
-            SCORES_PS_DISPATCH(true);
-        else
-            SCORES_PS_DISPATCH(false);
-#undef SCORES_PS_DISPATCH
-#undef SCORES_PS_LAUNCH
-        return true;
+    // persistent workgroups.  d / 4 in {8, 16, 25, 32} never comes here by default (the adj-in-registers kernel takes those): runtime K loop only
+    const int ncd = a.D.C * a.D.ndir;
+    const int units_x = (int)cdiv(ncd, 8) * units;
+    int wg_per_xcd = 64;  // 2 resident workgroups on each of the XCD's 32 CUs
+    if (units_x < wg_per_xcd) wg_per_xcd = units_x;
+    const size_t lds_ps = lds + 256 * sizeof(float);
+    dim3 pgrid((unsigned)(8 * wg_per_xcd));
+    if (l2) {
+        if (lds_ps > 65536) (void)hipFuncSetAttribute((const void*)lp_scores_ps_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ps);
+        lp_scores_ps_kernel<true, 0><<<pgrid, dim3(256), lds_ps, st>>>(a, ngroups, nt_per_group, units, wg_per_xcd);
+    } else {
+        if (lds_ps > 65536) (void)hipFuncSetAttribute((const void*)lp_scores_ps_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ps);
+        lp_scores_ps_kernel<false, 0><<<pgrid, dim3(256), lds_ps, st>>>(a, ngroups, nt_per_group, units, wg_per_xcd);
     }
-#define SCORES_RES_LAUNCH(L2V, NQV)                                                                                                     \
-    do {                                                                                                                                  \
-        if (lds > 65536) (void)hipFuncSetAttribute((const void*)lp_scores_res_kernel<L2V, NQV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        lp_scores_res_kernel<L2V, NQV><<<grid, dim3(256), lds, st>>>(a, ngroups, nt_per_group, units);                                      \
-    } while (0)
-#define SCORES_RES_DISPATCH(L2V)                          \
-    do {                                                  \
-        switch (a.D.d / 4) {                              \
-            case 8: SCORES_RES_LAUNCH(L2V, 8); break;     \
-            case 16: SCORES_RES_LAUNCH(L2V, 16); break;   \
-            case 25: SCORES_RES_LAUNCH(L2V, 25); break;   \
-            case 32: SCORES_RES_LAUNCH(L2V, 32); break;   \
-            default: SCORES_RES_LAUNCH(L2V, 0); break;    \
-        }                                                 \
-    } while (0)
-    if (l2)
-        SCORES_RES_DISPATCH(true);
-    else
-        SCORES_RES_DISPATCH(false);
-#undef SCORES_RES_DISPATCH
-#undef SCORES_RES_LAUNCH
     return true;
 }
 
@@ -1679,90 +1055,6 @@ static bool grad16_shape(const GradArgs& a, bool l2, int& nblk, int& nt) {
     } while (0)
 
 // which: 0 = both contractions in one launch, 1 = dAdj only, 2 = dNeg only
-// stream-K variant; `part` must hold grad16_sk_part_bytes() bytes.  Returns false when it does not apply (L2, several n-blocks, tiny shapes).
-size_t grad16_sk_part_bytes() { return (size_t)768 * 2 * 8 * 4 * 256 * sizeof(float); }
-bool launch_grad16_sk(const GradArgs& a, bool l2, float* part, hipStream_t st) {
-    int nblk, nt;
-    if (l2 || !part || !grad16_shape(a, l2, nblk, nt) || nblk != 1) return false;
-    const char* e = getenv("MARIUS_GRAD_SK");  // opt-in: measured SLOWER than the plain launch on the bench workload (0.515 vs 0.476 ms) —
-    if (!(e && e[0] == '1')) return false;     // the dynamic dispatch of 3200 staggered workgroups already hides most of the last round,
-                                               // while 768 persistent workgroups start in phase and pay two extra prologues each
-    const int tiles_adj = (int)cdiv(a.D.Bc, H_TM), tiles_neg = (int)cdiv(a.D.N, H_TM);
-    const int nch_adj = (int)cdiv(a.D.N, H_KC), nch_neg = (int)cdiv(a.D.Bc, H_KC);
-    const int ncd = a.D.C * a.D.ndir;
-    const int64_t total64 = (int64_t)ncd * (tiles_adj * nch_adj + tiles_neg * nch_neg);
-    if (total64 >= ((int64_t)1 << 30)) return false;
-    const int total = (int)total64;
-    int nwg = 768;
-    const char* w = getenv("MARIUS_GRAD_NWG");  // tests: force splits at small shapes
-    if (w) nwg = atoi(w);
-    const int maxch = nch_adj > nch_neg ? nch_adj : nch_neg;
-    if (nwg > total / maxch) nwg = total / maxch;  // every range at least one full K loop long: a tile is shared by at most two workgroups
-    if (nwg > 768) nwg = 768;
-    if (nwg < 1) return false;
-    const int nt_inst = nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : nt <= 7 ? 7 : 8;
-    const size_t lds = grad16_lds_bytes(a.D.N, nt_inst);
-#define GRAD16_SK(NTV)                                                                                                              \
-    do {                                                                                                                            \
-        lp_grad16_sk_kernel<NTV><<<dim3(nwg), dim3(256), lds, st>>>(a, tiles_adj, tiles_neg, nch_adj, nch_neg, total, nwg, part);   \
-        if (nwg > 1)                                                                                                                \
-            lp_grad16_fixup_kernel<NTV><<<dim3(nwg - 1), dim3(256), 0, st>>>(a, tiles_adj, tiles_neg, nch_adj, nch_neg, total, nwg, part); \
-    } while (0)
-    if (nt_inst == 1) GRAD16_SK(1);
-    else if (nt_inst == 2) GRAD16_SK(2);
-    else if (nt_inst == 4) GRAD16_SK(4);
-    else if (nt_inst == 7) GRAD16_SK(7);
-    else GRAD16_SK(8);
-#undef GRAD16_SK
-    return true;
-}
-
-// tail-split variant.  Opt-in (MARIUS_GRAD_HY=1; =2: only the balanced contiguous tile ranges per XCD, no K split): measured on the
-// bench workload 0.500 ms (split) / 0.473 ms (balance only) vs 0.474 ms for the plain launch.  The "5 rounds at 83 % fill" model of the
-// plain launch is wrong: in the partly filled last round a CU hosts fewer workgroups and each of them runs correspondingly faster
-// (the kernel is bound by the SIMDs' issue slots, not by the number of resident workgroups), so there is no tail to reclaim.
-bool launch_grad16_hy(const GradArgs& a, bool l2, float* part, hipStream_t st) {
-    int nblk, nt;
-    if (l2 || !part || !grad16_shape(a, l2, nblk, nt) || nblk != 1) return false;
-    const char* e = getenv("MARIUS_GRAD_HY");
-    if (!(e && (e[0] == '1' || e[0] == '2'))) return false;
-    const int tiles_adj = (int)cdiv(a.D.Bc, H_TM), tiles_neg = (int)cdiv(a.D.N, H_TM);
-    const int nch_adj = (int)cdiv(a.D.N, H_KC), nch_neg = (int)cdiv(a.D.Bc, H_KC);
-    const int64_t T64 = (int64_t)a.D.C * a.D.ndir * (tiles_adj + tiles_neg);
-    if (T64 >= ((int64_t)1 << 28)) return false;
-    const int T = (int)T64;
-    const int Tx = (T + 7) / 8;
-    int slots = HY_SLOTS;
-    const char* w = getenv("MARIUS_GRAD_HY_SLOTS");  // tests: force splits at small shapes
-    if (w) slots = atoi(w);
-    if (slots < 1) return false;
-    const int Wx = Tx / slots * slots, rx = Tx - Wx;
-    if (rx == 0) return false;                    // whole rounds only: the plain launch is already balanced
-    int sp = slots / rx;
-    sp = sp < nch_adj ? sp : nch_adj;
-    sp = sp < nch_neg ? sp : nch_neg;
-    sp = sp < 8 ? sp : 8;
-    const bool balance_only = e && e[0] == '2';  // experiment: contiguous, balanced tile ranges per XCD, no K split
-    if (balance_only) sp = 1;
-    if (sp < 2 && !balance_only) return false;    // the last round is more than half full
-    const int nt_inst = nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : nt <= 7 ? 7 : 8;
-    if ((size_t)8 * rx * sp * nt_inst * 4 * 256 * sizeof(float) > grad16_sk_part_bytes()) return false;
-    const size_t lds = grad16_lds_bytes(a.D.N, nt_inst);
-    const unsigned grid = (unsigned)(8 * Wx + 8 * rx * sp);
-#define GRAD16_HY(NTV)                                                                                                          \
-    do {                                                                                                                        \
-        lp_grad16_hy_kernel<NTV><<<dim3(grid), dim3(256), lds, st>>>(a, tiles_adj, tiles_neg, nch_adj, nch_neg, T, Tx, Wx, sp, part); \
-        if (sp > 1) lp_grad16_hyfix_kernel<NTV><<<dim3(8 * rx), dim3(256), 0, st>>>(a, tiles_adj, tiles_neg, T, Tx, Wx, sp, part); \
-    } while (0)
-    if (nt_inst == 1) GRAD16_HY(1);
-    else if (nt_inst == 2) GRAD16_HY(2);
-    else if (nt_inst == 4) GRAD16_HY(4);
-    else if (nt_inst == 7) GRAD16_HY(7);
-    else GRAD16_HY(8);
-#undef GRAD16_HY
-    return true;
-}
-
 bool launch_grad16(const GradArgs& a, bool l2, int which, hipStream_t st) {
     int nblk, nt;
     if (!grad16_shape(a, l2, nblk, nt)) return false;

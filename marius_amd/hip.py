@@ -43,7 +43,7 @@ class LpLayout(C.Structure):
         ("Bp", C.c_int64), ("n_ld", C.c_int64), ("d_ld", C.c_int64), ("total_bytes", C.c_size_t),
         ("adj", C.c_size_t * 2), ("pos", C.c_size_t * 2), ("neg", C.c_size_t * 2), ("lse", C.c_size_t * 2),
         ("rowloss", C.c_size_t * 2), ("loss", C.c_size_t), ("dadj", C.c_size_t * 2), ("gocc", C.c_size_t),
-        ("grel", C.c_size_t * 2), ("aux", C.c_size_t), ("lsepart", C.c_size_t), ("embp", C.c_size_t), ("adjp", C.c_size_t), ("kp", C.c_int64), ("negt", C.c_size_t), ("adjt", C.c_size_t), ("gradpart", C.c_size_t),
+        ("grel", C.c_size_t * 2), ("aux", C.c_size_t), ("lsepart", C.c_size_t), 
         ("dpos", C.c_size_t * 2), ("vlog", C.c_size_t), ("adjrec", C.c_size_t), ("negrec", C.c_size_t), ("fpart", C.c_size_t),
         ("flash", C.c_int32), ("reserved_", C.c_int32),
     ]
@@ -383,6 +383,9 @@ class LpWorkspace:
 
     def lse(self, dir_):
         return self._view(self.layout.lse[dir_], (self.layout.Bp,))
+
+    def rowloss(self, dir_):
+        return self._view(self.layout.rowloss[dir_], (self.layout.Bp,))
 
     def loss_values(self):
         return self._view(self.layout.loss, (4,))

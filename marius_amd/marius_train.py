@@ -118,12 +118,11 @@ def marius_train(cfg, log=print, train=True):
         opts = pb_opts
         train_edges.readPartitionSizes(os.path.join(ddir, "edges", "train_partition_offsets.txt"))  # io.cpp:110-121
         if not resume:
-            limit = math.sqrt(6.0 / (num_nodes + d))
             rows = max(1, (256 << 20) // (4 * d))
             with open(emb_path, "wb") as fe, open(state_path, "wb") as fs:  # initialised in slabs: the table need not fit anywhere at once
                 for lo in range(0, num_nodes, rows):
                     n = min(rows, num_nodes - lo)
-                    fe.write(torch.empty((n, d), dtype=torch.float32, device=dev).uniform_(-limit, limit).cpu().numpy().tobytes())
+                    fe.write(C.initialize_rows(C.embedding_init(cfg), n, d, (num_nodes, d), dev).cpu().numpy().tobytes())
                     fs.write(bytes(4 * d * n))
         else:
             meta = open(os.path.join(mdir, "metadata.csv")).read().split("\n")
@@ -153,8 +152,8 @@ def marius_train(cfg, log=print, train=True):
             state.filename = os.path.join(mdir, "embeddings_state.bin")
         model.load(os.path.join(mdir, ""), train)
     else:
-        limit = math.sqrt(6.0 / (num_nodes + d))  # GLOROT_UNIFORM over the table shape (initialization.cpp:26-41)
-        table = torch.empty((num_nodes, d), dtype=torch.float32, device=dev).uniform_(-limit, limit)
+        # model.encoder.layers[0][0].init (default GLOROT_UNIFORM over the table shape, initialization.cpp:26-41, 98-119)
+        table = C.initialize_rows(C.embedding_init(cfg), num_nodes, d, (num_nodes, d), dev)
         emb = H.InMemory(table)
         emb.filename = os.path.join(mdir, "embeddings.bin")
         state = H.InMemory(torch.zeros_like(table))

@@ -647,7 +647,9 @@ def run_sharded_bench(a, cfg, rank, world, dev):
             "metric": "edges/sec scored (pos+neg)", "value": round(pos_eps * (2 + 2 * N), 1), "unit": "scored edges/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f32 (contractions: 2-way bf16 split x 3 products, f32 accumulate)" if flash else "f32", "data": "synthetic",
+            "dtype": ("f32 (contractions: 2-way %s split x 3 products, f32 accumulate)" % (
+                "fp16 [22 significand bits per operand]" if (cpp_trainer is not None and model.last_step_records == "fp16") else "bf16 [16 significand bits per operand]")) if flash else "f32",
+            "data": "synthetic", "arith_check": getattr(a, "arith_check", None),
             "config": {"workload": "%s %s d=%d, node table sharded by contiguous id range over %d GPUs, B=%d per GPU (%s), C=%d N=%d, %s edges" % (
                 a.workload, cfg["decoder"], d, world, B, "global batch fixed" if strong else "fixed per GPU", C, N, a.edge_dist),
                 "num_nodes": num_nodes, "num_relations": R,

@@ -69,6 +69,13 @@ void reference_style_usage() {
     model->evaluate_batch(batch);
     model->clear_grad();
     model->step();
+    // a user optimiser over the model's parameters (the reference registers them with requires_grad(true), distmult.cpp:21-27):
+    // train_batch(batch, false) leaves relations_.grad(), the optimiser steps them
+    torch::optim::SGD user_opt(model->parameters(), torch::optim::SGDOptions(0.1));
+    model->train_batch(batch, false);
+    for (auto& kv : model->named_parameters()) (void)kv.value().grad();
+    user_opt.step();
+    user_opt.zero_grad();
     model->save("dir/");
     model->load("dir/", true);
     // negative.h:45-57

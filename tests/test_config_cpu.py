@@ -120,3 +120,42 @@ def test_marius_eval_does_not_create_a_model_dir(tmp_path):
     with pytest.raises(Exception):
         marius_train(cfg, log=lambda *a: None, train=False)
     assert not os.path.exists(cfg["storage"]["model_dir"])
+
+
+def test_embedding_layer_options_are_honoured_or_refused(tmp_path):
+    """LayerConfig of the embedding layer (marius_config.py:190-199).  `init` selects the node-table initialisation (initialization.cpp:67-119);
+    `bias` / `activation` (Layer::post_hook, layer.cpp:9-16) and a per-layer optimizer are not implemented on the device path and are an ERROR —
+    never accepted and ignored (a7)."""
+    import torch
+
+    def layer(**kw):
+        return {"model": {"encoder": {"layers": [[dict({"type": "EMBEDDING", "output_dim": 16}, **kw)]]}}}
+
+    path, _ = write(tmp_path, layer())
+    lay = C.load_config(path)["model"]["encoder"]["layers"][0][0]
+    assert lay["init"] == {"type": "GLOROT_UNIFORM", "options": {}} and lay["output_dim"] == 16
+    # the reference's defaults spelled out are accepted
+    path, _ = write(tmp_path, layer(bias=False, activation="none", input_dim=-1, optimizer={"type": "DEFAULT"}, init={"type": "uniform", "options": {"scale_factor": 0.25}}))
+    cfg = C.load_config(path)
+    assert C.embedding_init(cfg) == {"type": "UNIFORM", "options": {"scale_factor": 0.25}}
+    for bad, exc in ((dict(bias=True), NotImplementedError), (dict(activation="RELU"), NotImplementedError), (dict(optimizer={"type": "ADAM"}), NotImplementedError),
+                     (dict(options={"type": "GRAPH_SAGE"}), NotImplementedError), (dict(init={"type": "XAVIER"}), ValueError), (dict(input_dim=8), ValueError),
+                     (dict(init={"type": "ZEROS", "options": {"constant": 1.0}}), ValueError), (dict(dropout=0.5), ValueError), (dict(output_dim=0), ValueError)):
+        path, _ = write(tmp_path, layer(**bad))
+        with pytest.raises(exc):
+            C.load_config(path)
+    # initialize_rows: every distribution of initialization.cpp:67-95; the GLOROT scale comes from the FULL table shape (initialize_subtensor)
+    g = torch.Generator().manual_seed(0)
+    rows, d, fans = 4000, 16, (1_000_000, 16)
+    t = C.initialize_rows(C.check_init(None, "x"), rows, d, fans, "cpu", g)
+    limit = (6.0 / (fans[0] + fans[1])) ** 0.5
+    assert t.shape == (rows, d) and float(t.abs().max()) <= limit and float(t.abs().max()) > 0.9 * limit
+    t = C.initialize_rows(C.check_init({"type": "GLOROT_NORMAL"}, "x"), rows, d, fans, "cpu", g)
+    assert abs(float(t.std()) / (2.0 / (fans[0] + fans[1])) ** 0.5 - 1) < 0.05
+    t = C.initialize_rows(C.check_init({"type": "NORMAL", "options": {"mean": 2.0, "std": 0.5}}, "x"), rows, d, fans, "cpu", g)
+    assert abs(float(t.mean()) - 2.0) < 0.02 and abs(float(t.std()) - 0.5) < 0.02
+    t = C.initialize_rows(C.check_init({"type": "UNIFORM", "options": {"scale_factor": 0.25}}, "x"), rows, d, fans, "cpu", g)
+    assert 0.24 < float(t.abs().max()) <= 0.25
+    assert float(C.initialize_rows(C.check_init({"type": "CONSTANT", "options": {"constant": 3.0}}, "x"), 5, d, fans, "cpu").min()) == 3.0
+    assert float(C.initialize_rows(C.check_init({"type": "ONES"}, "x"), 5, d, fans, "cpu").max()) == 1.0
+    assert float(C.initialize_rows(C.check_init({"type": "ZEROS"}, "x"), 5, d, fans, "cpu").abs().max()) == 0.0

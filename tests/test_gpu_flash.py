@@ -99,20 +99,7 @@ def node_grad_of(W, edges, src_neg, dst_neg, U, d):
     return torch.zeros(U, d, dtype=torch.float64).index_add_(0, occ_ids, W.gocc()[:, :d].cpu().double())
 
 
-def occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction="sum", dtype=torch.float64, dst_filter=None, src_filter=None):
-    """The oracle with every occurrence (src, dst, src negatives, dst negatives: map_tensors order, util.cpp:180-205) as its own
-    leaf row: its node gradient is the per-occurrence gradient the kernels write to `gocc`, before the segmented sum.  Comparing
-    there is the well-conditioned check: a node that is an endpoint AND its own negative gets +g and -g, and the sum cancels to
-    rounding noise in any arithmetic."""
-    B, (C, N), d = edges.size(0), dst_neg.shape, emb.size(1)
-    occ_ids = torch.cat([edges[:, 0], edges[:, -1], src_neg.flatten(), dst_neg.flatten()])
-    L = occ_ids.numel()
-    e2 = torch.stack([torch.arange(B), edges[:, 1], torch.arange(B) + B], 1)
-    sn2 = (torch.arange(C * N) + 2 * B).reshape(C, N)
-    dn2 = (torch.arange(C * N) + 2 * B + C * N).reshape(C, N)
-    cv = lambda t: None if t is None else t.to(dtype)
-    w = O.train_batch(decoder, emb[occ_ids].to(dtype), torch.zeros(L, d, dtype=dtype), e2, dn2, sn2, cv(rel), cv(inv), dst_filter, src_filter, reduction=reduction)
-    return w, occ_ids
+from oracle.arith_check import error_pairs, occurrence_oracle, summary  # noqa: E402
 
 
 def check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv, U, R, reduction="sum", dst_filter=None, src_filter=None):
@@ -264,19 +251,6 @@ def test_flash_wide_rows_in_column_chunks_match_oracle(H, dev, decoder, use_inve
         assert torch.equal(W2.gocc(), W.gocc()) and torch.equal(W2.lse(0), W.lse(0))
 
 
-@pytest.mark.parametrize("B,C,N,d", [(1000, 10, 500, 100), (300, 4, 260, 128)])
-def test_flash_unfused_form_still_matches_oracle(H, dev, monkeypatch, B, C, N, d):
-    """MARIUS_FLASH_FUSED=0: statistics sweep + dAdj launch + dNeg launch (the round-2 form, kept for A/B runs)."""
-    monkeypatch.setenv("MARIUS_FLASH_FUSED", "0")
-    decoder, U, R = "COMPLEX", max(40, B), 11
-    emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=B + d)
-    want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv)
-    W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True)
-    mixed_close(W.neg(0), want["neg"], "neg (split scores)")
-    mixed_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss")
-    check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv, U, R)
-
-
 @pytest.mark.parametrize("decoder,B,C,N,d", [("COMPLEX", 4096, 4, 1000, 100), ("DISTMULT", 1000, 10, 500, 128), ("COMPLEX", 300, 3, 200, 64),
                                              ("COMPLEX", 50000, 50, 1000, 100)])  # the last one: the bench shape (10^8 score entries, every one checked)
 @pytest.mark.parametrize("f16", [False, True])
@@ -336,6 +310,38 @@ def test_flash_scores_obey_the_split_error_bound(H, dev, decoder, B, C, N, d, f1
     if f16 and B >= 1000:   # 22-bit operands: north_star's 1e-4 holds in the form the FP32-MFMA path is held to (pure relative, floor 1e-2 max)
         assert worst_rel <= 1e-4
     assert worst_rel1 <= 1e-4 and worst_rel <= 1e-3
+
+
+def flash_outputs(W, use_inverse=True):
+    """what oracle/arith_check.error_pairs compares, as CPU tensors"""
+    B, d = W.desc.B, W.desc.d
+    got = {"neg": W.neg(0).cpu(), "lse": W.lse(0).cpu(), "rowloss": W.rowloss(0).cpu(), "loss": W.loss_values()[0:1].cpu(), "gocc": W.gocc()[:, :d].cpu(),
+           "grel": W.grel(0)[:B, :d].cpu()}
+    if use_inverse:
+        got.update({"inv_neg": W.neg(1).cpu(), "inv_lse": W.lse(1).cpu(), "inv_rowloss": W.rowloss(1).cpu(), "inv_grel": W.grel(1)[:B, :d].cpu()})
+    return got
+
+
+@pytest.mark.parametrize("decoder,B,C,N,d,U,R", [("COMPLEX", 50000, 50, 1000, 100, 200000, 1000),    # the bench shape: 10^8 score entries
+                                                 ("DISTMULT", 4096, 4, 1000, 100, 9000, 17), ("COMPLEX", 1000, 10, 500, 64, 3000, 11)])
+def test_flash_arithmetic_against_the_reference_fp32_evaluation(H, dev, decoder, B, C, N, d, U, R):
+    """VERDICT r3 #2.  The flash path contracts fp16-half splits (22 significand bits per operand, lo x lo dropped) where the reference contracts
+    fp32 operands (ATen bmm, comparators.cpp:62-73).  Both are evaluated against the float64 oracle on the same batch and their errors compared
+    quantity by quantity — scores, per-row lse, per-row loss, per-occurrence node gradients, relation gradients; max and RMS, each normalised by
+    the float64 magnitude (oracle/arith_check.py).  The headline claim "no worse than the reference's own fp32 evaluation" means every ratio <= 1;
+    FLASH_VS_FP32 below is what this arithmetic is held to, and bench.py prints the same pairs (`arith_check`) and quotes the split path as
+    its headline only when they are <= 1."""
+    emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=4242)
+    W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, store=True, f16=True)
+    pairs = error_pairs(decoder, emb, edges, dst_neg, src_neg, rel, inv, flash_outputs(W))
+    print("\n" + summary(pairs))
+    for q in ("scores", "lse", "row_loss", "occ_grad", "rel_grad"):
+        assert pairs[q]["ratio_max"] <= FLASH_VS_FP32 and pairs[q]["ratio_rms"] <= FLASH_VS_FP32, (q, pairs[q])
+    # (the total loss is ONE number per batch: both evaluations are within a few ulp of it and which is closer is a coin flip — printed, not asserted)
+    assert pairs["loss"]["device_max"] <= 1e-6
+
+
+FLASH_VS_FP32 = 1.0
 
 
 @pytest.mark.parametrize("nwg", ["1", "2", "3", "5", "8", "16", "24"])

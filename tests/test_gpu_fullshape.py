@@ -124,7 +124,7 @@ def test_lp_bench_shape_matches_oracle(H, dev):
     check_against_oracle(H, dev, "COMPLEX", 50000, 50, 1000, 100, 200000, 1000, seed=2024)
 
 
-@pytest.mark.parametrize("variant", ["p", "a", "b", "r"])
+@pytest.mark.parametrize("variant", ["p", "r"])
 @pytest.mark.parametrize("decoder", ["COMPLEX", "DISTMULT"])
 def test_lp_multi_tile_shape_every_score_variant(H, dev, monkeypatch, variant, decoder):
     """Bc = 1024 (8 row tiles), N = 1000 (partial last column tile), several units per persistent workgroup."""

@@ -235,7 +235,8 @@ def test_user_plugins_train_through_the_virtual_api(M, dev):
     assert set(dm.named_parameters().keys()) == {"relation_embeddings", "inverse_relation_embeddings"}
     assert set(M.Model(dm, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev).named_parameters().keys()) == {
         "decoder.relation_embeddings", "decoder.inverse_relation_embeddings"}
-    dm.relations.fill_(3.0)
+    with torch.no_grad():
+        dm.relations.fill_(3.0)
     cl = dm.clone()
     assert cl.relations.data_ptr() != dm.relations.data_ptr() and torch.equal(cl.relations, dm.relations)   # Cloneable: a deep copy
     dm.reset()
@@ -469,8 +470,9 @@ def test_filtered_evaluation_matches_oracle(M, dev):
     dec = M.DistMult(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
     rel = torch.rand(R, d, generator=g) + 0.5
     inv = torch.rand(R, d, generator=g) + 0.5
-    dec.relations.copy_(rel.to(dev))
-    dec.inverse_relations.copy_(inv.to(dev))
+    with torch.no_grad():  # leaves that require grad (distmult.cpp:21-27)
+        dec.relations.copy_(rel.to(dev))
+        dec.inverse_relations.copy_(inv.to(dev))
     model = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
     res = M.SynchronousEvaluator(loader, model).evaluate()
     ranks = []
@@ -853,3 +855,42 @@ def test_marius_train_single_relation_dataset_uses_two_column_edges(M, dev, tmp_
     assert res[-1]["test"]["MRR"] > 0.3  # chance level: ~0.03 (the synthetic rule is learnt within the first epoch)
     again = marius_eval(cfg, log=lambda *a: None)
     assert abs(again[0]["test"]["MRR"] - res[-1]["test"]["MRR"]) < 0.05
+
+
+@pytest.mark.parametrize("decoder,d", [("DISTMULT", 20), ("COMPLEX", 64)])
+def test_user_optimizer_over_named_parameters_steps_the_relation_tables(M, dev, decoder, d):
+    """The reference registers relation_embeddings / inverse_relation_embeddings with requires_grad(true) (distmult.cpp:21-27) and its
+    train_batch(batch, call_step = false) leaves their .grad() for whoever steps the parameters (model.cpp:290-333, test_nn.py:197-207).  Same
+    here: after the hand-derived backward the parameters carry the oracle's relation gradients, and a torch optimizer the USER builds over
+    named_parameters() moves the tables (the requires_grad = false deviation made such an optimizer silently do nothing)."""
+    num_nodes, R, B, C, N, E, seed = 900, 7, 120, 4, 30, 480, 5
+    table, edges_all, emb, state, loader, model = _setup(M, dev, decoder, num_nodes, R, d, B, C, N, E, seed)
+    params = model.named_parameters()
+    assert set(params) == {"decoder.relation_embeddings", "decoder.inverse_relation_embeddings"} and all(p.requires_grad and p.is_leaf for p in params.values())
+    with torch.no_grad():  # distinct from the all-ones / half-ones initial tables
+        for i, p in enumerate(params.values()):
+            p.add_(0.25 * torch.randn(R, d, generator=torch.Generator().manual_seed(i)).to(dev))
+    rel0, inv0 = params["decoder.relation_embeddings"].detach().cpu().clone(), params["decoder.inverse_relation_embeddings"].detach().cpu().clone()
+    user_opt = torch.optim.SGD(list(params.values()), lr=0.05)
+    loader.initializeBatches(True)
+    batch = loader.getBatch(True)
+    loader.loadGPUParameters(batch)
+    model.train_batch(batch, False)   # forward, loss, backward; no optimizer step
+    torch.cuda.synchronize()
+    assert torch.equal(model.decoder.relations.detach().cpu(), rel0)
+    want = O.train_batch(decoder, batch.node_embeddings.cpu(), torch.zeros(batch.node_embeddings.size(0), d), batch.edges.cpu(),
+                         batch.dst_neg_indices_mapping.cpu(), batch.src_neg_indices_mapping.cpu(), rel0, inv0)
+    g_rel, g_inv = params["decoder.relation_embeddings"].grad, params["decoder.inverse_relation_embeddings"].grad
+    assert g_rel is not None and g_inv is not None
+    close(g_rel, want["rel_grad"], rtol=1e-4)
+    close(g_inv, want["inv_rel_grad"], rtol=1e-4)
+    user_opt.step()
+    close(model.decoder.relations.detach(), rel0 - 0.05 * want["rel_grad"], rtol=1e-4)
+    close(model.decoder.inverse_relations.detach(), inv0 - 0.05 * want["inv_rel_grad"], rtol=1e-4)
+    user_opt.zero_grad(set_to_none=False)
+    assert float(model.named_parameters()["decoder.relation_embeddings"].grad.abs().max()) == 0.0
+    # the fused trainer still trains the same (now grad-requiring) tables in place, and sees the user's write through the relation bound
+    trainer = M.SynchronousTrainer(loader, model)
+    trainer.train_steps(2)
+    torch.cuda.synchronize()
+    assert not torch.equal(model.decoder.relations.detach().cpu(), rel0)

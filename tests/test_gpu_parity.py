@@ -624,82 +624,6 @@ def test_sharded_hip_backend_equals_single_gpu_step(H, dev):
     dist.destroy_process_group()
 
 
-# ------------------------------------------------------------------------------------------------ bf16x6 split contraction kernels
-@pytest.mark.gpu
-@pytest.mark.parametrize("decoder,use_inverse,B,C,N,d", [("COMPLEX", True, 1000, 10, 500, 100), ("DISTMULT", False, 250, 7, 130, 100),
-                                                        ("DISTMULT", True, 300, 4, 260, 128), ("COMPLEX", True, 100, 10, 50, 64)])
-def test_split_bf16_kernels_match_oracle_and_fp32_path(H, dev, monkeypatch, decoder, use_inverse, B, C, N, d):
-    """MARIUS_SCORES=b runs the score and both backward contractions on the BF16 matrix pipe with exact 3-way operand splitting
-    (lp_split.hip, lp_split_grad.hip).  Same oracle, same tolerance as the FP32-MFMA path, and the two device paths must agree
-    to a few ulps of the accumulated magnitude (the split drops only 2^-24 terms)."""
-    U, R = max(40, B), 11
-    emb, state, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=B + d + 1)
-    want = O.train_batch(decoder, emb, state, edges, dst_neg, src_neg, rel, inv if use_inverse else None, reduction="sum")
-    out = {}
-    for variant in ("p", "b"):
-        monkeypatch.setenv("MARIUS_SCORES", variant)
-        W = run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, "sum")
-        torch.cuda.synchronize()
-        out[variant] = (W.neg(0).cpu().clone(), W.gocc()[:, :d].cpu().clone(), W.loss_values()[0:1].cpu().clone())
-    neg_b, gocc_b, loss_b = out["b"]
-    assert_close(neg_b, want["neg"], "neg (bf16x6)")
-    assert_close(loss_b, want["loss"].reshape(1), "loss (bf16x6)")
-    occ_ids = torch.cat([edges[:, 0], edges[:, 2], src_neg.flatten(), dst_neg.flatten()])
-    node_grad = torch.zeros(U, d, dtype=torch.float64).index_add_(0, occ_ids, gocc_b.double())
-    assert_close(node_grad.float(), want["node_grad"], "node_grad (bf16x6)")
-    neg_p, gocc_p, _ = out["p"]
-    assert (neg_b - neg_p).abs().max() <= 2e-5 * max(1.0, neg_p.abs().max().item())
-    assert (gocc_b - gocc_p).abs().max() <= 2e-5 * max(1.0, gocc_p.abs().max().item())
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("nwg", ["", "3"])
-def test_stream_k_backward_matches_plain_launch(H, dev, monkeypatch, nwg):
-    """MARIUS_GRAD_SK=1: persistent workgroups split the flat (tile, K chunk) list; tiles cut by a range boundary are completed by
-    the fix-up kernel.  Must reproduce the plain launch up to summation order."""
-    decoder, B, C, N, d = "COMPLEX", 1000, 10, 500, 100
-    U, R = B, 11
-    emb, state, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=77)
-    monkeypatch.setenv("MARIUS_GRAD_SK", "0")
-    monkeypatch.setenv("MARIUS_GRAD_HY", "0")
-    W = run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, "sum")
-    torch.cuda.synchronize()
-    want = W.gocc()[:, :d].cpu().clone()
-    monkeypatch.setenv("MARIUS_GRAD_SK", "1")
-    if nwg:
-        monkeypatch.setenv("MARIUS_GRAD_NWG", nwg)
-    W = run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, "sum")
-    torch.cuda.synchronize()
-    got = W.gocc()[:, :d].cpu()
-    assert (got - want).abs().max() <= 1e-5 * max(1.0, want.abs().max().item())
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("slots", ["", "7", "20", "64"])
-@pytest.mark.parametrize("decoder,use_inverse,B,C,N,d", [("COMPLEX", True, 1000, 10, 500, 100), ("DISTMULT", False, 250, 7, 130, 100)])
-def test_tail_split_backward_matches_plain_launch(H, dev, monkeypatch, slots, decoder, use_inverse, B, C, N, d):
-    """MARIUS_GRAD_HY=1 (opt-in, measured no faster): whole tiles for the full rounds, the tiles of the last round cut along K into
-    pieces + a fix-up that adds the pieces in order.  Must reproduce the plain launch up to summation order, and the oracle."""
-    U, R = B, 11
-    emb, state, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=78)
-    monkeypatch.setenv("MARIUS_GRAD_SK", "0")
-    monkeypatch.setenv("MARIUS_GRAD_HY", "0")
-    W = run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, "sum")
-    torch.cuda.synchronize()
-    want = W.gocc()[:, :d].cpu().clone()
-    monkeypatch.setenv("MARIUS_GRAD_HY", "1")
-    if slots:
-        monkeypatch.setenv("MARIUS_GRAD_HY_SLOTS", slots)
-    W = run_hip_lp(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, "sum")
-    torch.cuda.synchronize()
-    got = W.gocc()[:, :d].cpu()
-    assert (got - want).abs().max() <= 1e-5 * max(1.0, want.abs().max().item())
-    ref = O.train_batch(decoder, emb, state, edges, dst_neg, src_neg, rel, inv if use_inverse else None, reduction="sum")
-    occ_ids = torch.cat([edges[:, 0], edges[:, 2], src_neg.flatten(), dst_neg.flatten()])
-    node_grad = torch.zeros(U, d, dtype=torch.float64).index_add_(0, occ_ids, got.double())
-    assert_close(node_grad.float(), ref["node_grad"], "node_grad (tail split)")
-
-
 # ------------------------------------------------------------------------------------------------ dense Adam (optim.cpp:186-232)
 @pytest.mark.gpu
 @pytest.mark.parametrize("amsgrad,wd", [(False, 0.0), (True, 0.0), (False, 0.01)])

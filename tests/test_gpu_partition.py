@@ -290,8 +290,9 @@ def test_partitioned_evaluation_matches_oracle(M, dev, tmp_path):
     loader = M.DataLoader(est, emb, None, M.CorruptNodeNegativeSampler(1, N, 0.0, False, M.LocalFilterMode.DEG, gen), gen, B, False)
     dec = M.DistMult(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
     rel, inv = torch.rand(R, d, generator=g) + 0.5, torch.rand(R, d, generator=g) + 0.5
-    dec.relations.copy_(rel.to(dev))
-    dec.inverse_relations.copy_(inv.to(dev))
+    with torch.no_grad():  # leaves that require grad (distmult.cpp:21-27)
+        dec.relations.copy_(rel.to(dev))
+        dec.inverse_relations.copy_(inv.to(dev))
     model = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
     got = M.SynchronousEvaluator(loader, model).evaluate()
     assert emb.swaps > 0

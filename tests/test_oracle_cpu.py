@@ -342,3 +342,51 @@ def test_randperm_wide_path_matches_torch():
     out = torch.empty(n, dtype=torch.int64)
     assert L.marius_mt19937_randperm_host(st.data_ptr(), out.data_ptr(), n) == 0
     assert torch.equal(out, ref)
+
+
+def test_arith_check_is_neutral_on_the_reference_fp32_evaluation():
+    """oracle/arith_check.error_pairs compares a device evaluation and the reference's fp32 evaluation with the float64 oracle.  Fed the fp32
+    evaluation itself as the "device" result every ratio is exactly 1; fed the float64 result every device error is 0."""
+    from oracle.arith_check import error_pairs, occurrence_oracle
+
+    g = torch.Generator().manual_seed(0)
+    B, Cn, N, d, U, R = 60, 3, 20, 16, 50, 5
+    emb = torch.randn(U, d, generator=g) * 0.5
+    edges = torch.stack([torch.randint(U, (B,), generator=g), torch.randint(R, (B,), generator=g), torch.randint(U, (B,), generator=g)], 1)
+    dn, sn = torch.randint(U, (Cn, N), generator=g), torch.randint(U, (Cn, N), generator=g)
+    rel = O.init_relations("COMPLEX", R, d) + 0.3 * torch.randn(R, d, generator=g)
+    inv = O.init_relations("COMPLEX", R, d) + 0.3 * torch.randn(R, d, generator=g)
+    for dtype, want_ratio in ((torch.float32, 1.0), (torch.float64, 0.0)):
+        w, _ = occurrence_oracle("COMPLEX", emb, edges, dn, sn, rel, inv, dtype=dtype)
+        lse = torch.logsumexp(torch.cat([w["pos"][:, None], w["neg"]], 1), 1)
+        ilse = torch.logsumexp(torch.cat([w["inv_pos"][:, None], w["inv_neg"]], 1), 1)
+        got = {"neg": w["neg"], "inv_neg": w["inv_neg"], "lse": lse, "inv_lse": ilse, "rowloss": lse - w["pos"], "inv_rowloss": ilse - w["inv_pos"],
+               "loss": w["loss"], "gocc": w["node_grad"]}
+        pairs = error_pairs("COMPLEX", emb, edges, dn, sn, rel, inv, got)
+        for q in ("scores", "lse", "row_loss", "loss", "occ_grad"):
+            assert pairs[q]["ratio_max"] == want_ratio and pairs[q]["ratio_rms"] == want_ratio, (q, pairs[q])
+            assert 0 < pairs[q]["fp32_max"] < 1e-5
+
+
+def test_only_the_checker_legs_touch_the_oracle():
+    """oracle/ is test infrastructure: nothing under marius_amd/ or include/ names it, and bench.py imports it only inside its two checker legs
+    (cpu_baseline_leg: the timed CPU port; arith_check_leg: the float64 / float32 yardsticks) — never in the timed device region."""
+    import re
+
+    for base, _, files in os.walk(os.path.join(ROOT, "marius_amd")):
+        if os.sep + "lib" in base:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                text = open(os.path.join(base, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), os.path.join(base, f)
+                if f != "build.py":  # (building the checker is not using it)
+                    assert "oracle/_build" not in text and "libmt_oracle" not in text and "oracle/_ref" not in text, os.path.join(base, f)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    legs = {}
+    for m in re.finditer(r"^def (\w+)\(", src, re.M):
+        legs[m.start()] = m.group(1)
+    starts = sorted(legs)
+    for m in re.finditer(r"^\s*(from|import)\s+oracle\b", src, re.M):
+        owner = legs[max(s for s in starts if s <= m.start())]
+        assert owner in ("cpu_baseline_leg", "arith_check_leg"), owner
