@@ -1393,6 +1393,7 @@ static bool flash_f16_env() {
     static const bool on = [] { const char* e = getenv("MARIUS_FLASH_F16"); return !(e && e[0] == '0'); }();
     return on;
 }
+bool Model::flash_f16_enabled() { return flash_f16_env(); }
 
 void Model::ensure_relation_ranges() {
     Tensor* rels[2] = {&decoder_->relations_, &decoder_->inverse_relations_};

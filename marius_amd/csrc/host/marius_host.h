@@ -519,6 +519,7 @@ class Model : public torch::nn::Module {
     Scanned tracked_table_, tracked_rel_[2];
     Tensor external_node_bound_;  // set by the trainer for a partition-buffer slab (the buffer keeps it current)
     float* node_track_ = nullptr; // the bound the node-table update of this step must keep current (set by bind_ranges; nullptr: none)
+    static bool flash_f16_enabled();  // MARIUS_FLASH_F16=0 (read once): bf16 operand halves everywhere, no bounds kept
     void track_ranges(Tensor table);
     bool tracks(const Tensor& table) const { return ranges_valid_ && tracked_table_.is(table); }
     void drop_ranges();

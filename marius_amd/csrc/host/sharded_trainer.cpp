@@ -276,7 +276,7 @@ void ShardedTrainer::fetch(int64_t t) {
         // every rank's shard, so no rank's own table bound covers them — but the requester holds all of them right here: one pass over the
         // gathered copy (80 MB at the bench shape, on this stream, underneath the scoring of the previous batch) is exact and needs no
         // collective.  One float per slot: the scoring of batch t reads its slot's bound while batch t + 1's is being written.
-        if (s.U > 0)
+        if (s.U > 0 && Model::flash_f16_enabled())
             mcheck(marius_table_absmax(s.emb.data_ptr<float>(), s.U, s.emb.stride(0), d_, s.row_bound.data_ptr<float>(), (marius_stream_t)xchg.stream()));
     }
     span_end(s, 1, xchg_stream_);
@@ -305,7 +305,7 @@ void ShardedTrainer::compute(int64_t t) {
     ST_HIPCHECK(hipStreamWaitEvent(main.stream(), (hipEvent_t)s.fetched, 0));
     span_begin(s, 2, main_stream_);
     s.batch->node_embeddings_ = s.emb;
-    s.batch->row_bound_ = s.row_bound;
+    if (Model::flash_f16_enabled()) s.batch->row_bound_ = s.row_bound;
     s.grad = view(grad_[t % RING], s.U, {d_}, torch::kFloat32);
     // replicas step on their own relation gradients between averaging points (sync_interval > 1); with sync_interval 1 the dense
     // gradients are all-reduced first

@@ -21,9 +21,15 @@ import torch
 from oracle import lp_oracle as O
 
 
-def occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction="sum", dtype=torch.float64, dst_filter=None, src_filter=None):
+def occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction="sum", dtype=torch.float64, dst_filter=None, src_filter=None, device=None):
     """O.train_batch (model.cpp:290-333) with one leaf row per occurrence (src, dst, src negatives, dst negatives): its node gradient is the
-    per-occurrence gradient the device kernels write to `gocc`, before the segmented sum."""
+    per-occurrence gradient the device kernels write to `gocc`, before the segmented sum.  device: run the same ATen op sequence there (the
+    reference with storage.device_type cuda evaluates on the device: bmm = the vendor BLAS); results come back as CPU tensors."""
+    if device is not None:
+        mv = lambda t: None if t is None else t.to(device)  # noqa: E731
+        with torch.device(device):
+            w, occ = occurrence_oracle(decoder, mv(emb), mv(edges), mv(dst_neg), mv(src_neg), mv(rel), mv(inv), reduction, dtype, mv(dst_filter), mv(src_filter))
+        return {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in w.items()}, occ.cpu()
     B, (C, N) = edges.size(0), dst_neg.shape
     occ_ids = torch.cat([edges[:, 0], edges[:, -1], src_neg.flatten(), dst_neg.flatten()])
     L = occ_ids.numel()
@@ -49,7 +55,7 @@ def _row_terms(w):
     return out
 
 
-def _pair(got, ref32, want64):
+def _pair(got, ref32, want64, devref=None, other=None):
     """(max |err| / max |want|, rms err / rms want) of `got` and of the fp32 reference evaluation, same normalisation"""
     want = want64.detach().double().flatten()
     mx = max(float(want.abs().max()), 1e-300)
@@ -61,38 +67,83 @@ def _pair(got, ref32, want64):
 
     gm, gr = one(got)
     rm, rr = one(ref32)
-    return {"device_max": gm, "device_rms": gr, "fp32_max": rm, "fp32_rms": rr,
-            "ratio_max": gm / rm if rm > 0 else (0.0 if gm == 0 else math.inf), "ratio_rms": gr / rr if rr > 0 else (0.0 if gr == 0 else math.inf)}
+    out = {"device_max": gm, "device_rms": gr, "fp32_max": rm, "fp32_rms": rr,
+           "ratio_max": gm / rm if rm > 0 else (0.0 if gm == 0 else math.inf), "ratio_rms": gr / rr if rr > 0 else (0.0 if gr == 0 else math.inf)}
+    if devref is not None:  # the reference's op sequence in float32 evaluated on the accelerator (ATen device ops, vendor BLAS)
+        dm, dr = one(devref)
+        out.update({"fp32_on_device_max": dm, "fp32_on_device_rms": dr, "ratio_dev_max": gm / dm if dm > 0 else math.inf, "ratio_dev_rms": gr / dr if dr > 0 else math.inf})
+    if other is not None:  # a third fp32 evaluation of the same batch: this library's FP32-MFMA kernels (every product an fp32 product)
+        om, orr = one(other)
+        out.update({"fp32_mfma_max": om, "fp32_mfma_rms": orr})
+    return out
 
 
-def error_pairs(decoder, emb, edges, dst_neg, src_neg, rel, inv, got, reduction="sum"):
+def error_pairs(decoder, emb, edges, dst_neg, src_neg, rel, inv, got, reduction="sum", ref_device=None, fp32_mfma=None):
     """got: CPU tensors from the device path — neg / inv_neg [Bp, N] (optional: the flash path only stores them on request), lse / inv_lse [Bp],
     rowloss / inv_rowloss [Bp] (optional), loss (scalar), gocc [L, d] per-occurrence node gradients, grel / inv_grel [B, d] per-edge relation
     gradients (optional).  Returns {quantity: _pair(...)}; directions are pooled into one entry per quantity."""
     w64, _ = occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction, torch.float64)
     w32, _ = occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction, torch.float32)
     t64, t32 = _row_terms(w64), _row_terms(w32)
+    wd = td = None
+    if ref_device is not None:
+        wd, _ = occurrence_oracle(decoder, emb, edges, dst_neg, src_neg, rel, inv, reduction, torch.float32, device=ref_device)
+        td = _row_terms(wd)
     dirs = ("", "inv_") if inv is not None else ("",)
     out = {}
+    cat = lambda f: torch.cat([f(t).flatten() for t in dirs])  # noqa: E731
 
-    def pooled(key, g, r, w):
-        gs = [g(t) for t in dirs if g(t) is not None]
+    m = fp32_mfma  # same keys as `got`
+
+    def pooled(key, gk, r, w, dv):
+        gs = [got.get(t + gk) for t in dirs if got.get(t + gk) is not None]
         if not gs:
             return
-        out[key] = _pair(torch.cat([x.flatten() for x in gs]), torch.cat([r(t).flatten() for t in dirs]), torch.cat([w(t).flatten() for t in dirs]))
+        oth = None if m is None else torch.cat([m[t + gk].flatten() for t in dirs])
+        out[key] = _pair(torch.cat([x.flatten() for x in gs]), cat(r), cat(w), None if wd is None else cat(dv), oth)
 
-    pooled("scores", lambda t: got.get(t + "neg"), lambda t: w32[t + "neg"], lambda t: w64[t + "neg"])
-    pooled("lse", lambda t: got.get(t + "lse"), lambda t: t32[t + "lse"], lambda t: t64[t + "lse"])
-    pooled("row_loss", lambda t: got.get(t + "rowloss"), lambda t: t32[t + "rowloss"], lambda t: t64[t + "rowloss"])
-    out["loss"] = _pair(got["loss"].reshape(1), w32["loss"].reshape(1), w64["loss"].reshape(1))
-    out["occ_grad"] = _pair(got["gocc"], w32["node_grad"], w64["node_grad"])
+    pooled("scores", "neg", lambda t: w32[t + "neg"], lambda t: w64[t + "neg"], lambda t: wd[t + "neg"])
+    pooled("lse", "lse", lambda t: t32[t + "lse"], lambda t: t64[t + "lse"], lambda t: td[t + "lse"])
+    pooled("row_loss", "rowloss", lambda t: t32[t + "rowloss"], lambda t: t64[t + "rowloss"], lambda t: td[t + "rowloss"])
+    out["loss"] = _pair(got["loss"].reshape(1), w32["loss"].reshape(1), w64["loss"].reshape(1), None if wd is None else wd["loss"].reshape(1),
+                        None if m is None else m["loss"].reshape(1))
+    out["occ_grad"] = _pair(got["gocc"], w32["node_grad"], w64["node_grad"], None if wd is None else wd["node_grad"], None if m is None else m["gocc"])
     if got.get("grel") is not None and w64.get("rel_grad") is not None:
         # per-edge relation gradients are not a leaf of the oracle (it holds [R, d] sums): compare the sums, which is what the optimizer sees
         R = rel.size(0)
         ids = edges[:, 1]
-        sums = [torch.zeros(R, emb.size(1), dtype=torch.float64).index_add_(0, ids, got[k].double()) for k in (("grel", "inv_grel") if inv is not None else ("grel",))]
+        gk = ("grel", "inv_grel") if inv is not None else ("grel",)
+        rsum = lambda src: torch.cat([torch.zeros(R, emb.size(1), dtype=torch.float64).index_add_(0, ids, src[k].double()).flatten() for k in gk])  # noqa: E731
         keys = ("rel_grad", "inv_rel_grad") if inv is not None else ("rel_grad",)
-        out["rel_grad"] = _pair(torch.cat([s.flatten() for s in sums]), torch.cat([w32[k].flatten() for k in keys]), torch.cat([w64[k].flatten() for k in keys]))
+        out["rel_grad"] = _pair(rsum(got), torch.cat([w32[k].flatten() for k in keys]), torch.cat([w64[k].flatten() for k in keys]),
+                                None if wd is None else torch.cat([wd[k].flatten() for k in keys]), None if m is None else rsum(m))
+    return out
+
+
+ASSERTED = ("scores", "lse", "row_loss", "occ_grad", "rel_grad")
+
+
+def verdict(pairs, asserted=ASSERTED):
+    """How the device path compares with the fp32 evaluations of the same batch.  The strict reading "no worse than the reference's fp32
+    evaluation on every quantity, max and RMS" is counted against each evaluation separately (`le1_cpu_aten`, `le1_device_aten`, `le1_fp32_mfma`:
+    how many of the 2 x len(asserted) ratios are <= 1).  No fp32 evaluation meets it against the others — they differ among themselves by up
+    to 3x on the gradient quantities (summation order) — so `ok` asks for what any of them satisfies by construction: on every quantity, max
+    and RMS error no larger than those of the LEAST accurate fp32 evaluation available (the reference's op sequence on CPU tensors, on device
+    tensors, and this library's FP32-MFMA kernels)."""
+    out = {"le1_cpu_aten": 0, "le1_device_aten": 0, "le1_fp32_mfma": 0, "of": 2 * len(asserted), "worst_vs_least_accurate_fp32": 0.0}
+    ok = True
+    for q in asserted:
+        p = pairs[q]
+        for stat in ("max", "rms"):
+            dev = p["device_" + stat]
+            refs = {"le1_cpu_aten": p.get("fp32_" + stat), "le1_device_aten": p.get("fp32_on_device_" + stat), "le1_fp32_mfma": p.get("fp32_mfma_" + stat)}
+            for k, v in refs.items():
+                if v is not None and dev <= v:
+                    out[k] += 1
+            worst = max(v for v in refs.values() if v is not None)
+            out["worst_vs_least_accurate_fp32"] = max(out["worst_vs_least_accurate_fp32"], dev / worst if worst > 0 else math.inf)
+            ok = ok and dev <= worst
+    out["ok"] = ok
     return out
 
 
@@ -100,6 +151,11 @@ def summary(pairs):
     """one line per quantity, for test output"""
     lines = []
     for k, p in pairs.items():
-        lines.append("%-9s device max %.2e rms %.2e | reference fp32 max %.2e rms %.2e | ratio max %.2f rms %.2f" % (
-            k, p["device_max"], p["device_rms"], p["fp32_max"], p["fp32_rms"], p["ratio_max"], p["ratio_rms"]))
+        line = "%-9s device max %.2e rms %.2e | reference fp32 (CPU ATen) max %.2e rms %.2e | ratio max %.2f rms %.2f" % (
+            k, p["device_max"], p["device_rms"], p["fp32_max"], p["fp32_rms"], p["ratio_max"], p["ratio_rms"])
+        if "fp32_on_device_max" in p:
+            line += " | reference fp32 (device ATen) max %.2e rms %.2e | ratio max %.2f rms %.2f" % (p["fp32_on_device_max"], p["fp32_on_device_rms"], p["ratio_dev_max"], p["ratio_dev_rms"])
+        if "fp32_mfma_max" in p:
+            line += " | FP32-MFMA kernels max %.2e rms %.2e" % (p["fp32_mfma_max"], p["fp32_mfma_rms"])
+        lines.append(line)
     return "\n".join(lines)

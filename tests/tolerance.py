@@ -28,3 +28,12 @@ def close_report(got, want, what, rtol=RTOL, floor=FLOOR, atol_frac=None):
 def tiers(got, want, what):
     close_report(got, want, what, floor=0.1, atol_frac=1.0)
     close_report(got, want, what, rtol=3e-4, floor=0.01, atol_frac=3e-6)
+
+
+def well_conditioned(state_ref, floor=1e-8):
+    """Mask of the table elements whose trajectory is a well-conditioned function of the gradients.  Adagrad from an all-zero sum moves a weight
+    by lr g / (|g| + 1e-10) (batch.cpp:67-69): where a first gradient is rounding noise around zero — exactly 0 in one correct fp32 evaluation,
+    7e-13 in another — the two updates differ by up to lr (7e-13 -> 7e-4 of a step of 0.1), in ANY arithmetic.  Elements of touched rows whose
+    accumulated g^2 stayed below `floor` are such noise and are left out; rows nobody touched (state 0 throughout) stay in and must match exactly."""
+    touched_rows = (state_ref > 0).any(1, keepdim=True)
+    return (~touched_rows).expand_as(state_ref) | (state_ref > floor)
