@@ -367,8 +367,11 @@ __device__ __forceinline__ void fl_grad_tile(const unsigned char* T, int tr_off,
     }
 }
 
+// (chunks wider than 128 columns — KS > 8, stored-score modes — run one workgroup per CU: their block slots fill the LDS, and one wave per SIMD
+// may then use the whole 512-entry register file)
+__host__ __device__ constexpr int fl_wg_per_cu_ks(int mode, int ks) { return (mode >= FLASH_FWDS && ks > 8) ? 1 : fl_wg_per_cu(mode); }
 template <int KS, int MODE, bool STORE_S, bool F16>
-__global__ __launch_bounds__(FL_NT, fl_wg_per_cu(MODE)) void flash_kernel(FlashArgs a) {
+__global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel(FlashArgs a) {
     constexpr int KP = 16 * KS, P = fl_pitch(KS), SLOT = fl_slot_bytes(KS), NSLOT = fl_slots(MODE);
     // ---- scales (all powers of two).  Accumulated scores carry s_x s_y; V = exp2(...) is formed VSH binades up so that its fp16 halves keep
     // their bits (V <= 2^FL_TAU in the fused sweep, <= 1 where lse is known); the outputs are scaled back when they leave the registers.
@@ -952,18 +955,23 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(const float2* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------- host side
-// column chunks of the contraction index: one for d <= 128, ceil(d / 128) equal ones above (each a multiple of 4 columns: 400 = 4 x 100);
-// 0 = this d cannot be cut that way
+// Column chunks of the contraction index.  d <= 128: one, the stationary operand's whole K depth lives in registers next to the gradient
+// accumulators (KS <= 8).  Wider rows take the stored-score modes, which hold EITHER the K fragments (FWDS) OR the accumulators (DADJS / DNEGS)
+// and therefore carry chunks of up to 256 columns (KS <= 16; round 4 — round 3 cut at 128: 400 = 4 x 100): ceil(d / 256) equal chunks, each a
+// multiple of 4 columns (400 = 2 x 200).  Every chunk costs one pass over the stored scores in each of the three launches, so halving their number
+// takes 3.0 -> 1.4 GB per step off cfg5's shape.  0 = this d cannot be cut that way.  MARIUS_FLASH_WIDE=0: rows wider than 128 columns stay on
+// the FP32 matrix path; =128: the round-3 chunk width (A/B runs).
 int flash_chunks(int d) {
     if (d <= 128) return 1;
-    const char* e = getenv("MARIUS_FLASH_WIDE");  // 0: rows wider than 128 columns stay on the FP32 matrix path (A/B runs)
+    const char* e = getenv("MARIUS_FLASH_WIDE");
     if (e && e[0] == '0') return 0;
-    const int n = (d + 127) / 128;
+    const int w = (e && atoi(e) == 128) ? 128 : 256;
+    const int n = (d + w - 1) / w;
     return (d % (4 * n) == 0 && d <= 1024) ? n : 0;
 }
 static int fl_kc(int d) { const int n = flash_chunks(d); return n > 0 ? d / n : d; }  // columns per chunk
 static int fl_ks(int d) { return (fl_kc(d) + 15) / 16; }
-bool flash_chunked(int d) { return flash_chunks(d) > 1; }
+bool flash_chunked(int d) { return d > 128 && flash_chunks(d) >= 1; }  // stored-score modes (possibly with a single chunk)
 // bytes of the stored scores in tile order (see s_tile in flash_kernel): whole 128 x 32 tiles
 size_t flash_tiled_scores_bytes(const LpDims& D) {
     const size_t xt = (D.Bc + FL_XT - 1) / FL_XT, yb = ((D.N + 31) / 32 * 32) / FL_YB;
@@ -1008,7 +1016,8 @@ bool flash_applicable(const marius_lp_desc* desc, const LpDims& D) {
             return false;
     }
     const int ks = fl_ks(D.d);
-    if (ks < 2 || ks > 8) return false;  // instantiated K depths: d in (16, 128]
+    if (ks < 2 || ks > (flash_chunked(D.d) ? 16 : 8)) return false;  // instantiated K depths: d in (16, 128]; chunks of up to 256 columns in the stored-score modes
+    if (D.d > 128 && !flash_chunked(D.d)) return false;
     if (D.ndir == 2 && !desc->src_neg) return false;
     return true;
 }
@@ -1024,15 +1033,17 @@ bool flash_fused() { return true; }
 static int g_flash_reserved_cus = 0;
 void flash_set_reserved_cus(int n) { g_flash_reserved_cus = n; }
 
-static int fl_num_wg(int64_t tiles, int mode) {
-    int nwg = 256 * fl_wg_per_cu(mode);
+static int fl_num_wg(int64_t tiles, int mode, int ks) {
+    // (KS > 8, stored-score modes only: three 28-32 KB block slots + two score tiles leave room for one workgroup per CU)
+    const int per_cu = fl_wg_per_cu_ks(mode, ks);
+    int nwg = 256 * per_cu;
     // marius_flash_set_reserved_cus / MARIUS_FLASH_RESERVE: leave that many CUs' worth of workgroup slots empty.  The persistent
     // workgroups otherwise hold every VGPR of the chip for the length of the launch, and kernels of other streams (batch preparation,
     // the sharded trainer's row exchange) can only start in its tail.
     int reserve = g_flash_reserved_cus;
     const char* r = getenv("MARIUS_FLASH_RESERVE");
     if (r) reserve = atoi(r);
-    if (reserve > 0 && reserve < 128) nwg = (256 - reserve) * fl_wg_per_cu(mode);
+    if (reserve > 0 && reserve < 128) nwg = (256 - reserve) * per_cu;
     const char* e = getenv("MARIUS_FLASH_NWG");
     if (e) nwg = atoi(e);
     if (nwg > tiles) nwg = (int)tiles;
@@ -1061,6 +1072,18 @@ static int fl_launch(const FlashArgs& a, hipStream_t st) {
 
 template <int MODE, bool STORE_S>
 static int fl_dispatch(int ks, const FlashArgs& a, hipStream_t st) {
+    if constexpr (MODE >= FLASH_FWDS) {  // stored-score modes: chunks of up to 256 columns
+        switch (ks) {
+            case 9: return fl_launch<9, MODE, STORE_S>(a, st);
+            case 10: return fl_launch<10, MODE, STORE_S>(a, st);
+            case 11: return fl_launch<11, MODE, STORE_S>(a, st);
+            case 12: return fl_launch<12, MODE, STORE_S>(a, st);
+            case 13: return fl_launch<13, MODE, STORE_S>(a, st);
+            case 14: return fl_launch<14, MODE, STORE_S>(a, st);
+            case 15: return fl_launch<15, MODE, STORE_S>(a, st);
+            case 16: return fl_launch<16, MODE, STORE_S>(a, st);
+        }
+    }
     switch (ks) {
         case 2: return fl_launch<2, MODE, STORE_S>(a, st);
         case 3: return fl_launch<3, MODE, STORE_S>(a, st);
@@ -1111,7 +1134,7 @@ static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, cha
     a.XT = (a.Xrows + xt_rows - 1) / xt_rows;
     a.YB = a.YR / FL_YB;
     a.total = (int64_t)a.ncd * a.XT * a.YB;
-    a.nwg = fl_num_wg((int64_t)a.ncd * a.XT, mode);
+    a.nwg = fl_num_wg((int64_t)a.ncd * a.XT, mode, fl_ks(D.d));
     {
         const char* ro = getenv("MARIUS_FLASH_ROTATE");
         a.rotate = (ro && ro[0] == '0') ? 0 : 1;
@@ -1140,7 +1163,8 @@ int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj,
     const int ppr = KP / 4 + 1;
     const int nch = flash_chunks(D.d), kc = fl_kc(D.d);  // column chunks of the contraction index (1 for d <= 128) and their width
     const size_t adjset = fl_adjset_bytes(D), negset = fl_negset_bytes(D);
-    MARIUS_REQUIRE(nch == 1 || (!adj_packed && adj && S), "flash: rows wider than 128 need the fp32 adj rows and the score matrix");
+    const bool wide = flash_chunked(D.d);
+    MARIUS_REQUIRE(!wide || (!adj_packed && adj && S), "flash: rows wider than 128 need the fp32 adj rows and the score matrix");
     for (int c = 0; c < nch; ++c) {
         if (!adj_packed) {
             const int64_t n = (int64_t)D.ndir * D.C * XR * ppr;
@@ -1151,11 +1175,11 @@ int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj,
                                                                                  kc, KP, NR, row_vec_width(desc->emb, desc->emb_ld, 4), negrec + c * negset, gocc,
                                                                                  D.d_ld, negocc_off[0], negocc_off[1], rg, c * kc);
     }
-    if (!adj_packed && (dadj_zero || nch > 1)) flash_zero_kernel<<<dim3(1024), dim3(256), 0, st>>>(nch > 1 ? dadj : dadj_zero, D.ndir * D.Bp * D.d_ld, nullptr, 0, nullptr, 0);
+    if (!adj_packed && (dadj_zero || wide)) flash_zero_kernel<<<dim3(1024), dim3(256), 0, st>>>(wide ? dadj : dadj_zero, D.ndir * D.Bp * D.d_ld, nullptr, 0, nullptr, 0);
     int rc = check_launch("flash_pack");
     if (rc) return rc;
     FlashArgs a;
-    if (nch > 1) {  // S += adj_c neg_c^T chunk by chunk; the last launch also leaves the row statistics
+    if (wide) {  // S += adj_c neg_c^T chunk by chunk; the last launch also leaves the row statistics
         ProfScope ps(PROF_LP_SCORES, st);
         for (int c = 0; c < nch && !rc; ++c) {
             fl_common(a, D, FLASH_FWDS, adjrec + c * adjset, negrec + c * negset, rg);

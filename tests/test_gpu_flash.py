@@ -226,7 +226,8 @@ def test_flash_score_filter_matches_oracle(H, dev, use_inverse, B, C, N, d, F):
 
 @pytest.mark.parametrize("f16", [False, True])
 @pytest.mark.parametrize("decoder,use_inverse,B,C,N,d", [("COMPLEX", True, 1000, 4, 500, 400), ("COMPLEX", False, 2048, 4, 512, 400), ("DISTMULT", True, 700, 3, 1000, 256),
-                                                      ("COMPLEX", True, 260, 2, 300, 200), ("COMPLEX", True, 5, 4, 6, 400)])
+                                                      ("COMPLEX", True, 260, 2, 300, 200), ("COMPLEX", True, 5, 4, 6, 400), ("DISTMULT", True, 300, 3, 200, 132),
+                                                      ("COMPLEX", True, 300, 2, 260, 600), ("DISTMULT", False, 500, 4, 96, 176)])
 def test_flash_wide_rows_in_column_chunks_match_oracle(H, dev, decoder, use_inverse, B, C, N, d, f16):
     """d > 128 (cfg5: Twitter ComplEx d = 400): the contraction index is cut into ceil(d / 128) equal column chunks with one operand-record set
     each; the scores are accumulated chunk by chunk into an fp32 matrix (FLASH_FWDS: the last launch leaves the SoftmaxCE statistics) and the two
@@ -407,8 +408,10 @@ def test_flash_not_selected_outside_its_domain(H, dev):
     assert mk().layout.flash == 1
     assert mk(relop=2, cmp=1).layout.flash == 0          # TransE
     assert mk(loss=H.LOSS["RANKING"]).layout.flash == 0
-    assert mk(d=400).layout.flash == 1          # round 3: four column chunks of 100 with stored scores
-    assert mk(d=132).layout.flash == 0          # 2 chunks of 66: not a multiple of 4 columns
+    assert mk(d=400).layout.flash == 1          # stored scores, two column chunks of 200 (round 3: four of 100)
+    assert mk(d=132).layout.flash == 1          # one chunk of 132 (round 3: two of 66, not a multiple of 4 columns -> FP32 path)
+    assert mk(d=520).layout.flash == 0          # three chunks: 520 is not a multiple of 4 x 3
+    assert mk(d=130).layout.flash == 0          # not a multiple of 4 columns
     assert mk(d=12).layout.flash == 0
     assert H.LpWorkspace(0, 0, 100, 64, 4, 32, True, H.REDUCE_SUM, 3, True, dev).layout.flash == 0   # API contract: scores materialised
 
