@@ -1502,6 +1502,7 @@ DataLoader::DataLoader(shared_ptr<InMemory> edges, shared_ptr<Storage> node_embe
 }
 
 void DataLoader::setEdgeBucketSizes(std::vector<int64_t> sizes) {
+    buckets_validated_ = false;
     edge_bucket_starts_.assign(sizes.size() + 1, 0);
     for (size_t i = 0; i < sizes.size(); ++i) edge_bucket_starts_[i + 1] = edge_bucket_starts_[i] + sizes[i];
     if (edge_bucket_starts_.back() != edges_->dim0_size_) throw MariusRuntimeException("edge bucket sizes do not add up to the number of edges");
@@ -1577,11 +1578,48 @@ void DataLoader::nextEpoch(bool write) {
     if (!err.empty()) throw MariusRuntimeException(err);
 }
 
+// Every edge of an active bucket must have both endpoints in the buffer, or a batch is handed rows of partitions that are on disk (the
+// reference's index_select throws on the -1 such a node maps to).  That follows from two facts, checked where they are cheap (a
+// reduction + .item() per buffer state made the host wait for the whole preceding state at every swap): (1) the edge list really is sorted by
+// edge bucket and the bucket sizes describe it — ONE pass over the edges on the device, the first time a buffer state is laid out; (2) every
+// bucket assigned to a buffer state has both its partitions in that state — a host loop over a few dozen pairs per state.
+void DataLoader::validate_edge_buckets() {
+    if (buckets_validated_) return;
+    auto dev = edges_->device_;
+    const int64_t P = pb_embeddings_->options_->num_partitions;
+    const int64_t ps = (pb_embeddings_->dim0_size_ + P - 1) / P;
+    Tensor starts = torch::from_blob(edge_bucket_starts_.data(), {(int64_t)edge_bucket_starts_.size()}, torch::kInt64).clone().to(dev);
+    const int64_t E = edges_->dim0_size_, piece = 1ll << 26;
+    Tensor bad = torch::zeros({}, i64(dev));
+    for (int64_t lo = 0; lo < E; lo += piece) {
+        const int64_t n = std::min(piece, E - lo);
+        Tensor e = edges_->data_.narrow(0, lo, n);
+        Tensor bucket = e.select(1, 0).to(torch::kInt64).floor_divide(ps) * P + e.select(1, -1).to(torch::kInt64).floor_divide(ps);
+        Tensor expect = torch::bucketize(torch::arange(lo, lo + n, i64(dev)), starts, /*out_int32=*/false, /*right=*/true) - 1;
+        bad += bucket.ne(expect).sum();
+    }
+    if (bad.item<int64_t>() != 0)
+        throw MariusRuntimeException("DataLoader: " + std::to_string(bad.item<int64_t>()) +
+                                     " edges have an endpoint outside the partitions in memory whenever their bucket is active (edge list not sorted by edge "
+                                     "bucket, or wrong edge_bucket_sizes)");
+    buckets_validated_ = true;
+}
+
 void DataLoader::setActiveEdges() {
     auto dev = edges_->device_;
     const int64_t P = pb_embeddings_->options_->num_partitions;
+    validate_edge_buckets();
     Tensor buckets = edge_buckets_per_buffer_.at(buffer_cursor_);
     auto b = buckets.accessor<int64_t, 2>();
+    {
+        Tensor st = buffer_states_.at(buffer_cursor_).to(torch::kCPU, torch::kInt64).contiguous();
+        const int64_t* sp = st.data_ptr<int64_t>();
+        auto resident = [&](int64_t part) { return std::find(sp, sp + st.numel(), part) != sp + st.numel(); };
+        for (int64_t i = 0; i < buckets.size(0); ++i)
+            if (!resident(b[i][0]) || !resident(b[i][1]))
+                throw MariusRuntimeException("DataLoader: edge bucket (" + std::to_string(b[i][0]) + ", " + std::to_string(b[i][1]) + ") is assigned to buffer state " +
+                                             std::to_string(buffer_cursor_) + ", which does not hold both partitions (outside the partitions in memory)");
+    }
     std::vector<Tensor> parts;
     for (int64_t i = 0; i < buckets.size(0); ++i) {
         const int64_t id = b[i][0] * P + b[i][1];
@@ -1599,12 +1637,6 @@ void DataLoader::setActiveEdges() {
     std::vector<Tensor> columns{g2l.index_select(0, act.select(1, 0))};
     if (cols == 3) columns.push_back(act.select(1, 1));
     columns.push_back(g2l.index_select(0, act.select(1, -1)));
-    // Every edge of an active bucket must have both endpoints in the buffer.  An edge list that is not sorted by bucket (or bucket sizes that
-    // do not describe it) hands the batch rows of partitions that are on disk: the reference's index_select throws on the -1 such a node maps
-    // to; here the check is one reduction per buffer state, before any kernel sees the ids.
-    if (torch::minimum(columns.front().min(), columns.back().min()).item<int64_t>() < 0)
-        throw MariusRuntimeException("DataLoader: an edge of buffer state " + std::to_string(buffer_cursor_) +
-                                     " has an endpoint outside the partitions in memory (edge list not sorted by edge bucket, or wrong edge_bucket_sizes)");
     active_edges_ = torch::stack(columns, 1).contiguous();
 }
 

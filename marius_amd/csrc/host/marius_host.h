@@ -626,6 +626,8 @@ class DataLoader {
     void loadStorage();                             // dataloader.cpp:566-600: new ordering (consumes the generator), load the first buffer state
     void nextEpoch(bool write = true);              // dataloader.cpp:108-118: write the buffer back (training), unload
     void setActiveEdges();                          // dataloader.cpp:120-175 for the current buffer state
+    bool buckets_validated_ = false;
+    void validate_edge_buckets();                   // once per edge list: it is sorted by edge bucket and the bucket sizes describe it
     shared_ptr<Batch> getBatch(bool exact_unique = true);  // dataloader.cpp:360-471
     void loadGPUParameters(shared_ptr<Batch> batch);       // dataloader.cpp:529-548
     void updateEmbeddings(shared_ptr<Batch> batch, bool gpu = true);  // dataloader.cpp:550-564

@@ -1030,22 +1030,40 @@ size_t flash_part_bytes(const LpDims& D) { return fl_stats_bytes(D) + fl_filter_
 // forward statistics and dAdj are one sweep (FLASH_FDADJ); the two-launch form of round 2 lost its A/B run (0.726 vs 0.653 ms per step) and is gone
 bool flash_fused() { return true; }
 
+// How many persistent workgroups a launch gets.  Every workgroup walks a contiguous range of total / nwg items, i.e. tiles / nwg stationary
+// tiles: when that ratio is a fraction p / q with a small denominator the ranges repeat every q workgroups — neighbours start and finish
+// their tiles in step, the two contributors of a split tile meet at the same few cut points, and the rotated sweeps of a (chunk, direction)
+// stay aligned in that XCD's L2.  Measured at the bench shape (800 tiles; profiles/r4_flash_nwg_sweep.txt): 512 workgroups (25 / 16 tiles
+// each) 0.623 ms per step, 496 0.627, 488 0.616, 480 (5 / 3) 0.599, 472 0.612, 464 0.612, 448 0.617, 400 (2 / 1, no split tiles but 22 % of
+// the slots empty) 0.618.  So: among the multiples of 8 within 15 % below the slot count, the one whose tiles / nwg has the smallest
+// denominator (ties: the larger).  The CUs this leaves without a workgroup (16 of 256 at the bench shape) are not wasted either: the step's
+// other stream — the next batch's sort / sample / plan kernels — otherwise only gets CU slots in the tails of the matrix launches
+// (profiles/r4a_timeline_one_step.txt: a 10 us sort sweep took 117-132 us underneath them).
+// MARIUS_FLASH_RESERVE / marius flash_set_reserved_cus: CUs to leave empty on top of that; MARIUS_FLASH_NWG: the count itself (tests of every
+// split pattern).
 static int g_flash_reserved_cus = 0;
 void flash_set_reserved_cus(int n) { g_flash_reserved_cus = n; }
 
+static int64_t fl_gcd(int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; }
 static int fl_num_wg(int64_t tiles, int mode, int ks) {
-    // (KS > 8, stored-score modes only: three 28-32 KB block slots + two score tiles leave room for one workgroup per CU)
     const int per_cu = fl_wg_per_cu_ks(mode, ks);
-    int nwg = 256 * per_cu;
-    // marius_flash_set_reserved_cus / MARIUS_FLASH_RESERVE: leave that many CUs' worth of workgroup slots empty.  The persistent
-    // workgroups otherwise hold every VGPR of the chip for the length of the launch, and kernels of other streams (batch preparation,
-    // the sharded trainer's row exchange) can only start in its tail.
     int reserve = g_flash_reserved_cus;
     const char* r = getenv("MARIUS_FLASH_RESERVE");
     if (r) reserve = atoi(r);
-    if (reserve > 0 && reserve < 128) nwg = (256 - reserve) * per_cu;
+    if (reserve < 0 || reserve >= 128) reserve = 0;
+    int nwg = (256 - reserve) * per_cu;
     const char* e = getenv("MARIUS_FLASH_NWG");
-    if (e) nwg = atoi(e);
+    if (e) {
+        nwg = atoi(e);
+    } else if (nwg < tiles && per_cu > 1) {  // (the one-workgroup-per-CU launches of wide chunks are bound by their score traffic: 256 beats 240 there, 1.402 vs 1.418 ms)
+        int best = nwg & ~7;
+        int64_t best_q = best / fl_gcd(tiles, best);
+        for (int n = best - 8; n >= 8 && n * 100 >= nwg * 85; n -= 8) {
+            const int64_t q = n / fl_gcd(tiles, n);
+            if (q < best_q) { best = n; best_q = q; }
+        }
+        nwg = best;
+    }
     if (nwg > tiles) nwg = (int)tiles;
     if (nwg >= 8) nwg &= ~7;  // XCD-local ranges need a multiple of 8
     return nwg < 1 ? 1 : nwg;
