@@ -460,7 +460,7 @@ def main():
         # rows wider than 128 columns (cfg5's d = 400): the contraction index is cut into nch column chunks, the fp32 scores ARE stored (tile
         # order) and every launch streams them — these launches are bound by that traffic, not by the matrix pipe:
         # forward = nch launches timed as one (first stores, the others read-modify-write); backward = one (dAdj, dNeg) launch pair per chunk
-        nch = math.ceil(d / 128)
+        nch = math.ceil(d / 256)  # flash_chunks(): stored-score chunks of up to 256 columns (round 3: 128)
         s_bytes = 4.0 * ndir * Bp * N
         alg["lp_scores"] = ("hbm", (2 * nch - 1) * s_bytes)
         alg["lp_grad_adj"] = ("hbm", s_bytes)
@@ -512,7 +512,7 @@ def main():
                     "avg_ms": k["avg_ms"]}
         if wide:
             roofline["note"] = ("rows wider than 128 columns: %d column chunks over stored fp32 scores in tile order; achieved = score bytes a launch streams "
-                                "(4 ndir Bp N per pass; the forward = 2 nch - 1 passes) / launch time") % math.ceil(d / 128)
+                                "(4 ndir Bp N per pass; the forward = 2 nch - 1 passes) / launch time") % math.ceil(d / 256)
         if flash and k["bound"] == "mfma":
             ncon = 1 if dom == "lp_scores" else 2
             roofline.update({"peak_is": "dense 16-bit MFMA (bf16 and fp16 run at the same rate)", "bf16_products_per_fp32_product": 3, "contractions_per_launch": ncon,
