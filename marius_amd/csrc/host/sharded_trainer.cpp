@@ -59,29 +59,13 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
     (void)side_group_name;  // kept in the signature: earlier builds exchanged the receive counts over a CPU (gloo) group
     if (pg_->getSize() != world_ || pg_->getRank() != rank_) throw MariusRuntimeException("ShardedTrainer: process group does not match rank / world");
     const auto dev = table_.device();
-    {
-        // Experiment (MARIUS_SHARDED_HIPRIO=1): compute on a high-priority stream so that the persistent MFMA kernels win CU slots over the
-        // small kernels of the preparation / exchange streams.
-        const char* e = getenv("MARIUS_SHARDED_HIPRIO");
-        const bool hiprio = e && e[0] == '1';  // measured: 1.87 vs 1.40 ms per step — the side streams starve and the compute stream then waits for them; off
-        auto cur = c10::hip::getCurrentHIPStream(dev.index());
-        main_stream_ = new c10::hip::HIPStream(hiprio ? c10::hip::getStreamFromPool(true, dev.index()) : cur);
-        if (hiprio) {  // everything the caller enqueued so far (table initialisation ...) precedes the first step
-            hipEvent_t ev = new_event();
-            ST_HIPCHECK(hipEventRecord(ev, cur.stream()));
-            ST_HIPCHECK(hipStreamWaitEvent(strm(main_stream_).stream(), ev, 0));
-            ST_HIPCHECK(hipEventDestroy(ev));
-        }
-    }
-    // The side streams' kernels are short and sit on the critical path of the NEXT step (rows must have arrived before it can be scored);
-    // the compute stream's persistent kernels hold the whole chip while they run.  High priority for the side streams lets their
-    // workgroups take the first slots that free up (MARIUS_SHARDED_SIDE_HIPRIO=0: equal priorities).
-    const char* sp = getenv("MARIUS_SHARDED_SIDE_HIPRIO");
-    const bool side_hi = !(sp && sp[0] == '0');
-    const char* pp = getenv("MARIUS_SHARDED_PREP_HIPRIO");  // preparation alone (it runs batches ahead: latency matters less than for the exchange)
-    const bool prep_hi = pp ? pp[0] != '0' : side_hi;
-    prep_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(prep_hi, dev.index()));
-    xchg_stream_ = new c10::hip::HIPStream(staleness_ ? c10::hip::getStreamFromPool(side_hi, dev.index()) : strm(main_stream_));
+    // The compute stream is the caller's current stream (a high-priority compute stream was measured: 1.87 vs 1.40 ms per step — the side
+    // streams starve and the compute stream then waits for them).  The side streams' kernels are short and sit on the critical path of the
+    // NEXT step (rows must have arrived before it can be scored), while the compute stream's persistent kernels hold most of the chip: high
+    // priority lets the side streams' workgroups take the first slots that free up.
+    main_stream_ = new c10::hip::HIPStream(c10::hip::getCurrentHIPStream(dev.index()));
+    prep_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(/*isHighPriority=*/true, dev.index()));
+    xchg_stream_ = new c10::hip::HIPStream(staleness_ ? c10::hip::getStreamFromPool(/*isHighPriority=*/true, dev.index()) : strm(main_stream_));
     for (auto& s : slots_) {
         s.offs_dev = torch::empty({world_ + 1}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
         s.offs_host = torch::empty({world_ + 1}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));

@@ -1113,8 +1113,6 @@ static char scores_variant(const marius_lp_desc* d, const LpDims& D) {
 }
 // number of column groups of the fused SoftmaxCE partials, 0 when the loss must be computed from the materialised scores
 static int lse_fused_groups(const marius_lp_desc* d, const LpDims& D) {
-    const char* e = getenv("MARIUS_NO_FUSED_LSE");
-    if (e && e[0] == '1') return 0;
     if (kernel_level() != 2) return 0;
     if (D.loss != MARIUS_LOSS_SOFTMAX_CE) return 0;  // the other losses read the materialised scores
     if ((d->dst_filter && d->n_dst_filter > 0) || (d->src_filter && d->n_src_filter > 0)) return 0;
@@ -1179,10 +1177,7 @@ static bool vlog_path(const LpDims& D) {
     return D.loss != MARIUS_LOSS_SOFTMAX_CE && D.loss != MARIUS_LOSS_MSE && D.cmp == MARIUS_CMP_DOT && kernel_level() == 2;
 }
 
-static bool flash_store_scores(const marius_lp_desc* d) {
-    const char* e = getenv("MARIUS_FLASH_STORE_S");
-    return (d->flags & MARIUS_LP_STORE_SCORES) || (e && e[0] == '1');
-}
+static bool flash_store_scores(const marius_lp_desc* d) { return (d->flags & MARIUS_LP_STORE_SCORES) != 0; }
 
 static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layout* L) {
     size_t off = 0;
@@ -1253,18 +1248,16 @@ extern "C" int marius_lp_plan(const marius_lp_desc* desc, marius_lp_layout* layo
     return make_layout(desc, D, layout);
 }
 
-// the half-wave-per-edge prep / edge-backward kernels need 8-B aligned rows and d <= 128 (MARIUS_PREP=1: the any-shape kernels)
+// the half-wave-per-edge prep / edge-backward kernels need 8-B aligned rows and d <= 128 (everything else: the any-shape kernels)
 static bool lp_vec_ok(const marius_lp_desc* desc, const LpDims& D) {
-    const char* pv = getenv("MARIUS_PREP");
     return (D.d % 4 == 0) && D.d <= 128 && (desc->emb_ld % 2 == 0) && (desc->rel_ld % 2 == 0 || !desc->rel) && (D.d == D.d_ld) &&
            ((reinterpret_cast<uintptr_t>(desc->emb) & 7) == 0) && ((reinterpret_cast<uintptr_t>(desc->rel) & 7) == 0) &&
-           ((reinterpret_cast<uintptr_t>(desc->inv_rel) & 7) == 0) && !(pv && pv[0] == '1');
+           ((reinterpret_cast<uintptr_t>(desc->inv_rel) & 7) == 0);
 }
 // Flash path with the fused prep: adj exists as operand records only; the edge backward recomputes the four elements it needs from the rows
-// it reads anyway (saves the 2 Bp d 4-byte store and its re-read).  MARIUS_FLASH_KEEP_ADJ=1 keeps the fp32 copy (layout.adj) as well.
+// it reads anyway (saves the 2 Bp d 4-byte store and its re-read).
 static bool flash_adj_elided(const marius_lp_desc* desc, const LpDims& D, const marius_lp_layout* L) {
-    const char* k = getenv("MARIUS_FLASH_KEEP_ADJ");
-    return L->flash && lp_vec_ok(desc, D) && !(desc->flags & MARIUS_LP_STORE_SCORES) && !(k && k[0] == '1');
+    return L->flash && lp_vec_ok(desc, D) && !(desc->flags & MARIUS_LP_STORE_SCORES);
 }
 
 extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_layout* L, void* workspace, marius_stream_t stream) {
@@ -1350,7 +1343,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     sa.KC = ((sa.dk + sa.nkc - 1) / sa.nkc + 3) / 4 * 4;
     sa.KS = ((sa.KC / 2) & 1) ? sa.KC : sa.KC + 2;  // stride/2 odd -> conflict-free ds_read_b64 across 32 rows
     sa.D = D;
-    { const char* ab = getenv("MARIUS_ABLATE"); sa.ablate = ab ? atoi(ab) : 0; }
+    sa.ablate = 0;
     sa.lse_part = lse_fused(desc, D) ? (float*)(ws + L->lsepart) : nullptr;
     sa.dbg = getenv("MARIUS_TIMELINE_GRADS") ? nullptr : g_dbg_timeline;
     dim3 grid((unsigned)cdiv(D.N, F_TN), (unsigned)cdiv(D.Bc, F_TM), (unsigned)(D.C * D.ndir));
@@ -1464,7 +1457,7 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
         ga.S = (const float*)(ws + L->vlog);
         ga.D.loss = MARIUS_LOSS_SOFTMAX_CE;
     }
-    { const char* ab = getenv("MARIUS_ABLATE"); ga.ablate = ab ? atoi(ab) : 0; }
+    ga.ablate = 0;
     ga.dbg = getenv("MARIUS_TIMELINE_GRADS") ? g_dbg_timeline : nullptr;
     const unsigned nblk = (unsigned)cdiv(D.d, ga.ncols);
     dim3 ga_grid(nblk, (unsigned)cdiv(D.Bc, G_TM), (unsigned)(D.C * D.ndir));
@@ -1472,8 +1465,7 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     {
         // the tuned contraction kernels hard-code V = exp(S - lse); every other loss runs the generic kernels (dscore_any)
         const int lvl = (D.loss == MARIUS_LOSS_SOFTMAX_CE || vlog) ? kernel_level() : 0;
-        const char* sp = getenv("MARIUS_GRAD_SPLIT");  // 1 = separate launches for dAdj / dNeg (per-kernel timing)
-        const bool split = sp && sp[0] == '1';
+        const bool split = false;  // (the merged dAdj + dNeg launch; the separate launches below serve shapes it does not take)
         bool done = false;
         if (L->flash) {
             const bool filtered = (desc->dst_filter && desc->n_dst_filter > 0) || (D.ndir == 2 && desc->src_filter && desc->n_src_filter > 0);

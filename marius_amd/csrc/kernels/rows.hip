@@ -22,15 +22,8 @@ struct VecT<1> { using type = float; };
 constexpr int ROW_UNROLL = 4;
 // rows in flight per thread row of the gather.  tools/micro/gather_variants.hip (random 400-B rows of a 34 GB table, fresh ids per
 // launch, launches back to back) gives 37.8 us with 4, 34.8 us with 2, 38 us with 8; inside the training step (one launch between
-// other kernels) 4 is faster: 57-59 us vs 67-70 us between events.  Default 4; MARIUS_GATHER_UNROLL=2 selects the other build.
-static int gather_unroll() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MARIUS_GATHER_UNROLL");
-        v = (e && e[0] == '2') ? 2 : 4;
-    }
-    return v;
-}
+// other kernels) 4 is faster: 57-59 us vs 67-70 us between events.  4 it is.
+static int gather_unroll() { return 4; }
 
 template <int VEC, int NT, int GATHER_UNROLL>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ ta, const float* __restrict__ tb,

@@ -662,8 +662,7 @@ static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, cons
     ApplySum ap{gsum, g_ld, nullptr};
     // most rows of a batch occur once (uniform negatives over a large table): those segments skip the reduction entirely and the
     // update kernel reads their gradient straight from the occurrence row — no 80 MB round trip through gsum
-    const char* ns = getenv("MARIUS_SEG_NO_SKIP");
-    const bool skip = !(ns && ns[0] == '1') && vec <= vsum;
+    const bool skip = vec <= vsum;
     a.skip_singletons = skip ? 1 : 0;
     const int4* row_plan = nullptr;
     if (plan) {
@@ -710,7 +709,6 @@ extern "C" int marius_segment_adagrad_scatter_group(const marius_segment_update*
     hipStream_t st = as_stream(stream);
     const char* ge = getenv("MARIUS_SEG_GROUP");  // 0: one launch pair per table (A/B runs)
     bool grouped = njobs <= SEG_GROUP_MAX && !(ge && ge[0] == '0');
-    const char* ns = getenv("MARIUS_SEG_NO_SKIP");
     int per0 = 0;
     for (int j = 0; j < njobs && grouped; ++j) {  // the single-launch planned form's conditions (segment_adagrad_scatter_impl), for every job
         const marius_segment_update& u = jobs[j];
@@ -718,7 +716,7 @@ extern "C" int marius_segment_adagrad_scatter_group(const marius_segment_update*
               u.rows_ld >= u.d && u.table_ld >= u.d)) { grouped = false; break; }
         const int v = row_vec_width(u.rows, u.rows_ld, u.d), v2 = row_vec_width(u.table, u.table_ld, u.d), v3 = row_vec_width(u.state, u.table_ld, u.d);
         const int per = cdiv(u.d, 256);
-        if (v != 4 || v2 != 4 || v3 != 4 || per > 2 || (j > 0 && per != per0) || (ns && ns[0] == '1')) grouped = false;
+        if (v != 4 || v2 != 4 || v3 != 4 || per > 2 || (j > 0 && per != per0)) grouped = false;
         for (int i = 0; i < j; ++i)  // jobs run side by side: a shared scratch or a shared table would race
             if (jobs[i].carry == u.carry || jobs[i].table == u.table || jobs[i].state == u.state) grouped = false;
         per0 = per;
