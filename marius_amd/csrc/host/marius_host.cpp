@@ -1877,7 +1877,7 @@ shared_ptr<Batch> DataLoader::getBatch(bool exact_unique) {
     const auto dev_index = edges_->device_.index();
     c10::hip::HIPStream main = c10::hip::getCurrentHIPStream(dev_index);
     if (!loader_stream_) {
-        loader_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(false, dev_index));
+        loader_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(false, dev_index));  // (high priority: measured, no difference)
         for (auto& e : ev_pool_) {
             hipEvent_t ev;
             HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));

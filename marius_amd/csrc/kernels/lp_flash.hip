@@ -16,7 +16,12 @@
 //   * backward recomputes the score tile, forms V = dL/dS = g exp(S - lse) in registers and feeds it straight back into the
 //     matrix pipe as the A operand of the gradient contraction (the accumulator layout of a 32x32 tile IS the A-operand layout of
 //     the next MFMA once the streamed rows are stored in a fixed permutation): dAdj = V Neg and dNeg = V^T adj are two launches of
-//     the same kernel with the roles of the two operands swapped.  5 contractions x 3 products = 3e11 bf16 flop per bench step.
+//     the same kernel with the roles of the two operands swapped.  (Round 2: 5 contractions x 3 products per step; since round 3 the
+//     forward statistics and dAdj are ONE sweep — FLASH_FDADJ below — and a step needs 4: 2.4e11 16-bit flop at the bench shape.)
+//   * round 3: fp16 halves of power-of-two-scaled rows (22 significand bits) instead of bf16 ones whenever the caller supplies magnitude
+//     bounds (marius_lp_desc.absmax / absmax_rel); round 4: every training path does (a tracked table, the partition buffer's slab bound, or a
+//     scan of the gathered rows), the bound on adj follows the relation operator (FlRange::adj_bound), and the arithmetic is measured against
+//     the reference's fp32 evaluation in every bench run (oracle/arith_check.py).
 //
 // Operand records.  adj rows and negative rows are packed once per step (flash_pack_*_kernel) in OCCURRENCE order, one block of
 // XR = ceil32(rows) records per (direction, chunk):
@@ -29,7 +34,8 @@
 // `lsec` (adj records only) = lse log2(e) - log2(g), patched in by the merge kernel after the forward: V = exp2(S log2(e) - lsec).
 //
 // Work decomposition.  Items = (chunk-direction, 128-row tile of the stationary operand, 32-row block of the streamed operand),
-// streamed index fastest.  nwg persistent workgroups (2 per CU, 4 waves, a wave owns 32 stationary rows as MFMA fragments in
+// streamed index fastest.  nwg persistent workgroups (up to 2 per CU — fl_num_wg picks the count whose ranges align best with the tiles —
+// 4 waves, a wave owns 32 stationary rows as MFMA fragments in
 // registers) each take a contiguous, XCD-local range of items, balanced to +-1 block, with nwg <= number of tiles so that a tile is
 // shared by at most two workgroups: the gradient of a split tile is accumulated with float atomics onto a zeroed output by exactly
 // two contributors, which is order-independent (a + b == b + a), so results stay bit-reproducible; the forward statistics of a split

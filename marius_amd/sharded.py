@@ -581,7 +581,8 @@ def run_sharded_bench(a, cfg, rank, world, dev):
             # the constructor already runs every collective the steps use (all-reduce, both all-to-all(v) forms, the gloo count exchange)
             cpp_trainer = M.ShardedTrainer(loader, model, table, state, rank, world, num_nodes, dist.group.WORLD.group_name, side_group.group_name,
                                            staleness, sync_interval)
-            cpp_trainer.enable_spans(True)  # eight event records per step on three streams: which stage's stream is starved
+            # per-stage device spans (which stage's stream is starved): fourteen event records + seven queries per step on the host, so only on request
+            cpp_trainer.enable_spans(os.environ.get("MARIUS_SHARDED_SPANS", "0") == "1")
         except Exception as e:  # noqa: BLE001 — e.g. a c10d build without the C++ group registry: same schedule from Python
             import sys
             print("[rank %d] C++ ShardedTrainer unavailable (%s): falling back to the Python schedule" % (rank, e), file=sys.stderr)
@@ -669,10 +670,8 @@ def run_sharded_bench(a, cfg, rank, world, dev):
             out["host_issue_ms_per_step"] = round(host_total / a.steps * 1e3, 4)
             out["config"]["host"] = "C++ ShardedTrainer (libtorch, c10d)" if cpp_trainer is not None else "Python schedule (marius_amd/sharded.py)"
             if cpp_trainer is not None:
-                out["device_span_ms"] = dict(zip(["prepare", "fetch", "compute", "update", "fetch_ids_a2a", "fetch_owner_gather", "fetch_rows_a2a"], [round(x, 4) for x in cpp_trainer.span_ms]))
-                out["host_phase_ms_per_step"] = dict(zip(["prepare", "wait_split_points", "fetch", "compute", "update", "dense"],
-                                                         [round(x / (a.steps + a.warmup) * 1e3, 4) for x in cpp_trainer.phase_seconds]))
-            if False:
+                if os.environ.get("MARIUS_SHARDED_SPANS", "0") == "1":  # (the instrumentation costs the host-bound step 2-3 %: off unless asked for)
+                    out["device_span_ms"] = dict(zip(["prepare", "fetch", "compute", "update", "fetch_ids_a2a", "fetch_owner_gather", "fetch_rows_a2a"], [round(x, 4) for x in cpp_trainer.span_ms]))
                 out["host_phase_ms_per_step"] = dict(zip(["prepare", "wait_split_points", "fetch", "compute", "update", "dense"],
                                                          [round(x / (a.steps + a.warmup) * 1e3, 4) for x in cpp_trainer.phase_seconds]))
         ms, cnt = prof.get("lp_grad_adj", (0.0, 0))

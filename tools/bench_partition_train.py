@@ -122,7 +122,8 @@ def main():
     est = M.InMemory(edges)
     est.edge_bucket_sizes = sizes
     loader = M.DataLoader(est, emb, st, M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen), gen, B, True)
-    tr = M.SynchronousTrainer(loader, model())
+    pb_model = model()
+    tr = M.SynchronousTrainer(loader, pb_model)
     # epoch by hand (== SynchronousTrainer::train(1)) so that the parts can be timed: per-state batch layout (host randperm of the state's
     # edges + global -> buffer-local id remap), the training steps, the swaps, and the final write-back of the resident partitions
     t0 = time.perf_counter()
@@ -160,7 +161,10 @@ def main():
                 "epoch_wall_s_incl_load_and_writeback": round(wall, 2), "parameters_GB": round(2 * a.nodes * d * 4 / 1e9, 1),
                 "resident_GB": round(2 * a.capacity * (-(-a.nodes // p)) * d * 4 / 1e9, 1), "swap_GB_each_way_per_swap": round(2 * (-(-a.nodes // p)) * d * 4 / 1e9, 2),
                 "swaps": emb.swaps, "prefetch_hits": emb.prefetch_hits, "swap_seconds_embeddings": round(emb.swap_seconds, 3),
-                "swap_seconds_state": round(st.swap_seconds, 3), "buffer_states": len(loader.buffer_states)})
+                "swap_seconds_state": round(st.swap_seconds, 3), "buffer_states": len(loader.buffer_states),
+                # what the last step packed its operand records with: "fp16" = 22 significand bits per operand (slab bound), "bf16" = 16, "none" = FP32-MFMA path
+                "operand_records": pb_model.last_step_records, "flash_path": bool(pb_model.last_step_flash),
+                "dtype": "f32 (contractions: 2-way %s split x 3 products, f32 accumulate)" % pb_model.last_step_records if pb_model.last_step_flash else "f32"})
     for pth in paths:
         os.remove(pth)
     print(json.dumps(out))

@@ -25,7 +25,7 @@ python - <<PY
 import json
 try:
     d=json.load(open("gpurun_out/$tag/bench_sharded_w1.json"))
-    print("sharded w1", d["ms_per_step"], d["dtype"], d.get("device_span_ms"), d.get("host_issue_ms_per_step"), d.get("host_phase_ms_per_step"))
+    print("sharded w1", d["ms_per_step"], d["dtype"], d.get("host_issue_ms_per_step"), d.get("host_phase_ms_per_step"))
 except Exception as e:
     print("sharded FAILED", e); print(open("gpurun_out/$tag/bench_sharded_w1.err").read()[-2500:])
 PY
