@@ -261,6 +261,9 @@ void InMemory::indexAdd(Tensor indices, Tensor values) {  // storage.cpp:651-673
     require_device(data_, "indexAdd");
     mcheck(marius_scatter_add_rows(fp(data_), data_.stride(0), ip(indices), indices.size(0), (int32_t)dim1_size_, fp(values), values.stride(0),
                                    cur_stream()));
+    // written through a raw pointer: tell ATen's version counter, which is what a model that tracks this table's magnitude bound looks at
+    // (Model::Scanned; every other write path of this class is an ATen op and bumps it by itself)
+    data_.unsafeGetTensorImpl()->bump_version();
 }
 void Storage::readPartitionSizes(const std::string& filename) {
     std::ifstream f(filename);

@@ -1044,7 +1044,7 @@ bool flash_fused() { return true; }
 // the slots empty) 0.618.  So: among the multiples of 8 within 15 % below the slot count, the one whose tiles / nwg has the smallest
 // denominator (ties: the larger).  The CUs this leaves without a workgroup (16 of 256 at the bench shape) are not wasted either: the step's
 // other stream — the next batch's sort / sample / plan kernels — otherwise only gets CU slots in the tails of the matrix launches
-// (profiles/r4a_timeline_one_step.txt: a 10 us sort sweep took 117-132 us underneath them).
+// (profiles/r4_timeline_one_step_before_workgroup_rule.txt: a 10 us sort sweep took 117-132 us underneath them).
 // MARIUS_FLASH_RESERVE / marius flash_set_reserved_cus: CUs to leave empty on top of that; MARIUS_FLASH_NWG: the count itself (tests of every
 // split pattern).
 static int g_flash_reserved_cus = 0;

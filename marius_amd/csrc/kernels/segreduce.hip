@@ -15,7 +15,10 @@
 namespace marius {
 
 constexpr int SEG_R = 32;      // sorted positions per wave
-constexpr int SEG_BATCH = 8;   // row loads in flight per lane
+#ifndef MARIUS_SEG_BATCH
+#define MARIUS_SEG_BATCH 8
+#endif
+constexpr int SEG_BATCH = MARIUS_SEG_BATCH;  // row loads in flight per lane (tools/build_variant.py builds A/B variants of such constants)
 
 struct SegArgs {
     const float* rows;

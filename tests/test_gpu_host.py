@@ -179,6 +179,46 @@ def test_trainer_tracks_table_magnitude_through_a_thousandfold_growth(M, dev):
     close(state.data.cpu()[solid], cpu.state[solid], rtol=3e-4)
 
 
+def test_tracked_bound_follows_writes_from_outside_the_trainer(M, dev):
+    """the magnitude bound the fp16 records are scaled with was trusted as long as every write went through the tracked update.  A
+    write from outside — Storage.indexAdd from user code (a raw-pointer kernel), an ATen op on `data` — between two fused steps must make the
+    trainer rescan the table (the scan remembers pointer, row count and ATen version of what it saw), or rows 30x above the stale bound would
+    saturate the records silently.  Same for another table behind the same model."""
+    num_nodes, R, d, B, C, N, E, seed = 3000, 7, 100, 200, 4, 50, 800, 9
+    table, edges_all, emb, state, loader, model = _setup(M, dev, "COMPLEX", num_nodes, R, d, B, C, N, E, seed, init=0.2)
+    cpu = CpuLinkPredictionStep("COMPLEX", table.clone(), torch.zeros(num_nodes, d), R, B, C, N)
+    torch.manual_seed(seed)
+    perm = torch.randperm(E)
+    trainer = M.SynchronousTrainer(loader, model)
+    loader.initializeBatches(True)
+    trainer.train_steps(1)
+    cpu.step(edges_all[perm[0:B]])
+    torch.cuda.synchronize()
+    assert model.tracks(emb.data) and model.last_step_records == "fp16"
+    before = float(model.range_state[0])
+    # (1) raw-pointer write through the Storage API: a third of the rows grow 30-fold
+    ids = torch.arange(0, num_nodes, 3)
+    bump = cpu.table[ids] * 29.0
+    emb.indexAdd(ids.to(dev), bump.to(dev))
+    cpu.table[ids] += bump
+    assert not model.tracks(emb.data)
+    trainer.train_steps(1)
+    cpu.step(edges_all[perm[B:2 * B]])
+    torch.cuda.synchronize()
+    assert model.tracks(emb.data) and float(model.range_state[0]) >= float(emb.data.abs().max()) > 10 * before
+    # (2) an ATen in-place op on the tensor itself
+    emb.data.mul_(0.5)
+    cpu.table.mul_(0.5)
+    assert not model.tracks(emb.data)
+    trainer.train_steps(1)
+    cpu.step(edges_all[perm[2 * B:3 * B]])
+    torch.cuda.synchronize()
+    from tolerance import well_conditioned
+    ok = well_conditioned(cpu.state)
+    close(emb.data.cpu()[ok], cpu.table[ok], rtol=3e-4)
+    close(model.decoder.relations.detach(), cpu.rel, rtol=3e-4)
+
+
 def test_user_plugins_train_through_the_virtual_api(M, dev):
     """The reference's plug-in points (comparators.h:13-17 virtual operator(), model.h forward_lp, test_nn.py:113-127): a Python subclass of
     Comparator and a Python subclass of Model that overrides forward_lp are both picked up by the trainer.  Such models leave the fused
