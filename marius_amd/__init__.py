@@ -26,7 +26,8 @@ def host():
         from . import hip
 
         hip.lib()
-        ctypes.CDLL(hip.LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        # the host module's marius_* symbols bind to the first RTLD_GLOBAL copy: it must be the one hip.lib() opened (MARIUS_HIP_LIB experiment builds)
+        ctypes.CDLL(os.environ.get("MARIUS_HIP_LIB", hip.LIB_PATH), mode=ctypes.RTLD_GLOBAL)
         path = os.path.join(_HERE, "lib", "_marius_host" + sysconfig.get_config_var("EXT_SUFFIX"))
         if not os.path.exists(path):
             raise ImportError("%s not found — build it with `python -m marius_amd.build --host`" % path)

@@ -1286,6 +1286,9 @@ void Model::train_batch(shared_ptr<Batch> batch, bool call_step) {
 }
 
 void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor state, bool table_direct) {
+    // one row pitch for both (the update kernels take a single ld): contiguous tensors, or the two halves of an interleaved [row | state] buffer
+    if (table.stride(0) != state.stride(0) || table.stride(1) != 1 || state.stride(1) != 1)
+        throw MariusRuntimeException("backward_into_tables: the table and its optimizer state must share one row pitch and have unit column stride");
     if (table_direct) {
         if (!batch->global_edges_.defined()) throw MariusRuntimeException("backward_into_tables: table-direct step without the batch's global-id edges");
         batch->table_ = table;

@@ -15,10 +15,16 @@
 namespace marius {
 
 constexpr int SEG_R = 32;      // sorted positions per wave
+// (tools/build_variant.py + tools/ab_variants.sh time variants of these constants on one box.  Round 4, Freebase86m step: 8 row loads in flight per
+// lane 151 us for the reduce + update pair, 4 -> 144, 2 -> 141, 1 -> 141, 16 -> 167: most segments are singletons that are skipped, and the batch's
+// registers cost occupancy; Adagrad rows per thread 8 -> 200 us, 4 / 2 / 1 equal once a row's pieces map one to one onto lanes)
 #ifndef MARIUS_SEG_BATCH
-#define MARIUS_SEG_BATCH 8
+#define MARIUS_SEG_BATCH 2
 #endif
-constexpr int SEG_BATCH = MARIUS_SEG_BATCH;  // row loads in flight per lane (tools/build_variant.py builds A/B variants of such constants)
+#ifndef MARIUS_ADAGRAD_UNR
+#define MARIUS_ADAGRAD_UNR 4
+#endif
+constexpr int SEG_BATCH = MARIUS_SEG_BATCH;  // row loads in flight per lane
 
 struct SegArgs {
     const float* rows;
@@ -300,6 +306,18 @@ __global__ __launch_bounds__(256) void seg_plan_kernel(const int32_t* __restrict
 }
 
 static inline int dpad_of(int d) { return (d + 3) / 4 * 4; }
+// threads along a row in adagrad_rows_body: every VEC-float piece of a row gets its own lane when the row has at most 64 pieces
+// (MARIUS_ADAGRAD_TX_EXACT; d = 100: 25 lanes per row, 10 rows per pass and 6 idle threads — rounded up to a power of two it is 32 lanes with 7 idle in each row)
+// (measured: 144 -> 137 us for the reduce + update pair at d = 100)
+#ifndef MARIUS_ADAGRAD_TX_EXACT
+#define MARIUS_ADAGRAD_TX_EXACT 1
+#endif
+static inline int adagrad_tx(int vpr) {
+    if (MARIUS_ADAGRAD_TX_EXACT && vpr >= 1 && vpr <= 64) return vpr;
+    int tx = 1;
+    while (tx < vpr && tx < 64) tx <<= 1;
+    return tx;
+}
 
 // Row-parallel sparse Adagrad over the per-unique-row gradients g[U, dpad] (U = inverse[perm[n-1]] + 1 read on the device):
 //   ds = g*g; s = state[id] + ds; table[id] += -lr * (g / (sqrt(s) + eps)); state[id] = s        (batch.cpp:67-69 op order)
@@ -340,15 +358,17 @@ __device__ __forceinline__ void adagrad_rows_body(const AdagradRowsArgs& A, int6
     const int4* __restrict__ row_plan = A.row_plan;
     const int64_t U = row_plan ? n : inverse[perm[n - 1]] + 1;  // planned: rows past U carry id -1
     const int TX = A.tx_n, TY = 256 / TX;
-    const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x / TX;
-    constexpr int UNR = 4;
+    const int ty = threadIdx.x / TX, tx = threadIdx.x - ty * TX;  // TX need not be a power of two: the 256 - TX TY threads left over idle
+    constexpr int UNR = MARIUS_ADAGRAD_UNR;
     int64_t rows[UNR], ids[UNR];
     const float* grow[UNR];  // the row's gradient: the reduced sum, or (segment of one occurrence) that occurrence's row itself
 #pragma unroll
     for (int k = 0; k < UNR; ++k) {
         rows[k] = (block * UNR + k) * TY + ty;
         grow[k] = g + rows[k] * g_ld;
-        if (row_plan) {
+        if (ty >= TY) {
+            ids[k] = -1;
+        } else if (row_plan) {
             ids[k] = -1;
             if (rows[k] < U) {
                 const int4 q = row_plan[rows[k]];
@@ -675,10 +695,9 @@ static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, cons
         row_plan = (const int4*)(pp + plan_pos_bytes(n) + plan_chunk_bytes(n));
     }
     const int vpr = d / vec;
-    int tx = 1;
-    while (tx < vpr && tx < 64) tx <<= 1;
+    const int tx = adagrad_tx(vpr);
     const int ty = 256 / tx;
-    const unsigned row_blocks = (unsigned)cdiv(n, (int64_t)ty * 4);
+    const unsigned row_blocks = (unsigned)cdiv(n, (int64_t)ty * MARIUS_ADAGRAD_UNR);
     const float* occ = skip ? rows : nullptr;
     AdagradRowsArgs A{gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, tx, lr, eps, occ, rows_ld, seg_offsets, row_plan, 0, absmax};
     const int per = cdiv(d, 64 * vec);
@@ -751,10 +770,9 @@ extern "C" int marius_segment_adagrad_scatter_group(const marius_segment_update*
         J.sa.chunk_plan = (const int4*)(pp + plan_pos_bytes(u.n));
         const int4* row_plan = (const int4*)(pp + plan_pos_bytes(u.n) + plan_chunk_bytes(u.n));
         const int vpr = u.d / 4;
-        int tx = 1;
-        while (tx < vpr && tx < 64) tx <<= 1;
+        const int tx = adagrad_tx(vpr);
         const int ty = 256 / tx;
-        const unsigned row_blocks = (unsigned)cdiv(u.n, (int64_t)ty * 4);
+        const unsigned row_blocks = (unsigned)cdiv(u.n, (int64_t)ty * MARIUS_ADAGRAD_UNR);
         J.A = AdagradRowsArgs{gsum, g_ld, u.perm, u.inverse, u.n, u.uniq_ids, u.table, u.state, u.table_ld, vpr, tx, u.lr, u.eps, u.rows, u.rows_ld, u.seg_offsets, row_plan, 1, u.absmax};
         J.ada = ApplyAdagrad{u.uniq_ids, u.table, u.state, u.table_ld, u.lr, u.eps, u.absmax};
         J.nfix = (unsigned)cdiv(cdiv(u.n, SEG_R), 4);
