@@ -46,10 +46,11 @@ enum {
  * reserved_, marius_lp_layout.adjrec / negrec / fpart / flash, planned segment update, zero-initialised sort workspace; 4: MARIUS_LP_KEEP_DADJ,
  * layout.dadj doubled on the flash path; 5: marius_lp_desc.absmax, marius_table_absmax, the *_tracked update entry points; 6:
  * marius_segment_update, marius_segment_adagrad_scatter_group, marius_hip_struct_bytes(2); 7: marius_lp_desc.absmax_rel,
- * marius_table_absmax_counted; marius_lp_layout lost the operand planes of the removed bf16x6 kernels and the stream-K partials).  Every binder
+ * marius_table_absmax_counted; marius_lp_layout lost the operand planes of the removed bf16x6 kernels and the stream-K partials; 8:
+ * marius_lp_desc.upd_*, marius_segment_update.fused_below, marius_lp_fuses_endpoint_update, marius_segment_plan_occ_single).  Every binder
  * compares the value it was built against with what the loaded library returns and refuses to run on a mismatch: marius_amd/hip.py lib(),
  * the host module's init (bindings.cpp), and the plug-in recipe of INTEGRATION.md. */
-#define MARIUS_HIP_ABI_VERSION 7
+#define MARIUS_HIP_ABI_VERSION 8
 int marius_hip_abi_version(void);
 /* sizeof(marius_lp_desc) / sizeof(marius_lp_layout) as the library was compiled: a second line of defence for ctypes mirrors */
 int marius_hip_struct_bytes(int which /* 0: marius_lp_desc, 1: marius_lp_layout, 2: marius_segment_update */);
@@ -233,7 +234,21 @@ typedef struct marius_lp_desc {
      * caller whose batch rows are a gathered copy (sharded table, partition buffer, Model::train_batch) bounds the rows it gathered —
      * marius_table_absmax over the copy — while the relation bound belongs to the model.  NULL: absmax[1]. */
     const float* absmax_rel;
+    /* Optional, training only (MARIUS_LP_TRAIN_ONLY) and only when `emb` IS the node table (edges / negatives hold table rows): the edge backward
+     * applies the sparse Adagrad step (batch.cpp:67-69 op order, the arithmetic of marius_segment_adagrad_scatter bit for bit) of every endpoint
+     * occurrence whose node occurs ONCE in the batch straight to its table row — the row, its gradient and nothing else of that node are in the
+     * half-wave's registers at that point — instead of writing the gradient to `gocc` for the segment update to read back: 1,200 bytes of
+     * traffic less per such occurrence.  upd_occ_single: DEVICE uint8 per occurrence (marius_segment_plan_occ_single), upd_state: the table's
+     * Adagrad state (row pitch emb_ld), upd_absmax: optional magnitude tracking as in the *_tracked entry points.  The caller's segment update
+     * must then leave those rows alone: marius_segment_update.fused_below = 2 B.  Honoured only where marius_lp_fuses_endpoint_update() says so
+     * (the 16-byte-row kernels: d % 4 == 0, d <= 128, packed rows); ask before relying on it.  NULL upd_occ_single / upd_state: off. */
+    const uint8_t* upd_occ_single;
+    float* upd_state;
+    float* upd_absmax;
+    float upd_lr, upd_eps;
 } marius_lp_desc;
+/* 1: marius_lp_backward on this descriptor will apply the endpoint singletons' update itself (see upd_occ_single), 0: it will not */
+int marius_lp_fuses_endpoint_update(const marius_lp_desc* desc);
 
 /* marius_lp_desc.flags */
 enum {
@@ -328,6 +343,8 @@ int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld, const int
  * whatever stream prepares batches; marius_segment_adagrad_scatter_planned then runs the same three kernels with one coalesced load where
  * the unplanned form walks a chain of dependent index loads.  Same results bit for bit.  plan: marius_segment_plan_bytes(n) bytes. */
 size_t marius_segment_plan_bytes(int64_t n);
+/* the per-occurrence singleton flags inside a plan (uint8[n]: 1 = the occurrence's id occurs once among the n): marius_lp_desc.upd_occ_single */
+const uint8_t* marius_segment_plan_occ_single(const void* plan, int64_t n);
 int marius_segment_plan(const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, const int64_t* uniq_ids, int64_t n, void* plan,
                         marius_stream_t stream);
 int marius_segment_sum_rows_planned(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets,
@@ -364,6 +381,8 @@ typedef struct marius_segment_update {
     void* carry;
     const void* plan;
     float* absmax;
+    int64_t fused_below; /* > 0 (needs a plan): unique rows whose single occurrence is an occurrence row < fused_below were already updated by the
+                          * producer of `rows` (marius_lp_desc.upd_occ_single: the edge backward, occurrences [0, 2 B)) and are skipped */
 } marius_segment_update;
 int marius_segment_adagrad_scatter_group(const marius_segment_update* jobs, int32_t njobs, marius_stream_t stream);
 int marius_table_absmax(const float* table, int64_t rows, int64_t ld, int32_t d, float* absmax, marius_stream_t stream);

@@ -333,6 +333,8 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("step", &Model::step)
         .def("clear_grad", &Model::clear_grad)
         .def_readwrite("sparse_lr", &Model::sparse_lr_)
+        .def_readwrite("fuse_endpoint_update", &Model::fuse_endpoint_update_)
+        .def_readonly("last_step_fused_below", &Model::last_fused_below_)
         .def_readwrite("decoder", &Model::decoder_)
         .def_readwrite("reporter", &Model::reporter_)
         .def_readonly("loss", &Model::loss_)

@@ -1295,19 +1295,36 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
     }
     forward_lp_train(batch);
     batch->table_ = Tensor();
+    const int64_t L = batch->occ_perm_.size(0);
+    // Endpoint occurrences whose node occurs once in the batch (about half of them at the bench shape) take their Adagrad step inside the edge
+    // backward, which holds the row and its whole gradient in registers: no gocc store, no re-read next to the same table row in the update below
+    // (marius_lp_desc.upd_*; needs the table itself behind `emb` and the loader's plan for the per-occurrence flags).
+    int64_t fused_below = 0;
+    static const bool fuse_env = [] { const char* e = getenv("MARIUS_FUSE_ENDPOINT_UPDATE"); return !(e && e[0] == '0'); }();
+    if (table_direct && fuse_env && fuse_endpoint_update_ && batch->occ_plan_.defined()) {
+        marius_lp_desc& d = ctx_.desc;  // (rebuilt from zero by every forward: nothing to undo)
+        d.upd_occ_single = marius_segment_plan_occ_single(batch->occ_plan_.data_ptr(), L);
+        d.upd_state = fp(state);
+        d.upd_absmax = node_track_;
+        d.upd_lr = sparse_lr_;
+        d.upd_eps = 1e-10f;
+        if (marius_lp_fuses_endpoint_update(&d)) fused_below = 2 * d.B;
+        else d.upd_occ_single = nullptr, d.upd_state = nullptr, d.upd_absmax = nullptr;
+    }
+    last_fused_below_ = fused_below;
     model_backward(*this, batch);
     if (ev_grads_) HIPCHECK(hipEventRecord((hipEvent_t)ev_grads_, c10::hip::getCurrentHIPStream(device_.index()).stream()));
     const auto dev_index = device_.index();
-    const int64_t L = batch->occ_perm_.size(0);
     ensure(carry_, (int64_t)marius_segment_carry_bytes(L, ctx_.desc.d), device_);
     const float* gocc = (const float*)((const char*)ctx_.workspace.data_ptr() + ctx_.layout.gocc);
     // The node-table update and the relation-table updates are independent.  With the loader's plans at hand all of them are ONE pair of
     // launches (marius_segment_adagrad_scatter_group); the side stream the relation step used to run on, its fork / join events and four
     // launches are gone from the step's tail.
+    marius_segment_update node_job = {};
     if (batch->occ_plan_.defined()) {
         // relation jobs first: a hub relation's segment spans hundreds of chunks and is finished by ONE wave, so those workgroups should start
         // at the head of the launch, with the node table's many short ones filling in behind them
-        marius_segment_update jobs[3];
+        marius_segment_update jobs[3] = {};
         int njobs = 0;
         const bool rel_ok = relation_step_jobs(*this, batch, jobs, njobs);
         marius_segment_update& u = jobs[njobs++];
@@ -1327,10 +1344,12 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
         u.carry = carry_.data_ptr();
         u.plan = batch->occ_plan_.data_ptr();
         u.absmax = node_track_;
+        u.fused_below = fused_below;
         if (rel_ok) {
             mcheck(marius_segment_adagrad_scatter_group(jobs, njobs, cur_stream()));
             return;
         }
+        node_job = u;
     }
     // otherwise: the relation step (6 small, latency-bound launches) on a side stream underneath the node-table update, joined before
     // returning (the next forward reads the relation tables)
@@ -1357,7 +1376,9 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
         relation_grads_dense(*this, batch);
         step();  // (Adam, SGD, weight decay: the relation bound is rescanned before the next forward — touch_relations())
     }
-    if (node_track_)
+    if (fused_below > 0)  // (the job form carries fused_below; one job)
+        mcheck(marius_segment_adagrad_scatter_group(&node_job, 1, cur_stream()));
+    else if (node_track_)
         mcheck(marius_segment_adagrad_scatter_tracked(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
                                                       batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, ip(batch->unique_node_indices_), fp(table),
                                                       fp(state), table.stride(0), sparse_lr_, 1e-10f, carry_.data_ptr(),

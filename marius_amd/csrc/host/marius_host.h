@@ -452,6 +452,10 @@ class Model : public torch::nn::Module {
     shared_ptr<LinkPredictionReporter> reporter_;
     std::vector<shared_ptr<Optimizer>> optimizers_;
     float sparse_lr_ = 0.1f;
+    // table-direct fused step: endpoint occurrences whose node occurs once take their Adagrad step inside the edge backward (marius_lp_desc.upd_*);
+    // false (or MARIUS_FUSE_ENDPOINT_UPDATE=0 in the environment): every row goes through the segment update — same bits either way
+    bool fuse_endpoint_update_ = true;
+    int64_t last_fused_below_ = 0;  // diagnostic: occurrences [0, this) of the last table-direct step were eligible for the in-backward update (0: not fused)
     torch::Device device_ = torch::kCPU;
     Tensor relations_grad_, inverse_relations_grad_;
     LpContext ctx_;

@@ -864,8 +864,35 @@ struct EdgeBwdArgs {
     int keep_dadj;
     float* gocc;     // rows [0,B) = src occurrences, [B,2B) = dst occurrences
     float* grel[2];  // [B, d_ld]
+    // marius_lp_desc.upd_*: endpoint occurrences flagged in occ_single take their Adagrad step here (emb is then the table itself) and leave gocc unwritten
+    const uint8_t* occ_single;
+    float* upd_table;
+    float* upd_state;
+    float* upd_absmax;
+    float upd_lr, upd_eps;
     LpDims D;
 };
+
+// the sparse Adagrad step of one lane's four elements of a row (batch.cpp:67-69 op order): the arithmetic of segreduce.hip's update kernels, bit for bit
+__device__ __forceinline__ float edge_adagrad4(float* w_row, float* s_row, int c0, int c1, const float (&w)[4], const float (&g)[4], float lr, float eps) {
+#pragma clang fp contract(off)
+    const float2 s0 = *reinterpret_cast<const float2*>(s_row + c0), s1 = *reinterpret_cast<const float2*>(s_row + c1);
+    const float sv[4] = {s0.x, s0.y, s1.x, s1.y};
+    float sn[4], wn[4], seen = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float ds = g[k] * g[k];
+        sn[k] = sv[k] + ds;
+        const float dw = -lr * (g[k] / (sqrtf(sn[k]) + eps));
+        wn[k] = w[k] + dw;
+        seen = fmaxf(seen, fabsf(wn[k]));
+    }
+    *reinterpret_cast<float2*>(s_row + c0) = make_float2(sn[0], sn[1]);
+    *reinterpret_cast<float2*>(s_row + c1) = make_float2(sn[2], sn[3]);
+    *reinterpret_cast<float2*>(w_row + c0) = make_float2(wn[0], wn[1]);
+    *reinterpret_cast<float2*>(w_row + c1) = make_float2(wn[2], wn[3]);
+    return seen;
+}
 
 // gradient wrt (e, r) of a = op(e, r) given g = dL/da, for column c (complex: c < h handles the pair (c, c + h))
 // one wave per edge; handles both directions so every gocc element is written exactly once.
@@ -1066,6 +1093,18 @@ __global__ __launch_bounds__(256) void lp_edge_bwd2_kernel(EdgeBwdArgs a) {
             }
         }
     }
+    if (a.occ_single) {
+        // a node that occurs once in the batch: its row (x[]), its whole gradient (out_*) and nothing else of it are right here — take the Adagrad
+        // step now instead of a 400-byte store that the segment update reads back next to the same table row (its rows skip these: fused_below)
+        float seen = 0.f;
+        if (a.occ_single[i]) seen = edge_adagrad4(a.upd_table + s * a.emb_ld, a.upd_state + s * a.emb_ld, c0, c1, x[0], out_s, a.upd_lr, a.upd_eps);
+        else st4(a.gocc + i * D.d_ld, out_s);
+        if (a.occ_single[D.B + i]) seen = fmaxf(seen, edge_adagrad4(a.upd_table + t * a.emb_ld, a.upd_state + t * a.emb_ld, c0, c1, x[1], out_t, a.upd_lr, a.upd_eps));
+        else st4(a.gocc + (D.B + i) * D.d_ld, out_t);
+        // magnitude bound (marius_lp_desc.absmax): monotone, so the racy read filters almost every lane out once it has settled
+        if (a.upd_absmax && seen > *reinterpret_cast<volatile float*>(a.upd_absmax)) atomicMax(reinterpret_cast<unsigned int*>(a.upd_absmax), __float_as_uint(seen));
+        return;
+    }
     st4(a.gocc + i * D.d_ld, out_s);
     st4(a.gocc + (D.B + i) * D.d_ld, out_t);
 }
@@ -1258,6 +1297,15 @@ static bool lp_vec_ok(const marius_lp_desc* desc, const LpDims& D) {
 // it reads anyway (saves the 2 Bp d 4-byte store and its re-read).
 static bool flash_adj_elided(const marius_lp_desc* desc, const LpDims& D, const marius_lp_layout* L) {
     return L->flash && lp_vec_ok(desc, D) && !(desc->flags & MARIUS_LP_STORE_SCORES);
+}
+
+// Endpoint singletons take their Adagrad step inside the edge backward (marius_lp_desc.upd_*): only the 16-byte-row kernel does that, only when
+// training, and the state rows must be as aligned as the table's.
+extern "C" int marius_lp_fuses_endpoint_update(const marius_lp_desc* desc) {
+    if (!desc || !desc->upd_occ_single || !desc->upd_state || !(desc->flags & MARIUS_LP_TRAIN_ONLY) || (desc->flags & MARIUS_LP_KEEP_DADJ)) return 0;
+    LpDims D;
+    if (fill_dims(desc, D) != MARIUS_OK) return 0;
+    return (lp_vec_ok(desc, D) && (reinterpret_cast<uintptr_t>(desc->upd_state) & 7) == 0) ? 1 : 0;
 }
 
 extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_layout* L, void* workspace, marius_stream_t stream) {
@@ -1533,6 +1581,17 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
         ea.keep_dadj = (desc->flags & MARIUS_LP_KEEP_DADJ) ? 1 : 0;
     }
     ea.gocc = ga.gocc;
+    ea.occ_single = nullptr;
+    ea.upd_table = ea.upd_state = ea.upd_absmax = nullptr;
+    ea.upd_lr = ea.upd_eps = 0.f;
+    if (marius_lp_fuses_endpoint_update(desc)) {
+        ea.occ_single = desc->upd_occ_single;
+        ea.upd_table = const_cast<float*>(desc->emb);  // documented in marius_hip.h: with upd_* set, emb is the caller's (mutable) node table
+        ea.upd_state = desc->upd_state;
+        ea.upd_absmax = desc->upd_absmax;
+        ea.upd_lr = desc->upd_lr;
+        ea.upd_eps = desc->upd_eps;
+    }
     ea.grel[0] = (float*)(ws + L->grel[0]);
     ea.grel[1] = D.ndir == 2 ? (float*)(ws + L->grel[1]) : nullptr;
     ea.D = D;

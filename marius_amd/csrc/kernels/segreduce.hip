@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void seg_fixup_kernel(SegArgs a, Apply apply) 
 // row_plan [n]: per unique row u < U {table row id (int64 split in two ints), occurrence row of a singleton or -1, segment crosses a chunk boundary}
 __global__ __launch_bounds__(256) void seg_plan_kernel(const int32_t* __restrict__ perm, const int64_t* __restrict__ inverse, const int32_t* __restrict__ seg_offsets,
                                                        const int64_t* __restrict__ uniq, int64_t n, int4* __restrict__ pos_plan, int4* __restrict__ chunk_plan,
-                                                       int4* __restrict__ row_plan) {
+                                                       int4* __restrict__ row_plan, uint8_t* __restrict__ occ_single) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int64_t U = inverse[perm[n - 1]] + 1;
@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256) void seg_plan_kernel(const int32_t* __restrict
     const int u = (int)inverse[p];
     const int s0 = seg_offsets[u], s1 = seg_offsets[u + 1];
     pos_plan[k] = make_int4(p, u, (s0 >= k0 && s1 <= k1) ? 1 : 0, (s1 - s0 == 1) ? 1 : 0);
+    occ_single[p] = (s1 - s0 == 1) ? 1 : 0;  // the same flag by occurrence row (marius_lp_desc.upd_occ_single)
     if (k == k1 - 1) {  // last position of its chunk: does the chunk own a boundary-crossing segment (the one its last position belongs to)?
         const bool owner = (s0 >= k0) && (s1 > k1);
         chunk_plan[k / SEG_R] = make_int4(owner ? 1 : 0, u, (s0 != k0) ? 1 : 0, (int)((s1 - 1) / SEG_R));
@@ -339,6 +340,7 @@ struct AdagradRowsArgs {
     const int4* row_plan;
     int skip_crossing;  // 1: rows whose segment crosses a chunk boundary are updated by the fix-up workgroups of the same launch
     float* absmax;      // optional: track_absmax
+    int fused_below;    // > 0 (planned form): singleton rows whose occurrence row is < fused_below were updated by the rows' producer (marius_segment_update.fused_below)
 };
 
 template <int VEC>
@@ -375,6 +377,7 @@ __device__ __forceinline__ void adagrad_rows_body(const AdagradRowsArgs& A, int6
                 ids[k] = ((int64_t)q.y << 32) | (int64_t)(uint32_t)q.x;
                 if (occ && q.z >= 0) grow[k] = occ + (int64_t)q.z * occ_ld;
                 if (A.skip_crossing && q.w) ids[k] = -1;
+                if (q.z >= 0 && q.z < A.fused_below) ids[k] = -1;
             }
         } else {
             ids[k] = rows[k] < U ? uniq[rows[k]] : -1;
@@ -557,7 +560,12 @@ extern "C" int marius_segment_sum_rows_planned(const float* rows, int64_t rows_l
 static inline size_t plan_pos_bytes(int64_t n) { return ((size_t)(n > 0 ? n : 1) * sizeof(int4) + 255) / 256 * 256; }
 static inline size_t plan_chunk_bytes(int64_t n) { return ((size_t)cdiv(n > 0 ? n : 1, SEG_R) * sizeof(int4) + 255) / 256 * 256; }
 
-extern "C" size_t marius_segment_plan_bytes(int64_t n) { return 2 * plan_pos_bytes(n) + plan_chunk_bytes(n); }
+static inline size_t plan_occ_bytes(int64_t n) { return ((size_t)(n > 0 ? n : 1) + 255) / 256 * 256; }
+// [pos_plan | chunk_plan | row_plan | occ_single]
+extern "C" size_t marius_segment_plan_bytes(int64_t n) { return 2 * plan_pos_bytes(n) + plan_chunk_bytes(n) + plan_occ_bytes(n); }
+extern "C" const uint8_t* marius_segment_plan_occ_single(const void* plan, int64_t n) {
+    return plan ? (const uint8_t*)plan + 2 * plan_pos_bytes(n) + plan_chunk_bytes(n) : nullptr;
+}
 
 extern "C" int marius_segment_plan(const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, const int64_t* uniq_ids, int64_t n, void* plan,
                                    marius_stream_t stream) {
@@ -565,7 +573,8 @@ extern "C" int marius_segment_plan(const int32_t* perm, const int64_t* inverse, 
     if (n == 0) return MARIUS_OK;
     char* p = (char*)plan;
     seg_plan_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream)>>>(perm, inverse, seg_offsets, uniq_ids, n, (int4*)p,
-                                                                                        (int4*)(p + plan_pos_bytes(n)), (int4*)(p + plan_pos_bytes(n) + plan_chunk_bytes(n)));
+                                                                                        (int4*)(p + plan_pos_bytes(n)), (int4*)(p + plan_pos_bytes(n) + plan_chunk_bytes(n)),
+                                                                                        (uint8_t*)(p + 2 * plan_pos_bytes(n) + plan_chunk_bytes(n)));
     return check_launch("segment_plan");
 }
 
@@ -591,7 +600,7 @@ static int segment_sum_rows_impl(const float* rows, int64_t rows_ld, const int32
 
 static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, int64_t n,
                                         int32_t d, const int64_t* uniq_ids, float* table, float* state, int64_t table_ld, float lr, float eps, void* carry,
-                                        const void* plan, float* absmax, marius_stream_t stream);
+                                        const void* plan, float* absmax, marius_stream_t stream, int64_t fused_below = 0);
 
 extern "C" int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse,
                                               const int32_t* seg_offsets, int64_t n, int32_t d, const int64_t* uniq_ids,
@@ -666,7 +675,8 @@ extern "C" int marius_table_absmax_counted(const float* table, int64_t capacity,
 
 static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, const int32_t* perm, const int64_t* inverse, const int32_t* seg_offsets, int64_t n,
                                         int32_t d, const int64_t* uniq_ids, float* table, float* state, int64_t table_ld, float lr, float eps, void* carry,
-                                        const void* plan, float* absmax, marius_stream_t stream) {
+                                        const void* plan, float* absmax, marius_stream_t stream, int64_t fused_below) {
+    MARIUS_REQUIRE(fused_below <= 0 || plan, "segment_adagrad_scatter: fused_below needs a plan");
     SegArgs a;
     int rc = fill_args(a, rows, rows_ld, perm, inverse, seg_offsets, n, d, carry);
     if (rc) return rc;
@@ -699,7 +709,8 @@ static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, cons
     const int ty = 256 / tx;
     const unsigned row_blocks = (unsigned)cdiv(n, (int64_t)ty * MARIUS_ADAGRAD_UNR);
     const float* occ = skip ? rows : nullptr;
-    AdagradRowsArgs A{gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, tx, lr, eps, occ, rows_ld, seg_offsets, row_plan, 0, absmax};
+    MARIUS_REQUIRE(fused_below <= 0 || skip, "segment_adagrad_scatter: fused_below needs the singleton-skipping form (rows at least as aligned as the tables)");
+    AdagradRowsArgs A{gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, tx, lr, eps, occ, rows_ld, seg_offsets, row_plan, 0, absmax, (int)(fused_below > 0 ? fused_below : 0)};
     const int per = cdiv(d, 64 * vec);
     const char* fz = getenv("MARIUS_SEG_FUSED_FIXUP");  // 0: the fix-up as its own launch between reduction and update (A/B runs)
     if (plan && vec == vsum && vec == 4 && per <= 2 && !(fz && fz[0] == '0')) {
@@ -747,7 +758,7 @@ extern "C" int marius_segment_adagrad_scatter_group(const marius_segment_update*
         for (int j = 0; j < njobs; ++j) {
             const marius_segment_update& u = jobs[j];
             int rc = segment_adagrad_scatter_impl(u.rows, u.rows_ld, u.perm, u.inverse, u.seg_offsets, u.n, u.d, u.uniq_ids, u.table, u.state, u.table_ld, u.lr, u.eps,
-                                                  u.carry, u.plan, u.absmax, stream);
+                                                  u.carry, u.plan, u.absmax, stream, u.fused_below);
             if (rc) return rc;
         }
         return MARIUS_OK;
@@ -773,7 +784,8 @@ extern "C" int marius_segment_adagrad_scatter_group(const marius_segment_update*
         const int tx = adagrad_tx(vpr);
         const int ty = 256 / tx;
         const unsigned row_blocks = (unsigned)cdiv(u.n, (int64_t)ty * MARIUS_ADAGRAD_UNR);
-        J.A = AdagradRowsArgs{gsum, g_ld, u.perm, u.inverse, u.n, u.uniq_ids, u.table, u.state, u.table_ld, vpr, tx, u.lr, u.eps, u.rows, u.rows_ld, u.seg_offsets, row_plan, 1, u.absmax};
+        J.A = AdagradRowsArgs{gsum, g_ld, u.perm, u.inverse, u.n, u.uniq_ids, u.table, u.state, u.table_ld, vpr, tx, u.lr, u.eps, u.rows, u.rows_ld, u.seg_offsets, row_plan, 1, u.absmax,
+                              (int)(u.fused_below > 0 ? u.fused_below : 0)};
         J.ada = ApplyAdagrad{u.uniq_ids, u.table, u.state, u.table_ld, u.lr, u.eps, u.absmax};
         J.nfix = (unsigned)cdiv(cdiv(u.n, SEG_R), 4);
         J.red0 = red;

@@ -18,7 +18,7 @@ REDUCE_SUM, REDUCE_MEAN = 0, 1
 LOSS = {"SOFTMAX_CE": 0, "RANKING": 1, "CROSS_ENTROPY": 2, "BCE_AFTER_SIGMOID": 3, "BCE_WITH_LOGITS": 4, "MSE": 5, "SOFTPLUS": 6}
 LP_TRAIN_ONLY, LP_STORE_SCORES, LP_KEEP_DADJ = 1, 2, 4   # marius_lp_desc.flags
 MT_STATE_WORDS = 625
-ABI_VERSION = 7  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
+ABI_VERSION = 8  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
 
 
 class MariusHipError(RuntimeError):
@@ -35,6 +35,7 @@ class LpDesc(C.Structure):
         ("dst_filter", C.c_void_p), ("n_dst_filter", C.c_int64), ("src_filter", C.c_void_p), ("n_src_filter", C.c_int64),
         ("loss", C.c_int32), ("margin", C.c_float), ("flags", C.c_int32), ("reserved_", C.c_int32),
         ("absmax", C.c_void_p), ("absmax_rel", C.c_void_p),
+        ("upd_occ_single", C.c_void_p), ("upd_state", C.c_void_p), ("upd_absmax", C.c_void_p), ("upd_lr", C.c_float), ("upd_eps", C.c_float),
     ]
 
 
@@ -97,6 +98,8 @@ SIGNATURES = {
     "marius_segment_adagrad_scatter": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp]),
     "marius_segment_sum_rows_planned": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
     "marius_segment_plan_bytes": (C.c_size_t, [_i64]),
+    "marius_segment_plan_occ_single": (C.c_void_p, [_vp, _i64]),
+    "marius_lp_fuses_endpoint_update": (C.c_int, [_vp]),
     "marius_segment_plan": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "marius_segment_adagrad_scatter_planned": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp]),
     "marius_segment_adagrad_scatter_tracked": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
@@ -351,6 +354,17 @@ class LpWorkspace:
         self._keep = (emb, edges, dst_neg, src_neg, rel, inv_rel, dst_filter, src_filter)
         return self
 
+    def fuse_endpoint_update(self, occ_single=None, state=None, lr=0.0, eps=1e-10, absmax=None):
+        """marius_lp_desc.upd_*: the edge backward takes the Adagrad step of endpoint occurrences whose node occurs once (emb must be the
+        table itself); returns whether this library build honours it for the bound shapes.  No arguments: off."""
+        d = self.desc
+        d.upd_occ_single = occ_single.data_ptr() if occ_single is not None else None
+        d.upd_state = state.data_ptr() if state is not None else None
+        d.upd_absmax = absmax.data_ptr() if absmax is not None else None
+        d.upd_lr, d.upd_eps = lr, eps
+        self._upd = (occ_single, state, absmax)
+        return bool(lib().marius_lp_fuses_endpoint_update(C.byref(d)))
+
     def forward(self):
         check(lib().marius_lp_forward(C.byref(self.desc), C.byref(self.layout), ptr(self.ws), stream_ptr()), "lp_forward")
 
@@ -437,6 +451,13 @@ def segment_plan(um, n):
     return plan
 
 
+def segment_plan_occ_single(plan, n):
+    """uint8[n] view of the per-occurrence singleton flags inside a plan (marius_lp_desc.upd_occ_single)"""
+    p = lib().marius_segment_plan_occ_single(ptr(plan), n)
+    off = p - plan.data_ptr()
+    return plan[off:off + n]
+
+
 def table_absmax(*tables, out=None, count=None):
     """device float[1]: max |x| over the given [rows, d] tables (marius_table_absmax), max'ed into `out` when given; count: device int64
     holding the number of valid rows of a capacity-sized buffer (marius_table_absmax_counted)"""
@@ -473,7 +494,7 @@ class SegmentUpdate(C.Structure):
     """marius_segment_update (include/marius_hip.h): one table's job of marius_segment_adagrad_scatter_group"""
     _fields_ = [("rows", C.c_void_p), ("rows_ld", C.c_int64), ("perm", C.c_void_p), ("inverse", C.c_void_p), ("seg_offsets", C.c_void_p), ("n", C.c_int64),
                 ("d", C.c_int32), ("uniq_ids", C.c_void_p), ("table", C.c_void_p), ("state", C.c_void_p), ("table_ld", C.c_int64), ("lr", C.c_float),
-                ("eps", C.c_float), ("carry", C.c_void_p), ("plan", C.c_void_p), ("absmax", C.c_void_p)]
+                ("eps", C.c_float), ("carry", C.c_void_p), ("plan", C.c_void_p), ("absmax", C.c_void_p), ("fused_below", C.c_int64)]
 
 
 def segment_adagrad_scatter_group(jobs):
@@ -491,6 +512,7 @@ def segment_adagrad_scatter_group(jobs):
         a.rows, a.rows_ld, a.perm, a.inverse, a.seg_offsets, a.n, a.d = ptr(rows), rows.stride(0), ptr(um.perm), ptr(um.inverse), ptr(um.seg), n, d
         a.uniq_ids, a.table, a.state, a.table_ld = ptr(um.uniq), ptr(j["table"]), ptr(j["state"]), j["table"].stride(0)
         a.lr, a.eps, a.carry, a.plan, a.absmax = j["lr"], j.get("eps", 1e-10), ptr(carry), ptr(j.get("plan")), ptr(j.get("absmax"))
+        a.fused_below = int(j.get("fused_below", 0))
     check(lib().marius_segment_adagrad_scatter_group(C.cast(arr, C.c_void_p), len(jobs), stream_ptr()), "segment_adagrad_scatter_group")
 
 

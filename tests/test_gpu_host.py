@@ -153,6 +153,30 @@ def test_trainer_epoch_matches_cpu_reference_path(M, dev, decoder, f, fused, d):
         assert bool(model.last_step_flash) == (f == 0.0)   # a DEG filter on wide rows must NOT take the chunked launches (they would ignore it)
 
 
+@pytest.mark.parametrize("decoder,d,num_nodes", [("COMPLEX", 100, 4000), ("DISTMULT", 32, 4000), ("TRANSE", 20, 4000), ("COMPLEX", 100, 300)])
+def test_endpoint_update_inside_the_edge_backward_is_bit_identical(M, dev, decoder, d, num_nodes):
+    """Round 4: endpoint occurrences whose node occurs once in the batch take their Adagrad step inside the edge backward (marius_lp_desc.upd_*,
+    the row and its whole gradient are in the half-wave's registers) instead of going through gocc and the segment update.  Same arithmetic,
+    so two epochs must leave the table, the Adagrad state, the relation tables and the tracked magnitude bound bit for bit what the unfused
+    order leaves — with many singletons (4000 nodes) and with almost none (300 nodes: nearly every node repeats)."""
+    R, B, C, N, E, seed = 11, 250, 5, 40, 1000, 5
+    out = []
+    for fuse in (True, False):
+        table, edges_all, emb, state, loader, model = _setup(M, dev, decoder, num_nodes, R, d, B, C, N, E, seed)
+        model.fuse_endpoint_update = fuse
+        trainer = M.SynchronousTrainer(loader, model)
+        trainer.train(2)
+        torch.cuda.synchronize()
+        assert model.last_step_fused_below == (2 * B if fuse else 0)  # the path under test ran (and only when asked)
+        out.append((emb.data.clone(), state.data.clone(), model.decoder.relations.clone(), model.decoder.inverse_relations.clone(),
+                    model.range_state.clone() if model.ranges_valid else None))
+    for a, b in zip(out[0][:4], out[1][:4]):
+        assert torch.equal(a, b)
+    if out[0][4] is not None:
+        assert torch.equal(out[0][4], out[1][4])
+    assert float(out[0][1].sum()) > 0  # something was trained
+
+
 def test_trainer_tracks_table_magnitude_through_a_thousandfold_growth(M, dev):
     """fp16 operand records are packed with a power-of-two scale derived from a bound on the table's magnitude.  A freshly initialised table
     (+-1.3e-4, Freebase86m's glorot limit) whose rows jump to +-0.1 the first time Adagrad touches them — a factor 1000 inside one step — is the
