@@ -90,7 +90,7 @@ def event_pair_overhead_ms(k=100):
 
 def pmc_traffic_file(flash):
     """newest committed PMC traffic summary of the default bench command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.py)"""
-    names = ["r3_pmc_traffic.json", "r2_pmc_traffic.json"] if flash else ["r1h_pmc_traffic.json"]
+    names = ["r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"] if flash else ["r1h_pmc_traffic.json"]
     for n in names:
         if os.path.exists(os.path.join(ROOT, "profiles", n)):
             return os.path.join(ROOT, "profiles", n)
