@@ -451,6 +451,7 @@ def main():
         "segment_adagrad_scatter": ("hbm", L * d * 4.0 + U * d * 4.0 * 4 + (2.0 * B * d * 4.0 if R > 1 else 0.0)),
         "lp_lse": ("hbm", 2.0 * Bp * (math.ceil(math.ceil(N / 64) / 4) * 8.0 + 12.0)),  # fused SoftmaxCE: only the per-group partials are re-read
         "lp_prep": ("hbm", 2.0 * Bp * d * 4.0 * 4),
+        "lp_pack": ("hbm", ndir * C * N * (d * 4.0 * 2 + 4.0 * 16 * math.ceil(d / 16) + 16)),  # negatives: rows read, gocc rows zeroed, operand records written
         "lp_edge_bwd": ("hbm", 2.0 * B * d * 4.0 * 6),
         "sort_unique": ("hbm", L * (8.0 + 4.0) * 2 * 4),
         "mt19937_fill": ("hbm", 2.0 * C * N * 4.0 * 2),

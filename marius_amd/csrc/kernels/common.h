@@ -38,7 +38,7 @@ constexpr int WAVE = 64;
 
 // optional HIP-event profiler (see error.hip): PROF_SCOPE(id, stream) { launch; }
 enum ProfId { PROF_LP_SCORES = 0, PROF_LP_GRAD_ADJ, PROF_LP_GRAD_NEG, PROF_LP_PREP, PROF_LP_LSE, PROF_LP_EDGE_BWD, PROF_GATHER,
-              PROF_SEG_ADAGRAD, PROF_SORT_UNIQUE, PROF_MT_FILL, PROF_COUNT };
+              PROF_SEG_ADAGRAD, PROF_SORT_UNIQUE, PROF_MT_FILL, PROF_LP_PACK, PROF_COUNT };
 struct ProfMark {
     int id;
     hipEvent_t a, b;

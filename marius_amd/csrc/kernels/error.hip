@@ -29,7 +29,7 @@ int launch_debug(const char* what) {
 
 // ---- HIP-event profiler: events are recorded on the launch stream around selected kernels (bench.py roofline) ----
 static const char* kProfNames[PROF_COUNT] = {"lp_scores", "lp_grad_adj", "lp_grad_neg", "lp_prep", "lp_lse", "lp_edge_bwd",
-                                             "gather_rows", "segment_adagrad_scatter", "sort_unique", "mt19937_fill"};
+                                             "gather_rows", "segment_adagrad_scatter", "sort_unique", "mt19937_fill", "lp_pack"};
 static int g_prof_on = 0;
 static std::mutex g_prof_mu;
 struct ProfRec {

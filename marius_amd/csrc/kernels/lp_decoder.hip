@@ -195,54 +195,31 @@ __device__ __forceinline__ void relop4(int relop, bool has_rel, const float (&e)
     }
 }
 
-__global__ __launch_bounds__(256) void lp_prep2_kernel(PrepArgs a) {
-#pragma clang fp contract(off)
-    const LpDims& D = a.D;
-    const int l = threadIdx.x & 31;
-    const int64_t i = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
-    if (i >= D.Bp) {
-        // flash path: blocks past the edge rows zero the records that pad every chunk block to a multiple of 32 rows
-        if (a.frec) {
-            const int64_t r = i - D.Bp;  // pad record index over (dir, chunk, x in [Bc, XR))
-            const int npad = a.fXR - D.Bc;
-            if (npad > 0 && r < (int64_t)D.ndir * D.C * npad) {
-                const int64_t cd = r / npad;
-                const int x = D.Bc + (int)(r - cd * npad);
-                const int xp = 4 * (x & 3) + ((x >> 2) & 3) + (x & ~15);
-                const int P = 4 * a.fKP + 16;
-                char* rec = a.frec + (cd * a.fXR + xp) * (int64_t)P;
-                for (int o = 16 * l; o < P; o += 16 * 32) *reinterpret_cast<float4*>(rec + o) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-        return;
-    }
-    const int h2 = D.d / 2;
-    const bool act = 4 * l < D.d;          // lanes that own elements
-    const int c0 = 2 * l, c1 = h2 + 2 * l;  // first-half pair, second-half pair
-    if (i >= D.B) {  // pad_and_reshape zero rows; F.pad zero positives
-        for (int dir = 0; dir < D.ndir; ++dir) {
-            if (act && a.adj) {
-                float* adj = a.adj + ((int64_t)dir * D.Bp + i) * D.d_ld;
-                *reinterpret_cast<float2*>(adj + c0) = make_float2(0.f, 0.f);
-                *reinterpret_cast<float2*>(adj + c1) = make_float2(0.f, 0.f);
-            }
-            if (a.frec) {
-                const float zz[4] = {0.f, 0.f, 0.f, 0.f};
-                prep_flash_store(a, dir, i, l, c0, c1, zz, act);
-            }
-            if (l == 0) {
-                a.pos[(int64_t)dir * D.Bp + i] = 0.f;
-                if (a.x2) a.x2[(int64_t)dir * D.Bp + i] = 0.f;
-            }
-        }
-        return;
-    }
-    const int64_t* ed = a.edges + i * D.edge_cols;
-    const int64_t s = ed[0], t = ed[D.edge_cols - 1];
-    const float* es = a.emb + s * a.emb_ld;
-    const float* et = a.emb + t * a.emb_ld;
+// One edge row of the prep: its three phases, so that a half-wave can walk two rows with the loads of both in flight (lp_prep2_kernel<2>).
+#ifndef MARIUS_PREP_EDGES_PER_HALF_WAVE
+#define MARIUS_PREP_EDGES_PER_HALF_WAVE 2
+#endif
+struct Prep2Row {
+    int64_t s, t, e1;
     float x[2][4];  // [0] = src row, [1] = dst row; elements {c0, c0+1, c1, c1+1}
     float r[2][4];
+};
+__device__ __forceinline__ void prep2_ids(const PrepArgs& a, int64_t i, Prep2Row& R) {
+    const LpDims& D = a.D;
+    const int64_t* ed = a.edges + i * D.edge_cols;
+    R.s = ed[0];
+    R.t = ed[D.edge_cols - 1];
+    R.e1 = D.edge_cols == 3 ? ed[1] : 0;
+}
+__device__ __forceinline__ void prep2_rows(const PrepArgs& a, int l, Prep2Row& R) {
+    const LpDims& D = a.D;
+    const int h2 = D.d / 2;
+    const bool act = 4 * l < D.d;
+    const int c0 = 2 * l, c1 = h2 + 2 * l;
+    const float* es = a.emb + R.s * a.emb_ld;
+    const float* et = a.emb + R.t * a.emb_ld;
+    float (&x)[2][4] = R.x;
+    float (&r)[2][4] = R.r;
     const bool has_rel0 = (D.edge_cols == 3) && a.rel[0], has_rel1 = (D.edge_cols == 3) && a.rel[1];
     if (act) {
         const float2 a0 = *reinterpret_cast<const float2*>(es + c0), a1 = *reinterpret_cast<const float2*>(es + c1);
@@ -253,7 +230,7 @@ __global__ __launch_bounds__(256) void lp_prep2_kernel(PrepArgs a) {
         for (int dir = 0; dir < 2; ++dir) {
             const bool hr = dir == 0 ? has_rel0 : has_rel1;
             if (hr && dir < D.ndir) {
-                const float* rr = a.rel[dir] + ed[1] * a.rel_ld;
+                const float* rr = a.rel[dir] + R.e1 * a.rel_ld;
                 const float2 q0 = *reinterpret_cast<const float2*>(rr + c0), q1 = *reinterpret_cast<const float2*>(rr + c1);
                 r[dir][0] = q0.x; r[dir][1] = q0.y; r[dir][2] = q1.x; r[dir][3] = q1.y;
             } else {
@@ -264,6 +241,16 @@ __global__ __launch_bounds__(256) void lp_prep2_kernel(PrepArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) x[0][k] = x[1][k] = r[0][k] = r[1][k] = 0.f;
     }
+}
+__device__ __forceinline__ void prep2_finish(const PrepArgs& a, int64_t i, int l, const Prep2Row& R) {
+#pragma clang fp contract(off)
+    const LpDims& D = a.D;
+    const int h2 = D.d / 2;
+    const bool act = 4 * l < D.d;
+    const int c0 = 2 * l, c1 = h2 + 2 * l;
+    const float (&x)[2][4] = R.x;
+    const float (&r)[2][4] = R.r;
+    const bool has_rel0 = (D.edge_cols == 3) && a.rel[0], has_rel1 = (D.edge_cols == 3) && a.rel[1];
 #pragma unroll
     for (int dir = 0; dir < 2; ++dir) {
         if (dir >= D.ndir) break;
@@ -303,6 +290,80 @@ __global__ __launch_bounds__(256) void lp_prep2_kernel(PrepArgs a) {
         if (l == 0) {
             a.pos[(int64_t)dir * D.Bp + i] = acc;
             if (a.x2) a.x2[(int64_t)dir * D.Bp + i] = nrm;
+        }
+    }
+}
+// rows past the edges: the zero rows of pad_and_reshape and the records that pad every chunk block to a multiple of 32 rows
+__device__ __forceinline__ void prep2_pad(const PrepArgs& a, int64_t i, int l) {
+#pragma clang fp contract(off)
+    const LpDims& D = a.D;
+    if (i >= D.Bp) {
+        // flash path: blocks past the edge rows zero the records that pad every chunk block to a multiple of 32 rows
+        if (a.frec) {
+            const int64_t r = i - D.Bp;  // pad record index over (dir, chunk, x in [Bc, XR))
+            const int npad = a.fXR - D.Bc;
+            if (npad > 0 && r < (int64_t)D.ndir * D.C * npad) {
+                const int64_t cd = r / npad;
+                const int x = D.Bc + (int)(r - cd * npad);
+                const int xp = 4 * (x & 3) + ((x >> 2) & 3) + (x & ~15);
+                const int P = 4 * a.fKP + 16;
+                char* rec = a.frec + (cd * a.fXR + xp) * (int64_t)P;
+                for (int o = 16 * l; o < P; o += 16 * 32) *reinterpret_cast<float4*>(rec + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        return;
+    }
+    const int h2 = D.d / 2;
+    const bool act = 4 * l < D.d;          // lanes that own elements
+    const int c0 = 2 * l, c1 = h2 + 2 * l;  // first-half pair, second-half pair
+    if (i >= D.B) {  // pad_and_reshape zero rows; F.pad zero positives
+        for (int dir = 0; dir < D.ndir; ++dir) {
+            if (act && a.adj) {
+                float* adj = a.adj + ((int64_t)dir * D.Bp + i) * D.d_ld;
+                *reinterpret_cast<float2*>(adj + c0) = make_float2(0.f, 0.f);
+                *reinterpret_cast<float2*>(adj + c1) = make_float2(0.f, 0.f);
+            }
+            if (a.frec) {
+                const float zz[4] = {0.f, 0.f, 0.f, 0.f};
+                prep_flash_store(a, dir, i, l, c0, c1, zz, act);
+            }
+            if (l == 0) {
+                a.pos[(int64_t)dir * D.Bp + i] = 0.f;
+                if (a.x2) a.x2[(int64_t)dir * D.Bp + i] = 0.f;
+            }
+        }
+        return;
+    }
+}
+// EP edge rows per half-wave: the row loads of EP edges in flight behind one wait (the dependent chain edge ids -> rows -> stores is what a
+// half-wave spends its time on).  Same-box A/B at the bench shape: 1 -> 43.2 us, 2 -> 39.8 us (MARIUS_PREP_EDGES_PER_HALF_WAVE)
+template <int EP>
+__global__ __launch_bounds__(256) void lp_prep2_kernel(PrepArgs a) {
+    const LpDims& D = a.D;
+    const int l = threadIdx.x & 31;
+    const int64_t i0 = (int64_t)blockIdx.x * (8 * EP) + (threadIdx.x >> 5);
+    if constexpr (EP > 1) {
+        if (i0 + 8 * (EP - 1) < D.B) {  // all of them are edge rows: ids of all, rows of all, then the arithmetic and the stores
+            Prep2Row R[EP];
+#pragma unroll
+            for (int e = 0; e < EP; ++e) prep2_ids(a, i0 + 8 * e, R[e]);
+#pragma unroll
+            for (int e = 0; e < EP; ++e) prep2_rows(a, l, R[e]);
+#pragma unroll
+            for (int e = 0; e < EP; ++e) prep2_finish(a, i0 + 8 * e, l, R[e]);
+            return;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+        const int64_t i = i0 + 8 * e;
+        if (i >= D.B) {
+            prep2_pad(a, i, l);
+        } else {
+            Prep2Row R;
+            prep2_ids(a, i, R);
+            prep2_rows(a, l, R);
+            prep2_finish(a, i, l, R);
         }
     }
 }
@@ -1352,7 +1413,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
             flash_fused_prep = true;
         }
         if (vec_ok)
-            lp_prep2_kernel<<<dim3((unsigned)cdiv(prep_rows, 8)), dim3(256), 0, st>>>(pa);
+            lp_prep2_kernel<MARIUS_PREP_EDGES_PER_HALF_WAVE><<<dim3((unsigned)cdiv(prep_rows, 8 * MARIUS_PREP_EDGES_PER_HALF_WAVE)), dim3(256), 0, st>>>(pa);
         else
             lp_prep_kernel<<<dim3((unsigned)cdiv(D.Bp * D.ndir, 4)), dim3(256), 0, st>>>(pa);
     }

@@ -1195,6 +1195,7 @@ int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj,
             flash_pack_adj_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(adj, D.d_ld, D.Bp, D.Bc, D.C, D.ndir, kc, KP, XR, adjrec + c * adjset, rg, c * kc);
         }
         const int64_t n = (int64_t)D.ndir * D.C * NR * ppr;
+        ProfScope ps(PROF_LP_PACK, st);
         flash_pack_neg_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(desc->emb, desc->emb_ld, desc->dst_neg, desc->src_neg, D.N, D.C, D.ndir,
                                                                                  kc, KP, NR, row_vec_width(desc->emb, desc->emb_ld, 4), negrec + c * negset, gocc,
                                                                                  D.d_ld, negocc_off[0], negocc_off[1], rg, c * kc);
