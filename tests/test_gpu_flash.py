@@ -45,7 +45,7 @@ def make_batch(decoder, B, C, N, d, U, R, seed, scale=0.5, zipf=False):
     return emb, edges, dst_neg, src_neg, rel_t, inv_t
 
 
-def run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, store=True, reduction="sum", dst_filter=None, src_filter=None, f16=False):
+def run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, store=True, reduction="sum", dst_filter=None, src_filter=None, f16=False, poison=False):
     relop, cmp = DEC[decoder]
     B, (C, N), d = edges.size(0), dst_neg.shape, emb.size(1)
     flags = H.LP_TRAIN_ONLY | (H.LP_STORE_SCORES if store else 0)
@@ -58,6 +58,8 @@ def run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inver
         absmax = torch.cat([H.table_absmax(t(emb)), H.table_absmax(*tabs)])
         assert float(absmax[0]) == float(emb.abs().max()) and float(absmax[1]) == float(torch.stack([x.abs().max() for x in tabs]).max().cpu())
     W.bind(t(emb), t(edges), t(dst_neg), t(src_neg), t(rel), t(inv) if use_inverse else None, t(dst_filter), t(src_filter), absmax=absmax)
+    if poison:  # every occurrence gradient row must be WRITTEN by the step (stored, or zeroed before two workgroups add to it): nothing may survive
+        W.gocc().fill_(float("nan"))
     W.forward()
     W.loss()
     W.backward()
@@ -370,7 +372,7 @@ def test_flash_arithmetic_against_the_reference_fp32_evaluation(H, dev, decoder,
     assert pairs["loss"]["device_max"] <= 1e-6
 
 
-@pytest.mark.parametrize("nwg", ["1", "2", "3", "5", "8", "16", "24"])
+@pytest.mark.parametrize("nwg", ["1", "2", "3", "5", "7", "8", "11", "16", "24"])
 def test_flash_split_tiles_are_deterministic_and_consistent(H, dev, monkeypatch, nwg):
     """Tiles shared by two workgroups (partial row statistics, two-contributor float atomics onto a zeroed output) are
     bit-reproducible run to run — a + b == b + a — and agree with the unsplit distribution up to the association of the softmax sum."""
@@ -378,7 +380,8 @@ def test_flash_split_tiles_are_deterministic_and_consistent(H, dev, monkeypatch,
     emb, edges, dst_neg, src_neg, rel, inv = make_batch("COMPLEX", B, C, N, d, U, R, seed=3)
 
     def run():
-        W = run_flash(H, dev, "COMPLEX", emb, edges, dst_neg, src_neg, rel, inv, True, store=False)
+        # (poisoned gocc: every occurrence row must be written by the step itself)
+        W = run_flash(H, dev, "COMPLEX", emb, edges, dst_neg, src_neg, rel, inv, True, store=False, poison=True)
         return [t.clone() for t in (W.lse(0), W.lse(1), W.gocc(), W.dadj(0), W.dadj(1), W.loss_values())]
 
     monkeypatch.setenv("MARIUS_FLASH_NWG", "512")   # clipped to the number of tiles: every tile has one owner
