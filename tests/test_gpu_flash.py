@@ -382,17 +382,19 @@ def test_flash_split_tiles_are_deterministic_and_consistent(H, dev, monkeypatch,
     def run():
         # (poisoned gocc: every occurrence row must be written by the step itself)
         W = run_flash(H, dev, "COMPLEX", emb, edges, dst_neg, src_neg, rel, inv, True, store=False, poison=True)
-        return [t.clone() for t in (W.lse(0), W.lse(1), W.gocc(), W.dadj(0), W.dadj(1), W.loss_values())]
+        # (dadj: the B edge rows only — rows B .. Bp pad the last chunk, the edge backward never combines their partials)
+        return [t.clone() for t in (W.lse(0), W.lse(1), W.gocc(), W.dadj(0)[:B], W.dadj(1)[:B], W.loss_values())]
 
-    monkeypatch.setenv("MARIUS_FLASH_NWG", "512")   # clipped to the number of tiles: every tile has one owner
+    monkeypatch.setenv("MARIUS_FLASH_NWG", "512")   # clipped to the number of tiles (and to a multiple of 8): the reference distribution
     ref = run()
     monkeypatch.setenv("MARIUS_FLASH_NWG", nwg)
     got = [run() for _ in range(3)]
     for other in got[1:]:
         for a, b in zip(got[0], other):
             assert torch.equal(a, b)
-    for a, b in zip(ref, got[0]):
-        assert torch.allclose(a, b, rtol=2e-5, atol=2e-6 * float(a.abs().max()))
+    # (dL/dadj is a sum of ~N products V y whose grouping follows the split: 3e-5 of the largest entry; everything else 2e-6)
+    for k, (a, b) in enumerate(zip(ref, got[0])):
+        assert torch.allclose(a, b, rtol=2e-5, atol=(3e-5 if k in (3, 4) else 2e-6) * float(a.abs().max())), k
 
 
 def test_flash_mean_reduction(H, dev):
