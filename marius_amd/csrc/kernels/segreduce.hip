@@ -17,12 +17,13 @@ namespace marius {
 constexpr int SEG_R = 32;      // sorted positions per wave
 // (tools/build_variant.py + tools/ab_variants.sh time variants of these constants on one box.  Round 4, Freebase86m step: 8 row loads in flight per
 // lane 151 us for the reduce + update pair, 4 -> 144, 2 -> 141, 1 -> 141, 16 -> 167: most segments are singletons that are skipped, and the batch's
-// registers cost occupancy; Adagrad rows per thread 8 -> 200 us, 4 / 2 / 1 equal once a row's pieces map one to one onto lanes)
+// registers cost occupancy; Adagrad rows per thread 8 -> 200 us, 4 / 2 / 1 equal once a row's pieces map one to one onto lanes; with the endpoint
+// singletons updated by the edge backward (a third of the row slots skipped) 4 -> 116, 3 -> 113, 2 -> 112.5, 1 -> 119 us)
 #ifndef MARIUS_SEG_BATCH
 #define MARIUS_SEG_BATCH 2
 #endif
 #ifndef MARIUS_ADAGRAD_UNR
-#define MARIUS_ADAGRAD_UNR 4
+#define MARIUS_ADAGRAD_UNR 2
 #endif
 constexpr int SEG_BATCH = MARIUS_SEG_BATCH;  // row loads in flight per lane
 
