@@ -4,11 +4,12 @@ txt = open(sys.argv[1]).read()
 show_all = len(sys.argv) > 2
 for b in txt.split('Function Name: ')[1:]:
     name = b.split('\n')[0]
-    m = re.search(r'flash_kernelILi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELi(\d)', name)
+    m = re.search(r'flash_kernelILi(\d+)ELi(\d+)ELb(\d)ELb(\d)E(?:Li(\d)E)?', name)  # <KS, MODE, STORE_S, F16[, an experiment's extra parameter]>
     if not m:
         continue
-    ks, mode, st, f16, xs = map(int, m.groups())
-    if not show_all and xs != 2 and not (ks == 7 and mode in (2, 3)):
+    ks, mode, st, f16 = map(int, m.groups()[:4])
+    xs = int(m.group(5)) if m.group(5) else 1
+    if not show_all and xs == 1 and not (ks == 7 and mode in (2, 3)):
         continue
     def g(k):
         return re.search(k + r': (\d+)', b).group(1)
