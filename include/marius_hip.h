@@ -47,11 +47,16 @@ enum {
  * layout.dadj doubled on the flash path; 5: marius_lp_desc.absmax, marius_table_absmax, the *_tracked update entry points; 6:
  * marius_segment_update, marius_segment_adagrad_scatter_group, marius_hip_struct_bytes(2); 7: marius_lp_desc.absmax_rel,
  * marius_table_absmax_counted; marius_lp_layout lost the operand planes of the removed bf16x6 kernels and the stream-K partials; 8:
- * marius_lp_desc.upd_*, marius_segment_update.fused_below, marius_lp_fuses_endpoint_update, marius_segment_plan_occ_single).  Every binder
+ * marius_lp_desc.upd_*, marius_segment_update.fused_below, marius_lp_fuses_endpoint_update, marius_segment_plan_occ_single; 9: the
+ * fixed-capacity exchange entry points marius_a2a_capacity / marius_a2a_rows_post / marius_a2a_rows_wait, negative ids = padding slots in
+ * marius_merge_unique_runs / marius_segment_plan).  Every binder
  * compares the value it was built against with what the loaded library returns and refuses to run on a mismatch: marius_amd/hip.py lib(),
  * the host module's init (bindings.cpp), and the plug-in recipe of INTEGRATION.md. */
-#define MARIUS_HIP_ABI_VERSION 8
+#define MARIUS_HIP_ABI_VERSION 9
 int marius_hip_abi_version(void);
+/* The MARIUS_* environment switches of the kernel library (test / A-B selectors; a production run sets none) are read ONCE, when the
+ * library is loaded.  A process that changes one afterwards (the parity tests do, to reach a non-default kernel) calls this to re-read them. */
+int marius_config_reload(void);
 /* sizeof(marius_lp_desc) / sizeof(marius_lp_layout) as the library was compiled: a second line of defence for ctypes mirrors */
 int marius_hip_struct_bytes(int which /* 0: marius_lp_desc, 1: marius_lp_layout, 2: marius_segment_update */);
 const char* marius_hip_last_error(void);
@@ -181,7 +186,9 @@ int marius_sort_unique(const int64_t* ids, int64_t n, int32_t key_bits, int64_t*
 /* Same outputs as marius_sort_unique for an input that is the concatenation of num_runs (<= 64) strictly ascending runs
  * (run q = ids[run_offsets_host[q] .. run_offsets_host[q+1]); the owner side of the sharded exchange receives one such run per sender):
  * the sorted position of every element comes from num_runs - 1 binary searches instead of radix passes; ties keep input order (stable).
- * run_offsets_host is a HOST array of num_runs + 1 offsets.  Workspace as for marius_sort_unique. */
+ * run_offsets_host is a HOST array of num_runs + 1 offsets.  Workspace as for marius_sort_unique.
+ * A run may open with any number of -1 entries (the unused slots of a fixed-capacity exchange block, marius_a2a_rows_post): they merge
+ * into one leading segment with unique id -1, which marius_segment_plan marks dead. */
 int marius_merge_unique_runs(const int64_t* ids, int64_t n, const int64_t* run_offsets_host, int32_t num_runs, int64_t* uniq, int64_t* inverse,
                              int32_t* perm, int32_t* seg_offsets, int64_t* num_unique_dev, void* workspace, size_t workspace_bytes,
                              marius_stream_t stream);
@@ -191,6 +198,29 @@ int marius_merge_unique_runs(const int64_t* ids, int64_t n, const int64_t* run_o
  * id >= q * shard_rows, q = 0..num_shards (out[num_shards] = U).  These are the all-to-all split points. */
 int marius_owner_offsets(const int64_t* uniq, const int64_t* num_unique_dev, int64_t shard_rows, int32_t num_shards, int64_t* out,
                          marius_stream_t stream);
+
+/* ---- fixed-capacity row exchange of the sharded node table (SURVEY.md 8(b) a2a_rows_{post,wait}; replaces the host-memory embeddings +
+ * per-device replicas of src/cpp/src/pipeline/pipeline_gpu.cpp:23-80 and the rows that Batch::to / embeddingsToHost move over PCIe,
+ * src/cpp/src/data/batch.cpp:21-60,81-103).  The transport between the two halves is ONE equal-split all-to-all per payload, issued by the
+ * host on its communicator (ncclAllToAll(send, recv, cap * width, type, comm, stream) / c10d alltoall_base with empty split vectors): every
+ * (requester, owner) pair owns `cap` slots, so no split size — and no device -> host read-back — is needed.  See INTEGRATION.md.
+ *
+ * marius_a2a_capacity: the planned maximum of rows one requester asks of one owner — max_rows (the batch's id capacity 2 B + 2 C N) for
+ * world 1, else ceil(slack * max_rows / world) rounded up to 256 (slack >= 1; ids are spread evenly over the owners when node ids are
+ * shuffled at preprocessing, the reference's default). */
+int64_t marius_a2a_capacity(int64_t max_rows, int32_t world, double slack);
+/* Requester, before the id all-to-all.  uniq: the batch's ascending unique global ids (map_tensors), owner_offsets[world + 1]: their split
+ * points by owner (marius_owner_offsets).  Writes req_send[world * cap]: block q = (cap - cnt_q) entries of -1 followed by the cnt_q LOCAL
+ * row ids (global - q * shard_rows) asked of owner q, ascending; place[u] = slot of unique index u in that layout (the row of u in the
+ * row payload the owners send back, and the row its gradient is written to on the way out: marius_segment_sum_rows_planned's out_rows);
+ * *overflow_flag |= 1 if some cnt_q > cap (the caller must not use the batch: raise the slack). */
+int marius_a2a_rows_post(const int64_t* uniq, const int64_t* owner_offsets, int64_t shard_rows, int32_t world, int64_t cap, int64_t* req_send,
+                         int64_t* place, int32_t* overflow_flag, marius_stream_t stream);
+/* Requester, after the row all-to-all: emb[u, 0:d] = rows_recv[place[u], 0:d] for u < *num_unique_dev (batch order: what Batch::
+ * node_embeddings_ holds), and *absmax = max(*absmax, max |x| of the moved rows) when absmax != NULL (marius_lp_desc.absmax of the batch:
+ * the rows came from every rank's shard, the requester bounds what it received).  capacity = rows of emb. */
+int marius_a2a_rows_wait(const float* rows_recv, int64_t recv_ld, const int64_t* place, const int64_t* num_unique_dev, int64_t capacity, int32_t d,
+                         float* emb, int64_t emb_ld, float* absmax, marius_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ decoder */
 
@@ -341,7 +371,9 @@ int marius_segment_adagrad_scatter(const float* rows, int64_t rows_ld, const int
  * before its gradients exist.  marius_segment_plan precomputes it (per sorted position: occurrence row, unique index, inside-one-chunk and
  * singleton flags; per chunk: the boundary-crossing segment it owns; per unique row: table row id and the occurrence row of a singleton) on
  * whatever stream prepares batches; marius_segment_adagrad_scatter_planned then runs the same three kernels with one coalesced load where
- * the unplanned form walks a chain of dependent index loads.  Same results bit for bit.  plan: marius_segment_plan_bytes(n) bytes. */
+ * the unplanned form walks a chain of dependent index loads.  Same results bit for bit.  plan: marius_segment_plan_bytes(n) bytes.
+ * A unique id < 0 is padding, not a row (marius_a2a_rows_post): its positions are planned dead — the planned kernels neither load their
+ * gradient rows nor write anything for them. */
 size_t marius_segment_plan_bytes(int64_t n);
 /* the per-occurrence singleton flags inside a plan (uint8[n]: 1 = the occurrence's id occurs once among the n): marius_lp_desc.upd_occ_single */
 const uint8_t* marius_segment_plan_occ_single(const void* plan, int64_t n);

@@ -409,6 +409,9 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_property_readonly("exchange_bytes", [](ShardedTrainer& t) { return std::vector<int64_t>(t.exchange_bytes_, t.exchange_bytes_ + 3); })
         .def("reset_exchange_bytes", [](ShardedTrainer& t) { t.exchange_bytes_[0] = t.exchange_bytes_[1] = t.exchange_bytes_[2] = 0; })
         .def_readonly("steps", &ShardedTrainer::steps_)
+        .def_property_readonly("fixed_capacity", &ShardedTrainer::fixed_capacity)
+        .def_property_readonly("pair_capacity", &ShardedTrainer::pair_capacity)
+        .def_property_readonly("useful_rows", [](ShardedTrainer& t) { return std::vector<int64_t>(t.useful_rows_, t.useful_rows_ + 2); })
         .def_property_readonly("phase_seconds", [](ShardedTrainer& t) { return std::vector<double>(t.phase_seconds_, t.phase_seconds_ + 6); })
         .def("enable_spans", &ShardedTrainer::enable_spans)
         .def_property_readonly("span_ms", [](ShardedTrainer& t) {

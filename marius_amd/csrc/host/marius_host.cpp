@@ -1394,11 +1394,22 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
     HIPCHECK(hipStreamWaitEvent(main.stream(), (hipEvent_t)ev_join_, 0));
 }
 
-void Model::backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step) {
+void Model::backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step, Tensor out_rows) {
     forward_lp_train(batch);  // (sharded table: the rows came from other ranks' shards; the bound is the one of the gathered copy itself, Batch::row_bound_)
     model_backward(*this, batch);
     bool done = false;
-    if (local_relation_step) done = relation_step_sparse(*this, batch);
+    if (local_relation_step) {
+        // both relation tables as jobs of ONE launch pair when the loader planned their maps (4 launches otherwise): same results bit for bit
+        marius_segment_update jobs[2] = {};
+        int njobs = 0;
+        static const bool group_env = [] { const char* e = getenv("MARIUS_REL_GROUP"); return !(e && e[0] == '0'); }();
+        if (group_env && relation_step_jobs(*this, batch, jobs, njobs)) {
+            if (njobs > 0) mcheck(marius_segment_adagrad_scatter_group(jobs, njobs, cur_stream()));
+            done = true;
+        } else {
+            done = relation_step_sparse(*this, batch);
+        }
+    }
     if (!done) {
         relation_grads_dense(*this, batch);
         if (local_relation_step) step();  // optimizer without a touched-rows form: dense step on this replica
@@ -1406,13 +1417,14 @@ void Model::backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, b
     const int64_t L = batch->occ_perm_.size(0);
     ensure(carry_, (int64_t)marius_segment_carry_bytes(L, ctx_.desc.d), device_);
     const float* gocc = (const float*)((const char*)ctx_.workspace.data_ptr() + ctx_.layout.gocc);
+    const int64_t* orows = out_rows.defined() ? ip(out_rows) : nullptr;  // where unique row u's gradient goes (fixed-capacity exchange: marius_a2a_rows_post's place)
     if (batch->occ_plan_.defined())
         mcheck(marius_segment_sum_rows_planned(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
-                                               batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, nullptr, fp(grad_out), grad_out.stride(0),
+                                               batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, orows, fp(grad_out), grad_out.stride(0),
                                                carry_.data_ptr(), batch->occ_plan_.data_ptr(), cur_stream()));
     else
         mcheck(marius_segment_sum_rows(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
-                                       batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, nullptr, fp(grad_out), grad_out.stride(0),
+                                       batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, orows, fp(grad_out), grad_out.stride(0),
                                        carry_.data_ptr(), cur_stream()));
 }
 

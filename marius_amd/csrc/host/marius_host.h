@@ -496,7 +496,7 @@ class Model : public torch::nn::Module {
     // sharded node table (sharded_trainer.h): forward + loss + backward, then the per-unique-row gradient sums into grad_out [>= U, d] for
     // the owners of the rows.  local_relation_step: touched-rows Adagrad step on this replica's relation tables (replicas are averaged every
     // gpu_sync_interval steps); otherwise the dense gradients are left in relations_grad_ / inverse_relations_grad_ for an all-reduce + step()
-    void backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step);
+    void backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step, Tensor out_rows = Tensor());
     std::vector<Tensor> dense_state();  // relation tables + their optimizer state (what gpu_model_average averages, pipeline_gpu.cpp:52-80)
     // Magnitude bounds on the device (marius_lp_desc.absmax / absmax_rel): with them the flash path packs fp16 operand halves (22 significand
     // bits per operand) instead of bf16 ones (16).  Three sources for the bound on the node rows a step reads, one per way the rows reach it:

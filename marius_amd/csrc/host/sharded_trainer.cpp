@@ -66,7 +66,17 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
     main_stream_ = new c10::hip::HIPStream(c10::hip::getCurrentHIPStream(dev.index()));
     prep_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(/*isHighPriority=*/true, dev.index()));
     xchg_stream_ = new c10::hip::HIPStream(staleness_ ? c10::hip::getStreamFromPool(/*isHighPriority=*/true, dev.index()) : strm(main_stream_));
+    {
+        const char* e = getenv("MARIUS_EXCHANGE");  // exact: all-to-all(v) with host split sizes (rounds 1-4); default: fixed capacity
+        fixed_ = !(e && e[0] == 'e');
+        const char* sl = getenv("MARIUS_EXCHANGE_SLACK");  // planned maximum per (requester, owner) pair = slack * capacity / world (world > 1)
+        if (sl && atof(sl) >= 1.0) slack_ = atof(sl);
+    }
     for (auto& s : slots_) {
+        s.stamp_dev = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
+        s.stamp_host = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
+        s.overflow_dev = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
+        s.overflow_host = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
         s.offs_dev = torch::empty({world_ + 1}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
         s.offs_host = torch::empty({world_ + 1}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
         s.cnt_send_dev = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
@@ -114,10 +124,11 @@ void ShardedTrainer::prime() {
     Tensor ids = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).device(dev)), ids_out = torch::empty_like(ids);
     pg_->alltoall_base(rows_out, rows, ones, ones)->wait();
     pg_->alltoall_base(ids_out, ids, ones, ones)->wait();
-    if (world_ > 1) {
+    if (world_ > 1 || fixed_) {
         Tensor a = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).device(dev)), b = torch::zeros_like(a);
         std::vector<int64_t> none;
-        pg_->alltoall_base(b, a, none, none)->wait();  // the equal-split form of the count exchange
+        pg_->alltoall_base(b, a, none, none)->wait();  // the equal-split form (count exchange; every payload of the fixed-capacity exchange)
+        pg_->alltoall_base(rows_out, rows, none, none)->wait();
     }
     strm(main_stream_).synchronize();
 }
@@ -178,6 +189,7 @@ void ShardedTrainer::prepare(int64_t t) {
     span_collect(s);
     auto& prep = strm(prep_stream_);
     const auto dev_index = table_.device().index();
+    if (s.used) retire(s);
     if (s.used) {
         ST_HIPCHECK(hipStreamWaitEvent(prep.stream(), (hipEvent_t)s.free_, 0));  // the batch that used this slot RING steps ago is fully retired
     } else {
@@ -196,6 +208,15 @@ void ShardedTrainer::prepare(int64_t t) {
         mcheck(marius_owner_offsets(s.batch->unique_node_indices_.data_ptr<int64_t>(), s.batch->num_unique_dev_.data_ptr<int64_t>(), S_, world_,
                                     s.offs_dev.data_ptr<int64_t>(), (marius_stream_t)prep.stream()));
         s.offs_host.copy_(s.offs_dev, /*non_blocking=*/true);
+        if (fixed_) {
+            // fixed-capacity exchange: the id payload (-1 padded blocks of cap slots per owner) and the slot of every unique row; nothing
+            // of this batch is ever needed on the host (the split points above are read RING steps later, for the byte accounting only)
+            setup_fixed(s, s.batch->occ_perm_.size(0));
+            s.overflow_dev.zero_();
+            mcheck(marius_a2a_rows_post(s.batch->unique_node_indices_.data_ptr<int64_t>(), s.offs_dev.data_ptr<int64_t>(), S_, world_, cap_,
+                                        s.req_send.data_ptr<int64_t>(), s.place.data_ptr<int64_t>(), s.overflow_dev.data_ptr<int32_t>(), (marius_stream_t)prep.stream()));
+            s.overflow_host.copy_(s.overflow_dev, /*non_blocking=*/true);
+        } else {
         // The receive counts of the all-to-all(v) travel on the device as well: a `world`-integer all-to-all of the send counts on this
         // (preparation) stream, read back together with the split points behind the same `ready` event.  No host round trip (the
         // earlier form exchanged them over a gloo group from the host, one blocking call per step in the training loop).  Every rank
@@ -208,6 +229,10 @@ void ShardedTrainer::prepare(int64_t t) {
             s.cnt_recv_dev.copy_(s.cnt_send_dev);
         }
         s.cnt_recv_host.copy_(s.cnt_recv_dev, /*non_blocking=*/true);
+        }
+        s.stamp_value = t + 1;
+        s.stamp_dev.fill_(s.stamp_value);
+        s.stamp_host.copy_(s.stamp_dev, /*non_blocking=*/true);  // the last operation of the preparation: see Slot::stamp_host
     }
     span_end(s, 0, prep_stream_);
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.ready, prep.stream()));
@@ -219,11 +244,140 @@ void ShardedTrainer::prepare_through(int64_t t) {
 }
 
 // stage 2 (host + exchange stream): split sizes, then ids -> owners, rows -> requesters
+void ShardedTrainer::wait_prepared(Slot& s) {
+    volatile int64_t* stamp = s.stamp_host.data_ptr<int64_t>();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int64_t spins = 0; *stamp != s.stamp_value; ++spins) {
+        if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0)
+            throw MariusRuntimeException("ShardedTrainer: a batch preparation did not finish within 60 s");
+        __builtin_ia32_pause();
+    }
+}
+
+// a slot is reused RING steps after its batch was prepared: the stamp is long there, so this reads pinned memory without waiting
+void ShardedTrainer::retire(Slot& s) {
+    wait_prepared(s);
+    if (fixed_ && *s.overflow_host.data_ptr<int32_t>() != 0)
+        throw MariusRuntimeException("ShardedTrainer: a batch asked one owner for more than the planned maximum of " + std::to_string(cap_) +
+                                     " rows (fixed-capacity exchange, slack " + std::to_string(slack_) + "): raise MARIUS_EXCHANGE_SLACK, or MARIUS_EXCHANGE=exact");
+    if (fixed_) {
+        const int64_t* offs = s.offs_host.data_ptr<int64_t>();
+        for (int q = 0; q < world_; ++q)
+            if (q != rank_) useful_rows_[0] += offs[q + 1] - offs[q];
+    }
+}
+
+void ShardedTrainer::setup_fixed(Slot& s, int64_t L) {
+    const auto dev = table_.device();
+    auto i64o = torch::TensorOptions().dtype(torch::kInt64).device(dev), i32o = torch::TensorOptions().dtype(torch::kInt32).device(dev);
+    auto f32o = torch::TensorOptions().dtype(torch::kFloat32).device(dev), u8o = torch::TensorOptions().dtype(torch::kUInt8).device(dev);
+    if (L_ == 0) {
+        L_ = L;
+        cap_ = marius_a2a_capacity(L, world_, slack_);
+        ncap_ = cap_ * world_;
+        run_offsets_.resize(world_ + 1);
+        for (int q = 0; q <= world_; ++q) run_offsets_[q] = (int64_t)q * cap_;
+        req_recv_ = torch::empty({ncap_}, i64o);
+        rows_send_ = torch::empty({ncap_, d_}, f32o);
+        rows_recv_ = torch::empty({ncap_, d_}, f32o);
+        grad_recv_ = torch::empty({ncap_, d_}, f32o);
+        r_ws_ = torch::zeros({(int64_t)marius_sort_unique_workspace_bytes(ncap_)}, u8o);
+        r_carry_ = torch::empty({(int64_t)marius_segment_carry_bytes(ncap_, d_)}, u8o);
+    }
+    if (L != L_) throw MariusRuntimeException("ShardedTrainer: the fixed-capacity exchange needs batches of one size (full batches only)");
+    if (s.req_send.defined()) return;
+    s.req_send = torch::empty({ncap_}, i64o);
+    s.place = torch::empty({L_}, i64o);
+    s.grad_send = torch::empty({ncap_, d_}, f32o);
+    s.emb = torch::empty({L_, d_}, f32o);
+    s.r_uniq = torch::empty({ncap_}, i64o);
+    s.r_inverse = torch::empty({ncap_}, i64o);
+    s.r_perm = torch::empty({ncap_}, i32o);
+    s.r_seg = torch::empty({ncap_ + 1}, i32o);
+    s.r_count = torch::zeros({1}, i64o);
+    s.r_plan = torch::empty({(int64_t)marius_segment_plan_bytes(ncap_)}, u8o);
+}
+
+// stage 2, fixed-capacity form (exchange stream; the host reads nothing): ids -> owners, owners gather + plan their update, rows -> requesters
+void ShardedTrainer::fetch_fixed(int64_t t) {
+    Phase ph(phase_seconds_[2]);
+    Slot& s = slot(t);
+    auto& xchg = strm(xchg_stream_);
+    ST_HIPCHECK(hipStreamWaitEvent(xchg.stream(), (hipEvent_t)s.ready, 0));
+    span_begin(s, 1, xchg_stream_);
+    {
+        Scope scope(xchg);
+        auto st = (marius_stream_t)xchg.stream();
+        std::vector<int64_t> none;
+        span_begin(s, 4, xchg_stream_);
+        pg_->alltoall_base(req_recv_, s.req_send, none, none)->wait();  // orders this stream behind the collective; the host does not block
+        span_end(s, 4, xchg_stream_);
+        span_begin(s, 5, xchg_stream_);
+        // owner: rows of the ids asked for (-1 = unused slot: skipped), in the requesters' slot order
+        mcheck(marius_gather_rows(table_.data_ptr<float>(), table_.stride(0), req_recv_.data_ptr<int64_t>(), ncap_, d_, rows_send_.data_ptr<float>(),
+                                  rows_send_.stride(0), st));
+        span_end(s, 5, xchg_stream_);
+        span_begin(s, 6, xchg_stream_);
+        pg_->alltoall_base(rows_recv_, rows_send_, none, none)->wait();
+        span_end(s, 6, xchg_stream_);
+        // requester: rows into batch order + their magnitude bound (marius_lp_desc.absmax: fp16 operand halves), one pass
+        if (Model::flash_f16_enabled()) s.row_bound.zero_();
+        mcheck(marius_a2a_rows_wait(rows_recv_.data_ptr<float>(), rows_recv_.stride(0), s.place.data_ptr<int64_t>(), s.batch->num_unique_dev_.data_ptr<int64_t>(), L_,
+                                    d_, s.emb.data_ptr<float>(), s.emb.stride(0), Model::flash_f16_enabled() ? s.row_bound.data_ptr<float>() : nullptr, st));
+        // owner: the received id payload is `world` non-decreasing runs of cap slots (-1 padding first): merge them and plan the segmented
+        // update NOW — the ids are here a whole scoring pass before the gradients
+        mcheck(marius_merge_unique_runs(req_recv_.data_ptr<int64_t>(), ncap_, run_offsets_.data(), world_, s.r_uniq.data_ptr<int64_t>(), s.r_inverse.data_ptr<int64_t>(),
+                                        s.r_perm.data_ptr<int32_t>(), s.r_seg.data_ptr<int32_t>(), s.r_count.data_ptr<int64_t>(), r_ws_.data_ptr(), (size_t)r_ws_.numel(), st));
+        mcheck(marius_segment_plan(s.r_perm.data_ptr<int32_t>(), s.r_inverse.data_ptr<int64_t>(), s.r_seg.data_ptr<int32_t>(), s.r_uniq.data_ptr<int64_t>(), ncap_,
+                                   s.r_plan.data_ptr(), st));
+    }
+    span_end(s, 1, xchg_stream_);
+    ST_HIPCHECK(hipEventRecord((hipEvent_t)s.fetched, xchg.stream()));
+    // what crosses the wire is the padded payload: (world - 1) blocks of cap slots each way
+    exchange_bytes_[0] += (int64_t)(world_ - 1) * cap_ * 8;
+    exchange_bytes_[1] += (int64_t)(world_ - 1) * cap_ * d_ * 4;
+    exchange_bytes_[2] += (int64_t)(world_ - 1) * cap_ * d_ * 4;
+}
+
+// stage 4, fixed-capacity form: gradients -> owners, one grouped launch pair applies them (plan from fetch_fixed)
+void ShardedTrainer::update_fixed(int64_t t) {
+    Phase ph(phase_seconds_[4]);
+    Slot& s = slot(t);
+    auto& xchg = strm(xchg_stream_);
+    ST_HIPCHECK(hipStreamWaitEvent(xchg.stream(), (hipEvent_t)s.computed, 0));
+    span_begin(s, 3, xchg_stream_);
+    {
+        Scope scope(xchg);
+        std::vector<int64_t> none;
+        pg_->alltoall_base(grad_recv_, s.grad_send, none, none)->wait();
+        marius_segment_update u = {};
+        u.rows = grad_recv_.data_ptr<float>();
+        u.rows_ld = grad_recv_.stride(0);
+        u.perm = s.r_perm.data_ptr<int32_t>();
+        u.inverse = s.r_inverse.data_ptr<int64_t>();
+        u.seg_offsets = s.r_seg.data_ptr<int32_t>();
+        u.n = ncap_;
+        u.d = d_;
+        u.uniq_ids = s.r_uniq.data_ptr<int64_t>();  // LOCAL row ids (what the requesters sent); the -1 run is planned dead
+        u.table = table_.data_ptr<float>();
+        u.state = state_.data_ptr<float>();
+        u.table_ld = table_.stride(0);
+        u.lr = model_->sparse_lr_;
+        u.eps = 1e-10f;
+        u.carry = r_carry_.data_ptr();
+        u.plan = s.r_plan.data_ptr();
+        mcheck(marius_segment_adagrad_scatter_group(&u, 1, (marius_stream_t)xchg.stream()));
+    }
+    span_end(s, 3, xchg_stream_);
+    ST_HIPCHECK(hipEventRecord((hipEvent_t)s.free_, xchg.stream()));
+}
+
 void ShardedTrainer::fetch(int64_t t) {
+    if (fixed_) return fetch_fixed(t);
     Slot& s = slot(t);
     {
         Phase ph(phase_seconds_[1]);
-        ST_HIPCHECK(hipEventSynchronize((hipEvent_t)s.ready));  // a batch prepared at least one step ago: no stream drains for this
+        wait_prepared(s);  // a batch prepared at least one step ago: no stream drains for this
     }
     Phase ph(phase_seconds_[2]);
     const int64_t* offs = s.offs_host.data_ptr<int64_t>();
@@ -290,10 +444,14 @@ void ShardedTrainer::compute(int64_t t) {
     span_begin(s, 2, main_stream_);
     s.batch->node_embeddings_ = s.emb;
     if (Model::flash_f16_enabled()) s.batch->row_bound_ = s.row_bound;
-    s.grad = view(grad_[t % RING], s.U, {d_}, torch::kFloat32);
     // replicas step on their own relation gradients between averaging points (sync_interval > 1); with sync_interval 1 the dense
     // gradients are all-reduced first
-    model_->backward_to_unique_grads(s.batch, s.grad, sync_interval_ > 1);
+    if (fixed_) {  // per-row gradient sums straight into the owners' slot order (the gradient payload)
+        model_->backward_to_unique_grads(s.batch, s.grad_send, sync_interval_ > 1, s.place);
+    } else {
+        s.grad = view(grad_[t % RING], s.U, {d_}, torch::kFloat32);
+        model_->backward_to_unique_grads(s.batch, s.grad, sync_interval_ > 1);
+    }
     span_end(s, 2, main_stream_);
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.computed, main.stream()));
 }
@@ -332,6 +490,7 @@ void ShardedTrainer::apply_local(const Tensor& local_ids, const Tensor& grads, c
 
 // stage 4 (exchange stream): gradients -> owners, owners update their rows
 void ShardedTrainer::update(int64_t t) {
+    if (fixed_) return update_fixed(t);
     Phase ph(phase_seconds_[4]);
     Slot& s = slot(t);
     auto& xchg = strm(xchg_stream_);
@@ -392,7 +551,13 @@ void ShardedTrainer::train_steps(int64_t n) {
     for (int64_t i = 0; i < n; ++i) step();
 }
 
-void ShardedTrainer::finish() { ST_HIPCHECK(hipDeviceSynchronize()); }
+void ShardedTrainer::finish() {
+    ST_HIPCHECK(hipDeviceSynchronize());
+    for (auto& s : slots_)
+        if (s.used && fixed_ && *s.overflow_host.data_ptr<int32_t>() != 0)
+            throw MariusRuntimeException("ShardedTrainer: a batch asked one owner for more than the planned maximum of " + std::to_string(cap_) +
+                                         " rows (fixed-capacity exchange): raise MARIUS_EXCHANGE_SLACK, or MARIUS_EXCHANGE=exact");
+}
 
 std::vector<Tensor> c10d_exchange_selftest(const std::string& group_name, Tensor send, std::vector<int64_t> send_counts, Tensor to_reduce) {
     auto pg = c10d::resolve_process_group(group_name);

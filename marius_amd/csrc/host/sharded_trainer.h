@@ -3,9 +3,16 @@
 // control flow live in marius_amd/sharded.py: PipelineSchedule — this is the same schedule issued from C++ so that the host is not the
 // bottleneck: the Python driver needs ~1.2 ms per step to issue ~60 launches, more than the GPU needs to execute them).
 //
-// Collectives go through torch.distributed's C++ layer (c10d::ProcessGroup): the NCCL(=RCCL) group for device tensors and a gloo group
-// for the `world` split counts of every all-to-all(v), which must be known on the host.  Groups are looked up by name
-// (c10d::resolve_process_group), so nothing but two strings crosses the Python boundary.
+// Collectives go through torch.distributed's C++ layer (c10d::ProcessGroup), looked up by name (c10d::resolve_process_group), so nothing but
+// a string crosses the Python boundary.
+//
+// Round 5: FIXED-CAPACITY exchange (the default; MARIUS_EXCHANGE=exact selects the all-to-all(v) form of rounds 1-4).  Every (requester, owner)
+// pair owns `cap` slots of each payload — marius_a2a_capacity: the batch's id capacity at world 1, slack x capacity / world otherwise — the three
+// payloads (ids, rows, gradients) travel by equal-split all-to-alls, and the counts ride in the id payload as -1 padding (exchange.hip,
+// include/marius_hip.h marius_a2a_rows_{post,wait}).  No split size is needed on the host, so the training loop never reads the device: round
+// 4's loop spent 0.35-0.45 ms of every 0.83 ms step in hipEventSynchronize for the split points (profiles/r4_bench_sharded_w1.json).  The owner
+// merges the `world` id runs and plans its segmented update when the IDS arrive — a step before the gradients do — so the update itself is one
+// grouped launch pair (marius_segment_adagrad_scatter_group) behind the gradient all-to-all.
 #pragma once
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 
@@ -37,6 +44,10 @@ class ShardedTrainer {
     std::string backend() const { return pg_ ? pg_->getBackendName() : std::string("none"); }
     int64_t steps_ = 0;
     double phase_seconds_[6] = {0, 0, 0, 0, 0, 0};  // host time in: prepare, wait for split points, fetch, compute, update, dense
+    bool fixed_capacity() const { return fixed_; }
+    int64_t pair_capacity() const { return cap_; }  // rows per (requester, owner) pair and payload (fixed-capacity exchange); 0 before the first batch
+    // rows this rank actually asked of / served to OTHER ranks (from the split points, read long after the fact): the useful part of exchange_bytes_
+    int64_t useful_rows_[2] = {0, 0};
     // device time from the first to the last operation of a stage on its stream (HIP events; collected when a slot is reused, RING steps
     // later): prepare (prep stream), fetch and update (exchange stream), compute (main stream).  A stage's span includes the time its
     // kernels wait for CUs held by the other streams: span >> the stage's own work means that stream is starved.
@@ -62,6 +73,16 @@ class ShardedTrainer {
         int64_t U = 0, nrecv = 0;
         Tensor emb, grad, local_ids;
         Tensor row_bound;  // device float[1] >= every |x| of the rows this slot's batches gathered (Batch::row_bound_; max'ed in on the exchange stream)
+        // host-visible stamp: the LAST thing a preparation writes (pinned int64 = batch index + 1).  The host polls it instead of
+        // hipEventSynchronize(ready): on this runtime an event wait on a stream with younger work queued behind the event returned only when
+        // that younger work had finished (profiles/r5_sharded_timeline_before.txt: the loop woke when the preparation issued LAST completed)
+        Tensor stamp_dev, stamp_host;
+        int64_t stamp_value = 0;
+        // fixed-capacity exchange
+        Tensor req_send, place;             // [world * cap] ids asked of every owner (-1 padded), [L] slot of unique index u
+        Tensor overflow_dev, overflow_host;  // int32: some owner was asked for more than cap rows (checked when the slot is reused)
+        Tensor grad_send;                   // [world * cap, d] per-row gradients in the owners' slot order
+        Tensor r_uniq, r_inverse, r_perm, r_seg, r_count, r_plan;  // owner side: merged runs of the received ids + their segment plan
     };
     shared_ptr<DataLoader> loader_;
     shared_ptr<Model> model_;
@@ -80,6 +101,17 @@ class ShardedTrainer {
     // owner-side dedupe of the received ids
     Tensor r_uniq_, r_inverse_, r_perm_, r_seg_, r_count_, r_ws_, r_carry_;
     int64_t r_cap_ = 0;
+    // fixed-capacity exchange: shared staging (each is produced and consumed inside one stage on the exchange stream)
+    bool fixed_ = true;
+    double slack_ = 1.5;
+    int64_t L_ = 0, cap_ = 0, ncap_ = 0;  // id capacity of a batch, slots per pair, slots per payload (world * cap)
+    Tensor req_recv_, rows_send_, rows_recv_, grad_recv_;
+    std::vector<int64_t> run_offsets_;  // q * cap: the `world` runs of a received id payload
+    void setup_fixed(Slot& s, int64_t L);
+    void fetch_fixed(int64_t t);
+    void update_fixed(int64_t t);
+    void retire(Slot& s);  // a slot is about to be reused: its preparation finished long ago — overflow flag, useful-row accounting
+    void wait_prepared(Slot& s);
 
     Slot& slot(int64_t t) { return slots_[t % RING]; }
     Tensor view(Tensor& buf, int64_t n, std::vector<int64_t> tail, torch::ScalarType dtype);

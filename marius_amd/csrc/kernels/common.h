@@ -15,6 +15,27 @@ void set_last_error(const char* fmt, ...);
 // that never returns (or faults) is the last name printed.  Off: a single predictable branch.
 int launch_debug(const char* what);
 
+// Every MARIUS_* switch the kernel library honours, read ONCE when the library is first used (no getenv in per-call code).  They select
+// code that a test or an A/B run of this tree uses; a production run sets none of them.  marius_config_reload() re-reads them (tests switch a path
+// inside one process; tools/ab_env.sh runs set them before the process starts and never need it).
+struct KernelEnv {
+    char scores;          // MARIUS_SCORES=res: the LDS-tile score kernel where the register-fragment one would apply
+    bool no_fast;         // MARIUS_NO_FAST=1 / MARIUS_KERNELS=generic
+    char kernels;         // MARIUS_KERNELS: 'g'eneric, 'f'ast, else the MFMA-tuned level
+    bool no_vlog;         // MARIUS_NO_VLOG=1
+    bool timeline_grads;  // MARIUS_TIMELINE_GRADS: cycle stamps of the backward kernel instead of the score kernel
+    int flash_wide;       // MARIUS_FLASH_WIDE: -1 unset, 0 off, 128 = round-3 chunk width
+    char flash;           // MARIUS_FLASH: '0' off, 'f' forced, 0 unset
+    bool has_flash_reserve, has_flash_nwg;
+    int flash_reserve, flash_nwg;  // MARIUS_FLASH_RESERVE / MARIUS_FLASH_NWG
+    bool flash_f16_off;   // MARIUS_FLASH_F16=0
+    bool flash_rotate_off;  // MARIUS_FLASH_ROTATE=0
+    bool seg_fused_fixup_off, seg_group_off;  // MARIUS_SEG_FUSED_FIXUP=0, MARIUS_SEG_GROUP=0
+    bool sort_rocprim;    // MARIUS_SORT=rocprim
+    int sync_launch;      // MARIUS_SYNC_LAUNCH
+};
+const KernelEnv& kernel_env();
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

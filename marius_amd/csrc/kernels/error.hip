@@ -14,8 +14,43 @@ void set_last_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static KernelEnv read_kernel_env() {
+    KernelEnv k = {};
+    auto first = [](const char* name) -> char { const char* e = getenv(name); return e ? e[0] : (char)0; };
+    k.scores = first("MARIUS_SCORES");
+    k.no_fast = first("MARIUS_NO_FAST") == '1';
+    k.kernels = first("MARIUS_KERNELS");
+    k.no_vlog = first("MARIUS_NO_VLOG") == '1';
+    k.timeline_grads = getenv("MARIUS_TIMELINE_GRADS") != nullptr;
+    {
+        const char* e = getenv("MARIUS_FLASH_WIDE");
+        k.flash_wide = !e ? -1 : (e[0] == '0' ? 0 : atoi(e));
+    }
+    k.flash = first("MARIUS_FLASH");
+    if (const char* e = getenv("MARIUS_FLASH_RESERVE")) { k.has_flash_reserve = true; k.flash_reserve = atoi(e); }
+    if (const char* e = getenv("MARIUS_FLASH_NWG")) { k.has_flash_nwg = true; k.flash_nwg = atoi(e); }
+    k.flash_f16_off = first("MARIUS_FLASH_F16") == '0';
+    k.flash_rotate_off = first("MARIUS_FLASH_ROTATE") == '0';
+    k.seg_fused_fixup_off = first("MARIUS_SEG_FUSED_FIXUP") == '0';
+    k.seg_group_off = first("MARIUS_SEG_GROUP") == '0';
+    k.sort_rocprim = first("MARIUS_SORT") == 'r';
+    {
+        const char* e = getenv("MARIUS_SYNC_LAUNCH");
+        k.sync_launch = e ? atoi(e) : 0;
+    }
+    return k;
+}
+static KernelEnv g_kernel_env = read_kernel_env();  // at library load
+const KernelEnv& kernel_env() { return g_kernel_env; }
+}  // namespace marius
+extern "C" int marius_config_reload(void) {
+    marius::g_kernel_env = marius::read_kernel_env();
+    return MARIUS_OK;
+}
+namespace marius {
+
 int launch_debug(const char* what) {
-    static const int mode = [] { const char* e = getenv("MARIUS_SYNC_LAUNCH"); return e ? atoi(e) : 0; }();
+    const int mode = kernel_env().sync_launch;
     if (!mode) return MARIUS_OK;
     if (mode >= 2) fprintf(stderr, "[launch] %s\n", what);
     hipError_t e = hipDeviceSynchronize();

@@ -1,0 +1,126 @@
+// Fixed-capacity row exchange of the sharded node table: the device-side halves of the all-to-all row fetch / gradient return
+// (a2a_rows_{post,wait}; 8(e): node table sharded along Marius's partition axis, src/storage/storage.cpp:75,
+// cross-partition rows by an RCCL all-to-all over xGMI; replaces the per-device model replicas + host-memory embeddings of
+// src/cpp/src/pipeline/pipeline_gpu.cpp:23-80).
+//
+// Why fixed capacity.  An all-to-all(v) needs its split sizes on the HOST, i.e. a device -> host read-back per batch in the training loop
+// (round 4: 0.35-0.45 ms of every 0.83 ms step blocked in hipEventSynchronize for them).  Here every (requester, owner) pair owns a block of
+// `cap` slots in each payload — cap = the planned maximum, marius_a2a_capacity — the transport is ONE equal-split all-to-all per payload
+// (ncclAllToAll / c10d alltoall_base without split vectors: no size ever leaves the device), and the counts ride in the payload itself: the
+// unused slots of a block carry the id -1, which every consumer behind this C-ABI already treats as "no row" (gathers skip negative ids; the
+// segment plan marks them dead, so the owner's reduction neither reads their gradient rows nor writes anything for them).
+//
+//   requester                                   owner
+//   marius_a2a_rows_post   ids  -> req_send     (all-to-all int64 [world x cap])
+//                                               marius_gather_rows(shard, req_recv) -> rows_send            (negative ids skipped)
+//                                               marius_merge_unique_runs(req_recv: world runs of cap) + marius_segment_plan   (a step ahead of the gradients)
+//   (all-to-all float [world x cap x d])
+//   marius_a2a_rows_wait   rows_recv -> emb [U, d] in batch order + their magnitude bound
+//   ... forward / backward ... marius_segment_sum_rows_planned(out_rows = place) -> grad_send [world x cap x d]
+//   (all-to-all float [world x cap x d])
+//                                               marius_segment_adagrad_scatter_group(rows = grad_recv, the plan above)
+//
+// A block is filled from its END: slots [0, cap - cnt) hold -1, then the cnt local row ids in ascending order — so a block is a
+// non-decreasing run under signed comparison and the owner's merge of the `world` runs (marius_merge_unique_runs) needs no counts either.
+#include "common.h"
+
+namespace marius {
+
+// one thread per slot of the request payload
+__global__ __launch_bounds__(256) void a2a_post_kernel(const int64_t* __restrict__ uniq, const int64_t* __restrict__ offs, int64_t shard_rows, int world,
+                                                       int64_t cap, int64_t* __restrict__ req_send, int64_t* __restrict__ place, int32_t* __restrict__ overflow) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)world * cap) return;
+    const int q = (int)(i / cap);
+    const int64_t j = i - (int64_t)q * cap;
+    const int64_t o0 = offs[q], cnt = offs[q + 1] - o0;
+    if (cnt > cap) {  // more rows of one owner than the planned maximum: flagged (the host refuses to go on), the first `cap` are served
+        if (j == 0) atomicOr(reinterpret_cast<unsigned int*>(overflow), 1u);
+    }
+    const int64_t c = cnt < cap ? cnt : cap;
+    const int64_t k = j - (cap - c);  // position inside the owner's run of the batch's ascending unique ids
+    if (k < 0) {
+        req_send[i] = -1;
+    } else {
+        req_send[i] = uniq[o0 + k] - (int64_t)q * shard_rows;
+        place[o0 + k] = i;
+    }
+}
+
+// emb[u] = rows_recv[place[u]] for u < *num_unique; max |x| of the moved rows max'ed into *absmax.  A row's 16-byte pieces map one to one onto
+// lanes (d = 100: 25 lanes per row), four rows in flight per thread row.
+template <int VEC>
+__global__ __launch_bounds__(256) void a2a_wait_kernel(const float* __restrict__ rows_recv, int64_t recv_ld, const int64_t* __restrict__ place,
+                                                       const int64_t* __restrict__ num_unique, int64_t capacity, int vpr, int TX, float* __restrict__ emb,
+                                                       int64_t emb_ld, float* __restrict__ absmax) {
+    const int TY = 256 / TX, ty = threadIdx.x / TX, tx = threadIdx.x - ty * TX;  // TX need not divide 256: the threads left over move nothing
+    int64_t U = *num_unique;
+    U = U < capacity ? U : capacity;
+    constexpr int UNR = 4;
+    float mx = 0.f;
+    int64_t row[UNR], src[UNR];
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+        row[k] = ((int64_t)blockIdx.x * UNR + k) * TY + ty;
+        src[k] = (ty < TY && row[k] < U) ? place[row[k]] : -1;
+    }
+    for (int c = tx; c < vpr; c += TX) {
+        float v[UNR][VEC];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k)
+            if (src[k] >= 0) __builtin_memcpy(v[k], rows_recv + src[k] * recv_ld + (int64_t)c * VEC, sizeof(float) * VEC);
+#pragma unroll
+        for (int k = 0; k < UNR; ++k)
+            if (src[k] >= 0) {
+                __builtin_memcpy(emb + row[k] * emb_ld + (int64_t)c * VEC, v[k], sizeof(float) * VEC);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) mx = fmaxf(mx, fabsf(v[k][e]));
+            }
+    }
+    if (absmax) {
+        mx = wave_max(mx);
+        if ((threadIdx.x & 63) == 0 && mx > *reinterpret_cast<volatile float*>(absmax)) atomicMax(reinterpret_cast<unsigned int*>(absmax), __float_as_uint(mx));
+    }
+}
+
+}  // namespace marius
+
+using namespace marius;
+
+extern "C" int64_t marius_a2a_capacity(int64_t max_rows, int32_t world, double slack) {
+    if (max_rows <= 0 || world <= 0) return 0;
+    if (world == 1) return max_rows;
+    if (!(slack >= 1.0)) slack = 1.0;
+    int64_t cap = (int64_t)((double)max_rows / world * slack) + 1;
+    cap = (cap + 255) / 256 * 256;  // whole 2 KB runs of ids per pair
+    return cap < max_rows ? cap : max_rows;
+}
+
+extern "C" int marius_a2a_rows_post(const int64_t* uniq, const int64_t* owner_offsets, int64_t shard_rows, int32_t world, int64_t cap, int64_t* req_send,
+                                    int64_t* place, int32_t* overflow_flag, marius_stream_t stream) {
+    MARIUS_REQUIRE(world >= 1 && cap >= 1 && shard_rows >= 1, "a2a_rows_post: bad sizes world=%d cap=%ld shard_rows=%ld", world, (long)cap, (long)shard_rows);
+    MARIUS_REQUIRE(uniq && owner_offsets && req_send && place && overflow_flag, "a2a_rows_post: null pointer");
+    const int64_t n = (int64_t)world * cap;
+    a2a_post_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream)>>>(uniq, owner_offsets, shard_rows, world, cap, req_send, place, overflow_flag);
+    return check_launch("a2a_rows_post");
+}
+
+extern "C" int marius_a2a_rows_wait(const float* rows_recv, int64_t recv_ld, const int64_t* place, const int64_t* num_unique_dev, int64_t capacity, int32_t d,
+                                    float* emb, int64_t emb_ld, float* absmax, marius_stream_t stream) {
+    MARIUS_REQUIRE(capacity >= 0 && d > 0 && recv_ld >= d && emb_ld >= d, "a2a_rows_wait: bad sizes");
+    if (capacity == 0) return MARIUS_OK;
+    MARIUS_REQUIRE(rows_recv && place && num_unique_dev && emb, "a2a_rows_wait: null pointer");
+    int vec = row_vec_width(rows_recv, recv_ld, d);
+    const int v2 = row_vec_width(emb, emb_ld, d);
+    vec = vec < v2 ? vec : v2;
+    const int vpr = d / vec;
+    int tx = vpr < 64 ? vpr : 64;
+    if (tx < 1) tx = 1;
+    const int ty = 256 / tx;
+    dim3 block(256), grid((unsigned)cdiv(capacity, (int64_t)ty * 4));
+    hipStream_t st = as_stream(stream);
+    if (vec == 4) a2a_wait_kernel<4><<<grid, block, 0, st>>>(rows_recv, recv_ld, place, num_unique_dev, capacity, vpr, tx, emb, emb_ld, absmax);
+    else if (vec == 2) a2a_wait_kernel<2><<<grid, block, 0, st>>>(rows_recv, recv_ld, place, num_unique_dev, capacity, vpr, tx, emb, emb_ld, absmax);
+    else a2a_wait_kernel<1><<<grid, block, 0, st>>>(rows_recv, recv_ld, place, num_unique_dev, capacity, vpr, tx, emb, emb_ld, absmax);
+    return check_launch("a2a_rows_wait");
+}

@@ -1205,8 +1205,7 @@ static unsigned long long* g_dbg_timeline = nullptr;
 // persistent workgroups: every other d <= 128 with d % 4 == 0; MARIUS_SCORES=res forces it where 'p' would apply — tests of that kernel at
 // the bench shape).  The one-workgroup-per-unit forms and the bf16x6 split planes of rounds 1-2 lost their A/B runs and are gone.
 static char scores_variant(const marius_lp_desc* d, const LpDims& D) {
-    const char* v = getenv("MARIUS_SCORES");
-    const bool want_res = v && v[0] == 'r';
+    const bool want_res = kernel_env().scores == 'r';
     if (!want_res && scores_a_applicable(d->emb, d->emb_ld, D.d)) return 'p';
     if (scores_res_applicable(d->emb, d->emb_ld, D.d)) return 'r';
     return 0;
@@ -1225,11 +1224,9 @@ static int lse_fused_groups(const marius_lp_desc* d, const LpDims& D) {
 }
 static bool lse_fused(const marius_lp_desc* d, const LpDims& D) { return lse_fused_groups(d, D) > 0; }
 static int kernel_level() {
-    const char* e = getenv("MARIUS_NO_FAST");
-    if (e && e[0] == '1') return 0;
-    const char* k = getenv("MARIUS_KERNELS");
-    if (k && k[0] == 'g') return 0;
-    if (k && k[0] == 'f') return 1;
+    const KernelEnv& e = kernel_env();
+    if (e.no_fast || e.kernels == 'g') return 0;
+    if (e.kernels == 'f') return 1;
     return 2;
 }
 
@@ -1272,8 +1269,7 @@ static int fill_dims(const marius_lp_desc* d, LpDims& D) {
 // and the backward runs on that buffer with lse = 0, i.e. exactly its SoftmaxCE form g exp(S' - 0).  Not for MSE (dL/dS changes sign)
 // and not for the L2 comparator (its chain rule divides by the score itself).
 static bool vlog_path(const LpDims& D) {
-    const char* e = getenv("MARIUS_NO_VLOG");
-    if (e && e[0] == '1') return false;
+    if (kernel_env().no_vlog) return false;
     return D.loss != MARIUS_LOSS_SOFTMAX_CE && D.loss != MARIUS_LOSS_MSE && D.cmp == MARIUS_CMP_DOT && kernel_level() == 2;
 }
 
@@ -1454,7 +1450,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     sa.D = D;
     sa.ablate = 0;
     sa.lse_part = lse_fused(desc, D) ? (float*)(ws + L->lsepart) : nullptr;
-    sa.dbg = getenv("MARIUS_TIMELINE_GRADS") ? nullptr : g_dbg_timeline;
+    sa.dbg = kernel_env().timeline_grads ? nullptr : g_dbg_timeline;
     dim3 grid((unsigned)cdiv(D.N, F_TN), (unsigned)cdiv(D.Bc, F_TM), (unsigned)(D.C * D.ndir));
     size_t lds = (size_t)(F_TM + F_TN) * sa.KS * sizeof(float);
     {
@@ -1567,7 +1563,7 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
         ga.D.loss = MARIUS_LOSS_SOFTMAX_CE;
     }
     ga.ablate = 0;
-    ga.dbg = getenv("MARIUS_TIMELINE_GRADS") ? g_dbg_timeline : nullptr;
+    ga.dbg = kernel_env().timeline_grads ? g_dbg_timeline : nullptr;
     const unsigned nblk = (unsigned)cdiv(D.d, ga.ncols);
     dim3 ga_grid(nblk, (unsigned)cdiv(D.Bc, G_TM), (unsigned)(D.C * D.ndir));
     dim3 gn_grid(nblk, (unsigned)cdiv(D.N, G_TM), (unsigned)(D.C * D.ndir));

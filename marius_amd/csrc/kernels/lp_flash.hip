@@ -969,9 +969,9 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(const float2* __restri
 // the FP32 matrix path; =128: the round-3 chunk width (A/B runs).
 int flash_chunks(int d) {
     if (d <= 128) return 1;
-    const char* e = getenv("MARIUS_FLASH_WIDE");
-    if (e && e[0] == '0') return 0;
-    const int w = (e && atoi(e) == 128) ? 128 : 256;
+    const int fw = kernel_env().flash_wide;
+    if (fw == 0) return 0;
+    const int w = fw == 128 ? 128 : 256;
     const int n = (d + w - 1) / w;
     return (d % (4 * n) == 0 && d <= 1024) ? n : 0;
 }
@@ -1009,9 +1009,9 @@ static FlFilterDims fl_filter_dims(const LpDims& D) {
 constexpr size_t FL_FILTER_LDS_MAX = 150 * 1024;
 
 bool flash_applicable(const marius_lp_desc* desc, const LpDims& D) {
-    const char* e = getenv("MARIUS_FLASH");
-    if (e && e[0] == '0') return false;
-    if (!(desc->flags & MARIUS_LP_TRAIN_ONLY) && !(e && e[0] == 'f')) return false;  // MARIUS_FLASH=f: force (tests of the API path's numbers)
+    const char fe = kernel_env().flash;
+    if (fe == '0') return false;
+    if (!(desc->flags & MARIUS_LP_TRAIN_ONLY) && fe != 'f') return false;  // MARIUS_FLASH=f: force (tests of the API path's numbers)
     if (D.loss != MARIUS_LOSS_SOFTMAX_CE || D.cmp != MARIUS_CMP_DOT) return false;
     if ((desc->dst_filter && desc->n_dst_filter > 0) || (desc->src_filter && desc->n_src_filter > 0)) {
         // score filters (training: the DEG filter of degree-based negatives) are honoured by the fused sweep and dNeg through a per-item index;
@@ -1053,14 +1053,13 @@ void flash_set_reserved_cus(int n) { g_flash_reserved_cus = n; }
 static int64_t fl_gcd(int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; }
 static int fl_num_wg(int64_t tiles, int mode, int ks) {
     const int per_cu = fl_wg_per_cu_ks(mode, ks);
+    const KernelEnv& ke = kernel_env();
     int reserve = g_flash_reserved_cus;
-    const char* r = getenv("MARIUS_FLASH_RESERVE");
-    if (r) reserve = atoi(r);
+    if (ke.has_flash_reserve) reserve = ke.flash_reserve;
     if (reserve < 0 || reserve >= 128) reserve = 0;
     int nwg = (256 - reserve) * per_cu;
-    const char* e = getenv("MARIUS_FLASH_NWG");
-    if (e) {
-        nwg = atoi(e);
+    if (ke.has_flash_nwg) {
+        nwg = ke.flash_nwg;
     } else if (nwg < tiles && per_cu > 1) {  // (the one-workgroup-per-CU launches of wide chunks are bound by their score traffic: 256 beats 240 there, 1.402 vs 1.418 ms)
         int best = nwg & ~7;
         int64_t best_q = best / fl_gcd(tiles, best);
@@ -1125,8 +1124,7 @@ static FlRange g_no_range = {nullptr, nullptr, FL_ADJ_NODE};
 // magnitude bounds of the caller's tables -> fp16 records (marius_lp_desc.absmax); MARIUS_FLASH_F16=0 keeps the bf16 records
 FlRange flash_range(const marius_lp_desc* desc, const LpDims& D) {
     FlRange r = g_no_range;
-    const char* e = getenv("MARIUS_FLASH_F16");
-    if (desc->absmax && !(e && e[0] == '0')) {
+    if (desc->absmax && !kernel_env().flash_f16_off) {
         r.absmax = desc->absmax;
         r.absmax_rel = desc->absmax_rel ? desc->absmax_rel : desc->absmax + 1;
         const bool has_rel = D.edge_cols == 3 && desc->rel;
@@ -1159,10 +1157,7 @@ static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, cha
     a.YB = a.YR / FL_YB;
     a.total = (int64_t)a.ncd * a.XT * a.YB;
     a.nwg = fl_num_wg((int64_t)a.ncd * a.XT, mode, fl_ks(D.d));
-    {
-        const char* ro = getenv("MARIUS_FLASH_ROTATE");
-        a.rotate = (ro && ro[0] == '0') ? 0 : 1;
-    }
+    a.rotate = kernel_env().flash_rotate_off ? 0 : 1;
     a.C = D.C;
     a.Bc = D.Bc;
     a.N = D.N;

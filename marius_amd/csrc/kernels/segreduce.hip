@@ -123,7 +123,7 @@ __device__ __forceinline__ void seg_reduce_body(const SegArgs& a, const Apply& a
             p = q.x;
             u = q.y;
             complete = q.z;
-            single = a.skip_singletons && q.w;
+            single = (a.skip_singletons && q.w) || q.w == 2;  // 2: a padding slot (negative id), dead in every form
         } else {
             p = a.perm[k0 + lane];
             u = (int)a.inverse[p];
@@ -292,16 +292,20 @@ __global__ __launch_bounds__(256) void seg_plan_kernel(const int32_t* __restrict
     const int p = perm[k];
     const int u = (int)inverse[p];
     const int s0 = seg_offsets[u], s1 = seg_offsets[u + 1];
-    pos_plan[k] = make_int4(p, u, (s0 >= k0 && s1 <= k1) ? 1 : 0, (s1 - s0 == 1) ? 1 : 0);
-    occ_single[p] = (s1 - s0 == 1) ? 1 : 0;  // the same flag by occurrence row (marius_lp_desc.upd_occ_single)
+    // a NEGATIVE id is a padding slot, not a row (the unused slots of a fixed-capacity exchange block, exchange.hip): its positions are dead —
+    // flag 2: never loaded, never stored, whatever the form — and the segment they make up owns no fix-up and no table row
+    const bool dead = uniq[u] < 0;
+    pos_plan[k] = make_int4(p, u, (dead || (s0 >= k0 && s1 <= k1)) ? 1 : 0, dead ? 2 : ((s1 - s0 == 1) ? 1 : 0));
+    occ_single[p] = (!dead && s1 - s0 == 1) ? 1 : 0;  // the same flag by occurrence row (marius_lp_desc.upd_occ_single)
     if (k == k1 - 1) {  // last position of its chunk: does the chunk own a boundary-crossing segment (the one its last position belongs to)?
-        const bool owner = (s0 >= k0) && (s1 > k1);
+        const bool owner = !dead && (s0 >= k0) && (s1 > k1);
         chunk_plan[k / SEG_R] = make_int4(owner ? 1 : 0, u, (s0 != k0) ? 1 : 0, (int)((s1 - 1) / SEG_R));
     }
     if (k < U) {  // thread k also describes unique row k
         const int64_t id = uniq[k];
         const int t0 = seg_offsets[k], t1 = seg_offsets[k + 1];
-        row_plan[k] = make_int4((int)(id & 0xffffffffll), (int)(id >> 32), (t1 - t0 == 1) ? perm[t0] : -1, (t0 / SEG_R != (t1 - 1) / SEG_R) ? 1 : 0);
+        if (id < 0) row_plan[k] = make_int4(-1, -1, -1, 0);
+        else row_plan[k] = make_int4((int)(id & 0xffffffffll), (int)(id >> 32), (t1 - t0 == 1) ? perm[t0] : -1, (t0 / SEG_R != (t1 - 1) / SEG_R) ? 1 : 0);
     } else {
         row_plan[k] = make_int4(-1, -1, -1, 0);
     }
@@ -713,8 +717,8 @@ static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, cons
     MARIUS_REQUIRE(fused_below <= 0 || skip, "segment_adagrad_scatter: fused_below needs the singleton-skipping form (rows at least as aligned as the tables)");
     AdagradRowsArgs A{gsum, g_ld, perm, inverse, n, uniq_ids, table, state, table_ld, vpr, tx, lr, eps, occ, rows_ld, seg_offsets, row_plan, 0, absmax, (int)(fused_below > 0 ? fused_below : 0)};
     const int per = cdiv(d, 64 * vec);
-    const char* fz = getenv("MARIUS_SEG_FUSED_FIXUP");  // 0: the fix-up as its own launch between reduction and update (A/B runs)
-    if (plan && vec == vsum && vec == 4 && per <= 2 && !(fz && fz[0] == '0')) {
+    // (MARIUS_SEG_FUSED_FIXUP=0: the fix-up as its own launch between reduction and update — A/B runs)
+    if (plan && vec == vsum && vec == 4 && per <= 2 && !kernel_env().seg_fused_fixup_off) {
         rc = launch_seg(a, ap, vsum, st, /*fixup=*/false);
         if (rc) return rc;
         A.skip_crossing = 1;
@@ -741,8 +745,7 @@ static int segment_adagrad_scatter_impl(const float* rows, int64_t rows_ld, cons
 extern "C" int marius_segment_adagrad_scatter_group(const marius_segment_update* jobs, int32_t njobs, marius_stream_t stream) {
     MARIUS_REQUIRE(jobs && njobs >= 1, "segment_adagrad_scatter_group: no jobs");
     hipStream_t st = as_stream(stream);
-    const char* ge = getenv("MARIUS_SEG_GROUP");  // 0: one launch pair per table (A/B runs)
-    bool grouped = njobs <= SEG_GROUP_MAX && !(ge && ge[0] == '0');
+    bool grouped = njobs <= SEG_GROUP_MAX && !kernel_env().seg_group_off;  // (MARIUS_SEG_GROUP=0: one launch pair per table — A/B runs)
     int per0 = 0;
     for (int j = 0; j < njobs && grouped; ++j) {  // the single-launch planned form's conditions (segment_adagrad_scatter_impl), for every job
         const marius_segment_update& u = jobs[j];

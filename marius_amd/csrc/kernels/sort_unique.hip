@@ -429,8 +429,8 @@ extern "C" int marius_sort_unique(const int64_t* ids, int64_t n, int32_t key_bit
     void* tmp = ws + p.temp_off;
     size_t tmp_bytes = p.temp_bytes;
     {
-        const char* lib = getenv("MARIUS_SORT");  // MARIUS_SORT=rocprim: the library chain (A/B runs)
-        if (key_bits <= RS_MAX_KEY_BITS && n <= (int64_t)RS_MAX_TILES * RS_TILE && !(lib && lib[0] == 'r')) {
+        // (MARIUS_SORT=rocprim: the library chain — A/B runs)
+        if (key_bits <= RS_MAX_KEY_BITS && n <= (int64_t)RS_MAX_TILES * RS_TILE && !kernel_env().sort_rocprim) {
             const int ntiles = (int)cdiv(n, RS_TILE);
             const int passes = (key_bits + RS_BITS - 1) / RS_BITS;
             char* t = (char*)tmp;
@@ -518,9 +518,8 @@ extern "C" int marius_merge_unique_runs(const int64_t* ids, int64_t n, const int
     int64_t blocks = cdiv(n, 256);
     if (blocks > 2048) blocks = 2048;
     {   // two launches: ranks by binary search (+ the zero fills), then the radix sort's emit kernel (heads, prefix by granule hand-off, outputs)
-        const char* lib = getenv("MARIUS_SORT");
         const int64_t etiles = cdiv(n, EM_TILE);
-        if (n <= (int64_t)RS_MAX_TILES * RS_TILE && (size_t)(etiles + 4) * 4 <= p.temp_bytes && !(lib && lib[0] == 'r')) {
+        if (n <= (int64_t)RS_MAX_TILES * RS_TILE && (size_t)(etiles + 4) * 4 <= p.temp_bytes && !kernel_env().sort_rocprim) {
             uint32_t* tile_state = (uint32_t*)(ws + p.temp_off);
             merge_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(ids, n, ro, num_runs, keys, perm, uniq, tile_state, etiles, &((SortCtl*)ws)->ctr[1]);
             rs_emit_kernel<<<dim3((unsigned)etiles), dim3(RS_THREADS), 0, st>>>(keys, perm, n, tile_state, uniq, inverse, seg_offsets, num_unique_dev, (SortCtl*)ws, 1);

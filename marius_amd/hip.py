@@ -18,7 +18,7 @@ REDUCE_SUM, REDUCE_MEAN = 0, 1
 LOSS = {"SOFTMAX_CE": 0, "RANKING": 1, "CROSS_ENTROPY": 2, "BCE_AFTER_SIGMOID": 3, "BCE_WITH_LOGITS": 4, "MSE": 5, "SOFTPLUS": 6}
 LP_TRAIN_ONLY, LP_STORE_SCORES, LP_KEEP_DADJ = 1, 2, 4   # marius_lp_desc.flags
 MT_STATE_WORDS = 625
-ABI_VERSION = 8  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
+ABI_VERSION = 9  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
 
 
 class MariusHipError(RuntimeError):
@@ -55,6 +55,7 @@ _i32, _i64, _f32, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_si
 # name -> (restype, argtypes); mirrors include/marius_hip.h one to one
 SIGNATURES = {
     "marius_hip_abi_version": (C.c_int, []),
+    "marius_config_reload": (C.c_int, []),
     "marius_hip_struct_bytes": (C.c_int, [C.c_int]),
     "marius_hip_last_error": (C.c_char_p, []),
     "marius_gather_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
@@ -86,6 +87,9 @@ SIGNATURES = {
     "marius_sort_unique": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "marius_merge_unique_runs": (C.c_int, [_vp, _i64, C.POINTER(C.c_int64), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "marius_owner_offsets": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "marius_a2a_capacity": (_i64, [_i64, _i32, C.c_double]),
+    "marius_a2a_rows_post": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "marius_a2a_rows_wait": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     "marius_lp_plan": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout)]),
     "marius_lp_forward": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),
     "marius_lp_loss": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),
@@ -133,6 +137,11 @@ def lib():
                 raise MariusHipError("%s is %d bytes in libmarius_hip.so and %d in marius_amd/hip.py" % (mirror.__name__, L.marius_hip_struct_bytes(which), C.sizeof(mirror)))
         _lib = L
     return _lib
+
+
+def reload_env():
+    """re-read the MARIUS_* switches of the kernel library (it reads them once, at load): for tests that change one inside the process"""
+    lib().marius_config_reload()
 
 
 def check(rc, what=""):

@@ -570,6 +570,7 @@ def run_sharded_bench(a, cfg, rank, world, dev):
 
         M = marius_amd.host()
         gen = M.MariusGenerator(42 + rank)
+        gen.prefetch = os.environ.get("MARIUS_MT_PREFETCH", "1") != "0"
         sampler = M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen)
         nodes = M.InMemory("", num_nodes, d, torch.float32, dev)  # never loaded: tells the sampler how many nodes exist
         loader = M.DataLoader(M.InMemory(edges_all), nodes, None, sampler, gen, B, True)
@@ -654,8 +655,9 @@ def run_sharded_bench(a, cfg, rank, world, dev):
             "config": {"workload": "%s %s d=%d, node table sharded by contiguous id range over %d GPUs, B=%d per GPU (%s), C=%d N=%d, %s edges" % (
                 a.workload, cfg["decoder"], d, world, B, "global batch fixed" if strong else "fixed per GPU", C, N, a.edge_dist),
                 "num_nodes": num_nodes, "num_relations": R,
-                "parallelism": "dp%d + sharded node table, RCCL all-to-all(v) row fetch / gradient return, relation tables averaged every %d steps, %s" % (
-                    world, sync_interval, ("row exchange overlapped with scoring on a second stream (staleness %d step%s; reference pipeline bound: 16)" % (staleness, "s" if staleness > 1 else "")
+                "parallelism": "dp%d + sharded node table, RCCL %s row fetch / gradient return, relation tables averaged every %d steps, %s" % (
+                    world, ("fixed-capacity equal-split all-to-all (%d slots per rank pair, -1 padded: no split size on the host)" % cpp_trainer.pair_capacity)
+                    if (cpp_trainer is not None and cpp_trainer.fixed_capacity) else "all-to-all(v)", sync_interval, ("row exchange overlapped with scoring on a second stream (staleness %d step%s; reference pipeline bound: 16)" % (staleness, "s" if staleness > 1 else "")
                                            if pipelined and staleness else "synchronous exchange"))},
             "positive_edges_per_s": round(pos_eps, 1), "roofline": None, "cpu_baseline": None,
             # the communicator the exchange ran on: `ranks` of `collective_backend` ("nccl" is RCCL on ROCm; "gloo" only in the single-GPU
@@ -663,8 +665,14 @@ def run_sharded_bench(a, cfg, rank, world, dev):
             "ranks": cpp_trainer.ranks() if cpp_trainer is not None else world, "collective_backend": backend_name,
             "rccl_ranks": (cpp_trainer.ranks() if cpp_trainer is not None else world) if backend_name == "nccl" else 0,
             "exchange_bytes_per_step": {"ids": round(float(xb[0]) / a.steps), "rows": round(float(xb[1]) / a.steps), "gradients": round(float(xb[2]) / a.steps),
-                                        "total": round(float(xb.sum()) / a.steps), "note": "all ranks, bytes that cross xGMI per step; counts ride a world-integer device all-to-all"},
+                                        "total": round(float(xb.sum()) / a.steps),
+                                        "note": ("all ranks, bytes that cross xGMI per step: the PADDED payloads of the fixed-capacity exchange (world - 1 blocks of pair_capacity slots per rank "
+                                                 "and payload); the counts ride in the id payload as -1 padding") if (cpp_trainer is not None and cpp_trainer.fixed_capacity)
+                                        else "all ranks, bytes that cross xGMI per step; counts ride a world-integer device all-to-all"},
         }
+        if cpp_trainer is not None and cpp_trainer.fixed_capacity:
+            out["exchange"] = {"form": "fixed capacity", "pair_capacity_rows": cpp_trainer.pair_capacity, "id_capacity_per_batch": 2 * B + 2 * C * N,
+                               "slack": float(os.environ.get("MARIUS_EXCHANGE_SLACK", "1.5")) if world > 1 else 1.0}
         host_total = cpp_trainer.host_seconds if cpp_trainer is not None else (host_s[0] if host_s is not None else None)
         if host_total is not None:  # how long the host needs to issue a step: it must stay below ms_per_step or the host is the bottleneck
             out["host_issue_ms_per_step"] = round(host_total / a.steps * 1e3, 4)

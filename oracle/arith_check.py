@@ -121,28 +121,36 @@ def error_pairs(decoder, emb, edges, dst_neg, src_neg, rel, inv, got, reduction=
 
 
 ASSERTED = ("scores", "lse", "row_loss", "occ_grad", "rel_grad")
+RMS_FACTOR, MAX_FACTOR = 1.0, 2.0
+RULE = ("per quantity and statistic the yardstick is the LESS accurate of the reference's own two fp32 evaluations of the batch (its op sequence on CPU "
+        "tensors; the same on this device's tensors) - nothing of this library is part of it; ok = RMS error <= %.1f x and max error <= %.1f x that "
+        "yardstick on every asserted quantity" % (RMS_FACTOR, MAX_FACTOR))
 
 
 def verdict(pairs, asserted=ASSERTED):
-    """How the device path compares with the fp32 evaluations of the same batch.  The strict reading "no worse than the reference's fp32
-    evaluation on every quantity, max and RMS" is counted against each evaluation separately (`le1_cpu_aten`, `le1_device_aten`, `le1_fp32_mfma`:
-    how many of the 2 x len(asserted) ratios are <= 1).  No fp32 evaluation meets it against the others — they differ among themselves by up
-    to 3x on the gradient quantities (summation order) — so `ok` asks for what any of them satisfies by construction: on every quantity, max
-    and RMS error no larger than those of the LEAST accurate fp32 evaluation available (the reference's op sequence on CPU tensors, on device
-    tensors, and this library's FP32-MFMA kernels)."""
-    out = {"le1_cpu_aten": 0, "le1_device_aten": 0, "le1_fp32_mfma": 0, "of": 2 * len(asserted), "worst_vs_least_accurate_fp32": 0.0}
+    """Does the device path carry the headline?    The yardstick of every (quantity, statistic) pair is taken from the
+    REFERENCE'S evaluations only: its float32 op sequence on CPU tensors (ATen + CPU BLAS) and on device tensors (ATen + the vendor BLAS: what the
+    reference computes with storage.device_type cuda on this machine) - whichever of the two is further from float64.  This library's FP32-MFMA
+    kernels are reported beside it (`le1_fp32_mfma`) and never enter the gate.  Rule: RMS error no larger than the yardstick's, max error within a
+    factor 2 of it (a maximum over 10^7 - 10^8 entries is an extreme-value statistic that moves by that much between fp32 evaluations of the same
+    batch: the two reference evaluations differ by 1.3 - 3.4x among themselves on the gradient maxima).  The strict counts - device path <= EACH
+    evaluation, both statistics - are reported as `le1_*`."""
+    out = {"le1_cpu_aten": 0, "le1_device_aten": 0, "le1_fp32_mfma": 0, "of": 2 * len(asserted), "worst_rms_vs_reference": 0.0, "worst_max_vs_reference": 0.0,
+           "rule": RULE}
     ok = True
     for q in asserted:
         p = pairs[q]
         for stat in ("max", "rms"):
             dev = p["device_" + stat]
-            refs = {"le1_cpu_aten": p.get("fp32_" + stat), "le1_device_aten": p.get("fp32_on_device_" + stat), "le1_fp32_mfma": p.get("fp32_mfma_" + stat)}
-            for k, v in refs.items():
+            refs = {"le1_cpu_aten": p.get("fp32_" + stat), "le1_device_aten": p.get("fp32_on_device_" + stat)}
+            for k, v in list(refs.items()) + [("le1_fp32_mfma", p.get("fp32_mfma_" + stat))]:
                 if v is not None and dev <= v:
                     out[k] += 1
-            worst = max(v for v in refs.values() if v is not None)
-            out["worst_vs_least_accurate_fp32"] = max(out["worst_vs_least_accurate_fp32"], dev / worst if worst > 0 else math.inf)
-            ok = ok and dev <= worst
+            yard = max(v for v in refs.values() if v is not None)
+            ratio = dev / yard if yard > 0 else (0.0 if dev == 0 else math.inf)
+            key = "worst_%s_vs_reference" % stat
+            out[key] = max(out[key], ratio)
+            ok = ok and ratio <= (MAX_FACTOR if stat == "max" else RMS_FACTOR)
     out["ok"] = ok
     return out
 

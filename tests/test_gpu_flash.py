@@ -337,11 +337,12 @@ def test_flash_arithmetic_against_the_reference_fp32_evaluation(H, dev, decoder,
     vendor BLAS result moves a few percent from run to run) and 0.6-1.6 of it at the small shapes, 0.7-2.9 of the CPU evaluation — while this
     library's own FP32-MFMA kernels (every product an fp32 product) sit at 0.7-3.4 of the CPU evaluation: fp32 evaluations differ among themselves
     by that much (summation order), the split path is inside their spread and closer to float64 than the FP32-MFMA path on most quantities.
-    Asserted (oracle/arith_check.verdict):
-      * at the bench shape (the configuration the metric is quoted on): on every quantity, max and RMS error no larger than those of the least
-        accurate of the three fp32 evaluations of the batch (CPU ATen, device ATen, FP32-MFMA kernels) — the condition under which bench.py lets
-        the split path carry the headline (`arith_check.ok`); how many of the 10 ratios are <= 1 against EACH evaluation is printed beside it;
-      * at every shape: within 2x (max) / 1.5x (RMS) of the less accurate of the two reference evaluations."""
+    Asserted (oracle/arith_check.verdict; VERDICT r4 #2: the yardstick is taken from the reference's two evaluations only, never from this library's
+    own FP32-MFMA kernels, which are printed beside it):
+      * at the bench shape (the configuration the metric is quoted on): RMS error <= 1.0 x and max error <= 2.0 x the less accurate of the two
+        reference evaluations, on every quantity — the condition under which bench.py lets the split path carry the headline (`arith_check.ok`);
+        how many of the 10 ratios are <= 1 against EACH evaluation is printed beside it;
+      * at the small shapes: within 2x (max) / 1.5x (RMS) of the less accurate of the two reference evaluations."""
     from oracle.arith_check import ASSERTED, verdict
 
     emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=4242)
@@ -386,8 +387,10 @@ def test_flash_split_tiles_are_deterministic_and_consistent(H, dev, monkeypatch,
         return [t.clone() for t in (W.lse(0), W.lse(1), W.gocc(), W.dadj(0)[:B], W.dadj(1)[:B], W.loss_values())]
 
     monkeypatch.setenv("MARIUS_FLASH_NWG", "512")   # clipped to the number of tiles (and to a multiple of 8): the reference distribution
+    H.reload_env()
     ref = run()
     monkeypatch.setenv("MARIUS_FLASH_NWG", nwg)
+    H.reload_env()
     got = [run() for _ in range(3)]
     for other in got[1:]:
         for a, b in zip(got[0], other):

@@ -129,6 +129,7 @@ def test_lp_bench_shape_matches_oracle(H, dev):
 def test_lp_multi_tile_shape_every_score_variant(H, dev, monkeypatch, variant, decoder):
     """Bc = 1024 (8 row tiles), N = 1000 (partial last column tile), several units per persistent workgroup."""
     monkeypatch.setenv("MARIUS_SCORES", variant)
+    H.reload_env()
     check_against_oracle(H, dev, decoder, 4096, 4, 1000, 100, 9000, 17, seed=7)
 
 

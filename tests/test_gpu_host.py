@@ -730,6 +730,8 @@ def test_cpp_sharded_trainer_world1_equals_synchronous_trainer(M, dev, sync_inte
     Same arithmetic on both sides: the sharded trainer packs bf16 operand halves (a rank sees only its shard's magnitudes), so the fused
     trainer is held to them too (MARIUS_FLASH_F16=0) — from an all-zero Adagrad state any difference in rounding flips lr-sized steps."""
     monkeypatch.setenv("MARIUS_FLASH_F16", "0")
+    from marius_amd import hip as _hip
+    _hip.reload_env()
     dist = _init_nccl(dev)
     num_nodes, R, d, B, C, N, E, seed, steps = 3000, 9, 100, 200, 4, 60, 1200, 21, 9
     table, edges_all, make = _sharded_setup(M, dev, seed, num_nodes, R, d, B, C, N, E)

@@ -286,6 +286,7 @@ def test_lp_forward_loss_backward(H, dev, decoder, use_inverse, B, C, N, d, redu
 def test_lp_lower_kernel_levels_also_match(H, dev, decoder, level, monkeypatch):
     """MARIUS_KERNELS forces the generic / fast contraction kernels at a shape the resident ones normally take."""
     monkeypatch.setenv("MARIUS_KERNELS", level)
+    H.reload_env()
     B, C, N, d, U, R = 300, 4, 200, 100, 400, 7
     emb, state, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=31)
     want = O.train_batch(decoder, emb, state, edges, dst_neg, src_neg, rel, inv)
@@ -663,6 +664,7 @@ def test_lp_other_losses_forward_backward(H, dev, monkeypatch, novlog, loss, dec
         if decoder == "TRANSE":
             pytest.skip("the L2 comparator always takes the generic kernels")
         monkeypatch.setenv("MARIUS_NO_VLOG", "1")
+        H.reload_env()
     U, R, margin = max(40, B), 11, 0.7
     emb, state, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=B + d + len(loss))
     want = O.train_batch(decoder, emb, state, edges, dst_neg, src_neg, rel, inv if use_inverse else None, reduction=reduction, loss=loss, margin=margin)

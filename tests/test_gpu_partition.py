@@ -409,6 +409,8 @@ def test_one_buffer_state_with_ten_million_active_edges(M, dev, tmp_path, monkey
     results = []
     for tag, fused_fixup in (("a", "1"), ("b", "0")):
         monkeypatch.setenv("MARIUS_SEG_FUSED_FIXUP", fused_fixup)
+        from marius_amd import hip as _hip
+        _hip.reload_env()
         fe, fs = str(tmp_path / (tag + "_emb.bin")), str(tmp_path / (tag + "_state.bin"))
         P.write_table(fe, table.numpy())
         P.write_table(fs, np.zeros((num_nodes, d), dtype=np.float32))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # cfg5 at Twitter-2010's real size: 41,652,230 nodes x d = 400 (66.6 GB + 66.6 GB Adagrad state), 1.47 B synthetic edges, 16 partitions of which 8 resident.
-# usage (GPU box): bash tools/gpu_session_cfg5.sh <tag> [edges]    -> gpurun_out/<tag>/{partition_cfg5.json, bench_twitter.json}
+# usage (GPU box): bash tools/sessions/gpu_session_cfg5.sh <tag> [edges]    -> gpurun_out/<tag>/{partition_cfg5.json, bench_twitter.json}
 tag=${1:-cfg5}; edges=${2:-1470000000}
 ulimit -c 0
 out=gpurun_out/$tag; mkdir -p $out

@@ -1,10 +1,8 @@
 #!/bin/bash
-# end-of-round evidence: whole GPU suite, smoke, default bench line, kernel stats + PMC traffic + one-step timeline of the default command,
-# forced-sharded world-1 line, cfg5-shaped (twitter) line.   usage (GPU box): bash tools/gpu_session_final.sh <tag>
-tag=${1:-final}
-bash tools/gpu_session_full.sh $tag
-bash tools/gpu_session_profile.sh ${tag}_prof
-bash tools/gpu_session_timeline.sh ${tag}_tl
+# profile + timeline + the twitter / degree-fraction lines of the final code (the second half of tools/gpu_session_final.sh):  bash tools/sessions/gpu_session_evidence.sh
+tag=r4fin2; mkdir -p gpurun_out/$tag
+bash tools/sessions/gpu_session_profile.sh ${tag}_prof
+bash tools/sessions/gpu_session_timeline.sh ${tag}_tl
 timeout 200 python bench.py --workload twitter --no-arith-check --no-cpu-baseline > gpurun_out/$tag/bench_twitter.json 2> gpurun_out/$tag/bench_twitter.err
 timeout 200 python bench.py --steps 100 --degree-fraction 0.5 --no-arith-check --no-cpu-baseline --no-fp32-pass > gpurun_out/$tag/bench_f05.json 2> gpurun_out/$tag/bench_f05.err
 python - <<PY

@@ -1,6 +1,6 @@
 #!/bin/bash
 # whole GPU suite (all failures listed, not -x) + the printed arithmetic pairs + smoke + bench lines (default, forced-sharded world 1)
-# usage (GPU box): bash tools/gpu_session_full.sh <tag>   -> gpurun_out/<tag>/
+# usage (GPU box): bash tools/sessions/gpu_session_full.sh <tag>   -> gpurun_out/<tag>/
 tag=${1:-full}
 ulimit -c 0
 mkdir -p gpurun_out/$tag

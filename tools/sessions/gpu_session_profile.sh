@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence of the default bench command: kernel trace + stats, then FETCH_SIZE / WRITE_SIZE in separate --pmc passes.
-# usage (GPU box): bash tools/gpu_session_profile.sh <tag>     -> gpurun_out/<tag>/{bench.json, kernel_stats.txt, pmc_traffic.json}
+# usage (GPU box): bash tools/sessions/gpu_session_profile.sh <tag>     -> gpurun_out/<tag>/{bench.json, kernel_stats.txt, pmc_traffic.json}
 tag=${1:-r3}
 ulimit -c 0
 export TMPDIR=/tmp

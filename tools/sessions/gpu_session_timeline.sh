@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-stream timeline of one steady-state step of the default bench command (rocprofv3 kernel trace -> tools/trace_gaps.py)
-# usage (GPU box): bash tools/gpu_session_timeline.sh <tag> [bench args]   -> gpurun_out/<tag>/timeline.txt
+# usage (GPU box): bash tools/sessions/gpu_session_timeline.sh <tag> [bench args]   -> gpurun_out/<tag>/timeline.txt
 tag=${1:-tl}; shift
 ulimit -c 0
 export TMPDIR=/tmp
