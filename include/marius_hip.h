@@ -213,14 +213,19 @@ int64_t marius_a2a_capacity(int64_t max_rows, int32_t world, double slack);
  * points by owner (marius_owner_offsets).  Writes req_send[world * cap]: block q = (cap - cnt_q) entries of -1 followed by the cnt_q LOCAL
  * row ids (global - q * shard_rows) asked of owner q, ascending; place[u] = slot of unique index u in that layout (the row of u in the
  * row payload the owners send back, and the row its gradient is written to on the way out: marius_segment_sum_rows_planned's out_rows);
- * *overflow_flag |= 1 if some cnt_q > cap (the caller must not use the batch: raise the slack). */
+ * *overflow_flag |= 1 if some cnt_q > cap (the caller must not use the batch: raise the slack).  Optional (n_occ > 0): slot_of_occ[i] =
+ * place[inverse[i]] for the n_occ occurrences of map_tensors (inverse of marius_sort_unique) — the batch's local indices in slot terms
+ * (marius_remap_edges with it gives Batch::edges_, its tail the negatives' mappings), so that the decoder reads the received row payload
+ * IN PLACE instead of a compacted copy. */
 int marius_a2a_rows_post(const int64_t* uniq, const int64_t* owner_offsets, int64_t shard_rows, int32_t world, int64_t cap, int64_t* req_send,
-                         int64_t* place, int32_t* overflow_flag, marius_stream_t stream);
-/* Requester, after the row all-to-all: emb[u, 0:d] = rows_recv[place[u], 0:d] for u < *num_unique_dev (batch order: what Batch::
- * node_embeddings_ holds), and *absmax = max(*absmax, max |x| of the moved rows) when absmax != NULL (marius_lp_desc.absmax of the batch:
- * the rows came from every rank's shard, the requester bounds what it received).  capacity = rows of emb. */
-int marius_a2a_rows_wait(const float* rows_recv, int64_t recv_ld, const int64_t* place, const int64_t* num_unique_dev, int64_t capacity, int32_t d,
-                         float* emb, int64_t emb_ld, float* absmax, marius_stream_t stream);
+                         int64_t* place, int32_t* overflow_flag, const int64_t* inverse, int64_t n_occ, int64_t* slot_of_occ, marius_stream_t stream);
+/* Requester, after the row all-to-all: *absmax = max(*absmax, max |x| over the `rows` = world * cap rows of the payload) when absmax != NULL
+ * (marius_lp_desc.absmax of the batch: the rows came from every rank's shard, the requester bounds what it received; the buffer must have
+ * been zero-initialised once: unused slots keep rows of earlier batches).  With emb != NULL it also leaves a copy in batch order —
+ * emb[u, 0:d] = rows_recv[place[u], 0:d] for u < *num_unique_dev (what Batch::node_embeddings_ holds in the reference; capacity = rows of
+ * emb) — for callers that did not rewrite their indices; the bound then covers exactly the copied rows. */
+int marius_a2a_rows_wait(const float* rows_recv, int64_t recv_ld, int64_t rows, int32_t d, float* absmax, const int64_t* place,
+                         const int64_t* num_unique_dev, int64_t capacity, float* emb, int64_t emb_ld, marius_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ decoder */
 
@@ -253,7 +258,9 @@ typedef struct marius_lp_desc {
     int32_t loss;         /* MARIUS_LOSS_* (0 = SoftmaxCrossEntropy: a zero-initialised descriptor keeps its old meaning) */
     float margin;         /* RankingLoss margin (loss.h:43-55) */
     int32_t flags;        /* MARIUS_LP_* (0 = the API contract: adj / pos / neg are all materialised) */
-    int32_t reserved_;
+    int32_t free_cus;     /* flash path: compute units the persistent matrix launches of this batch leave WITHOUT a workgroup, for kernels the caller
+                           * runs beside them on other streams (the sharded trainer's row exchange and batch preparation); 0 = only what the
+                           * workgroup-count rule leaves anyway.  Results do not depend on it. */
     /* Optional, flash path only: DEVICE float[2] = { bound on |entries of the node table the batch rows come from|, bound on |entries of the
      * relation tables| } (any upper bound; marius_table_absmax computes one, the *_tracked Adagrad entry points keep it current).  When
      * given, the operand records hold fp16 halves of power-of-two scaled rows (22 significand bits per operand) instead of bf16 halves

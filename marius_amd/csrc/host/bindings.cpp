@@ -414,6 +414,7 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_property_readonly("useful_rows", [](ShardedTrainer& t) { return std::vector<int64_t>(t.useful_rows_, t.useful_rows_ + 2); })
         .def_property_readonly("phase_seconds", [](ShardedTrainer& t) { return std::vector<double>(t.phase_seconds_, t.phase_seconds_ + 6); })
         .def("enable_spans", &ShardedTrainer::enable_spans)
+        .def("reset_counters", &ShardedTrainer::reset_counters)
         .def_property_readonly("span_ms", [](ShardedTrainer& t) {
             std::vector<double> v(7, 0.0);
             for (int k = 0; k < 7; ++k) v[k] = t.span_n_[k] ? t.span_ms_[k] / (double)t.span_n_[k] : 0.0;

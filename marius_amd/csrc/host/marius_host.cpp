@@ -433,6 +433,7 @@ static void lp_setup(LpContext& ctx, shared_ptr<EdgeDecoder> dec, const Tensor& 
     d.loss = loss_kind;
     d.margin = margin;
     d.flags = lp_flags;
+    d.free_cus = (lp_flags & MARIUS_LP_TRAIN_ONLY) ? ctx.free_cus : 0;
     d.absmax = (ctx.absmax.defined() && (lp_flags & MARIUS_LP_TRAIN_ONLY)) ? ctx.absmax.data_ptr<float>() : nullptr;
     d.absmax_rel = (d.absmax && ctx.absmax_rel.defined()) ? ctx.absmax_rel.data_ptr<float>() : nullptr;
     Tensor e = edges.contiguous(), dn = dst_negs.contiguous(), sn = src_negs.defined() ? src_negs.contiguous() : Tensor();

@@ -299,6 +299,7 @@ struct LpContext {
     bool has_loss = false;
     Tensor absmax;             // optional device float (marius_lp_desc.absmax): bound on the node rows the step reads; set per step by Model::bind_ranges, used only with MARIUS_LP_TRAIN_ONLY
     Tensor absmax_rel;         // optional device float[1] (marius_lp_desc.absmax_rel); undefined: absmax is float[2] and holds both
+    int free_cus = 0;          // marius_lp_desc.free_cus of the training forward (set by a trainer that runs other streams beside the matrix launches)
     Tensor view(size_t off, std::vector<int64_t> shape, std::vector<int64_t> strides = {}) const;
 };
 

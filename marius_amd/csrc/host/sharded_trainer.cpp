@@ -18,6 +18,7 @@ namespace marius_amd {
     } while (0)
 
 namespace {
+double g_fine[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // MARIUS_SHARDED_FINE=1: host seconds inside prepare() — wait event, prepareBatch, offsets + post, copies + stamp, event record
 struct Phase {  // adds the enclosed host time to one slot of ShardedTrainer::phase_seconds_
     double& acc;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -67,8 +68,10 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
     prep_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(/*isHighPriority=*/true, dev.index()));
     xchg_stream_ = new c10::hip::HIPStream(staleness_ ? c10::hip::getStreamFromPool(/*isHighPriority=*/true, dev.index()) : strm(main_stream_));
     {
-        const char* e = getenv("MARIUS_EXCHANGE");  // exact: all-to-all(v) with host split sizes (rounds 1-4); default: fixed capacity
-        fixed_ = !(e && e[0] == 'e');
+        // exact (default): all-to-all(v), split sizes read from pinned memory a few steps after the device wrote them; fixed: fixed-capacity
+        // equal-split payloads, nothing read on the host (sharded_trainer.h: measured, 25 % more rows through every exchange stage at world 1)
+        const char* e = getenv("MARIUS_EXCHANGE");
+        fixed_ = e && e[0] == 'f';
         const char* sl = getenv("MARIUS_EXCHANGE_SLACK");  // planned maximum per (requester, owner) pair = slack * capacity / world (world > 1)
         if (sl && atof(sl) >= 1.0) slack_ = atof(sl);
     }
@@ -90,6 +93,21 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
     }
     loader_->run_ahead_ = false;
     loader_->num_relations_ = model_->decoder_->num_relations_;
+    // The exchange and preparation streams carry ~0.9 GB of row traffic per step in kernels that can only run where the persistent matrix
+    // launches leave a CU free: 32 CUs without a flash workgroup (400 instead of 480 workgroups at the bench shape: whole tiles, no split tile)
+    // cost the matrix launches 4 % and take the step from 0.726 to 0.696 ms at world 1 (sweep 0 / 16 / 32 / 48 / 64 / 96: profiles/r5_sharded_free_cus.txt)
+    {
+        const char* e = getenv("MARIUS_SHARDED_FREE_CUS");
+        model_->ctx_.free_cus = e ? atoi(e) : 32;
+    }
+    // The MT19937 words are produced on the preparation stream itself, request by request: the run-ahead pool's own stream is a FIFTH stream
+    // beside compute / preparation / exchange / RCCL, and with the runtime's four hardware queues it lands on the compute stream's queue — its
+    // 0.9 ms single-workgroup fill then stands in front of the matrix launches every eighth batch (0.845 vs 0.763 ms per step, world 1); a fifth
+    // hardware queue (GPU_MAX_HW_QUEUES=5) is worse still (1.20 ms).  profiles/r5_sharded_streams.txt
+    if (loader_->generator_) {
+        static const bool pool_env = [] { const char* e = getenv("MARIUS_MT_PREFETCH"); return e && e[0] == '1'; }();
+        loader_->generator_->prefetch_ = pool_env;
+    }
     {
         Scope scope(strm(main_stream_));  // the permutation upload is ordered before the first preparation (which waits for this stream)
         loader_->initializeBatches(true);
@@ -189,7 +207,10 @@ void ShardedTrainer::prepare(int64_t t) {
     span_collect(s);
     auto& prep = strm(prep_stream_);
     const auto dev_index = table_.device().index();
-    if (s.used) retire(s);
+    if (s.used) {
+        Phase pw(phase_seconds_[1]);  // (fixed-capacity form: the only place the loop can wait — for a preparation issued RING steps ago)
+        retire(s);
+    }
     if (s.used) {
         ST_HIPCHECK(hipStreamWaitEvent(prep.stream(), (hipEvent_t)s.free_, 0));  // the batch that used this slot RING steps ago is fully retired
     } else {
@@ -204,7 +225,11 @@ void ShardedTrainer::prepare(int64_t t) {
         Scope scope(prep);
         const int64_t B = loader_->batch_size_;
         if ((loader_->batch_id_ + 1) * B > loader_->num_edges_) loader_->initializeBatches(true);  // next epoch: a new permutation (full batches only)
-        s.batch = loader_->prepareBatch(/*exact_unique=*/false);
+        {
+            Phase pf(g_fine[1]);
+            s.batch = loader_->prepareBatch(/*exact_unique=*/false);
+        }
+        Phase pf2(g_fine[2]);
         mcheck(marius_owner_offsets(s.batch->unique_node_indices_.data_ptr<int64_t>(), s.batch->num_unique_dev_.data_ptr<int64_t>(), S_, world_,
                                     s.offs_dev.data_ptr<int64_t>(), (marius_stream_t)prep.stream()));
         s.offs_host.copy_(s.offs_dev, /*non_blocking=*/true);
@@ -214,8 +239,18 @@ void ShardedTrainer::prepare(int64_t t) {
             setup_fixed(s, s.batch->occ_perm_.size(0));
             s.overflow_dev.zero_();
             mcheck(marius_a2a_rows_post(s.batch->unique_node_indices_.data_ptr<int64_t>(), s.offs_dev.data_ptr<int64_t>(), S_, world_, cap_,
-                                        s.req_send.data_ptr<int64_t>(), s.place.data_ptr<int64_t>(), s.overflow_dev.data_ptr<int32_t>(), (marius_stream_t)prep.stream()));
+                                        s.req_send.data_ptr<int64_t>(), s.place.data_ptr<int64_t>(), s.overflow_dev.data_ptr<int32_t>(),
+                                        s.batch->occ_inverse_.data_ptr<int64_t>(), L_, s.slot_of_occ.data_ptr<int64_t>(), (marius_stream_t)prep.stream()));
             s.overflow_host.copy_(s.overflow_dev, /*non_blocking=*/true);
+            // the batch's local indices in slot terms (dataloader.cpp:460-466 with place o inverse instead of inverse): the decoder then reads
+            // the row payload where the all-to-all left it — no compacted [U, d] copy
+            const int64_t Bb = s.batch->global_edges_.size(0), cols = s.batch->global_edges_.size(1), CN = s.batch->src_neg_indices_.numel();
+            if (!s.edges_slot.defined() || s.edges_slot.size(0) != Bb) s.edges_slot = torch::empty({Bb, cols}, s.batch->global_edges_.options());
+            mcheck(marius_remap_edges(s.batch->global_edges_.data_ptr<int64_t>(), s.slot_of_occ.data_ptr<int64_t>(), Bb, (int32_t)cols, s.edges_slot.data_ptr<int64_t>(),
+                                      (marius_stream_t)prep.stream()));
+            s.batch->edges_ = s.edges_slot;
+            s.batch->src_neg_indices_mapping_ = s.slot_of_occ.narrow(0, 2 * Bb, CN).view(s.batch->src_neg_indices_.sizes());
+            s.batch->dst_neg_indices_mapping_ = s.slot_of_occ.narrow(0, 2 * Bb + CN, CN).view(s.batch->dst_neg_indices_.sizes());
         } else {
         // The receive counts of the all-to-all(v) travel on the device as well: a `world`-integer all-to-all of the send counts on this
         // (preparation) stream, read back together with the split points behind the same `ready` event.  No host round trip (the
@@ -279,7 +314,6 @@ void ShardedTrainer::setup_fixed(Slot& s, int64_t L) {
         for (int q = 0; q <= world_; ++q) run_offsets_[q] = (int64_t)q * cap_;
         req_recv_ = torch::empty({ncap_}, i64o);
         rows_send_ = torch::empty({ncap_, d_}, f32o);
-        rows_recv_ = torch::empty({ncap_, d_}, f32o);
         grad_recv_ = torch::empty({ncap_, d_}, f32o);
         r_ws_ = torch::zeros({(int64_t)marius_sort_unique_workspace_bytes(ncap_)}, u8o);
         r_carry_ = torch::empty({(int64_t)marius_segment_carry_bytes(ncap_, d_)}, u8o);
@@ -288,8 +322,9 @@ void ShardedTrainer::setup_fixed(Slot& s, int64_t L) {
     if (s.req_send.defined()) return;
     s.req_send = torch::empty({ncap_}, i64o);
     s.place = torch::empty({L_}, i64o);
+    s.slot_of_occ = torch::empty({L_}, i64o);
     s.grad_send = torch::empty({ncap_, d_}, f32o);
-    s.emb = torch::empty({L_, d_}, f32o);
+    s.emb = torch::zeros({ncap_, d_}, f32o);  // the row payload as received (zeroed ONCE: unused slots then hold finite values for the bound scan)
     s.r_uniq = torch::empty({ncap_}, i64o);
     s.r_inverse = torch::empty({ncap_}, i64o);
     s.r_perm = torch::empty({ncap_}, i32o);
@@ -318,12 +353,13 @@ void ShardedTrainer::fetch_fixed(int64_t t) {
                                   rows_send_.stride(0), st));
         span_end(s, 5, xchg_stream_);
         span_begin(s, 6, xchg_stream_);
-        pg_->alltoall_base(rows_recv_, rows_send_, none, none)->wait();
+        pg_->alltoall_base(s.emb, rows_send_, none, none)->wait();
         span_end(s, 6, xchg_stream_);
-        // requester: rows into batch order + their magnitude bound (marius_lp_desc.absmax: fp16 operand halves), one pass
-        if (Model::flash_f16_enabled()) s.row_bound.zero_();
-        mcheck(marius_a2a_rows_wait(rows_recv_.data_ptr<float>(), rows_recv_.stride(0), s.place.data_ptr<int64_t>(), s.batch->num_unique_dev_.data_ptr<int64_t>(), L_,
-                                    d_, s.emb.data_ptr<float>(), s.emb.stride(0), Model::flash_f16_enabled() ? s.row_bound.data_ptr<float>() : nullptr, st));
+        // requester: magnitude bound of the received payload (marius_lp_desc.absmax: fp16 operand halves); the rows are scored where they landed
+        if (Model::flash_f16_enabled()) {
+            s.row_bound.zero_();
+            mcheck(marius_a2a_rows_wait(s.emb.data_ptr<float>(), s.emb.stride(0), ncap_, d_, s.row_bound.data_ptr<float>(), nullptr, nullptr, 0, nullptr, 0, st));
+        }
         // owner: the received id payload is `world` non-decreasing runs of cap slots (-1 padding first): merge them and plan the segmented
         // update NOW — the ids are here a whole scoring pass before the gradients
         mcheck(marius_merge_unique_runs(req_recv_.data_ptr<int64_t>(), ncap_, run_offsets_.data(), world_, s.r_uniq.data_ptr<int64_t>(), s.r_inverse.data_ptr<int64_t>(),
@@ -416,6 +452,7 @@ void ShardedTrainer::fetch(int64_t t) {
         // collective.  One float per slot: the scoring of batch t reads its slot's bound while batch t + 1's is being written.
         if (s.U > 0 && Model::flash_f16_enabled())
             mcheck(marius_table_absmax(s.emb.data_ptr<float>(), s.U, s.emb.stride(0), d_, s.row_bound.data_ptr<float>(), (marius_stream_t)xchg.stream()));
+        plan_local(s);  // the owner's merge + segment plan of this batch's update: the ids are here a scoring pass before the gradients
     }
     span_end(s, 1, xchg_stream_);
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.fetched, xchg.stream()));
@@ -456,36 +493,64 @@ void ShardedTrainer::compute(int64_t t) {
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.computed, main.stream()));
 }
 
-// owner side: a row may have been requested by several ranks -> sort / unique the received ids, sum per row, one Adagrad step per row
-void ShardedTrainer::apply_local(const Tensor& local_ids, const Tensor& grads, const std::vector<int64_t>& recv_counts) {
-    const int64_t n = local_ids.size(0);
+// owner side: a row may have been requested by several ranks -> merge the senders' ascending id runs, sum per row, one Adagrad step per row.
+// plan_local runs when the IDS arrive (fetch: a scoring pass before the gradients), apply_local when the gradients do: one grouped launch pair.
+void ShardedTrainer::plan_local(Slot& s) {
+    const int64_t n = s.local_ids.size(0);
     if (n == 0) return;
     const auto dev = table_.device();
-    if (r_cap_ < n) {
+    auto i64o = torch::TensorOptions().dtype(torch::kInt64).device(dev), i32o = torch::TensorOptions().dtype(torch::kInt32).device(dev);
+    auto u8o = torch::TensorOptions().dtype(torch::kUInt8).device(dev);
+    if (!s.r_uniq.defined() || s.r_uniq.size(0) < n) {  // per slot: the plan of batch t + 1 is written while the update of batch t still reads its own
+        const int64_t cap = std::max<int64_t>(n + n / 2, 1024);
+        s.r_uniq = torch::empty({cap}, i64o);
+        s.r_inverse = torch::empty({cap}, i64o);
+        s.r_perm = torch::empty({cap}, i32o);
+        s.r_seg = torch::empty({cap + 1}, i32o);
+        s.r_count = torch::zeros({1}, i64o);
+        s.r_plan = torch::empty({(int64_t)marius_segment_plan_bytes(cap)}, u8o);
+    }
+    if (r_cap_ < n) {  // shared scratch: the merge workspace (used inside fetch only) and the update's carries (inside update only)
         r_cap_ = std::max<int64_t>(n + n / 2, 1024);
-        auto i64o = torch::TensorOptions().dtype(torch::kInt64).device(dev), i32o = torch::TensorOptions().dtype(torch::kInt32).device(dev);
-        r_uniq_ = torch::empty({r_cap_}, i64o);
-        r_inverse_ = torch::empty({r_cap_}, i64o);
-        r_perm_ = torch::empty({r_cap_}, i32o);
-        r_seg_ = torch::empty({r_cap_ + 1}, i32o);
-        r_count_ = torch::zeros({1}, i64o);
-        r_ws_ = torch::zeros({(int64_t)marius_sort_unique_workspace_bytes(r_cap_)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
-        r_carry_ = torch::empty({(int64_t)marius_segment_carry_bytes(r_cap_, d_)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+        r_ws_ = torch::zeros({(int64_t)marius_sort_unique_workspace_bytes(r_cap_)}, u8o);
+        r_carry_ = torch::empty({(int64_t)marius_segment_carry_bytes(r_cap_, d_)}, u8o);
     }
     auto st = cur_stream();
     // every sender's list is ascending and duplicate-free: merge the `world` runs (binary searches) instead of radix-sorting them
-    std::vector<int64_t> runs(recv_counts.size() + 1, 0);
-    for (size_t q = 0; q < recv_counts.size(); ++q) runs[q + 1] = runs[q] + recv_counts[q];
-    if ((int)recv_counts.size() <= 64)
-        mcheck(marius_merge_unique_runs(local_ids.data_ptr<int64_t>(), n, runs.data(), (int32_t)recv_counts.size(), r_uniq_.data_ptr<int64_t>(),
-                                        r_inverse_.data_ptr<int64_t>(), r_perm_.data_ptr<int32_t>(), r_seg_.data_ptr<int32_t>(), r_count_.data_ptr<int64_t>(),
+    std::vector<int64_t> runs(s.recv_counts.size() + 1, 0);
+    for (size_t q = 0; q < s.recv_counts.size(); ++q) runs[q + 1] = runs[q] + s.recv_counts[q];
+    if ((int)s.recv_counts.size() <= 64)
+        mcheck(marius_merge_unique_runs(s.local_ids.data_ptr<int64_t>(), n, runs.data(), (int32_t)s.recv_counts.size(), s.r_uniq.data_ptr<int64_t>(),
+                                        s.r_inverse.data_ptr<int64_t>(), s.r_perm.data_ptr<int32_t>(), s.r_seg.data_ptr<int32_t>(), s.r_count.data_ptr<int64_t>(),
                                         r_ws_.data_ptr(), (size_t)r_ws_.numel(), st));
     else
-        mcheck(marius_sort_unique(local_ids.data_ptr<int64_t>(), n, key_bits(table_.size(0)), r_uniq_.data_ptr<int64_t>(), r_inverse_.data_ptr<int64_t>(),
-                                  r_perm_.data_ptr<int32_t>(), r_seg_.data_ptr<int32_t>(), r_count_.data_ptr<int64_t>(), r_ws_.data_ptr(), (size_t)r_ws_.numel(), st));
-    mcheck(marius_segment_adagrad_scatter(grads.data_ptr<float>(), grads.stride(0), r_perm_.data_ptr<int32_t>(), r_inverse_.data_ptr<int64_t>(),
-                                          r_seg_.data_ptr<int32_t>(), n, d_, r_uniq_.data_ptr<int64_t>(), table_.data_ptr<float>(), state_.data_ptr<float>(),
-                                          table_.stride(0), model_->sparse_lr_, 1e-10f, r_carry_.data_ptr(), st));
+        mcheck(marius_sort_unique(s.local_ids.data_ptr<int64_t>(), n, key_bits(table_.size(0)), s.r_uniq.data_ptr<int64_t>(), s.r_inverse.data_ptr<int64_t>(),
+                                  s.r_perm.data_ptr<int32_t>(), s.r_seg.data_ptr<int32_t>(), s.r_count.data_ptr<int64_t>(), r_ws_.data_ptr(), (size_t)r_ws_.numel(), st));
+    // (the plan's size is part of its layout: it is written and read with the same n)
+    mcheck(marius_segment_plan(s.r_perm.data_ptr<int32_t>(), s.r_inverse.data_ptr<int64_t>(), s.r_seg.data_ptr<int32_t>(), s.r_uniq.data_ptr<int64_t>(), n,
+                               s.r_plan.data_ptr(), st));
+}
+
+void ShardedTrainer::apply_local(Slot& s, const Tensor& grads) {
+    const int64_t n = s.local_ids.size(0);
+    if (n == 0) return;
+    marius_segment_update u = {};
+    u.rows = grads.data_ptr<float>();
+    u.rows_ld = grads.stride(0);
+    u.perm = s.r_perm.data_ptr<int32_t>();
+    u.inverse = s.r_inverse.data_ptr<int64_t>();
+    u.seg_offsets = s.r_seg.data_ptr<int32_t>();
+    u.n = n;
+    u.d = d_;
+    u.uniq_ids = s.r_uniq.data_ptr<int64_t>();
+    u.table = table_.data_ptr<float>();
+    u.state = state_.data_ptr<float>();
+    u.table_ld = table_.stride(0);
+    u.lr = model_->sparse_lr_;
+    u.eps = 1e-10f;
+    u.carry = r_carry_.data_ptr();
+    u.plan = s.r_plan.data_ptr();
+    mcheck(marius_segment_adagrad_scatter_group(&u, 1, cur_stream()));  // (falls back to the planned single-table launches where the grouped form does not apply)
 }
 
 // stage 4 (exchange stream): gradients -> owners, owners update their rows
@@ -499,7 +564,7 @@ void ShardedTrainer::update(int64_t t) {
     {
         Scope scope(xchg);
         Tensor recv_grad = a2a(s.grad, s.send_counts, s.recv_counts, view(buf_recv_grad_, s.nrecv, {d_}, torch::kFloat32));
-        apply_local(s.local_ids, recv_grad, s.recv_counts);
+        apply_local(s, recv_grad);
     }
     span_end(s, 3, xchg_stream_);
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.free_, xchg.stream()));
@@ -553,6 +618,9 @@ void ShardedTrainer::train_steps(int64_t n) {
 
 void ShardedTrainer::finish() {
     ST_HIPCHECK(hipDeviceSynchronize());
+    if (getenv("MARIUS_SHARDED_FINE"))
+        fprintf(stderr, "[sharded fine] per step ms: prepareBatch %.4f, rest of prepare %.4f (steps %ld)\n", g_fine[1] / std::max<int64_t>(steps_, 1) * 1e3,
+                g_fine[2] / std::max<int64_t>(steps_, 1) * 1e3, (long)steps_);
     for (auto& s : slots_)
         if (s.used && fixed_ && *s.overflow_host.data_ptr<int32_t>() != 0)
             throw MariusRuntimeException("ShardedTrainer: a batch asked one owner for more than the planned maximum of " + std::to_string(cap_) +

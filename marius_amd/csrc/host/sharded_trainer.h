@@ -6,13 +6,21 @@
 // Collectives go through torch.distributed's C++ layer (c10d::ProcessGroup), looked up by name (c10d::resolve_process_group), so nothing but
 // a string crosses the Python boundary.
 //
-// Round 5: FIXED-CAPACITY exchange (the default; MARIUS_EXCHANGE=exact selects the all-to-all(v) form of rounds 1-4).  Every (requester, owner)
-// pair owns `cap` slots of each payload — marius_a2a_capacity: the batch's id capacity at world 1, slack x capacity / world otherwise — the three
-// payloads (ids, rows, gradients) travel by equal-split all-to-alls, and the counts ride in the id payload as -1 padding (exchange.hip,
-// include/marius_hip.h marius_a2a_rows_{post,wait}).  No split size is needed on the host, so the training loop never reads the device: round
-// 4's loop spent 0.35-0.45 ms of every 0.83 ms step in hipEventSynchronize for the split points (profiles/r4_bench_sharded_w1.json).  The owner
-// merges the `world` id runs and plans its segmented update when the IDS arrive — a step before the gradients do — so the update itself is one
-// grouped launch pair (marius_segment_adagrad_scatter_group) behind the gradient all-to-all.
+// Round 5: two forms of the exchange, same schedule.
+//   exact (default)  all-to-all(v): the split sizes of a batch are written to pinned memory by its preparation, AHEAD steps before the exchange
+//                    needs them, together with a stamp the loop polls (no hipEventSynchronize: see Slot::stamp_host).
+//   fixed            (MARIUS_EXCHANGE=fixed) FIXED-CAPACITY payloads: every (requester, owner) pair owns `cap` slots of each payload —
+//                    marius_a2a_capacity: the batch's id capacity at world 1, slack x capacity / world otherwise — the three payloads (ids, rows,
+//                    gradients) travel by equal-split all-to-alls, the counts ride in the id payload as -1 padding (exchange.hip,
+//                    marius_a2a_rows_{post,wait}), the decoder scores the row payload where it landed (the batch's local indices are rewritten to
+//                    payload slots), and the owner plans its segmented update when the IDS arrive, a scoring pass before the gradients.  The host
+//                    reads nothing from the device.
+// Measured at world 1 (profiles/r5_sharded_exchange_forms.txt): what round 4 read as "the loop blocks 0.35-0.45 ms per step for split points" is
+// BACK-PRESSURE — the host runs ahead of a device that is the bottleneck, and blocks at whatever its first dependence on the device is; with the
+// fixed form that dependence is gone and the loop blocks the same 0.25-0.4 ms at the slot-reuse check instead, while every exchange stage moves
+// 25 % more rows (capacity 200,000 against 159,000 unique ids per batch): 0.757-0.79 ms per step against 0.696-0.73 exact.  On xGMI the padding
+// would be wire bytes (slack 1.5: +50 %).  So the exact form stays the default and the fixed form is kept, tested at world 1 / 2 / 8, for
+// transports or hosts where a per-batch read-back is not to be had.
 #pragma once
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 
@@ -55,6 +63,13 @@ class ShardedTrainer {
     int64_t span_n_[7] = {0, 0, 0, 0, 0, 0, 0};
     bool spans_ = false;
     void enable_spans(bool on) { spans_ = on; }
+    void reset_counters() {  // after a warm-up: its first steps carry one-time costs (allocations, code-object loads, collective setup)
+        host_seconds_ = 0;
+        for (auto& p : phase_seconds_) p = 0;
+        steps_ = 0;
+        exchange_bytes_[0] = exchange_bytes_[1] = exchange_bytes_[2] = 0;
+        useful_rows_[0] = useful_rows_[1] = 0;
+    }
 
    private:
     struct Slot {
@@ -80,6 +95,7 @@ class ShardedTrainer {
         int64_t stamp_value = 0;
         // fixed-capacity exchange
         Tensor req_send, place;             // [world * cap] ids asked of every owner (-1 padded), [L] slot of unique index u
+        Tensor slot_of_occ, edges_slot;     // [L] payload slot of every occurrence, [B, cols] Batch::edges_ in slot terms: the decoder reads the row payload in place
         Tensor overflow_dev, overflow_host;  // int32: some owner was asked for more than cap rows (checked when the slot is reused)
         Tensor grad_send;                   // [world * cap, d] per-row gradients in the owners' slot order
         Tensor r_uniq, r_inverse, r_perm, r_seg, r_count, r_plan;  // owner side: merged runs of the received ids + their segment plan
@@ -99,13 +115,13 @@ class ShardedTrainer {
     // grow-only buffers (per-step sizes vary with the number of unique ids)
     Tensor buf_req_, buf_rows_, buf_recv_grad_, emb_[RING], grad_[RING], local_[RING];
     // owner-side dedupe of the received ids
-    Tensor r_uniq_, r_inverse_, r_perm_, r_seg_, r_count_, r_ws_, r_carry_;
+    Tensor r_ws_, r_carry_;
     int64_t r_cap_ = 0;
     // fixed-capacity exchange: shared staging (each is produced and consumed inside one stage on the exchange stream)
-    bool fixed_ = true;
+    bool fixed_ = false;
     double slack_ = 1.5;
     int64_t L_ = 0, cap_ = 0, ncap_ = 0;  // id capacity of a batch, slots per pair, slots per payload (world * cap)
-    Tensor req_recv_, rows_send_, rows_recv_, grad_recv_;
+    Tensor req_recv_, rows_send_, grad_recv_;
     std::vector<int64_t> run_offsets_;  // q * cap: the `world` runs of a received id payload
     void setup_fixed(Slot& s, int64_t L);
     void fetch_fixed(int64_t t);
@@ -122,7 +138,8 @@ class ShardedTrainer {
     void compute(int64_t t);
     void update(int64_t t);
     void dense(int64_t t);
-    void apply_local(const Tensor& local_ids, const Tensor& grads, const std::vector<int64_t>& recv_counts);
+    void plan_local(Slot& s);
+    void apply_local(Slot& s, const Tensor& grads);
     Tensor a2a(const Tensor& in, const std::vector<int64_t>& send_counts, const std::vector<int64_t>& recv_counts, Tensor out);
     void prime();
     void span_begin(Slot& s, int stage, void* stream);

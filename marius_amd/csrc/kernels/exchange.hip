@@ -15,8 +15,9 @@
 //                                               marius_gather_rows(shard, req_recv) -> rows_send            (negative ids skipped)
 //                                               marius_merge_unique_runs(req_recv: world runs of cap) + marius_segment_plan   (a step ahead of the gradients)
 //   (all-to-all float [world x cap x d])
-//   marius_a2a_rows_wait   rows_recv -> emb [U, d] in batch order + their magnitude bound
-//   ... forward / backward ... marius_segment_sum_rows_planned(out_rows = place) -> grad_send [world x cap x d]
+//   marius_a2a_rows_wait   magnitude bound of the received rows (and, on request, a copy in batch order)
+//   ... forward / backward on rows_recv IN PLACE: the batch's local indices were rewritten to payload slots by the post call ...
+//   marius_segment_sum_rows_planned(out_rows = place) -> grad_send [world x cap x d]
 //   (all-to-all float [world x cap x d])
 //                                               marius_segment_adagrad_scatter_group(rows = grad_recv, the plan above)
 //
@@ -45,6 +46,13 @@ __global__ __launch_bounds__(256) void a2a_post_kernel(const int64_t* __restrict
         req_send[i] = uniq[o0 + k] - (int64_t)q * shard_rows;
         place[o0 + k] = i;
     }
+}
+
+// out[i] = place[inverse[i]]: the payload slot of every occurrence (the batch's local indices — edges_, the negatives' mappings — in slot terms, so
+// that the decoder reads the received payload in place instead of a compacted copy of it)
+__global__ __launch_bounds__(256) void a2a_slot_of_occ_kernel(const int64_t* __restrict__ place, const int64_t* __restrict__ inverse, int64_t n, int64_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = place[inverse[i]];
 }
 
 // emb[u] = rows_recv[place[u]] for u < *num_unique; max |x| of the moved rows max'ed into *absmax.  A row's 16-byte pieces map one to one onto
@@ -97,19 +105,31 @@ extern "C" int64_t marius_a2a_capacity(int64_t max_rows, int32_t world, double s
 }
 
 extern "C" int marius_a2a_rows_post(const int64_t* uniq, const int64_t* owner_offsets, int64_t shard_rows, int32_t world, int64_t cap, int64_t* req_send,
-                                    int64_t* place, int32_t* overflow_flag, marius_stream_t stream) {
+                                    int64_t* place, int32_t* overflow_flag, const int64_t* inverse, int64_t n_occ, int64_t* slot_of_occ, marius_stream_t stream) {
     MARIUS_REQUIRE(world >= 1 && cap >= 1 && shard_rows >= 1, "a2a_rows_post: bad sizes world=%d cap=%ld shard_rows=%ld", world, (long)cap, (long)shard_rows);
     MARIUS_REQUIRE(uniq && owner_offsets && req_send && place && overflow_flag, "a2a_rows_post: null pointer");
+    MARIUS_REQUIRE(n_occ == 0 || (inverse && slot_of_occ), "a2a_rows_post: null occurrence map");
     const int64_t n = (int64_t)world * cap;
-    a2a_post_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream)>>>(uniq, owner_offsets, shard_rows, world, cap, req_send, place, overflow_flag);
+    hipStream_t st = as_stream(stream);
+    a2a_post_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(uniq, owner_offsets, shard_rows, world, cap, req_send, place, overflow_flag);
+    if (n_occ > 0) a2a_slot_of_occ_kernel<<<dim3((unsigned)cdiv(n_occ, 256)), dim3(256), 0, st>>>(place, inverse, n_occ, slot_of_occ);
     return check_launch("a2a_rows_post");
 }
 
-extern "C" int marius_a2a_rows_wait(const float* rows_recv, int64_t recv_ld, const int64_t* place, const int64_t* num_unique_dev, int64_t capacity, int32_t d,
-                                    float* emb, int64_t emb_ld, float* absmax, marius_stream_t stream) {
-    MARIUS_REQUIRE(capacity >= 0 && d > 0 && recv_ld >= d && emb_ld >= d, "a2a_rows_wait: bad sizes");
+extern "C" int marius_table_absmax(const float* table, int64_t rows, int64_t ld, int32_t d, float* absmax, marius_stream_t stream);
+
+extern "C" int marius_a2a_rows_wait(const float* rows_recv, int64_t recv_ld, int64_t rows, int32_t d, float* absmax, const int64_t* place,
+                                    const int64_t* num_unique_dev, int64_t capacity, float* emb, int64_t emb_ld, marius_stream_t stream) {
+    MARIUS_REQUIRE(rows >= 0 && d > 0 && recv_ld >= d, "a2a_rows_wait: bad sizes");
+    if (rows == 0) return MARIUS_OK;
+    MARIUS_REQUIRE(rows_recv, "a2a_rows_wait: null pointer");
+    if (!emb) {  // the payload is scored in place: only the bound (unused slots hold rows of earlier batches or the zeros of the first allocation: the
+                 // bound stays an upper bound)
+        if (!absmax) return MARIUS_OK;
+        return marius_table_absmax(rows_recv, rows, recv_ld, d, absmax, stream);
+    }
+    MARIUS_REQUIRE(place && num_unique_dev && capacity >= 0 && emb_ld >= d, "a2a_rows_wait: a batch-order copy needs place, the unique count and its capacity");
     if (capacity == 0) return MARIUS_OK;
-    MARIUS_REQUIRE(rows_recv && place && num_unique_dev && emb, "a2a_rows_wait: null pointer");
     int vec = row_vec_width(rows_recv, recv_ld, d);
     const int v2 = row_vec_width(emb, emb_ld, d);
     vec = vec < v2 ? vec : v2;

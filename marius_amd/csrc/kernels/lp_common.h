@@ -182,7 +182,6 @@ int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj,
                   float* gocc, const int64_t negocc_off[2], float* dadj_zero, const float* pos, float* dadj, float* dadj2, hipStream_t st);
 int flash_merge(const LpDims& D, const float2* part, const float* pos, float* lse, float* rowloss, float* dpos, float* blocksum, char* adjrec,
                 hipStream_t st);
-void flash_set_reserved_cus(int n);
 int flash_backward(const marius_lp_desc* desc, const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2],
                    const float2* part, bool filtered, float* S, hipStream_t st);
 int flash_chunks(int d);   // column chunks of the contraction index: 1 for d <= 128, ceil(d / 128) equal ones above, 0 = not representable

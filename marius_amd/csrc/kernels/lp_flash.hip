@@ -1045,16 +1045,14 @@ bool flash_fused() { return true; }
 // denominator (ties: the larger).  The CUs this leaves without a workgroup (16 of 256 at the bench shape) are not wasted either: the step's
 // other stream — the next batch's sort / sample / plan kernels — otherwise only gets CU slots in the tails of the matrix launches
 // (profiles/r4_timeline_one_step_before_workgroup_rule.txt: a 10 us sort sweep took 117-132 us underneath them).
-// MARIUS_FLASH_RESERVE / marius flash_set_reserved_cus: CUs to leave empty on top of that; MARIUS_FLASH_NWG: the count itself (tests of every
-// split pattern).
-static int g_flash_reserved_cus = 0;
-void flash_set_reserved_cus(int n) { g_flash_reserved_cus = n; }
+// marius_lp_desc.free_cus (MARIUS_FLASH_RESERVE overrides it): CUs to leave empty on top of that — a caller that runs other streams beside the
+// matrix launches (the sharded trainer) asks for them; MARIUS_FLASH_NWG: the count itself (tests of every split pattern).
 
 static int64_t fl_gcd(int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; }
-static int fl_num_wg(int64_t tiles, int mode, int ks) {
+static int fl_num_wg(int64_t tiles, int mode, int ks, int free_cus) {
     const int per_cu = fl_wg_per_cu_ks(mode, ks);
     const KernelEnv& ke = kernel_env();
-    int reserve = g_flash_reserved_cus;
+    int reserve = free_cus;
     if (ke.has_flash_reserve) reserve = ke.flash_reserve;
     if (reserve < 0 || reserve >= 128) reserve = 0;
     int nwg = (256 - reserve) * per_cu;
@@ -1135,7 +1133,7 @@ FlRange flash_range(const marius_lp_desc* desc, const LpDims& D) {
     }
     return r;
 }
-static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, char* negrec, const FlRange& rg) {
+static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, char* negrec, const FlRange& rg, int free_cus) {
     a.rg = rg;
     const int xt_rows = FL_XT;
     const int XRa = (D.Bc + 31) / 32 * 32, NRn = (D.N + 31) / 32 * 32;
@@ -1156,7 +1154,7 @@ static void fl_common(FlashArgs& a, const LpDims& D, int mode, char* adjrec, cha
     a.XT = (a.Xrows + xt_rows - 1) / xt_rows;
     a.YB = a.YR / FL_YB;
     a.total = (int64_t)a.ncd * a.XT * a.YB;
-    a.nwg = fl_num_wg((int64_t)a.ncd * a.XT, mode, fl_ks(D.d));
+    a.nwg = fl_num_wg((int64_t)a.ncd * a.XT, mode, fl_ks(D.d), free_cus);
     a.rotate = kernel_env().flash_rotate_off ? 0 : 1;
     a.C = D.C;
     a.Bc = D.Bc;
@@ -1202,7 +1200,7 @@ int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj,
     if (wide) {  // S += adj_c neg_c^T chunk by chunk; the last launch also leaves the row statistics
         ProfScope ps(PROF_LP_SCORES, st);
         for (int c = 0; c < nch && !rc; ++c) {
-            fl_common(a, D, FLASH_FWDS, adjrec + c * adjset, negrec + c * negset, rg);
+            fl_common(a, D, FLASH_FWDS, adjrec + c * adjset, negrec + c * negset, rg, desc->free_cus);
             a.part = part;
             a.S = S;
             a.chunk_first = c == 0;
@@ -1213,14 +1211,14 @@ int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj,
         return rc;
     }
     if (S) {  // statistics-only sweep of the score-storing parity runs (its statistics are then rewritten below)
-        fl_common(a, D, FLASH_FWD, adjrec, negrec, rg);
+        fl_common(a, D, FLASH_FWD, adjrec, negrec, rg, desc->free_cus);
         a.part = part;
         a.S = S;
         ProfScope ps(PROF_LP_SCORES, st);
         rc = S ? fl_dispatch<FLASH_FWD, true>(ks, a, st) : fl_dispatch<FLASH_FWD, false>(ks, a, st);
         if (rc) return rc;
     }
-    fl_common(a, D, FLASH_FDADJ, adjrec, negrec, rg);
+    fl_common(a, D, FLASH_FDADJ, adjrec, negrec, rg, desc->free_cus);
     a.part = part;
     a.pos = pos;
     a.out = dadj;
@@ -1276,7 +1274,7 @@ int flash_backward(const marius_lp_desc* desc, const LpDims& D, char* adjrec, ch
         const int nch = flash_chunks(D.d), kc = fl_kc(D.d);
         const size_t adjset = fl_adjset_bytes(D), negset = fl_negset_bytes(D);
         for (int c = 0; c < nch && !rc; ++c) {
-            fl_common(a, D, FLASH_DADJS, adjrec + c * adjset, negrec + c * negset, rg);
+            fl_common(a, D, FLASH_DADJS, adjrec + c * adjset, negrec + c * negset, rg, desc->free_cus);
             a.S = S;
             a.s_tiled = (desc->flags & MARIUS_LP_STORE_SCORES) ? 0 : 1;
             a.d = kc;
@@ -1287,7 +1285,7 @@ int flash_backward(const marius_lp_desc* desc, const LpDims& D, char* adjrec, ch
                 rc = fl_dispatch<FLASH_DADJS, false>(ks, a, st);
             }
             if (rc) break;
-            fl_common(a, D, FLASH_DNEGS, adjrec + c * adjset, negrec + c * negset, rg);
+            fl_common(a, D, FLASH_DNEGS, adjrec + c * adjset, negrec + c * negset, rg, desc->free_cus);
             a.S = S;
             a.s_tiled = (desc->flags & MARIUS_LP_STORE_SCORES) ? 0 : 1;
             a.d = kc;
@@ -1301,7 +1299,7 @@ int flash_backward(const marius_lp_desc* desc, const LpDims& D, char* adjrec, ch
         return rc;
     }
     (void)dadj;  // dAdj left the forward sweep as partials (flash_forward)
-    fl_common(a, D, FLASH_DNEG, adjrec, negrec, rg);
+    fl_common(a, D, FLASH_DNEG, adjrec, negrec, rg, desc->free_cus);
     a.out = gocc;
     a.out_ld = D.d_ld;
     a.negocc_off[0] = negocc_off[0];

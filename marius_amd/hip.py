@@ -33,7 +33,7 @@ class LpDesc(C.Structure):
         ("edges", C.c_void_p), ("dst_neg", C.c_void_p), ("src_neg", C.c_void_p),
         ("rel", C.c_void_p), ("inv_rel", C.c_void_p), ("rel_ld", C.c_int64), ("R", C.c_int64),
         ("dst_filter", C.c_void_p), ("n_dst_filter", C.c_int64), ("src_filter", C.c_void_p), ("n_src_filter", C.c_int64),
-        ("loss", C.c_int32), ("margin", C.c_float), ("flags", C.c_int32), ("reserved_", C.c_int32),
+        ("loss", C.c_int32), ("margin", C.c_float), ("flags", C.c_int32), ("free_cus", C.c_int32),
         ("absmax", C.c_void_p), ("absmax_rel", C.c_void_p),
         ("upd_occ_single", C.c_void_p), ("upd_state", C.c_void_p), ("upd_absmax", C.c_void_p), ("upd_lr", C.c_float), ("upd_eps", C.c_float),
     ]
@@ -88,8 +88,8 @@ SIGNATURES = {
     "marius_merge_unique_runs": (C.c_int, [_vp, _i64, C.POINTER(C.c_int64), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "marius_owner_offsets": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "marius_a2a_capacity": (_i64, [_i64, _i32, C.c_double]),
-    "marius_a2a_rows_post": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
-    "marius_a2a_rows_wait": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
+    "marius_a2a_rows_post": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "marius_a2a_rows_wait": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "marius_lp_plan": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout)]),
     "marius_lp_forward": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),
     "marius_lp_loss": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),
@@ -321,6 +321,30 @@ def owner_offsets(um, shard_rows, num_shards):
     out = torch.empty(num_shards + 1, dtype=torch.int64, device=um.uniq.device)
     check(lib().marius_owner_offsets(ptr(um.uniq), ptr(um.count), shard_rows, num_shards, ptr(out), stream_ptr()), "owner_offsets")
     return out.cpu()
+
+
+def a2a_capacity(max_rows, world, slack=1.5):
+    return int(lib().marius_a2a_capacity(max_rows, world, slack))
+
+
+def a2a_rows_post(um, offs_dev, shard_rows, world, cap, inverse=None):
+    """requester half of the fixed-capacity exchange (marius_a2a_rows_post): returns (req_send [world * cap], place [capacity of um],
+    overflow flag int32[1], slot_of_occ [len(inverse)] or None)"""
+    dev = um.uniq.device
+    req = torch.empty(world * cap, dtype=torch.int64, device=dev)
+    place = torch.full((um.cap,), -7, dtype=torch.int64, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    slot = None if inverse is None else torch.empty(inverse.numel(), dtype=torch.int64, device=dev)
+    check(lib().marius_a2a_rows_post(ptr(um.uniq), ptr(offs_dev), shard_rows, world, cap, ptr(req), ptr(place), ptr(flag), ptr(inverse),
+                                     0 if inverse is None else inverse.numel(), ptr(slot), stream_ptr()), "a2a_rows_post")
+    return req, place, flag, slot
+
+
+def a2a_rows_wait(rows_recv, absmax=None, place=None, count_dev=None, emb=None):
+    """marius_a2a_rows_wait: bound of the received payload (absmax, device float[1], max'ed in) and — with emb — its copy in batch order"""
+    check(lib().marius_a2a_rows_wait(ptr(rows_recv), rows_recv.stride(0), rows_recv.size(0), rows_recv.size(1), ptr(absmax), ptr(place), ptr(count_dev),
+                                     0 if emb is None else emb.size(0), ptr(emb), 0 if emb is None else emb.stride(0), stream_ptr()), "a2a_rows_wait")
+    return emb
 
 
 class LpWorkspace:

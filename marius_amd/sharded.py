@@ -570,7 +570,6 @@ def run_sharded_bench(a, cfg, rank, world, dev):
 
         M = marius_amd.host()
         gen = M.MariusGenerator(42 + rank)
-        gen.prefetch = os.environ.get("MARIUS_MT_PREFETCH", "1") != "0"
         sampler = M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen)
         nodes = M.InMemory("", num_nodes, d, torch.float32, dev)  # never loaded: tells the sampler how many nodes exist
         loader = M.DataLoader(M.InMemory(edges_all), nodes, None, sampler, gen, B, True)
@@ -624,8 +623,7 @@ def run_sharded_bench(a, cfg, rank, world, dev):
     if host_s is not None:
         host_s[0] = 0.0
     if cpp_trainer is not None:
-        cpp_trainer.host_seconds = 0.0
-        cpp_trainer.reset_exchange_bytes()
+        cpp_trainer.reset_counters()
     H.profile_reset()
     H.profile_enable(True, only="lp_grad_adj")  # HIP events around the dominant kernel only (one pair per step)
     t0 = time.perf_counter()
@@ -633,6 +631,8 @@ def run_sharded_bench(a, cfg, rank, world, dev):
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
+    if cpp_trainer is not None:
+        cpp_trainer.finish()  # (after the timed region is closed: raises if a batch exceeded the fixed exchange capacity)
     H.profile_enable(False)
     prof = H.profile_read()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
@@ -680,8 +680,12 @@ def run_sharded_bench(a, cfg, rank, world, dev):
             if cpp_trainer is not None:
                 if os.environ.get("MARIUS_SHARDED_SPANS", "0") == "1":  # (the instrumentation costs the host-bound step 2-3 %: off unless asked for)
                     out["device_span_ms"] = dict(zip(["prepare", "fetch", "compute", "update", "fetch_ids_a2a", "fetch_owner_gather", "fetch_rows_a2a"], [round(x, 4) for x in cpp_trainer.span_ms]))
-                out["host_phase_ms_per_step"] = dict(zip(["prepare", "wait_split_points", "fetch", "compute", "update", "dense"],
-                                                         [round(x / (a.steps + a.warmup) * 1e3, 4) for x in cpp_trainer.phase_seconds]))
+                ph = [x / a.steps * 1e3 for x in cpp_trainer.phase_seconds]
+                # `prepare` includes the slot-reuse check of the fixed-capacity form; `wait_for_device` is the time the loop stood still because the
+                # DEVICE had not got that far (back-pressure: the host runs ahead of it) — the split points of the exact form, the slot-reuse stamp of
+                # the fixed form.  host_busy = what the host needs to issue a step.
+                out["host_phase_ms_per_step"] = dict(zip(["prepare", "wait_for_device", "fetch", "compute", "update", "dense"], [round(x, 4) for x in ph]))
+                out["host_busy_ms_per_step"] = round(out["host_issue_ms_per_step"] - ph[1], 4)
         ms, cnt = prof.get("lp_grad_adj", (0.0, 0))
         if cnt:  # rank 0's dominant kernel, same accounting as the N = 1 line
             out["roofline"] = bench_mod.dominant_roofline(ms / cnt, B, C, N, d, 2, flash, a.workload == "freebase86m" and not a.num_nodes and not strong)

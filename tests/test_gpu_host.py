@@ -723,13 +723,15 @@ def _init_nccl(dev):
     return dist
 
 
+@pytest.mark.parametrize("exchange", ["exact", "fixed"])
 @pytest.mark.parametrize("sync_interval", [1, 16])
-def test_cpp_sharded_trainer_world1_equals_synchronous_trainer(M, dev, sync_interval, monkeypatch):
+def test_cpp_sharded_trainer_world1_equals_synchronous_trainer(M, dev, sync_interval, exchange, monkeypatch):
     """ShardedTrainer (owner split points, all-to-all(v) through c10d, owner-side dedupe + Adagrad, prepared one step ahead) at world
     size 1 and staleness 0 walks the same trajectory as the fused single-GPU trainer — across an epoch boundary (new permutation).
     Same arithmetic on both sides: the sharded trainer packs bf16 operand halves (a rank sees only its shard's magnitudes), so the fused
     trainer is held to them too (MARIUS_FLASH_F16=0) — from an all-zero Adagrad state any difference in rounding flips lr-sized steps."""
     monkeypatch.setenv("MARIUS_FLASH_F16", "0")
+    monkeypatch.setenv("MARIUS_EXCHANGE", exchange)  # read by the ShardedTrainer constructor: all-to-all(v) or the fixed-capacity payloads
     from marius_amd import hip as _hip
     _hip.reload_env()
     dist = _init_nccl(dev)
@@ -745,7 +747,7 @@ def test_cpp_sharded_trainer_world1_equals_synchronous_trainer(M, dev, sync_inte
     tr = M.ShardedTrainer(lb, mb, tb, sb, 0, 1, num_nodes, dist.group.WORLD.group_name, "", 0, sync_interval)
     tr.train_steps(steps)
     tr.finish()
-    assert tr.steps == steps and tr.host_seconds > 0
+    assert tr.steps == steps and tr.host_seconds > 0 and tr.fixed_capacity == (exchange == "fixed")
     close(tb, ea.data, rtol=1e-6)
     close(sb, sa.data, rtol=1e-6)
     close(mb.decoder.relations, ma.decoder.relations, rtol=1e-6)
@@ -753,10 +755,12 @@ def test_cpp_sharded_trainer_world1_equals_synchronous_trainer(M, dev, sync_inte
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["exact", "fixed"])
 @pytest.mark.parametrize("stale", [1, 2, 3])
-def test_cpp_sharded_trainer_staleness1_matches_stale_oracle(M, dev, stale):
+def test_cpp_sharded_trainer_staleness1_matches_stale_oracle(M, dev, stale, exchange, monkeypatch):
     """Overlapped exchange: the rows of batch t + s are read before the update of batch t is applied (s updates stale; the first s batches
     before any update), the Adagrad state is read by the owner at update time.  Same loop on the CPU oracle."""
+    monkeypatch.setenv("MARIUS_EXCHANGE", exchange)
     dist = _init_nccl(dev)
     num_nodes, R, d, B, C, N, E, seed, steps = 2000, 7, 32, 150, 3, 40, 1500, 5, 7
     table, edges_all, make = _sharded_setup(M, dev, seed, num_nodes, R, d, B, C, N, E)

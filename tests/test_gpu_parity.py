@@ -3,6 +3,7 @@
 Bars: bit-exact for ids / indices / copies; floats within rtol 1e-4 (north_star: "within 1e-4 relative on float
 scores"), with an absolute floor of 1e-4 x the tensor's max magnitude for entries that cancel to ~0.
 """
+import ctypes
 import math
 
 import numpy as np
@@ -714,3 +715,94 @@ def test_merge_unique_runs_equals_sort_unique(H, dev, runs):
     assert int(b.count.item()) == U == torch.unique(ids).numel()
     assert torch.equal(b.uniq[:n], a.uniq[:n]) and torch.equal(b.inverse[:n], a.inverse[:n])
     assert torch.equal(b.perm[:n], a.perm[:n]) and torch.equal(b.seg[:U + 1], a.seg[:U + 1])
+
+
+# ------------------------------------------------------------------------------------------------ fixed-capacity exchange (exchange.hip)
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,cap_slack", [(1, 1.0), (2, 1.5), (8, 1.5), (4, 1.0)])
+def test_fixed_capacity_exchange_halves_against_numpy(H, dev, world, cap_slack):
+    """marius_a2a_rows_post / _wait and the dead (-1) padding through merge -> plan -> grouped update, against a numpy restatement and against the
+    same update on the compacted lists.  One process plays every rank: `world` requesters, each asking `world` owners (contiguous
+    id ranges of ceil(num_nodes / world) rows, storage.cpp:75); the all-to-alls are index shuffles here."""
+    g = torch.Generator().manual_seed(11 + world)
+    num_nodes, d, L = 5000, 100, 1600
+    S = (num_nodes + world - 1) // world
+    cap = H.a2a_capacity(L, world, cap_slack)
+    assert cap == (L if world == 1 else min(L, (int(L / world * cap_slack) + 1 + 255) // 256 * 256))
+    table = torch.rand(num_nodes, d, generator=g) - 0.5
+    reqs, places, ums, invs, slots = [], [], [], [], []
+    for r in range(world):
+        ids = torch.randint(num_nodes, (L,), generator=g)
+        if r == 0:
+            ids[: L // 3] = ids[0]  # a hub: a segment spanning many chunks on the requester side
+        um = H.UniqueMap(L, dev).run(ids.to(dev), 63)
+        U = int(um.count.item())
+        offs = torch.empty(world + 1, dtype=torch.int64, device=dev)
+        H.check(H.lib().marius_owner_offsets(H.ptr(um.uniq), H.ptr(um.count), S, world, H.ptr(offs), H.stream_ptr()), "owner_offsets")
+        req, place, flag, slot = H.a2a_rows_post(um, offs, S, world, cap, inverse=um.inverse)
+        torch.cuda.synchronize()
+        uq, of = um.uniq[:U].cpu().numpy(), offs.cpu().numpy()
+        want_req = np.full(world * cap, -1, dtype=np.int64)
+        want_place = np.zeros(U, dtype=np.int64)
+        over = False
+        for q in range(world):
+            cnt = int(of[q + 1] - of[q])
+            over |= cnt > cap
+            c = min(cnt, cap)
+            want_req[q * cap + cap - c:(q + 1) * cap] = uq[of[q]:of[q] + c] - q * S
+            want_place[of[q]:of[q] + c] = np.arange(q * cap + cap - c, (q + 1) * cap)
+        assert bool(flag.item()) == over
+        if over:
+            continue
+        assert np.array_equal(req.cpu().numpy(), want_req)
+        assert np.array_equal(place[:U].cpu().numpy(), want_place)
+        assert np.array_equal(slot.cpu().numpy(), want_place[um.inverse.cpu().numpy()])
+        reqs.append(req)
+        places.append(place)
+        ums.append(um)
+    if len(reqs) < world:
+        return  # (capacity exceeded for some requester at slack 1.0: the flag was the point)
+    # ---- rows: every owner gathers for every requester (negative ids skipped), the requester bounds / compacts what it received
+    for r in range(world):
+        recv = torch.zeros(world * cap, d, device=dev)
+        for q in range(world):
+            shard = table[q * S:min((q + 1) * S, num_nodes)].to(dev)
+            H.gather_rows(shard, reqs[r][q * cap:(q + 1) * cap], out=recv[q * cap:(q + 1) * cap])
+        U = int(ums[r].count.item())
+        emb = torch.full((L, d), float("nan"), device=dev)
+        bound = torch.zeros(1, device=dev)
+        H.a2a_rows_wait(recv, absmax=bound, place=places[r], count_dev=ums[r].count, emb=emb)
+        want = table[ums[r].uniq[:U].cpu()]
+        assert torch.equal(emb[:U].cpu(), want) and bool(torch.isnan(emb[U:]).all())
+        assert float(bound) == float(want.abs().max())
+        bound2 = torch.zeros(1, device=dev)
+        H.a2a_rows_wait(recv, absmax=bound2)
+        assert float(bound2) == float(want.abs().max())  # (unused slots are zeros here)
+        assert torch.equal(recv[places[r][:U]].cpu(), want)  # the payload read in place through the slot indices
+    # ---- owner 0: merge the `world` received runs (with their -1 padding), plan, grouped update == the update over the compacted lists
+    recv_ids = torch.cat([reqs[r][0:cap] for r in range(world)])  # block 0 of every requester
+    n = world * cap
+    grads = torch.rand(n, d, generator=g).to(dev) - 0.5
+    grads[recv_ids < 0] = float("nan")  # a dead slot's gradient row must never be read
+    arr = (ctypes.c_int64 * (world + 1))(*[q * cap for q in range(world + 1)])
+    b = H.UniqueMap(n, dev)
+    H.check(H.lib().marius_merge_unique_runs(H.ptr(recv_ids), n, arr, world, H.ptr(b.uniq), H.ptr(b.inverse), H.ptr(b.perm), H.ptr(b.seg), H.ptr(b.count),
+                                             H.ptr(b.ws), b.ws.numel(), H.stream_ptr()), "merge_unique_runs")
+    plan = H.segment_plan(b, n)
+    S0 = min(S, num_nodes)
+    t1, s1 = table[:S0].clone().to(dev), torch.full((S0, d), 0.01, device=dev)
+    H.segment_adagrad_scatter_group([dict(rows=grads, um=b, n=n, d=d, table=t1, state=s1, lr=0.1, plan=plan)])
+    keep = (recv_ids >= 0).nonzero().flatten()
+    c = H.UniqueMap(n, dev).run(recv_ids[keep].contiguous(), 63)
+    t2, s2 = table[:S0].clone().to(dev), torch.full((S0, d), 0.01, device=dev)
+    if keep.numel():
+        H.segment_adagrad_scatter(grads[keep].contiguous(), c, keep.numel(), d, t2, s2, 0.1)
+    torch.cuda.synchronize()
+    # same occurrence order inside every segment; the -1 run shifts the 32-position chunk boundaries, so a segment of 3+ occurrences may be
+    # associated differently ((a + b) + c vs a + (b + c)): bit-equal up to two requesters per row, 1e-6 beyond
+    assert not bool(torch.isnan(t1).any()) and not bool(torch.isnan(s1).any())
+    assert torch.equal((s1 != 0.01).any(1), (s2 != 0.01).any(1)), "the set of updated rows differs"
+    if world <= 2:
+        assert torch.equal(t1, t2) and torch.equal(s1, s2)
+    else:
+        assert torch.allclose(t1, t2, rtol=1e-6, atol=1e-7) and torch.allclose(s1, s2, rtol=1e-6, atol=1e-8)

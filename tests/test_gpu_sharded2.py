@@ -30,11 +30,11 @@ def make_inputs(cfg, world=2):
     return table, edges
 
 
-def worker(rank, world, port, outdir, sync_interval, staleness, cfg=CFG):
+def worker(rank, world, port, outdir, sync_interval, staleness, cfg=CFG, exchange="exact"):
     import marius_amd
     from marius_amd.sharded import shard_range
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo", MARIUS_EXCHANGE=exchange)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     side = dist.new_group(backend="gloo")
     dev = torch.device("cuda", 0)
@@ -54,6 +54,7 @@ def worker(rank, world, port, outdir, sync_interval, staleness, cfg=CFG):
     tr = M.ShardedTrainer(loader, model, tb, sb, rank, world, cfg["num_nodes"], dist.group.WORLD.group_name, side.group_name, staleness, sync_interval)
     tr.train_steps(cfg["steps"])
     tr.finish()
+    assert tr.fixed_capacity == (exchange == "fixed")
     torch.save({"shard": tb.cpu(), "state": sb.cpu(), "rel": dec.relations.cpu(), "inv_rel": dec.inverse_relations.cpu(), "flash": bool(model.last_step_flash),
                 "records": model.last_step_records}, os.path.join(outdir, "r%d.pt" % rank))
     dist.destroy_process_group()
@@ -117,16 +118,18 @@ def simulate(cfg, world=2, staleness=0):
     return table, state, rel, inv
 
 
-@pytest.mark.parametrize("world,staleness,flash", [(2, 0, False), (2, 1, False), (2, 2, False), (8, 1, False), (2, 0, True), (2, 1, True), (8, 1, True)])
-def test_cpp_sharded_trainer_ranks_equal_union_batch_update(world, staleness, flash):
+@pytest.mark.parametrize("world,staleness,flash,exchange", [(2, 0, False, "exact"), (2, 1, False, "exact"), (2, 2, False, "exact"), (8, 1, False, "exact"),
+                                                            (2, 0, True, "exact"), (2, 1, True, "exact"), (8, 1, True, "exact"),
+                                                            (2, 0, False, "fixed"), (2, 1, True, "fixed"), (8, 1, True, "fixed"), (8, 0, False, "fixed")])
+def test_cpp_sharded_trainer_ranks_equal_union_batch_update(world, staleness, flash, exchange):
     from marius_amd.sharded import shard_range
 
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     cfg = CFG_FLASH if flash else CFG
-    port = 41000 + 2000 * staleness + 100 * world + 37 * int(flash) + os.getpid() % 1000
+    port = 41000 + 2000 * staleness + 100 * world + 37 * int(flash) + 19 * int(exchange == "fixed") + os.getpid() % 1000
     with tempfile.TemporaryDirectory() as outdir:
-        mp.spawn(worker, args=(world, port, outdir, 1, staleness, cfg), nprocs=world, join=True)
+        mp.spawn(worker, args=(world, port, outdir, 1, staleness, cfg, exchange), nprocs=world, join=True)
         res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(world)]
     table, state, rel, inv = simulate(cfg, world, staleness)
     shared = 0
