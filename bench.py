@@ -193,6 +193,7 @@ def alt_arithmetic_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_
     R, d, B, C, N = cfg["num_relations"], cfg["d"], cfg["B"], cfg["C"], cfg["N"]
     prev = os.environ.get("MARIUS_FLASH")
     os.environ["MARIUS_FLASH"] = flash_env
+    H.reload_env()  # the kernel library reads its MARIUS_* switches once, at load
     try:
         gen = M.MariusGenerator(43)
         loader = M.DataLoader(M.InMemory(edges_all), M.InMemory(table), M.InMemory(state), M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen), gen, B, True)
@@ -238,6 +239,7 @@ def alt_arithmetic_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_
             os.environ.pop("MARIUS_FLASH", None)
         else:
             os.environ["MARIUS_FLASH"] = prev
+        H.reload_env()
 
 
 def cpu_baseline_leg(cfg, B, C, N, edges_all, cpu_seconds):
@@ -355,6 +357,7 @@ def main():
         demote = bool(int(flag.item()))
     if demote:
         os.environ["MARIUS_FLASH"] = "0"  # every rank: the timed region runs fp32 products
+        H.reload_env()
     a.arith_check = arith
 
     if world > 1 or os.environ.get("MARIUS_FORCE_SHARDED") == "1":

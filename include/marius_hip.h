@@ -278,7 +278,11 @@ typedef struct marius_lp_desc {
      * traffic less per such occurrence.  upd_occ_single: DEVICE uint8 per occurrence (marius_segment_plan_occ_single), upd_state: the table's
      * Adagrad state (row pitch emb_ld), upd_absmax: optional magnitude tracking as in the *_tracked entry points.  The caller's segment update
      * must then leave those rows alone: marius_segment_update.fused_below = 2 B.  Honoured only where marius_lp_fuses_endpoint_update() says so
-     * (the 16-byte-row kernels: d % 4 == 0, d <= 128, packed rows); ask before relying on it.  NULL upd_occ_single / upd_state: off. */
+     * (the 16-byte-row kernels: d % 4 == 0, d <= 128, packed rows); ask before relying on it.  NULL upd_occ_single / upd_state: off.
+     * CALLER'S CONTRACT (the library cannot check it): `emb` is the MUTABLE node table itself, U its row count, `edges` hold table row ids, and
+     * upd_state is that table's optimizer state with the SAME row pitch emb_ld — the backward writes w and s through these pointers.  Binding a
+     * gathered [U, d] copy, or a state of another pitch, corrupts memory.  After marius_lp_backward the `gocc` rows of the occurrences
+     * flagged in upd_occ_single below 2 B are UNDEFINED (never written): only a segment update carrying fused_below = 2 B may consume gocc. */
     const uint8_t* upd_occ_single;
     float* upd_state;
     float* upd_absmax;

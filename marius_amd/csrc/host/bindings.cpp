@@ -347,6 +347,7 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_readonly("row_bound", &Model::row_bound_)  // running bound of the rows of gathered batches (Model::bind_ranges)
         .def("tracks", &Model::tracks, py::arg("table"))
         .def("touch_relations", &Model::touch_relations)  // call after writing the relation tables through a raw pointer (ATen writes are seen by their version)
+        .def("touch_table", &Model::touch_table)          // the same for the tracked node table (raw-pointer writers: ctypes scatter calls, user kernels)
         // what the last training forward packed its operand records with: "fp16" (22 significand bits per operand) or "bf16" (16)
         .def_property_readonly("last_step_records", [](Model& self) { return std::string(self.ctx_.layout.flash ? (self.ctx_.desc.absmax ? "fp16" : "bf16") : "none"); })
         .def_property_readonly("last_step_flash", [](Model& self) { return self.ctx_.layout.flash != 0; })  // did the last fused step take the flash decoder path

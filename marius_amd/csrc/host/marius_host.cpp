@@ -1372,6 +1372,13 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
         sparse_ok = relation_step_sparse(*this, batch);
     }
     HIPCHECK(hipEventRecord((hipEvent_t)ev_join_, side.stream()));
+    // whatever happens below, the caller's stream must not run ahead of the relation step on the side stream (a throw from the node
+    // update used to leave ev_join_ unwaited, with the tables half-stepped AND the next forward racing the side stream)
+    struct Join {
+        hipStream_t main;
+        hipEvent_t ev;
+        ~Join() { (void)hipStreamWaitEvent(main, ev, 0); }
+    } join{main.stream(), (hipEvent_t)ev_join_};
     if (!sparse_ok) {
         clear_grad();
         relation_grads_dense(*this, batch);
@@ -1392,7 +1399,6 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
         mcheck(marius_segment_adagrad_scatter(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
                                               batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, ip(batch->unique_node_indices_), fp(table),
                                               fp(state), table.stride(0), sparse_lr_, 1e-10f, carry_.data_ptr(), cur_stream()));
-    HIPCHECK(hipStreamWaitEvent(main.stream(), (hipEvent_t)ev_join_, 0));
 }
 
 void Model::backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step, Tensor out_rows) {
@@ -1624,12 +1630,17 @@ void DataLoader::nextEpoch(bool write) {
 // edge bucket and the bucket sizes describe it — ONE pass over the edges on the device, the first time a buffer state is laid out; (2) every
 // bucket assigned to a buffer state has both its partitions in that state — a host loop over a few dozen pairs per state.
 void DataLoader::validate_edge_buckets() {
-    if (buckets_validated_) return;
+    // the verdict is kept for exactly the edge list it was reached on: storage pointer, row count and ATen version (replacing or
+    // reordering edges_->data_ after setEdgeBucketSizes used to go unnoticed)
+    const void* key_ptr = edges_->data_.defined() ? edges_->data_.data_ptr() : nullptr;
+    const int64_t key_rows = edges_->dim0_size_;
+    const uint32_t key_ver = edges_->data_.defined() ? (uint32_t)edges_->data_._version() : 0u;
+    if (buckets_validated_ && validated_ptr_ == key_ptr && validated_rows_ == key_rows && validated_version_ == key_ver) return;
     auto dev = edges_->device_;
     const int64_t P = pb_embeddings_->options_->num_partitions;
     const int64_t ps = (pb_embeddings_->dim0_size_ + P - 1) / P;
     Tensor starts = torch::from_blob(edge_bucket_starts_.data(), {(int64_t)edge_bucket_starts_.size()}, torch::kInt64).clone().to(dev);
-    const int64_t E = edges_->dim0_size_, piece = 1ll << 26;
+    const int64_t E = edges_->dim0_size_, piece = 1ll << 24;  // (a few int64 temporaries of `piece` elements live at once: 128 MB each)
     Tensor bad = torch::zeros({}, i64(dev));
     for (int64_t lo = 0; lo < E; lo += piece) {
         const int64_t n = std::min(piece, E - lo);
@@ -1638,11 +1649,15 @@ void DataLoader::validate_edge_buckets() {
         Tensor expect = torch::bucketize(torch::arange(lo, lo + n, i64(dev)), starts, /*out_int32=*/false, /*right=*/true) - 1;
         bad += bucket.ne(expect).sum();
     }
-    if (bad.item<int64_t>() != 0)
-        throw MariusRuntimeException("DataLoader: " + std::to_string(bad.item<int64_t>()) +
+    const int64_t nbad = bad.item<int64_t>();
+    if (nbad != 0)
+        throw MariusRuntimeException("DataLoader: " + std::to_string(nbad) +
                                      " edges have an endpoint outside the partitions in memory whenever their bucket is active (edge list not sorted by edge "
                                      "bucket, or wrong edge_bucket_sizes)");
     buckets_validated_ = true;
+    validated_ptr_ = key_ptr;
+    validated_rows_ = key_rows;
+    validated_version_ = key_ver;
 }
 
 void DataLoader::setActiveEdges() {

@@ -529,6 +529,10 @@ class Model : public torch::nn::Module {
     bool tracks(const Tensor& table) const { return ranges_valid_ && tracked_table_.is(table); }
     void drop_ranges();
     void touch_relations() { rel_ranges_valid_ = false; }
+    // The node-table counterpart: anything that writes a TRACKED table through a raw pointer — a ctypes / C-ABI scatter, a user
+    // kernel — without going through InMemory::indexAdd (which bumps the ATen version the scan remembers) calls this; the table is rescanned
+    // before the next training forward instead of being packed against a stale bound (fp16 halves would saturate silently).
+    void touch_table() { drop_ranges(); }
     void ensure_relation_ranges();
     float* relation_bound() { return rel_ranges_valid_ ? range_state_.data_ptr<float>() + 1 : nullptr; }
     // chooses the bounds of one training forward (ctx_.absmax / absmax_rel); direct: the batch reads batch->table_ in place
@@ -632,6 +636,9 @@ class DataLoader {
     void nextEpoch(bool write = true);              // dataloader.cpp:108-118: write the buffer back (training), unload
     void setActiveEdges();                          // dataloader.cpp:120-175 for the current buffer state
     bool buckets_validated_ = false;
+    const void* validated_ptr_ = nullptr;  // the edge list validate_edge_buckets() last passed: data pointer, rows, ATen version
+    int64_t validated_rows_ = 0;
+    uint32_t validated_version_ = 0;
     void validate_edge_buckets();                   // once per edge list: it is sorted by edge bucket and the bucket sizes describe it
     shared_ptr<Batch> getBatch(bool exact_unique = true);  // dataloader.cpp:360-471
     void loadGPUParameters(shared_ptr<Batch> batch);       // dataloader.cpp:529-548

@@ -389,8 +389,14 @@ class LpWorkspace:
 
     def fuse_endpoint_update(self, occ_single=None, state=None, lr=0.0, eps=1e-10, absmax=None):
         """marius_lp_desc.upd_*: the edge backward takes the Adagrad step of endpoint occurrences whose node occurs once (emb must be the
-        table itself); returns whether this library build honours it for the bound shapes.  No arguments: off."""
+        table itself); returns whether this library build honours it for the bound shapes.  No arguments: off.
+        Checked here because the C-ABI cannot: the bound `emb` must be the mutable table whose row pitch the state shares, and have
+        at least as many rows.  The gocc rows of flagged endpoint occurrences are undefined after backward()."""
         d = self.desc
+        if state is not None:
+            emb = self._keep[0] if getattr(self, "_keep", None) else None
+            if emb is None or state.dim() != 2 or state.stride(0) != d.emb_ld or state.size(0) != emb.size(0) or state.size(1) != emb.size(1) or state.data_ptr() == emb.data_ptr():
+                raise MariusHipError("fuse_endpoint_update: bind() the node TABLE first; the state must be a distinct tensor of the table's shape and row pitch")
         d.upd_occ_single = occ_single.data_ptr() if occ_single is not None else None
         d.upd_state = state.data_ptr() if state is not None else None
         d.upd_absmax = absmax.data_ptr() if absmax is not None else None

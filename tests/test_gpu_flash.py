@@ -45,7 +45,17 @@ def make_batch(decoder, B, C, N, d, U, R, seed, scale=0.5, zipf=False):
     return emb, edges, dst_neg, src_neg, rel_t, inv_t
 
 
+_LAST = {"f16": False}  # operand records of the last run_flash: what mixed_close holds the result to
+
+
+def train64(decoder, emb, U, d, edges, dst_neg, src_neg, rel, inv, *args, **kw):
+    """the oracle in float64: the yardstick of every forward / loss quantity (an fp32 oracle carries ~1e-6 x max of its own)"""
+    return O.train_batch(decoder, emb.double(), torch.zeros(U, d, dtype=torch.float64), edges, dst_neg, src_neg, rel.double(), None if inv is None else inv.double(),
+                         *args, **kw)
+
+
 def run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, store=True, reduction="sum", dst_filter=None, src_filter=None, f16=False, poison=False):
+    _LAST["f16"] = bool(f16)
     relop, cmp = DEC[decoder]
     B, (C, N), d = edges.size(0), dst_neg.shape, emb.size(1)
     flags = H.LP_TRAIN_ONLY | (H.LP_STORE_SCORES if store else 0)
@@ -68,24 +78,36 @@ def run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inver
 
 
 def mixed_close(got, want, what, rtol=1e-4, ref32=None, scale=None):
-    """the contract's mixed form: |err| <= rtol |want| + rtol max|want|, plus the worst pure-relative error over entries >= 0.1 max.
-    For gradients `want` is the oracle evaluated in float64 and `ref32` the same oracle in the reference's fp32 arithmetic: its own
-    distance from the float64 result is printed next to ours (p - 1 with p -> 1, or sums of hundreds of +- terms, lose digits in
-    ANY fp32 evaluation)."""
+    """fp16 operand records (22 significand bits per operand: every training path since round 4): the three tiers of tests/tolerance.py — worst
+    PURE relative error <= 1e-4 over entries >= 0.1 max, <= 3e-4 over entries >= 0.01 max, absolute error <= 3e-6 max below — with no absolute
+    term over the large entries.  bf16 records (16 bits; MARIUS_FLASH_F16=0 / callers without magnitude bounds): the split bound
+    3 2^-18 sum|a_k b_k| is ~1e-5 of the accumulated magnitude, stated as |err| <= rtol |want| + rtol max|want| plus 1e-4 pure-relative over
+    entries >= 0.1 max.  For gradients `want` is the oracle in float64 and `ref32` the same oracle in the reference's fp32 arithmetic: its own
+    distance from the float64 result is printed next to ours (p - 1 with p -> 1, or sums of hundreds of +- terms, lose digits in ANY fp32
+    evaluation).  scale: the magnitude of the terms an entry is summed from, when that is larger than the entries themselves."""
     got, want = got.detach().cpu().double(), want.detach().cpu().double()
     assert got.shape == want.shape, (what, got.shape, want.shape)
     mx = max(want.abs().max().item(), 1e-30)
-    if scale is not None:  # the magnitude of the terms an entry is summed from, when that is larger than the entries themselves
+    if scale is not None:
         mx = max(mx, scale)
     err = (got - want).abs()
-    ok = err <= rtol * mx + rtol * want.abs()
     big = want.abs() >= 0.1 * mx
     rel = (err[big] / want.abs()[big]).max().item() if bool(big.any()) else 0.0
     extra = ""
     if ref32 is not None:
         e32 = (ref32.detach().cpu().double() - want).abs()
         extra = "   [fp32 oracle vs fp64: err/max %.2e, rel %.2e]" % ((e32.max() / mx).item(), (e32[big] / want.abs()[big]).max().item() if bool(big.any()) else 0.0)
-    print("%-24s worst err / max %.2e   worst rel over entries >= 0.1 max %.2e   max %.3e%s" % (what, (err.max() / mx).item(), rel, mx, extra))
+    if _LAST["f16"]:
+        mid = want.abs() >= 0.01 * mx
+        rel_mid = (err[mid] / want.abs()[mid]).max().item() if bool(mid.any()) else 0.0
+        small = (err[~mid].max().item() / mx) if bool((~mid).any()) else 0.0
+        print("%-24s [fp16 records] rel over >= 0.1 max %.2e   over >= 0.01 max %.2e   abs/max below %.2e   max %.3e%s" % (what, rel, rel_mid, small, mx, extra))
+        assert rel <= rtol, "%s: worst relative error %.3e over entries >= 0.1 max" % (what, rel)
+        assert rel_mid <= 3 * rtol, "%s: worst relative error %.3e over entries >= 0.01 max" % (what, rel_mid)
+        assert small <= 3e-6, "%s: worst small-entry error %.3e x max" % (what, small)
+        return (err.max() / mx).item(), rel
+    ok = err <= rtol * mx + rtol * want.abs()
+    print("%-24s [bf16 records] worst err / max %.2e   worst rel over entries >= 0.1 max %.2e   max %.3e%s" % (what, (err.max() / mx).item(), rel, mx, extra))
     assert bool(ok.all()), "%s: max abs err %.3e vs max %.3e" % (what, err.max().item(), mx)
     assert rel <= rtol, "%s: worst relative error %.3e over the large entries" % (what, rel)
     return (err.max() / mx).item(), rel
@@ -139,7 +161,7 @@ SHAPES = [(6, 3, 5, 50), (100, 10, 50, 50), (1000, 10, 500, 100), (250, 7, 130, 
 def test_flash_forward_loss_backward_match_oracle(H, dev, decoder, use_inverse, B, C, N, d, f16):
     U, R = max(40, B), 11
     emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=B + d, zipf=(B == 250))
-    want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv if use_inverse else None)
+    want = train64(decoder, emb, U, d, edges, dst_neg, src_neg, rel, inv if use_inverse else None)
     W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, f16=f16)
     assert W.layout.Bp == want["pos"].numel()
     mixed_close(W.pos(0), want["pos"], "pos")
@@ -169,7 +191,7 @@ def test_flash_translation_operator_scales_adj_by_the_sum_of_the_bounds(H, dev, 
     edges = torch.stack([torch.randint(U, (B,), generator=g), torch.randint(R, (B,), generator=g), torch.randint(U, (B,), generator=g)], 1)
     edges[0] = torch.tensor([0, 0, 1])   # an adj row that reaches M_e + M_r in its first column
     dst_neg, src_neg = torch.randint(U, (C, N), generator=g), torch.randint(U, (C, N), generator=g)
-    want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv)
+    want = train64(decoder, emb, U, d, edges, dst_neg, src_neg, rel, inv)
     W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, f16=True)
     mixed_close(W.neg(0), want["neg"], "neg (split scores)")
     mixed_close(W.neg(1), want["inv_neg"], "inv_neg (split scores)")
@@ -187,7 +209,7 @@ def test_flash_online_softmax_reference_moves(H, dev, scale, B, C, N, d):
     the 1e-4 gradient tolerance in ANY 16-bit-significand contraction: V = exp(S - lse) multiplies the score error; measured 1.6e-4.)"""
     decoder, U, R = "COMPLEX", 900, 7
     emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=17, scale=scale)
-    want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv)
+    want = train64(decoder, emb, U, d, edges, dst_neg, src_neg, rel, inv)
     W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, store=False)
     spread = (want["neg"].max(1)[0] - want["pos"]).max().item()
     print("largest (max negative - positive) over the rows: %.1f" % spread)
@@ -216,7 +238,7 @@ def test_flash_score_filter_matches_oracle(H, dev, use_inverse, B, C, N, d, F):
 
     dst_filter, src_filter = mk(), mk()
     inv_u = inv if use_inverse else None
-    want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv_u, dst_filter, src_filter if use_inverse else None)
+    want = train64(decoder, emb, U, d, edges, dst_neg, src_neg, rel, inv_u, dst_filter, src_filter if use_inverse else None)
     W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, store=False, dst_filter=dst_filter, src_filter=src_filter if use_inverse else None)
     assert float((want["neg"] == -1e9).sum()) == F
     mixed_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss")
@@ -238,7 +260,7 @@ def test_flash_wide_rows_in_column_chunks_match_oracle(H, dev, decoder, use_inve
     U, R = max(40, B), 11
     emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=B + d, scale=0.3)
     inv_u = inv if use_inverse else None
-    want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv_u)
+    want = train64(decoder, emb, U, d, edges, dst_neg, src_neg, rel, inv_u)
     W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, use_inverse, store=False, f16=f16)
     assert W.layout.neg[0] != 0                          # the score matrix exists on this path (in tile order: LpWorkspace.neg un-tiles it)
     mixed_close(W.neg(0), want["neg"], "neg (stored scores)")
@@ -403,7 +425,7 @@ def test_flash_split_tiles_are_deterministic_and_consistent(H, dev, monkeypatch,
 def test_flash_mean_reduction(H, dev):
     B, C, N, d, U, R = 96, 4, 40, 100, 60, 5
     emb, edges, dst_neg, src_neg, rel, inv = make_batch("DISTMULT", B, C, N, d, U, R, seed=77)
-    want = O.train_batch("DISTMULT", emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv, reduction="mean")
+    want = train64("DISTMULT", emb, U, d, edges, dst_neg, src_neg, rel, inv, reduction="mean")
     W = run_flash(H, dev, "DISTMULT", emb, edges, dst_neg, src_neg, rel, inv, True, reduction="mean")
     mixed_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss (mean)")
     check_gradients(W, "DISTMULT", emb, edges, dst_neg, src_neg, rel, inv, U, R, reduction="mean")
@@ -429,7 +451,7 @@ def test_flash_bench_shape_matches_oracle(H, dev):
     check is on the loss, the row statistics and every gradient."""
     decoder, B, C, N, d, U, R = "COMPLEX", 50000, 50, 1000, 100, 200000, 1000
     emb, edges, dst_neg, src_neg, rel, inv = make_batch(decoder, B, C, N, d, U, R, seed=2024)
-    want = O.train_batch(decoder, emb, torch.zeros(U, d), edges, dst_neg, src_neg, rel, inv)
+    want = train64(decoder, emb, U, d, edges, dst_neg, src_neg, rel, inv)
     W = run_flash(H, dev, decoder, emb, edges, dst_neg, src_neg, rel, inv, True, store=False)
     assert W.layout.neg[0] == 0 and W.layout.neg[1] == 0      # nothing score-shaped was allocated
     mixed_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss")
