@@ -30,6 +30,7 @@ struct KernelEnv {
     int flash_reserve, flash_nwg;  // MARIUS_FLASH_RESERVE / MARIUS_FLASH_NWG
     bool flash_f16_off;   // MARIUS_FLASH_F16=0
     bool flash_rotate_off;  // MARIUS_FLASH_ROTATE=0
+    bool flash_tail4_off;   // MARIUS_FLASH_TAIL4=0: d = 36 / 68 / 100 keep a k-step of their own for the last four columns (round-4 record layout)
     bool seg_fused_fixup_off, seg_group_off;  // MARIUS_SEG_FUSED_FIXUP=0, MARIUS_SEG_GROUP=0
     bool sort_rocprim;    // MARIUS_SORT=rocprim
     int sync_launch;      // MARIUS_SYNC_LAUNCH

@@ -31,6 +31,7 @@ static KernelEnv read_kernel_env() {
     if (const char* e = getenv("MARIUS_FLASH_NWG")) { k.has_flash_nwg = true; k.flash_nwg = atoi(e); }
     k.flash_f16_off = first("MARIUS_FLASH_F16") == '0';
     k.flash_rotate_off = first("MARIUS_FLASH_ROTATE") == '0';
+    k.flash_tail4_off = first("MARIUS_FLASH_TAIL4") == '0';
     k.seg_fused_fixup_off = first("MARIUS_SEG_FUSED_FIXUP") == '0';
     k.seg_group_off = first("MARIUS_SEG_GROUP") == '0';
     k.sort_rocprim = first("MARIUS_SORT") == 'r';

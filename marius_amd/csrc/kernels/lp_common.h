@@ -186,6 +186,7 @@ int flash_backward(const marius_lp_desc* desc, const LpDims& D, char* adjrec, ch
                    const float2* part, bool filtered, float* S, hipStream_t st);
 int flash_chunks(int d);   // column chunks of the contraction index: 1 for d <= 128, ceil(d / 128) equal ones above, 0 = not representable
 bool flash_chunked(int d); // d > 128: stored scores + per-chunk launches
+bool flash_tail4(int d);   // the records of this width fold their last four columns into the hi region (lp_flash.hip: fl_pitch)
 size_t flash_tiled_scores_bytes(const LpDims& D);  // the stored scores in tile order (internal layout; row-major [Bp, n_ld] with MARIUS_LP_STORE_SCORES)
 // fp16 operand records (lp_flash.hip): the scale an operand set is packed with, derived on the device from marius_lp_desc.absmax
 struct FlRange {

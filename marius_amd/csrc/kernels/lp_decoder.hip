@@ -35,6 +35,7 @@ struct PrepArgs {
     // of dadj that the two-contributor accumulation of the backward needs.  frec == nullptr: not the flash path.
     char* frec;
     int fKP, fXR;
+    int fP, fTail;  // record pitch in bytes; 1: the folded column tail of lp_flash.hip (fl_pitch) — the last four columns' hi and lo halves share one 16-byte piece
     float* fdadj;  // [ndir][Bp, d_ld]
     FlRange frg;   // fp16 records: the adj scale is derived from it (lp_common.h); absmax == nullptr: bf16 records
     LpDims D;
@@ -126,11 +127,14 @@ __device__ __forceinline__ unsigned prep_pack_bf16x2(float x, float y) {
 __device__ __forceinline__ void prep_flash_store(const PrepArgs& a, int dir, int64_t i, int l, int c0, int c1, const float (&v)[4], bool act) {
 #pragma clang fp contract(off)
     const LpDims& D = a.D;
-    const int P = 4 * a.fKP + 16;
+    const int P = a.fP;
     const int64_t c = i / D.Bc;
     const int x = (int)(i - c * D.Bc);
     const int xp = 4 * (x & 3) + ((x >> 2) & 3) + (x & ~15);  // fl_rho
     char* rec = a.frec + (((int64_t)dir * D.C + c) * a.fXR + xp) * (int64_t)P;
+    // folded column tail: the lo halves of columns d - 4 .. d - 1 sit 8 bytes behind their hi halves instead of in the lo region
+    const int lo0 = (a.fTail && c0 >= D.d - 4) ? 2 * c0 + 8 : 2 * a.fKP + 2 * c0;
+    const int lo1 = (a.fTail && c1 >= D.d - 4) ? 2 * c1 + 8 : 2 * a.fKP + 2 * c1;
     if (act) {
         // x s = h + l with both halves in the record's element type (fp16 when the caller gave magnitude bounds — s = the adj scale, a power
         // of two — else bf16 with s = 1): the same split flash_pack_adj_kernel makes (fl_write_piece)
@@ -152,8 +156,8 @@ __device__ __forceinline__ void prep_flash_store(const PrepArgs& a, int dir, int
         }
         *reinterpret_cast<unsigned*>(rec + 2 * c0) = (unsigned)H[0] | ((unsigned)H[1] << 16);
         *reinterpret_cast<unsigned*>(rec + 2 * c1) = (unsigned)H[2] | ((unsigned)H[3] << 16);
-        *reinterpret_cast<unsigned*>(rec + 2 * a.fKP + 2 * c0) = (unsigned)L[0] | ((unsigned)L[1] << 16);
-        *reinterpret_cast<unsigned*>(rec + 2 * a.fKP + 2 * c1) = (unsigned)L[2] | ((unsigned)L[3] << 16);
+        *reinterpret_cast<unsigned*>(rec + lo0) = (unsigned)L[0] | ((unsigned)L[1] << 16);
+        *reinterpret_cast<unsigned*>(rec + lo1) = (unsigned)L[2] | ((unsigned)L[3] << 16);
         if (a.fdadj) {
             float* z = a.fdadj + ((int64_t)dir * D.Bp + i) * D.d_ld;
             *reinterpret_cast<float2*>(z + c0) = make_float2(0.f, 0.f);
@@ -162,12 +166,14 @@ __device__ __forceinline__ void prep_flash_store(const PrepArgs& a, int dir, int
     } else {
         const int q = l - D.d / 4;             // idle lanes write the zero K padding, one element pair each
         const int col = D.d + 2 * q;
-        if (col < a.fKP) {
+        if (a.fTail) {  // the eight zeros behind T = [h | l]: bytes 2 d + 8 .. 2 d + 23 of the hi region; the lo region has no padding
+            if (q < 4) *reinterpret_cast<unsigned*>(rec + 2 * D.d + 8 + 4 * q) = 0u;
+        } else if (col < a.fKP) {
             *reinterpret_cast<unsigned*>(rec + 2 * col) = 0u;
             *reinterpret_cast<unsigned*>(rec + 2 * a.fKP + 2 * col) = 0u;
         }
     }
-    if (l == 0) *reinterpret_cast<float4*>(rec + 4 * a.fKP) = make_float4(0.f, 0.f, 0.f, 0.f);  // lsec: patched in by the merge kernel
+    if (l == 0) *reinterpret_cast<float4*>(rec + P - 16) = make_float4(0.f, 0.f, 0.f, 0.f);  // lsec: patched in by the merge kernel
 }
 
 // adj = op(e, r) on the four elements {c0, c0 + 1, c1, c1 + 1} a lane owns (ComplEx: (re, im) = (k, k + 2)); the SAME expressions, with
@@ -306,7 +312,7 @@ __device__ __forceinline__ void prep2_pad(const PrepArgs& a, int64_t i, int l) {
                 const int64_t cd = r / npad;
                 const int x = D.Bc + (int)(r - cd * npad);
                 const int xp = 4 * (x & 3) + ((x >> 2) & 3) + (x & ~15);
-                const int P = 4 * a.fKP + 16;
+                const int P = a.fP;
                 char* rec = a.frec + (cd * a.fXR + xp) * (int64_t)P;
                 for (int o = 16 * l; o < P; o += 16 * 32) *reinterpret_cast<float4*>(rec + o) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -1391,7 +1397,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     pa.x2 = x2;
     pa.D = D;
     pa.frec = nullptr;
-    pa.fKP = pa.fXR = 0;
+    pa.fKP = pa.fXR = pa.fP = pa.fTail = 0;
     pa.fdadj = nullptr;
     pa.frg = FlRange{nullptr, nullptr, FL_ADJ_NODE};
     bool flash_fused_prep = false;
@@ -1402,6 +1408,8 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
         if (vec_ok && L->flash) {  // the adj records and the dadj zero fill ride along (lp_flash.hip)
             pa.fKP = (D.d + 15) / 16 * 16;
             pa.fXR = (D.Bc + 31) / 32 * 32;
+            pa.fTail = flash_tail4(D.d) ? 1 : 0;
+            pa.fP = pa.fTail ? 4 * pa.fKP - 16 : 4 * pa.fKP + 16;
             pa.frec = ws + L->adjrec;
             pa.frg = flash_range(desc, D);
             pa.fdadj = flash_fused() ? nullptr : (float*)(ws + L->dadj[0]);  // fused form: partials are stored, never accumulated

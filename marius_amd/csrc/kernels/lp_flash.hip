@@ -102,8 +102,18 @@ __host__ __device__ constexpr int fl_sring_bytes(int mode) { return fl_sslots(mo
 __host__ __device__ constexpr int fl_wg_per_cu(int mode) { return (FL_WAVES == 8 || (mode >= 4 && FL_S_DEEP)) ? 1 : (mode == 0 ? (FL_FWD_SLOTS == 3 ? 3 : 2) : 2); }
 constexpr float FL_LOG2E = 1.4426950408889634f, FL_LN2 = 0.6931471805599453f;
 
-__host__ __device__ constexpr int fl_pitch(int KS) { return 64 * KS + 16; }                                    // bytes per record
-__host__ __device__ constexpr int fl_slot_bytes(int KS) { return (32 * fl_pitch(KS) + FL_WAVES * 1024 - 1) / (FL_WAVES * 1024) * (FL_WAVES * 1024); }   // DMA granule: 4 waves x 1 KB
+// Round 5: the FOLDED COLUMN TAIL.  d = 100 fills six k-steps of 16 and leaves four columns: as a seventh k-step of its own they cost three MFMAs
+// in the score contraction and six in the gradient contraction for 4 of 16 (32) useful columns.  When d = 4 (mod 16) and the number of k-steps
+// is odd (d = 36, 68, 100) the record keeps those four columns' hi AND lo halves side by side in ONE 16-byte piece at the end of the hi region,
+//     record = [ hi: 16 (KS - 1) | T = h0 h1 h2 h3 l0 l1 l2 l3 | 8 zeros | lo: 16 (KS - 1) | lsec: f32 | 12 B pad ],   P = 64 KS - 16,
+// so that (a) the last score k-step is TWO MFMAs on the streamed fragment [T | 0]: against [h'h' | 0] (h h' + l h') and against [l'0 | 0] (h l');
+// (b) the last 32-column tile of the gradient contraction — which starts at T because KS - 1 is even — is TWO MFMAs per k-step, V_h and V_l against
+// the hi window, whose columns 0-3 / 4-7 are the h / l parts of the four tail columns (added when the accumulators leave the registers; the
+// V_l l product it also forms is the one the three-product scheme drops).  42 instead of 45 MFMAs per item; lo offset 2 KP and P = 16 (mod 32)
+// are unchanged, so every bank-conflict property of the old layout holds.  MARIUS_FLASH_TAIL4=0: the seven-k-step layout (A/B runs).
+__host__ __device__ constexpr int fl_pitch(int KS, bool TAIL = false) { return TAIL ? 64 * KS - 16 : 64 * KS + 16; }   // bytes per record
+__host__ __device__ constexpr int fl_lsec_off(int KS, bool TAIL = false) { return fl_pitch(KS, TAIL) - 16; }        // byte offset of lsec in a record
+__host__ __device__ constexpr int fl_slot_bytes(int KS, bool TAIL = false) { return (32 * fl_pitch(KS, TAIL) + FL_WAVES * 1024 - 1) / (FL_WAVES * 1024) * (FL_WAVES * 1024); }   // DMA granule: 4 waves x 1 KB
 __host__ __device__ constexpr int fl_rho(int y) { return 4 * (y & 3) + ((y >> 2) & 3) + (y & ~15); }          // logical -> physical slot in a 16-group
 __host__ __device__ constexpr int fl_pi(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }         // swap bits 2 and 3
 
@@ -149,9 +159,15 @@ __global__ __launch_bounds__(256) void flash_zero_kernel(float* a, int64_t na, f
 
 // ---------------------------------------------------------------------------------------------------------------- pack kernels
 // fp32 row -> record.  One thread per 4 consecutive elements (8 B of hi, 8 B of lo); threads past d write the zero K padding.
+// tail_piece >= 0 (folded column tail): piece tail_piece holds the last four columns — hi then lo side by side; the two pieces behind it are the
+// eight zeros of T's k-step (written where the old layout had hi padding), the piece after those writes nothing
 template <bool F16>
-__device__ __forceinline__ void fl_write_piece(char* rec, int KP, int piece, float4 v, float scale) {
+__device__ __forceinline__ void fl_write_piece(char* rec, int KP, int piece, float4 v, float scale, int tail_piece = -1) {
 #pragma clang fp contract(off)
+    if (tail_piece >= 0 && piece > tail_piece) {
+        if (piece <= tail_piece + 2) *reinterpret_cast<uint2*>(rec + (piece + 1) * 8) = make_uint2(0u, 0u);
+        return;
+    }
     const float x[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};  // scale is a power of two: exact
     unsigned short H[4], L[4];
 #pragma unroll
@@ -160,14 +176,16 @@ __device__ __forceinline__ void fl_write_piece(char* rec, int KP, int piece, flo
         L[j] = fl_cvt16<F16>(x[j] - fl_back16<F16>(H[j]));
     }
     *reinterpret_cast<uint2*>(rec + piece * 8) = make_uint2((unsigned)H[0] | ((unsigned)H[1] << 16), (unsigned)H[2] | ((unsigned)H[3] << 16));
-    *reinterpret_cast<uint2*>(rec + 2 * KP + piece * 8) = make_uint2((unsigned)L[0] | ((unsigned)L[1] << 16), (unsigned)L[2] | ((unsigned)L[3] << 16));
+    char* lo = piece == tail_piece ? rec + piece * 8 + 8 : rec + 2 * KP + piece * 8;
+    *reinterpret_cast<uint2*>(lo) = make_uint2((unsigned)L[0] | ((unsigned)L[1] << 16), (unsigned)L[2] | ((unsigned)L[3] << 16));
 }
 
 // adj [ndir][Bp][d_ld] fp32 (written by lp_prep*) -> adj records; chunk c of direction dir holds rows c Bc .. (c + 1) Bc of that direction
 // d = columns of this record set, taken from column col0 on (one set per column chunk when the rows are wider than 128)
 __global__ __launch_bounds__(256) void flash_pack_adj_kernel(const float* __restrict__ adj, int64_t d_ld, int64_t Bp, int Bc, int C, int ndir, int d,
-                                                             int KP, int XR, char* __restrict__ rec, FlRange rg, int col0) {
+                                                             int KP, int XR, char* __restrict__ rec, FlRange rg, int col0, int tail) {
     const int ppr = KP / 4 + 1;  // pieces per record (+1: the tail)
+    const int tp = tail ? (d - 4) / 4 : -1;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nrec = (int64_t)ndir * C * XR;
     if (idx >= nrec * ppr) return;
@@ -175,10 +193,10 @@ __global__ __launch_bounds__(256) void flash_pack_adj_kernel(const float* __rest
     const int piece = (int)(idx - r * ppr);
     const int64_t cd = r / XR;
     const int x = (int)(r - cd * XR);
-    const int P = 4 * KP + 16;
+    const int P = tail ? 4 * KP - 16 : 4 * KP + 16;
     char* o = rec + (cd * XR + fl_rho(x)) * (int64_t)P;
     if (piece == KP / 4) {  // tail: lsec of a padding record must be finite (V of a zero row is multiplied by zeros)
-        *reinterpret_cast<float4*>(o + 4 * KP) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(o + P - 16) = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -192,16 +210,17 @@ __global__ __launch_bounds__(256) void flash_pack_adj_kernel(const float* __rest
             if (4 * piece + 2 < d) v.z = src[2];
         }
     }
-    if (rg.absmax) fl_write_piece<true>(o, KP, piece, v, fl_scales(rg).s_adj);
-    else fl_write_piece<false>(o, KP, piece, v, 1.f);
+    if (rg.absmax) fl_write_piece<true>(o, KP, piece, v, fl_scales(rg).s_adj, tp);
+    else fl_write_piece<false>(o, KP, piece, v, 1.f, tp);
 }
 
 // negatives: record (dir, c, j) = emb[negmap[dir][c N + j]]; rows N .. NR are zero
 __global__ __launch_bounds__(256) void flash_pack_neg_kernel(const float* __restrict__ emb, int64_t emb_ld, const int64_t* __restrict__ neg0,
                                                              const int64_t* __restrict__ neg1, int N, int C, int ndir, int d, int KP, int NR,
                                                              int vec, char* __restrict__ rec, float* __restrict__ gocc, int64_t d_ld, int64_t off0,
-                                                             int64_t off1, FlRange rg, int col0) {
+                                                             int64_t off1, FlRange rg, int col0, int tail) {
     const int ppr = KP / 4 + 1;
+    const int tp = tail ? (d - 4) / 4 : -1;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nrec = (int64_t)ndir * C * NR;
     if (idx >= nrec * ppr) return;
@@ -209,10 +228,10 @@ __global__ __launch_bounds__(256) void flash_pack_neg_kernel(const float* __rest
     const int piece = (int)(idx - r * ppr);
     const int64_t cd = r / NR;
     const int j = (int)(r - cd * NR);
-    const int P = 4 * KP + 16;
+    const int P = tail ? 4 * KP - 16 : 4 * KP + 16;
     char* o = rec + (cd * NR + fl_rho(j)) * (int64_t)P;
     if (piece == KP / 4) {
-        *reinterpret_cast<float4*>(o + 4 * KP) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(o + P - 16) = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -225,8 +244,8 @@ __global__ __launch_bounds__(256) void flash_pack_neg_kernel(const float* __rest
         // the negative's gradient row is accumulated by at most two workgroups of the backward: it starts from zero
         if (col0 + 4 * piece < d_ld) *reinterpret_cast<float4*>(gocc + ((dir ? off1 : off0) + c * N + j) * d_ld + col0 + 4 * piece) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (rg.absmax) fl_write_piece<true>(o, KP, piece, v, fl_scales(rg).s_neg);
-    else fl_write_piece<false>(o, KP, piece, v, 1.f);
+    if (rg.absmax) fl_write_piece<true>(o, KP, piece, v, fl_scales(rg).s_neg, tp);
+    else fl_write_piece<false>(o, KP, piece, v, 1.f, tp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- score filter index
@@ -309,7 +328,9 @@ __device__ __forceinline__ v16f fl_mfma(const v8bf& a, const v8bf& b, v16f c) {
 // ---- the two matrix phases, shared by both kernels.  Operand fragments are read from LDS two steps ahead of the MFMAs that consume
 // them (a three-entry register ring): without the explicit distance hipcc emits read -> wait -> MFMA chains and every step pays the LDS
 // latency inside the matrix phase.
-template <int KS, bool F16>
+// TAIL: the last k-step is the folded column tail — the streamed fragment [T | 0] against xh[KS - 1] = [h' h' | 0] and xl[KS - 1] = [l' 0 | 0]
+// (built by load_x): two MFMAs, no lo fragment
+template <int KS, bool F16, bool TAIL>
 __device__ __forceinline__ v16f fl_score_tile(const unsigned char* T, int a_off, const v8bf (&xh)[KS], const v8bf (&xl)[KS]) {
     constexpr int KP = 16 * KS;
     v16f accM, accC;
@@ -319,13 +340,13 @@ __device__ __forceinline__ v16f fl_score_tile(const unsigned char* T, int a_off,
 #pragma unroll
     for (int ks = 0; ks < 2 && ks < KS; ++ks) {
         yh[ks] = *reinterpret_cast<const v8bf*>(T + a_off + 32 * ks);
-        yl[ks] = *reinterpret_cast<const v8bf*>(T + a_off + 2 * KP + 32 * ks);
+        if (!(TAIL && ks == KS - 1)) yl[ks] = *reinterpret_cast<const v8bf*>(T + a_off + 2 * KP + 32 * ks);
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         if (ks + 2 < KS) {
             yh[(ks + 2) % 3] = *reinterpret_cast<const v8bf*>(T + a_off + 32 * (ks + 2));
-            yl[(ks + 2) % 3] = *reinterpret_cast<const v8bf*>(T + a_off + 2 * KP + 32 * (ks + 2));
+            if (!(TAIL && ks + 2 == KS - 1)) yl[(ks + 2) % 3] = *reinterpret_cast<const v8bf*>(T + a_off + 2 * KP + 32 * (ks + 2));
         }
 #ifdef FL_ONE_ACC
         accM = fl_mfma<F16>(yl[ks % 3], xh[ks], accM);
@@ -334,7 +355,7 @@ __device__ __forceinline__ v16f fl_score_tile(const unsigned char* T, int a_off,
 #else
         accM = fl_mfma<F16>(yh[ks % 3], xh[ks], accM);
         accC = fl_mfma<F16>(yh[ks % 3], xl[ks], accC);
-        accC = fl_mfma<F16>(yl[ks % 3], xh[ks], accC);
+        if (!(TAIL && ks == KS - 1)) accC = fl_mfma<F16>(yl[ks % 3], xh[ks], accC);
 #endif
     }
     v16f acc;
@@ -346,39 +367,47 @@ __device__ __forceinline__ v16f fl_score_tile(const unsigned char* T, int a_off,
 struct FlTrFrag {
     union { v4s p[2]; v8bf f; } h, l;
 };
-template <int KS>
+// TAIL: the last column tile starts at T (KS - 1 is even): its hi window is [h0..3 l0..3 | 8 zeros | 16 columns of the lo region], so V_h and V_l
+// against it give the h and l parts of the four tail columns in accumulator columns 0-3 and 4-7 (folded by fl_fold_tail when the accumulators
+// leave the registers); there is no lo window
+template <int KS, bool TAIL>
 __device__ __forceinline__ FlTrFrag fl_tr_read(const unsigned char* T, int tr_off, int g) {  // g = 2 ct + s
-    constexpr int KP = 16 * KS, P = fl_pitch(KS);
+    constexpr int KP = 16 * KS, P = fl_pitch(KS, TAIL), NCT = (KP + 31) / 32;
     const unsigned char* q = T + tr_off + (16 * (g & 1)) * P + 64 * (g >> 1);
     FlTrFrag r;
     r.h.p[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q));
     r.h.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + P));
-    r.l.p[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + 2 * KP));
-    r.l.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + 2 * KP + P));
+    if (!(TAIL && (g >> 1) == NCT - 1)) {
+        r.l.p[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + 2 * KP));
+        r.l.p[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(q + 2 * KP + P));
+    }
     return r;
 }
-template <int KS, int NCT, bool F16>
+template <int KS, int NCT, bool F16, bool TAIL>
 __device__ __forceinline__ void fl_grad_tile(const unsigned char* T, int tr_off, const v8bf (&wh)[2], const v8bf (&wl)[2], v16f (&out)[NCT]) {
     constexpr int G = 2 * NCT;
     FlTrFrag b[3];
 #pragma unroll
-    for (int g = 0; g < 2 && g < G; ++g) b[g] = fl_tr_read<KS>(T, tr_off, g);
+    for (int g = 0; g < 2 && g < G; ++g) b[g] = fl_tr_read<KS, TAIL>(T, tr_off, g);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        if (g + 2 < G) b[(g + 2) % 3] = fl_tr_read<KS>(T, tr_off, g + 2);
+        if (g + 2 < G) b[(g + 2) % 3] = fl_tr_read<KS, TAIL>(T, tr_off, g + 2);
         const int ct = g >> 1, s_ = g & 1;
         out[ct] = fl_mfma<F16>(wh[s_], b[g % 3].h.f, out[ct]);
-        out[ct] = fl_mfma<F16>(wh[s_], b[g % 3].l.f, out[ct]);
+        if (!(TAIL && ct == NCT - 1)) out[ct] = fl_mfma<F16>(wh[s_], b[g % 3].l.f, out[ct]);
         out[ct] = fl_mfma<F16>(wl[s_], b[g % 3].h.f, out[ct]);
     }
 }
+// accumulator columns 4-7 of the tail tile hold the lo parts of columns 0-3: lane c takes lane c + 4's value (lanes of one half-wave share rows)
+__device__ __forceinline__ float fl_fold_tail(float v) { return v + __shfl_down(v, 4, 64); }
 
 // (chunks wider than 128 columns — KS > 8, stored-score modes — run one workgroup per CU: their block slots fill the LDS, and one wave per SIMD
 // may then use the whole 512-entry register file)
 __host__ __device__ constexpr int fl_wg_per_cu_ks(int mode, int ks) { return (mode >= FLASH_FWDS && ks > 8) ? 1 : fl_wg_per_cu(mode); }
-template <int KS, int MODE, bool STORE_S, bool F16>
+template <int KS, int MODE, bool STORE_S, bool F16, bool TAIL>
 __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel(FlashArgs a) {
-    constexpr int KP = 16 * KS, P = fl_pitch(KS), SLOT = fl_slot_bytes(KS), NSLOT = fl_slots(MODE);
+    static_assert(!TAIL || ((KS & 1) && KS >= 3 && MODE < FLASH_FWDS), "folded column tail: odd k-step counts of the d <= 128 kernels only");
+    constexpr int KP = 16 * KS, P = fl_pitch(KS, TAIL), LSEC = fl_lsec_off(KS, TAIL), SLOT = fl_slot_bytes(KS, TAIL), NSLOT = fl_slots(MODE);
     // ---- scales (all powers of two).  Accumulated scores carry s_x s_y; V = exp2(...) is formed VSH binades up so that its fp16 halves keep
     // their bits (V <= 2^FL_TAU in the fused sweep, <= 1 where lse is known); the outputs are scaled back when they leave the registers.
     const FlScales sc_ = F16 ? fl_scales(a.rg) : FlScales{1.f, 1.f};
@@ -505,9 +534,17 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             xh[ks] = *reinterpret_cast<const v8bf*>(r + 32 * ks + 16 * h);
-            xl[ks] = *reinterpret_cast<const v8bf*>(r + 2 * KP + 32 * ks + 16 * h);
+            if (!(TAIL && ks == KS - 1)) xl[ks] = *reinterpret_cast<const v8bf*>(r + 2 * KP + 32 * ks + 16 * h);
         }
-        if (BASE == FLASH_DADJ) lsec_x = *reinterpret_cast<const float*>(r + 4 * KP);
+        if constexpr (TAIL) {  // the piece just read is T = [h0..3 | l0..3] (lanes h = 1: the zero piece): B operands [h h | .] and [l 0 | .]
+            union { v8bf v; unsigned u[4]; } t, xa, xb;
+            t.v = xh[KS - 1];
+            xa.u[0] = t.u[0]; xa.u[1] = t.u[1]; xa.u[2] = t.u[0]; xa.u[3] = t.u[1];
+            xb.u[0] = t.u[2]; xb.u[1] = t.u[3]; xb.u[2] = 0u; xb.u[3] = 0u;
+            xh[KS - 1] = xa.v;
+            xl[KS - 1] = xb.v;
+        }
+        if (BASE == FLASH_DADJ) lsec_x = *reinterpret_cast<const float*>(r + LSEC);
         if (MODE == FLASH_FDADJ) {  // the row's positive score is a term of the same softmax: start from it (rows past Xrows are never stored)
             mref = (x < a.Xrows) ? a.pos[(int64_t)dir * a.Bp + (int64_t)c_ * a.Bc + x] * FL_LOG2E : 0.f;
             lsum = 0.f;
@@ -569,7 +606,8 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
 #pragma unroll
                 for (int r_ = 0; r_ < 16; ++r_) {
                     const int x = xt * FL_XT + wave * 32 + acc_row(r_, h);
-                    if (x < a.Xrows && col < a.d) dst[(base + x) * a.out_ld + col] = out[ct][r_] * out_unscale;
+                    const float v = (TAIL && ct == NCT - 1) ? fl_fold_tail(out[ct][r_]) : out[ct][r_];
+                    if (x < a.Xrows && col < a.d) dst[(base + x) * a.out_ld + col] = v * out_unscale;
                 }
             }
         } else {
@@ -581,10 +619,11 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
 #pragma unroll
                 for (int r_ = 0; r_ < 16; ++r_) {
                     const int x = xt * FL_XT + wave * 32 + acc_row(r_, h);
+                    const float v = (TAIL && ct == NCT - 1) ? fl_fold_tail(out[ct][r_]) : out[ct][r_];
                     if (x < a.Xrows && col < a.d) {
                         float* p = a.out + (base + x) * a.out_ld + col;
-                        if (sole) *p = out[ct][r_] * out_unscale;
-                        else unsafeAtomicAdd(p, out[ct][r_] * out_unscale);
+                        if (sole) *p = v * out_unscale;
+                        else unsafeAtomicAdd(p, v * out_unscale);
                     }
                 }
             }
@@ -794,7 +833,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
 
         // ---- S tile: D[y][x] = sum_k Y[y][k] X[x][k]
         v16f accS;
-        if constexpr (!SLOAD) accS = fl_score_tile<KS, F16>(T, a_off, xh, xl);
+        if constexpr (!SLOAD) accS = fl_score_tile<KS, F16, TAIL>(T, a_off, xh, xl);
 
         if (BASE == FLASH_FWD) {
             float t[16];
@@ -896,7 +935,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
                         float ls;
                         if (BASE == FLASH_DADJ) ls = lsec_x;
                         else if (MODE == FLASH_FDADJ) ls = mref;
-                        else ls = *reinterpret_cast<const float*>(T + (16 * s_ + fl_rho(8 * h + e + q)) * P + 4 * KP);
+                        else ls = *reinterpret_cast<const float*>(T + (16 * s_ + fl_rho(8 * h + e + q)) * P + LSEC);
                         w2[q] = __builtin_amdgcn_exp2f(fmaf(t[r_], c_s, VSH - ls));
                         if (MODE == FLASH_FDADJ) lsum += w2[q];
                     }
@@ -910,7 +949,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
             // ---- out[x][col] += sum_y V[y][x] Y[y][col]
             if constexpr (BASE != FLASH_FWD) {
                 const v8bf whv[2] = {wh[0].v, wh[1].v}, wlv[2] = {wl[0].v, wl[1].v};
-                fl_grad_tile<KS, NCT, F16>(T, tr_off, whv, wlv, out);
+                fl_grad_tile<KS, NCT, F16, TAIL>(T, tr_off, whv, wlv, out);
             }
         }
         if (++yb == a.YB) { yb = 0; ++tile; }
@@ -926,7 +965,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
 __global__ __launch_bounds__(256) void flash_merge_kernel(const float2* __restrict__ part, const float* __restrict__ pos, int64_t rows, int64_t Bp,
                                                           int Bc, int C, int XR, int KP, float* __restrict__ lse, float* __restrict__ rowloss,
                                                           float* __restrict__ dpos, float gscale, float* __restrict__ blocksum, char* __restrict__ adjrec,
-                                                          int nsets, int64_t set_bytes) {
+                                                          int nsets, int64_t set_bytes, int P) {
     __shared__ float red[256];
     const int64_t bpd = (Bp + 255) / 256;
     const int64_t dir = blockIdx.x / bpd, blk = blockIdx.x - dir * bpd;
@@ -947,9 +986,8 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(const float2* __restri
         mine = l - p;
         const int64_t c = r / Bc;
         const int x = (int)(r - c * Bc);
-        const int P = 4 * KP + 16;
-        for (int q = 0; q < nsets; ++q)  // every column chunk's record set carries the row's lsec
-            *reinterpret_cast<float*>(adjrec + q * set_bytes + ((dir * C + c) * XR + fl_rho(x)) * (int64_t)P + 4 * KP) = l * FL_LOG2E - log2f(gscale);
+        for (int q = 0; q < nsets; ++q)  // every column chunk's record set carries the row's lsec (the 16 bytes that close a record)
+            *reinterpret_cast<float*>(adjrec + q * set_bytes + ((dir * C + c) * XR + fl_rho(x)) * (int64_t)P + P - 16) = l * FL_LOG2E - log2f(gscale);
     }
     red[threadIdx.x] = mine;
     __syncthreads();
@@ -977,14 +1015,17 @@ int flash_chunks(int d) {
 }
 static int fl_kc(int d) { const int n = flash_chunks(d); return n > 0 ? d / n : d; }  // columns per chunk
 static int fl_ks(int d) { return (fl_kc(d) + 15) / 16; }
+// folded column tail (see fl_pitch): d = 4 (mod 16) with an odd number of k-steps — d = 36, 68, 100
+bool flash_tail4(int d) { return d <= 128 && (d & 15) == 4 && (fl_ks(d) & 1) && fl_ks(d) >= 3 && !kernel_env().flash_tail4_off; }
+static int fl_pitch_d(int d) { return fl_pitch(fl_ks(d), flash_tail4(d)); }
 bool flash_chunked(int d) { return d > 128 && flash_chunks(d) >= 1; }  // stored-score modes (possibly with a single chunk)
 // bytes of the stored scores in tile order (see s_tile in flash_kernel): whole 128 x 32 tiles
 size_t flash_tiled_scores_bytes(const LpDims& D) {
     const size_t xt = (D.Bc + FL_XT - 1) / FL_XT, yb = ((D.N + 31) / 32 * 32) / FL_YB;
     return (size_t)D.ndir * D.C * xt * yb * FL_XT * FL_YB * sizeof(float);
 }
-static size_t fl_adjset_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.Bc + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)); }
-static size_t fl_negset_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.N + 31) / 32 * 32) * fl_pitch(fl_ks(D.d)); }
+static size_t fl_adjset_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.Bc + 31) / 32 * 32) * fl_pitch_d(D.d); }
+static size_t fl_negset_bytes(const LpDims& D) { return (size_t)D.ndir * D.C * ((D.N + 31) / 32 * 32) * fl_pitch_d(D.d); }
 
 // score-filter index (flash_filter_index_kernel): item counts of the two orientations, entry capacity, bytes behind the statistics in `fpart`
 struct FlFilterDims {
@@ -1072,23 +1113,27 @@ static int fl_num_wg(int64_t tiles, int mode, int ks, int free_cus) {
     return nwg < 1 ? 1 : nwg;
 }
 
-template <int KS, int MODE, bool STORE_S, bool F16>
+template <int KS, int MODE, bool STORE_S, bool F16, bool TAIL>
 static int fl_launch_t(const FlashArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)fl_slots(MODE) * fl_slot_bytes(KS) + fl_sring_bytes(MODE);
+    const size_t lds = (size_t)fl_slots(MODE) * fl_slot_bytes(KS, TAIL) + fl_sring_bytes(MODE);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_kernel<KS, MODE, STORE_S, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_kernel<KS, MODE, STORE_S, F16, TAIL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             set_last_error("flash: cannot raise the dynamic LDS limit to %zu", lds);
             return MARIUS_ERR_HIP;
         }
         attr_done = true;
     }
-    flash_kernel<KS, MODE, STORE_S, F16><<<dim3((unsigned)a.nwg), dim3(FL_NT), lds, st>>>(a);
+    flash_kernel<KS, MODE, STORE_S, F16, TAIL><<<dim3((unsigned)a.nwg), dim3(FL_NT), lds, st>>>(a);
     return check_launch("flash_kernel");
 }
 template <int KS, int MODE, bool STORE_S>
 static int fl_launch(const FlashArgs& a, hipStream_t st) {
-    return a.rg.absmax ? fl_launch_t<KS, MODE, STORE_S, true>(a, st) : fl_launch_t<KS, MODE, STORE_S, false>(a, st);
+    if constexpr ((KS & 1) && KS >= 3 && KS <= 8 && MODE < FLASH_FWDS) {
+        if (flash_tail4(a.d) && (a.d + 15) / 16 == KS)
+            return a.rg.absmax ? fl_launch_t<KS, MODE, STORE_S, true, true>(a, st) : fl_launch_t<KS, MODE, STORE_S, false, true>(a, st);
+    }
+    return a.rg.absmax ? fl_launch_t<KS, MODE, STORE_S, true, false>(a, st) : fl_launch_t<KS, MODE, STORE_S, false, false>(a, st);
 }
 
 template <int MODE, bool STORE_S>
@@ -1185,13 +1230,14 @@ int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj,
     for (int c = 0; c < nch; ++c) {
         if (!adj_packed) {
             const int64_t n = (int64_t)D.ndir * D.C * XR * ppr;
-            flash_pack_adj_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(adj, D.d_ld, D.Bp, D.Bc, D.C, D.ndir, kc, KP, XR, adjrec + c * adjset, rg, c * kc);
+            flash_pack_adj_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(adj, D.d_ld, D.Bp, D.Bc, D.C, D.ndir, kc, KP, XR, adjrec + c * adjset, rg, c * kc,
+                                                                                      flash_tail4(D.d) ? 1 : 0);
         }
         const int64_t n = (int64_t)D.ndir * D.C * NR * ppr;
         ProfScope ps(PROF_LP_PACK, st);
         flash_pack_neg_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st>>>(desc->emb, desc->emb_ld, desc->dst_neg, desc->src_neg, D.N, D.C, D.ndir,
                                                                                  kc, KP, NR, row_vec_width(desc->emb, desc->emb_ld, 4), negrec + c * negset, gocc,
-                                                                                 D.d_ld, negocc_off[0], negocc_off[1], rg, c * kc);
+                                                                                 D.d_ld, negocc_off[0], negocc_off[1], rg, c * kc, flash_tail4(D.d) ? 1 : 0);
     }
     if (!adj_packed && (dadj_zero || wide)) flash_zero_kernel<<<dim3(1024), dim3(256), 0, st>>>(wide ? dadj : dadj_zero, D.ndir * D.Bp * D.d_ld, nullptr, 0, nullptr, 0);
     int rc = check_launch("flash_pack");
@@ -1256,7 +1302,7 @@ int flash_merge(const LpDims& D, const float2* part, const float* pos, float* ls
     const int64_t bpd = cdiv(D.Bp, 256);
     const int ks = fl_ks(D.d);
     flash_merge_kernel<<<dim3((unsigned)(bpd * D.ndir)), dim3(256), 0, st>>>(part, pos, D.Bp * D.ndir, D.Bp, D.Bc, D.C, (D.Bc + 31) / 32 * 32, 16 * ks, lse,
-                                                                            rowloss, dpos, D.gscale, blocksum, adjrec, flash_chunks(D.d), (int64_t)fl_adjset_bytes(D));
+                                                                            rowloss, dpos, D.gscale, blocksum, adjrec, flash_chunks(D.d), (int64_t)fl_adjset_bytes(D), fl_pitch_d(D.d));
     return check_launch("flash_merge");
 }
 

@@ -151,7 +151,8 @@ def check_gradients(W, decoder, emb, edges, dst_neg, src_neg, rel, inv, U, R, re
 
 
 SHAPES = [(6, 3, 5, 50), (100, 10, 50, 50), (1000, 10, 500, 100), (250, 7, 130, 100), (300, 4, 260, 128), (64, 2, 40, 64),
-          (5, 4, 6, 100), (2, 4, 64, 100), (1, 3, 33, 100), (777, 3, 1000, 112), (200, 4, 96, 20), (300, 5, 70, 40), (260, 2, 300, 80), (130, 3, 64, 96)]
+          (5, 4, 6, 100), (2, 4, 64, 100), (1, 3, 33, 100), (777, 3, 1000, 112), (200, 4, 96, 20), (300, 5, 70, 40), (260, 2, 300, 80), (130, 3, 64, 96),
+          (300, 5, 70, 36), (260, 2, 300, 68), (140, 2, 1000, 100)]  # d = 36 / 68 / 100: the folded column tail of the operand records (lp_flash.hip: fl_pitch)
 
 
 @pytest.mark.parametrize("f16", [False, True])
