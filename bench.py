@@ -88,12 +88,43 @@ def event_pair_overhead_ms(k=100):
     return tot / k
 
 
-def pmc_traffic_file(flash):
-    """newest committed PMC traffic summary of the default bench command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.py)"""
-    names = ["r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"] if flash else ["r1h_pmc_traffic.json"]
+def pmc_traffic_file(flash, workload="freebase86m", degree_fraction=0.0):
+    """newest committed PMC traffic summary of this workload's bench command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.py)"""
+    if not flash:
+        names = ["r1h_pmc_traffic.json"] if workload == "freebase86m" and not degree_fraction else []
+    elif workload == "twitter":
+        names = ["r5_pmc_traffic_twitter.json"]
+    elif degree_fraction:
+        names = ["r5_pmc_traffic_deg05.json"] if abs(degree_fraction - 0.5) < 1e-9 else []
+    elif workload == "freebase86m":
+        names = ["r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"]
+    else:
+        names = []
     for n in names:
         if os.path.exists(os.path.join(ROOT, "profiles", n)):
             return os.path.join(ROOT, "profiles", n)
+    return None
+
+
+def pmc_bytes_of(pmc, dom, flash):
+    """HBM bytes per launch of the kernel accounted as `dom` in a PMC summary (kernel names as rocprofv3 prints them)"""
+    import re
+    if flash:
+        modes = {"lp_scores": (0, 4), "lp_grad_adj": (3, 1, 5), "lp_grad_neg": (2, 6)}.get(dom)
+        if modes:
+            for m in modes:  # flash_kernel<KS, MODE, ...>: the first mode of the list that ran
+                for name, v in pmc.items():
+                    if re.match(r"flash_kernel<\d+, %d[,>]" % m, name):
+                        return v["hbm_bytes"]
+            return None
+        key = {"gather_rows": "gather_rows_kernel", "segment_adagrad_scatter": "adagrad_with_fixup_group_kernel", "lp_prep": "lp_prep2_kernel", "lp_pack": "flash_pack_neg_kernel",
+               "lp_edge_bwd": "lp_edge_bwd2_kernel"}.get(dom)
+    else:
+        key = {"lp_grad_adj": "lp_grad16_kernel", "lp_grad_neg": "lp_grad16_kernel", "lp_scores": "lp_scores_ap_kernel", "gather_rows": "gather_rows_kernel",
+               "segment_adagrad_scatter": "adagrad_unique_rows_kernel"}.get(dom)
+    for name, v in pmc.items():
+        if key and name.startswith(key):
+            return v["hbm_bytes"]
     return None
 
 
@@ -108,9 +139,7 @@ def dominant_roofline(avg_ms, B, C, N, d, ndir, flash, pmc_ok, kernel="lp_grad_a
     traffic = None
     pmc_path = pmc_traffic_file(flash)
     if pmc_ok and pmc_path:
-        for name, v in json.load(open(pmc_path))["kernels"].items():
-            if name.startswith(("flash_kernel<7, 3", "flash_kernel<7, 1") if flash else "lp_grad16_kernel"):
-                traffic = v["hbm_bytes"]
+        traffic = pmc_bytes_of(json.load(open(pmc_path))["kernels"], "lp_grad_adj", flash)
     out = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
            "traffic_source": ("%s (separate rocprofv3 --pmc passes of this command; a constant, NOT measured in this run)" % os.path.relpath(pmc_path, ROOT)) if traffic else None,
            "avg_ms": round(avg_ms, 4)}
@@ -498,18 +527,9 @@ def main():
         # HBM bytes per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
         # this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md) — only valid for the workload it was collected on
         traffic = None
-        pmc_path = pmc_traffic_file(flash)
-        if a.workload == "freebase86m" and not a.num_nodes and pmc_path:
-            pmc = json.load(open(pmc_path))["kernels"]
-            if flash:
-                key = {"lp_grad_adj": ("flash_kernel<7, 3", "flash_kernel<7, 1"), "lp_grad_neg": "flash_kernel<7, 2", "lp_scores": "flash_kernel<7, 0",
-                       "gather_rows": "gather_rows_kernel", "segment_adagrad_scatter": "adagrad_unique_rows_kernel"}.get(dom)
-            else:
-                key = {"lp_grad_adj": "lp_grad16_kernel", "lp_grad_neg": "lp_grad16_kernel", "lp_scores": "lp_scores_ap_kernel",
-                       "gather_rows": "gather_rows_kernel", "segment_adagrad_scatter": "adagrad_unique_rows_kernel"}.get(dom)
-            for name, v in pmc.items():
-                if key and name.startswith(key):
-                    traffic = v["hbm_bytes"]
+        pmc_path = pmc_traffic_file(flash, a.workload, a.degree_fraction)
+        if not a.num_nodes and a.loss.upper() == "SOFTMAX_CE" and pmc_path:
+            traffic = pmc_bytes_of(json.load(open(pmc_path))["kernels"], dom, flash)
         roofline = {"kernel": dom + (" (dAdj + dNeg contractions, one launch)" if not flash and dom == "lp_grad_adj" and prof.get("lp_grad_neg", (0, 0))[1] == 0 else ""),
                     "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"], "frac": k["frac"],
                     "traffic": traffic,
