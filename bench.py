@@ -253,14 +253,14 @@ def alt_arithmetic_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_
                 avg = ms / cnt
                 ach = 2 * contraction_flops / (avg * 1e-3) / 1e12
                 out.update({"kernel": "lp_grad16 (dAdj + dNeg contractions from the stored scores, one launch)", "kernel_avg_ms": round(avg, 4), "achieved": round(ach, 2),
-                            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4)})
+                            "peak": MFMA_F32_PEAK_TF, "kernel_unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4)})
         else:
             out.update({"dtype": "f32 (contractions: 2-way %s split x 3 products, f32 accumulate)" % model.last_step_records,
                         "note": "the flash path: NOT the headline because arith_check.ok is false"})
             if cnt:
                 avg = ms / cnt
                 ach = 2 * 3 * contraction_flops / (avg * 1e-3) / 1e12
-                out.update({"kernel": "flash fused sweep (scores + V Neg)", "kernel_avg_ms": round(avg, 4), "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                out.update({"kernel": "flash fused sweep (scores + V Neg)", "kernel_avg_ms": round(avg, 4), "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "kernel_unit": "TFLOP/s",
                             "frac": round(ach / MFMA_BF16_PEAK_TF, 4)})
         return out
     finally:

@@ -426,6 +426,12 @@ typedef struct marius_segment_update {
     float* absmax;
     int64_t fused_below; /* > 0 (needs a plan): unique rows whose single occurrence is an occurrence row < fused_below were already updated by the
                           * producer of `rows` (marius_lp_desc.upd_occ_single: the edge backward, occurrences [0, 2 B)) and are skipped */
+    /* A job with sum_out != NULL only REDUCES (marius_segment_sum_rows_planned as a job of the group; table / state / uniq_ids / lr / eps / absmax
+     * are ignored, a plan is required): sum_out[r(u), 0:d] = sum of the rows of unique index u, r(u) = sum_out_rows ? sum_out_rows[u] : u.  The sharded
+     * trainer's step has two relation-table updates and this reduction of the node gradients at its tail: one launch pair instead of three. */
+    float* sum_out;
+    int64_t sum_out_ld;
+    const int64_t* sum_out_rows;
 } marius_segment_update;
 int marius_segment_adagrad_scatter_group(const marius_segment_update* jobs, int32_t njobs, marius_stream_t stream);
 int marius_table_absmax(const float* table, int64_t rows, int64_t ld, int32_t d, float* absmax, marius_stream_t stream);

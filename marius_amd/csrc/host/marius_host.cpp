@@ -1404,14 +1404,38 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
 void Model::backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step, Tensor out_rows) {
     forward_lp_train(batch);  // (sharded table: the rows came from other ranks' shards; the bound is the one of the gathered copy itself, Batch::row_bound_)
     model_backward(*this, batch);
+    const int64_t L = batch->occ_perm_.size(0);
+    ensure(carry_, (int64_t)marius_segment_carry_bytes(L, ctx_.desc.d), device_);
+    const float* gocc = (const float*)((const char*)ctx_.workspace.data_ptr() + ctx_.layout.gocc);
+    const int64_t* orows = out_rows.defined() ? ip(out_rows) : nullptr;  // where unique row u's gradient goes (fixed-capacity exchange: marius_a2a_rows_post's place)
     bool done = false;
     if (local_relation_step) {
-        // both relation tables as jobs of ONE launch pair when the loader planned their maps (4 launches otherwise): same results bit for bit
-        marius_segment_update jobs[2] = {};
+        // The step's tail as ONE launch pair when the loader planned the maps: both relation tables' touched-rows Adagrad steps and the reduction of the
+        // node gradients are jobs of marius_segment_adagrad_scatter_group (the last one reduce-only: marius_segment_update.sum_out) — five launches
+        // otherwise (two pairs for the relation tables of round 4's four, reduce + fix-up for the nodes).  Same results bit for bit.
+        marius_segment_update jobs[3] = {};
         int njobs = 0;
         static const bool group_env = [] { const char* e = getenv("MARIUS_REL_GROUP"); return !(e && e[0] == '0'); }();
         if (group_env && relation_step_jobs(*this, batch, jobs, njobs)) {
+            bool nodes_in = false;
+            if (batch->occ_plan_.defined()) {
+                marius_segment_update& u = jobs[njobs++];
+                u.rows = gocc;
+                u.rows_ld = ctx_.layout.d_ld;
+                u.perm = batch->occ_perm_.data_ptr<int32_t>();
+                u.inverse = ip(batch->occ_inverse_);
+                u.seg_offsets = batch->occ_seg_offsets_.data_ptr<int32_t>();
+                u.n = L;
+                u.d = ctx_.desc.d;
+                u.carry = carry_.data_ptr();
+                u.plan = batch->occ_plan_.data_ptr();
+                u.sum_out = fp(grad_out);
+                u.sum_out_ld = grad_out.stride(0);
+                u.sum_out_rows = orows;
+                nodes_in = true;
+            }
             if (njobs > 0) mcheck(marius_segment_adagrad_scatter_group(jobs, njobs, cur_stream()));
+            if (nodes_in) return;
             done = true;
         } else {
             done = relation_step_sparse(*this, batch);
@@ -1421,10 +1445,6 @@ void Model::backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, b
         relation_grads_dense(*this, batch);
         if (local_relation_step) step();  // optimizer without a touched-rows form: dense step on this replica
     }
-    const int64_t L = batch->occ_perm_.size(0);
-    ensure(carry_, (int64_t)marius_segment_carry_bytes(L, ctx_.desc.d), device_);
-    const float* gocc = (const float*)((const char*)ctx_.workspace.data_ptr() + ctx_.layout.gocc);
-    const int64_t* orows = out_rows.defined() ? ip(out_rows) : nullptr;  // where unique row u's gradient goes (fixed-capacity exchange: marius_a2a_rows_post's place)
     if (batch->occ_plan_.defined())
         mcheck(marius_segment_sum_rows_planned(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
                                                batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, orows, fp(grad_out), grad_out.stride(0),

@@ -426,6 +426,43 @@ __device__ __forceinline__ void adagrad_rows_body(const AdagradRowsArgs& A, int6
     track_absmax(A.absmax, seen);
 }
 
+// Reduce-only job of a group (marius_segment_update.sum_out): the rows that occur once are COPIED — occurrence row -> output row — by the row
+// blocks of the second launch (the reduce launch skipped them, exactly as it does for the Adagrad jobs); every other row was written by the reduce
+// launch or is finished by the fix-up blocks.  Same thread layout as adagrad_rows_body.
+template <int VEC>
+__device__ __forceinline__ void copy_single_rows_body(const AdagradRowsArgs& A, const ApplySum& S, int64_t block) {
+    const int TX = A.tx_n, TY = 256 / TX;
+    const int ty = threadIdx.x / TX, tx = threadIdx.x - ty * TX;
+    constexpr int UNR = MARIUS_ADAGRAD_UNR;
+    const float* src[UNR];
+    float* dst[UNR];
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+        const int64_t row = (block * UNR + k) * TY + ty;
+        src[k] = nullptr;
+        dst[k] = nullptr;
+        if (ty < TY && row < A.n) {
+            const int4 q = A.row_plan[row];
+            if (q.z >= 0 && !(q.x == -1 && q.y == -1)) {  // a real row (not past the unique count, not padding) with a single occurrence
+                src[k] = A.occ + (int64_t)q.z * A.occ_ld;
+                dst[k] = S.out + (S.out_rows ? S.out_rows[row] : row) * S.out_ld;
+            }
+        }
+    }
+    for (int c = tx; c < A.vpr; c += TX) {
+        float v[UNR][VEC];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k)
+            if (src[k]) load_vec<VEC>(src[k] + c * VEC, v[k]);
+#pragma unroll
+        for (int k = 0; k < UNR; ++k)
+            if (src[k]) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) dst[k][c * VEC + e] = v[k][e];
+            }
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void adagrad_unique_rows_kernel(AdagradRowsArgs A) {
     adagrad_rows_body<VEC>(A, (int64_t)blockIdx.x);
@@ -452,6 +489,7 @@ struct SegJob {
     ApplyAdagrad ada;
     AdagradRowsArgs A;
     unsigned red0, upd0, nfix;  // first workgroup of the job in the reduce / update grid; fix-up workgroups at the head of its update range
+    int sum_only;               // 1: a reduce-only job (marius_segment_update.sum_out): `sum` is the destination itself, the row blocks copy the singletons
 };
 struct SegGroup {
     SegJob job[SEG_GROUP_MAX];
@@ -476,7 +514,12 @@ __global__ __launch_bounds__(256) void adagrad_with_fixup_group_kernel(SegGroup 
 #define SEG_JOB(J)                                                                                          \
     if (J == G.njobs - 1 || b0 < G.job[J + 1 < SEG_GROUP_MAX ? J + 1 : J].upd0) {                             \
         const unsigned b = b0 - G.job[J].upd0;                                                              \
-        if (b < G.job[J].nfix)                                                                              \
+        if (G.job[J].sum_only) {                                                                            \
+            if (b < G.job[J].nfix)                                                                          \
+                seg_fixup_body<VEC, NIT, ApplySum>(G.job[J].sa, G.job[J].sum, (int64_t)b);                   \
+            else                                                                                            \
+                copy_single_rows_body<VEC>(G.job[J].A, G.job[J].sum, (int64_t)(b - G.job[J].nfix));          \
+        } else if (b < G.job[J].nfix)                                                                       \
             seg_fixup_body<VEC, NIT, ApplyAdagrad>(G.job[J].sa, G.job[J].ada, (int64_t)b);                   \
         else                                                                                                \
             adagrad_rows_body<VEC>(G.job[J].A, (int64_t)(b - G.job[J].nfix));                                \
@@ -749,20 +792,24 @@ extern "C" int marius_segment_adagrad_scatter_group(const marius_segment_update*
     int per0 = 0;
     for (int j = 0; j < njobs && grouped; ++j) {  // the single-launch planned form's conditions (segment_adagrad_scatter_impl), for every job
         const marius_segment_update& u = jobs[j];
-        if (!(u.n > 0 && u.plan && u.d > 0 && u.d <= 512 && u.rows && u.perm && u.inverse && u.seg_offsets && u.carry && u.uniq_ids && u.table && u.state &&
-              u.rows_ld >= u.d && u.table_ld >= u.d)) { grouped = false; break; }
-        const int v = row_vec_width(u.rows, u.rows_ld, u.d), v2 = row_vec_width(u.table, u.table_ld, u.d), v3 = row_vec_width(u.state, u.table_ld, u.d);
+        const bool so = u.sum_out != nullptr;
+        if (!(u.n > 0 && u.plan && u.d > 0 && u.d <= 512 && u.rows && u.perm && u.inverse && u.seg_offsets && u.carry && u.rows_ld >= u.d &&
+              (so ? u.sum_out_ld >= u.d : (u.uniq_ids && u.table && u.state && u.table_ld >= u.d)))) { grouped = false; break; }
+        const int v = row_vec_width(u.rows, u.rows_ld, u.d);
+        const int v2 = so ? row_vec_width(u.sum_out, u.sum_out_ld, u.d) : row_vec_width(u.table, u.table_ld, u.d), v3 = so ? 4 : row_vec_width(u.state, u.table_ld, u.d);
         const int per = cdiv(u.d, 256);
         if (v != 4 || v2 != 4 || v3 != 4 || per > 2 || (j > 0 && per != per0)) grouped = false;
         for (int i = 0; i < j; ++i)  // jobs run side by side: a shared scratch or a shared table would race
-            if (jobs[i].carry == u.carry || jobs[i].table == u.table || jobs[i].state == u.state) grouped = false;
+            if (jobs[i].carry == u.carry || (!so && !jobs[i].sum_out && (jobs[i].table == u.table || jobs[i].state == u.state)) || (so && jobs[i].sum_out == u.sum_out))
+                grouped = false;
         per0 = per;
     }
     if (!grouped) {
         for (int j = 0; j < njobs; ++j) {
             const marius_segment_update& u = jobs[j];
-            int rc = segment_adagrad_scatter_impl(u.rows, u.rows_ld, u.perm, u.inverse, u.seg_offsets, u.n, u.d, u.uniq_ids, u.table, u.state, u.table_ld, u.lr, u.eps,
-                                                  u.carry, u.plan, u.absmax, stream, u.fused_below);
+            int rc = u.sum_out ? segment_sum_rows_impl(u.rows, u.rows_ld, u.perm, u.inverse, u.seg_offsets, u.n, u.d, u.sum_out_rows, u.sum_out, u.sum_out_ld, u.carry, u.plan, stream)
+                               : segment_adagrad_scatter_impl(u.rows, u.rows_ld, u.perm, u.inverse, u.seg_offsets, u.n, u.d, u.uniq_ids, u.table, u.state, u.table_ld, u.lr, u.eps,
+                                                              u.carry, u.plan, u.absmax, stream, u.fused_below);
             if (rc) return rc;
         }
         return MARIUS_OK;
@@ -778,7 +825,8 @@ extern "C" int marius_segment_adagrad_scatter_group(const marius_segment_update*
         if (rc) return rc;
         float* gsum = (float*)((char*)u.carry + carry_only_bytes(u.n, u.d));
         const int64_t g_ld = dpad_of(u.d);
-        J.sum = ApplySum{gsum, g_ld, nullptr};
+        J.sum_only = u.sum_out ? 1 : 0;
+        J.sum = u.sum_out ? ApplySum{u.sum_out, u.sum_out_ld, u.sum_out_rows} : ApplySum{gsum, g_ld, nullptr};
         J.sa.skip_singletons = 1;
         const char* pp = (const char*)u.plan;
         J.sa.pos_plan = (const int4*)pp;

@@ -533,12 +533,13 @@ class SegmentUpdate(C.Structure):
     """marius_segment_update (include/marius_hip.h): one table's job of marius_segment_adagrad_scatter_group"""
     _fields_ = [("rows", C.c_void_p), ("rows_ld", C.c_int64), ("perm", C.c_void_p), ("inverse", C.c_void_p), ("seg_offsets", C.c_void_p), ("n", C.c_int64),
                 ("d", C.c_int32), ("uniq_ids", C.c_void_p), ("table", C.c_void_p), ("state", C.c_void_p), ("table_ld", C.c_int64), ("lr", C.c_float),
-                ("eps", C.c_float), ("carry", C.c_void_p), ("plan", C.c_void_p), ("absmax", C.c_void_p), ("fused_below", C.c_int64)]
+                ("eps", C.c_float), ("carry", C.c_void_p), ("plan", C.c_void_p), ("absmax", C.c_void_p), ("fused_below", C.c_int64),
+                ("sum_out", C.c_void_p), ("sum_out_ld", C.c_int64), ("sum_out_rows", C.c_void_p)]
 
 
 def segment_adagrad_scatter_group(jobs):
-    """jobs: list of dicts with the keyword arguments of segment_adagrad_scatter (rows, um, n, d, table, state, lr [, eps, carry, plan, absmax]);
-    all tables updated by one pair of launches"""
+    """jobs: list of dicts with the keyword arguments of segment_adagrad_scatter (rows, um, n, d, table, state, lr [, eps, carry, plan, absmax]),
+    or reduce-only jobs (rows, um, n, d, plan, sum_out [, sum_out_rows, carry]); all of them in one pair of launches"""
     arr = (SegmentUpdate * len(jobs))()
     keep = []
     for a, j in zip(arr, jobs):
@@ -549,8 +550,13 @@ def segment_adagrad_scatter_group(jobs):
             carry = segment_carry(n, d, rows.device)
         keep.append(carry)
         a.rows, a.rows_ld, a.perm, a.inverse, a.seg_offsets, a.n, a.d = ptr(rows), rows.stride(0), ptr(um.perm), ptr(um.inverse), ptr(um.seg), n, d
+        a.carry, a.plan = ptr(carry), ptr(j.get("plan"))
+        if j.get("sum_out") is not None:  # a reduce-only job (marius_segment_update.sum_out)
+            out = j["sum_out"]
+            a.sum_out, a.sum_out_ld, a.sum_out_rows = ptr(out), out.stride(0), ptr(j.get("sum_out_rows"))
+            continue
         a.uniq_ids, a.table, a.state, a.table_ld = ptr(um.uniq), ptr(j["table"]), ptr(j["state"]), j["table"].stride(0)
-        a.lr, a.eps, a.carry, a.plan, a.absmax = j["lr"], j.get("eps", 1e-10), ptr(carry), ptr(j.get("plan")), ptr(j.get("absmax"))
+        a.lr, a.eps, a.absmax = j["lr"], j.get("eps", 1e-10), ptr(j.get("absmax"))
         a.fused_below = int(j.get("fused_below", 0))
     check(lib().marius_segment_adagrad_scatter_group(C.cast(arr, C.c_void_p), len(jobs), stream_ptr()), "segment_adagrad_scatter_group")
 

@@ -501,6 +501,44 @@ def test_grouped_update_of_three_tables_equals_the_separate_updates(H, dev, plan
         assert float(bw) == float(bg) == float(tg.abs().max())
 
 
+@pytest.mark.parametrize("with_rows", [False, True])
+def test_group_with_a_reduce_only_job_equals_the_separate_calls(H, dev, with_rows):
+    """marius_segment_update.sum_out: the sharded step's tail — both relation tables' Adagrad steps AND the reduction of the node gradients into the
+    gradient payload — as one launch pair.  The reduce-only job must equal marius_segment_sum_rows_planned (bit for bit; the rows with a single
+    occurrence are copied instead of summed from zero), with and without the output-row indirection, and the Adagrad jobs beside it their own calls."""
+    g = torch.Generator().manual_seed(23)
+    d, n, nrows, nrel, B = 100, 200000, 150000, 3000, 50000
+    ids = (torch.rand(n, generator=g) ** 3 * nrows).long().clamp_(0, nrows - 1)
+    um = H.UniqueMap(n, dev).run(ids.to(dev), key_bits=28)
+    plan = H.segment_plan(um, n)
+    U = int(um.count.item())
+    rows = (torch.randn(n, d, generator=g) * 0.1).to(dev)
+    out_rows = torch.randperm(n, generator=g).to(dev) if with_rows else None   # any injective map into an [n, d] payload
+    want = torch.full((n, d), 7.0, device=dev)
+    H.segment_sum_rows(rows, um, n, d, want, out_rows=out_rows, plan=plan)
+    rel_ids = (torch.rand(B, generator=g) ** 3 * nrel).long().clamp_(0, nrel - 1)
+    rm = H.UniqueMap(B, dev).run(rel_ids.to(dev), key_bits=14)
+    rplan = H.segment_plan(rm, B)
+    rrows = [(torch.randn(B, d, generator=g) * 0.1).to(dev) for _ in range(2)]
+    tabs = [(torch.randn(nrel, d, generator=g) * 1e-3, torch.rand(nrel, d, generator=g) * 1e-4) for _ in range(2)]
+    ref = []
+    for (t, s_), r in zip(tabs, rrows):
+        tw, sw = t.to(dev), s_.to(dev)
+        H.segment_adagrad_scatter(r, rm, B, d, tw, sw, lr=0.1, plan=rplan)
+        ref.append((tw, sw))
+    got = torch.full((n, d), 7.0, device=dev)
+    mine = [(t.to(dev), s_.to(dev)) for t, s_ in tabs]
+    H.segment_adagrad_scatter_group([dict(rows=rrows[0], um=rm, n=B, d=d, table=mine[0][0], state=mine[0][1], lr=0.1, plan=rplan),
+                                     dict(rows=rrows[1], um=rm, n=B, d=d, table=mine[1][0], state=mine[1][1], lr=0.1, plan=rplan),
+                                     dict(rows=rows, um=um, n=n, d=d, plan=plan, sum_out=got, sum_out_rows=out_rows)])
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)   # (untouched payload rows keep their 7.0 in both)
+    touched = (got != 7.0).any(1).sum().item()
+    assert touched == U
+    for (tw, sw), (tg, sg) in zip(ref, mine):
+        assert torch.equal(tw, tg) and torch.equal(sw, sg)
+
+
 # ------------------------------------------------------------------------------------------------ whole steps vs the CPU path
 @pytest.mark.parametrize("decoder,f", [("COMPLEX", 0.0), ("DISTMULT", 0.5), ("TRANSE", 0.0)])
 def test_train_steps_match_cpu_reference_path(H, dev, decoder, f):
