@@ -76,7 +76,7 @@ MariusGenerator::~MariusGenerator() {
         if (p.ready) (void)hipEventDestroy((hipEvent_t)p.ready);
         if (p.done) (void)hipEventDestroy((hipEvent_t)p.done);
     }
-    if (side_stream_) (void)hipStreamDestroy((hipStream_t)side_stream_);
+    if (side_stream_ && side_stream_owned_) (void)hipStreamDestroy((hipStream_t)side_stream_);
 }
 void MariusGenerator::drop_pools() {
     for (auto& p : pools_) {
@@ -136,12 +136,15 @@ Tensor MariusGenerator::raw_words(int64_t n, torch::Device dev) {
         hipStream_t s;
         HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         side_stream_ = s;
-        // the state upload / earlier direct fills were enqueued on the main stream: order the side stream after them
+    }
+    if (!side_ordered_) {
+        // the state upload / earlier direct fills were enqueued on the main stream: order the fill stream (own or the caller's) after them
         hipEvent_t e;
         HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHECK(hipEventRecord(e, main));
-        HIPCHECK(hipStreamWaitEvent(s, e, 0));
+        HIPCHECK(hipStreamWaitEvent((hipStream_t)side_stream_, e, 0));
         HIPCHECK(hipEventDestroy(e));
+        side_ordered_ = true;
     }
     const int64_t want = std::max<int64_t>(n * pool_requests_, 1 << 16);
     for (int i = 0; i < 2; ++i) {

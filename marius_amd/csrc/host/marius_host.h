@@ -70,6 +70,13 @@ class MariusGenerator {
     // to exactly the consumed position, so host draws (randperm at the epoch boundary) stay in sequence.
     bool prefetch_ = true;
     int pool_requests_ = 16;
+    // the pool fills run on a stream of the caller's instead of one of their own (not owned; set before the first draw).  The sharded trainer hands
+    // over its exchange stream: a stream of the generator's own would be the process's fifth (sharded_trainer.cpp)
+    void use_fill_stream(void* hip_stream) {
+        side_stream_ = hip_stream;
+        side_stream_owned_ = false;
+        side_ordered_ = false;
+    }
 
    private:
     struct Pool {
@@ -83,6 +90,8 @@ class MariusGenerator {
     Pool pools_[2];
     int cur_ = 0;
     void* side_stream_ = nullptr;  // hipStream_t
+    bool side_stream_owned_ = true;
+    bool side_ordered_ = false;  // the fill stream has been ordered behind the state upload
     void fill_pool(int i, torch::Device dev);
     void drop_pools();
 };

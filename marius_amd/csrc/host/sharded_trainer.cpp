@@ -100,13 +100,22 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
         const char* e = getenv("MARIUS_SHARDED_FREE_CUS");
         model_->ctx_.free_cus = e ? atoi(e) : 32;
     }
-    // The MT19937 words are produced on the preparation stream itself, request by request: the run-ahead pool's own stream is a FIFTH stream
-    // beside compute / preparation / exchange / RCCL, and with the runtime's four hardware queues it lands on the compute stream's queue — its
-    // 0.9 ms single-workgroup fill then stands in front of the matrix launches every eighth batch (0.845 vs 0.763 ms per step, world 1); a fifth
-    // hardware queue (GPU_MAX_HW_QUEUES=5) is worse still (1.20 ms).  profiles/r5_sharded_streams.txt
+    // Where the MT19937 words come from.  The run-ahead pool's own stream would be a FIFTH stream beside compute / preparation / exchange / RCCL, and
+    // with the runtime's four hardware queues it lands on the compute stream's queue — its 0.9 ms single-workgroup fill then stands in front of the
+    // matrix launches every eighth batch (0.762-0.845 ms per step at world 1; a fifth hardware queue, GPU_MAX_HW_QUEUES=5, is worse still: 1.20 ms).
+    // Default: generated on the preparation stream itself, request by request (0.661 ms on the box of the A/B, profiles/r5_sharded_streams.txt).
+    // MARIUS_MT_FILL=xchg keeps the pool, one batch per pool, filled on the EXCHANGE stream (tried because the preparation stream's ~25 dependent
+    // launches are the step's critical path and the two fills are 0.15 ms of it: 0.749 ms — the fills delay the exchange more than they spared the
+    // preparation); =own: the pool on a stream of its own, round 4's form.
     if (loader_->generator_) {
-        static const bool pool_env = [] { const char* e = getenv("MARIUS_MT_PREFETCH"); return e && e[0] == '1'; }();
-        loader_->generator_->prefetch_ = pool_env;
+        static const char mode = [] { const char* e = getenv("MARIUS_MT_FILL"); return e ? e[0] : 'p'; }();
+        if (mode == 'x' && staleness_ > 0) {
+            loader_->generator_->prefetch_ = true;
+            loader_->generator_->pool_requests_ = 2;
+            loader_->generator_->use_fill_stream((void*)strm(xchg_stream_).stream());
+        } else if (mode != 'o') {
+            loader_->generator_->prefetch_ = false;
+        }
     }
     {
         Scope scope(strm(main_stream_));  // the permutation upload is ordered before the first preparation (which waits for this stream)
