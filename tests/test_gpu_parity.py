@@ -762,11 +762,13 @@ def test_fixed_capacity_exchange_halves_against_numpy(H, dev, world, cap_slack):
     """marius_a2a_rows_post / _wait and the dead (-1) padding through merge -> plan -> grouped update, against a numpy restatement and against the
     same update on the compacted lists.  One process plays every rank: `world` requesters, each asking `world` owners (contiguous
     id ranges of ceil(num_nodes / world) rows, storage.cpp:75); the all-to-alls are index shuffles here."""
+    from oracle import exchange_oracle as X
+
     g = torch.Generator().manual_seed(11 + world)
     num_nodes, d, L = 5000, 100, 1600
     S = (num_nodes + world - 1) // world
     cap = H.a2a_capacity(L, world, cap_slack)
-    assert cap == (L if world == 1 else min(L, (int(L / world * cap_slack) + 1 + 255) // 256 * 256))
+    assert cap == X.capacity(L, world, cap_slack)
     table = torch.rand(num_nodes, d, generator=g) - 0.5
     reqs, places, ums, invs, slots = [], [], [], [], []
     for r in range(world):
@@ -780,15 +782,8 @@ def test_fixed_capacity_exchange_halves_against_numpy(H, dev, world, cap_slack):
         req, place, flag, slot = H.a2a_rows_post(um, offs, S, world, cap, inverse=um.inverse)
         torch.cuda.synchronize()
         uq, of = um.uniq[:U].cpu().numpy(), offs.cpu().numpy()
-        want_req = np.full(world * cap, -1, dtype=np.int64)
-        want_place = np.zeros(U, dtype=np.int64)
-        over = False
-        for q in range(world):
-            cnt = int(of[q + 1] - of[q])
-            over |= cnt > cap
-            c = min(cnt, cap)
-            want_req[q * cap + cap - c:(q + 1) * cap] = uq[of[q]:of[q] + c] - q * S
-            want_place[of[q]:of[q] + c] = np.arange(q * cap + cap - c, (q + 1) * cap)
+        assert np.array_equal(of, X.owner_offsets(uq, S, world))
+        want_req, want_place, over = X.post(uq, S, world, cap)   # oracle/exchange_oracle.py: the numpy restatement
         assert bool(flag.item()) == over
         if over:
             continue
