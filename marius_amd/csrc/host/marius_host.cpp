@@ -2044,7 +2044,7 @@ shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
     inverse_ = torch::empty({L}, i64(dev));
     perm_ = torch::empty({L}, i32(dev));
     seg_ = torch::empty({L + 1}, i32(dev));
-    count_ = torch::zeros({1}, i64(dev));
+    count_ = torch::empty({1}, i64(dev));  // (written by the sort's emit launch — or its empty-input launch — before anything reads it: no zero fill)
     const size_t wsb = marius_sort_unique_workspace_bytes(L);
     if (!sort_ws_.defined() || (size_t)sort_ws_.numel() < wsb) sort_ws_ = torch::zeros({(int64_t)wsb}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));  // zeroed: the sort's control block
     mcheck(marius_assemble_ids(ip(edges), B, cols, ip(batch->src_neg_indices_), ip(batch->dst_neg_indices_), CN, ip(all_ids_), st));
@@ -2072,7 +2072,7 @@ shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
         batch->rel_inverse_ = torch::empty({B}, i64(dev));
         batch->rel_perm_ = torch::empty({B}, i32(dev));
         batch->rel_seg_ = torch::empty({B + 1}, i32(dev));
-        batch->rel_count_ = torch::zeros({1}, i64(dev));
+        batch->rel_count_ = torch::empty({1}, i64(dev));
         mcheck(marius_sort_unique(ip(rel_ids), B, key_bits_for(num_relations_), ip(batch->rel_uniq_), ip(batch->rel_inverse_),
                                   batch->rel_perm_.data_ptr<int32_t>(), batch->rel_seg_.data_ptr<int32_t>(), ip(batch->rel_count_), sort_ws_.data_ptr(),
                                   (size_t)sort_ws_.numel(), st));

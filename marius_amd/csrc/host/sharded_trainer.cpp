@@ -275,8 +275,10 @@ void ShardedTrainer::prepare(int64_t t) {
         s.cnt_recv_host.copy_(s.cnt_recv_dev, /*non_blocking=*/true);
         }
         s.stamp_value = t + 1;
-        s.stamp_dev.fill_(s.stamp_value);
-        s.stamp_host.copy_(s.stamp_dev, /*non_blocking=*/true);  // the last operation of the preparation: see Slot::stamp_host
+        // the last operation of the preparation (see Slot::stamp_host): ONE copy out of a device table of stamp values (no fill launch)
+        if (!stamps_dev_.defined() || s.stamp_value > stamps_dev_.size(0))
+            stamps_dev_ = torch::arange(1, std::max<int64_t>(2 * s.stamp_value, 1 << 16) + 1, torch::TensorOptions().dtype(torch::kInt64).device(table_.device()));
+        s.stamp_host.copy_(stamps_dev_.narrow(0, s.stamp_value - 1, 1), /*non_blocking=*/true);
     }
     span_end(s, 0, prep_stream_);
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.ready, prep.stream()));

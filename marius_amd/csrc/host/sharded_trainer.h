@@ -116,6 +116,7 @@ class ShardedTrainer {
     Tensor buf_req_, buf_rows_, buf_recv_grad_, emb_[RING], grad_[RING], local_[RING];
     // owner-side dedupe of the received ids
     Tensor r_ws_, r_carry_;
+    Tensor stamps_dev_;  // 1, 2, 3, ...: the stamp of batch t is copied out of it (Slot::stamp_host)
     int64_t r_cap_ = 0;
     // fixed-capacity exchange: shared staging (each is produced and consumed inside one stage on the exchange stream)
     bool fixed_ = false;
