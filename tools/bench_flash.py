@@ -13,7 +13,7 @@ dn, sn = torch.randint(U, (C, N), generator=g).to(dev), torch.randint(U, (C, N),
 rel, inv = (torch.randn(R, d, generator=g) * 0.3 + 1).to(dev), (torch.randn(R, d, generator=g) * 0.3 + 1).to(dev)
 for name, flags in (("flash", H.LP_TRAIN_ONLY), ("materialised", 0)):
     W = H.LpWorkspace(1, 0, d, B, C, N, True, H.REDUCE_SUM, 3, True, dev, flags=flags)
-    W.bind(emb, edges, dn, sn, rel, inv)
+    W.bind(emb, edges, dn, sn, rel, inv, absmax=torch.cat([H.table_absmax(emb), H.table_absmax(rel, inv)]) if flags else None)  # fp16 records, as every trainer packs them
     for _ in range(3):
         W.forward(); W.loss(); W.backward()
     torch.cuda.synchronize()
@@ -28,7 +28,7 @@ for name, flags in (("flash", H.LP_TRAIN_ONLY), ("materialised", 0)):
         name, W.layout.flash, tf / K, tl / K, tb / K, (tf + tl + tb) / K, float(W.loss_values()[0]), W.layout.total_bytes / 1e6))
 H.profile_enable(True)
 W = H.LpWorkspace(1, 0, d, B, C, N, True, H.REDUCE_SUM, 3, True, dev, flags=H.LP_TRAIN_ONLY)
-W.bind(emb, edges, dn, sn, rel, inv)
+W.bind(emb, edges, dn, sn, rel, inv, absmax=torch.cat([H.table_absmax(emb), H.table_absmax(rel, inv)]))
 H.profile_reset()
 for _ in range(10):
     W.forward(); W.loss(); W.backward()
