@@ -93,6 +93,16 @@ constexpr int FL_WAVES = FL_WAVES_N, FL_NT = 64 * FL_WAVES, FL_XT = 32 * FL_WAVE
 #ifndef FL_S_DEEP
 #define FL_S_DEEP 0
 #endif
+// 1: the DMA pieces of the next streamed block are issued between the k-steps of the score contraction instead of in a run at the top of the item
+#ifndef FL_DMA_INTERLEAVE
+#define FL_DMA_INTERLEAVE 1
+#endif
+#ifndef FL_DMA_KS0   // first k-step that is followed by a DMA piece, and the k-step distance between pieces
+#define FL_DMA_KS0 0
+#endif
+#ifndef FL_DMA_STRIDE
+#define FL_DMA_STRIDE 1
+#endif
 __host__ __device__ constexpr int fl_slots(int mode) { return FL_WAVES == 8 ? 6 : (mode == 0 ? FL_FWD_SLOTS : (mode >= 4 && !FL_S_DEEP) ? 3 : 4); }
 // the stored-score modes (d > 128) keep a second ring beside the streamed blocks — the 16 KB score tile of every item in flight — and
 // run one workgroup per CU for it
@@ -330,8 +340,10 @@ __device__ __forceinline__ v16f fl_mfma(const v8bf& a, const v8bf& b, v16f c) {
 // latency inside the matrix phase.
 // TAIL: the last k-step is the folded column tail — the streamed fragment [T | 0] against xh[KS - 1] = [h' h' | 0] and xl[KS - 1] = [l' 0 | 0]
 // (built by load_x): two MFMAs, no lo fragment
-template <int KS, bool F16, bool TAIL>
-__device__ __forceinline__ v16f fl_score_tile(const unsigned char* T, int a_off, const v8bf (&xh)[KS], const v8bf (&xl)[KS]) {
+// `between(ks)` runs after the MFMAs of k-step ks (FL_DMA_INTERLEAVE: the next block's DMA pieces are issued there, one per k-step, into the
+// shadow of the matrix instructions in flight instead of in a run of their own at the top of the item)
+template <int KS, bool F16, bool TAIL, class Between>
+__device__ __forceinline__ v16f fl_score_tile(const unsigned char* T, int a_off, const v8bf (&xh)[KS], const v8bf (&xl)[KS], const Between& between) {
     constexpr int KP = 16 * KS;
     v16f accM, accC;
 #pragma unroll
@@ -357,6 +369,7 @@ __device__ __forceinline__ v16f fl_score_tile(const unsigned char* T, int a_off,
         accC = fl_mfma<F16>(yh[ks % 3], xl[ks], accC);
         if (!(TAIL && ks == KS - 1)) accC = fl_mfma<F16>(yl[ks % 3], xh[ks], accC);
 #endif
+        between(ks);
     }
     v16f acc;
 #pragma unroll
@@ -441,18 +454,23 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
     // iteration (it cannot tell which slot a DMA writes), which serialises the ring.  M0 = LDS byte address of the piece.
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto dma = [&](int tile, int yb, int slot) {
+    auto dma_piece = [&](const char* src, unsigned dst, int i) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src + i * (FL_WAVES * 1024)), "s"(dst + (unsigned)(i * FL_WAVES * 1024))
+                     : "memory");
+    };
+    auto dma_src = [&](int tile, int yb) {
         const int cdp = tile / a.XT;
-        const char* src = a.yrec + (((int64_t)cdp * a.YR + (int64_t)yb * FL_YB) * P) + lane * 16 + wave_u * 1024;
-        const unsigned dst = lds_base + (unsigned)(slot * SLOT) + (unsigned)(wave_u * 1024);
+        return a.yrec + (((int64_t)cdp * a.YR + (int64_t)yb * FL_YB) * P) + lane * 16 + wave_u * 1024;
+    };
+    auto dma_dst = [&](int slot) { return lds_base + (unsigned)(slot * SLOT) + (unsigned)(wave_u * 1024); };
+    auto dma = [&](int tile, int yb, int slot) {
+        const char* src = dma_src(tile, yb);
+        const unsigned dst = dma_dst(slot);
 #pragma unroll
-        for (int i = 0; i < DMA_PER_WAVE; ++i) {
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(src + i * (FL_WAVES * 1024)), "s"(dst + (unsigned)(i * FL_WAVES * 1024))
-                         : "memory");
-        }
+        for (int i = 0; i < DMA_PER_WAVE; ++i) dma_piece(src, dst, i);
     };
 
     // stored-score modes, tile order: the score tile of an item travels with its streamed block, straight into LDS (a register prefetch cannot
@@ -820,7 +838,15 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * DMA_PER_WAVE) : "memory");
             __builtin_amdgcn_s_barrier();
         }
-        dma(ptile, ps.lo + ps.r, pslot);
+        // the next block's DMA: FL_DMA_INTERLEAVE spreads its pieces over the first k-steps of this item's score contraction (the order of the
+        // loads and the counted waits are unchanged: all pieces are issued before the next item's wait)
+        constexpr bool DMA_IL = FL_DMA_INTERLEAVE && !SLOAD && !SACC && KS >= FL_DMA_KS0 + FL_DMA_STRIDE * (DMA_PER_WAVE - 1) + 1;
+        const char* nsrc = dma_src(ptile, ps.lo + ps.r);
+        const unsigned ndst = dma_dst(pslot);
+        if constexpr (!DMA_IL) {
+#pragma unroll
+            for (int i = 0; i < DMA_PER_WAVE; ++i) dma_piece(nsrc, ndst, i);
+        }
         padvance();
         pslot = pslot + 1 == NSLOT ? 0 : pslot + 1;
         const unsigned char* T = smem + slot * SLOT;
@@ -833,7 +859,13 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
 
         // ---- S tile: D[y][x] = sum_k Y[y][k] X[x][k]
         v16f accS;
-        if constexpr (!SLOAD) accS = fl_score_tile<KS, F16, TAIL>(T, a_off, xh, xl);
+        if constexpr (!SLOAD)
+            accS = fl_score_tile<KS, F16, TAIL>(T, a_off, xh, xl, [&](int ks) {
+                if constexpr (DMA_IL) {
+                    if (ks >= FL_DMA_KS0 && (ks - FL_DMA_KS0) % FL_DMA_STRIDE == 0 && (ks - FL_DMA_KS0) / FL_DMA_STRIDE < DMA_PER_WAVE)
+                        dma_piece(nsrc, ndst, (ks - FL_DMA_KS0) / FL_DMA_STRIDE);
+                }
+            });
 
         if (BASE == FLASH_FWD) {
             float t[16];
@@ -944,6 +976,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
                     float lo0, lo1;
                     fl_lo_pair<F16>(w2[0], w2[1], hi, lo0, lo1);
                     wl[s_].u[e >> 1] = fl_cvt16x2<F16>(lo0, lo1);
+
                 }
             }
             // ---- out[x][col] += sum_y V[y][x] Y[y][col]
