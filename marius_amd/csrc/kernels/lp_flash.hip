@@ -97,6 +97,9 @@ constexpr int FL_WAVES = FL_WAVES_N, FL_NT = 64 * FL_WAVES, FL_XT = 32 * FL_WAVE
 #ifndef FL_DMA_INTERLEAVE
 #define FL_DMA_INTERLEAVE 1
 #endif
+#ifndef FL_DMA_TRIM
+#define FL_DMA_TRIM 1
+#endif
 #ifndef FL_DMA_KS0   // first k-step that is followed by a DMA piece, and the k-step distance between pieces
 #define FL_DMA_KS0 0
 #endif
@@ -466,11 +469,16 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
         return a.yrec + (((int64_t)cdp * a.YR + (int64_t)yb * FL_YB) * P) + lane * 16 + wave_u * 1024;
     };
     auto dma_dst = [&](int slot) { return lds_base + (unsigned)(slot * SLOT) + (unsigned)(wave_u * 1024); };
+    // FL_DMA_TRIM: a slot is a whole number of 4 KB rounds (one 1 KB piece per wave and round) but a block is 32 P bytes — 13.5 pieces of 16 at
+    // d = 100: the waves whose last piece lies wholly beyond the block do not issue it (and wait for one load less per block in flight)
+    constexpr int NPIECES = (32 * P + 1023) / 1024;
+    const bool short_wave = FL_DMA_TRIM && !(SACC || SLOAD) && (wave_u + FL_WAVES * (DMA_PER_WAVE - 1)) >= NPIECES;
     auto dma = [&](int tile, int yb, int slot) {
         const char* src = dma_src(tile, yb);
         const unsigned dst = dma_dst(slot);
 #pragma unroll
-        for (int i = 0; i < DMA_PER_WAVE; ++i) dma_piece(src, dst, i);
+        for (int i = 0; i < DMA_PER_WAVE; ++i)
+            if (!(short_wave && i == DMA_PER_WAVE - 1)) dma_piece(src, dst, i);
     };
 
     // stored-score modes, tile order: the score tile of an item travels with its streamed block, straight into LDS (a register prefetch cannot
@@ -835,7 +843,8 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
                 }
             }
         } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * DMA_PER_WAVE) : "memory");
+            if (short_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * (DMA_PER_WAVE - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 2) * DMA_PER_WAVE) : "memory");
             __builtin_amdgcn_s_barrier();
         }
         // the next block's DMA: FL_DMA_INTERLEAVE spreads its pieces over the first k-steps of this item's score contraction (the order of the
@@ -845,7 +854,8 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
         const unsigned ndst = dma_dst(pslot);
         if constexpr (!DMA_IL) {
 #pragma unroll
-            for (int i = 0; i < DMA_PER_WAVE; ++i) dma_piece(nsrc, ndst, i);
+            for (int i = 0; i < DMA_PER_WAVE; ++i)
+                if (!(short_wave && i == DMA_PER_WAVE - 1)) dma_piece(nsrc, ndst, i);
         }
         padvance();
         pslot = pslot + 1 == NSLOT ? 0 : pslot + 1;
@@ -862,8 +872,9 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
         if constexpr (!SLOAD)
             accS = fl_score_tile<KS, F16, TAIL>(T, a_off, xh, xl, [&](int ks) {
                 if constexpr (DMA_IL) {
-                    if (ks >= FL_DMA_KS0 && (ks - FL_DMA_KS0) % FL_DMA_STRIDE == 0 && (ks - FL_DMA_KS0) / FL_DMA_STRIDE < DMA_PER_WAVE)
-                        dma_piece(nsrc, ndst, (ks - FL_DMA_KS0) / FL_DMA_STRIDE);
+                    if (ks >= FL_DMA_KS0 && (ks - FL_DMA_KS0) % FL_DMA_STRIDE == 0 && (ks - FL_DMA_KS0) / FL_DMA_STRIDE < DMA_PER_WAVE) {
+                        if (!(short_wave && (ks - FL_DMA_KS0) / FL_DMA_STRIDE == DMA_PER_WAVE - 1)) dma_piece(nsrc, ndst, (ks - FL_DMA_KS0) / FL_DMA_STRIDE);
+                    }
                 }
             });
 
