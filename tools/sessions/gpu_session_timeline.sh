@@ -8,5 +8,5 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 ( cd /tmp && timeout 400 rocprofv3 --kernel-trace -d /tmp/tl_$tag -o kt --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-pass --no-arith-check --no-profile --steps 40 --warmup 10 "$@" > $out/kt.log 2>&1 )
 f=$(find /tmp/tl_$tag -name "*kernel_trace.csv" | head -1)
-python $GRAFT_REPO_ROOT/tools/trace_gaps.py $f lp_prep2_kernel 30 > $out/timeline.txt
+python $GRAFT_REPO_ROOT/tools/trace_gaps.py $f lp_prep2 30 > $out/timeline.txt
 cat $out/timeline.txt | cut -c1-150

@@ -39,8 +39,8 @@ pmc deg05 --degree-fraction 0.5
 MARIUS_FORCE_SHARDED=1 timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-arith-check > $out/bench_sharded_w1.json 2> $out/bench_sharded_w1.err
 ( cd /tmp && MARIUS_FORCE_SHARDED=1 timeout 300 rocprofv3 --kernel-trace -d /tmp/tl_${tag}_sh -o kt --output-format csv -- python $R/bench.py --no-cpu-baseline --no-arith-check --steps 40 --warmup 10 > $out/kt_sharded.log 2>&1 )
 f=$(find /tmp/tl_${tag}_sh -name "*kernel_trace.csv" | head -1)
-python tools/trace_gaps.py $f lp_prep2_kernel 30 > $out/sharded_timeline.txt
-python tools/trace_kernel_table.py $f lp_prep2_kernel > $out/sharded_kernel_table.txt
+python tools/trace_gaps.py $f lp_prep2 30 > $out/sharded_timeline.txt
+python tools/trace_kernel_table.py $f lp_prep2 > $out/sharded_kernel_table.txt
 # ---- the driver's command, twice more
 for i in 1 2; do timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_$i.json 2> $out/bench_driver_$i.err; done
 python - <<PY

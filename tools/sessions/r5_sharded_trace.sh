@@ -25,6 +25,6 @@ except Exception as e: print("sharded failed", e); print(open("$out/bench_sharde
 PY
 ( cd /tmp && MARIUS_FORCE_SHARDED=1 timeout 300 rocprofv3 --kernel-trace -d /tmp/tl_$tag -o kt --output-format csv -- python $R/bench.py --no-cpu-baseline --no-arith-check --steps 40 --warmup 10 > $out/kt.log 2>&1 )
 f=$(find /tmp/tl_$tag -name "*kernel_trace.csv" | head -1)
-python tools/trace_gaps.py $f lp_prep2_kernel 30 > $out/timeline_sharded_w1.txt
-python tools/trace_kernel_table.py $f lp_prep2_kernel > $out/kernel_table_sharded_w1.txt
+python tools/trace_gaps.py $f lp_prep2 30 > $out/timeline_sharded_w1.txt
+python tools/trace_kernel_table.py $f lp_prep2 > $out/kernel_table_sharded_w1.txt
 head -60 $out/kernel_table_sharded_w1.txt | cut -c1-170

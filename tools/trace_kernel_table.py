@@ -2,7 +2,7 @@
 steps = occurrences of the anchor kernel; per kernel and queue: calls per step, busy us per step, average us."""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-anchor = sys.argv[2] if len(sys.argv) > 2 else "lp_prep2_kernel"
+anchor = sys.argv[2] if len(sys.argv) > 2 else "lp_prep2"
 qkey = "Queue_Id" if "Queue_Id" in rows[0] else "Stream_Id"
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
