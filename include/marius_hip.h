@@ -213,7 +213,8 @@ int64_t marius_a2a_capacity(int64_t max_rows, int32_t world, double slack);
  * points by owner (marius_owner_offsets).  Writes req_send[world * cap]: block q = (cap - cnt_q) entries of -1 followed by the cnt_q LOCAL
  * row ids (global - q * shard_rows) asked of owner q, ascending; place[u] = slot of unique index u in that layout (the row of u in the
  * row payload the owners send back, and the row its gradient is written to on the way out: marius_segment_sum_rows_planned's out_rows);
- * *overflow_flag |= 1 if some cnt_q > cap (the caller must not use the batch: raise the slack).  Optional (n_occ > 0): slot_of_occ[i] =
+ * *overflow_flag |= 1 if some cnt_q > cap (the caller must not use the batch: raise the slack; the first cap rows of such an owner are
+ * served, the others get place 0 — a defined slot, so that nothing indexes out of the payload before the flag is read).  Optional (n_occ > 0): slot_of_occ[i] =
  * place[inverse[i]] for the n_occ occurrences of map_tensors (inverse of marius_sort_unique) — the batch's local indices in slot terms
  * (marius_remap_edges with it gives Batch::edges_, its tail the negatives' mappings), so that the decoder reads the received row payload
  * IN PLACE instead of a compacted copy. */

@@ -37,6 +37,9 @@ __global__ __launch_bounds__(256) void a2a_post_kernel(const int64_t* __restrict
     const int64_t o0 = offs[q], cnt = offs[q + 1] - o0;
     if (cnt > cap) {  // more rows of one owner than the planned maximum: flagged (the host refuses to go on), the first `cap` are served
         if (j == 0) atomicOr(reinterpret_cast<unsigned int*>(overflow), 1u);
+        // the rows beyond them get slot 0: a defined index inside the payload, so that nothing downstream (slot_of_occ, the in-place scoring of
+        // the payload) indexes with an unwritten value in the steps before the host reads the flag
+        for (int64_t r = cap + j; r < cnt; r += cap) place[o0 + r] = 0;
     }
     const int64_t c = cnt < cap ? cnt : cap;
     const int64_t k = j - (cap - c);  // position inside the owner's run of the batch's ascending unique ids

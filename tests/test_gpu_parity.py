@@ -785,10 +785,10 @@ def test_fixed_capacity_exchange_halves_against_numpy(H, dev, world, cap_slack):
         assert np.array_equal(of, X.owner_offsets(uq, S, world))
         want_req, want_place, over = X.post(uq, S, world, cap)   # oracle/exchange_oracle.py: the numpy restatement
         assert bool(flag.item()) == over
+        assert np.array_equal(req.cpu().numpy(), want_req)
+        assert np.array_equal(place[:U].cpu().numpy(), want_place)  # (rows beyond an owner's capacity: slot 0, a defined index inside the payload)
         if over:
             continue
-        assert np.array_equal(req.cpu().numpy(), want_req)
-        assert np.array_equal(place[:U].cpu().numpy(), want_place)
         assert np.array_equal(slot.cpu().numpy(), want_place[um.inverse.cpu().numpy()])
         reqs.append(req)
         places.append(place)
