@@ -154,29 +154,57 @@ def dominant_roofline(avg_ms, B, C, N, d, ndir, flash, pmc_ok, kernel="lp_grad_a
     return out
 
 
-def arith_check_leg(H, cfg, B, C, N, dev, seed=4242):
-    """CHECKER leg (oracle/arith_check.py; like cpu_baseline, the only other place bench.py touches oracle/): one batch of the workload's shape
+ARITH_SEEDS = (4242, 1, 2, 3, 4)
+
+
+def trained_table_inputs(cfg, B, C, N, table, edges_all, model, dev, batch_index=7, seed=99):
+    """Inputs of the arithmetic check drawn from the LIVE tables after some training steps: one batch of the workload — B of its
+    edges, uniform negatives — whose rows are gathered from the node table as it stands: glorot rows (+-2.6e-4 at Freebase86m's size) beside rows
+    that have taken Adagrad steps (~0.1), three decades inside one power-of-two operand scale; the relation tables as trained; and the magnitude
+    bounds the trainer itself packs with (Model::range_state: table-wide, tracked by the fused update), not bounds of the batch's own rows."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    e = edges_all[batch_index * B:(batch_index + 1) * B].long()
+    src_neg = torch.randint(cfg["num_nodes"], (C, N), device=dev, generator=g)
+    dst_neg = torch.randint(cfg["num_nodes"], (C, N), device=dev, generator=g)
+    uniq, inv = torch.unique(torch.cat([e[:, 0], e[:, -1], src_neg.flatten(), dst_neg.flatten()]), return_inverse=True)  # map_tensors (util.cpp:180-205)
+    CN = C * N
+    edges = torch.stack([inv[:B], e[:, 1], inv[B:2 * B]], 1)
+    rows = table[uniq]
+    touched = float((rows.abs().amax(1) > 4 * math.sqrt(6.0 / (cfg["num_nodes"] + cfg["d"]))).float().mean())
+    return {"emb": rows.cpu(), "edges": edges.cpu(), "src_neg": inv[2 * B:2 * B + CN].reshape(C, N).cpu(), "dst_neg": inv[2 * B + CN:].reshape(C, N).cpu(),
+            "rel": model.decoder.relations.detach().cpu().clone(), "inv": model.decoder.inverse_relations.detach().cpu().clone(),
+            "absmax": model.range_state.clone() if model.ranges_valid and model.rel_ranges_valid else None,
+            "describe": "trained-table: rows of one workload batch gathered from the live node table (%d unique rows, %.0f %% of them past their first Adagrad step, the "
+                        "rest at glorot scale), trained relation tables, the trainer's own table-wide magnitude bounds" % (uniq.numel(), 100 * touched)}
+
+
+def arith_check_leg(H, cfg, B, C, N, dev, seeds=ARITH_SEEDS, extra_inputs=()):
+    """CHECKER leg (oracle/arith_check.py; like cpu_baseline, the only other place bench.py touches oracle/): batches of the workload's shape
     through the flash decoder path on the device, through the reference's op sequence in float32 (torch CPU: the ATen calls of
     comparators.cpp:62-73, loss.cpp:50-67, autograd) and in float64; per quantity the max / RMS error of the device path and of the reference's
     own fp32 evaluation against float64 — evaluated on CPU tensors and on this device's tensors (what the reference itself computes on this
-    GPU) — plus this library's FP32-MFMA kernels (reported, not part of the gate), and the ratios.  `ok` (oracle/arith_check.verdict): per
-    quantity and statistic the yardstick is the less accurate of the REFERENCE'S two evaluations; the split path must have RMS error <= 1.0 x and
-    max error <= 2.0 x that yardstick on every quantity.  Then it carries the headline; otherwise the headline is measured with MARIUS_FLASH=0
-    (fp32 products) and the split path is `fast_path`.  The strict counts (flash <= EACH evaluation, both statistics) are reported beside it."""
+    GPU) — plus this library's FP32-MFMA kernels (reported, not part of the gate), and the ratios.  Inputs (one fixed seed is a
+    coin toss, not a gate): synthetic batches N(0, 0.5^2) for every seed of `seeds`, plus `extra_inputs` (trained_table_inputs: rows of the live
+    table).  `ok` (oracle/arith_check.verdict / combine) must hold on EVERY input; the worst ratios over all of them are in `verdict`.  Then the
+    split path carries the headline; otherwise the headline is measured with MARIUS_FLASH=0 (fp32 products) and the split path is `fast_path`."""
     from oracle import lp_oracle as O
-    from oracle.arith_check import ASSERTED, error_pairs, verdict
+    from oracle.arith_check import ASSERTED, combine, error_pairs, verdict
 
     decoder, d = cfg["decoder"], cfg["d"]
     relop, cmp_ = {"DISTMULT": (0, 0), "COMPLEX": (1, 0)}[decoder]
-    U, R = 4 * B, min(cfg["num_relations"], 1000)
-    g = torch.Generator().manual_seed(seed)
-    emb = torch.randn(U, d, generator=g) * 0.5
-    edges = torch.stack([torch.randint(U, (B,), generator=g), torch.randint(R, (B,), generator=g), torch.randint(U, (B,), generator=g)], 1)
-    dst_neg, src_neg = torch.randint(U, (C, N), generator=g), torch.randint(U, (C, N), generator=g)
-    rel = O.init_relations(decoder, R, d) + 0.3 * torch.randn(R, d, generator=g)
-    inv = O.init_relations(decoder, R, d) + 0.3 * torch.randn(R, d, generator=g)
     t0 = time.perf_counter()
     t = lambda x: x.to(dev)  # noqa: E731
+
+    def synthetic(seed):
+        U, R = 4 * B, min(cfg["num_relations"], 1000)
+        g = torch.Generator().manual_seed(seed)
+        emb = torch.randn(U, d, generator=g) * 0.5
+        edges = torch.stack([torch.randint(U, (B,), generator=g), torch.randint(R, (B,), generator=g), torch.randint(U, (B,), generator=g)], 1)
+        dst_neg, src_neg = torch.randint(U, (C, N), generator=g), torch.randint(U, (C, N), generator=g)
+        rel = O.init_relations(decoder, R, d) + 0.3 * torch.randn(R, d, generator=g)
+        inv = O.init_relations(decoder, R, d) + 0.3 * torch.randn(R, d, generator=g)
+        return {"emb": emb, "edges": edges, "dst_neg": dst_neg, "src_neg": src_neg, "rel": rel, "inv": inv, "absmax": None,
+                "describe": "synthetic seed %d: %d candidate rows ~ N(0, 0.5^2), %d relations" % (seed, U, R)}
 
     def outputs(W):
         W.forward()
@@ -187,30 +215,44 @@ def arith_check_leg(H, cfg, B, C, N, dev, seed=4242):
                 "inv_rowloss": W.rowloss(1).cpu(), "loss": W.loss_values()[0:1].cpu(), "gocc": W.gocc()[:, :d].cpu(), "grel": W.grel(0)[:B, :d].cpu(),
                 "inv_grel": W.grel(1)[:B, :d].cpu()}
 
-    W = H.LpWorkspace(relop, cmp_, d, B, C, N, True, H.REDUCE_SUM, 3, True, dev, flags=H.LP_TRAIN_ONLY | H.LP_STORE_SCORES)
-    if W.layout.flash != 1:
-        return None
-    absmax = torch.cat([H.table_absmax(t(emb)), H.table_absmax(t(rel), t(inv))])
-    W.bind(t(emb), t(edges), t(dst_neg), t(src_neg), t(rel), t(inv), absmax=absmax)
-    got = outputs(W)
-    del W
-    X = H.LpWorkspace(relop, cmp_, d, B, C, N, True, H.REDUCE_SUM, 3, True, dev)  # flags 0: the FP32-MFMA kernels, scores materialised
-    X.bind(t(emb), t(edges), t(dst_neg), t(src_neg), t(rel), t(inv))
-    exact = outputs(X)
-    del X
-    pairs = error_pairs(decoder, emb, edges, dst_neg, src_neg, rel, inv, got, ref_device=dev, fp32_mfma=exact)
-    v = verdict(pairs)
-    rnd = lambda p: {k: float("%.3g" % x) for k, x in p.items()}  # noqa: E731
-    return {"ok": v["ok"], "verdict": {k: (float("%.3g" % x) if isinstance(x, float) else x) for k, x in v.items()},
-            "quantities": {q: rnd(p) for q, p in pairs.items()}, "asserted": list(ASSERTED),
-            "what": "one batch of the workload's shape evaluated four ways in float32-class arithmetic and once in float64 (the yardstick): device_* = the flash "
-                    "path [fp16-half split x 3 products]; fp32_* = the reference's op sequence on CPU tensors [ATen + CPU BLAS]; fp32_on_device_* = the same op "
-                    "sequence on this GPU's tensors [ATen + rocBLAS: what the reference computes with storage.device_type cuda here]; fp32_mfma_* = this "
-                    "library's FP32-MFMA kernels [every product an fp32 product: the `fp32_exact` path].  Each: max |err| / max |want| and rms err / rms want. "
-                    "ratio_* = flash / CPU evaluation, ratio_dev_* = flash / device evaluation.  verdict.le1_*: how many of the 10 asserted (quantity, "
-                    "statistic) pairs have flash <= that evaluation; verdict.rule states the gate (reference evaluations only; fp32_mfma_* is context); "
-                    "`loss` is one number per batch (reported, not asserted)",
-            "inputs": "B=%d C=%d N=%d d=%d, %d candidate rows ~ N(0, 0.5^2), %d relations, seed %d" % (B, C, N, d, U, R, seed),
+    def evaluate(x):
+        emb, edges, dst_neg, src_neg, rel, inv = (x[k] for k in ("emb", "edges", "dst_neg", "src_neg", "rel", "inv"))
+        W = H.LpWorkspace(relop, cmp_, d, B, C, N, True, H.REDUCE_SUM, 3, True, dev, flags=H.LP_TRAIN_ONLY | H.LP_STORE_SCORES)
+        if W.layout.flash != 1:
+            return None
+        absmax = x["absmax"] if x["absmax"] is not None else torch.cat([H.table_absmax(t(emb)), H.table_absmax(t(rel), t(inv))])
+        W.bind(t(emb), t(edges), t(dst_neg), t(src_neg), t(rel), t(inv), absmax=absmax)
+        got = outputs(W)
+        del W
+        X = H.LpWorkspace(relop, cmp_, d, B, C, N, True, H.REDUCE_SUM, 3, True, dev)  # flags 0: the FP32-MFMA kernels, scores materialised
+        X.bind(t(emb), t(edges), t(dst_neg), t(src_neg), t(rel), t(inv))
+        exact = outputs(X)
+        del X
+        return error_pairs(decoder, emb, edges, dst_neg, src_neg, rel, inv, got, ref_device=dev, fp32_mfma=exact, yardstick_device=dev)
+
+    rnd = lambda p: {k: (float("%.3g" % v) if isinstance(v, float) else v) for k, v in p.items()}  # noqa: E731
+    per_input, verdicts, first_pairs = [], [], None
+    for x in [synthetic(s) for s in seeds] + list(extra_inputs):
+        pairs = evaluate(x)
+        if pairs is None:
+            return None
+        v = verdict(pairs)
+        verdicts.append(v)
+        first_pairs = first_pairs or pairs
+        worst = {q: {"ratio_rms": float("%.3g" % max(pairs[q]["ratio_rms"], pairs[q]["ratio_dev_rms"])), "ratio_max": float("%.3g" % max(pairs[q]["ratio_max"], pairs[q]["ratio_dev_max"])),
+                     "device_max": float("%.3g" % pairs[q]["device_max"]), "device_rms": float("%.3g" % pairs[q]["device_rms"])} for q in ASSERTED}
+        per_input.append({"input": x["describe"], "ok": v["ok"], "strict_le_reference": v["strict_le_reference"], "worst_rms_vs_reference": float("%.3g" % v["worst_rms_vs_reference"]),
+                          "worst_max_vs_reference": float("%.3g" % v["worst_max_vs_reference"]), "le1_cpu_aten": v["le1_cpu_aten"], "le1_device_aten": v["le1_device_aten"],
+                          "flash_vs_either_reference_evaluation": worst})
+    total = combine(verdicts)
+    return {"ok": total["ok"], "verdict": rnd(total), "seeds": list(seeds), "inputs": [p["input"] for p in per_input], "per_input": per_input,
+            "quantities": {q: rnd(p) for q, p in first_pairs.items()}, "asserted": list(ASSERTED),
+            "what": "each input: one batch of the workload's shape (B=%d C=%d N=%d d=%d) evaluated four ways in float32-class arithmetic and once in float64 (the yardstick, ATen on the "
+                    "device): device_* = the flash path [fp16-half split x 3 products]; fp32_* = the reference's op sequence on CPU tensors [ATen + CPU BLAS]; fp32_on_device_* = the same "
+                    "op sequence on this GPU's tensors [ATen + rocBLAS: what the reference computes with storage.device_type cuda here]; fp32_mfma_* = this library's FP32-MFMA "
+                    "kernels [every product an fp32 product: the `fp32_exact` path].  Each: max |err| / max |want| and rms err / rms want.  `quantities` = the full table of the "
+                    "FIRST input; per_input[*].flash_vs_either_reference_evaluation = per quantity the larger of flash / CPU evaluation and flash / device evaluation.  "
+                    "verdict: worst ratios over all inputs and the rule; `loss` is one number per batch (reported, not asserted)" % (B, C, N, d),
             "seconds": round(time.perf_counter() - t0, 1)}
 
 
@@ -374,9 +416,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=_nccl_options())
     # ---- which arithmetic carries the headline: the flash path only if it is no worse than the reference's own fp32 evaluation
+    # (oracle/arith_check.py: the rule; several seeds).  N = 1 adds one more input below — rows of the live table after ARITH_PRETRAIN steps.
+    sharded_run = world > 1 or os.environ.get("MARIUS_FORCE_SHARDED") == "1"
+    check_wanted = (not a.no_arith_check and a.loss.upper() == "SOFTMAX_CE" and cfg["decoder"] in ("DISTMULT", "COMPLEX") and R > 1 and
+                    os.environ.get("MARIUS_FLASH", "1") != "0" and flash_selected(H, cfg, B, C, N) and d <= 128)
     arith = None
-    if rank == 0 and not a.no_arith_check and a.loss.upper() == "SOFTMAX_CE" and cfg["decoder"] in ("DISTMULT", "COMPLEX") and R > 1 and \
-            os.environ.get("MARIUS_FLASH", "1") != "0" and flash_selected(H, cfg, B, C, N) and d <= 128:
+    if rank == 0 and check_wanted and (sharded_run or a.driver != "cpp"):
         arith = arith_check_leg(H, cfg, B, C, N, dev)
     demote = arith is not None and not arith["ok"]
     if world > 1 and not a.no_arith_check:  # every rank takes rank 0's decision
@@ -389,7 +434,7 @@ def main():
         H.reload_env()
     a.arith_check = arith
 
-    if world > 1 or os.environ.get("MARIUS_FORCE_SHARDED") == "1":
+    if sharded_run:
         from marius_amd.sharded import run_sharded_bench
         return run_sharded_bench(a, cfg, rank, world, dev)
 
@@ -403,15 +448,37 @@ def main():
         # host side in C++ on libtorch (marius_amd/csrc/host): DataLoader / Model / SynchronousTrainer of the reference's API
         import marius_amd
         M = marius_amd.host()
-        gen = M.MariusGenerator(42)
-        sampler = M.CorruptNodeNegativeSampler(C, N, a.degree_fraction, False, M.LocalFilterMode.DEG, gen)
-        loader = M.DataLoader(M.InMemory(edges_all), M.InMemory(table), M.InMemory(state), sampler, gen, B, True)
-        dec = {"DISTMULT": M.DistMult, "COMPLEX": M.ComplEx, "TRANSE": M.TransE}[cfg["decoder"]](R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
-        model = M.Model(dec, M.getLossFunction(a.loss.upper(), "sum", 0.1), M.LinkPredictionReporter(), dev)
-        model.setup_optimizers(0.1)
-        model.sparse_lr = 0.1
-        trainer = M.SynchronousTrainer(loader, model)
-        loader.initializeBatches(True)  # setActiveEdges: randperm on the same generator stream
+        def make_trainer(seed):
+            gen = M.MariusGenerator(seed)
+            sampler = M.CorruptNodeNegativeSampler(C, N, a.degree_fraction, False, M.LocalFilterMode.DEG, gen)
+            loader = M.DataLoader(M.InMemory(edges_all), M.InMemory(table), M.InMemory(state), sampler, gen, B, True)
+            dec = {"DISTMULT": M.DistMult, "COMPLEX": M.ComplEx, "TRANSE": M.TransE}[cfg["decoder"]](R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+            model = M.Model(dec, M.getLossFunction(a.loss.upper(), "sum", 0.1), M.LinkPredictionReporter(), dev)
+            model.setup_optimizers(0.1)
+            model.sparse_lr = 0.1
+            trainer = M.SynchronousTrainer(loader, model)
+            loader.initializeBatches(True)  # setActiveEdges: randperm on the same generator stream
+            return loader, model, trainer
+
+        if check_wanted:
+            # The gate's last input comes from the tables a trainer has worked on: ARITH_PRETRAIN untimed steps of the workload (their own
+            # generator seed), then one batch's rows out of the live table.  The timed trainer below starts from a fresh model / loader (seed 42)
+            # over the same node table — which has then seen those steps: glorot rows beside trained ones, as in any real epoch.
+            ARITH_PRETRAIN = 200
+            _, pre_model, pre_trainer = make_trainer(41)
+            pre_trainer.train_steps(ARITH_PRETRAIN)
+            torch.cuda.synchronize()
+            extra = [trained_table_inputs(cfg, B, C, N, table, edges_all, pre_model, dev)] if pre_model.last_step_flash else []
+            del pre_trainer
+            arith = arith_check_leg(H, cfg, B, C, N, dev, extra_inputs=extra)
+            del pre_model
+            if arith is not None:
+                arith["pretrain_steps_before_trained_table_input"] = ARITH_PRETRAIN
+                if not arith["ok"]:
+                    os.environ["MARIUS_FLASH"] = "0"  # the timed region runs fp32 products
+                    H.reload_env()
+            a.arith_check = arith
+        loader, model, trainer = make_trainer(42)
 
         def run(k0, k):
             trainer.train_steps(k)

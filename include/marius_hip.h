@@ -49,10 +49,10 @@ enum {
  * marius_table_absmax_counted; marius_lp_layout lost the operand planes of the removed bf16x6 kernels and the stream-K partials; 8:
  * marius_lp_desc.upd_*, marius_segment_update.fused_below, marius_lp_fuses_endpoint_update, marius_segment_plan_occ_single; 9: the
  * fixed-capacity exchange entry points marius_a2a_capacity / marius_a2a_rows_post / marius_a2a_rows_wait, negative ids = padding slots in
- * marius_merge_unique_runs / marius_segment_plan).  Every binder
+ * marius_merge_unique_runs / marius_segment_plan; 10: marius_a2a_publish / marius_a2a_record_* / marius_owner_offsets_counts, marius_layer_post_hook*).  Every binder
  * compares the value it was built against with what the loaded library returns and refuses to run on a mismatch: marius_amd/hip.py lib(),
  * the host module's init (bindings.cpp), and the plug-in recipe of INTEGRATION.md. */
-#define MARIUS_HIP_ABI_VERSION 9
+#define MARIUS_HIP_ABI_VERSION 10
 int marius_hip_abi_version(void);
 /* The MARIUS_* environment switches of the kernel library (test / A-B selectors; a production run sets none) are read ONCE, when the
  * library is loaded.  A process that changes one afterwards (the parity tests do, to reach a non-default kernel) calls this to re-read them. */
@@ -109,6 +109,20 @@ int marius_dense_adagrad_step(float* param, float* state_sum, const float* grad,
  * w -= lr/(1-b1^t) * exp_avg/denom, t = num_steps + 1.  max_exp_avg_sq = NULL unless amsgrad. */
 int marius_dense_adam_step(float* param, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, const float* grad, int64_t n, float lr,
                            float beta1, float beta2, float eps, float weight_decay, int64_t num_steps, marius_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ encoder (embedding-only)
+ * Layer::post_hook  src/nn/layers/layer.cpp:9-16, applied by GeneralEncoder::forward (src/nn/encoders/encoder.cpp:195-257) to the [n, d] rows the
+ * embedding layer hands on (EmbeddingLayer::forward is a column view, embedding.cpp:17):  out = act(x + bias), bias [d] or NULL (config bias:
+ * false), act = apply_activation (src/nn/activation.cpp:7-21).  out may alias x. */
+enum { MARIUS_ACT_NONE = 0, MARIUS_ACT_RELU = 1, MARIUS_ACT_SIGMOID = 2 };
+int marius_layer_post_hook(const float* x, int64_t x_ld, const float* bias, int32_t activation, int64_t n, int32_t d, float* out, int64_t out_ld,
+                           marius_stream_t stream);
+/* its backward (what autograd derives for the reference): gx = gy * act'(.) from the forward OUTPUT y (relu: [y > 0]; sigmoid: y (1 - y); y may
+ * be NULL for NONE), gx may alias gy; bias_grad [d] (NULL: no bias) = column sums of gx, computed in two deterministic stages through
+ * `workspace` (marius_layer_post_hook_workspace_bytes(n, d) bytes): no float atomics, the same bits on every run. */
+size_t marius_layer_post_hook_workspace_bytes(int64_t n, int32_t d);
+int marius_layer_post_hook_backward(const float* gy, int64_t gy_ld, const float* y, int64_t y_ld, int32_t activation, int64_t n, int32_t d, float* gx,
+                                    int64_t gx_ld, float* bias_grad, void* workspace, size_t workspace_bytes, marius_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ sampling */
 
@@ -227,6 +241,25 @@ int marius_a2a_rows_post(const int64_t* uniq, const int64_t* owner_offsets, int6
  * emb) — for callers that did not rewrite their indices; the bound then covers exactly the copied rows. */
 int marius_a2a_rows_wait(const float* rows_recv, int64_t recv_ld, int64_t rows, int32_t d, float* absmax, const int64_t* place,
                          const int64_t* num_unique_dev, int64_t capacity, float* emb, int64_t emb_ld, marius_stream_t stream);
+/* No `comm` parameter on the pair above, on purpose (SURVEY.md 8(b) sketches a2a_rows_{post,wait}(comm, ...)): this library never calls RCCL.  The
+ * collective between the two halves is issued by the HOST on whatever communicator it owns (c10d::ProcessGroupNCCL in sharded_trainer.cpp,
+ * ncclAllToAll in a plug-in: INTEGRATION.md) on the same stream, so libmarius_hip.so links against nothing but the HIP runtime and works under
+ * any transport the host has (the world-2 / world-8 tests run the same kernels under gloo).
+ *
+ * The host side of an all-to-all(v) needs a batch's split sizes.  marius_owner_offsets_counts = marius_owner_offsets that also writes
+ * counts[q] = out[q + 1] - out[q] (the send counts; counts may be NULL).  marius_a2a_publish hands the batch's whole exchange header to the host
+ * in ONE ordered record: record_mapped is device-mapped pinned host memory (hipHostMalloc, fine-grained: a torch pinned tensor) of
+ * marius_a2a_record_words(world) = 2 world + 4 int64 words — [0] stamp, [1 .. world + 1] owner_offsets, [world + 2 .. 2 world + 1] recv_counts
+ * (NULL: the send counts owner_offsets[q + 1] - owner_offsets[q], i.e. world 1 / no count exchange), [2 world + 2] *overflow_flag (NULL: 0),
+ * [2 world + 3] marius_a2a_record_checksum of the words before it.  One single-wave kernel stores the payload, fences at system scope and
+ * then stores the stamp (!= 0) with release semantics; the host acquires the stamp, copies the record, and accepts it only if the checksum
+ * matches (a torn or stale read is re-polled, never acted on).  Replaces the three unordered D2H copies + polled stamp of ABI 9's host. */
+int marius_owner_offsets_counts(const int64_t* uniq, const int64_t* num_unique_dev, int64_t shard_rows, int32_t num_shards, int64_t* out,
+                                int64_t* counts, marius_stream_t stream);
+int32_t marius_a2a_record_words(int32_t world);
+uint64_t marius_a2a_record_checksum(const int64_t* record_host, int32_t world); /* host function: plain C over a host copy of the record */
+int marius_a2a_publish(const int64_t* owner_offsets, const int64_t* recv_counts, const int32_t* overflow_flag, int32_t world, int64_t stamp,
+                       int64_t* record_mapped, marius_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ decoder */
 

@@ -305,7 +305,21 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_readwrite("beta_2", &ModelConfig::beta_2)
         .def_readwrite("weight_decay", &ModelConfig::weight_decay)
         .def_readwrite("amsgrad", &ModelConfig::amsgrad)
-        .def_readwrite("sparse_lr", &ModelConfig::sparse_lr);
+        .def_readwrite("sparse_lr", &ModelConfig::sparse_lr)
+        .def_readwrite("encoder_bias", &ModelConfig::encoder_bias)
+        .def_readwrite("encoder_activation", &ModelConfig::encoder_activation)
+        .def_readwrite("encoder_bias_init", &ModelConfig::encoder_bias_init);
+    py::enum_<ActivationFunction>(m, "ActivationFunction").value("NONE", ActivationFunction::NONE).value("RELU", ActivationFunction::RELU).value("SIGMOID", ActivationFunction::SIGMOID);
+    py::class_<GeneralEncoder, std::shared_ptr<GeneralEncoder>>(m, "GeneralEncoder")
+        .def(py::init<>())
+        .def(py::init<int, bool, ActivationFunction, torch::Device, torch::Tensor>(), py::arg("output_dim"), py::arg("bias"), py::arg("activation"), py::arg("device"),
+             py::arg("bias_init") = torch::Tensor())
+        .def("forward", &GeneralEncoder::forward, py::arg("embeddings"))
+        .def("backward", &GeneralEncoder::backward, py::arg("grad_encoded"), py::arg("encoded"))
+        .def("has_post_hook", &GeneralEncoder::has_post_hook)
+        .def_readonly("bias", &GeneralEncoder::bias_)
+        .def_readonly("bias_grad", &GeneralEncoder::bias_grad_)
+        .def_readonly("activation", &GeneralEncoder::activation_);
     m.def("initModelFromConfig", static_cast<std::shared_ptr<Model> (*)(const ModelConfig&, std::vector<torch::Device>, int, bool)>(&initModelFromConfig),
           py::arg("model_config"), py::arg("devices"), py::arg("num_relations"), py::arg("train"));
     py::class_<Model, PyModel, std::shared_ptr<Model>>(m, "Model", py::dynamic_attr())
@@ -314,6 +328,9 @@ PYBIND11_MODULE(_marius_host, m) {
         .def("forward_lp", [](Model& self, std::shared_ptr<Batch> b, bool train) { return self.Model::forward_lp(b, train); }, py::arg("batch"),
              py::arg("train") = true)
         .def("fused_ok", &Model::fused_ok)
+        .def("has_post_hook", &Model::has_post_hook)
+        .def("set_encoder", &Model::set_encoder, py::arg("encoder"))
+        .def_readonly("encoder", &Model::encoder_)
         .def("broadcast", &Model::broadcast, py::arg("devices"))
         .def("all_reduce", &Model::all_reduce)
         .def("set_process_group", &Model::set_process_group, py::arg("group_name"))
@@ -414,6 +431,8 @@ PYBIND11_MODULE(_marius_host, m) {
         .def_property_readonly("pair_capacity", &ShardedTrainer::pair_capacity)
         .def_property_readonly("useful_rows", [](ShardedTrainer& t) { return std::vector<int64_t>(t.useful_rows_, t.useful_rows_ + 2); })
         .def_property_readonly("phase_seconds", [](ShardedTrainer& t) { return std::vector<double>(t.phase_seconds_, t.phase_seconds_ + 6); })
+        .def_readonly("torn_reads", &ShardedTrainer::torn_reads_)
+        .def("describe_state", &ShardedTrainer::describe_state)
         .def("enable_spans", &ShardedTrainer::enable_spans)
         .def("reset_counters", &ShardedTrainer::reset_counters)
         .def_property_readonly("span_ms", [](ShardedTrainer& t) {

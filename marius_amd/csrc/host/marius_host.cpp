@@ -78,6 +78,23 @@ MariusGenerator::~MariusGenerator() {
     }
     if (side_stream_ && side_stream_owned_) (void)hipStreamDestroy((hipStream_t)side_stream_);
 }
+void MariusGenerator::use_fill_stream(void* hip_stream) {
+    if (side_stream_ && side_stream_owned_) {  // a stream of our own already exists: finish what it holds and destroy it
+        (void)hipStreamSynchronize((hipStream_t)side_stream_);
+        (void)hipStreamDestroy((hipStream_t)side_stream_);
+    }
+    side_stream_ = hip_stream;
+    side_stream_owned_ = false;
+    side_ordered_ = false;
+}
+void MariusGenerator::release_fill_stream() {
+    if (side_stream_ && !side_stream_owned_) {
+        to_host();  // waits for the borrowed stream, rewinds the state to exactly the consumed position, drops the pools filled on that stream
+        side_stream_ = nullptr;
+        side_stream_owned_ = true;
+        side_ordered_ = false;
+    }
+}
 void MariusGenerator::drop_pools() {
     for (auto& p : pools_) {
         p.filled = p.waited = p.has_done = false;
@@ -876,6 +893,59 @@ Model::Model(shared_ptr<EdgeDecoder> decoder, shared_ptr<LossFunction> loss, sha
     learning_task_ = decoder_->learning_task_;
     devices_ = {device};
 }
+// ------------------------------------------------------------------------------------------------ encoder (one embedding layer + post-hook)
+GeneralEncoder::GeneralEncoder(int output_dim, bool bias, ActivationFunction activation, torch::Device device, Tensor bias_init)
+    : activation_(activation), output_dim_(output_dim) {
+    if (output_dim < 1) throw MariusRuntimeException("GeneralEncoder: output_dim must be positive");
+    if (bias) {  // Layer::init_bias (layer.cpp:18-22): registered as "bias", requires grad
+        Tensor b = bias_init.defined() ? bias_init.to(device, torch::kFloat32).reshape({output_dim}).contiguous().clone()
+                                       : torch::zeros({output_dim}, torch::TensorOptions().dtype(torch::kFloat32).device(device));
+        bias_ = register_parameter("bias", b.set_requires_grad(true));
+        bias_grad_ = torch::zeros_like(b);
+    }
+}
+
+Tensor GeneralEncoder::forward(Tensor embeddings) {
+    if (!embeddings.defined()) throw MariusRuntimeException("Encoder requires embeddings and/or features as input");  // encoder.cpp:210
+    if (!has_post_hook()) return embeddings;
+    if (output_dim_ && embeddings.size(1) != output_dim_) throw TensorSizeMismatchException(embeddings, "embedding layer output_dim and the node rows differ in width");
+    if (torch::GradMode::is_enabled() && (embeddings.requires_grad() || (bias_.defined() && bias_.grad_fn()))) {
+        Tensor x = bias_.defined() ? embeddings + bias_ : embeddings;  // layer.cpp:10-12
+        if (activation_ == ActivationFunction::RELU) return torch::relu(x);
+        if (activation_ == ActivationFunction::SIGMOID) return torch::sigmoid(x);
+        return x;
+    }
+    require_device(embeddings, "GeneralEncoder::forward");
+    Tensor x = embeddings.stride(1) == 1 ? embeddings : embeddings.contiguous();
+    Tensor out = torch::empty({x.size(0), x.size(1)}, x.options());
+    torch::NoGradGuard ng;
+    mcheck(marius_layer_post_hook(fp(x), x.stride(0), bias_.defined() ? fp(bias_) : nullptr, (int32_t)activation_, x.size(0), (int32_t)x.size(1), fp(out), out.stride(0),
+                                  cur_stream()));
+    return out;
+}
+
+Tensor GeneralEncoder::backward(Tensor grad_encoded, Tensor encoded) {
+    if (!has_post_hook()) return grad_encoded;
+    require_device(grad_encoded, "GeneralEncoder::backward");
+    torch::NoGradGuard ng;
+    Tensor g = grad_encoded.stride(1) == 1 ? grad_encoded : grad_encoded.contiguous();
+    const int64_t n = g.size(0);
+    const int32_t d = (int32_t)g.size(1);
+    const size_t wsb = bias_.defined() ? marius_layer_post_hook_workspace_bytes(n, d) : 0;
+    if (wsb && (!ws_.defined() || (size_t)ws_.numel() < wsb || ws_.device() != g.device()))
+        ws_ = torch::empty({(int64_t)wsb}, torch::TensorOptions().dtype(torch::kUInt8).device(g.device()));
+    Tensor gx = torch::empty({n, (int64_t)d}, g.options());
+    const bool need_y = activation_ != ActivationFunction::NONE;
+    mcheck(marius_layer_post_hook_backward(fp(g), g.stride(0), need_y ? fp(encoded) : nullptr, need_y ? encoded.stride(0) : 0, (int32_t)activation_, n, d, fp(gx), gx.stride(0),
+                                           bias_.defined() ? fp(bias_grad_) : nullptr, wsb ? ws_.data_ptr() : nullptr, wsb, cur_stream()));
+    return gx;
+}
+
+void Model::set_encoder(shared_ptr<GeneralEncoder> encoder) {
+    encoder_ = encoder;
+    if (encoder_) replace_module("encoder", encoder_);
+}
+
 static shared_ptr<EdgeDecoder> as_edge_decoder(shared_ptr<Decoder> d) {
     auto e = std::dynamic_pointer_cast<EdgeDecoder>(d);
     if (!e) throw MariusRuntimeException("Decoder currently not supported.");  // this build: edge decoders (link prediction) only
@@ -887,8 +957,7 @@ Model::Model(shared_ptr<GeneralEncoder> encoder, shared_ptr<Decoder> decoder, sh
             reporter ? std::dynamic_pointer_cast<LinkPredictionReporter>(reporter) : std::make_shared<LinkPredictionReporter>(),
             as_edge_decoder(decoder)->tensor_options_.device()) {
     if (!reporter_) throw MariusRuntimeException("Reporter must be specified for this learning task.");  // model.cpp:44: not a link-prediction reporter
-    if (encoder && !encoder->parameters().empty()) throw MariusRuntimeException("Model: this build trains embedding-only models (the encoder must be a pass-through)");
-    encoder_ = encoder;
+    encoder_ = encoder;  // a pass-through, or one embedding layer with a post-hook (GeneralEncoder): its bias is a dense parameter
     if (encoder_) register_module("encoder", encoder_);
     optimizers_ = optimizers;
 }
@@ -898,12 +967,14 @@ void Model::setup_optimizers(shared_ptr<ModelConfig> c) {  // model.cpp:161-250 
 }
 void Model::setup_optimizers(float dense_lr) {
     std::vector<std::pair<Tensor, Tensor>> params;
+    if (encoder_ && encoder_->bias_.defined()) params.emplace_back(encoder_->bias_, encoder_->bias_grad_);  // "embedding:0_0_bias": encoder parameters first (model.cpp:175-183)
     if (decoder_->relations_.defined()) params.emplace_back(decoder_->relations_, relations_grad_);
     if (decoder_->inverse_relations_.defined()) params.emplace_back(decoder_->inverse_relations_, inverse_relations_grad_);
     optimizers_ = {std::make_shared<AdagradOptimizer>(params, dense_lr)};
 }
 void Model::setup_optimizer(const std::string& type, float lr, float eps, float beta_1, float beta_2, float weight_decay, bool amsgrad) {
     std::vector<std::pair<Tensor, Tensor>> params;
+    if (encoder_ && encoder_->bias_.defined()) params.emplace_back(encoder_->bias_, encoder_->bias_grad_);  // "embedding:0_0_bias": encoder parameters first (model.cpp:175-183)
     if (decoder_->relations_.defined()) params.emplace_back(decoder_->relations_, relations_grad_);
     if (decoder_->inverse_relations_.defined()) params.emplace_back(decoder_->inverse_relations_, inverse_relations_grad_);
     if (type == "ADAGRAD") {
@@ -918,8 +989,9 @@ void Model::setup_optimizer(const std::string& type, float lr, float eps, float 
         throw MariusRuntimeException("Unrecognized optimizer type: " + type);
     }
 }
-static std::vector<std::string> decoder_param_keys(const Model& m) {  // named_parameters() order of the decoder (distmult.cpp:21-27)
-    std::vector<std::string> k;
+static std::vector<std::string> decoder_param_keys(const Model& m) {  // the dense optimizer's parameter keys: encoder layers first (model.cpp:175-183), then
+    std::vector<std::string> k;                                      // named_parameters() order of the decoder (distmult.cpp:21-27)
+    if (m.encoder_ && m.encoder_->bias_.defined()) k.push_back("embedding:0_0_bias");
     if (m.decoder_->relations_.defined()) k.push_back("relation_embeddings");
     if (m.decoder_->inverse_relations_.defined()) k.push_back("inverse_relation_embeddings");
     return k;
@@ -928,6 +1000,7 @@ void Model::save(const std::string& directory) {  // model.cpp:82-106
     torch::serialize::OutputArchive model_archive, state_archive;
     // encoder_->save: GeneralEncoder registers its embedding layer as the (parameter-less) submodule "embedding:0_0" (encoder.cpp:43-45)
     torch::serialize::OutputArchive embedding_layer;
+    if (encoder_ && encoder_->bias_.defined()) embedding_layer.write("bias", encoder_->bias_);  // EmbeddingLayer's registered parameter (layer.cpp:18-22)
     model_archive.write("embedding:0_0", embedding_layer);
     // decoder_->save: its parameters by registered name
     if (decoder_->relations_.defined()) model_archive.write("relation_embeddings", decoder_->relations_);
@@ -955,6 +1028,13 @@ void Model::load(const std::string& directory, bool train) {  // model.cpp:108-1
         }
     }
     torch::NoGradGuard ng;
+    if (encoder_ && encoder_->bias_.defined()) {
+        torch::serialize::InputArchive embedding_layer;
+        model_archive.read("embedding:0_0", embedding_layer);
+        Tensor t;
+        embedding_layer.read("bias", t);
+        encoder_->bias_.copy_(t);
+    }
     if (decoder_->relations_.defined()) {
         Tensor t;
         model_archive.read("relation_embeddings", t);
@@ -1027,16 +1107,18 @@ void Model::broadcast(std::vector<torch::Device> devices) {  // model.cpp:136-14
 std::tuple<Tensor, Tensor, Tensor, Tensor> Model::forward_lp(shared_ptr<Batch> batch, bool train) {
     (void)train;  // evaluation also calls forward_lp(batch, true) in the reference (model.cpp:337)
     const bool builtin = decoder_->comparator_->kind() >= 0 && decoder_->relation_operator_->kind() >= 0;
+    // model.cpp:253: encoded_nodes = encoder_->forward(batch->node_embeddings_, ...) — a view unless the embedding layer has a post-hook
+    Tensor nodes = has_post_hook() ? encoder_->forward(batch->node_embeddings_) : batch->node_embeddings_;
     if (decoder_->decoder_method_ == EdgeDecoderMethod::CORRUPT_NODE &&
-        (!builtin || (torch::GradMode::is_enabled() && batch->node_embeddings_.requires_grad())))
-        return node_corrupt_forward_generic(decoder_, batch->edges_, batch->node_embeddings_, batch->dst_neg_indices_mapping_, batch->src_neg_indices_mapping_,
+        (!builtin || (torch::GradMode::is_enabled() && nodes.requires_grad())))
+        return node_corrupt_forward_generic(decoder_, batch->edges_, nodes, batch->dst_neg_indices_mapping_, batch->src_neg_indices_mapping_,
                                             batch->dst_neg_filter_, batch->src_neg_filter_);
     if (decoder_->decoder_method_ == EdgeDecoderMethod::ONLY_POS) {
-        auto t = only_pos_forward(decoder_, batch->edges_, batch->node_embeddings_);
+        auto t = only_pos_forward(decoder_, batch->edges_, nodes);
         return std::forward_as_tuple(std::get<0>(t), Tensor(), std::get<1>(t), Tensor());
     }
     if (decoder_->decoder_method_ != EdgeDecoderMethod::CORRUPT_NODE) throw MariusRuntimeException("Decoder method currently unsupported.");
-    return node_corrupt_forward(decoder_, batch->edges_, batch->node_embeddings_, batch->dst_neg_indices_mapping_, batch->src_neg_indices_mapping_, &ctx_,
+    return node_corrupt_forward(decoder_, batch->edges_, nodes, batch->dst_neg_indices_mapping_, batch->src_neg_indices_mapping_, &ctx_,
                                 batch->dst_neg_filter_, batch->src_neg_filter_, loss_function_ ? loss_function_->reduction_type_ : LossReduction::SUM,
                                 loss_function_ ? loss_function_->kind() : MARIUS_LOSS_SOFTMAX_CE, loss_function_ ? loss_function_->margin() : 0.f);
 }
@@ -1044,6 +1126,9 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> Model::forward_lp(shared_ptr<Batch> b
 std::tuple<Tensor, Tensor, Tensor, Tensor> Model::forward_lp_train(shared_ptr<Batch> batch) {
     if (decoder_->decoder_method_ != EdgeDecoderMethod::CORRUPT_NODE) return forward_lp(batch, true);
     const bool direct = batch->table_.defined();
+    if (direct && has_post_hook())
+        throw MariusRuntimeException("Model: an embedding layer with a bias or an activation trains through Model::train_batch (gathered rows); the table-direct fused "
+                                     "step reads node rows in place and has no post-hook");
     bind_ranges(batch, direct);
     return node_corrupt_forward(decoder_, direct ? batch->global_edges_ : batch->edges_, direct ? batch->table_ : batch->node_embeddings_,
                                 direct ? batch->dst_neg_indices_ : batch->dst_neg_indices_mapping_,
@@ -1193,9 +1278,11 @@ void Model::train_batch_generic(shared_ptr<Batch> batch, bool call_step) {
     Tensor emb = emb_plain.detach().requires_grad_(true);
     Tensor rel = rel_plain.defined() ? rel_plain.detach().requires_grad_(true) : Tensor();
     Tensor inv = inv_plain.defined() ? inv_plain.detach().requires_grad_(true) : Tensor();
+    Tensor bias_plain = encoder_ ? encoder_->bias_ : Tensor(), bias = bias_plain.defined() ? bias_plain.detach().requires_grad_(true) : Tensor();
     batch->node_embeddings_ = emb;
     decoder_->relations_ = rel;
     decoder_->inverse_relations_ = inv;
+    if (bias.defined()) encoder_->bias_ = bias;
     Tensor loss;
     try {
         auto t = forward_lp(batch, true);
@@ -1213,11 +1300,16 @@ void Model::train_batch_generic(shared_ptr<Batch> batch, bool call_step) {
         batch->node_embeddings_ = emb_plain;
         decoder_->relations_ = rel_plain;
         decoder_->inverse_relations_ = inv_plain;
+        if (bias.defined()) encoder_->bias_ = bias_plain;
         throw;
     }
     batch->node_embeddings_ = emb_plain;
     decoder_->relations_ = rel_plain;
     decoder_->inverse_relations_ = inv_plain;
+    if (bias.defined()) {
+        encoder_->bias_ = bias_plain;
+        encoder_->bias_grad_.copy_(bias.grad().defined() ? bias.grad() : torch::zeros_like(bias_plain));
+    }
     if (rel.defined()) relations_grad_.copy_(rel.grad().defined() ? rel.grad() : torch::zeros_like(rel_plain));
     if (inv.defined() && inverse_relations_grad_.defined()) inverse_relations_grad_.copy_(inv.grad().defined() ? inv.grad() : torch::zeros_like(inv_plain));
     batch->node_embeddings_grad_ = emb.grad().defined() ? emb.grad() : torch::zeros_like(emb_plain);
@@ -1230,6 +1322,7 @@ void Model::train_batch_generic(shared_ptr<Batch> batch, bool call_step) {
 // optimizer over named_parameters() after train_batch(batch, false)): the hand-derived backward writes relations_grad_ /
 // inverse_relations_grad_, which are made the parameters' .grad() here (aliases: clear_grad() zeroes both views of the same memory)
 void Model::publish_grads() {
+    if (encoder_ && encoder_->bias_.defined()) encoder_->bias_.mutable_grad() = encoder_->bias_grad_;
     if (decoder_->relations_.defined() && relations_grad_.defined()) decoder_->relations_.mutable_grad() = relations_grad_;
     if (decoder_->inverse_relations_.defined() && inverse_relations_grad_.defined()) decoder_->inverse_relations_.mutable_grad() = inverse_relations_grad_;
 }
@@ -1264,6 +1357,14 @@ shared_ptr<Model> initModelFromConfig(const ModelConfig& c, std::vector<torch::D
     auto loss = getLossFunction(c.loss, c.loss_reduction == "MEAN" ? LossReduction::MEAN : LossReduction::SUM, c.margin);
     auto model = std::make_shared<Model>(decoder, loss, std::make_shared<LinkPredictionReporter>(), dev);
     model->sparse_lr_ = c.sparse_lr;
+    {   // the embedding layer's post-hook (LayerConfig bias / bias_init / activation; default: none — a pass-through encoder)
+        ActivationFunction act = ActivationFunction::NONE;
+        if (c.encoder_activation == "RELU") act = ActivationFunction::RELU;
+        else if (c.encoder_activation == "SIGMOID") act = ActivationFunction::SIGMOID;
+        else if (c.encoder_activation != "NONE") throw MariusRuntimeException("Unsupported activation function");  // activation.cpp:19
+        if (c.encoder_bias || act != ActivationFunction::NONE)
+            model->set_encoder(std::make_shared<GeneralEncoder>(c.embedding_dim, c.encoder_bias, act, dev, c.encoder_bias_init));
+    }
     if (train) model->setup_optimizer(c.dense_optimizer, c.dense_lr, c.eps, c.beta_1, c.beta_2, c.weight_decay, c.amsgrad);
     model->broadcast({dev});
     return model;
@@ -1272,6 +1373,18 @@ shared_ptr<Model> initModelFromConfig(const ModelConfig& c, std::vector<torch::D
 void Model::train_batch(shared_ptr<Batch> batch, bool call_step) {
     if (!fused_ok()) return train_batch_generic(batch, call_step);
     if (call_step) clear_grad();
+    // Layer::post_hook of the embedding layer (layer.cpp:9-16): the decoder scores act(rows + bias); the rows themselves stay in the batch for
+    // the sparse update (Batch::accumulateGradients works on the raw embeddings, batch.cpp:62-79)
+    Tensor raw_rows;
+    if (has_post_hook()) {
+        raw_rows = batch->node_embeddings_;
+        batch->node_embeddings_ = encoder_->forward(raw_rows);
+    }
+    struct Restore {  // exception-safe: the batch gets its raw rows back whatever happens below
+        shared_ptr<Batch>& b;
+        Tensor& raw;
+        ~Restore() { if (raw.defined()) b->node_embeddings_ = raw; }
+    } restore{batch, raw_rows};
     forward_lp_train(batch);
     model_backward(*this, batch);
     relation_grads_dense(*this, batch);
@@ -1284,6 +1397,10 @@ void Model::train_batch(shared_ptr<Batch> batch, bool call_step) {
     mcheck(marius_segment_sum_rows(gocc, ctx_.layout.d_ld, batch->occ_perm_.data_ptr<int32_t>(), ip(batch->occ_inverse_),
                                    batch->occ_seg_offsets_.data_ptr<int32_t>(), L, ctx_.desc.d, nullptr, fp(batch->node_embeddings_grad_),
                                    batch->node_embeddings_grad_.stride(0), carry_.data_ptr(), cur_stream()));
+    if (raw_rows.defined()) {  // through the post-hook: d/d(rows) = d/d(encoded) * act'(.), bias.grad = its column sums
+        batch->node_embeddings_grad_ = encoder_->backward(batch->node_embeddings_grad_, batch->node_embeddings_);
+        batch->node_embeddings_ = raw_rows;
+    }
     publish_grads();
     if (call_step) step();
     if (batch->node_embeddings_.defined()) batch->accumulateGradients(sparse_lr_);
@@ -1405,6 +1522,7 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
 }
 
 void Model::backward_to_unique_grads(shared_ptr<Batch> batch, Tensor grad_out, bool local_relation_step, Tensor out_rows) {
+    if (has_post_hook()) throw MariusRuntimeException("Model: the sharded trainer scores the exchanged rows as they are; an embedding layer with a bias or an activation is not supported there");
     forward_lp_train(batch);  // (sharded table: the rows came from other ranks' shards; the bound is the one of the gathered copy itself, Batch::row_bound_)
     model_backward(*this, batch);
     const int64_t L = batch->occ_perm_.size(0);
@@ -2106,7 +2224,8 @@ void DataLoader::updateEmbeddings(shared_ptr<Batch> batch, bool gpu) {
 
 // ------------------------------------------------------------------------------------------------ trainer / evaluator
 void SynchronousTrainer::train_one(bool fused) {
-    fused = fused && model_->fused_ok();  // user plug-ins train through the API-granular path (virtual calls + autograd)
+    fused = fused && model_->fused_ok() && !model_->has_post_hook();  // user plug-ins (virtual calls + autograd) and an embedding layer with a post-hook
+                                                                       // (gathered rows through marius_layer_post_hook) train through the API-granular path
     dataloader_->run_ahead_ = fused;
     dataloader_->num_relations_ = fused ? model_->decoder_->num_relations_ : 0;
     if (fused) {

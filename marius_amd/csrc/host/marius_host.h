@@ -72,11 +72,8 @@ class MariusGenerator {
     int pool_requests_ = 16;
     // the pool fills run on a stream of the caller's instead of one of their own (not owned; set before the first draw).  The sharded trainer hands
     // over its exchange stream: a stream of the generator's own would be the process's fifth (sharded_trainer.cpp)
-    void use_fill_stream(void* hip_stream) {
-        side_stream_ = hip_stream;
-        side_stream_owned_ = false;
-        side_ordered_ = false;
-    }
+    void use_fill_stream(void* hip_stream);
+    void release_fill_stream();  // forget a borrowed fill stream (its owner is going away): the next pool fill creates the generator's own again
 
    private:
     struct Pool {
@@ -435,16 +432,42 @@ struct ModelConfig {
     float dense_lr = 0.1f, eps = 1e-10f, beta_1 = 0.9f, beta_2 = 0.999f, weight_decay = 0.f;
     bool amsgrad = false;
     float sparse_lr = 0.1f;                      // model.sparse_optimizer.options.learning_rate
+    bool encoder_bias = false;                   // model.encoder.layers[0][0].bias (LayerConfig, marius_config.py:190-199)
+    std::string encoder_activation = "NONE";     // model.encoder.layers[0][0].activation
+    Tensor encoder_bias_init;                    // [embedding_dim] from bias_init (undefined: ZEROS)
 };
 
-// encoder.h: the general encoder.  This build trains embedding-only models, whose encoder is a pass-through (encoder.cpp:195-257 with a
-// single embedding layer): the class exists so that code written against model.h:28-33 compiles; any non-null encoder with parameters
-// is rejected by Model's constructor.
-class GeneralEncoder : public torch::nn::Module {};
+// encoder.h / layer.h: the general encoder of an embedding-only model = ONE EmbeddingLayer: a column view of the batch's rows
+// (EmbeddingLayer::forward, embedding.cpp:17) followed by Layer::post_hook (layer.cpp:9-16): `+ bias` when LayerConfig::bias, then the
+// activation (activation.cpp:7-21: NONE / RELU / SIGMOID).  Default-constructed: a pass-through (no parameters), which is what every
+// BASELINE configuration uses and the only form the table-direct fused step accepts (its kernels read node rows in place); with a bias or an
+// activation the model trains through the API-granular step (gathered [U, d] rows -> marius_layer_post_hook -> decoder -> its backward ->
+// sparse Adagrad on the raw rows), the bias as a dense parameter "embedding:0_0_bias" of the dense optimizer (model.cpp:175-183).
+enum class ActivationFunction { NONE = 0, RELU = 1, SIGMOID = 2 };
+class GeneralEncoder : public torch::nn::Module {
+   public:
+    GeneralEncoder() = default;
+    // bias_init: the initial bias [output_dim] (initialize_tensor(config_->bias_init, ...), layer.cpp:18-22; undefined = ZEROS, the default)
+    GeneralEncoder(int output_dim, bool bias, ActivationFunction activation, torch::Device device, Tensor bias_init = Tensor());
+    bool has_post_hook() const { return bias_.defined() || activation_ != ActivationFunction::NONE; }
+    // encoder.cpp:195-257 for the single embedding layer.  Differentiable libtorch ops when autograd is recording through `embeddings` (user
+    // plug-ins: Model::train_batch_generic), the HIP kernel otherwise.
+    Tensor forward(Tensor embeddings);
+    // gradient w.r.t. the embeddings from the gradient w.r.t. forward's output (and that output); fills bias_grad_ (deterministic column sums)
+    Tensor backward(Tensor grad_encoded, Tensor encoded);
+    Tensor bias_, bias_grad_;
+    ActivationFunction activation_ = ActivationFunction::NONE;
+    int output_dim_ = 0;
+
+   private:
+    Tensor ws_;
+};
 
 class Model : public torch::nn::Module {
    public:
-    shared_ptr<GeneralEncoder> encoder_;  // nullptr or parameter-less (embedding-only)
+    shared_ptr<GeneralEncoder> encoder_;  // nullptr / pass-through, or one embedding layer with a post-hook (bias, activation)
+    bool has_post_hook() const { return encoder_ && encoder_->has_post_hook(); }
+    void set_encoder(shared_ptr<GeneralEncoder> encoder);  // (re)binds the encoder; call setup_optimizer* afterwards so that its bias is stepped
     LearningTask learning_task_ = LearningTask::LINK_PREDICTION;
     // Multi-GPU (model.h:33): the reference keeps one replica per device inside one process.  This build runs one process per GPU
     // (torch.distributed over RCCL), so a process only ever holds its own replica; broadcast() records the device list and all_reduce()

@@ -8,6 +8,8 @@
 
 #include <chrono>
 #include <cmath>
+#include <sstream>
+#include <thread>
 
 namespace marius_amd {
 
@@ -18,7 +20,15 @@ namespace marius_amd {
     } while (0)
 
 namespace {
-double g_fine[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // MARIUS_SHARDED_FINE=1: host seconds inside prepare() — wait event, prepareBatch, offsets + post, copies + stamp, event record
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
 struct Phase {  // adds the enclosed host time to one slot of ShardedTrainer::phase_seconds_
     double& acc;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -54,6 +64,8 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
     lo_ = std::min<int64_t>((int64_t)rank_ * S_, num_nodes_);
     if (table_.size(0) != std::min<int64_t>(lo_ + S_, num_nodes_) - lo_) throw MariusRuntimeException("ShardedTrainer: shard has the wrong number of rows");
     d_ = (int)table_.size(1);
+    saved_full_batches_ = loader_->full_batches_only_;
+    saved_plan_ahead_ = loader_->plan_ahead_;
     loader_->full_batches_only_ = true;  // prepare() wraps to the next epoch when fewer than a full batch remains
     loader_->plan_ahead_ = true;         // the reductions' index work rides with the preparation (marius_segment_plan)
     pg_ = c10d::resolve_process_group(group_name);
@@ -75,22 +87,25 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
         const char* sl = getenv("MARIUS_EXCHANGE_SLACK");  // planned maximum per (requester, owner) pair = slack * capacity / world (world > 1)
         if (sl && atof(sl) >= 1.0) slack_ = atof(sl);
     }
+    {
+        const char* e = getenv("MARIUS_SHARDED_DEADLINE_S");
+        if (e && atof(e) > 0) deadline_s_ = atof(e);
+    }
+    const int64_t rec_words = marius_a2a_record_words(world_);
     for (auto& s : slots_) {
-        s.stamp_dev = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
-        s.stamp_host = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
+        s.rec_host = torch::zeros({rec_words}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));  // stamp 0 = nothing published
+        s.hdr.assign(rec_words, 0);
         s.overflow_dev = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
-        s.overflow_host = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
         s.offs_dev = torch::empty({world_ + 1}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
-        s.offs_host = torch::empty({world_ + 1}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
         s.cnt_send_dev = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
         s.cnt_recv_dev = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
-        s.cnt_recv_host = torch::zeros({world_}, torch::TensorOptions().dtype(torch::kInt64).pinned_memory(true));
         s.row_bound = torch::zeros({1}, torch::TensorOptions().dtype(torch::kFloat32).device(dev));
         s.ready = new_event();
         s.fetched = new_event();
         s.computed = new_event();
         s.free_ = new_event();
     }
+    saved_run_ahead_ = loader_->run_ahead_;
     loader_->run_ahead_ = false;
     loader_->num_relations_ = model_->decoder_->num_relations_;
     // The exchange and preparation streams carry ~0.9 GB of row traffic per step in kernels that can only run where the persistent matrix
@@ -98,6 +113,7 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
     // cost the matrix launches 4 % and take the step from 0.726 to 0.696 ms at world 1 (sweep 0 / 16 / 32 / 48 / 64 / 96: profiles/r5_sharded_free_cus.txt)
     {
         const char* e = getenv("MARIUS_SHARDED_FREE_CUS");
+        saved_free_cus_ = model_->ctx_.free_cus;  // put back by the destructor: a Model later driven by SynchronousTrainer fills the chip again
         model_->ctx_.free_cus = e ? atoi(e) : 32;
     }
     // Where the MT19937 words come from.  The run-ahead pool's own stream would be a FIFTH stream beside compute / preparation / exchange / RCCL, and
@@ -108,6 +124,8 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
     // launches are the step's critical path and the two fills are 0.15 ms of it: 0.749 ms — the fills delay the exchange more than they spared the
     // preparation); =own: the pool on a stream of its own, round 4's form.
     if (loader_->generator_) {
+        saved_prefetch_ = loader_->generator_->prefetch_;
+        saved_pool_requests_ = loader_->generator_->pool_requests_;
         static const char mode = [] { const char* e = getenv("MARIUS_MT_FILL"); return e ? e[0] : 'p'; }();
         if (mode == 'x' && staleness_ > 0) {
             loader_->generator_->prefetch_ = true;
@@ -126,6 +144,16 @@ ShardedTrainer::ShardedTrainer(shared_ptr<DataLoader> loader, shared_ptr<Model> 
 
 ShardedTrainer::~ShardedTrainer() {
     (void)hipDeviceSynchronize();
+    // what the constructor changed on the model / loader / generator it was handed
+    model_->ctx_.free_cus = saved_free_cus_;
+    loader_->full_batches_only_ = saved_full_batches_;
+    loader_->plan_ahead_ = saved_plan_ahead_;
+    loader_->run_ahead_ = saved_run_ahead_;
+    if (loader_->generator_) {
+        loader_->generator_->release_fill_stream();  // (MARIUS_MT_FILL=xchg lent it the exchange stream, which dies with this object)
+        loader_->generator_->prefetch_ = saved_prefetch_;
+        loader_->generator_->pool_requests_ = saved_pool_requests_;
+    }
     for (auto& s : slots_)
         for (void* e : {s.ready, s.fetched, s.computed, s.free_})
             if (e) (void)hipEventDestroy((hipEvent_t)e);
@@ -174,9 +202,31 @@ Tensor ShardedTrainer::view(Tensor& buf, int64_t n, std::vector<int64_t> tail, t
     return buf.narrow(0, 0, n);
 }
 
-Tensor ShardedTrainer::a2a(const Tensor& in, const std::vector<int64_t>& send_counts, const std::vector<int64_t>& recv_counts, Tensor out) {
+// An all-to-all(v) whose two sides disagree never completes (the c10d watchdog ends the process ten minutes later): every split vector is
+// checked against the tensors it describes before the collective is issued, and a mismatch names the batch.
+void ShardedTrainer::check_splits(const Slot& s, const char* what, const Tensor& in, const std::vector<int64_t>& in_split, const Tensor& out,
+                                  const std::vector<int64_t>& out_split) const {
+    int64_t ns = 0, nr = 0;
+    bool neg = false;
+    for (auto c : in_split) { ns += c; neg = neg || c < 0; }
+    for (auto c : out_split) { nr += c; neg = neg || c < 0; }
+    const bool self_ok = world_ > 1 || in_split[0] == out_split[0];  // world 1: what this rank sends itself is what it receives
+    if (neg || (int)in_split.size() != world_ || (int)out_split.size() != world_ || in.size(0) != ns || out.size(0) != nr || !self_ok) {
+        std::ostringstream m;
+        m << "ShardedTrainer: " << what << " all-to-all(v) of batch " << s.batch_index << " (slot " << (s.batch_index % RING) << ", rank " << rank_ << "): send rows " << in.size(0)
+          << " vs split sum " << ns << ", receive rows " << out.size(0) << " vs split sum " << nr << "; send splits [";
+        for (auto c : in_split) m << c << " ";
+        m << "] receive splits [";
+        for (auto c : out_split) m << c << " ";
+        m << "]";
+        throw MariusRuntimeException(m.str());
+    }
+}
+
+Tensor ShardedTrainer::a2a(const Slot& s, const char* what, const Tensor& in, const std::vector<int64_t>& send_counts, const std::vector<int64_t>& recv_counts, Tensor out) {
     Tensor src = in.contiguous();
     std::vector<int64_t> out_split = recv_counts, in_split = send_counts;
+    check_splits(s, what, src, in_split, out, out_split);
     pg_->alltoall_base(out, src, out_split, in_split)->wait();  // NCCL work: orders the current stream behind the collective, the host does not block
     return out;
 }
@@ -211,15 +261,14 @@ void ShardedTrainer::span_collect(Slot& s) {
 }
 
 void ShardedTrainer::prepare(int64_t t) {
-    Phase ph(phase_seconds_[0]);
     Slot& s = slot(t);
-    span_collect(s);
-    auto& prep = strm(prep_stream_);
-    const auto dev_index = table_.device().index();
     if (s.used) {
         Phase pw(phase_seconds_[1]);  // (fixed-capacity form: the only place the loop can wait — for a preparation issued RING steps ago)
         retire(s);
     }
+    Phase ph(phase_seconds_[0]);
+    span_collect(s);
+    auto& prep = strm(prep_stream_);
     if (s.used) {
         ST_HIPCHECK(hipStreamWaitEvent(prep.stream(), (hipEvent_t)s.free_, 0));  // the batch that used this slot RING steps ago is fully retired
     } else {
@@ -227,7 +276,6 @@ void ShardedTrainer::prepare(int64_t t) {
         ST_HIPCHECK(hipEventRecord(e, strm(main_stream_).stream()));
         ST_HIPCHECK(hipStreamWaitEvent(prep.stream(), e, 0));
         ST_HIPCHECK(hipEventDestroy(e));
-        (void)dev_index;
     }
     span_begin(s, 0, prep_stream_);
     {
@@ -235,50 +283,52 @@ void ShardedTrainer::prepare(int64_t t) {
         const int64_t B = loader_->batch_size_;
         if ((loader_->batch_id_ + 1) * B > loader_->num_edges_) loader_->initializeBatches(true);  // next epoch: a new permutation (full batches only)
         {
-            Phase pf(g_fine[1]);
+            Phase pf(fine_seconds_[0]);
             s.batch = loader_->prepareBatch(/*exact_unique=*/false);
         }
-        Phase pf2(g_fine[2]);
-        mcheck(marius_owner_offsets(s.batch->unique_node_indices_.data_ptr<int64_t>(), s.batch->num_unique_dev_.data_ptr<int64_t>(), S_, world_,
-                                    s.offs_dev.data_ptr<int64_t>(), (marius_stream_t)prep.stream()));
-        s.offs_host.copy_(s.offs_dev, /*non_blocking=*/true);
+        Phase pf2(fine_seconds_[1]);
+        s.batch_index = t;
+        auto st = (marius_stream_t)prep.stream();
+        // split points by owner and the all-to-all(v) send counts, one launch
+        mcheck(marius_owner_offsets_counts(s.batch->unique_node_indices_.data_ptr<int64_t>(), s.batch->num_unique_dev_.data_ptr<int64_t>(), S_, world_,
+                                           s.offs_dev.data_ptr<int64_t>(), s.cnt_send_dev.data_ptr<int64_t>(), st));
+        const int64_t* recv_counts_dev = nullptr;   // NULL: the header carries the send counts (world 1: what this rank asks itself for)
+        const int32_t* overflow_dev = nullptr;
         if (fixed_) {
-            // fixed-capacity exchange: the id payload (-1 padded blocks of cap slots per owner) and the slot of every unique row; nothing
-            // of this batch is ever needed on the host (the split points above are read RING steps later, for the byte accounting only)
+            // fixed-capacity exchange: the id payload (-1 padded blocks of cap slots per owner) and the slot of every unique row; the exchange
+            // itself needs nothing of this batch on the host (the header is read for the overflow flag and the byte accounting only)
             setup_fixed(s, s.batch->occ_perm_.size(0));
             s.overflow_dev.zero_();
             mcheck(marius_a2a_rows_post(s.batch->unique_node_indices_.data_ptr<int64_t>(), s.offs_dev.data_ptr<int64_t>(), S_, world_, cap_,
                                         s.req_send.data_ptr<int64_t>(), s.place.data_ptr<int64_t>(), s.overflow_dev.data_ptr<int32_t>(),
-                                        s.batch->occ_inverse_.data_ptr<int64_t>(), L_, s.slot_of_occ.data_ptr<int64_t>(), (marius_stream_t)prep.stream()));
-            s.overflow_host.copy_(s.overflow_dev, /*non_blocking=*/true);
+                                        s.batch->occ_inverse_.data_ptr<int64_t>(), L_, s.slot_of_occ.data_ptr<int64_t>(), st));
+            if (world_ > 1) {
+                // every rank must refuse an overflowing batch TOGETHER (a rank that throws alone leaves its peers blocked in the next all-to-all
+                // until the c10d watchdog fires): the flag is max-reduced over the ranks here, four batches before anybody exchanges the batch
+                std::vector<Tensor> v{s.overflow_dev};
+                c10d::AllreduceOptions opts;
+                opts.reduceOp = c10d::ReduceOp::MAX;
+                pg_->allreduce(v, opts)->wait();
+            }
+            overflow_dev = s.overflow_dev.data_ptr<int32_t>();
             // the batch's local indices in slot terms (dataloader.cpp:460-466 with place o inverse instead of inverse): the decoder then reads
             // the row payload where the all-to-all left it — no compacted [U, d] copy
             const int64_t Bb = s.batch->global_edges_.size(0), cols = s.batch->global_edges_.size(1), CN = s.batch->src_neg_indices_.numel();
             if (!s.edges_slot.defined() || s.edges_slot.size(0) != Bb) s.edges_slot = torch::empty({Bb, cols}, s.batch->global_edges_.options());
-            mcheck(marius_remap_edges(s.batch->global_edges_.data_ptr<int64_t>(), s.slot_of_occ.data_ptr<int64_t>(), Bb, (int32_t)cols, s.edges_slot.data_ptr<int64_t>(),
-                                      (marius_stream_t)prep.stream()));
+            mcheck(marius_remap_edges(s.batch->global_edges_.data_ptr<int64_t>(), s.slot_of_occ.data_ptr<int64_t>(), Bb, (int32_t)cols, s.edges_slot.data_ptr<int64_t>(), st));
             s.batch->edges_ = s.edges_slot;
             s.batch->src_neg_indices_mapping_ = s.slot_of_occ.narrow(0, 2 * Bb, CN).view(s.batch->src_neg_indices_.sizes());
             s.batch->dst_neg_indices_mapping_ = s.slot_of_occ.narrow(0, 2 * Bb + CN, CN).view(s.batch->dst_neg_indices_.sizes());
-        } else {
-        // The receive counts of the all-to-all(v) travel on the device as well: a `world`-integer all-to-all of the send counts on this
-        // (preparation) stream, read back together with the split points behind the same `ready` event.  No host round trip (the
-        // earlier form exchanged them over a gloo group from the host, one blocking call per step in the training loop).  Every rank
-        // issues its collectives in the same program order, which is all a communicator requires.
-        torch::sub_out(s.cnt_send_dev, s.offs_dev.narrow(0, 1, world_), s.offs_dev.narrow(0, 0, world_));
-        if (world_ > 1) {
+        } else if (world_ > 1) {
+            // The receive counts of the all-to-all(v) travel on the device as well: a `world`-integer all-to-all of the send counts on this
+            // (preparation) stream.  Every rank issues its collectives in the same program order, which is all a communicator requires.
             std::vector<int64_t> none;
             pg_->alltoall_base(s.cnt_recv_dev, s.cnt_send_dev, none, none)->wait();
-        } else {
-            s.cnt_recv_dev.copy_(s.cnt_send_dev);
+            recv_counts_dev = s.cnt_recv_dev.data_ptr<int64_t>();
         }
-        s.cnt_recv_host.copy_(s.cnt_recv_dev, /*non_blocking=*/true);
-        }
+        // the LAST operation of the preparation: the whole header in one ordered record (exchange.hip: payload, system fence, stamp)
         s.stamp_value = t + 1;
-        // the last operation of the preparation (see Slot::stamp_host): ONE copy out of a device table of stamp values (no fill launch)
-        if (!stamps_dev_.defined() || s.stamp_value > stamps_dev_.size(0))
-            stamps_dev_ = torch::arange(1, std::max<int64_t>(2 * s.stamp_value, 1 << 16) + 1, torch::TensorOptions().dtype(torch::kInt64).device(table_.device()));
-        s.stamp_host.copy_(stamps_dev_.narrow(0, s.stamp_value - 1, 1), /*non_blocking=*/true);
+        mcheck(marius_a2a_publish(s.offs_dev.data_ptr<int64_t>(), recv_counts_dev, overflow_dev, world_, s.stamp_value, s.rec_host.data_ptr<int64_t>(), st));
     }
     span_end(s, 0, prep_stream_);
     ST_HIPCHECK(hipEventRecord((hipEvent_t)s.ready, prep.stream()));
@@ -289,27 +339,66 @@ void ShardedTrainer::prepare_through(int64_t t) {
     while (next_prepared_ <= t) prepare(next_prepared_++);
 }
 
-// stage 2 (host + exchange stream): split sizes, then ids -> owners, rows -> requesters
+// what a stuck pipeline looks like from the host: which headers arrived, which events fired, which streams still hold work
+std::string ShardedTrainer::describe_state() const {
+    std::ostringstream m;
+    auto q = [](void* e) { return !e ? "-" : hipEventQuery((hipEvent_t)e) == hipSuccess ? "done" : "pending"; };
+    m << "rank " << rank_ << "/" << world_ << " step " << step_index_ << " prepared<" << next_prepared_ << " fetched<" << next_fetched_ << " exchange " << (fixed_ ? "fixed" : "exact")
+      << " torn_reads " << torn_reads_ << "; streams:";
+    const char* names[3] = {"main", "prep", "xchg"};
+    void* streams[3] = {main_stream_, prep_stream_, xchg_stream_};
+    for (int k = 0; k < 3; ++k)
+        m << " " << names[k] << "=" << (streams[k] && hipStreamQuery(((c10::hip::HIPStream*)streams[k])->stream()) == hipSuccess ? "idle" : "busy");
+    for (int k = 0; k < RING; ++k) {
+        const Slot& s = slots_[k];
+        if (!s.used) continue;
+        const int64_t seen = __atomic_load_n(s.rec_host.data_ptr<int64_t>(), __ATOMIC_ACQUIRE);
+        m << "; slot " << k << " batch " << s.batch_index << " stamp " << seen << "/" << s.stamp_value << " ready=" << q(s.ready) << " fetched=" << q(s.fetched)
+          << " computed=" << q(s.computed) << " free=" << q(s.free_);
+    }
+    return m.str();
+}
+
+// stage 2 (host + exchange stream): split sizes, then ids -> owners, rows -> requesters.
+// The header of a batch prepared at least one step ago: poll the stamp (acquire), copy the record, verify its checksum; a record that fails
+// the checksum is polled again (and counted), one that never arrives fails the step with the pipeline's state in the message.
 void ShardedTrainer::wait_prepared(Slot& s) {
-    volatile int64_t* stamp = s.stamp_host.data_ptr<int64_t>();
+    if (s.hdr_stamp == s.stamp_value) return;
+    const int64_t* rec = s.rec_host.data_ptr<int64_t>();
+    const int n = (int)s.hdr.size();
     const auto t0 = std::chrono::steady_clock::now();
-    for (int64_t spins = 0; *stamp != s.stamp_value; ++spins) {
-        if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0)
-            throw MariusRuntimeException("ShardedTrainer: a batch preparation did not finish within 60 s");
-        __builtin_ia32_pause();
+    for (int64_t spins = 0;; ++spins) {
+        if (__atomic_load_n(rec, __ATOMIC_ACQUIRE) == s.stamp_value) {
+            s.hdr[0] = s.stamp_value;
+            for (int w = 1; w < n; ++w) s.hdr[w] = __atomic_load_n(rec + w, __ATOMIC_RELAXED);
+            if ((uint64_t)s.hdr[n - 1] == marius_a2a_record_checksum(s.hdr.data(), world_)) {
+                s.hdr_stamp = s.stamp_value;
+                return;
+            }
+            ++torn_reads_;
+        }
+        if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > deadline_s_) {
+            failed_ = true;
+            throw MariusRuntimeException("ShardedTrainer: the header of batch " + std::to_string(s.batch_index) + " did not reach the host within " +
+                                         std::to_string(deadline_s_) + " s (MARIUS_SHARDED_DEADLINE_S) — " + describe_state());
+        }
+        cpu_relax();
     }
 }
 
-// a slot is reused RING steps after its batch was prepared: the stamp is long there, so this reads pinned memory without waiting
+void ShardedTrainer::refuse_overflow(const Slot& s) const {
+    if (s.hdr[2 * world_ + 2] != 0)
+        throw MariusRuntimeException("ShardedTrainer: batch " + std::to_string(s.batch_index) + " asked one owner for more than the planned maximum of " + std::to_string(cap_) +
+                                     " rows on some rank (fixed-capacity exchange, slack " + std::to_string(slack_) + "): raise MARIUS_EXCHANGE_SLACK, or MARIUS_EXCHANGE=exact." +
+                                     "  Nothing of the batch was exchanged or applied; every rank raises at this batch.");
+}
+
+// a slot is reused RING steps after its batch was prepared: the header is long there, so this reads pinned memory without waiting
 void ShardedTrainer::retire(Slot& s) {
     wait_prepared(s);
-    if (fixed_ && *s.overflow_host.data_ptr<int32_t>() != 0)
-        throw MariusRuntimeException("ShardedTrainer: a batch asked one owner for more than the planned maximum of " + std::to_string(cap_) +
-                                     " rows (fixed-capacity exchange, slack " + std::to_string(slack_) + "): raise MARIUS_EXCHANGE_SLACK, or MARIUS_EXCHANGE=exact");
     if (fixed_) {
-        const int64_t* offs = s.offs_host.data_ptr<int64_t>();
         for (int q = 0; q < world_; ++q)
-            if (q != rank_) useful_rows_[0] += offs[q + 1] - offs[q];
+            if (q != rank_) useful_rows_[0] += s.hdr[2 + q] - s.hdr[1 + q];
     }
 }
 
@@ -346,8 +435,16 @@ void ShardedTrainer::setup_fixed(Slot& s, int64_t L) {
 
 // stage 2, fixed-capacity form (exchange stream; the host reads nothing): ids -> owners, owners gather + plan their update, rows -> requesters
 void ShardedTrainer::fetch_fixed(int64_t t) {
-    Phase ph(phase_seconds_[2]);
     Slot& s = slot(t);
+    {
+        // the header was published AHEAD batches ago: no wait in steady state.  The overflow flag in it is the MAX over all ranks, so every rank
+        // refuses the batch here, BEFORE any of its payloads is exchanged, scored or applied (no corrupted update ever reaches a shard)
+        Phase pw(phase_seconds_[1]);
+        wait_prepared(s);
+        if (s.hdr[2 * world_ + 2] != 0) failed_ = true;
+        refuse_overflow(s);
+    }
+    Phase ph(phase_seconds_[2]);
     auto& xchg = strm(xchg_stream_);
     ST_HIPCHECK(hipStreamWaitEvent(xchg.stream(), (hipEvent_t)s.ready, 0));
     span_begin(s, 1, xchg_stream_);
@@ -427,16 +524,22 @@ void ShardedTrainer::fetch(int64_t t) {
         wait_prepared(s);  // a batch prepared at least one step ago: no stream drains for this
     }
     Phase ph(phase_seconds_[2]);
-    const int64_t* offs = s.offs_host.data_ptr<int64_t>();
+    const int64_t* offs = s.hdr.data() + 1;
+    const int64_t* rc = s.hdr.data() + world_ + 2;
     s.send_counts.assign(world_, 0);
     for (int i = 0; i < world_; ++i) s.send_counts[i] = offs[i + 1] - offs[i];
-    {
-        const int64_t* rc = s.cnt_recv_host.data_ptr<int64_t>();
-        s.recv_counts.assign(rc, rc + world_);
-    }
+    s.recv_counts.assign(rc, rc + world_);
     s.U = offs[world_];
     s.nrecv = 0;
     for (auto c : s.recv_counts) s.nrecv += c;
+    {   // a header that passed its checksum is what the device wrote; this guards the device side (a wrong unique count, a shard-size mismatch)
+        bool ok = offs[0] == 0 && s.U >= 0 && s.U <= s.batch->unique_node_indices_.size(0);
+        for (int i = 0; i < world_; ++i) ok = ok && s.send_counts[i] >= 0 && s.recv_counts[i] >= 0 && s.recv_counts[i] <= table_.size(0);
+        if (!ok) {
+            failed_ = true;
+            throw MariusRuntimeException("ShardedTrainer: implausible exchange header for batch " + std::to_string(s.batch_index) + " — " + describe_state());
+        }
+    }
     const int k = (int)(t % RING);
     auto& xchg = strm(xchg_stream_);
     ST_HIPCHECK(hipStreamWaitEvent(xchg.stream(), (hipEvent_t)s.ready, 0));
@@ -444,7 +547,7 @@ void ShardedTrainer::fetch(int64_t t) {
     {
         Scope scope(xchg);
         span_begin(s, 4, xchg_stream_);
-        Tensor req = a2a(s.batch->unique_node_indices_.narrow(0, 0, s.U), s.send_counts, s.recv_counts, view(buf_req_, s.nrecv, {}, torch::kInt64));
+        Tensor req = a2a(s, "id", s.batch->unique_node_indices_.narrow(0, 0, s.U), s.send_counts, s.recv_counts, view(buf_req_, s.nrecv, {}, torch::kInt64));
         span_end(s, 4, xchg_stream_);
         span_begin(s, 5, xchg_stream_);
         s.local_ids = view(local_[k], s.nrecv, {}, torch::kInt64);
@@ -455,7 +558,7 @@ void ShardedTrainer::fetch(int64_t t) {
                                       rows.stride(0), (marius_stream_t)xchg.stream()));
         span_end(s, 5, xchg_stream_);
         span_begin(s, 6, xchg_stream_);
-        s.emb = a2a(rows, s.recv_counts, s.send_counts, view(emb_[k], s.U, {d_}, torch::kFloat32));
+        s.emb = a2a(s, "row", rows, s.recv_counts, s.send_counts, view(emb_[k], s.U, {d_}, torch::kFloat32));
         span_end(s, 6, xchg_stream_);
         // Magnitude bound of the rows this batch will read (marius_lp_desc.absmax: fp16 operand halves on the flash path).  The rows come from
         // every rank's shard, so no rank's own table bound covers them — but the requester holds all of them right here: one pass over the
@@ -472,6 +575,8 @@ void ShardedTrainer::fetch(int64_t t) {
         exchange_bytes_[0] += s.send_counts[q] * 8;             // ids to the owners
         exchange_bytes_[1] += s.recv_counts[q] * (int64_t)d_ * 4;  // rows served to the requesters
         exchange_bytes_[2] += s.send_counts[q] * (int64_t)d_ * 4;  // gradients returned to the owners (update())
+        useful_rows_[0] += s.send_counts[q];
+        useful_rows_[1] += s.recv_counts[q];
     }
 }
 
@@ -574,7 +679,7 @@ void ShardedTrainer::update(int64_t t) {
     span_begin(s, 3, xchg_stream_);
     {
         Scope scope(xchg);
-        Tensor recv_grad = a2a(s.grad, s.send_counts, s.recv_counts, view(buf_recv_grad_, s.nrecv, {d_}, torch::kFloat32));
+        Tensor recv_grad = a2a(s, "gradient", s.grad, s.send_counts, s.recv_counts, view(buf_recv_grad_, s.nrecv, {d_}, torch::kFloat32));
         apply_local(s, recv_grad);
     }
     span_end(s, 3, xchg_stream_);
@@ -603,6 +708,7 @@ void ShardedTrainer::dense(int64_t t) {
 }
 
 void ShardedTrainer::step() {
+    if (failed_) throw MariusRuntimeException("ShardedTrainer: an earlier step failed; the pipeline is half-advanced and cannot continue");
     const auto t0 = std::chrono::steady_clock::now();
     const int64_t t = step_index_;
     fetch_through(t);  // no-op except on the first step
@@ -630,12 +736,9 @@ void ShardedTrainer::train_steps(int64_t n) {
 void ShardedTrainer::finish() {
     ST_HIPCHECK(hipDeviceSynchronize());
     if (getenv("MARIUS_SHARDED_FINE"))
-        fprintf(stderr, "[sharded fine] per step ms: prepareBatch %.4f, rest of prepare %.4f (steps %ld)\n", g_fine[1] / std::max<int64_t>(steps_, 1) * 1e3,
-                g_fine[2] / std::max<int64_t>(steps_, 1) * 1e3, (long)steps_);
-    for (auto& s : slots_)
-        if (s.used && fixed_ && *s.overflow_host.data_ptr<int32_t>() != 0)
-            throw MariusRuntimeException("ShardedTrainer: a batch asked one owner for more than the planned maximum of " + std::to_string(cap_) +
-                                         " rows (fixed-capacity exchange): raise MARIUS_EXCHANGE_SLACK, or MARIUS_EXCHANGE=exact");
+        fprintf(stderr, "[sharded fine] per step ms: prepareBatch %.4f, rest of prepare %.4f (steps %ld)\n", fine_seconds_[0] / std::max<int64_t>(steps_, 1) * 1e3,
+                fine_seconds_[1] / std::max<int64_t>(steps_, 1) * 1e3, (long)steps_);
+    // batches prepared ahead but never fetched are dropped; an overflow among them was never acted on and is nobody's error
 }
 
 std::vector<Tensor> c10d_exchange_selftest(const std::string& group_name, Tensor send, std::vector<int64_t> send_counts, Tensor to_reduce) {

@@ -7,8 +7,8 @@
 // a string crosses the Python boundary.
 //
 // Round 5: two forms of the exchange, same schedule.
-//   exact (default)  all-to-all(v): the split sizes of a batch are written to pinned memory by its preparation, AHEAD steps before the exchange
-//                    needs them, together with a stamp the loop polls (no hipEventSynchronize: see Slot::stamp_host).
+//   exact (default)  all-to-all(v): the split sizes of a batch reach the host as ONE ordered record (marius_a2a_publish: payload, system fence,
+//                    stamp; checksummed), written by the batch's preparation AHEAD steps before the exchange needs it (Slot::rec_host).
 //   fixed            (MARIUS_EXCHANGE=fixed) FIXED-CAPACITY payloads: every (requester, owner) pair owns `cap` slots of each payload —
 //                    marius_a2a_capacity: the batch's id capacity at world 1, slack x capacity / world otherwise — the three payloads (ids, rows,
 //                    gradients) travel by equal-split all-to-alls, the counts ride in the id payload as -1 padding (exchange.hip,
@@ -53,8 +53,12 @@ class ShardedTrainer {
     int64_t steps_ = 0;
     double phase_seconds_[6] = {0, 0, 0, 0, 0, 0};  // host time in: prepare, wait for split points, fetch, compute, update, dense
     bool fixed_capacity() const { return fixed_; }
+    // records whose first read failed the checksum and were polled again (wait_prepared): 0 unless the platform reorders the kernel's stores
+    int64_t torn_reads_ = 0;
+    std::string describe_state() const;  // every slot's stamp and events, every stream's status: what a deadline failure reports
     int64_t pair_capacity() const { return cap_; }  // rows per (requester, owner) pair and payload (fixed-capacity exchange); 0 before the first batch
-    // rows this rank actually asked of / served to OTHER ranks (from the split points, read long after the fact): the useful part of exchange_bytes_
+    // rows this rank actually asked of [0] / was asked for by [1] OTHER ranks (from the published header): the useful part of exchange_bytes_
+    // ([1] needs the receive counts: exact form only; the fixed-capacity form exchanges no counts and leaves it 0)
     int64_t useful_rows_[2] = {0, 0};
     // device time from the first to the last operation of a stage on its stream (HIP events; collected when a slot is reused, RING steps
     // later): prepare (prep stream), fetch and update (exchange stream), compute (main stream).  A stage's span includes the time its
@@ -69,14 +73,15 @@ class ShardedTrainer {
         steps_ = 0;
         exchange_bytes_[0] = exchange_bytes_[1] = exchange_bytes_[2] = 0;
         useful_rows_[0] = useful_rows_[1] = 0;
+        fine_seconds_[0] = fine_seconds_[1] = 0;
     }
 
    private:
     struct Slot {
         shared_ptr<Batch> batch;
-        Tensor offs_dev, offs_host;  // [world + 1] split points of the batch's ascending unique ids by owner
-        Tensor cnt_send_dev, cnt_recv_dev, cnt_recv_host;  // [world] rows this rank asks of every owner / is asked for by every requester
-        void* ready = nullptr;       // prep stream: batch prepared, split points on their way to the host
+        Tensor offs_dev;                    // [world + 1] split points of the batch's ascending unique ids by owner
+        Tensor cnt_send_dev, cnt_recv_dev;  // [world] rows this rank asks of every owner / is asked for by every requester
+        void* ready = nullptr;       // prep stream: batch prepared, header published
         void* fetched = nullptr;     // rows of this batch have arrived
         void* computed = nullptr;    // per-row gradients complete
         void* free_ = nullptr;       // owners applied the gradients: every buffer of the slot is reusable
@@ -88,15 +93,21 @@ class ShardedTrainer {
         int64_t U = 0, nrecv = 0;
         Tensor emb, grad, local_ids;
         Tensor row_bound;  // device float[1] >= every |x| of the rows this slot's batches gathered (Batch::row_bound_; max'ed in on the exchange stream)
-        // host-visible stamp: the LAST thing a preparation writes (pinned int64 = batch index + 1).  The host polls it instead of
-        // hipEventSynchronize(ready): on this runtime an event wait on a stream with younger work queued behind the event returned only when
-        // that younger work had finished (profiles/r5_sharded_timeline_before.txt: the loop woke when the preparation issued LAST completed)
-        Tensor stamp_dev, stamp_host;
+        // The batch's exchange header on the host: pinned int64 [2 world + 4] = stamp | split points | receive counts | overflow | checksum, written by
+        // the LAST kernel of the preparation (marius_a2a_publish: payload stores, system fence, then the stamp = batch index + 1 with release
+        // semantics).  The host polls the stamp (acquire) instead of hipEventSynchronize(ready) — on this runtime an event wait on a stream with
+        // younger work queued behind the event returned only when that younger work had finished (profiles/r5_sharded_timeline_before.txt) —
+        // copies the record to `hdr` and accepts it only if the checksum matches.
+        Tensor rec_host;
+        std::vector<int64_t> hdr;   // the accepted copy
+        int64_t hdr_stamp = 0;      // stamp of the record in hdr (== stamp_value once wait_prepared returned)
         int64_t stamp_value = 0;
+        int64_t batch_index = -1;
         // fixed-capacity exchange
         Tensor req_send, place;             // [world * cap] ids asked of every owner (-1 padded), [L] slot of unique index u
         Tensor slot_of_occ, edges_slot;     // [L] payload slot of every occurrence, [B, cols] Batch::edges_ in slot terms: the decoder reads the row payload in place
-        Tensor overflow_dev, overflow_host;  // int32: some owner was asked for more than cap rows (checked when the slot is reused)
+        Tensor overflow_dev;  // int32: some owner was asked for more than cap rows — all-reduced (MAX) over the ranks on the preparation stream and
+                              // published in the header, so EVERY rank refuses the batch before anything of it is exchanged (fetch_fixed)
         Tensor grad_send;                   // [world * cap, d] per-row gradients in the owners' slot order
         Tensor r_uniq, r_inverse, r_perm, r_seg, r_count, r_plan;  // owner side: merged runs of the received ids + their segment plan
     };
@@ -116,7 +127,6 @@ class ShardedTrainer {
     Tensor buf_req_, buf_rows_, buf_recv_grad_, emb_[RING], grad_[RING], local_[RING];
     // owner-side dedupe of the received ids
     Tensor r_ws_, r_carry_;
-    Tensor stamps_dev_;  // 1, 2, 3, ...: the stamp of batch t is copied out of it (Slot::stamp_host)
     int64_t r_cap_ = 0;
     // fixed-capacity exchange: shared staging (each is produced and consumed inside one stage on the exchange stream)
     bool fixed_ = false;
@@ -127,8 +137,17 @@ class ShardedTrainer {
     void setup_fixed(Slot& s, int64_t L);
     void fetch_fixed(int64_t t);
     void update_fixed(int64_t t);
-    void retire(Slot& s);  // a slot is about to be reused: its preparation finished long ago — overflow flag, useful-row accounting
-    void wait_prepared(Slot& s);
+    void retire(Slot& s);  // a slot is about to be reused: its preparation finished long ago — useful-row accounting
+    void wait_prepared(Slot& s);  // the slot's header is on the host, checksum-verified, in s.hdr
+    void check_splits(const Slot& s, const char* what, const Tensor& in, const std::vector<int64_t>& in_split, const Tensor& out, const std::vector<int64_t>& out_split) const;
+    void refuse_overflow(const Slot& s) const;
+    double deadline_s_ = 60.0;          // MARIUS_SHARDED_DEADLINE_S
+    bool failed_ = false;               // a step threw: the pipeline state is half-advanced, every later call refuses
+    double fine_seconds_[2] = {0, 0};   // MARIUS_SHARDED_FINE=1: host seconds inside prepareBatch / the rest of prepare()
+    // what the constructor changed on objects it does not own, put back by the destructor
+    int saved_free_cus_ = 0;
+    bool saved_prefetch_ = true, saved_full_batches_ = false, saved_plan_ahead_ = false, saved_run_ahead_ = true;
+    int saved_pool_requests_ = 0;
 
     Slot& slot(int64_t t) { return slots_[t % RING]; }
     Tensor view(Tensor& buf, int64_t n, std::vector<int64_t> tail, torch::ScalarType dtype);
@@ -141,7 +160,7 @@ class ShardedTrainer {
     void dense(int64_t t);
     void plan_local(Slot& s);
     void apply_local(Slot& s, const Tensor& grads);
-    Tensor a2a(const Tensor& in, const std::vector<int64_t>& send_counts, const std::vector<int64_t>& recv_counts, Tensor out);
+    Tensor a2a(const Slot& s, const char* what, const Tensor& in, const std::vector<int64_t>& send_counts, const std::vector<int64_t>& recv_counts, Tensor out);
     void prime();
     void span_begin(Slot& s, int stage, void* stream);
     void span_end(Slot& s, int stage, void* stream);

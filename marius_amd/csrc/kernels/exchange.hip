@@ -94,6 +94,62 @@ __global__ __launch_bounds__(256) void a2a_wait_kernel(const float* __restrict__
     }
 }
 
+// ---- the exchange header of a batch, handed to the host in ONE ordered record ------------------------------------------------------------
+// An all-to-all(v) needs its split sizes on the host.  Rounds 2-5 moved them with three independent non-blocking device -> host copies (split
+// points, receive counts, a stamp) and let the host poll the stamp: correct only as long as the copies become host-visible in stream order,
+// which nothing in the loop ever checked — and a stale split vector gives an all-to-all(v) whose two sides disagree: a collective that never
+// completes.  Now ONE single-wave kernel writes the whole header straight into the (device-mapped, fine-grained) pinned record:
+//   word 0                    stamp      written LAST, system-scope release, after a system fence behind the payload stores
+//   words 1 .. W+1            owner split points offs[0 .. W]
+//   words W+2 .. 2W+1         rows every requester asks of this rank (recv_counts; = the send counts when there is no count exchange)
+//   word 2W+2                 overflow flag of the fixed-capacity form (0 otherwise)
+//   word 2W+3                 checksum over stamp and payload (a2a_record_checksum, same function on the host)
+// The host acquires the stamp, copies the record out, recomputes the checksum and re-polls on a mismatch: a torn or stale read is then
+// something the loop DETECTS and counts (ShardedTrainer::torn_reads_), never something it acts on.
+__host__ __device__ inline uint64_t a2a_mix(uint64_t h, uint64_t v) {
+    h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+    return h * 0xff51afd7ed558ccdull;
+}
+
+__global__ __launch_bounds__(64) void a2a_publish_kernel(const int64_t* __restrict__ offs, const int64_t* __restrict__ recv_counts,
+                                                         const int32_t* __restrict__ overflow, int world, int64_t stamp, int64_t* __restrict__ rec) {
+    const int W = world, lane = threadIdx.x;
+    uint64_t h = a2a_mix(0x6d617269757361ull, (uint64_t)stamp);  // every lane walks the whole payload for the checksum (W is the rank count: tiny)
+    for (int w = 1; w <= 2 * W + 2; ++w) {
+        int64_t v;
+        if (w <= W + 1) v = offs[w - 1];
+        else if (w <= 2 * W + 1) v = recv_counts ? recv_counts[w - W - 2] : offs[w - W - 1] - offs[w - W - 2];
+        else v = overflow ? (int64_t)*overflow : 0;
+        h = a2a_mix(h, (uint64_t)v);
+        if ((w & 63) == lane) __hip_atomic_store(rec + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (((2 * W + 3) & 63) == lane) __hip_atomic_store(rec + 2 * W + 3, (int64_t)h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();  // every lane: its payload stores are performed at system scope ...
+    __syncthreads();         // ... before lane 0 passes this barrier (release fences are cumulative across it)
+    if (lane == 0) __hip_atomic_store(rec, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// offs as owner_offsets_kernel; counts[q] = offs[q + 1] - offs[q] (the all-to-all(v) send counts) in the same launch
+__global__ void owner_offsets_counts_kernel(const int64_t* __restrict__ uniq, const int64_t* __restrict__ num_unique, int64_t shard_rows, int P,
+                                            int64_t* __restrict__ out, int64_t* __restrict__ counts) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > P) return;
+    const int64_t U = *num_unique;
+    int64_t bound[2];
+    for (int k = 0; k < 2; ++k) {
+        const int qq = q + k;
+        const int64_t key = (int64_t)qq * shard_rows;
+        int64_t lo = 0, hi = U;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (uniq[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        bound[k] = (qq >= P) ? U : lo;
+    }
+    out[q] = bound[0];
+    if (q < P && counts) counts[q] = bound[1] - bound[0];
+}
+
 }  // namespace marius
 
 using namespace marius;
@@ -146,4 +202,26 @@ extern "C" int marius_a2a_rows_wait(const float* rows_recv, int64_t recv_ld, int
     else if (vec == 2) a2a_wait_kernel<2><<<grid, block, 0, st>>>(rows_recv, recv_ld, place, num_unique_dev, capacity, vpr, tx, emb, emb_ld, absmax);
     else a2a_wait_kernel<1><<<grid, block, 0, st>>>(rows_recv, recv_ld, place, num_unique_dev, capacity, vpr, tx, emb, emb_ld, absmax);
     return check_launch("a2a_rows_wait");
+}
+
+extern "C" int32_t marius_a2a_record_words(int32_t world) { return world > 0 ? 2 * world + 4 : 0; }
+
+extern "C" uint64_t marius_a2a_record_checksum(const int64_t* record, int32_t world) {
+    uint64_t h = a2a_mix(0x6d617269757361ull, (uint64_t)record[0]);
+    for (int w = 1; w <= 2 * world + 2; ++w) h = a2a_mix(h, (uint64_t)record[w]);
+    return h;
+}
+
+extern "C" int marius_a2a_publish(const int64_t* owner_offsets, const int64_t* recv_counts, const int32_t* overflow_flag, int32_t world, int64_t stamp,
+                                  int64_t* record_mapped, marius_stream_t stream) {
+    MARIUS_REQUIRE(owner_offsets && record_mapped && world >= 1 && stamp != 0, "a2a_publish: bad arguments (stamp 0 is the unpublished state)");
+    a2a_publish_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(owner_offsets, recv_counts, overflow_flag, world, stamp, record_mapped);
+    return check_launch("a2a_publish");
+}
+
+extern "C" int marius_owner_offsets_counts(const int64_t* uniq, const int64_t* num_unique_dev, int64_t shard_rows, int32_t num_shards, int64_t* out,
+                                           int64_t* counts, marius_stream_t stream) {
+    MARIUS_REQUIRE(uniq && num_unique_dev && out && shard_rows > 0 && num_shards > 0, "owner_offsets_counts: bad arguments");
+    owner_offsets_counts_kernel<<<dim3((unsigned)cdiv(num_shards + 1, 64)), dim3(64), 0, as_stream(stream)>>>(uniq, num_unique_dev, shard_rows, num_shards, out, counts);
+    return check_launch("owner_offsets_counts");
 }

@@ -1134,13 +1134,22 @@ bool flash_fused() { return true; }
 // matrix launches (the sharded trainer) asks for them; MARIUS_FLASH_NWG: the count itself (tests of every split pattern).
 
 static int64_t fl_gcd(int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; }
+static int fl_device_cus() {  // compute units of the current device (256 on an MI355X), asked once
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return cus;
+}
 static int fl_num_wg(int64_t tiles, int mode, int ks, int free_cus) {
     const int per_cu = fl_wg_per_cu_ks(mode, ks);
     const KernelEnv& ke = kernel_env();
     int reserve = free_cus;
     if (ke.has_flash_reserve) reserve = ke.flash_reserve;
-    if (reserve < 0 || reserve >= 128) reserve = 0;
-    int nwg = (256 - reserve) * per_cu;
+    const int cus = fl_device_cus();
+    if (reserve < 0 || reserve >= cus / 2) reserve = 0;
+    int nwg = (cus - reserve) * per_cu;
     if (ke.has_flash_nwg) {
         nwg = ke.flash_nwg;
     } else if (nwg < tiles && per_cu > 1) {  // (the one-workgroup-per-CU launches of wide chunks are bound by their score traffic: 256 beats 240 there, 1.402 vs 1.418 ms)

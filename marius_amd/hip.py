@@ -18,7 +18,7 @@ REDUCE_SUM, REDUCE_MEAN = 0, 1
 LOSS = {"SOFTMAX_CE": 0, "RANKING": 1, "CROSS_ENTROPY": 2, "BCE_AFTER_SIGMOID": 3, "BCE_WITH_LOGITS": 4, "MSE": 5, "SOFTPLUS": 6}
 LP_TRAIN_ONLY, LP_STORE_SCORES, LP_KEEP_DADJ = 1, 2, 4   # marius_lp_desc.flags
 MT_STATE_WORDS = 625
-ABI_VERSION = 9  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
+ABI_VERSION = 10  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
 
 
 class MariusHipError(RuntimeError):
@@ -90,6 +90,13 @@ SIGNATURES = {
     "marius_a2a_capacity": (_i64, [_i64, _i32, C.c_double]),
     "marius_a2a_rows_post": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "marius_a2a_rows_wait": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "marius_layer_post_hook": (C.c_int, [_vp, _i64, _vp, _i32, _i64, _i32, _vp, _i64, _vp]),
+    "marius_layer_post_hook_workspace_bytes": (_sz, [_i64, _i32]),
+    "marius_layer_post_hook_backward": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "marius_owner_offsets_counts": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "marius_a2a_record_words": (_i32, [_i32]),
+    "marius_a2a_record_checksum": (C.c_uint64, [_vp, _i32]),
+    "marius_a2a_publish": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp]),
     "marius_lp_plan": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout)]),
     "marius_lp_forward": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),
     "marius_lp_loss": (C.c_int, [C.POINTER(LpDesc), C.POINTER(LpLayout), _vp, _vp]),
@@ -338,6 +345,52 @@ def a2a_rows_post(um, offs_dev, shard_rows, world, cap, inverse=None):
     check(lib().marius_a2a_rows_post(ptr(um.uniq), ptr(offs_dev), shard_rows, world, cap, ptr(req), ptr(place), ptr(flag), ptr(inverse),
                                      0 if inverse is None else inverse.numel(), ptr(slot), stream_ptr()), "a2a_rows_post")
     return req, place, flag, slot
+
+
+ACT = {"NONE": 0, "RELU": 1, "SIGMOID": 2}
+
+
+def layer_post_hook(x, bias=None, activation="NONE", out=None):
+    """Layer::post_hook (layer.cpp:9-16): act(x + bias) over the rows of x [n, d]"""
+    _dev(x)
+    out = torch.empty_like(x) if out is None else out
+    check(lib().marius_layer_post_hook(ptr(x), x.stride(0), ptr(bias), ACT[activation], x.size(0), x.size(1), ptr(out), out.stride(0), stream_ptr()), "layer_post_hook")
+    return out
+
+
+def layer_post_hook_backward(gy, y, activation="NONE", with_bias=True):
+    """(gx [n, d], bias_grad [d] or None) of layer_post_hook from the gradient of its output and the output itself"""
+    _dev(gy)
+    n, d = gy.shape
+    gx = torch.empty_like(gy)
+    bg = torch.empty(d, dtype=torch.float32, device=gy.device) if with_bias else None
+    wsb = lib().marius_layer_post_hook_workspace_bytes(n, d)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=gy.device)
+    check(lib().marius_layer_post_hook_backward(ptr(gy), gy.stride(0), ptr(y), 0 if y is None else y.stride(0), ACT[activation], n, d, ptr(gx), gx.stride(0), ptr(bg),
+                                                ptr(ws), wsb, stream_ptr()), "layer_post_hook_backward")
+    return gx, bg
+
+
+def owner_offsets_counts(um, shard_rows, world):
+    """marius_owner_offsets_counts: (offs [world + 1], send counts [world]) of a sorted unique map, one launch"""
+    offs = torch.empty(world + 1, dtype=torch.int64, device=um.uniq.device)
+    cnt = torch.empty(world, dtype=torch.int64, device=um.uniq.device)
+    check(lib().marius_owner_offsets_counts(ptr(um.uniq), ptr(um.count), shard_rows, world, ptr(offs), ptr(cnt), stream_ptr()), "owner_offsets_counts")
+    return offs, cnt
+
+
+def a2a_publish(offs_dev, record_pinned, stamp, recv_counts=None, overflow=None):
+    """marius_a2a_publish: the batch's exchange header -> ONE ordered record in pinned host memory (record_pinned: int64 [2 world + 4], pinned)"""
+    world = offs_dev.numel() - 1
+    assert record_pinned.is_pinned() and record_pinned.dtype == torch.int64 and record_pinned.numel() >= lib().marius_a2a_record_words(world)
+    check(lib().marius_a2a_publish(ptr(offs_dev), ptr(recv_counts), ptr(overflow), world, int(stamp), record_pinned.data_ptr(), stream_ptr()), "a2a_publish")
+
+
+def a2a_record_ok(record_host, world):
+    """host check of a published record: checksum word == marius_a2a_record_checksum of the words before it"""
+    r = record_host.contiguous()
+    want = lib().marius_a2a_record_checksum(r.data_ptr(), world)
+    return (int(r[2 * world + 3]) & 0xFFFFFFFFFFFFFFFF) == want
 
 
 def a2a_rows_wait(rows_recv, absmax=None, place=None, count_dev=None, emb=None):

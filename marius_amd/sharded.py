@@ -686,6 +686,7 @@ def run_sharded_bench(a, cfg, rank, world, dev):
                 # the fixed form.  host_busy = what the host needs to issue a step.
                 out["host_phase_ms_per_step"] = dict(zip(["prepare", "wait_for_device", "fetch", "compute", "update", "dense"], [round(x, 4) for x in ph]))
                 out["host_busy_ms_per_step"] = round(out["host_issue_ms_per_step"] - ph[1], 4)
+                out["header_reads_repolled"] = int(cpp_trainer.torn_reads)  # exchange headers whose first host read failed the checksum (expected 0)
         ms, cnt = prof.get("lp_grad_adj", (0.0, 0))
         if cnt:  # rank 0's dominant kernel, same accounting as the N = 1 line
             out["roofline"] = bench_mod.dominant_roofline(ms / cnt, B, C, N, d, 2, flash, a.workload == "freebase86m" and not a.num_nodes and not strong)

@@ -72,3 +72,24 @@ def owner_update(table, state, recv_ids, grads, lr, eps=1e-10):
         state[rid] = s
         table[rid] = table[rid] + (-lr * (g / (np.sqrt(s) + np.float32(eps)))).astype(np.float32)
     return uniq
+
+
+# ---- the exchange header record (marius_a2a_publish / marius_a2a_record_checksum, exchange.hip) ---------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+def _mix(h, v):
+    h ^= (v + 0x9E3779B97F4A7C15 + ((h << 6) & _M64) + (h >> 2)) & _M64
+    return (h * 0xFF51AFD7ED558CCD) & _M64
+
+
+def record(offs, recv_counts=None, overflow=0, stamp=1):
+    """int64 [2 world + 4]: stamp | offs[0..world] | recv counts (None: the send counts offs[q + 1] - offs[q]) | overflow | checksum"""
+    offs = np.asarray(offs, dtype=np.int64)
+    world = len(offs) - 1
+    rc = np.diff(offs) if recv_counts is None else np.asarray(recv_counts, dtype=np.int64)
+    words = np.concatenate([[stamp], offs, rc, [overflow]]).astype(np.int64)
+    h = _mix(0x6D617269757361, int(stamp) & _M64)
+    for v in words[1:]:
+        h = _mix(h, int(v) & _M64)
+    return np.concatenate([words, np.array([h], dtype=np.uint64).view(np.int64)])

@@ -127,3 +127,29 @@ def test_post_layout_and_capacity_rule():
     uniq = np.arange(0, 300, dtype=np.int64)  # all of them owned by shard 0 of 2
     req, place, over = X.post(uniq, 1000, 2, 256)
     assert over
+
+
+def test_exchange_header_record_checksum_host_function_matches_restatement():
+    """marius_a2a_record_checksum is a HOST function of libmarius_hip.so (no GPU needed): it must equal the numpy restatement of the record the
+    publish kernel writes, and any single changed word — a stale split point, a torn read — must fail it."""
+    import torch
+
+    from marius_amd import hip as H
+    from oracle import exchange_oracle as X
+
+    L = H.lib()
+    rng = np.random.default_rng(7)
+    for world in (1, 2, 8, 64):
+        assert L.marius_a2a_record_words(world) == 2 * world + 4
+        cuts = np.sort(rng.integers(0, 200000, world - 1)) if world > 1 else np.zeros(0, dtype=np.int64)
+        offs = np.concatenate([[0], cuts, [200000]]).astype(np.int64)
+        for recv in (None, rng.integers(0, 50000, world)):
+            rec = X.record(offs, recv, overflow=int(world == 8), stamp=1234567 + world)
+            t = torch.from_numpy(rec.copy())
+            want = int(np.array([rec[-1]], dtype=np.int64).view(np.uint64)[0])
+            assert L.marius_a2a_record_checksum(t.data_ptr(), world) == want
+            assert H.a2a_record_ok(t, world)
+            for w in range(2 * world + 3):  # every word before the checksum is covered, the stamp included
+                bad = t.clone()
+                bad[w] += 1
+                assert not H.a2a_record_ok(bad, world), w

@@ -1,7 +1,7 @@
 """GPU parity tests: HIP path (through the C-ABI of libmarius_hip.so) vs the oracle on the same seeded inputs.
 
-Bars: bit-exact for ids / indices / copies; floats within rtol 1e-4 (north_star: "within 1e-4 relative on float
-scores"), with an absolute floor of 1e-4 x the tensor's max magnitude for entries that cancel to ~0.
+Bars: bit-exact for ids / indices / copies; floats within the three tiers of tests/tolerance.py at rtol 1e-4 (north_star: "within 1e-4
+relative on float scores"): pure relative 1e-4 over entries >= 0.1 max, 3e-4 over entries >= 0.01 max, 3e-6 x max below.
 """
 import ctypes
 import math
@@ -12,6 +12,7 @@ import torch
 
 from oracle import lp_oracle as O
 from oracle.mt_oracle import OracleGenerator
+from tolerance import tiers
 
 pytestmark = pytest.mark.gpu
 
@@ -19,13 +20,9 @@ RTOL = 1e-4
 
 
 def assert_close(got, want, what, rtol=RTOL):
-    got, want = got.detach().cpu().double(), want.detach().cpu().double()
-    assert got.shape == want.shape, (what, got.shape, want.shape)
-    atol = rtol * max(want.abs().max().item(), 1e-30)
-    err = (got - want).abs()
-    ok = err <= atol + rtol * want.abs()
-    assert bool(ok.all()), "%s: max abs err %.3e (atol %.3e), worst rel %.3e" % (
-        what, err.max().item(), atol, (err / want.abs().clamp_min(1e-30)).max().item())
+    """tests/tolerance.py:tiers — pure relative error <= rtol over entries >= 0.1 max |want|, <= 3 rtol over entries >= 0.01 max, absolute error
+    <= 0.03 rtol x max below (round 6: the old form added atol = rtol x max to EVERY entry, which passed anything below 1 % of the maximum)"""
+    tiers(got, want, what, rtol=rtol)
 
 
 @pytest.fixture(scope="module")
@@ -593,8 +590,22 @@ def test_sharded_hip_backend_equals_single_gpu_step(H, dev):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
+    import datetime
+
     if not dist.is_initialized():
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
+    try:
+        _sharded_hip_backend_body(H, dev, dist)
+    finally:  # a failed run must not leave its communicator to the rest of the process
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def _sharded_hip_backend_body(H, dev, dist):
+    from marius_amd.lp_step import DeviceLinkPredictionStep
+    from marius_amd.sharded import HipBackend, sharded_step
+
     num_nodes, R, d, B, C, N, E, seed = 3000, 9, 100, 200, 4, 60, 1200, 21
     g = torch.Generator().manual_seed(2)
     table = (torch.rand(num_nodes, d, generator=g) - 0.5) * 0.5
@@ -661,7 +672,6 @@ def test_sharded_hip_backend_equals_single_gpu_step(H, dev):
     assert not torch.equal(trace[2]["emb"], snaps[2][trace[2]["uniq"]])  # the test data does make consecutive batches share rows
     assert_close(td, T, "overlapped table", rtol=1e-5)
     assert_close(sd, S_, "overlapped state", rtol=1e-5)
-    dist.destroy_process_group()
 
 
 # ------------------------------------------------------------------------------------------------ dense Adam (optim.cpp:186-232)
@@ -783,6 +793,16 @@ def test_fixed_capacity_exchange_halves_against_numpy(H, dev, world, cap_slack):
         torch.cuda.synchronize()
         uq, of = um.uniq[:U].cpu().numpy(), offs.cpu().numpy()
         assert np.array_equal(of, X.owner_offsets(uq, S, world))
+        # the same split points with the send counts in one launch, and the header record the host side of the all-to-all(v) reads:
+        # ONE kernel writes payload, fence, stamp into pinned memory (marius_a2a_publish) — bit-equal to the numpy record, checksum included
+        offs2, cnt = H.owner_offsets_counts(um, S, world)
+        rec = torch.zeros(2 * world + 4, dtype=torch.int64).pin_memory()
+        recv_counts = torch.randint(0, 999, (world,), generator=g).to(dev) if r % 2 else None
+        H.a2a_publish(offs2, rec, stamp=100 + r, recv_counts=recv_counts, overflow=flag)
+        torch.cuda.synchronize()
+        assert torch.equal(offs2, offs) and np.array_equal(cnt.cpu().numpy(), np.diff(of))
+        assert np.array_equal(rec.numpy(), X.record(of, None if recv_counts is None else recv_counts.cpu().numpy(), int(flag.item()), 100 + r))
+        assert H.a2a_record_ok(rec, world)
         want_req, want_place, over = X.post(uq, S, world, cap)   # oracle/exchange_oracle.py: the numpy restatement
         assert bool(flag.item()) == over
         assert np.array_equal(req.cpu().numpy(), want_req)

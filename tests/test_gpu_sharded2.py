@@ -155,6 +155,67 @@ def test_cpp_sharded_trainer_ranks_equal_union_batch_update(world, staleness, fl
         assert not torch.allclose(simulate(cfg, world, 0)[0], table, rtol=1e-4, atol=1e-6)
 
 
+def overflow_worker(rank, world, port, outdir):
+    import marius_amd
+    from marius_amd.sharded import shard_range
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo", MARIUS_EXCHANGE="fixed", MARIUS_EXCHANGE_SLACK="1.0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    side = dist.new_group(backend="gloo")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    M = marius_amd.host()
+    num_nodes, R, d, B, C, N, E = 100000, 5, 16, 600, 3, 300, 1800
+    g = torch.Generator().manual_seed(11 + rank)
+    table = (torch.rand(num_nodes, d, generator=torch.Generator().manual_seed(3)) - 0.5) * 0.8
+    # rank 1's batches are ordinary; rank 0's edges have BOTH endpoints in shard 0: with the uniform negatives that is ~2100 of its 3000 ids for
+    # one owner, more than the 1536 slots a (requester, owner) pair owns at slack 1.0
+    hi_id = num_nodes if rank == 1 else num_nodes // 2
+    edges = torch.stack([torch.randint(hi_id, (E,), generator=g), torch.randint(R, (E,), generator=g), torch.randint(hi_id, (E,), generator=g)], 1)
+    lo, hi = shard_range(num_nodes, rank, world)
+    tb, sb = table[lo:hi].clone().to(dev), torch.zeros(hi - lo, d, device=dev)
+    gen = M.MariusGenerator(5 + rank)
+    sampler = M.CorruptNodeNegativeSampler(C, N, 0.0, False, M.LocalFilterMode.DEG, gen)
+    loader = M.DataLoader(M.InMemory(edges.to(torch.int32).to(dev)), M.InMemory("", num_nodes, d, torch.float32, dev), None, sampler, gen, B, True)
+    dec = M.ComplEx(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+    model = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+    model.setup_optimizers(0.1)
+    model.sparse_lr = 0.1
+    tr = M.ShardedTrainer(loader, model, tb, sb, rank, world, num_nodes, dist.group.WORLD.group_name, side.group_name, 1, 1)
+    msg, again = "", ""
+    try:
+        tr.train_steps(3)
+    except Exception as e:  # noqa: BLE001
+        msg = str(e)
+    try:
+        tr.step()
+    except Exception as e:  # noqa: BLE001
+        again = str(e)
+    torch.cuda.synchronize()
+    torch.save({"msg": msg, "again": again, "steps": tr.steps, "cap": tr.pair_capacity, "shard_unchanged": bool(torch.equal(tb.cpu(), table[lo:hi])),
+                "state_zero": bool((sb == 0).all())}, os.path.join(outdir, "r%d.pt" % rank))
+    del tr
+    dist.destroy_process_group()
+
+
+def test_fixed_capacity_overflow_is_refused_by_every_rank_before_anything_is_applied():
+    """a batch that asks one owner for more rows than a pair's capacity used to be flagged only on the overflowing rank, read
+    RING steps later — after the rows beyond the capacity had been scored from slot 0 and their gradients applied to a real row — while the other
+    rank blocked in the next all-to-all until the c10d watchdog fired.  Now the flag is max-reduced over the ranks on the preparation stream and
+    travels in the published header: BOTH ranks raise at that batch, before any of its payloads is exchanged, and no shard row has changed."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    port = 43000 + os.getpid() % 1000
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(overflow_worker, args=(2, port, outdir), nprocs=2, join=True)
+        res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(2)]
+    for r in range(2):
+        assert "planned maximum" in res[r]["msg"] and "batch 0" in res[r]["msg"], res[r]["msg"]  # rank 1 did not overflow itself: it raises all the same
+        assert "earlier step failed" in res[r]["again"]
+        assert res[r]["steps"] == 0 and res[r]["cap"] == 1536
+        assert res[r]["shard_unchanged"] and res[r]["state_zero"]
+
+
 def test_bench_launch_contract_two_ranks():
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` as the driver launches it, with the collectives on gloo so
     that both ranks can share this box's single GPU (MARIUS_BENCH_BACKEND, testing only): one JSON line from rank 0 with the contract's keys."""

@@ -25,9 +25,11 @@ def close_report(got, want, what, rtol=RTOL, floor=FLOOR, atol_frac=None):
     return rel, small
 
 
-def tiers(got, want, what):
-    close_report(got, want, what, floor=0.1, atol_frac=1.0)
-    close_report(got, want, what, rtol=3e-4, floor=0.01, atol_frac=3e-6)
+def tiers(got, want, what, rtol=RTOL):
+    """the three tiers at rtol (default north_star's 1e-4): PURE relative error <= rtol over entries >= 0.1 max, <= 3 rtol over entries >= 0.01 max,
+    absolute error <= 0.03 rtol x max (3e-6 x max at 1e-4) below — no `atol = rtol x max` term over the entries that carry the result"""
+    close_report(got, want, what, rtol=rtol, floor=0.1, atol_frac=1.0)
+    close_report(got, want, what, rtol=3 * rtol, floor=0.01, atol_frac=0.03 * rtol)
 
 
 def well_conditioned(state_ref, floor=1e-8):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5 evidence of the committed tree: default workload (bench line, rocprofv3 kernel stats, PMC traffic, one-step timeline), the twitter
 # (cfg5 shape) and degree-fraction-0.5 workloads (bench line, kernel stats, PMC traffic), forced-sharded world 1 (bench line, timeline, kernel
-# table), and the driver's own command twice.   usage (GPU box): bash tools/sessions/r5_evidence.sh <tag>
+# table), and the driver's own command twice.   usage (GPU box): bash tools/sessions/evidence.sh <tag>
 tag=${1:-r5ev}
 ulimit -c 0
 export TMPDIR=/tmp
