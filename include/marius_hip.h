@@ -49,7 +49,7 @@ enum {
  * marius_table_absmax_counted; marius_lp_layout lost the operand planes of the removed bf16x6 kernels and the stream-K partials; 8:
  * marius_lp_desc.upd_*, marius_segment_update.fused_below, marius_lp_fuses_endpoint_update, marius_segment_plan_occ_single; 9: the
  * fixed-capacity exchange entry points marius_a2a_capacity / marius_a2a_rows_post / marius_a2a_rows_wait, negative ids = padding slots in
- * marius_merge_unique_runs / marius_segment_plan; 10: marius_a2a_publish / marius_a2a_record_* / marius_owner_offsets_counts, marius_layer_post_hook*).  Every binder
+ * marius_merge_unique_runs / marius_segment_plan; 10: marius_a2a_publish / marius_a2a_record_* / marius_owner_offsets_counts, marius_layer_post_hook*, marius_prepare_maps).  Every binder
  * compares the value it was built against with what the loaded library returns and refuses to run on a mismatch: marius_amd/hip.py lib(),
  * the host module's init (bindings.cpp), and the plug-in recipe of INTEGRATION.md. */
 #define MARIUS_HIP_ABI_VERSION 10
@@ -206,6 +206,39 @@ int marius_sort_unique(const int64_t* ids, int64_t n, int32_t key_bits, int64_t*
 int marius_merge_unique_runs(const int64_t* ids, int64_t n, const int64_t* run_offsets_host, int32_t num_runs, int64_t* uniq, int64_t* inverse,
                              int32_t* perm, int32_t* seg_offsets, int64_t* num_unique_dev, void* workspace, size_t workspace_bytes,
                              marius_stream_t stream);
+
+/* The whole map chain of one batch in ONE persistent launch (round 6): for up to two id lists at once — the batch's node ids and its relation
+ * ids — assemble the ids (DataLoader::edgeSample src/data/dataloader.cpp:400-409: cat(src, dst, src_neg, dst_neg); or one column of the edges),
+ * map_tensors (src/common/util.cpp:180-205: marius_sort_unique's outputs, bit for bit), the batch's edges in batch-local ids
+ * (marius_remap_edges, dataloader.cpp:460-466) and the index plan of the segmented update (marius_segment_plan).  Replaces
+ * marius_assemble_ids + marius_sort_unique (1 + passes + 1 launches) + marius_remap_edges + marius_segment_plan per list: 13 dependent launches
+ * on the preparation stream become one.  Work items are drawn from a queue in dependency order and phases are separated by completion counters
+ * with agent-scope release / acquire, so no co-residency of workgroups is assumed (a single workgroup would complete the launch).
+ * A job's ids are either given (ids_in [n]) or assembled into ids_out [n] by the launch: col < 0 -> cat(edges[:, 0], edges[:, last], src_neg,
+ * dst_neg) (either negative list may be NULL; n = 2 B + CN per list given), col >= 0 -> edges[:, col] (n = B).  edges_out (optional,
+ * col < 0): [B, edge_cols] batch-local edges.  plan (optional): marius_segment_plan_bytes(n) bytes.  workspace: as marius_sort_unique
+ * (zero-initialised once; one per job; left reusable by either form).  marius_prepare_maps_supported: 1 when every job fits the fused launch
+ * (0 < n <= 2 M ids, key_bits <= 36) — otherwise call the separate entry points. */
+typedef struct marius_map_job {
+    const int64_t* ids_in;
+    int64_t* ids_out;
+    const int64_t* edges;
+    const int64_t* src_neg;
+    const int64_t* dst_neg;
+    int64_t B, CN, n;
+    int32_t edge_cols, col, key_bits, reserved_;
+    int64_t* uniq;
+    int64_t* inverse;
+    int32_t* perm;
+    int32_t* seg_offsets;
+    int64_t* num_unique_dev;
+    void* plan;
+    int64_t* edges_out;
+    void* workspace;
+    size_t workspace_bytes;
+} marius_map_job;
+int marius_prepare_maps_supported(const marius_map_job* jobs, int32_t num_jobs);
+int marius_prepare_maps(const marius_map_job* jobs, int32_t num_jobs, marius_stream_t stream);
 
 /* Sharded node table (partition axis of src/storage/storage.cpp:75 / buffer.cpp:340-356: shard q owns ids
  * [q * shard_rows, (q+1) * shard_rows)):  out[q] = first position in the ascending list uniq[0..*num_unique_dev) with

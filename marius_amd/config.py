@@ -147,8 +147,8 @@ def load_config(path, train=True):
     return cfg
 
 
-# LayerConfig (marius_config.py:190-199) of the one embedding layer.  What the layer's post-hook would add (Layer::post_hook, layer.cpp:9-16:
-# `+ bias`, then the activation) is NOT implemented on the device path, so asking for it is an error here — never a silently different model.
+# LayerConfig (marius_config.py:190-199) of the one embedding layer.  Its post-hook (Layer::post_hook, layer.cpp:9-16: `+ bias`, then the
+# activation) is marius_layer_post_hook / _backward behind GeneralEncoder (round 6); a model that uses it trains through the API-granular step.
 INIT_TYPES = {"GLOROT_UNIFORM": {}, "GLOROT_NORMAL": {}, "UNIFORM": {"scale_factor": 1.0}, "NORMAL": {"mean": 0.0, "std": 1.0}, "ZEROS": {}, "ONES": {},
               "CONSTANT": {"constant": 0.0}}  # InitConfig / *InitOptions (marius_config.py:96-160), initialization.cpp:67-95
 
@@ -179,12 +179,11 @@ def check_embedding_layer(layer):
         raise ValueError("model.encoder.layers[0][0]: an embedding layer has no input (input_dim must be -1 or equal to output_dim)")
     if out.get("options"):
         raise NotImplementedError("model.encoder.layers[0][0].options: an EMBEDDING layer takes none (LayerOptions, marius_config.py:163-187)")
-    if bool(out.get("bias", False)):
-        raise NotImplementedError("model.encoder.layers[0][0].bias: true — the embedding layer's bias (Layer::post_hook, layer.cpp:9-16) is not implemented on "
-                                  "the MI355X path; remove the key (the reference's default is false)")
-    if str(out.get("activation", "NONE")).upper() != "NONE":
-        raise NotImplementedError("model.encoder.layers[0][0].activation: %s — the embedding layer's activation (Layer::post_hook, layer.cpp:9-16) is not "
-                                  "implemented on the MI355X path; use NONE (the reference's default)" % out["activation"])
+    out["bias"] = bool(out.get("bias", False))
+    out["activation"] = str(out.get("activation", "NONE")).upper()
+    if out["activation"] not in ("NONE", "RELU", "SIGMOID"):  # ActivationFunction (options.h) / apply_activation (activation.cpp:7-21)
+        raise ValueError("model.encoder.layers[0][0].activation: %s (NONE, RELU or SIGMOID)" % out["activation"])
+    out["bias_init"] = check_init(out.get("bias_init") or {"type": "ZEROS"}, "model.encoder.layers[0][0].bias_init")  # LayerConfig default: ZEROS
     opt = out.get("optimizer")
     if opt and str(opt.get("type", "DEFAULT")).upper() != "DEFAULT":
         raise NotImplementedError("model.encoder.layers[0][0].optimizer: node embeddings are trained by model.sparse_optimizer (ADAGRAD)")

@@ -312,8 +312,10 @@ PYBIND11_MODULE(_marius_host, m) {
     py::enum_<ActivationFunction>(m, "ActivationFunction").value("NONE", ActivationFunction::NONE).value("RELU", ActivationFunction::RELU).value("SIGMOID", ActivationFunction::SIGMOID);
     py::class_<GeneralEncoder, std::shared_ptr<GeneralEncoder>>(m, "GeneralEncoder")
         .def(py::init<>())
+        .def(py::init([](int output_dim, bool bias, ActivationFunction act, torch::Device dev) { return std::make_shared<GeneralEncoder>(output_dim, bias, act, dev); }),
+             py::arg("output_dim"), py::arg("bias"), py::arg("activation"), py::arg("device"))
         .def(py::init<int, bool, ActivationFunction, torch::Device, torch::Tensor>(), py::arg("output_dim"), py::arg("bias"), py::arg("activation"), py::arg("device"),
-             py::arg("bias_init") = torch::Tensor())
+             py::arg("bias_init"))
         .def("forward", &GeneralEncoder::forward, py::arg("embeddings"))
         .def("backward", &GeneralEncoder::backward, py::arg("grad_encoded"), py::arg("encoded"))
         .def("has_post_hook", &GeneralEncoder::has_post_hook)

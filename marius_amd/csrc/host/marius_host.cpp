@@ -943,7 +943,9 @@ Tensor GeneralEncoder::backward(Tensor grad_encoded, Tensor encoded) {
 
 void Model::set_encoder(shared_ptr<GeneralEncoder> encoder) {
     encoder_ = encoder;
-    if (encoder_) replace_module("encoder", encoder_);
+    if (!encoder_) return;
+    if (named_children().contains("encoder")) replace_module("encoder", encoder_);
+    else register_module("encoder", encoder_);
 }
 
 static shared_ptr<EdgeDecoder> as_edge_decoder(shared_ptr<Decoder> d) {
@@ -2165,12 +2167,81 @@ shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
     count_ = torch::empty({1}, i64(dev));  // (written by the sort's emit launch — or its empty-input launch — before anything reads it: no zero fill)
     const size_t wsb = marius_sort_unique_workspace_bytes(L);
     if (!sort_ws_.defined() || (size_t)sort_ws_.numel() < wsb) sort_ws_ = torch::zeros({(int64_t)wsb}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));  // zeroed: the sort's control block
-    mcheck(marius_assemble_ids(ip(edges), B, cols, ip(batch->src_neg_indices_), ip(batch->dst_neg_indices_), CN, ip(all_ids_), st));
-    mcheck(marius_sort_unique(ip(all_ids_), L, key_bits_, ip(uniq_), ip(inverse_), perm_.data_ptr<int32_t>(), seg_.data_ptr<int32_t>(), ip(count_),
-                              sort_ws_.data_ptr(), (size_t)sort_ws_.numel(), st));
     batch->global_edges_ = edges;
     batch->edges_ = torch::empty({B, cols}, i64(dev));
-    mcheck(marius_remap_edges(ip(edges), ip(inverse_), B, cols, ip(batch->edges_), st));
+    const bool plan = train_ && (run_ahead_ || plan_ahead_);  // the fused update's index work, done here (this stream runs a step ahead of the gradients)
+    const bool rels = train_ && cols == 3 && num_relations_ > 0;  // index_select backward into [R, d] wants the relation ids grouped: sort them here
+    if (plan) batch->occ_plan_ = torch::empty({(int64_t)marius_segment_plan_bytes(L)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+    Tensor rel_ids;
+    if (rels) {
+        batch->rel_uniq_ = torch::empty({B}, i64(dev));
+        batch->rel_inverse_ = torch::empty({B}, i64(dev));
+        batch->rel_perm_ = torch::empty({B}, i32(dev));
+        batch->rel_seg_ = torch::empty({B + 1}, i32(dev));
+        batch->rel_count_ = torch::empty({1}, i64(dev));
+        if (plan) batch->rel_plan_ = torch::empty({(int64_t)marius_segment_plan_bytes(B)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+        const size_t wsr = marius_sort_unique_workspace_bytes(B);  // its own workspace: the fused launch works on both lists at once
+        if (!sort_ws_rel_.defined() || (size_t)sort_ws_rel_.numel() < wsr) sort_ws_rel_ = torch::zeros({(int64_t)wsr}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+    }
+    // ONE persistent launch for the whole chain of both id lists (marius_prepare_maps: ids assembled, unique maps, batch-local edges, segment
+    // plans); the separate launches (MARIUS_MAPS=unfused, or a list outside the fused launch's range) compute the same bits
+    marius_map_job jobs[2] = {};
+    jobs[0].ids_out = ip(all_ids_);
+    jobs[0].edges = ip(edges);
+    jobs[0].src_neg = ip(batch->src_neg_indices_);
+    jobs[0].dst_neg = ip(batch->dst_neg_indices_);
+    jobs[0].B = B;
+    jobs[0].CN = CN;
+    jobs[0].n = L;
+    jobs[0].edge_cols = cols;
+    jobs[0].col = -1;
+    jobs[0].key_bits = key_bits_;
+    jobs[0].uniq = ip(uniq_);
+    jobs[0].inverse = ip(inverse_);
+    jobs[0].perm = perm_.data_ptr<int32_t>();
+    jobs[0].seg_offsets = seg_.data_ptr<int32_t>();
+    jobs[0].num_unique_dev = ip(count_);
+    jobs[0].plan = plan ? batch->occ_plan_.data_ptr() : nullptr;
+    jobs[0].edges_out = ip(batch->edges_);
+    jobs[0].workspace = sort_ws_.data_ptr();
+    jobs[0].workspace_bytes = (size_t)sort_ws_.numel();
+    if (rels) {
+        rel_ids = torch::empty({B}, i64(dev));
+        jobs[1].ids_out = ip(rel_ids);
+        jobs[1].edges = ip(edges);
+        jobs[1].B = B;
+        jobs[1].n = B;
+        jobs[1].edge_cols = cols;
+        jobs[1].col = 1;
+        jobs[1].key_bits = key_bits_for(num_relations_);
+        jobs[1].uniq = ip(batch->rel_uniq_);
+        jobs[1].inverse = ip(batch->rel_inverse_);
+        jobs[1].perm = batch->rel_perm_.data_ptr<int32_t>();
+        jobs[1].seg_offsets = batch->rel_seg_.data_ptr<int32_t>();
+        jobs[1].num_unique_dev = ip(batch->rel_count_);
+        jobs[1].plan = plan ? batch->rel_plan_.data_ptr() : nullptr;
+        jobs[1].workspace = sort_ws_rel_.data_ptr();
+        jobs[1].workspace_bytes = (size_t)sort_ws_rel_.numel();
+    }
+    const int njobs = rels ? 2 : 1;
+    if (marius_prepare_maps_supported(jobs, njobs)) {
+        mcheck(marius_prepare_maps(jobs, njobs, st));
+    } else {
+        mcheck(marius_assemble_ids(ip(edges), B, cols, ip(batch->src_neg_indices_), ip(batch->dst_neg_indices_), CN, ip(all_ids_), st));
+        mcheck(marius_sort_unique(ip(all_ids_), L, key_bits_, ip(uniq_), ip(inverse_), perm_.data_ptr<int32_t>(), seg_.data_ptr<int32_t>(), ip(count_),
+                                  sort_ws_.data_ptr(), (size_t)sort_ws_.numel(), st));
+        mcheck(marius_remap_edges(ip(edges), ip(inverse_), B, cols, ip(batch->edges_), st));
+        if (plan) mcheck(marius_segment_plan(perm_.data_ptr<int32_t>(), ip(inverse_), seg_.data_ptr<int32_t>(), ip(uniq_), L, batch->occ_plan_.data_ptr(), st));
+        if (rels) {
+            rel_ids = edges.select(1, 1).contiguous();
+            mcheck(marius_sort_unique(ip(rel_ids), B, key_bits_for(num_relations_), ip(batch->rel_uniq_), ip(batch->rel_inverse_),
+                                      batch->rel_perm_.data_ptr<int32_t>(), batch->rel_seg_.data_ptr<int32_t>(), ip(batch->rel_count_), sort_ws_rel_.data_ptr(),
+                                      (size_t)sort_ws_rel_.numel(), st));
+            if (plan)
+                mcheck(marius_segment_plan(batch->rel_perm_.data_ptr<int32_t>(), ip(batch->rel_inverse_), batch->rel_seg_.data_ptr<int32_t>(), ip(batch->rel_uniq_), B,
+                                           batch->rel_plan_.data_ptr(), st));
+        }
+    }
     batch->src_neg_indices_mapping_ = inverse_.narrow(0, 2 * B, CN).view(batch->src_neg_indices_.sizes());
     batch->dst_neg_indices_mapping_ = inverse_.narrow(0, 2 * B + CN, CN).view(batch->dst_neg_indices_.sizes());
     // exact_unique: the reference's tensor [U] (one 8-byte D2H copy); otherwise capacity-sized with a zero tail (no host sync)
@@ -2180,26 +2251,6 @@ shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
     batch->occ_inverse_ = inverse_;
     batch->occ_seg_offsets_ = seg_;
     batch->num_unique_dev_ = count_;
-    if (train_ && (run_ahead_ || plan_ahead_)) {  // the fused update's index work, done here (this stream runs a step ahead of the gradients)
-        batch->occ_plan_ = torch::empty({(int64_t)marius_segment_plan_bytes(L)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
-        mcheck(marius_segment_plan(perm_.data_ptr<int32_t>(), ip(inverse_), seg_.data_ptr<int32_t>(), ip(uniq_), L, batch->occ_plan_.data_ptr(), st));
-    }
-    if (train_ && cols == 3 && num_relations_ > 0) {  // index_select backward into [R, d] wants the relation ids grouped: sort them here
-        Tensor rel_ids = edges.select(1, 1).contiguous();
-        batch->rel_uniq_ = torch::empty({B}, i64(dev));
-        batch->rel_inverse_ = torch::empty({B}, i64(dev));
-        batch->rel_perm_ = torch::empty({B}, i32(dev));
-        batch->rel_seg_ = torch::empty({B + 1}, i32(dev));
-        batch->rel_count_ = torch::empty({1}, i64(dev));
-        mcheck(marius_sort_unique(ip(rel_ids), B, key_bits_for(num_relations_), ip(batch->rel_uniq_), ip(batch->rel_inverse_),
-                                  batch->rel_perm_.data_ptr<int32_t>(), batch->rel_seg_.data_ptr<int32_t>(), ip(batch->rel_count_), sort_ws_.data_ptr(),
-                                  (size_t)sort_ws_.numel(), st));
-        if (run_ahead_ || plan_ahead_) {
-            batch->rel_plan_ = torch::empty({(int64_t)marius_segment_plan_bytes(B)}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
-            mcheck(marius_segment_plan(batch->rel_perm_.data_ptr<int32_t>(), ip(batch->rel_inverse_), batch->rel_seg_.data_ptr<int32_t>(), ip(batch->rel_uniq_), B,
-                                       batch->rel_plan_.data_ptr(), st));
-        }
-    }
     return batch;
 }
 

@@ -595,7 +595,7 @@ class DataLoader {
     int64_t batches_left_ = 0, batch_id_ = 0, total_batches_ = 0;
     Tensor active_perm_;  // device int64 permutation of the epoch
     // unique-map scratch (capacity-sized)
-    Tensor all_ids_, uniq_, inverse_, perm_, seg_, count_, sort_ws_;
+    Tensor all_ids_, uniq_, inverse_, perm_, seg_, count_, sort_ws_, sort_ws_rel_;  // (two sort workspaces: the fused map launch works on the node ids and the relation ids at once)
     int key_bits_ = 63;
     // run-ahead: getBatch() hands out a batch prepared on the loader stream while the previous step was computing, then starts the
     // next one.  Preparation (edge slice, negatives, map_tensors, relation-id sort) never reads the tables and consumes the generator

@@ -33,6 +33,8 @@ struct KernelEnv {
     bool flash_tail4_off;   // MARIUS_FLASH_TAIL4=0: d = 36 / 68 / 100 keep a k-step of their own for the last four columns (round-4 record layout)
     bool seg_fused_fixup_off, seg_group_off;  // MARIUS_SEG_FUSED_FIXUP=0, MARIUS_SEG_GROUP=0
     bool sort_rocprim;    // MARIUS_SORT=rocprim
+    bool maps_unfused;    // MARIUS_MAPS=unfused: the batch preparation as separate launches (assemble, sort passes, emit, remap, plan) — A/B runs, tests of both forms
+    int mt_threads;       // MARIUS_MT_THREADS: workgroup size of the MT19937 fill (64 / 128 / 256; 0 = default) — A/B runs
     int sync_launch;      // MARIUS_SYNC_LAUNCH
 };
 const KernelEnv& kernel_env();

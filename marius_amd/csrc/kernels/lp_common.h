@@ -175,12 +175,13 @@ bool flash_applicable(const marius_lp_desc* desc, const LpDims& D);
 size_t flash_adjrec_bytes(const LpDims& D);
 size_t flash_negrec_bytes(const LpDims& D);
 size_t flash_part_bytes(const LpDims& D);
+const float* flash_part_weights(const LpDims& D, const float2* part);  // [2][ndir Bp] g exp(m_k - lse), written by flash_merge
 // adj_packed: lp_prep2_kernel already wrote the adj records (and zeroed dadj); otherwise they are packed from `adj` here and dadj_zero
 // (if given) is zeroed.  The negatives' gocc rows are always zeroed by the negative pack kernel.
 bool flash_fused();  // forward statistics + dAdj in one sweep (default); false: MARIUS_FLASH_FUSED=0
 int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj, char* adjrec, char* negrec, float2* part, float* S, bool adj_packed,
                   float* gocc, const int64_t negocc_off[2], float* dadj_zero, const float* pos, float* dadj, float* dadj2, hipStream_t st);
-int flash_merge(const LpDims& D, const float2* part, const float* pos, float* lse, float* rowloss, float* dpos, float* blocksum, char* adjrec,
+int flash_merge(const LpDims& D, const float2* part, const float* pos, float* lse, float* rowloss, float* dpos, float* blocksum, char* adjrec, bool f16,
                 hipStream_t st);
 int flash_backward(const marius_lp_desc* desc, const LpDims& D, char* adjrec, char* negrec, float* dadj, float* gocc, const int64_t negocc_off[2],
                    const float2* part, bool filtered, float* S, hipStream_t st);

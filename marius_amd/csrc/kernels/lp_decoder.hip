@@ -925,6 +925,7 @@ struct EdgeBwdArgs {
     // flash path, fused form (dadj2 != nullptr): dadj / dadj2 hold the UNNORMALISED partials of a row's (at most two) contributors, `part` their
     // statistics (mref, sum V) [2][ndir Bp]: dL/dadj = g (exp(m0 - lse) O0 + exp(m1 - lse) O1).  keep_dadj: store that back into dadj.
     const float* dadj2;
+    const float* pw;   // [2][ndir Bp] the contributors' weights g exp(m_k - lse) (flash_merge_kernel, float64)
     const float2* part;
     const float* lse;
     float gscale;
@@ -1001,9 +1002,9 @@ __global__ __launch_bounds__(256) void lp_edge_bwd_kernel(EdgeBwdArgs a) {
                 float g = a.dadj[rowoff + cc];
                 if (a.dadj2) {
                     const int64_t row = (int64_t)dir * D.Bp + i, prows = (int64_t)D.ndir * D.Bp;
-                    const float2 p0 = a.part[row], p1 = a.part[prows + row];
-                    g *= a.gscale * __expf(p0.x - a.lse[row]);
-                    if (p1.y > 0.f) g += a.gscale * __expf(p1.x - a.lse[row]) * a.dadj2[rowoff + cc];
+                    const float2 p1 = a.part[prows + row];
+                    g *= a.pw[row];
+                    if (p1.y > 0.f) g += a.pw[prows + row] * a.dadj2[rowoff + cc];
                     if (a.keep_dadj) const_cast<float*>(a.dadj)[rowoff + cc] = g;
                 }
                 if (D.cmp == MARIUS_CMP_L2) {
@@ -1083,13 +1084,12 @@ __global__ __launch_bounds__(256) void lp_edge_bwd2_kernel(EdgeBwdArgs a) {
         ld4(a.dadj + rowoff, dv[dir]);
         if (a.dadj2) {  // fused flash sweep: combine the contributors' unnormalised partials
             const int64_t row = (int64_t)dir * D.Bp + i, prows = (int64_t)D.ndir * D.Bp;
-            const float2 p0 = a.part[row], p1 = a.part[prows + row];
-            const float l_ = a.lse[row];
-            const float c0_ = a.gscale * __expf(p0.x - l_);
+            const float2 p1 = a.part[prows + row];
+            const float c0_ = a.pw[row];
 #pragma unroll
             for (int k = 0; k < 4; ++k) dv[dir][k] *= c0_;
             if (p1.y > 0.f) {
-                const float c1_ = a.gscale * __expf(p1.x - l_);
+                const float c1_ = a.pw[prows + row];
                 float o1[4];
                 ld4(a.dadj2 + rowoff, o1);
 #pragma unroll
@@ -1505,7 +1505,7 @@ extern "C" int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout
             const int64_t bpd = cdiv(D.Bp, 256);
             float* blocksum = (float*)(ws + L->aux);
             rc = flash_merge(D, (const float2*)(ws + L->fpart), (const float*)(ws + L->pos[0]), (float*)(ws + L->lse[0]), (float*)(ws + L->rowloss[0]),
-                             dpos, blocksum, ws + L->adjrec, st);
+                             dpos, blocksum, ws + L->adjrec, desc->absmax != nullptr && !kernel_env().flash_f16_off, st);
             if (rc) return rc;
             lp_loss_reduce_blocks_kernel<<<dim3(1), dim3(256), 0, st>>>(blocksum, bpd, D.ndir, D.gscale, (float*)(ws + L->loss));
             return check_launch("lp_loss_reduce");
@@ -1636,12 +1636,14 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     ea.dadj = ga.dadj;
     ea.dadj2 = nullptr;
     ea.part = nullptr;
+    ea.pw = nullptr;
     ea.lse = nullptr;
     ea.gscale = D.gscale;
     ea.keep_dadj = 0;
     if (L->flash && flash_fused() && !flash_chunked(D.d)) {  // (rows wider than 128 take the stored-score launches: dadj is final there)
         ea.dadj2 = ga.dadj + (size_t)D.ndir * D.Bp * D.d_ld;
         ea.part = (const float2*)(ws + L->fpart);
+        ea.pw = flash_part_weights(D, ea.part);
         ea.lse = (const float*)(ws + L->lse[0]);
         ea.keep_dadj = (desc->flags & MARIUS_LP_KEEP_DADJ) ? 1 : 0;
     }

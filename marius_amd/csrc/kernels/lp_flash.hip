@@ -540,7 +540,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
 
     // stationary fragments (B operand of the S-MFMA): lane holds X[x = l31][k = 16 ks + 8 h .. + 7], hi and lo
     v8bf xh[KS], xl[KS];
-    float lsec_x = 0.f;     // DADJ: lsec of the lane's own adj row
+    float2 lsec_x = make_float2(0.f, 0.f);  // DADJ: (hi, lo) of lsec - VSH of the lane's own adj row (flash_merge_kernel)
     v16f out[BASE == FLASH_FWD ? 1 : NCT];
     float m2 = -INFINITY, lsum = 0.f;  // FWD: running max of S log2(e) and sum of exp2 over this lane's columns
     float mref = 0.f;                  // FDADJ: reference of the lane's own row x = l31 (log2 units; the same in both lane halves); lsum: this lane's share of sum V
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
             xh[KS - 1] = xa.v;
             xl[KS - 1] = xb.v;
         }
-        if (BASE == FLASH_DADJ) lsec_x = *reinterpret_cast<const float*>(r + LSEC);
+        if (BASE == FLASH_DADJ) lsec_x = *reinterpret_cast<const float2*>(r + LSEC);
         if (MODE == FLASH_FDADJ) {  // the row's positive score is a term of the same softmax: start from it (rows past Xrows are never stored)
             mref = (x < a.Xrows) ? a.pos[(int64_t)dir * a.Bp + (int64_t)c_ * a.Bc + x] * FL_LOG2E : 0.f;
             lsum = 0.f;
@@ -975,12 +975,13 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int r_ = 8 * s_ + e + q;
-                        float ls;
-                        if (BASE == FLASH_DADJ) ls = lsec_x;
-                        else if (MODE == FLASH_FDADJ) ls = mref;
-                        else ls = *reinterpret_cast<const float*>(T + (16 * s_ + fl_rho(8 * h + e + q)) * P + LSEC);
-                        w2[q] = __builtin_amdgcn_exp2f(fmaf(t[r_], c_s, VSH - ls));
-                        if (MODE == FLASH_FDADJ) lsum += w2[q];
+                        if constexpr (MODE == FLASH_FDADJ) {  // against the row's running reference (the same rounding in the sum and in the partial: it cancels)
+                            w2[q] = __builtin_amdgcn_exp2f(fmaf(t[r_], c_s, VSH - mref));
+                            lsum += w2[q];
+                        } else {  // against lsec - VSH, carried as (hi, lo): its fp32 representation error would be a relative error of V
+                            const float2 ls = BASE == FLASH_DADJ ? lsec_x : *reinterpret_cast<const float2*>(T + (16 * s_ + fl_rho(8 * h + e + q)) * P + LSEC);
+                            w2[q] = __builtin_amdgcn_exp2f(fmaf(t[r_], c_s, -ls.x) - ls.y);
+                        }
                     }
                     const unsigned hi = fl_cvt16x2<F16>(w2[0], w2[1]);
                     wh[s_].u[e >> 1] = hi;
@@ -1005,11 +1006,17 @@ __global__ __launch_bounds__(FL_NT, fl_wg_per_cu_ks(MODE, KS)) void flash_kernel
 }
 
 // ---------------------------------------------------------------------------------------------------------------- merge
-// lse = log(e^pos + sum over the (at most two) partials), row loss, dL/dpos, per-block loss sums; patches lsec into the adj records.
+// lse = log(e^pos + sum over the (at most two) partials), row loss, dL/dpos, per-block loss sums; the contributors' weights g exp(m_k - lse);
+// patches lsec into the adj records.
+// Round 6: in FLOAT64, and lsec as a (hi, lo) float pair.  Found by the arithmetic check's trained-table input (flat softmax over 1001 scores
+// near zero: lse ~ 6.9, lsec ~ 10): V = exp2(S log2(e) - lsec) inherits the ABSOLUTE error of lsec as a RELATIVE error, and an fp32 lsec of
+// magnitude 10 carries 4.8e-7 of representation error on top of the fp32 roundings of m + log(sum) — 3e-7 RMS on every gradient entry, three
+// times the reference's own fp32 evaluation, while the scores themselves were twice as accurate as the reference's.  100,000 rows of a few
+// double-precision transcendentals cost nothing next to the launches either side.
 __global__ __launch_bounds__(256) void flash_merge_kernel(const float2* __restrict__ part, const float* __restrict__ pos, int64_t rows, int64_t Bp,
                                                           int Bc, int C, int XR, int KP, float* __restrict__ lse, float* __restrict__ rowloss,
                                                           float* __restrict__ dpos, float gscale, float* __restrict__ blocksum, char* __restrict__ adjrec,
-                                                          int nsets, int64_t set_bytes, int P) {
+                                                          int nsets, int64_t set_bytes, int P, float* __restrict__ weights, float vsh) {
     __shared__ float red[256];
     const int64_t bpd = (Bp + 255) / 256;
     const int64_t dir = blockIdx.x / bpd, blk = blockIdx.x - dir * bpd;
@@ -1017,21 +1024,29 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(const float2* __restri
     float mine = 0.f;
     if (r < Bp) {
         const int64_t row = dir * Bp + r;
-        const float p = pos[row];
+        const double p = (double)pos[row];
         const float2 v0 = part[row], v1 = part[rows + row];
-        const float m = fmaxf(p, fmaxf(v0.x, v1.x));
-        const float sneg = v0.y * __expf(v0.x - m) + v1.y * __expf(v1.x - m);
-        const float sum = __expf(p - m) + sneg;
-        const float l = m + __logf(sum);
-        lse[row] = l;
-        rowloss[row] = l - p;
+        double m = p;
+        if (v0.y > 0.f) m = fmax(m, (double)v0.x);
+        if (v1.y > 0.f) m = fmax(m, (double)v1.x);
+        const double e0 = v0.y > 0.f ? (double)v0.y * exp((double)v0.x - m) : 0.0, e1 = v1.y > 0.f ? (double)v1.y * exp((double)v1.x - m) : 0.0;
+        const double sum = exp(p - m) + e0 + e1;
+        const double l = m + log(sum);
+        lse[row] = (float)l;
+        rowloss[row] = (float)(l - p);
         // dL/dpos = p_pos - 1 = -(sum of the negatives' probabilities): the second form has no cancellation when p_pos -> 1
-        dpos[row] = -(sneg / sum) * gscale;
-        mine = l - p;
+        dpos[row] = (float)(-((e0 + e1) / sum) * (double)gscale);
+        mine = (float)(l - p);
+        // dL/dadj = w0 O0 + w1 O1 over the contributors' unnormalised partials O_k = sum_j exp(s_j - m_k) neg_j:  w_k = g exp(m_k - lse) = g exp(m_k - m) / sum
+        weights[row] = v0.y > 0.f ? (float)((double)gscale * exp((double)v0.x - m) / sum) : 0.f;
+        weights[rows + row] = v1.y > 0.f ? (float)((double)gscale * exp((double)v1.x - m) / sum) : 0.f;
         const int64_t c = r / Bc;
         const int x = (int)(r - c * Bc);
+        // lsec - VSH (the binades V is formed up by: flash_kernel) as a float pair: the kernels compute exp2(fma(S, c, -hi) - lo)
+        const double ls = l * 1.4426950408889634074 - log2((double)gscale) - (double)vsh;
+        const float hi = (float)ls, lo = (float)(ls - (double)hi);
         for (int q = 0; q < nsets; ++q)  // every column chunk's record set carries the row's lsec (the 16 bytes that close a record)
-            *reinterpret_cast<float*>(adjrec + q * set_bytes + ((dir * C + c) * XR + fl_rho(x)) * (int64_t)P + P - 16) = l * FL_LOG2E - log2f(gscale);
+            *reinterpret_cast<float2*>(adjrec + q * set_bytes + ((dir * C + c) * XR + fl_rho(x)) * (int64_t)P + P - 16) = make_float2(hi, lo);
     }
     red[threadIdx.x] = mine;
     __syncthreads();
@@ -1115,7 +1130,11 @@ bool flash_applicable(const marius_lp_desc* desc, const LpDims& D) {
 
 size_t flash_adjrec_bytes(const LpDims& D) { return fl_adjset_bytes(D) * flash_chunks(D.d) + 32768; }   // one record set per column chunk
 size_t flash_negrec_bytes(const LpDims& D) { return fl_negset_bytes(D) * flash_chunks(D.d) + 32768; }
-static size_t fl_stats_bytes(const LpDims& D) { return ((size_t)2 * D.ndir * D.Bp * sizeof(float2) + 255) / 256 * 256; }
+// [2][ndir Bp] (mref, sum V) pairs of a row's (at most two) contributors, then [2][ndir Bp] floats: the weights g exp(m_k - lse) the merge kernel
+// derives from them in float64 (what the edge backward multiplies the unnormalised dAdj partials with)
+static size_t fl_pairs_bytes(const LpDims& D) { return (size_t)2 * D.ndir * D.Bp * sizeof(float2); }
+static size_t fl_stats_bytes(const LpDims& D) { return (fl_pairs_bytes(D) + (size_t)2 * D.ndir * D.Bp * sizeof(float) + 255) / 256 * 256; }
+const float* flash_part_weights(const LpDims& D, const float2* part) { return (const float*)((const char*)part + fl_pairs_bytes(D)); }
 // [statistics | filter index (offsets of both orientations, entries of both orientations)]
 size_t flash_part_bytes(const LpDims& D) { return fl_stats_bytes(D) + fl_filter_dims(D).bytes; }
 // forward statistics and dAdj are one sweep (FLASH_FDADJ); the two-launch form of round 2 lost its A/B run (0.726 vs 0.653 ms per step) and is gone
@@ -1351,11 +1370,12 @@ int flash_forward(const marius_lp_desc* desc, const LpDims& D, const float* adj,
 }
 
 int flash_merge(const LpDims& D, const float2* part, const float* pos, float* lse, float* rowloss, float* dpos, float* blocksum, char* adjrec,
-                hipStream_t st) {
+                bool f16, hipStream_t st) {
     const int64_t bpd = cdiv(D.Bp, 256);
     const int ks = fl_ks(D.d);
     flash_merge_kernel<<<dim3((unsigned)(bpd * D.ndir)), dim3(256), 0, st>>>(part, pos, D.Bp * D.ndir, D.Bp, D.Bc, D.C, (D.Bc + 31) / 32 * 32, 16 * ks, lse,
-                                                                            rowloss, dpos, D.gscale, blocksum, adjrec, flash_chunks(D.d), (int64_t)fl_adjset_bytes(D), fl_pitch_d(D.d));
+                                                                            rowloss, dpos, D.gscale, blocksum, adjrec, flash_chunks(D.d), (int64_t)fl_adjset_bytes(D), fl_pitch_d(D.d),
+                                                                            const_cast<float*>(flash_part_weights(D, part)), f16 ? 14.f : 0.f);
     return check_launch("flash_merge");
 }
 

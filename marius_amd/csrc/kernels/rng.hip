@@ -27,11 +27,15 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-__global__ __launch_bounds__(256) void mt19937_fill_kernel(uint32_t* __restrict__ state, uint32_t* __restrict__ out,
-                                                           int64_t n) {
-    __shared__ uint32_t buf[2][MT_N];
+// T threads.  T = 64 (one wave, round 6): the three phases of a twist are ordered by the wave's own in-order LDS queue — the barrier of a
+// single-wave workgroup costs nothing — so a 624-word block is three dependent LDS round trips of 4 / 4 / 3 elements per lane instead of
+// three 4-wave barriers; 256 threads is the round 1-5 form.
+template <int T>
+__global__ __launch_bounds__(T) void mt19937_fill_kernel(uint32_t* __restrict__ state, uint32_t* __restrict__ out, int64_t n) {
+    __shared__ uint32_t buf[2][MT_N + 8];
+    constexpr int P = MT_N - MT_M;  // 227
     const int tid = threadIdx.x;
-    for (int i = tid; i < MT_N; i += 256) buf[0][i] = state[i];
+    for (int i = tid; i < MT_N; i += T) buf[0][i] = state[i];
     int idx = (int)state[MT_N];
     int cur = 0;
     __syncthreads();
@@ -41,19 +45,22 @@ __global__ __launch_bounds__(256) void mt19937_fill_kernel(uint32_t* __restrict_
             uint32_t* o = buf[cur];
             uint32_t* w = buf[cur ^ 1];
             // phase A: i in [0, 227): new[i] = old[i+397] ^ f(old[i], old[i+1])
-            if (tid < MT_N - MT_M) w[tid] = mt_mix(o[tid], o[tid + 1], o[tid + MT_M]);
+#pragma unroll
+            for (int i = tid; i < P; i += T) w[i] = mt_mix(o[i], o[i + 1], o[i + MT_M]);
             __syncthreads();
             // phase B: i in [227, 454): new[i] = new[i-227] ^ f(old[i], old[i+1])
-            if (tid < MT_N - MT_M) {
-                int i = tid + (MT_N - MT_M);
-                w[i] = mt_mix(o[i], o[i + 1], w[i - (MT_N - MT_M)]);
+#pragma unroll
+            for (int k = tid; k < P; k += T) {
+                const int i = k + P;
+                w[i] = mt_mix(o[i], o[i + 1], w[k]);
             }
             __syncthreads();
             // phase C: i in [454, 624): new[i] = new[i-227] ^ f(old[i], i == 623 ? new[0] : old[i+1])
-            if (tid < MT_N - 2 * (MT_N - MT_M)) {
-                int i = tid + 2 * (MT_N - MT_M);
-                uint32_t nxt = (i == MT_N - 1) ? w[0] : o[i + 1];
-                w[i] = mt_mix(o[i], nxt, w[i - (MT_N - MT_M)]);
+#pragma unroll
+            for (int k = tid; k < MT_N - 2 * P; k += T) {
+                const int i = k + 2 * P;
+                const uint32_t nxt = (i == MT_N - 1) ? w[0] : o[i + 1];
+                w[i] = mt_mix(o[i], nxt, w[i - P]);
             }
             __syncthreads();
             cur ^= 1;
@@ -63,13 +70,13 @@ __global__ __launch_bounds__(256) void mt19937_fill_kernel(uint32_t* __restrict_
         int take = MT_N - idx;
         if ((int64_t)take > left) take = (int)left;
         const uint32_t* s = buf[cur];
-        for (int i = tid; i < take; i += 256) out[produced + i] = mt_temper(s[idx + i]);
+        for (int i = tid; i < take; i += T) out[produced + i] = mt_temper(s[idx + i]);
         idx += take;
         produced += take;
         // the next twist writes buf[cur^1] only, and reads buf[cur]: no hazard with the tempering reads above
     }
     __syncthreads();
-    for (int i = tid; i < MT_N; i += 256) state[i] = buf[cur][i];
+    for (int i = tid; i < MT_N; i += T) state[i] = buf[cur][i];
     if (tid == 0) state[MT_N] = (uint32_t)idx;
 }
 
@@ -259,7 +266,10 @@ extern "C" int marius_mt19937_fill(uint32_t* state_dev, uint32_t* out_dev, int64
     MARIUS_REQUIRE(state_dev && n >= 0 && (n == 0 || out_dev), "mt19937_fill: bad arguments");
     if (n == 0) return MARIUS_OK;
     ProfScope ps(PROF_MT_FILL, as_stream(stream));
-    mt19937_fill_kernel<<<dim3(1), dim3(256), 0, as_stream(stream)>>>(state_dev, out_dev, n);
+    const int t = kernel_env().mt_threads;
+    if (t == 256) mt19937_fill_kernel<256><<<dim3(1), dim3(256), 0, as_stream(stream)>>>(state_dev, out_dev, n);
+    else if (t == 128) mt19937_fill_kernel<128><<<dim3(1), dim3(128), 0, as_stream(stream)>>>(state_dev, out_dev, n);
+    else mt19937_fill_kernel<64><<<dim3(1), dim3(64), 0, as_stream(stream)>>>(state_dev, out_dev, n);
     return check_launch("mt19937_fill");
 }
 

@@ -11,10 +11,11 @@
 // a segment that crosses chunk boundaries leaves per-chunk partials in `carry` and is finished by the wave of the
 // chunk where it starts (second launch).  Every output row has exactly one writer: no atomics.
 #include "common.h"
+#include "seg_plan.h"
 
 namespace marius {
 
-constexpr int SEG_R = 32;      // sorted positions per wave
+// (SEG_R = 32 sorted positions per wave: seg_plan.h)
 // (tools/build_variant.py + tools/ab_variants.sh time variants of these constants on one box.  Round 4, Freebase86m step: 8 row loads in flight per
 // lane 151 us for the reduce + update pair, 4 -> 144, 2 -> 141, 1 -> 141, 16 -> 167: most segments are singletons that are skipped, and the batch's
 // registers cost occupancy; Adagrad rows per thread 8 -> 200 us, 4 / 2 / 1 equal once a row's pieces map one to one onto lanes; with the endpoint
@@ -280,35 +281,13 @@ __global__ __launch_bounds__(256) void seg_fixup_kernel(SegArgs a, Apply apply) 
     seg_fixup_body<VEC, NIT, Apply>(a, apply, (int64_t)blockIdx.x);
 }
 
-// ---- plan: everything the three kernels derive from perm / inverse / seg_offsets alone
-// row_plan [n]: per unique row u < U {table row id (int64 split in two ints), occurrence row of a singleton or -1, segment crosses a chunk boundary}
+// ---- plan: everything the three kernels derive from perm / inverse / seg_offsets alone (seg_plan.h: seg_plan_position)
 __global__ __launch_bounds__(256) void seg_plan_kernel(const int32_t* __restrict__ perm, const int64_t* __restrict__ inverse, const int32_t* __restrict__ seg_offsets,
-                                                       const int64_t* __restrict__ uniq, int64_t n, int4* __restrict__ pos_plan, int4* __restrict__ chunk_plan,
-                                                       int4* __restrict__ row_plan, uint8_t* __restrict__ occ_single) {
+                                                       const int64_t* __restrict__ uniq, int64_t n, SegPlanPtrs P) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int64_t U = inverse[perm[n - 1]] + 1;
-    const int64_t k0 = k / SEG_R * SEG_R, k1 = min(k0 + SEG_R, n);
-    const int p = perm[k];
-    const int u = (int)inverse[p];
-    const int s0 = seg_offsets[u], s1 = seg_offsets[u + 1];
-    // a NEGATIVE id is a padding slot, not a row (the unused slots of a fixed-capacity exchange block, exchange.hip): its positions are dead —
-    // flag 2: never loaded, never stored, whatever the form — and the segment they make up owns no fix-up and no table row
-    const bool dead = uniq[u] < 0;
-    pos_plan[k] = make_int4(p, u, (dead || (s0 >= k0 && s1 <= k1)) ? 1 : 0, dead ? 2 : ((s1 - s0 == 1) ? 1 : 0));
-    occ_single[p] = (!dead && s1 - s0 == 1) ? 1 : 0;  // the same flag by occurrence row (marius_lp_desc.upd_occ_single)
-    if (k == k1 - 1) {  // last position of its chunk: does the chunk own a boundary-crossing segment (the one its last position belongs to)?
-        const bool owner = !dead && (s0 >= k0) && (s1 > k1);
-        chunk_plan[k / SEG_R] = make_int4(owner ? 1 : 0, u, (s0 != k0) ? 1 : 0, (int)((s1 - 1) / SEG_R));
-    }
-    if (k < U) {  // thread k also describes unique row k
-        const int64_t id = uniq[k];
-        const int t0 = seg_offsets[k], t1 = seg_offsets[k + 1];
-        if (id < 0) row_plan[k] = make_int4(-1, -1, -1, 0);
-        else row_plan[k] = make_int4((int)(id & 0xffffffffll), (int)(id >> 32), (t1 - t0 == 1) ? perm[t0] : -1, (t0 / SEG_R != (t1 - 1) / SEG_R) ? 1 : 0);
-    } else {
-        row_plan[k] = make_int4(-1, -1, -1, 0);
-    }
+    seg_plan_position(k, n, U, perm, inverse, seg_offsets, uniq, P);
 }
 
 static inline int dpad_of(int d) { return (d + 3) / 4 * 4; }
@@ -605,10 +584,6 @@ extern "C" int marius_segment_sum_rows_planned(const float* rows, int64_t rows_l
     return segment_sum_rows_impl(rows, rows_ld, perm, inverse, seg_offsets, n, d, out_rows, out, out_ld, carry, plan, stream);
 }
 
-static inline size_t plan_pos_bytes(int64_t n) { return ((size_t)(n > 0 ? n : 1) * sizeof(int4) + 255) / 256 * 256; }
-static inline size_t plan_chunk_bytes(int64_t n) { return ((size_t)cdiv(n > 0 ? n : 1, SEG_R) * sizeof(int4) + 255) / 256 * 256; }
-
-static inline size_t plan_occ_bytes(int64_t n) { return ((size_t)(n > 0 ? n : 1) + 255) / 256 * 256; }
 // [pos_plan | chunk_plan | row_plan | occ_single]
 extern "C" size_t marius_segment_plan_bytes(int64_t n) { return 2 * plan_pos_bytes(n) + plan_chunk_bytes(n) + plan_occ_bytes(n); }
 extern "C" const uint8_t* marius_segment_plan_occ_single(const void* plan, int64_t n) {
@@ -619,10 +594,7 @@ extern "C" int marius_segment_plan(const int32_t* perm, const int64_t* inverse, 
                                    marius_stream_t stream) {
     MARIUS_REQUIRE(n >= 0 && (n == 0 || (perm && inverse && seg_offsets && uniq_ids && plan)), "segment_plan: bad arguments");
     if (n == 0) return MARIUS_OK;
-    char* p = (char*)plan;
-    seg_plan_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream)>>>(perm, inverse, seg_offsets, uniq_ids, n, (int4*)p,
-                                                                                        (int4*)(p + plan_pos_bytes(n)), (int4*)(p + plan_pos_bytes(n) + plan_chunk_bytes(n)),
-                                                                                        (uint8_t*)(p + 2 * plan_pos_bytes(n) + plan_chunk_bytes(n)));
+    seg_plan_kernel<<<dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream)>>>(perm, inverse, seg_offsets, uniq_ids, n, seg_plan_ptrs(plan, n));
     return check_launch("segment_plan");
 }
 

@@ -13,6 +13,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "common.h"
+#include "seg_plan.h"
 
 namespace marius {
 
@@ -189,13 +190,19 @@ __global__ __launch_bounds__(SW_THREADS) void rs_ghist_kernel(const uint64_t* __
 
 // pay_in == nullptr: the payload of key i is i (first pass).  ghist: this pass's global digit histogram; state: [ntiles][RS_RADIX]
 // granules of this pass (zero on entry).
-__global__ __launch_bounds__(SW_THREADS) void rs_sweep_kernel(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ pay_in, int64_t n, int shift,
-                                                              const uint32_t* __restrict__ ghist, uint32_t* __restrict__ state, uint64_t* __restrict__ keys_out,
-                                                              int32_t* __restrict__ pay_out, uint32_t* __restrict__ tile_ctr) {
-    __shared__ int32_t off[RS_RADIX];            // global position of this tile's first key of each digit
-    __shared__ int32_t cw[SW_WAVES][RS_RADIX];   // per-wave running digit counts, then per-wave bases
-    __shared__ int32_t wsum[SW_WAVES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = rs_draw_tile(tile_ctr);
+struct SweepSmem {
+    int32_t off[RS_RADIX];            // global position of this tile's first key of each digit
+    int32_t cw[SW_WAVES][RS_RADIX];   // per-wave running digit counts, then per-wave bases
+    int32_t wsum[SW_WAVES];
+};
+// one tile of one pass (SW_THREADS threads).  COHERENT: the fused launch (prepare_maps_kernel) reads ghist with an agent-scope load — it was
+// accumulated by atomics of workgroups on other XCDs inside the SAME launch
+__device__ __forceinline__ void rs_sweep_tile(SweepSmem& sm, const int tile, const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ pay_in, int64_t n, int shift,
+                                              const uint32_t* __restrict__ ghist, uint32_t* __restrict__ state, uint64_t* __restrict__ keys_out, int32_t* __restrict__ pay_out) {
+    int32_t (&off)[RS_RADIX] = sm.off;
+    int32_t (&cw)[SW_WAVES][RS_RADIX] = sm.cw;
+    int32_t (&wsum)[SW_WAVES] = sm.wsum;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t wbase_idx = (int64_t)tile * RS_TILE + (int64_t)wave * 64 * SW_ITEMS;
     uint64_t key[SW_ITEMS];
     int32_t pay[SW_ITEMS];
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(SW_THREADS) void rs_sweep_kernel(const uint64_t* __
     }
     // ---- exclusive scan of the global digit totals
     {
-        const int32_t total = (int32_t)ghist[tid];
+        const int32_t total = (int32_t)rs_poll(ghist + tid);
         int32_t x = total;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -288,19 +295,28 @@ __global__ __launch_bounds__(SW_THREADS) void rs_sweep_kernel(const uint64_t* __
     }
 }
 
+__global__ __launch_bounds__(SW_THREADS) void rs_sweep_kernel(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ pay_in, int64_t n, int shift,
+                                                              const uint32_t* __restrict__ ghist, uint32_t* __restrict__ state, uint64_t* __restrict__ keys_out,
+                                                              int32_t* __restrict__ pay_out, uint32_t* __restrict__ tile_ctr) {
+    __shared__ SweepSmem sm;
+    const int tile = rs_draw_tile(tile_ctr);
+    rs_sweep_tile(sm, tile, keys_in, pay_in, n, shift, ghist, state, keys_out, pay_out);
+}
+
 // unique index of every sorted position = heads in earlier tiles (granule hand-off) + inclusive scan inside the tile; emits uniq / inverse /
-// seg_offsets / count.  tile_state: [ntiles] granules, zero on entry.
-__global__ __launch_bounds__(RS_THREADS) void rs_emit_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ perm, int64_t n,
-                                                             uint32_t* __restrict__ tile_state, int64_t* __restrict__ uniq, int64_t* __restrict__ inverse,
-                                                             int32_t* __restrict__ seg_offsets, int64_t* __restrict__ num_unique, SortCtl* __restrict__ ctl, int my_ctr) {
-    __shared__ int32_t red[RS_WAVES], wsum[RS_WAVES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = rs_draw_tile(&ctl->ctr[my_ctr]);
-    if (tile == 0 && tid == 0) {  // last launch of a call: hand-shake word and the first launch's counter return to zero (a replay of a captured
-        ctl->ready = 0ull;        // call waits and counts again).  This launch's own counter, like those of the sweeps, is zeroed by the FIRST launch
-        ctl->ctr[0] = 0u;         // of the next call that uses the workspace (rs_ghist_kernel / merge_rank_kernel), before anything draws from it.
-    }
+// seg_offsets / count.  tile_state: [ntiles] granules, zero on entry.  THREADS threads, tiles of THREADS * EM_ITEMS positions.
+template <int THREADS>
+struct EmitSmem {
+    int32_t red[THREADS / 64], wsum[THREADS / 64];
+};
+template <int THREADS>
+__device__ __forceinline__ void rs_emit_tile(EmitSmem<THREADS>& sm, const int tile, const uint64_t* __restrict__ keys, const int32_t* __restrict__ perm, int64_t n,
+                                             uint32_t* __restrict__ tile_state, int64_t* __restrict__ uniq, int64_t* __restrict__ inverse, int32_t* __restrict__ seg_offsets,
+                                             int64_t* __restrict__ num_unique) {
+    constexpr int WAVES = THREADS / 64, TILE = THREADS * EM_ITEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // thread t owns EM_ITEMS consecutive positions: local head count, block scan of the thread sums
-    const int64_t k0 = (int64_t)tile * EM_TILE + (int64_t)tid * EM_ITEMS;
+    const int64_t k0 = (int64_t)tile * TILE + (int64_t)tid * EM_ITEMS;
     uint64_t kk[EM_ITEMS];
     int32_t pp[EM_ITEMS];
     bool head[EM_ITEMS];
@@ -321,14 +337,14 @@ __global__ __launch_bounds__(RS_THREADS) void rs_emit_kernel(const uint64_t* __r
         const int32_t y = __shfl_up(x, o, 64);
         if (lane >= o) x += y;
     }
-    if (lane == 63) wsum[wave] = x;
+    if (lane == 63) sm.wsum[wave] = x;
     __syncthreads();
     int32_t tile_total = 0;
-    for (int w = 0; w < RS_WAVES; ++w) tile_total += wsum[w];
+    for (int w = 0; w < WAVES; ++w) tile_total += sm.wsum[w];
     if (tid == 0) rs_publish(tile_state + tile, (uint32_t)tile_total);
     // heads in earlier tiles
     int32_t b = 0;
-    for (int t = tid; t < tile; t += RS_THREADS) {
+    for (int t = tid; t < tile; t += THREADS) {
         uint32_t v;
         do {
             v = rs_poll(tile_state + t);
@@ -337,12 +353,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_emit_kernel(const uint64_t* __r
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
-    if (lane == 0) red[wave] = b;
+    if (lane == 0) sm.red[wave] = b;
     __syncthreads();
     int32_t base = 0;
-    for (int w = 0; w < RS_WAVES; ++w) base += red[w];
+    for (int w = 0; w < WAVES; ++w) base += sm.red[w];
     int32_t before = base + x - mine;
-    for (int w = 0; w < wave; ++w) before += wsum[w];
+    for (int w = 0; w < wave; ++w) before += sm.wsum[w];
     int32_t u = before - 1;  // unique index of the position before this thread's first one
 #pragma unroll
     for (int r = 0; r < EM_ITEMS; ++r) {
@@ -358,6 +374,187 @@ __global__ __launch_bounds__(RS_THREADS) void rs_emit_kernel(const uint64_t* __r
                 seg_offsets[u + 1] = (int32_t)n;
                 *num_unique = (int64_t)u + 1;
             }
+        }
+    }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_emit_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ perm, int64_t n,
+                                                             uint32_t* __restrict__ tile_state, int64_t* __restrict__ uniq, int64_t* __restrict__ inverse,
+                                                             int32_t* __restrict__ seg_offsets, int64_t* __restrict__ num_unique, SortCtl* __restrict__ ctl, int my_ctr) {
+    __shared__ EmitSmem<RS_THREADS> sm;
+    const int tile = rs_draw_tile(&ctl->ctr[my_ctr]);
+    if (tile == 0 && threadIdx.x == 0) {  // last launch of a call: hand-shake word and the first launch's counter return to zero (a replay of a captured
+        ctl->ready = 0ull;                // call waits and counts again).  This launch's own counter, like those of the sweeps, is zeroed by the FIRST launch
+        ctl->ctr[0] = 0u;                 // of the next call that uses the workspace (rs_ghist_kernel / merge_rank_kernel), before anything draws from it.
+    }
+    rs_emit_tile<RS_THREADS>(sm, tile, keys, perm, n, tile_state, uniq, inverse, seg_offsets, num_unique);
+}
+
+// ------------------------------------------------------------------------------------------------ one launch for the whole map chain
+// marius_prepare_maps (round 6; VERDICT r3-r5: "one persistent sort + plan launch"): assemble ids -> digit histograms -> radix passes -> run heads /
+// unique map -> batch-local edges + segment plan, for up to two id lists at once (the batch's node ids and its relation ids), in ONE persistent
+// launch instead of 1 + 5 + 1 + 1 (+ 1 + 4 + 1) dependent launches on the preparation stream.
+//
+// Work = a queue of items (phase, tile), phases in dependency order, the two jobs' phases interleaved.  Every workgroup draws the next item from
+// one counter; before it starts an item it waits until the phase the item depends on (the previous phase of the same job) has COMPLETED — a
+// per-phase completion counter — with an agent-scope acquire after the wait and an agent-scope release before every completion (the fence
+// pair a grid barrier is made of: L2 write-back / invalidate across the XCDs).  No co-residency is assumed anywhere: items are drawn in
+// order, so whatever an item waits for — the earlier phase, and inside a pass the granules of earlier tiles — has already been DRAWN by a
+// workgroup that is running; a launch with a single workgroup completes (slowly).  The last workgroup to leave puts the control block back
+// to zero (replay, reuse).
+constexpr int PM_MAX_JOBS = 2, PM_MAX_PHASES = 16;
+enum { PM_INIT = 0, PM_HIST = 1, PM_SWEEP = 2, PM_EMIT = 3, PM_PLAN = 4 };
+constexpr int PM_EM_TILE = SW_THREADS * EM_ITEMS;  // emit tile of the fused launch (512 threads)
+struct PmCtl {  // at byte 64 of job 0's workspace control block (SortCtl sits at byte 0: the two forms can alternate on one workspace)
+    uint32_t next, exited;
+    uint32_t done[PM_MAX_PHASES];
+};
+static_assert(64 + sizeof(PmCtl) <= SORT_CTL_BYTES && sizeof(SortCtl) <= 64, "control block");
+struct PmJob {
+    // where the ids come from: ids_in (given), or assembled into `ids` by the first phase — col < 0: cat(src, dst, src_neg, dst_neg)
+    // (marius_assemble_ids order); col >= 0: that column of edges
+    const int64_t* ids_in;
+    int64_t* ids;
+    const int64_t* edges;
+    const int64_t* src_neg;
+    const int64_t* dst_neg;
+    int64_t B, CN, n;
+    int cols, col, passes, ntiles, etiles, ptiles, has_plan;
+    uint64_t *keys, *keys2;
+    int32_t *payA, *payB, *perm;
+    uint32_t *ghist, *state, *tile_state;
+    int64_t *uniq, *inverse, *count;
+    int32_t* seg;
+    SegPlanPtrs plan;
+    int64_t* edges_out;
+};
+struct PmPhase {
+    int job, kind, pass, first, nitems, dep;
+};
+struct PmArgs {
+    PmJob job[PM_MAX_JOBS];
+    PmPhase ph[PM_MAX_PHASES];
+    int nph, total;
+    PmCtl* ctl;
+};
+
+__device__ __forceinline__ int64_t pm_id(const PmJob& J, int64_t i) {
+    if (J.ids_in) return J.ids_in[i];
+    if (J.col >= 0) return J.edges[i * J.cols + J.col];
+    if (i < J.B) return J.edges[i * J.cols];
+    if (i < 2 * J.B) return J.edges[(i - J.B) * J.cols + J.cols - 1];
+    const int64_t t = i - 2 * J.B;
+    if (J.src_neg) return t < J.CN ? J.src_neg[t] : J.dst_neg[t - J.CN];
+    return J.dst_neg[t];
+}
+
+union PmSmem {
+    uint32_t h[RS_MAX_PASSES][RS_RADIX];
+    SweepSmem sw;
+    EmitSmem<SW_THREADS> em;
+};
+
+__global__ __launch_bounds__(SW_THREADS) void prepare_maps_kernel(const PmArgs A) {
+    __shared__ PmSmem sm;
+    __shared__ int s_item;
+    const int tid = threadIdx.x;
+    PmCtl* ctl = A.ctl;
+    for (;;) {
+        if (tid == 0) s_item = (int)atomicAdd(&ctl->next, 1u);
+        __syncthreads();
+        const int item = s_item;
+        __syncthreads();
+        if (item >= A.total) break;
+        int g = 0;
+        while (g + 1 < A.nph && item >= A.ph[g + 1].first) ++g;
+        const PmPhase ph = A.ph[g];
+        const PmJob& J = A.job[ph.job];
+        const int tile = item - ph.first;
+        if (ph.dep >= 0) {
+            if (tid == 0) {
+                const uint32_t want = (uint32_t)A.ph[ph.dep].nitems;
+                // (bounded: ~10^8 polls is tens of seconds — orders of magnitude past any legitimate wait; a launch that ever gets there reports an
+                // impossible unique count (-1) instead of hanging the device)
+                unsigned long long spins = 0;
+                while (__hip_atomic_load(&ctl->done[ph.dep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1ull << 27)) {
+                        *J.count = -1;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        if (ph.kind == PM_INIT) {  // what must be zero before any atomic lands: every job's global digit histograms
+            for (int j = 0; j < PM_MAX_JOBS; ++j)
+                if (A.job[j].n > 0)
+                    for (int b = tid; b < RS_MAX_PASSES * RS_RADIX; b += SW_THREADS) __hip_atomic_store(A.job[j].ghist + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (ph.kind == PM_HIST) {
+            // ids of this tile (assembled here when they are not given), the digit histograms of all passes, and the zero fills the later
+            // phases expect: this tile's granules of every pass, its emit granules, uniq[]
+            for (int b = tid; b < RS_MAX_PASSES * RS_RADIX; b += SW_THREADS) (&sm.h[0][0])[b] = 0;
+            __syncthreads();
+            const int64_t base = (int64_t)tile * RS_TILE;
+#pragma unroll
+            for (int r = 0; r < SW_ITEMS; ++r) {
+                const int64_t i = base + r * SW_THREADS + tid;
+                if (i < J.n) {
+                    const uint64_t k = (uint64_t)pm_id(J, i);
+                    if (!J.ids_in) J.ids[i] = (int64_t)k;
+                    J.uniq[i] = 0;
+                    for (int ps = 0; ps < J.passes; ++ps) atomicAdd(&sm.h[ps][(int)((k >> (ps * RS_BITS)) & (RS_RADIX - 1))], 1u);
+                }
+            }
+            constexpr int EPT = RS_TILE / PM_EM_TILE;
+            if (tid < EPT && tile * EPT + tid < J.etiles) J.tile_state[tile * EPT + tid] = 0;
+            for (int ps = 0; ps < J.passes; ++ps) {
+                const size_t row = ((size_t)ps * J.ntiles + tile) * RS_RADIX;
+                for (int b = tid; b < RS_RADIX; b += SW_THREADS) J.state[row + b] = 0;
+            }
+            __syncthreads();
+            for (int b = tid; b < J.passes * RS_RADIX; b += SW_THREADS) {
+                const uint32_t v = (&sm.h[0][0])[b];
+                if (v) atomicAdd(&J.ghist[b], v);
+            }
+        } else if (ph.kind == PM_SWEEP) {
+            // ping-pong so that the last pass lands in (keys, perm)
+            const int ps = ph.pass;
+            const bool to_keys = ((J.passes - 1 - ps) % 2) == 0;
+            const uint64_t* kin = ps == 0 ? (const uint64_t*)(J.ids_in ? J.ids_in : J.ids) : (to_keys ? J.keys2 : J.keys);
+            const int32_t* pin = ps == 0 ? nullptr : (to_keys ? J.payB : J.payA);
+            uint64_t* kout = to_keys ? J.keys : J.keys2;
+            int32_t* pout = (ps == J.passes - 1) ? J.perm : (to_keys ? J.payA : J.payB);
+            rs_sweep_tile(sm.sw, tile, kin, pin, J.n, ps * RS_BITS, J.ghist + (size_t)ps * RS_RADIX, J.state + (size_t)ps * J.ntiles * RS_RADIX, kout, pout);
+        } else if (ph.kind == PM_EMIT) {
+            rs_emit_tile<SW_THREADS>(sm.em, tile, J.keys, J.perm, J.n, J.tile_state, J.uniq, J.inverse, J.seg, J.count);
+        } else {  // PM_PLAN: the batch's edges in batch-local ids (marius_remap_edges) and the index plan of the segmented update (marius_segment_plan)
+            const int64_t U = *J.count;
+            const int64_t base = (int64_t)tile * RS_TILE;
+#pragma unroll
+            for (int r = 0; r < SW_ITEMS; ++r) {
+                const int64_t k = base + r * SW_THREADS + tid;
+                if (k < J.n) {
+                    if (J.has_plan) seg_plan_position(k, J.n, U, J.perm, J.inverse, J.seg, J.uniq, J.plan);
+                    if (J.edges_out && k < J.B) {  // dataloader.cpp:460-466
+                        J.edges_out[k * J.cols] = J.inverse[k];
+                        if (J.cols == 3) J.edges_out[k * J.cols + 1] = J.edges[k * J.cols + 1];
+                        J.edges_out[k * J.cols + J.cols - 1] = J.inverse[J.B + k];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(&ctl->done[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+        const uint32_t e = __hip_atomic_fetch_add(&ctl->exited, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (e == gridDim.x - 1) {  // everybody else has left: nobody reads the control block any more
+            for (int g = 0; g < PM_MAX_PHASES; ++g) __hip_atomic_store(&ctl->done[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->exited, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -485,6 +682,104 @@ extern "C" int marius_sort_unique(const int64_t* ids, int64_t n, int32_t key_bit
     emit_unique_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const int64_t*)keys, scan, perm, n, uniq, inverse,
                                                                     seg_offsets, num_unique_dev);
     return check_launch("sort_unique");
+}
+
+// ---- marius_prepare_maps: the fused map launch (prepare_maps_kernel above)
+static bool pm_supported(const marius_map_job& j) {
+    return j.n > 0 && j.n <= (int64_t)RS_MAX_TILES * RS_TILE && j.key_bits > 0 && j.key_bits <= RS_MAX_KEY_BITS;
+}
+
+extern "C" int marius_prepare_maps_supported(const marius_map_job* jobs, int32_t num_jobs) {
+    if (!jobs || num_jobs < 1 || num_jobs > PM_MAX_JOBS || kernel_env().sort_rocprim || kernel_env().maps_unfused) return 0;
+    for (int j = 0; j < num_jobs; ++j)
+        if (!pm_supported(jobs[j])) return 0;
+    return 1;
+}
+
+extern "C" int marius_prepare_maps(const marius_map_job* jobs, int32_t num_jobs, marius_stream_t stream) {
+    MARIUS_REQUIRE(jobs && num_jobs >= 1 && num_jobs <= PM_MAX_JOBS, "prepare_maps: one or two jobs");
+    PmArgs A = {};
+    int width = 0;
+    for (int j = 0; j < num_jobs; ++j) {
+        const marius_map_job& in = jobs[j];
+        MARIUS_REQUIRE(pm_supported(in), "prepare_maps: job %d: n = %ld / key_bits = %d outside the fused launch's range (marius_prepare_maps_supported)", j, (long)in.n, in.key_bits);
+        MARIUS_REQUIRE(in.uniq && in.inverse && in.perm && in.seg_offsets && in.num_unique_dev && in.workspace, "prepare_maps: job %d: null output", j);
+        MARIUS_REQUIRE(in.ids_in || in.ids_out, "prepare_maps: job %d: ids are neither given (ids_in) nor is there room to assemble them (ids_out)", j);
+        if (!in.ids_in) {
+            MARIUS_REQUIRE(in.edges && in.B > 0 && (in.edge_cols == 2 || in.edge_cols == 3), "prepare_maps: job %d: assembling ids needs the batch's edges", j);
+            if (in.col >= 0) MARIUS_REQUIRE(in.col < in.edge_cols && in.n == in.B, "prepare_maps: job %d: a column job has one id per edge", j);
+            else MARIUS_REQUIRE(in.n == 2 * in.B + (in.src_neg ? in.CN : 0) + (in.dst_neg ? in.CN : 0), "prepare_maps: job %d: n != 2 B + negatives", j);
+        }
+        MARIUS_REQUIRE(!in.edges_out || (in.edges && in.n >= 2 * in.B), "prepare_maps: job %d: edges_out needs the edges and the endpoints' positions", j);
+        SortPlan p;
+        if (make_plan(in.n, p) != MARIUS_OK) return MARIUS_ERR_HIP;
+        MARIUS_REQUIRE(in.workspace_bytes >= p.total, "prepare_maps: job %d: workspace too small (%zu < %zu)", j, in.workspace_bytes, p.total);
+        PmJob& J = A.job[j];
+        J.ids_in = in.ids_in;
+        J.ids = in.ids_out;
+        J.edges = in.edges;
+        J.src_neg = in.src_neg;
+        J.dst_neg = in.dst_neg;
+        J.B = in.B;
+        J.CN = in.CN;
+        J.n = in.n;
+        J.cols = in.edge_cols;
+        J.col = in.col;
+        J.passes = (in.key_bits + RS_BITS - 1) / RS_BITS;
+        J.ntiles = (int)cdiv(in.n, RS_TILE);
+        J.etiles = (int)cdiv(in.n, PM_EM_TILE);
+        J.ptiles = J.ntiles;
+        J.has_plan = in.plan ? 1 : 0;
+        char* ws = (char*)in.workspace;
+        J.keys = (uint64_t*)(ws + p.keys_off);
+        char* t = ws + p.temp_off;
+        J.keys2 = (uint64_t*)t;
+        t += align_up((size_t)in.n * 8, 256);
+        J.payA = (int32_t*)t;
+        t += align_up((size_t)in.n * 4, 256);
+        J.payB = (int32_t*)t;
+        t += align_up((size_t)in.n * 4, 256);
+        J.ghist = (uint32_t*)t;
+        J.state = J.ghist + (size_t)RS_MAX_PASSES * RS_RADIX;
+        J.tile_state = J.state + (size_t)J.passes * J.ntiles * RS_RADIX;
+        J.perm = in.perm;
+        J.uniq = in.uniq;
+        J.inverse = in.inverse;
+        J.count = in.num_unique_dev;
+        J.seg = in.seg_offsets;
+        if (in.plan) J.plan = seg_plan_ptrs(in.plan, in.n);
+        J.edges_out = in.edges_out;
+        if (J.ntiles > width) width = J.ntiles;
+    }
+    // phases in dependency order, the jobs interleaved; every phase depends on the previous phase of its own job
+    int last[PM_MAX_JOBS] = {-1, -1};
+    auto add = [&](int job, int kind, int pass, int nitems) {
+        PmPhase& ph = A.ph[A.nph];
+        ph = {job, kind, pass, A.total, nitems, kind == PM_HIST ? 0 : last[job]};
+        last[job] = A.nph++;
+        A.total += nitems;
+    };
+    add(0, PM_INIT, 0, 1);
+    last[0] = last[1] = 0;
+    for (int j = 0; j < num_jobs; ++j) add(j, PM_HIST, 0, A.job[j].ntiles);
+    int maxp = 0;
+    for (int j = 0; j < num_jobs; ++j) maxp = A.job[j].passes > maxp ? A.job[j].passes : maxp;
+    for (int ps = 0; ps < maxp; ++ps)
+        for (int j = 0; j < num_jobs; ++j)
+            if (ps < A.job[j].passes) add(j, PM_SWEEP, ps, A.job[j].ntiles);
+    for (int j = num_jobs - 1; j >= 0; --j) add(j, PM_EMIT, 0, A.job[j].etiles);   // (the shorter chain first: its plan phase then fills the wait for the longer one's emit)
+    for (int j = num_jobs - 1; j >= 0; --j)
+        if (A.job[j].has_plan || A.job[j].edges_out) add(j, PM_PLAN, 0, A.job[j].ptiles);
+    MARIUS_REQUIRE(A.nph <= PM_MAX_PHASES, "prepare_maps: too many phases");
+    A.ctl = (PmCtl*)((char*)jobs[0].workspace + 64);
+    // one workgroup per tile of the widest phase (a pass of the larger job) plus the other job's share, capped: the queue needs no particular count
+    int nwg = width + (num_jobs > 1 ? A.job[1].ntiles : 0);
+    if (nwg > 96) nwg = 96;
+    if (nwg < 1) nwg = 1;
+    hipStream_t st = as_stream(stream);
+    ProfScope ps(PROF_SORT_UNIQUE, st);
+    prepare_maps_kernel<<<dim3((unsigned)nwg), dim3(SW_THREADS), 0, st>>>(A);
+    return check_launch("prepare_maps");
 }
 
 extern "C" int marius_merge_unique_runs(const int64_t* ids, int64_t n, const int64_t* run_offsets_host, int32_t num_runs, int64_t* uniq, int64_t* inverse,

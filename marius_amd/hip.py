@@ -52,6 +52,13 @@ class LpLayout(C.Structure):
 
 _i32, _i64, _f32, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
+
+class MapJob(C.Structure):  # marius_map_job
+    _fields_ = [("ids_in", _vp), ("ids_out", _vp), ("edges", _vp), ("src_neg", _vp), ("dst_neg", _vp), ("B", _i64), ("CN", _i64), ("n", _i64),
+                ("edge_cols", _i32), ("col", _i32), ("key_bits", _i32), ("reserved_", _i32), ("uniq", _vp), ("inverse", _vp), ("perm", _vp),
+                ("seg_offsets", _vp), ("num_unique_dev", _vp), ("plan", _vp), ("edges_out", _vp), ("workspace", _vp), ("workspace_bytes", _sz)]
+
+
 # name -> (restype, argtypes); mirrors include/marius_hip.h one to one
 SIGNATURES = {
     "marius_hip_abi_version": (C.c_int, []),
@@ -93,6 +100,8 @@ SIGNATURES = {
     "marius_layer_post_hook": (C.c_int, [_vp, _i64, _vp, _i32, _i64, _i32, _vp, _i64, _vp]),
     "marius_layer_post_hook_workspace_bytes": (_sz, [_i64, _i32]),
     "marius_layer_post_hook_backward": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "marius_prepare_maps_supported": (C.c_int, [C.POINTER(MapJob), _i32]),
+    "marius_prepare_maps": (C.c_int, [C.POINTER(MapJob), _i32, _vp]),
     "marius_owner_offsets_counts": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "marius_a2a_record_words": (_i32, [_i32]),
     "marius_a2a_record_checksum": (C.c_uint64, [_vp, _i32]),
@@ -321,6 +330,30 @@ class UniqueMap:
         check(lib().marius_sort_unique(ptr(ids), n, key_bits, ptr(self.uniq), ptr(self.inverse), ptr(self.perm), ptr(self.seg),
                                        ptr(self.count), ptr(self.ws), self.ws_bytes, stream_ptr()), "sort_unique")
         return self
+
+
+def map_job(um, key_bits, ids=None, edges=None, src_neg=None, dst_neg=None, col=-1, ids_out=None, plan=None, edges_out=None):
+    """one marius_map_job writing into the UniqueMap `um`: ids given, or assembled from the batch's edges (+ negatives) by the launch"""
+    j = MapJob()
+    n = ids.numel() if ids is not None else (edges.size(0) if col >= 0 else 2 * edges.size(0) + sum(t.numel() for t in (src_neg, dst_neg) if t is not None))
+    assert n <= um.cap
+    p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    j.ids_in, j.ids_out, j.edges, j.src_neg, j.dst_neg = p(ids), p(ids_out), p(edges), p(src_neg), p(dst_neg)
+    j.B = 0 if edges is None else edges.size(0)
+    j.CN = max([t.numel() for t in (src_neg, dst_neg) if t is not None] + [0])
+    j.n, j.edge_cols, j.col, j.key_bits = n, (0 if edges is None else edges.size(1)), col, key_bits
+    j.uniq, j.inverse, j.perm, j.seg_offsets, j.num_unique_dev = p(um.uniq), p(um.inverse), p(um.perm), p(um.seg), p(um.count)
+    j.plan, j.edges_out, j.workspace, j.workspace_bytes = p(plan), p(edges_out), p(um.ws), um.ws_bytes
+    return j
+
+
+def prepare_maps(jobs):
+    """marius_prepare_maps: the whole map chain of up to two id lists in one persistent launch; False when a job is outside its range"""
+    arr = (MapJob * len(jobs))(*jobs)
+    if not lib().marius_prepare_maps_supported(arr, len(jobs)):
+        return False
+    check(lib().marius_prepare_maps(arr, len(jobs), stream_ptr()), "prepare_maps")
+    return True
 
 
 def owner_offsets(um, shard_rows, num_shards):

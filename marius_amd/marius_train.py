@@ -61,6 +61,13 @@ def marius_train(cfg, log=print, train=True):
     # getLossFunction (loss.cpp:189-209); RankingLossOptions.margin defaults to 0.1 (datatypes.py:41-43)
     loss = H.getLossFunction(str(cfg["model"]["loss"]["type"]).upper(), str(lopt.get("reduction", "SUM")), float(lopt.get("margin", 0.1)))
     model = H.Model(decoder, loss, H.LinkPredictionReporter(), dev)
+    layer = cfg["model"]["encoder"]["layers"][0][0]
+    if layer["bias"] or layer["activation"] != "NONE":  # Layer::post_hook of the embedding layer (layer.cpp:9-16); bias init: initialize_tensor(bias_init, {d})
+        act = getattr(H.ActivationFunction, layer["activation"])
+        if layer["bias"]:
+            model.set_encoder(H.GeneralEncoder(d, True, act, dev, C.initialize_rows(layer["bias_init"], 1, d, (1, d), dev).reshape(d)))
+        else:
+            model.set_encoder(H.GeneralEncoder(d, False, act, dev))
     dopt = cfg["model"]["dense_optimizer"]
     o = dopt.get("options") or {}
     dtype_ = str(dopt.get("type", "ADAGRAD")).upper()

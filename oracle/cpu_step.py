@@ -22,6 +22,8 @@ class CpuLinkPredictionStep:
         self.filtered_edges = None  # (src-sorted, dst-sorted) known edges: filtered sampler (negative.cpp:321-325, 354-356)
         self.rel_sum = torch.zeros_like(self.rel)
         self.inv_rel_sum = torch.zeros_like(self.rel) if inverse_edges else None
+        # the embedding layer's post-hook (layer.cpp:9-16; default none): bias [d] is a parameter of the dense optimizer (model.cpp:175-183)
+        self.enc_bias, self.enc_activation, self.enc_bias_sum = None, "NONE", None
 
     def get_negatives(self, edges, inverse):
         """negative.cpp:328-366 on the global torch CPU generator."""
@@ -51,7 +53,11 @@ class CpuLinkPredictionStep:
         emb = O.index_read(self.table, uniq)
         st = O.index_read(self.state, uniq)
         out = O.train_batch(self.decoder, emb, st, edges_local, dst_map, src_map, self.rel, self.inv_rel, dst_filter, src_filter,
-                            self.reduction, self.sparse_lr, self.loss, self.margin)
+                            self.reduction, self.sparse_lr, self.loss, self.margin, encoder_bias=self.enc_bias, encoder_activation=self.enc_activation)
+        if self.enc_bias is not None:
+            if self.enc_bias_sum is None:
+                self.enc_bias_sum = torch.zeros_like(self.enc_bias)
+            O.dense_adagrad_step(self.enc_bias, out["bias_grad"], self.enc_bias_sum, self.dense_lr)
         O.dense_adagrad_step(self.rel, out["rel_grad"], self.rel_sum, self.dense_lr)
         if self.inverse:
             O.dense_adagrad_step(self.inv_rel, out["inv_rel_grad"], self.inv_rel_sum, self.dense_lr)

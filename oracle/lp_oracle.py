@@ -328,16 +328,38 @@ def index_add(table, ids, values):
 
 
 # ----------------------------------------------------------------------------- a12/a14/a17: one train step on a batch
-def train_batch(decoder, node_embeddings, node_state, edges, dst_neg_map, src_neg_map, relations, inverse_relations,
-                dst_filter=None, src_filter=None, reduction="sum", sparse_lr=0.1, loss="SOFTMAX_CE", margin=0.1):
-    """nn/model.cpp:290-333 (train_batch) + :252-288 (forward_lp) on batch-local tensors.
+def apply_activation(activation, x):
+    """nn/activation.cpp:7-21"""
+    if activation == "RELU":
+        return torch.relu(x)
+    if activation == "SIGMOID":
+        return torch.sigmoid(x)
+    if activation == "NONE":
+        return x
+    raise RuntimeError("Unsupported activation function")
 
-    Returns dict with scores, loss, node grad [U,d], relation grads, dw, ds.
+
+def post_hook(x, bias=None, activation="NONE"):
+    """Layer::post_hook nn/layers/layer.cpp:9-16: `input + bias_` when config_->bias, then apply_activation — what GeneralEncoder::forward
+    (nn/encoders/encoder.cpp:221-224) applies to the rows EmbeddingLayer::forward (embedding.cpp:17, a column view) hands on"""
+    if bias is not None:
+        x = x + bias
+    return apply_activation(activation, x)
+
+
+def train_batch(decoder, node_embeddings, node_state, edges, dst_neg_map, src_neg_map, relations, inverse_relations,
+                dst_filter=None, src_filter=None, reduction="sum", sparse_lr=0.1, loss="SOFTMAX_CE", margin=0.1, encoder_bias=None, encoder_activation="NONE"):
+    """nn/model.cpp:290-333 (train_batch) + :252-288 (forward_lp) on batch-local tensors.  encoder_bias / encoder_activation: the embedding
+    layer's post-hook (model.cpp:253 encoder_->forward; default: none).
+
+    Returns dict with scores, loss, node grad [U,d], relation grads, dw, ds (and bias_grad when a bias is given).
     """
     emb = node_embeddings.clone().requires_grad_(True)
     rel = relations.clone().requires_grad_(True) if relations is not None else None
     inv = inverse_relations.clone().requires_grad_(True) if inverse_relations is not None else None
-    pos, neg, inv_pos, inv_neg = node_corrupt_forward(decoder, edges, emb, dst_neg_map, src_neg_map, rel, inv)
+    bias = encoder_bias.clone().requires_grad_(True) if encoder_bias is not None else None
+    encoded = post_hook(emb, bias, encoder_activation)
+    pos, neg, inv_pos, inv_neg = node_corrupt_forward(decoder, edges, encoded, dst_neg_map, src_neg_map, rel, inv)
     neg = apply_score_filter(neg, dst_filter)
     if inv_neg is not None:
         inv_neg = apply_score_filter(inv_neg, src_filter)
@@ -354,5 +376,5 @@ def train_batch(decoder, node_embeddings, node_state, edges, dst_neg_map, src_ne
         "inv_pos": None if inv_pos is None else inv_pos.detach(),
         "inv_neg": None if inv_neg is None else inv_neg.detach(),
         "loss": loss.detach(), "node_grad": emb.grad, "rel_grad": None if rel is None else rel.grad,
-        "inv_rel_grad": None if inv is None else inv.grad, "dw": dw, "ds": ds,
+        "inv_rel_grad": None if inv is None else inv.grad, "dw": dw, "ds": ds, "bias_grad": None if bias is None else bias.grad,
     }

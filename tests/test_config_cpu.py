@@ -124,8 +124,8 @@ def test_marius_eval_does_not_create_a_model_dir(tmp_path):
 
 def test_embedding_layer_options_are_honoured_or_refused(tmp_path):
     """LayerConfig of the embedding layer (marius_config.py:190-199).  `init` selects the node-table initialisation (initialization.cpp:67-119);
-    `bias` / `activation` (Layer::post_hook, layer.cpp:9-16) and a per-layer optimizer are not implemented on the device path and are an ERROR —
-    never accepted and ignored (a7)."""
+    `bias` / `bias_init` / `activation` (Layer::post_hook, layer.cpp:9-16) are honoured since round 6 (GeneralEncoder + marius_layer_post_hook); a
+    per-layer optimizer is not implemented and is an ERROR — never accepted and ignored."""
     import torch
 
     def layer(**kw):
@@ -138,7 +138,13 @@ def test_embedding_layer_options_are_honoured_or_refused(tmp_path):
     path, _ = write(tmp_path, layer(bias=False, activation="none", input_dim=-1, optimizer={"type": "DEFAULT"}, init={"type": "uniform", "options": {"scale_factor": 0.25}}))
     cfg = C.load_config(path)
     assert C.embedding_init(cfg) == {"type": "UNIFORM", "options": {"scale_factor": 0.25}}
-    for bad, exc in ((dict(bias=True), NotImplementedError), (dict(activation="RELU"), NotImplementedError), (dict(optimizer={"type": "ADAM"}), NotImplementedError),
+    path, _ = write(tmp_path, layer(bias=True, activation="relu", bias_init={"type": "CONSTANT", "options": {"constant": 0.5}}))
+    lay = C.load_config(path)["model"]["encoder"]["layers"][0][0]
+    assert lay["bias"] is True and lay["activation"] == "RELU" and lay["bias_init"] == {"type": "CONSTANT", "options": {"constant": 0.5}}
+    path, _ = write(tmp_path, layer(activation="SIGMOID"))
+    lay = C.load_config(path)["model"]["encoder"]["layers"][0][0]
+    assert lay["bias"] is False and lay["activation"] == "SIGMOID" and lay["bias_init"]["type"] == "ZEROS"
+    for bad, exc in ((dict(activation="TANH"), ValueError), (dict(bias=True, bias_init={"type": "XAVIER"}), ValueError), (dict(optimizer={"type": "ADAM"}), NotImplementedError),
                      (dict(options={"type": "GRAPH_SAGE"}), NotImplementedError), (dict(init={"type": "XAVIER"}), ValueError), (dict(input_dim=8), ValueError),
                      (dict(init={"type": "ZEROS", "options": {"constant": 1.0}}), ValueError), (dict(dropout=0.5), ValueError), (dict(output_dim=0), ValueError)):
         path, _ = write(tmp_path, layer(**bad))

@@ -14,7 +14,7 @@ import yaml
 
 from oracle import lp_oracle as O
 from oracle.cpu_step import CpuLinkPredictionStep
-from tolerance import tiers
+from tolerance import TRAJECTORY_RTOL, tiers, well_conditioned
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -139,18 +139,129 @@ def test_trainer_epoch_matches_cpu_reference_path(M, dev, decoder, f, fused, d):
         for s in range(E // B):
             cpu.step(edges_all[perm[s * B:(s + 1) * B]])
     assert torch.equal(loader.active_perm.cpu(), perm)
-    from tolerance import well_conditioned
-    ok = well_conditioned(cpu.state)   # (all-zero initial Adagrad state: see there; > 99 % of the touched elements stay in)
-    assert float(ok.float().mean()) > 0.99
-    close(emb.data.cpu()[ok], cpu.table[ok], rtol=3e-4)
-    close(state.data.cpu()[ok], cpu.state[ok], rtol=3e-4)
-    close(model.decoder.relations, cpu.rel, rtol=3e-4)
-    close(model.decoder.inverse_relations, cpu.inv_rel, rtol=3e-4)
+    ok = well_conditioned(cpu.state, rel=1e-3)   # (all-zero initial Adagrad state, eight steps: tests/tolerance.py; > 95 % of the touched elements stay in)
+    assert float(ok.float().mean()) > 0.95
+    close(emb.data.cpu()[ok], cpu.table[ok], rtol=TRAJECTORY_RTOL, what="node table")
+    close(state.data.cpu()[ok], cpu.state[ok], rtol=TRAJECTORY_RTOL, what="Adagrad state")
+    close(model.decoder.relations, cpu.rel, rtol=TRAJECTORY_RTOL, what="relations")
+    close(model.decoder.inverse_relations, cpu.inv_rel, rtol=TRAJECTORY_RTOL, what="inverse relations")
     assert trainer.last_edges_per_second > 0
     if model.last_step_flash:  # every way the rows reach the decoder carries a magnitude bound (table scan + tracked update when fused, the gathered
         assert model.last_step_records == "fp16"  # copy's own bound on the API-granular path): 22-significand-bit operand halves, never bf16
     if fused and d == 200:
         assert bool(model.last_step_flash) == (f == 0.0)   # a DEG filter on wide rows must NOT take the chunked launches (they would ignore it)
+
+
+# ------------------------------------------------------------------------------------------------ a7: Layer::post_hook of the embedding layer
+@pytest.mark.parametrize("activation", ["NONE", "RELU", "SIGMOID"])
+@pytest.mark.parametrize("with_bias", [True, False])
+@pytest.mark.parametrize("n,d,pad", [(1, 2, 0), (777, 50, 0), (5000, 100, 0), (333, 400, 0), (901, 100, 28), (64, 7, 3)])
+def test_layer_post_hook_kernels_match_the_reference_ops(dev, activation, with_bias, n, d, pad):
+    """marius_layer_post_hook / _backward against Layer::post_hook as the reference computes it (layer.cpp:9-16: `input + bias_`, then
+    apply_activation, activation.cpp:7-21 — torch::relu / torch::sigmoid) and against autograd's backward of exactly those ops; rows with a
+    padded pitch, odd widths (scalar path), one row.  RELU and NONE are bit-exact (an add, a select); SIGMOID within 2e-7 relative (expf);
+    the bias gradient is a deterministic two-stage column sum: bit-identical run to run, 1e-6-relative to autograd's (other summation order)."""
+    from marius_amd import hip as H
+
+    g = torch.Generator().manual_seed(n * 31 + d)
+    buf = torch.randn(n, d + pad, generator=g)
+    x = buf[:, :d]
+    bias = torch.randn(d, generator=g) * 0.3 if with_bias else None
+    gy = torch.randn(n, d, generator=g)
+    xr = x.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True) if with_bias else None
+    want = O.post_hook(xr, br, activation)   # oracle/lp_oracle.py: the reference's ops
+    want.backward(gy)
+    xd = buf.to(dev)[:, :d]
+    assert xd.stride(0) == d + pad
+    y = H.layer_post_hook(xd, None if bias is None else bias.to(dev), activation)
+    gx, bg = H.layer_post_hook_backward(gy.to(dev), y, activation, with_bias=with_bias)
+    gx2, bg2 = H.layer_post_hook_backward(gy.to(dev), y, activation, with_bias=with_bias)
+    torch.cuda.synchronize()
+    if activation == "SIGMOID":
+        assert float(((y.cpu() - want.detach()).abs() / want.detach().abs()).max()) <= 2e-7
+        assert float((gx.cpu() - xr.grad).abs().max()) <= 3e-7 * float(gy.abs().max())   # |sigmoid'| <= 1/4
+    else:
+        assert torch.equal(y.cpu(), want.detach())
+        assert torch.equal(gx.cpu(), xr.grad)
+    assert torch.equal(gx, gx2)
+    if with_bias:
+        assert torch.equal(bg, bg2), "bias gradient is not bit-reproducible"
+        col_abs = float(gx.cpu().abs().sum(0).max()) + 1e-30
+        assert float((bg.cpu().double() - gx.cpu().double().sum(0)).abs().max()) <= 1e-6 * col_abs   # the column sums of the gradient it wrote
+        assert float((bg.cpu() - br.grad).abs().max()) <= 2e-6 * col_abs                             # and autograd's (another summation order)
+    else:
+        assert bg is None
+
+
+@pytest.mark.parametrize("decoder,activation,with_bias,d", [("COMPLEX", "RELU", True, 100), ("DISTMULT", "SIGMOID", True, 64), ("COMPLEX", "NONE", True, 20),
+                                                            ("TRANSE", "RELU", False, 20), ("COMPLEX", "SIGMOID", False, 100)])
+def test_trainer_epochs_with_an_embedding_layer_post_hook_match_the_cpu_reference_path(M, dev, decoder, activation, with_bias, d):
+    """an embedding layer with `bias: true` and / or an activation (LayerConfig, marius_config.py:190-199).  The decoder scores
+    act(rows + bias) (GeneralEncoder::forward, encoder.cpp:221-224 -> Layer::post_hook), the sparse update moves the RAW rows with the gradient
+    taken through the hook, and the bias is a parameter of the dense optimizer, listed before the decoder's (model.cpp:175-183).  Two epochs of
+    SynchronousTrainer (which takes the API-granular step for such a model) against the same loop on the CPU oracle, same generator stream."""
+    num_nodes, R, B, C, N, E, seed = 4000, 11, 250, 5, 40, 1000, 321
+    table, edges_all, emb, state, loader, model = _setup(M, dev, decoder, num_nodes, R, d, B, C, N, E, seed)
+    b0 = torch.linspace(-0.2, 0.3, d)
+    act = getattr(M.ActivationFunction, activation)
+    model.set_encoder(M.GeneralEncoder(d, True, act, dev, b0.to(dev)) if with_bias else M.GeneralEncoder(d, False, act, dev))
+    model.setup_optimizers(0.1)  # after set_encoder: the bias joins the dense optimizer's parameters
+    assert model.has_post_hook() and ("encoder.bias" in model.named_parameters()) == with_bias
+    trainer = M.SynchronousTrainer(loader, model)
+    trainer.train(2)
+    cpu = CpuLinkPredictionStep(decoder, table.clone(), torch.zeros(num_nodes, d), R, B, C, N)
+    cpu.enc_bias, cpu.enc_activation = (b0.clone() if with_bias else None), activation
+    torch.manual_seed(seed)
+    for epoch in range(2):
+        perm = torch.randperm(E)
+        for s in range(E // B):
+            cpu.step(edges_all[perm[s * B:(s + 1) * B]])
+    assert torch.equal(loader.active_perm.cpu(), perm)
+    ok = well_conditioned(cpu.state, rel=1e-3)
+    assert float(ok.float().mean()) > 0.5  # (a RELU zeroes whole gradient entries, a sigmoid' shrinks them: many touched elements sit at a noise-level Adagrad sum)
+    close(emb.data.cpu()[ok], cpu.table[ok], rtol=TRAJECTORY_RTOL, what="node table")
+    close(state.data.cpu()[ok], cpu.state[ok], rtol=TRAJECTORY_RTOL, what="Adagrad state")
+    close(model.decoder.relations, cpu.rel, rtol=TRAJECTORY_RTOL, what="relations")
+    if cpu.inv_rel is not None:
+        close(model.decoder.inverse_relations, cpu.inv_rel, rtol=TRAJECTORY_RTOL, what="inverse relations")
+    if with_bias:
+        close(model.encoder.bias.detach(), cpu.enc_bias, rtol=TRAJECTORY_RTOL, what="encoder bias")
+        assert not torch.allclose(model.encoder.bias.detach().cpu(), b0)  # it was trained
+    # evaluation scores through the same hook (Model::forward_lp -> encoder_->forward)
+    batch = M.Batch(False)
+    e = edges_all[:50]
+    uniq, inv = torch.unique(torch.cat([e[:, 0], e[:, 2]]), return_inverse=True)
+    batch.edges = torch.stack([inv[:50], e[:, 1], inv[50:]], 1).to(dev)
+    batch.node_embeddings = emb.data[uniq.to(dev)]
+    dn = torch.randint(uniq.numel(), (1, 30), generator=torch.Generator().manual_seed(1))
+    batch.dst_neg_indices_mapping = dn.to(dev)
+    batch.src_neg_indices_mapping = dn.to(dev)
+    pos, neg, ipos, ineg = model.forward_lp(batch, True)
+    enc = O.post_hook(emb.data.cpu()[uniq], model.encoder.bias.detach().cpu() if with_bias else None, activation)
+    wp, wn, wip, win = O.node_corrupt_forward(decoder, batch.edges.cpu(), enc, dn, dn, model.decoder.relations.detach().cpu(), model.decoder.inverse_relations.detach().cpu())
+    close(pos[:50], wp[:50], what="pos scores through the hook")
+    close(neg[:50], wn[:50], what="neg scores through the hook")
+
+
+def test_model_directory_round_trip_keeps_the_encoder_bias(M, dev, tmp_path):
+    """Model::save / load (model.cpp:82-134): encoder_->save writes the embedding layer's `bias` under "embedding:0_0", the dense optimizer's state
+    carries it under "embedding:0_0_bias" ahead of the decoder's parameters."""
+    d, R = 16, 5
+    def make():
+        dec = M.ComplEx(R, d, dev, True, M.EdgeDecoderMethod.CORRUPT_NODE)
+        m = M.Model(dec, M.SoftmaxCrossEntropy("sum"), M.LinkPredictionReporter(), dev)
+        m.set_encoder(M.GeneralEncoder(d, True, M.ActivationFunction.RELU, dev))
+        m.setup_optimizers(0.1)
+        return m
+    a, b = make(), make()
+    with torch.no_grad():
+        a.encoder.bias.copy_(torch.arange(d, dtype=torch.float32) * 0.01)
+        a.dense_state()[3].fill_(0.25)  # [bias, rel, inv_rel, sum(bias), sum(rel), sum(inv_rel)]
+    a.save(str(tmp_path) + "/")
+    b.load(str(tmp_path) + "/", True)
+    assert torch.equal(b.encoder.bias, a.encoder.bias) and float(b.dense_state()[3].min()) == 0.25
+    assert len(a.dense_state()) == 6
 
 
 @pytest.mark.parametrize("decoder,d,num_nodes", [("COMPLEX", 100, 4000), ("DISTMULT", 32, 4000), ("TRANSE", 20, 4000), ("COMPLEX", 100, 300)])
@@ -197,10 +308,10 @@ def test_trainer_tracks_table_magnitude_through_a_thousandfold_growth(M, dev):
             cpu.step(edges_all[perm[s * B:(s + 1) * B]])
     # Adagrad from an all-zero state moves a weight by lr * sign(g): two correct fp32 evaluations can differ by 2 lr where g is rounding noise
     # around 0.  Compare where the CPU path's accumulated state says the gradients were not noise.
-    solid = cpu.state > 1e-8
+    solid = (cpu.state > 1e-8) & well_conditioned(cpu.state, rel=1e-3)
     assert float(solid.float().mean()) > 0.05
-    close(emb.data.cpu()[solid], cpu.table[solid], rtol=3e-4)
-    close(state.data.cpu()[solid], cpu.state[solid], rtol=3e-4)
+    close(emb.data.cpu()[solid], cpu.table[solid], rtol=TRAJECTORY_RTOL, what="node table")
+    close(state.data.cpu()[solid], cpu.state[solid], rtol=TRAJECTORY_RTOL, what="Adagrad state")
 
 
 def test_tracked_bound_follows_writes_from_outside_the_trainer(M, dev):
@@ -237,10 +348,9 @@ def test_tracked_bound_follows_writes_from_outside_the_trainer(M, dev):
     trainer.train_steps(1)
     cpu.step(edges_all[perm[2 * B:3 * B]])
     torch.cuda.synchronize()
-    from tolerance import well_conditioned
-    ok = well_conditioned(cpu.state)
-    close(emb.data.cpu()[ok], cpu.table[ok], rtol=3e-4)
-    close(model.decoder.relations.detach(), cpu.rel, rtol=3e-4)
+    ok = well_conditioned(cpu.state, rel=1e-3)
+    close(emb.data.cpu()[ok], cpu.table[ok], rtol=TRAJECTORY_RTOL, what="node table")
+    close(model.decoder.relations.detach(), cpu.rel, rtol=TRAJECTORY_RTOL, what="relations")
 
 
 def test_user_plugins_train_through_the_virtual_api(M, dev):

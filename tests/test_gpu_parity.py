@@ -19,10 +19,10 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4
 
 
-def assert_close(got, want, what, rtol=RTOL):
+def assert_close(got, want, what, rtol=RTOL, small_frac=None):
     """tests/tolerance.py:tiers — pure relative error <= rtol over entries >= 0.1 max |want|, <= 3 rtol over entries >= 0.01 max, absolute error
     <= 0.03 rtol x max below (round 6: the old form added atol = rtol x max to EVERY entry, which passed anything below 1 % of the maximum)"""
-    tiers(got, want, what, rtol=rtol)
+    tiers(got, want, what, rtol=rtol, small_frac=small_frac)
 
 
 @pytest.fixture(scope="module")
@@ -204,6 +204,102 @@ def test_sort_unique_replays_from_a_captured_graph(H, dev):
         u, inv = torch.unique(fresh, return_inverse=True)
         U = int(um.count.item())
         assert U == u.numel() and torch.equal(um.uniq[:U].cpu(), u) and torch.equal(um.inverse[:n].cpu(), inv)
+
+
+def _plan_valid_bytes(H, plan, n, U):
+    """the defined part of a marius_segment_plan buffer (padding between its four arrays is never written): pos_plan [n], chunk_plan, row_plan [n], occ_single [n]"""
+    pos = (n * 16 + 255) // 256 * 256
+    chunk = ((n + 31) // 32 * 16 + 255) // 256 * 256
+    return torch.cat([plan[:n * 16], plan[pos:pos + (n + 31) // 32 * 16], plan[pos + chunk:pos + chunk + n * 16], plan[2 * pos + chunk:2 * pos + chunk + n]])
+
+
+@pytest.mark.parametrize("B,C,N,num_nodes,R,cols,hubs", [(50000, 50, 1000, 86054151, 14824, 3, True),   # the bench batch: 49 + 13 tiles, 3 + 2 passes
+                                                       (1000, 10, 500, 14541, 237, 3, False),          # FB15k-237 shape
+                                                       (250, 5, 40, 4000, 11, 3, False), (7, 1, 3, 50, 2, 3, False), (1, 1, 1, 2, 1, 3, False),
+                                                       (4096, 1, 4096, 1 << 20, 1, 2, False),           # 2-column edges: one job, n = 3 tiles exactly
+                                                       (2049, 3, 683, 99999, 5, 3, True)])              # n = one past a tile boundary
+def test_prepare_maps_one_launch_equals_the_separate_launches(H, dev, B, C, N, num_nodes, R, cols, hubs):
+    """marius_prepare_maps (round 6): ids assembled, both unique maps, batch-local edges and both segment plans in ONE persistent launch (work items
+    drawn from a queue, phases separated by completion counters) must leave bit for bit what marius_assemble_ids + marius_sort_unique +
+    marius_remap_edges + marius_segment_plan leave, for the node ids and the relation ids of the same batch — and what map_tensors
+    (util.cpp:180-205) gives on the CPU.  Repeated on the same workspaces, alternating with the separate form (both leave the control block zero)."""
+    g = torch.Generator().manual_seed(B + N)
+    CN = C * N
+    nbits, rbits = max(1, math.ceil(math.log2(num_nodes))), max(1, math.ceil(math.log2(R + 1)))
+    L = 2 * B + 2 * CN
+    um, ur = H.UniqueMap(L, dev), H.UniqueMap(B, dev)        # fused
+    vm, vr = H.UniqueMap(L, dev), H.UniqueMap(B, dev)        # separate launches
+    for trial in range(3):
+        src, dst = torch.randint(num_nodes, (B,), generator=g), torch.randint(num_nodes, (B,), generator=g)
+        if hubs:  # a few nodes in a large share of the edges: segments spanning many tiles
+            src[torch.rand(B, generator=g) < 0.3] = int(torch.randint(num_nodes, (1,), generator=g))
+            dst[torch.rand(B, generator=g) < 0.1] = int(src[0])
+        rel = torch.randint(R, (B,), generator=g)
+        edges = (torch.stack([src, rel, dst], 1) if cols == 3 else torch.stack([src, dst], 1)).to(dev)
+        sneg, dneg = torch.randint(num_nodes, (C, N), generator=g).to(dev), torch.randint(num_nodes, (C, N), generator=g).to(dev)
+        # ---- separate launches
+        ids = torch.empty(L, dtype=torch.int64, device=dev)
+        H.check(H.lib().marius_assemble_ids(H.ptr(edges), B, cols, H.ptr(sneg), H.ptr(dneg), CN, H.ptr(ids), H.stream_ptr()), "assemble_ids")
+        vm.run(ids, nbits)
+        want_edges = torch.empty_like(edges)
+        H.check(H.lib().marius_remap_edges(H.ptr(edges), H.ptr(vm.inverse), B, cols, H.ptr(want_edges), H.stream_ptr()), "remap_edges")
+        want_plan = H.segment_plan(vm, L)
+        if cols == 3:
+            vr.run(edges[:, 1].contiguous(), rbits)
+            want_rplan = H.segment_plan(vr, B)
+        # ---- one launch
+        ids_out, rel_out = torch.full((L,), -1, dtype=torch.int64, device=dev), torch.full((B,), -1, dtype=torch.int64, device=dev)
+        got_edges = torch.full_like(edges, -1)
+        plan = torch.empty(int(H.lib().marius_segment_plan_bytes(L)), dtype=torch.uint8, device=dev)
+        rplan = torch.empty(int(H.lib().marius_segment_plan_bytes(B)), dtype=torch.uint8, device=dev)
+        jobs = [H.map_job(um, nbits, edges=edges, src_neg=sneg, dst_neg=dneg, ids_out=ids_out, plan=plan, edges_out=got_edges)]
+        if cols == 3:
+            jobs.append(H.map_job(ur, rbits, edges=edges, col=1, ids_out=rel_out, plan=rplan))
+        assert H.prepare_maps(jobs)
+        torch.cuda.synchronize()
+        assert torch.equal(ids_out, ids) and torch.equal(got_edges, want_edges)
+        for a, b, n, gp, wp in ((um, vm, L, plan, want_plan),) + (((ur, vr, B, rplan, want_rplan),) if cols == 3 else ()):
+            U = int(b.count.item())
+            assert int(a.count.item()) == U
+            assert torch.equal(a.uniq[:n], b.uniq[:n]) and torch.equal(a.inverse[:n], b.inverse[:n]) and torch.equal(a.perm[:n], b.perm[:n])   # (uniq: zero tail included)
+            assert torch.equal(a.seg[:U + 1], b.seg[:U + 1])
+            assert torch.equal(_plan_valid_bytes(H, gp, n, U), _plan_valid_bytes(H, wp, n, U))
+        if cols == 3:
+            assert torch.equal(rel_out, edges[:, 1])
+        if trial == 0:  # and the CPU restatement of map_tensors
+            e = edges.cpu()
+            uniq_ref, mapped = O.map_tensors([e[:, 0], e[:, -1], sneg.cpu().flatten(), dneg.cpu().flatten()])
+            U = int(um.count.item())
+            assert torch.equal(um.uniq[:U].cpu(), uniq_ref) and torch.equal(um.inverse[:L].cpu(), torch.cat(mapped))
+        # the separate form on the FUSED form's workspace, then the fused form again (next trial): either leaves it reusable
+        um.run(ids, nbits)
+        assert torch.equal(um.inverse[:L], vm.inverse[:L])
+
+
+def test_prepare_maps_given_ids_many_replays_next_to_a_busy_stream(H, dev):
+    """ids_in form (a list that already exists) and robustness of the queue: 300 back-to-back launches on a side stream while the main stream keeps
+    every CU busy with large GEMMs — workgroups of the persistent launch then start late and out of step, which the item queue must not care about
+    (nothing waits for a workgroup that has not started)."""
+    g = torch.Generator().manual_seed(3)
+    n = 200000
+    ids = torch.randint(86054151, (n,), generator=g).to(dev)
+    um = H.UniqueMap(n, dev)
+    want = H.UniqueMap(n, dev).run(ids, 27)
+    a = torch.randn(4096, 4096, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    for it in range(300):
+        if it % 10 == 0:
+            for _ in range(4):
+                a = (a @ a) * 1e-3
+        with torch.cuda.stream(side):
+            um.uniq.fill_(-5)
+            assert H.prepare_maps([H.map_job(um, 27, ids=ids)])
+    torch.cuda.synchronize()
+    assert torch.equal(um.uniq, want.uniq) and torch.equal(um.inverse, want.inverse) and torch.equal(um.perm, want.perm) and int(um.count.item()) == int(want.count.item())
+    # outside the fused launch's range: refused by the predicate, not attempted
+    assert not H.prepare_maps([H.map_job(H.UniqueMap(8, dev), 40, ids=torch.zeros(8, dtype=torch.int64, device=dev))])
 
 
 def test_sort_unique_empty(H, dev):
@@ -568,8 +664,9 @@ def test_train_steps_match_cpu_reference_path(H, dev, decoder, f):
         U = int(hipstep.um.count.item())
         assert torch.equal(hipstep.um.uniq[:U].cpu(), want["uniq"])
         assert_close(W.pos(0), want["pos"], "pos step %d" % s)
-        assert_close(W.neg(0), want["neg"], "neg step %d" % s)
-        assert_close(W.neg(1), want["inv_neg"], "inv_neg step %d" % s)
+        l2 = 1e-4 if decoder == "TRANSE" else None   # small distances: sqrt of a cancelling x^2 + y^2 - 2 x y (tests/tolerance.py:tiers)
+        assert_close(W.neg(0), want["neg"], "neg step %d" % s, small_frac=l2)
+        assert_close(W.neg(1), want["inv_neg"], "inv_neg step %d" % s, small_frac=l2)
         assert_close(W.loss_values()[0:1], want["loss"].reshape(1), "loss step %d" % s)
     assert_close(t_d, cpu.table, "node table after 3 steps", rtol=2e-4)
     assert_close(s_d, cpu.state, "adagrad state after 3 steps", rtol=2e-4)
