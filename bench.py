@@ -241,7 +241,7 @@ def arith_check_leg(H, cfg, B, C, N, dev, seeds=ARITH_SEEDS, extra_inputs=()):
         first_pairs = first_pairs or pairs
         worst = {q: {"ratio_rms": float("%.3g" % max(pairs[q]["ratio_rms"], pairs[q]["ratio_dev_rms"])), "ratio_max": float("%.3g" % max(pairs[q]["ratio_max"], pairs[q]["ratio_dev_max"])),
                      "device_max": float("%.3g" % pairs[q]["device_max"]), "device_rms": float("%.3g" % pairs[q]["device_rms"])} for q in ASSERTED}
-        per_input.append({"input": x["describe"], "ok": v["ok"], "strict_le_reference": v["strict_le_reference"], "worst_rms_vs_reference": float("%.3g" % v["worst_rms_vs_reference"]),
+        per_input.append({"input": x["describe"], "ok": v["ok"], "equal_to_fp32_within_10pct": v["equal_to_fp32_within_10pct"], "strict_le_reference": v["strict_le_reference"], "worst_rms_vs_reference": float("%.3g" % v["worst_rms_vs_reference"]),
                           "worst_max_vs_reference": float("%.3g" % v["worst_max_vs_reference"]), "le1_cpu_aten": v["le1_cpu_aten"], "le1_device_aten": v["le1_device_aten"],
                           "flash_vs_either_reference_evaluation": worst})
     total = combine(verdicts)

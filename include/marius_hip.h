@@ -238,6 +238,7 @@ typedef struct marius_map_job {
     size_t workspace_bytes;
 } marius_map_job;
 int marius_prepare_maps_supported(const marius_map_job* jobs, int32_t num_jobs);
+int marius_prepare_maps_preferred(void); /* policy, not capability: 1 when MARIUS_MAPS=fused asks the DataLoader for the one-launch form (default: the separate launches) */
 int marius_prepare_maps(const marius_map_job* jobs, int32_t num_jobs, marius_stream_t stream);
 
 /* Sharded node table (partition axis of src/storage/storage.cpp:75 / buffer.cpp:340-356: shard q owns ids

@@ -2183,8 +2183,9 @@ shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
         const size_t wsr = marius_sort_unique_workspace_bytes(B);  // its own workspace: the fused launch works on both lists at once
         if (!sort_ws_rel_.defined() || (size_t)sort_ws_rel_.numel() < wsr) sort_ws_rel_ = torch::zeros({(int64_t)wsr}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
     }
-    // ONE persistent launch for the whole chain of both id lists (marius_prepare_maps: ids assembled, unique maps, batch-local edges, segment
-    // plans); the separate launches (MARIUS_MAPS=unfused, or a list outside the fused launch's range) compute the same bits
+    // The separate launches (default), or — MARIUS_MAPS=fused — ONE persistent launch for the whole chain of both id lists (marius_prepare_maps: ids
+    // assembled, unique maps, batch-local edges, segment plans).  Same bits either way; the one-launch form measured 6 % slower per step inside the
+    // pipeline (its ~90 resident workgroups hold CU slots the main stream's persistent kernels want: DESIGN 4.2), so it is opt-in
     marius_map_job jobs[2] = {};
     jobs[0].ids_out = ip(all_ids_);
     jobs[0].edges = ip(edges);
@@ -2224,7 +2225,7 @@ shared_ptr<Batch> DataLoader::prepareBatch(bool exact_unique) {
         jobs[1].workspace_bytes = (size_t)sort_ws_rel_.numel();
     }
     const int njobs = rels ? 2 : 1;
-    if (marius_prepare_maps_supported(jobs, njobs)) {
+    if (marius_prepare_maps_preferred() && marius_prepare_maps_supported(jobs, njobs)) {
         mcheck(marius_prepare_maps(jobs, njobs, st));
     } else {
         mcheck(marius_assemble_ids(ip(edges), B, cols, ip(batch->src_neg_indices_), ip(batch->dst_neg_indices_), CN, ip(all_ids_), st));

@@ -33,7 +33,9 @@ struct KernelEnv {
     bool flash_tail4_off;   // MARIUS_FLASH_TAIL4=0: d = 36 / 68 / 100 keep a k-step of their own for the last four columns (round-4 record layout)
     bool seg_fused_fixup_off, seg_group_off;  // MARIUS_SEG_FUSED_FIXUP=0, MARIUS_SEG_GROUP=0
     bool sort_rocprim;    // MARIUS_SORT=rocprim
-    bool maps_unfused;    // MARIUS_MAPS=unfused: the batch preparation as separate launches (assemble, sort passes, emit, remap, plan) — A/B runs, tests of both forms
+    bool maps_fused;      // MARIUS_MAPS=fused: the DataLoader prepares a batch's maps with the ONE persistent launch (marius_prepare_maps) instead of the separate
+                          // launches — measured slower inside the pipeline, so it is opt-in (marius_prepare_maps_preferred)
+    int pm_nwg;           // MARIUS_PM_NWG: workgroups of the fused map launch (0 = default) — A/B runs, the single-workgroup test
     int mt_threads;       // MARIUS_MT_THREADS: workgroup size of the MT19937 fill (64 / 128 / 256; 0 = default) — A/B runs
     int sync_launch;      // MARIUS_SYNC_LAUNCH
 };

@@ -35,7 +35,11 @@ static KernelEnv read_kernel_env() {
     k.seg_fused_fixup_off = first("MARIUS_SEG_FUSED_FIXUP") == '0';
     k.seg_group_off = first("MARIUS_SEG_GROUP") == '0';
     k.sort_rocprim = first("MARIUS_SORT") == 'r';
-    k.maps_unfused = first("MARIUS_MAPS") == 'u';
+    k.maps_fused = first("MARIUS_MAPS") == 'f';
+    {
+        const char* e = getenv("MARIUS_PM_NWG");
+        k.pm_nwg = e ? atoi(e) : 0;
+    }
     {
         const char* e = getenv("MARIUS_MT_THREADS");
         k.mt_threads = e ? atoi(e) : 0;

@@ -27,9 +27,9 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-// T threads.  T = 64 (one wave, round 6): the three phases of a twist are ordered by the wave's own in-order LDS queue — the barrier of a
-// single-wave workgroup costs nothing — so a 624-word block is three dependent LDS round trips of 4 / 4 / 3 elements per lane instead of
-// three 4-wave barriers; 256 threads is the round 1-5 form.
+// T threads.  T = 64 (one wave, tried in round 6): the three phases of a twist are ordered by the wave's own in-order LDS queue — the barrier
+// of a single-wave workgroup costs nothing — so a 624-word block is three dependent LDS round trips of 4 / 4 / 3 elements per lane instead of
+// three 4-wave barriers.  Measured SLOWER (203 vs 107 us per 100,000 words): 256 threads stays the default (MARIUS_MT_THREADS selects).
 template <int T>
 __global__ __launch_bounds__(T) void mt19937_fill_kernel(uint32_t* __restrict__ state, uint32_t* __restrict__ out, int64_t n) {
     __shared__ uint32_t buf[2][MT_N + 8];
@@ -267,9 +267,11 @@ extern "C" int marius_mt19937_fill(uint32_t* state_dev, uint32_t* out_dev, int64
     if (n == 0) return MARIUS_OK;
     ProfScope ps(PROF_MT_FILL, as_stream(stream));
     const int t = kernel_env().mt_threads;
-    if (t == 256) mt19937_fill_kernel<256><<<dim3(1), dim3(256), 0, as_stream(stream)>>>(state_dev, out_dev, n);
+    // default 256 threads: measured 107 / 150 / 203 us per 100,000 words with 256 / 128 / 64 threads (tools/bench_mt.py, profiles/r6_mt_threads.txt) — the
+    // single-wave form saves the barriers but leaves each lane 10 elements per twist, and the twist is bound by that
+    if (t == 64) mt19937_fill_kernel<64><<<dim3(1), dim3(64), 0, as_stream(stream)>>>(state_dev, out_dev, n);
     else if (t == 128) mt19937_fill_kernel<128><<<dim3(1), dim3(128), 0, as_stream(stream)>>>(state_dev, out_dev, n);
-    else mt19937_fill_kernel<64><<<dim3(1), dim3(64), 0, as_stream(stream)>>>(state_dev, out_dev, n);
+    else mt19937_fill_kernel<256><<<dim3(1), dim3(256), 0, as_stream(stream)>>>(state_dev, out_dev, n);
     return check_launch("mt19937_fill");
 }
 

@@ -1,6 +1,8 @@
 // The index plan of the segmented update (marius_segment_plan): layout and the per-position rule, shared by the stand-alone plan launch
 // (segreduce.hip) and the fused map launch (sort_unique.hip: marius_prepare_maps computes the plan as its last phase).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace marius {
@@ -30,13 +32,20 @@ inline SegPlanPtrs seg_plan_ptrs(void* plan, int64_t n) {
 //   occ_single[p] the singleton flag by occurrence row (marius_lp_desc.upd_occ_single)
 // A NEGATIVE id is a padding slot, not a row (the unused slots of a fixed-capacity exchange block, exchange.hip): its positions are dead — never
 // loaded, never stored, whatever the form — and the segment they make up owns no fix-up and no table row.
+// COH: the inputs were written earlier in the SAME launch (the fused map launch): agent-scope loads (sort_unique.hip: rs_ld)
+template <bool COH = false>
 __device__ __forceinline__ void seg_plan_position(int64_t k, int64_t n, int64_t U, const int32_t* __restrict__ perm, const int64_t* __restrict__ inverse,
                                                   const int32_t* __restrict__ seg_offsets, const int64_t* __restrict__ uniq, const SegPlanPtrs& P) {
+    auto ld = [](auto* q) {
+        typedef std::remove_cv_t<std::remove_pointer_t<decltype(q)>> T;
+        if constexpr (COH) return __hip_atomic_load(const_cast<T*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *q;
+    };
     const int64_t k0 = k / SEG_R * SEG_R, k1 = min(k0 + SEG_R, n);
-    const int p = perm[k];
-    const int u = (int)inverse[p];
-    const int s0 = seg_offsets[u], s1 = seg_offsets[u + 1];
-    const bool dead = uniq[u] < 0;
+    const int p = ld(perm + k);
+    const int u = (int)ld(inverse + p);
+    const int s0 = ld(seg_offsets + u), s1 = ld(seg_offsets + u + 1);
+    const bool dead = ld(uniq + u) < 0;
     P.pos_plan[k] = make_int4(p, u, (dead || (s0 >= k0 && s1 <= k1)) ? 1 : 0, dead ? 2 : ((s1 - s0 == 1) ? 1 : 0));
     P.occ_single[p] = (!dead && s1 - s0 == 1) ? 1 : 0;
     if (k == k1 - 1) {  // last position of its chunk: does the chunk own a boundary-crossing segment (the one its last position belongs to)?
@@ -44,10 +53,10 @@ __device__ __forceinline__ void seg_plan_position(int64_t k, int64_t n, int64_t 
         P.chunk_plan[k / SEG_R] = make_int4(owner ? 1 : 0, u, (s0 != k0) ? 1 : 0, (int)((s1 - 1) / SEG_R));
     }
     if (k < U) {  // position k also describes unique row k
-        const int64_t id = uniq[k];
-        const int t0 = seg_offsets[k], t1 = seg_offsets[k + 1];
+        const int64_t id = ld(uniq + k);
+        const int t0 = ld(seg_offsets + k), t1 = ld(seg_offsets + k + 1);
         if (id < 0) P.row_plan[k] = make_int4(-1, -1, -1, 0);
-        else P.row_plan[k] = make_int4((int)(id & 0xffffffffll), (int)(id >> 32), (t1 - t0 == 1) ? perm[t0] : -1, (t0 / SEG_R != (t1 - 1) / SEG_R) ? 1 : 0);
+        else P.row_plan[k] = make_int4((int)(id & 0xffffffffll), (int)(id >> 32), (t1 - t0 == 1) ? ld(perm + t0) : -1, (t0 / SEG_R != (t1 - 1) / SEG_R) ? 1 : 0);
     } else {
         P.row_plan[k] = make_int4(-1, -1, -1, 0);
     }

@@ -145,6 +145,58 @@ __device__ __forceinline__ int rs_draw_tile(uint32_t* ctr) {
 __device__ __forceinline__ void rs_publish(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v | RS_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t rs_poll(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// COH = true (the fused launch): data one phase writes and a later phase reads inside the SAME launch moves with agent-scope accesses (sc1: written
+// through to memory, read past the XCD-local L2) instead of being bracketed by agent-scope fences.  A fence there is a whole-cache operation
+// (buffer_wbl2 / buffer_inv) executed per work item by every wave — measured: the launch took 226 us, twice the separate launches it replaces, and
+// each invalidate also drops the lines the main stream's kernels keep L2-resident.  COH = false (the separate launches): plain accesses, the
+// kernel boundary is the fence.
+template <bool COH, typename T>
+__device__ __forceinline__ T rs_ld(const T* p) {
+    if constexpr (COH) return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH, typename T>
+__device__ __forceinline__ void rs_st(T* p, T v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// Every spin of the fused launch is BOUNDED by the constant 100 MHz clock (a wait that lasts RS_WAIT_TICKS = 50 ms is four orders of magnitude past
+// a whole launch): the waiter then gives up, leaves a record {where, phase, tile, what it waited for, last value seen} in the control block and the
+// launch reports the impossible unique count -1 instead of hanging the device.  err == nullptr (the separate launches): unbounded, as before.
+constexpr unsigned long long RS_WAIT_TICKS = 5000000ull;
+constexpr int RS_ERR_RECORDS = 6;
+struct RsErr {
+    uint32_t n;
+    uint32_t rec[RS_ERR_RECORDS][4];
+};
+struct RsWatch {
+    RsErr* err;
+    int phase, tile;
+    unsigned long long t0;
+    uint32_t it;
+    __device__ __forceinline__ RsWatch(RsErr* e, int ph, int tl) : err(e), phase(ph), tile(tl), t0(0), it(0) {}
+    // true: give up
+    __device__ __forceinline__ bool expired(int where, int what, uint32_t seen) {
+        if (!err) return false;
+        if ((++it & 255u) != 0) return false;
+        const unsigned long long now = wall_clock64();
+        if (t0 == 0) {
+            t0 = now;
+            return false;
+        }
+        if (now - t0 < RS_WAIT_TICKS) return false;
+        const uint32_t k = __hip_atomic_fetch_add(&err->n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k < (uint32_t)RS_ERR_RECORDS) {
+            err->rec[k][0] = (uint32_t)where | ((uint32_t)phase << 8);
+            err->rec[k][1] = (uint32_t)tile;
+            err->rec[k][2] = (uint32_t)what;
+            err->rec[k][3] = seen;
+        }
+        return true;
+    }
+};
+
 // ghist: [passes][RS_RADIX] global digit histograms.  Nothing is zeroed by a launch of its own: workgroup 0 zeroes ghist and then raises
 // `ready` to this call's ticket (a process-wide counter: no earlier call, no stale workspace content and no graph replay — rs_emit_kernel
 // puts 0 back — can hold the same value); the other workgroups build their LDS histograms meanwhile and wait for the ticket before their
@@ -195,10 +247,12 @@ struct SweepSmem {
     int32_t cw[SW_WAVES][RS_RADIX];   // per-wave running digit counts, then per-wave bases
     int32_t wsum[SW_WAVES];
 };
-// one tile of one pass (SW_THREADS threads).  COHERENT: the fused launch (prepare_maps_kernel) reads ghist with an agent-scope load — it was
-// accumulated by atomics of workgroups on other XCDs inside the SAME launch
+// one tile of one pass (SW_THREADS threads).  ghist is read with an agent-scope load either way — in the fused launch it was accumulated by
+// atomics of workgroups on other XCDs inside the SAME launch
+template <bool COH = false>
 __device__ __forceinline__ void rs_sweep_tile(SweepSmem& sm, const int tile, const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ pay_in, int64_t n, int shift,
-                                              const uint32_t* __restrict__ ghist, uint32_t* __restrict__ state, uint64_t* __restrict__ keys_out, int32_t* __restrict__ pay_out) {
+                                              const uint32_t* __restrict__ ghist, uint32_t* __restrict__ state, uint64_t* __restrict__ keys_out, int32_t* __restrict__ pay_out,
+                                              RsErr* err = nullptr, int phase = 0) {
     int32_t (&off)[RS_RADIX] = sm.off;
     int32_t (&cw)[SW_WAVES][RS_RADIX] = sm.cw;
     int32_t (&wsum)[SW_WAVES] = sm.wsum;
@@ -209,8 +263,8 @@ __device__ __forceinline__ void rs_sweep_tile(SweepSmem& sm, const int tile, con
 #pragma unroll
     for (int r = 0; r < SW_ITEMS; ++r) {
         const int64_t i = wbase_idx + r * 64 + lane;
-        key[r] = i < n ? keys_in[i] : 0ull;
-        pay[r] = (i < n && pay_in) ? pay_in[i] : (int32_t)i;
+        key[r] = i < n ? rs_ld<COH>(keys_in + i) : 0ull;
+        pay[r] = (i < n && pay_in) ? rs_ld<COH>(pay_in + i) : (int32_t)i;
     }
     for (int b = tid; b < SW_WAVES * RS_RADIX; b += SW_THREADS) (&cw[0][0])[b] = 0;
     __syncthreads();
@@ -254,6 +308,7 @@ __device__ __forceinline__ void rs_sweep_tile(SweepSmem& sm, const int tile, con
     // ---- keys of the digit in earlier tiles: their granules, RS_POLL in flight, re-polled until every flag is up
     constexpr int RS_POLL = 24;
     int32_t prefix = 0;
+    RsWatch watch(err, phase, tile);
     for (int t0 = 0; t0 < tile; t0 += RS_POLL) {
         uint32_t v[RS_POLL];
         bool done;
@@ -263,6 +318,7 @@ __device__ __forceinline__ void rs_sweep_tile(SweepSmem& sm, const int tile, con
             for (int u = 0; u < RS_POLL; ++u) v[u] = (t0 + u < tile) ? rs_poll(state + (int64_t)(t0 + u) * RS_RADIX + tid) : RS_FLAG;
 #pragma unroll
             for (int u = 0; u < RS_POLL; ++u) done = done && (v[u] & RS_FLAG);
+            if (!done && watch.expired(1, t0, v[0])) break;
         } while (!done);
 #pragma unroll
         for (int u = 0; u < RS_POLL; ++u) prefix += (int32_t)(v[u] & ~RS_FLAG);
@@ -289,8 +345,8 @@ __device__ __forceinline__ void rs_sweep_tile(SweepSmem& sm, const int tile, con
         if (i < n) {
             const int d = (int)((key[r] >> shift) & (RS_RADIX - 1));
             const int64_t pos = (int64_t)off[d] + cw[wave][d] + rank[r];
-            keys_out[pos] = key[r];
-            pay_out[pos] = pay[r];
+            rs_st<COH>(keys_out + pos, key[r]);
+            rs_st<COH>(pay_out + pos, pay[r]);
         }
     }
 }
@@ -309,10 +365,10 @@ template <int THREADS>
 struct EmitSmem {
     int32_t red[THREADS / 64], wsum[THREADS / 64];
 };
-template <int THREADS>
+template <int THREADS, bool COH = false>
 __device__ __forceinline__ void rs_emit_tile(EmitSmem<THREADS>& sm, const int tile, const uint64_t* __restrict__ keys, const int32_t* __restrict__ perm, int64_t n,
                                              uint32_t* __restrict__ tile_state, int64_t* __restrict__ uniq, int64_t* __restrict__ inverse, int32_t* __restrict__ seg_offsets,
-                                             int64_t* __restrict__ num_unique) {
+                                             int64_t* __restrict__ num_unique, RsErr* err = nullptr, int phase = 0) {
     constexpr int WAVES = THREADS / 64, TILE = THREADS * EM_ITEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // thread t owns EM_ITEMS consecutive positions: local head count, block scan of the thread sums
@@ -320,13 +376,13 @@ __device__ __forceinline__ void rs_emit_tile(EmitSmem<THREADS>& sm, const int ti
     uint64_t kk[EM_ITEMS];
     int32_t pp[EM_ITEMS];
     bool head[EM_ITEMS];
-    uint64_t prev = (k0 > 0 && k0 - 1 < n) ? keys[k0 - 1] : 0ull;
+    uint64_t prev = (k0 > 0 && k0 - 1 < n) ? rs_ld<COH>(keys + (k0 - 1)) : 0ull;
     int32_t mine = 0;
 #pragma unroll
     for (int r = 0; r < EM_ITEMS; ++r) {
         const int64_t k = k0 + r;
-        kk[r] = k < n ? keys[k] : 0ull;
-        pp[r] = k < n ? perm[k] : 0;
+        kk[r] = k < n ? rs_ld<COH>(keys + k) : 0ull;
+        pp[r] = k < n ? rs_ld<COH>(perm + k) : 0;
         head[r] = k < n && (k == 0 || kk[r] != prev);
         prev = kk[r];
         mine += head[r] ? 1 : 0;
@@ -344,11 +400,12 @@ __device__ __forceinline__ void rs_emit_tile(EmitSmem<THREADS>& sm, const int ti
     if (tid == 0) rs_publish(tile_state + tile, (uint32_t)tile_total);
     // heads in earlier tiles
     int32_t b = 0;
+    RsWatch watch(err, phase, tile);
     for (int t = tid; t < tile; t += THREADS) {
         uint32_t v;
         do {
             v = rs_poll(tile_state + t);
-        } while (!(v & RS_FLAG));
+        } while (!(v & RS_FLAG) && !watch.expired(2, t, v));
         b += (int32_t)(v & ~RS_FLAG);
     }
 #pragma unroll
@@ -366,13 +423,13 @@ __device__ __forceinline__ void rs_emit_tile(EmitSmem<THREADS>& sm, const int ti
         if (k < n) {
             if (head[r]) {
                 ++u;
-                uniq[u] = (int64_t)kk[r];
-                seg_offsets[u] = (int32_t)k;
+                rs_st<COH>(uniq + u, (int64_t)kk[r]);
+                rs_st<COH>(seg_offsets + u, (int32_t)k);
             }
-            inverse[pp[r]] = u;
+            rs_st<COH>(inverse + pp[r], (int64_t)u);
             if (k == n - 1) {
-                seg_offsets[u + 1] = (int32_t)n;
-                *num_unique = (int64_t)u + 1;
+                rs_st<COH>(seg_offsets + (u + 1), (int32_t)n);
+                rs_st<COH>(num_unique, (int64_t)u + 1);
             }
         }
     }
@@ -408,6 +465,7 @@ constexpr int PM_EM_TILE = SW_THREADS * EM_ITEMS;  // emit tile of the fused lau
 struct PmCtl {  // at byte 64 of job 0's workspace control block (SortCtl sits at byte 0: the two forms can alternate on one workspace)
     uint32_t next, exited;
     uint32_t done[PM_MAX_PHASES];
+    RsErr err;  // waits that gave up (marius_prepare_maps_errors): zero after a healthy launch
 };
 static_assert(64 + sizeof(PmCtl) <= SORT_CTL_BYTES && sizeof(SortCtl) <= 64, "control block");
 struct PmJob {
@@ -429,7 +487,7 @@ struct PmJob {
     int64_t* edges_out;
 };
 struct PmPhase {
-    int job, kind, pass, first, nitems, dep;
+    int job, kind, pass, first, nitems, dep, dep_items;  // dep: phase this one waits for (-1: none), dep_items: its item count
 };
 struct PmArgs {
     PmJob job[PM_MAX_JOBS];
@@ -454,107 +512,128 @@ union PmSmem {
     EmitSmem<SW_THREADS> em;
 };
 
+// one work item.  (J and ph are picked by STATIC index under uniform branches in the kernel: indexing the kernel-argument struct with a run-time
+// value makes hipcc copy it into scratch — the same finding as the grouped segment update, DESIGN_HISTORY 4.1)
+__device__ __forceinline__ void pm_item(const PmJob& J, const PmPhase& ph, const int g, const int tile, PmSmem& sm, const PmJob& J0, const PmJob& J1, RsErr* err) {
+    const int tid = threadIdx.x;
+    if (ph.kind == PM_INIT) {  // what must be zero before any atomic lands: every job's global digit histograms
+        if (J0.n > 0)
+            for (int b = tid; b < RS_MAX_PASSES * RS_RADIX; b += SW_THREADS) __hip_atomic_store(J0.ghist + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (J1.n > 0)
+            for (int b = tid; b < RS_MAX_PASSES * RS_RADIX; b += SW_THREADS) __hip_atomic_store(J1.ghist + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (ph.kind == PM_HIST) {
+        // ids of this tile (assembled here when they are not given), the digit histograms of all passes, and the zero fills the later
+        // phases expect: this tile's granules of every pass, its emit granules, uniq[]
+        for (int b = tid; b < RS_MAX_PASSES * RS_RADIX; b += SW_THREADS) (&sm.h[0][0])[b] = 0;
+        __syncthreads();
+        const int64_t base = (int64_t)tile * RS_TILE;
+#pragma unroll
+        for (int r = 0; r < SW_ITEMS; ++r) {
+            const int64_t i = base + r * SW_THREADS + tid;
+            if (i < J.n) {
+                const uint64_t k = (uint64_t)pm_id(J, i);
+                if (!J.ids_in) rs_st<true>(J.ids + i, (int64_t)k);
+                rs_st<true>(J.uniq + i, (int64_t)0);
+                for (int ps = 0; ps < J.passes; ++ps) atomicAdd(&sm.h[ps][(int)((k >> (ps * RS_BITS)) & (RS_RADIX - 1))], 1u);
+            }
+        }
+        constexpr int EPT = RS_TILE / PM_EM_TILE;
+        if (tid < EPT && tile * EPT + tid < J.etiles) rs_st<true>(J.tile_state + (tile * EPT + tid), 0u);
+        for (int ps = 0; ps < J.passes; ++ps) {
+            const size_t row = ((size_t)ps * J.ntiles + tile) * RS_RADIX;
+            for (int b = tid; b < RS_RADIX; b += SW_THREADS) rs_st<true>(J.state + (row + b), 0u);
+        }
+        __syncthreads();
+        for (int b = tid; b < J.passes * RS_RADIX; b += SW_THREADS) {
+            const uint32_t v = (&sm.h[0][0])[b];
+            if (v) atomicAdd(&J.ghist[b], v);
+        }
+    } else if (ph.kind == PM_SWEEP) {
+        // ping-pong so that the last pass lands in (keys, perm)
+        const int ps = ph.pass;
+        const bool to_keys = ((J.passes - 1 - ps) % 2) == 0;
+        const uint64_t* kin = ps == 0 ? (const uint64_t*)(J.ids_in ? J.ids_in : J.ids) : (to_keys ? J.keys2 : J.keys);
+        const int32_t* pin = ps == 0 ? nullptr : (to_keys ? J.payB : J.payA);
+        uint64_t* kout = to_keys ? J.keys : J.keys2;
+        int32_t* pout = (ps == J.passes - 1) ? J.perm : (to_keys ? J.payA : J.payB);
+        rs_sweep_tile<true>(sm.sw, tile, kin, pin, J.n, ps * RS_BITS, J.ghist + (size_t)ps * RS_RADIX, J.state + (size_t)ps * J.ntiles * RS_RADIX, kout, pout, err, g);
+    } else if (ph.kind == PM_EMIT) {
+        rs_emit_tile<SW_THREADS, true>(sm.em, tile, J.keys, J.perm, J.n, J.tile_state, J.uniq, J.inverse, J.seg, J.count, err, g);
+    } else {  // PM_PLAN: the batch's edges in batch-local ids (marius_remap_edges) and the index plan of the segmented update (marius_segment_plan)
+        const int64_t U = rs_ld<true>(J.count);
+        const int64_t base = (int64_t)tile * RS_TILE;
+#pragma unroll
+        for (int r = 0; r < SW_ITEMS; ++r) {
+            const int64_t k = base + r * SW_THREADS + tid;
+            if (k < J.n) {
+                if (J.has_plan) seg_plan_position<true>(k, J.n, U, J.perm, J.inverse, J.seg, J.uniq, J.plan);
+                if (J.edges_out && k < J.B) {  // dataloader.cpp:460-466
+                    J.edges_out[k * J.cols] = rs_ld<true>(J.inverse + k);
+                    if (J.cols == 3) J.edges_out[k * J.cols + 1] = J.edges[k * J.cols + 1];
+                    J.edges_out[k * J.cols + J.cols - 1] = rs_ld<true>(J.inverse + (J.B + k));
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(SW_THREADS) void prepare_maps_kernel(const PmArgs A) {
     __shared__ PmSmem sm;
     __shared__ int s_item;
     const int tid = threadIdx.x;
     PmCtl* ctl = A.ctl;
+    // Loop shape (found the hard way): everything thread 0 does alone — completing the previous item, drawing the next — sits in ONE block at
+    // the head, and the drawn item is made a wave-uniform value (readfirstlane) before anything branches on it.  With `item` left as the VGPR an LDS read
+    // gives, the exit test is a divergent branch to the compiler; its structurizer then peeled "thread 0: done[g]++ ... draw" into an outer loop and sent
+    // the other 63 lanes of wave 0 round the inner loop (barrier, read s_item) without lane 0: the barrier was passed with the OLD s_item and the
+    // workgroup repeated its item for ever (one workgroup, one phase was enough to hang the device).
+    int g_prev = -1;
     for (;;) {
-        if (tid == 0) s_item = (int)atomicAdd(&ctl->next, 1u);
+        if (tid == 0) {
+            if (g_prev >= 0) __hip_atomic_fetch_add(&ctl->done[g_prev], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (every thread's release fence precedes the barrier that ended the item)
+            s_item = (int)atomicAdd(&ctl->next, 1u);
+        }
         __syncthreads();
-        const int item = s_item;
-        __syncthreads();
+        const int item = __builtin_amdgcn_readfirstlane(s_item);
         if (item >= A.total) break;
+        PmPhase ph = A.ph[0];
         int g = 0;
-        while (g + 1 < A.nph && item >= A.ph[g + 1].first) ++g;
-        const PmPhase ph = A.ph[g];
-        const PmJob& J = A.job[ph.job];
+#pragma unroll
+        for (int q = 1; q < PM_MAX_PHASES; ++q)
+            if (q < A.nph && item >= A.ph[q].first) {
+                ph = A.ph[q];
+                g = q;
+            }
         const int tile = item - ph.first;
         if (ph.dep >= 0) {
             if (tid == 0) {
-                const uint32_t want = (uint32_t)A.ph[ph.dep].nitems;
-                // (bounded: ~10^8 polls is tens of seconds — orders of magnitude past any legitimate wait; a launch that ever gets there reports an
-                // impossible unique count (-1) instead of hanging the device)
-                unsigned long long spins = 0;
-                while (__hip_atomic_load(&ctl->done[ph.dep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                const uint32_t want = (uint32_t)ph.dep_items;
+                RsWatch watch(&ctl->err, g, tile);
+                uint32_t seen;
+                while ((seen = __hip_atomic_load(&ctl->done[ph.dep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < want) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1ull << 27)) {
-                        *J.count = -1;
-                        break;
-                    }
+                    if (watch.expired(0, ph.dep, seen)) break;
                 }
             }
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();  // (no cache invalidate: what the item reads of earlier phases it reads with agent-scope loads — rs_ld<true>)
         }
-        if (ph.kind == PM_INIT) {  // what must be zero before any atomic lands: every job's global digit histograms
-            for (int j = 0; j < PM_MAX_JOBS; ++j)
-                if (A.job[j].n > 0)
-                    for (int b = tid; b < RS_MAX_PASSES * RS_RADIX; b += SW_THREADS) __hip_atomic_store(A.job[j].ghist + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (ph.kind == PM_HIST) {
-            // ids of this tile (assembled here when they are not given), the digit histograms of all passes, and the zero fills the later
-            // phases expect: this tile's granules of every pass, its emit granules, uniq[]
-            for (int b = tid; b < RS_MAX_PASSES * RS_RADIX; b += SW_THREADS) (&sm.h[0][0])[b] = 0;
-            __syncthreads();
-            const int64_t base = (int64_t)tile * RS_TILE;
-#pragma unroll
-            for (int r = 0; r < SW_ITEMS; ++r) {
-                const int64_t i = base + r * SW_THREADS + tid;
-                if (i < J.n) {
-                    const uint64_t k = (uint64_t)pm_id(J, i);
-                    if (!J.ids_in) J.ids[i] = (int64_t)k;
-                    J.uniq[i] = 0;
-                    for (int ps = 0; ps < J.passes; ++ps) atomicAdd(&sm.h[ps][(int)((k >> (ps * RS_BITS)) & (RS_RADIX - 1))], 1u);
-                }
-            }
-            constexpr int EPT = RS_TILE / PM_EM_TILE;
-            if (tid < EPT && tile * EPT + tid < J.etiles) J.tile_state[tile * EPT + tid] = 0;
-            for (int ps = 0; ps < J.passes; ++ps) {
-                const size_t row = ((size_t)ps * J.ntiles + tile) * RS_RADIX;
-                for (int b = tid; b < RS_RADIX; b += SW_THREADS) J.state[row + b] = 0;
-            }
-            __syncthreads();
-            for (int b = tid; b < J.passes * RS_RADIX; b += SW_THREADS) {
-                const uint32_t v = (&sm.h[0][0])[b];
-                if (v) atomicAdd(&J.ghist[b], v);
-            }
-        } else if (ph.kind == PM_SWEEP) {
-            // ping-pong so that the last pass lands in (keys, perm)
-            const int ps = ph.pass;
-            const bool to_keys = ((J.passes - 1 - ps) % 2) == 0;
-            const uint64_t* kin = ps == 0 ? (const uint64_t*)(J.ids_in ? J.ids_in : J.ids) : (to_keys ? J.keys2 : J.keys);
-            const int32_t* pin = ps == 0 ? nullptr : (to_keys ? J.payB : J.payA);
-            uint64_t* kout = to_keys ? J.keys : J.keys2;
-            int32_t* pout = (ps == J.passes - 1) ? J.perm : (to_keys ? J.payA : J.payB);
-            rs_sweep_tile(sm.sw, tile, kin, pin, J.n, ps * RS_BITS, J.ghist + (size_t)ps * RS_RADIX, J.state + (size_t)ps * J.ntiles * RS_RADIX, kout, pout);
-        } else if (ph.kind == PM_EMIT) {
-            rs_emit_tile<SW_THREADS>(sm.em, tile, J.keys, J.perm, J.n, J.tile_state, J.uniq, J.inverse, J.seg, J.count);
-        } else {  // PM_PLAN: the batch's edges in batch-local ids (marius_remap_edges) and the index plan of the segmented update (marius_segment_plan)
-            const int64_t U = *J.count;
-            const int64_t base = (int64_t)tile * RS_TILE;
-#pragma unroll
-            for (int r = 0; r < SW_ITEMS; ++r) {
-                const int64_t k = base + r * SW_THREADS + tid;
-                if (k < J.n) {
-                    if (J.has_plan) seg_plan_position(k, J.n, U, J.perm, J.inverse, J.seg, J.uniq, J.plan);
-                    if (J.edges_out && k < J.B) {  // dataloader.cpp:460-466
-                        J.edges_out[k * J.cols] = J.inverse[k];
-                        if (J.cols == 3) J.edges_out[k * J.cols + 1] = J.edges[k * J.cols + 1];
-                        J.edges_out[k * J.cols + J.cols - 1] = J.inverse[J.B + k];
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(&ctl->done[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ph.job == 0) pm_item(A.job[0], ph, g, tile, sm, A.job[0], A.job[1], &ctl->err);
+        else pm_item(A.job[1], ph, g, tile, sm, A.job[0], A.job[1], &ctl->err);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every wave: its (write-through) stores have completed — s_waitcnt vmcnt(0), no cache write-back
+        __syncthreads();  // the item is complete; s_item has been read by everybody
+        g_prev = g;
     }
     if (tid == 0) {
-        const uint32_t e = __hip_atomic_fetch_add(&ctl->exited, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // (relaxed throughout: the control block is only ever touched by agent-scope atomics, and the next launch starts after this one has ended)
+        const uint32_t e = __hip_atomic_fetch_add(&ctl->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (e == gridDim.x - 1) {  // everybody else has left: nobody reads the control block any more
-            for (int g = 0; g < PM_MAX_PHASES; ++g) __hip_atomic_store(&ctl->done[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_load(&ctl->err.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {  // a wait gave up: the maps are not to be used
+                rs_st<true>(A.job[0].count, (int64_t)-1);
+                if (A.job[1].n > 0) rs_st<true>(A.job[1].count, (int64_t)-1);
+            }
+            for (int q = 0; q < PM_MAX_PHASES; ++q) __hip_atomic_store(&ctl->done[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctl->next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ctl->exited, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -690,11 +769,13 @@ static bool pm_supported(const marius_map_job& j) {
 }
 
 extern "C" int marius_prepare_maps_supported(const marius_map_job* jobs, int32_t num_jobs) {
-    if (!jobs || num_jobs < 1 || num_jobs > PM_MAX_JOBS || kernel_env().sort_rocprim || kernel_env().maps_unfused) return 0;
+    if (!jobs || num_jobs < 1 || num_jobs > PM_MAX_JOBS || kernel_env().sort_rocprim) return 0;
     for (int j = 0; j < num_jobs; ++j)
         if (!pm_supported(jobs[j])) return 0;
     return 1;
 }
+
+extern "C" int marius_prepare_maps_preferred(void) { return kernel_env().maps_fused ? 1 : 0; }
 
 extern "C" int marius_prepare_maps(const marius_map_job* jobs, int32_t num_jobs, marius_stream_t stream) {
     MARIUS_REQUIRE(jobs && num_jobs >= 1 && num_jobs <= PM_MAX_JOBS, "prepare_maps: one or two jobs");
@@ -755,7 +836,8 @@ extern "C" int marius_prepare_maps(const marius_map_job* jobs, int32_t num_jobs,
     int last[PM_MAX_JOBS] = {-1, -1};
     auto add = [&](int job, int kind, int pass, int nitems) {
         PmPhase& ph = A.ph[A.nph];
-        ph = {job, kind, pass, A.total, nitems, kind == PM_HIST ? 0 : last[job]};
+        const int dep = kind == PM_HIST ? 0 : last[job];
+        ph = {job, kind, pass, A.total, nitems, dep, dep >= 0 ? A.ph[dep].nitems : 0};
         last[job] = A.nph++;
         A.total += nitems;
     };
@@ -771,10 +853,18 @@ extern "C" int marius_prepare_maps(const marius_map_job* jobs, int32_t num_jobs,
     for (int j = num_jobs - 1; j >= 0; --j)
         if (A.job[j].has_plan || A.job[j].edges_out) add(j, PM_PLAN, 0, A.job[j].ptiles);
     MARIUS_REQUIRE(A.nph <= PM_MAX_PHASES, "prepare_maps: too many phases");
+    if (const char* e = getenv("MARIUS_PM_MAXPH")) {  // debugging: only the first k phases
+        const int k = atoi(e);
+        if (k >= 1 && k < A.nph) {
+            A.nph = k;
+            A.total = A.ph[k].first;
+        }
+    }
     A.ctl = (PmCtl*)((char*)jobs[0].workspace + 64);
     // one workgroup per tile of the widest phase (a pass of the larger job) plus the other job's share, capped: the queue needs no particular count
     int nwg = width + (num_jobs > 1 ? A.job[1].ntiles : 0);
     if (nwg > 96) nwg = 96;
+    if (kernel_env().pm_nwg > 0) nwg = kernel_env().pm_nwg;
     if (nwg < 1) nwg = 1;
     hipStream_t st = as_stream(stream);
     ProfScope ps(PROF_SORT_UNIQUE, st);

@@ -101,6 +101,7 @@ SIGNATURES = {
     "marius_layer_post_hook_workspace_bytes": (_sz, [_i64, _i32]),
     "marius_layer_post_hook_backward": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "marius_prepare_maps_supported": (C.c_int, [C.POINTER(MapJob), _i32]),
+    "marius_prepare_maps_preferred": (C.c_int, []),
     "marius_prepare_maps": (C.c_int, [C.POINTER(MapJob), _i32, _vp]),
     "marius_owner_offsets_counts": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "marius_a2a_record_words": (_i32, [_i32]),

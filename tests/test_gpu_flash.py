@@ -362,8 +362,9 @@ def test_flash_arithmetic_against_the_reference_fp32_evaluation(H, dev, decoder,
     by that much (summation order), the split path is inside their spread and closer to float64 than the FP32-MFMA path on most quantities.
     Asserted (oracle/arith_check.verdict; VERDICT r4 #2: the yardstick is taken from the reference's two evaluations only, never from this library's
     own FP32-MFMA kernels, which are printed beside it):
-      * at the bench shape (the configuration the metric is quoted on): RMS error <= 1.0 x and max error <= 2.0 x the less accurate of the two
-        reference evaluations, on every quantity — the condition under which bench.py lets the split path carry the headline (`arith_check.ok`);
+      * at the bench shape (the configuration the metric is quoted on): RMS error <= 1.10 x and max error <= 2.0 x the less accurate of the two
+        reference evaluations, on every quantity (`equal_to_fp32_within_10pct`: holds on these synthetic rows, NOT on rows of a trained table, where
+        the path shows its 22 bits — bench.py's `arith_check` carries that input and the rule that decides the headline, `ok`: 4 x / 8 x);
         how many of the 10 ratios are <= 1 against EACH evaluation is printed beside it;
       * at the small shapes: within 2x (max) / 1.5x (RMS) of the less accurate of the two reference evaluations."""
     from oracle.arith_check import ASSERTED, verdict
@@ -388,7 +389,7 @@ def test_flash_arithmetic_against_the_reference_fp32_evaluation(H, dev, decoder,
     v = verdict(pairs)
     print("\n" + summary(pairs) + "\n" + str(v))
     if B == 50000:
-        assert v["ok"], v
+        assert v["ok"] and v["equal_to_fp32_within_10pct"], v   # (synthetic N(0, 0.5^2) rows: the round-5 rule holds here; on rows of a trained table only `ok` does — bench.py)
     for q in ASSERTED:
         p = pairs[q]
         assert p["device_max"] <= 2.0 * max(p["fp32_max"], p["fp32_on_device_max"]) and p["device_rms"] <= 1.5 * max(p["fp32_rms"], p["fp32_on_device_rms"]), (q, p)

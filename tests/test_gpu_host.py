@@ -14,7 +14,7 @@ import yaml
 
 from oracle import lp_oracle as O
 from oracle.cpu_step import CpuLinkPredictionStep
-from tolerance import TRAJECTORY_RTOL, tiers, well_conditioned
+from tolerance import TRAJECTORY_RTOL, tiers, trajectory_close, well_conditioned
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -139,9 +139,9 @@ def test_trainer_epoch_matches_cpu_reference_path(M, dev, decoder, f, fused, d):
         for s in range(E // B):
             cpu.step(edges_all[perm[s * B:(s + 1) * B]])
     assert torch.equal(loader.active_perm.cpu(), perm)
-    ok = well_conditioned(cpu.state, rel=1e-3)   # (all-zero initial Adagrad state, eight steps: tests/tolerance.py; > 95 % of the touched elements stay in)
-    assert float(ok.float().mean()) > 0.95
-    close(emb.data.cpu()[ok], cpu.table[ok], rtol=TRAJECTORY_RTOL, what="node table")
+    trajectory_close(emb.data, cpu.table, cpu.state, 0.1, 2 * (E // B), "node table")   # every element, bounded by its own conditioning (tests/tolerance.py)
+    ok = well_conditioned(cpu.state, rel=1e-3)   # (the state itself: elements whose accumulated g^2 is not rounding noise)
+    assert float(ok.float().mean()) > 0.9
     close(state.data.cpu()[ok], cpu.state[ok], rtol=TRAJECTORY_RTOL, what="Adagrad state")
     close(model.decoder.relations, cpu.rel, rtol=TRAJECTORY_RTOL, what="relations")
     close(model.decoder.inverse_relations, cpu.inv_rel, rtol=TRAJECTORY_RTOL, what="inverse relations")
@@ -308,9 +308,9 @@ def test_trainer_tracks_table_magnitude_through_a_thousandfold_growth(M, dev):
             cpu.step(edges_all[perm[s * B:(s + 1) * B]])
     # Adagrad from an all-zero state moves a weight by lr * sign(g): two correct fp32 evaluations can differ by 2 lr where g is rounding noise
     # around 0.  Compare where the CPU path's accumulated state says the gradients were not noise.
+    trajectory_close(emb.data, cpu.table, cpu.state, 0.1, 2 * (E // B), "node table")
     solid = (cpu.state > 1e-8) & well_conditioned(cpu.state, rel=1e-3)
     assert float(solid.float().mean()) > 0.05
-    close(emb.data.cpu()[solid], cpu.table[solid], rtol=TRAJECTORY_RTOL, what="node table")
     close(state.data.cpu()[solid], cpu.state[solid], rtol=TRAJECTORY_RTOL, what="Adagrad state")
 
 
@@ -350,7 +350,7 @@ def test_tracked_bound_follows_writes_from_outside_the_trainer(M, dev):
     torch.cuda.synchronize()
     ok = well_conditioned(cpu.state, rel=1e-3)
     close(emb.data.cpu()[ok], cpu.table[ok], rtol=TRAJECTORY_RTOL, what="node table")
-    close(model.decoder.relations.detach(), cpu.rel, rtol=TRAJECTORY_RTOL, what="relations")
+    trajectory_close(model.decoder.relations.detach(), cpu.rel, cpu.rel_sum, 0.1, 3, "relations")
 
 
 def test_user_plugins_train_through_the_virtual_api(M, dev):

@@ -51,3 +51,36 @@ def well_conditioned(state_ref, floor=1e-8, rel=None):
     if rel is not None and bool((state_ref > 0).any()):
         floor = max(floor, rel * float(state_ref[state_ref > 0].median()))
     return (~touched_rows).expand_as(state_ref) | (state_ref > floor)
+
+
+# |difference of a gradient coordinate| / max |gradient| between two float32-class evaluations of one batch: each is 1-2e-6 from float64 (bench.py
+# arith_check: `worst_abs_max`), two of them differ by up to twice that, and a factor 2 of margin
+GRAD_NOISE = 8e-6
+
+
+def trajectory_close(got, want, state_ref, lr, steps, what, rtol=TRAJECTORY_RTOL):
+    """Weights after `steps` Adagrad steps from an all-zero state, element by element, with the bound the update rule itself implies instead of a mask:
+        |got - want| <= rtol |want| + 0.03 rtol max|want|                  (the tiers' relative and small-entry terms)
+                        + min(lr steps, lr steps GRAD_NOISE sqrt(max S / S_i))   (conditioning of w -= lr g / sqrt(S): batch.cpp:67-69)
+    where S = the reference path's accumulated g^2.  A coordinate whose gradients were as large as any gets 3e-6 of slack at lr 0.1, eight steps;
+    one whose gradients were 1e-3 of the largest gets 3e-3; one whose S is rounding noise gets the whole lr steps (its first step is lr sign(noise)
+    in any arithmetic).  Rows nobody touched (S = 0 throughout the row) must be EQUAL."""
+    import torch
+
+    got, want, S = got.detach().cpu().double(), want.detach().cpu().double(), state_ref.detach().cpu().double()
+    assert got.shape == want.shape == S.shape, (what, got.shape, want.shape, S.shape)
+    if S.dim() == 1:
+        got, want, S = got[None], want[None], S[None]
+    touched = (S > 0).any(1, keepdim=True).expand_as(S)
+    assert torch.equal(got[~touched], want[~touched]), "%s: a row nobody touched changed" % what
+    smax, mx = float(S.max()), max(float(want.abs().max()), 1e-30)
+    cond = torch.full_like(S, float(lr * steps))
+    pos = S > 0
+    cond[pos] = torch.clamp(lr * steps * GRAD_NOISE * torch.sqrt(smax / S[pos]), max=lr * steps)
+    allowed = rtol * want.abs() + 0.03 * rtol * mx + cond
+    err = (got - want).abs()
+    worst = float((err / allowed)[touched].max()) if bool(touched.any()) else 0.0
+    tight = float((err <= rtol * want.abs() + 0.03 * rtol * mx)[touched].double().mean()) if bool(touched.any()) else 1.0
+    print("%-28s worst error / bound %.3f   (%.1f %% of the touched elements inside the relative terms alone)   max %.3e" % (what, worst, 100 * tight, mx))
+    assert worst <= 1.0, "%s: an element is %.2f x outside its conditioning bound" % (what, worst)
+    assert tight > 0.9, "%s: only %.1f %% of the touched elements inside the relative terms" % (what, 100 * tight)
