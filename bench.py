@@ -368,6 +368,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-fp32-pass", action="store_true", help="skip the short pass that reports the step time of the other arithmetic (fp32_exact / fast_path) beside the headline number")
+    ap.add_argument("--demoted-from", default=None, help="internal: the check that ran after a first timed region (flash path) failed; this re-executed run times the fp32 path and carries the check's record (JSON file)")
+    ap.add_argument("--step-groups", type=int, default=0, help="diagnostic: after the timed region, time this many further groups of 5 steps (a synchronisation either side) and report them with the allocator's counters")
     ap.add_argument("--no-arith-check", action="store_true", help="skip the arithmetic check (flash path vs the reference's fp32 evaluation vs float64) that decides which path carries the headline")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--strong", action="store_true", help="N > 1: strong scaling (the global batch stays B; default is weak scaling, B per GPU)")
@@ -417,10 +419,18 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=_nccl_options())
     # ---- which arithmetic carries the headline: the flash path only if it is no worse than the reference's own fp32 evaluation
     # (oracle/arith_check.py: the rule; several seeds).  N = 1 adds one more input below — rows of the live table after ARITH_PRETRAIN steps.
+    ARITH_PRETRAIN = 200
+    demoted = None
+    if a.demoted_from:
+        demoted = json.load(open(a.demoted_from))
+        os.environ["MARIUS_FLASH"] = "0"  # the timed region runs fp32 products
+        H.reload_env()
     sharded_run = world > 1 or os.environ.get("MARIUS_FORCE_SHARDED") == "1"
     check_wanted = (not a.no_arith_check and a.loss.upper() == "SOFTMAX_CE" and cfg["decoder"] in ("DISTMULT", "COMPLEX") and R > 1 and
                     os.environ.get("MARIUS_FLASH", "1") != "0" and flash_selected(H, cfg, B, C, N) and d <= 128)
-    arith = None
+    arith = None if demoted is None else demoted["arith_check"]
+    if a.demoted_from:
+        check_wanted = False
     if rank == 0 and check_wanted and (sharded_run or a.driver != "cpp"):
         arith = arith_check_leg(H, cfg, B, C, N, dev)
     demote = arith is not None and not arith["ok"]
@@ -460,24 +470,20 @@ def main():
             loader.initializeBatches(True)  # setActiveEdges: randperm on the same generator stream
             return loader, model, trainer
 
-        if check_wanted:
+        extra = []
+        if check_wanted and not a.demoted_from:
             # The gate's last input comes from the tables a trainer has worked on: ARITH_PRETRAIN untimed steps of the workload (their own
             # generator seed), then one batch's rows out of the live table.  The timed trainer below starts from a fresh model / loader (seed 42)
             # over the same node table — which has then seen those steps: glorot rows beside trained ones, as in any real epoch.
-            ARITH_PRETRAIN = 200
+            # The check ITSELF (a minute of device work, float64 yardsticks included) runs AFTER the timed region (`deferred_check` below): on
+            # some boxes of the pool the 20 timed steps ran 7-10 % slower right after it (0.61-0.64 vs 0.57 ms; not on others: 0.563 either
+            # way — profiles/r6_driver_window.txt), and a checker must not move the number it guards.  If it then fails, the process
+            # re-executes itself with the fp32 path timed instead (--demoted-from) and the flash figures reported as `fast_path`.
             _, pre_model, pre_trainer = make_trainer(41)
             pre_trainer.train_steps(ARITH_PRETRAIN)
             torch.cuda.synchronize()
             extra = [trained_table_inputs(cfg, B, C, N, table, edges_all, pre_model, dev)] if pre_model.last_step_flash else []
-            del pre_trainer
-            arith = arith_check_leg(H, cfg, B, C, N, dev, extra_inputs=extra)
-            del pre_model
-            if arith is not None:
-                arith["pretrain_steps_before_trained_table_input"] = ARITH_PRETRAIN
-                if not arith["ok"]:
-                    os.environ["MARIUS_FLASH"] = "0"  # the timed region runs fp32 products
-                    H.reload_env()
-            a.arith_check = arith
+            del pre_trainer, pre_model, _
         loader, model, trainer = make_trainer(42)
 
         def run(k0, k):
@@ -506,14 +512,29 @@ def main():
     # microseconds of stream time, and a pair around each of the ~20 kernels of a step inflated the step by 6 %.
     DOMINANT = "lp_grad_adj"
     H.profile_enable(not a.no_profile, only=DOMINANT)
+    allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
     run(a.warmup, a.steps)
     host_issue = time.perf_counter() - t0  # the host loop returns when everything is enqueued; close to dt = the host is the limit
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    allocs_timed = torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0
     H.profile_enable(False)
     prof_timed = H.profile_read()
     U, loss, _, _ = last_stats()
+    step_groups = None
+    if a.step_groups > 0:
+        step_groups = []
+        done_steps = a.warmup + a.steps
+        for _ in range(a.step_groups):
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            run(done_steps, 5)
+            torch.cuda.synchronize()
+            st = torch.cuda.memory_stats()
+            step_groups.append({"ms_per_step": round((time.perf_counter() - tg) / 5 * 1e3, 4), "device_allocs": st.get("num_device_alloc", 0), "device_frees": st.get("num_device_free", 0),
+                                "reserved_gb": round(torch.cuda.memory_reserved() / 1e9, 2)})
+            done_steps += 5
     # Untimed follow-up pass with events around every instrumented kernel: the per-kernel table (`kernels`)
     prof = {}
     if not a.no_profile:
@@ -624,11 +645,24 @@ def main():
     # (MARIUS_FLASH=0), a short pass after the timed region on a fresh Model / loader over the same tables — what the 16-bit-significand
     # contraction of the headline number buys, stated next to it
     fp32_exact = fast_path = None
-    if a.driver == "cpp" and not a.no_fp32_pass and a.loss.upper() == "SOFTMAX_CE":
-        if flash:
-            fp32_exact = alt_arithmetic_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_flops, "0")
-        elif arith is not None and not arith["ok"]:
-            fast_path = alt_arithmetic_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_flops, "1")
+    if a.driver == "cpp" and check_wanted:  # deferred_check: see the note where the trained-table input is drawn
+        arith = arith_check_leg(H, cfg, B, C, N, dev, extra_inputs=extra)
+        if arith is not None:
+            arith["pretrain_steps_before_trained_table_input"] = ARITH_PRETRAIN
+            arith["evaluated"] = "after the timed region (a failing check re-executes the run with the fp32 path timed: --demoted-from)"
+            a.arith_check = arith
+            if not arith["ok"]:
+                import tempfile
+                f = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+                json.dump({"arith_check": arith, "fast_path": {"ms_per_step": round(ms_per_step, 4), "steps": a.steps, "warmup": a.warmup, "value": round(scored_eps, 1), "unit": "scored edges/s",
+                                                                  "note": "the flash path, timed first: NOT the headline because arith_check.ok is false"}}, f)
+                f.close()
+                sys.stdout.flush()
+                os.execv(sys.executable, [sys.executable] + sys.argv + ["--demoted-from", f.name])
+    if demoted is not None:
+        fast_path = demoted["fast_path"]
+    if a.driver == "cpp" and not a.no_fp32_pass and a.loss.upper() == "SOFTMAX_CE" and flash:
+        fp32_exact = alt_arithmetic_pass(M, H, cfg, a, table, state, edges_all, dev, contraction_flops, "0")
 
     # ---- CPU baseline: the oracle (port of the reference's CPU path) on a bounded sample, host cores of this box
     cpu = None
@@ -656,7 +690,7 @@ def main():
             a.workload, cfg["decoder"], d, B, C, N, (" degree_fraction %.2f" % a.degree_fraction) if a.degree_fraction else "", a.edge_dist), "num_nodes": num_nodes, "num_relations": R, "num_edges": cfg["num_edges"],
             "parallelism": "single GPU", "host": "C++ SynchronousTrainer (libtorch)" if a.driver == "cpp" else "python ctypes driver"},
         "positive_edges_per_s": round(pos_eps, 1), "unique_rows_last_batch": U, "loss_last_batch": loss,
-        "roofline": roofline, "arith_check": arith, "fp32_exact": fp32_exact, "fast_path": fast_path, "hbm_read_roofline_gather_score": gs, "kernels": kernels, "cpu_baseline": cpu,
+        "device_allocations_in_timed_region": allocs_timed, "step_groups": step_groups, "roofline": roofline, "arith_check": arith, "fp32_exact": fp32_exact, "fast_path": fast_path, "hbm_read_roofline_gather_score": gs, "kernels": kernels, "cpu_baseline": cpu,
     }
     emit_json(out)
 

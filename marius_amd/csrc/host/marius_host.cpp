@@ -2,7 +2,9 @@
 #include "marius_host.h"
 
 #include <condition_variable>
+#include <array>
 #include <deque>
+#include <map>
 #include <exception>
 #include <mutex>
 #include <thread>
@@ -67,6 +69,23 @@ struct StreamScope {  // make `s` the current torch stream of this thread for th
 };
 }  // namespace
 
+void* aux_stream(int device_index, int which) {
+    static std::mutex mu;
+    static std::map<int, std::array<hipStream_t, AUX_COUNT>> streams;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = streams.find(device_index);
+    if (it == streams.end()) {
+        int prev = 0;
+        HIPCHECK(hipGetDevice(&prev));
+        HIPCHECK(hipSetDevice(device_index));
+        std::array<hipStream_t, AUX_COUNT> a{};
+        for (auto& s : a) HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));  // all three at once, in a fixed order: the same queues in every process
+        HIPCHECK(hipSetDevice(prev));
+        it = streams.emplace(device_index, a).first;
+    }
+    return it->second[which];
+}
+
 MariusGenerator::MariusGenerator(uint64_t seed) {
     state_host_ = torch::zeros({MARIUS_MT_STATE_WORDS}, torch::kInt32);
     marius_mt19937_seed_host((uint32_t*)state_host_.data_ptr<int32_t>(), seed);
@@ -76,13 +95,9 @@ MariusGenerator::~MariusGenerator() {
         if (p.ready) (void)hipEventDestroy((hipEvent_t)p.ready);
         if (p.done) (void)hipEventDestroy((hipEvent_t)p.done);
     }
-    if (side_stream_ && side_stream_owned_) (void)hipStreamDestroy((hipStream_t)side_stream_);
 }
 void MariusGenerator::use_fill_stream(void* hip_stream) {
-    if (side_stream_ && side_stream_owned_) {  // a stream of our own already exists: finish what it holds and destroy it
-        (void)hipStreamSynchronize((hipStream_t)side_stream_);
-        (void)hipStreamDestroy((hipStream_t)side_stream_);
-    }
+    if (side_stream_ && side_stream_owned_) (void)hipStreamSynchronize((hipStream_t)side_stream_);  // the process-wide fill stream: finish what it holds for us
     side_stream_ = hip_stream;
     side_stream_owned_ = false;
     side_ordered_ = false;
@@ -149,11 +164,7 @@ Tensor MariusGenerator::raw_words(int64_t n, torch::Device dev) {
         mcheck(marius_mt19937_fill((uint32_t*)state_dev_.data_ptr<int32_t>(), (uint32_t*)out.data_ptr<int32_t>(), n, (marius_stream_t)main));
         return out;
     }
-    if (!side_stream_) {
-        hipStream_t s;
-        HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        side_stream_ = s;
-    }
+    if (!side_stream_) side_stream_ = aux_stream(dev.index(), AUX_FILL);  // (shared by every generator of the process; never destroyed)
     if (!side_ordered_) {
         // the state upload / earlier direct fills were enqueued on the main stream: order the fill stream (own or the caller's) after them
         hipEvent_t e;
@@ -1478,7 +1489,7 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
     // returning (the next forward reads the relation tables)
     c10::hip::HIPStream main = c10::hip::getCurrentHIPStream(dev_index);
     if (!side_stream_) {
-        side_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(false, dev_index));
+        side_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromExternal((hipStream_t)aux_stream(dev_index, AUX_RELATIONS), dev_index));
         hipEvent_t e0, e1;
         HIPCHECK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
@@ -2075,7 +2086,7 @@ shared_ptr<Batch> DataLoader::getBatch(bool exact_unique) {
     const auto dev_index = edges_->device_.index();
     c10::hip::HIPStream main = c10::hip::getCurrentHIPStream(dev_index);
     if (!loader_stream_) {
-        loader_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromPool(false, dev_index));  // (high priority: measured, no difference)
+        loader_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromExternal((hipStream_t)aux_stream(dev_index, AUX_LOADER), dev_index));
         for (auto& e : ev_pool_) {
             hipEvent_t ev;
             HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));

@@ -55,6 +55,16 @@ enum class DecoderType { DISTMULT, TRANSE, COMPLEX };
 // ------------------------------------------------------------------------------------------------ generator (ATen CPU MT19937 stream)
 // torch::manual_seed(seed) + the global CPU generator of the reference (marius.cpp:47), as an explicit object whose state can
 // live on the host (randperm) or on the device (negative sampling).
+// Process-wide auxiliary streams, one set per device, created together on first use and never destroyed: AUX_LOADER (the DataLoader's batch
+// preparation), AUX_FILL (the generator's run-ahead MT19937 pools), AUX_RELATIONS (the relation-table step underneath the node-table update).
+// Every DataLoader / MariusGenerator / Model of the process shares them.  Round 6 finding: with a stream per OBJECT (torch's pool, or
+// hipStreamCreate in the generator) the second trainer of a process — bench.py builds one for the arithmetic check's pretraining before the timed
+// one — got streams number 4 and 5; the runtime maps streams onto 4 hardware queues, so the timed trainer's loader stream shared a queue with the
+// main stream, its kernels no longer ran underneath the matrix launches, and every step was 60-70 us slower (0.64 vs 0.57 ms) for the rest of
+// the process.
+enum AuxStream { AUX_LOADER = 0, AUX_FILL = 1, AUX_RELATIONS = 2, AUX_COUNT = 3 };
+void* aux_stream(int device_index, int which);  // hipStream_t
+
 class MariusGenerator {
    public:
     explicit MariusGenerator(uint64_t seed);
@@ -86,8 +96,8 @@ class MariusGenerator {
     };
     Pool pools_[2];
     int cur_ = 0;
-    void* side_stream_ = nullptr;  // hipStream_t
-    bool side_stream_owned_ = true;
+    void* side_stream_ = nullptr;  // hipStream_t: the process-wide fill stream (aux_stream) unless a caller lends its own (use_fill_stream)
+    bool side_stream_owned_ = true;  // false: borrowed through use_fill_stream
     bool side_ordered_ = false;  // the fill stream has been ordered behind the state upload
     void fill_pool(int i, torch::Device dev);
     void drop_pools();

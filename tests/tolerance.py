@@ -58,13 +58,23 @@ def well_conditioned(state_ref, floor=1e-8, rel=None):
 GRAD_NOISE = 8e-6
 
 
-def trajectory_close(got, want, state_ref, lr, steps, what, rtol=TRAJECTORY_RTOL):
+def first_touch(first, state):
+    """running record of every element's accumulated g^2 right after the step that first made it non-zero (call after each reference step)"""
+    import torch
+
+    return torch.where((first == 0) & (state > 0), state, first)
+
+
+def trajectory_close(got, want, state_ref, lr, steps, what, rtol=TRAJECTORY_RTOL, first_state=None):
     """Weights after `steps` Adagrad steps from an all-zero state, element by element, with the bound the update rule itself implies instead of a mask:
         |got - want| <= rtol |want| + 0.03 rtol max|want|                  (the tiers' relative and small-entry terms)
                         + min(lr steps, lr steps GRAD_NOISE sqrt(max S / S_i))   (conditioning of w -= lr g / sqrt(S): batch.cpp:67-69)
     where S = the reference path's accumulated g^2.  A coordinate whose gradients were as large as any gets 3e-6 of slack at lr 0.1, eight steps;
     one whose gradients were 1e-3 of the largest gets 3e-3; one whose S is rounding noise gets the whole lr steps (its first step is lr sign(noise)
-    in any arithmetic).  Rows nobody touched (S = 0 throughout the row) must be EQUAL."""
+    in any arithmetic).  Rows nobody touched (S = 0 throughout the row) must be EQUAL.
+    first_state (first_touch): S right after an element's FIRST non-zero gradient.  Step k divides by sqrt(S_k), the sum SO FAR, so an element whose
+    first gradient was small and whose later ones were large is as ill-conditioned as its first step, whatever the final sum says: with it the
+    conditioning term uses S_first instead of the final S."""
     import torch
 
     got, want, S = got.detach().cpu().double(), want.detach().cpu().double(), state_ref.detach().cpu().double()
@@ -76,7 +86,10 @@ def trajectory_close(got, want, state_ref, lr, steps, what, rtol=TRAJECTORY_RTOL
     smax, mx = float(S.max()), max(float(want.abs().max()), 1e-30)
     cond = torch.full_like(S, float(lr * steps))
     pos = S > 0
-    cond[pos] = torch.clamp(lr * steps * GRAD_NOISE * torch.sqrt(smax / S[pos]), max=lr * steps)
+    Sc = S
+    if first_state is not None:
+        Sc = first_state.detach().cpu().double().reshape(S.shape)
+    cond[pos] = torch.clamp(lr * steps * GRAD_NOISE * torch.sqrt(smax / Sc[pos].clamp_min(1e-300)), max=lr * steps)
     allowed = rtol * want.abs() + 0.03 * rtol * mx + cond
     err = (got - want).abs()
     worst = float((err / allowed)[touched].max()) if bool(touched.any()) else 0.0

@@ -8,6 +8,8 @@ for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
 anchors = [r for r in rows if anchor in r["Kernel_Name"]]
+if which < 0:
+    which += len(anchors)
 t0, t1 = anchors[which]["s"], anchors[which + 1]["s"]
 print("step length us", (t1 - t0) / 1e3)
 qkey = "Queue_Id" if "Queue_Id" in rows[0] else "Stream_Id"
