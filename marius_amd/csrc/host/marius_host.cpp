@@ -69,6 +69,19 @@ struct StreamScope {  // make `s` the current torch stream of this thread for th
 };
 }  // namespace
 
+// Flags of every event this file uses to order one stream of the device after another (loader -> main, main -> loader gate, pool fills, the
+// relation side stream): no timing and NO system-scope fence.  A default event makes its record a system-scope release — an L2 write-back the
+// following kernel waits for (measured: the 7 us hole between edge_bwd and seg_reduce on the main queue, where the loader's gate is recorded) —
+// which only a HOST reader of device-written host memory needs, and none of these events has one (the host reads results through
+// torch's own synchronising copies).  MARIUS_EVENT_FENCE=system restores the default (A/B runs).
+unsigned order_event_flags() {
+    static const unsigned f = [] {
+        const char* e = getenv("MARIUS_EVENT_FENCE");
+        return (e && e[0] == 's') ? (unsigned)hipEventDisableTiming : (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
+    }();
+    return f;
+}
+
 void* aux_stream(int device_index, int which) {
     static std::mutex mu;
     static std::map<int, std::array<hipStream_t, AUX_COUNT>> streams;
@@ -168,7 +181,7 @@ Tensor MariusGenerator::raw_words(int64_t n, torch::Device dev) {
     if (!side_ordered_) {
         // the state upload / earlier direct fills were enqueued on the main stream: order the fill stream (own or the caller's) after them
         hipEvent_t e;
-        HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&e, order_event_flags()));
         HIPCHECK(hipEventRecord(e, main));
         HIPCHECK(hipStreamWaitEvent((hipStream_t)side_stream_, e, 0));
         HIPCHECK(hipEventDestroy(e));
@@ -184,8 +197,8 @@ Tensor MariusGenerator::raw_words(int64_t n, torch::Device dev) {
             p.size = want;
             if (!p.ready) {
                 hipEvent_t a, b;
-                HIPCHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-                HIPCHECK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+                HIPCHECK(hipEventCreateWithFlags(&a, order_event_flags()));
+                HIPCHECK(hipEventCreateWithFlags(&b, order_event_flags()));
                 p.ready = a;
                 p.done = b;
             }
@@ -1491,8 +1504,8 @@ void Model::backward_into_tables(shared_ptr<Batch> batch, Tensor table, Tensor s
     if (!side_stream_) {
         side_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromExternal((hipStream_t)aux_stream(dev_index, AUX_RELATIONS), dev_index));
         hipEvent_t e0, e1;
-        HIPCHECK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
-        HIPCHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&e0, order_event_flags()));
+        HIPCHECK(hipEventCreateWithFlags(&e1, order_event_flags()));
         ev_fork_ = e0;
         ev_join_ = e1;
     }
@@ -1852,7 +1865,7 @@ void DataLoader::setActiveEdges() {
 void* DataLoader::gate_event() {
     if (!gate_event_) {
         hipEvent_t e;
-        HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&e, order_event_flags()));
         gate_event_ = e;
     }
     return gate_event_;
@@ -2089,12 +2102,12 @@ shared_ptr<Batch> DataLoader::getBatch(bool exact_unique) {
         loader_stream_ = new c10::hip::HIPStream(c10::hip::getStreamFromExternal((hipStream_t)aux_stream(dev_index, AUX_LOADER), dev_index));
         for (auto& e : ev_pool_) {
             hipEvent_t ev;
-            HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&ev, order_event_flags()));
             e = ev;
         }
         for (auto& e : ev_main_) {
             hipEvent_t ev;
-            HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&ev, order_event_flags()));
             e = ev;
         }
         if (loader_thread_enabled()) {

@@ -64,6 +64,7 @@ enum class DecoderType { DISTMULT, TRANSE, COMPLEX };
 // the process.
 enum AuxStream { AUX_LOADER = 0, AUX_FILL = 1, AUX_RELATIONS = 2, AUX_COUNT = 3 };
 void* aux_stream(int device_index, int which);  // hipStream_t
+unsigned order_event_flags();  // hipEventCreateWithFlags flags of stream-ordering events (no timing, no system-scope fence)
 
 class MariusGenerator {
    public:

@@ -91,7 +91,8 @@ void prof_begin(int id, hipStream_t st, ProfMark& m) {
     m.id = -1;
     if (!g_prof_on) return;
     if (g_prof_on >= 2 && id != g_prof_on - 2) return;  // single-kernel mode
-    if (hipEventCreate(&m.a) != hipSuccess || hipEventCreate(&m.b) != hipSuccess) return;
+    // device-scope release: a default event's record is a system-scope fence (L2 write-back) the bracketed kernel and its successor pay for
+    if (hipEventCreateWithFlags(&m.a, hipEventReleaseToDevice) != hipSuccess || hipEventCreateWithFlags(&m.b, hipEventReleaseToDevice) != hipSuccess) return;
     m.id = id;
     (void)hipEventRecord(m.a, st);
 }
