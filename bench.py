@@ -571,7 +571,9 @@ def main():
         # counted, their few thousand touched table rows are not)
         "segment_adagrad_scatter": ("hbm", L * d * 4.0 + U * d * 4.0 * 4 + (2.0 * B * d * 4.0 if R > 1 else 0.0)),
         "lp_lse": ("hbm", 2.0 * Bp * (math.ceil(math.ceil(N / 64) / 4) * 8.0 + 12.0)),  # fused SoftmaxCE: only the per-group partials are re-read
-        "lp_prep": ("hbm", 2.0 * Bp * d * 4.0 * 4),
+        # prep: both endpoint rows of every edge read once, the touched relation rows of both tables, one operand record per row and direction written
+        # (the old 4 rows x 2 directions over-stated what the launch must move; the PMC pass counts 104 MB)
+        "lp_prep": ("hbm", B * 2 * d * 4.0 + ndir * min(R, B) * d * 4.0 + ndir * Bp * (4.0 * 16 * math.ceil(d / 16) + 16 + 4)),
         "lp_pack": ("hbm", ndir * C * N * (d * 4.0 * 2 + 4.0 * 16 * math.ceil(d / 16) + 16)),  # negatives: rows read, gocc rows zeroed, operand records written
         "lp_edge_bwd": ("hbm", 2.0 * B * d * 4.0 * 6),
         "sort_unique": ("hbm", L * (8.0 + 4.0) * 2 * 4),
