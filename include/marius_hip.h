@@ -49,10 +49,10 @@ enum {
  * marius_table_absmax_counted; marius_lp_layout lost the operand planes of the removed bf16x6 kernels and the stream-K partials; 8:
  * marius_lp_desc.upd_*, marius_segment_update.fused_below, marius_lp_fuses_endpoint_update, marius_segment_plan_occ_single; 9: the
  * fixed-capacity exchange entry points marius_a2a_capacity / marius_a2a_rows_post / marius_a2a_rows_wait, negative ids = padding slots in
- * marius_merge_unique_runs / marius_segment_plan; 10: marius_a2a_publish / marius_a2a_record_* / marius_owner_offsets_counts, marius_layer_post_hook*, marius_prepare_maps).  Every binder
+ * marius_merge_unique_runs / marius_segment_plan; 10: marius_a2a_publish / marius_a2a_record_* / marius_owner_offsets_counts, marius_layer_post_hook*, marius_prepare_maps; 11: marius_lp_layout.flash_cfg, marius_prepare_maps_preferred, the neighbour-sampling / GraphSage entry points marius_nbr_* and marius_segment_gather_sum).  Every binder
  * compares the value it was built against with what the loaded library returns and refuses to run on a mismatch: marius_amd/hip.py lib(),
  * the host module's init (bindings.cpp), and the plug-in recipe of INTEGRATION.md. */
-#define MARIUS_HIP_ABI_VERSION 10
+#define MARIUS_HIP_ABI_VERSION 11
 int marius_hip_abi_version(void);
 /* The MARIUS_* environment switches of the kernel library (test / A-B selectors; a production run sets none) are read ONCE, when the
  * library is loaded.  A process that changes one afterwards (the parity tests do, to reach a non-default kernel) calls this to re-read them. */
@@ -396,7 +396,9 @@ typedef struct marius_lp_layout {
     size_t negrec;    /* flash path: negative operand records [ndir C][N  rounded to 32][4 kp + 16 B]                              */
     size_t fpart;     /* flash path: SoftmaxCE partials [2][ndir Bp] (max, sum exp)                                                  */
     int32_t flash;    /* 1 when marius_lp_plan selected the flash path for this descriptor (then neg[] = 0 unless STORE_SCORES)      */
-    int32_t reserved_;
+    int32_t flash_cfg;/* flash path: the record layout the plan sized its buffers for (column chunks, folded tail), checked by every launch that uses
+                       * the layout: MARIUS_ERR_INVALID instead of records written past their buffers when MARIUS_FLASH_* changed in between
+                       * (marius_config_reload)                                                                                      */
 } marius_lp_layout;
 
 int marius_lp_plan(const marius_lp_desc* desc, marius_lp_layout* layout);
@@ -506,6 +508,44 @@ int marius_table_absmax(const float* table, int64_t rows, int64_t ld, int32_t d,
 /* The same over the first *num_rows_dev rows (a device count: the unique count of map_tensors) of a capacity-sized row buffer. */
 int marius_table_absmax_counted(const float* table, int64_t capacity, const int64_t* num_rows_dev, int64_t ld, int32_t d, float* absmax,
                                 marius_stream_t stream);
+
+/* ---- DENSE neighbour sampling and GraphSage aggregation (cfg4; first slice, round 6): neighbor.hip ------------------------------------------
+ * The graph is the reference's MariusGraph (src/cpp/src/data/graph.cpp:16-44): an edge list sorted by destination (incoming neighbours) or by
+ * source (outgoing), [E, cols] int64, with per-node first-edge offsets and degrees [num_nodes].
+ *
+ * marius_nbr_degrees: MariusGraph::getNeighborsForNodeIds up to the sampler (graph.cpp:128-189) + the capping of sample_uniform_gpu
+ *   (src/cpp/src/data/samplers/neighbor.cpp:84-88): num[i] = degree of node_ids[i], global_offsets[i] = its first edge, capped[i] = min(num[i],
+ *   max_neighbors) (max_neighbors < 0: NeighborSamplingLayer::ALL, capped = num), local_offsets = exclusive scan of capped, *total_dev = its sum.
+ * marius_nbr_gather: sample_all_gpu (neighbor.cpp:9-17) / sample_uniform_gpu (neighbor.cpp:81-105): out_edges[p] = sorted_edges[global_offsets[i] + j], i the
+ *   owner of output p, j = p - local_offsets[i] where the node keeps all its neighbours, rand_samples[p] % num[i] where it has more than
+ *   max_neighbors (rand_samples [total]: the reference's torch::randint(max_degree, [total]) — drawn by the caller, as the MT19937 words of the
+ *   negative sampler are; NULL for ALL).  total = the host's copy of *total_dev (the reference reads it with .item() at the same point).
+ * marius_nbr_delta_ids: the ids the next hop expands (neighbor.cpp:515-529, device branch: bitmap + nonzero()): ascending unique ids among
+ *   column 0 of in_edges and the last column of out_edges (either list may be empty) that are not in node_ids.  marks: [num_nodes] bytes, all zero
+ *   on entry and on return (allocated once per graph); keys: [n_in + n_out] scratch; uniq .. workspace: as marius_sort_unique over n_in + n_out ids
+ *   (uniq[0 .. *num_unique_dev) is the result).  O(batch), where the reference zero-fills and scans num_nodes entries per hop.
+ * marius_nbr_positions: DENSEGraph::performMap (graph.cpp:361-398): out[t] = position in node_ids of edges[t, col]; table: [num_nodes] int64
+ *   scratch (no initialisation needed: every id looked up is in node_ids).
+ * marius_segment_gather_sum: GraphSageLayer::forward up to the matmuls (src/cpp/src/nn/layers/gnn/graph_sage_layer.cpp:37-90, layer_helpers.cpp:11-30):
+ *   out[s] = sum over list a's segment s of rows[index_a[t]] (+ the same over list b: outgoing + incoming), rows added IN INDEX ORDER (the CPU
+ *   index_add_ order: bit-identical), then mode 1 (MEAN): / where(deg != 0, deg, 1), mode 2 (GCN): (sum + self_rows[s]) / (deg + 1), deg = deg_a
+ *   (+ deg_b).  offsets_*: [n] segment starts.  pre_div (optional, [rows]): every gathered row is divided by (float)pre_div[its row index] first —
+ *   with index = the segment id of every occurrence of an input row (sorted by input row: marius_sort_unique's perm) this is the backward of
+ *   the gather + mean.  d <= 512. */
+size_t marius_nbr_workspace_bytes(int64_t n);
+int marius_nbr_degrees(const int64_t* node_ids, int64_t n, const int64_t* num_neighbors_tbl, const int64_t* offsets_tbl, int64_t max_neighbors, int64_t* num,
+                       int64_t* global_offsets, int64_t* capped, int64_t* local_offsets, int64_t* total_dev, void* workspace, size_t workspace_bytes,
+                       marius_stream_t stream);
+int marius_nbr_gather(const int64_t* sorted_edges, int32_t cols, const int64_t* num, const int64_t* global_offsets, const int64_t* local_offsets,
+                      const int64_t* capped, int64_t n, const int64_t* rand_samples, int64_t total, int64_t* out_edges, marius_stream_t stream);
+int marius_nbr_delta_ids(const int64_t* in_edges, int64_t n_in, const int64_t* out_edges, int64_t n_out, int32_t cols, const int64_t* node_ids,
+                         int64_t n_node_ids, int64_t num_nodes, uint8_t* marks, int64_t* keys, int64_t* uniq, int64_t* inverse, int32_t* perm,
+                         int32_t* seg_offsets, int64_t* num_unique_dev, void* sort_workspace, size_t sort_workspace_bytes, marius_stream_t stream);
+int marius_nbr_positions(const int64_t* node_ids, int64_t n, const int64_t* edges, int32_t cols, int32_t col, int64_t T, int64_t* table, int64_t* out,
+                         marius_stream_t stream);
+int marius_segment_gather_sum(const float* rows, int64_t rows_ld, int32_t d, const int64_t* index_a, const int64_t* offsets_a, int64_t T_a,
+                              const int64_t* index_b, const int64_t* offsets_b, int64_t T_b, int64_t n, const int64_t* pre_div, const int64_t* deg_a,
+                              const int64_t* deg_b, int32_t mode, const float* self_rows, int64_t self_ld, float* out, int64_t out_ld, marius_stream_t stream);
 
 #ifdef __cplusplus
 }

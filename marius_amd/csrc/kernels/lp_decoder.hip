@@ -1281,6 +1281,12 @@ static bool vlog_path(const LpDims& D) {
 
 static bool flash_store_scores(const marius_lp_desc* d) { return (d->flags & MARIUS_LP_STORE_SCORES) != 0; }
 
+// what of the environment the flash buffers of a layout were sized for: (column chunks << 8) | folded tail | valid bit
+static int flash_cfg_now(int d) { return 0x10000 | (flash_chunks(d) << 8) | (flash_tail4(d) ? 1 : 0); }
+#define MARIUS_REQUIRE_FLASH_CFG(L, D, who)                                                                                                         \
+    MARIUS_REQUIRE(!(L)->flash || (L)->flash_cfg == flash_cfg_now((D).d),                                                                            \
+                   who ": the flash record layout changed between marius_lp_plan and this launch (MARIUS_FLASH_TAIL4 / MARIUS_FLASH_WIDE reloaded?): plan again")
+
 static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layout* L) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -1300,7 +1306,7 @@ static int make_layout(const marius_lp_desc* d, const LpDims& D, marius_lp_layou
     for (int dir = 0; dir < D.ndir; ++dir) L->pos[dir] = base + (size_t)dir * rows * 4;
     const bool flash = kernel_level() == 2 && flash_applicable(d, D);
     L->flash = flash ? 1 : 0;
-    L->reserved_ = 0;
+    L->flash_cfg = flash ? flash_cfg_now(D.d) : 0;
     if (!flash || flash_store_scores(d) || flash_chunked(D.d)) {  // the flash path never materialises the scores — except for rows wider than 128 columns
         size_t sbytes = rows * D.n_ld * 4 * D.ndir;
         if (flash && flash_chunked(D.d) && flash_tiled_scores_bytes(D) > sbytes) sbytes = flash_tiled_scores_bytes(D);  // tile order needs whole tiles
@@ -1378,6 +1384,7 @@ extern "C" int marius_lp_forward(const marius_lp_desc* desc, const marius_lp_lay
     MARIUS_REQUIRE(L && workspace && desc->emb && desc->edges && desc->dst_neg, "lp_forward: null pointer");
     MARIUS_REQUIRE(desc->emb_ld >= desc->d, "lp_forward: emb_ld < d");
     MARIUS_REQUIRE(desc->edge_cols == 2 || desc->rel, "lp_forward: relations missing for 3-column edges");
+    MARIUS_REQUIRE_FLASH_CFG(L, D, "lp_forward");
     hipStream_t st = as_stream(stream);
     char* ws = (char*)workspace;
     const bool l2 = (D.cmp == MARIUS_CMP_L2);
@@ -1495,6 +1502,7 @@ extern "C" int marius_lp_loss(const marius_lp_desc* desc, const marius_lp_layout
     int rc = fill_dims(desc, D);
     if (rc) return rc;
     MARIUS_REQUIRE(L && workspace, "lp_loss: null pointer");
+    MARIUS_REQUIRE_FLASH_CFG(L, D, "lp_loss");
     hipStream_t st = as_stream(stream);
     char* ws = (char*)workspace;
     const int64_t rows = D.Bp * D.ndir;
@@ -1544,6 +1552,7 @@ extern "C" int marius_lp_backward(const marius_lp_desc* desc, const marius_lp_la
     int rc = fill_dims(desc, D);
     if (rc) return rc;
     MARIUS_REQUIRE(L && workspace, "lp_backward: null pointer");
+    MARIUS_REQUIRE_FLASH_CFG(L, D, "lp_backward");
     hipStream_t st = as_stream(stream);
     char* ws = (char*)workspace;
     const bool l2 = (D.cmp == MARIUS_CMP_L2);

@@ -18,7 +18,7 @@ REDUCE_SUM, REDUCE_MEAN = 0, 1
 LOSS = {"SOFTMAX_CE": 0, "RANKING": 1, "CROSS_ENTROPY": 2, "BCE_AFTER_SIGMOID": 3, "BCE_WITH_LOGITS": 4, "MSE": 5, "SOFTPLUS": 6}
 LP_TRAIN_ONLY, LP_STORE_SCORES, LP_KEEP_DADJ = 1, 2, 4   # marius_lp_desc.flags
 MT_STATE_WORDS = 625
-ABI_VERSION = 10  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
+ABI_VERSION = 11  # include/marius_hip.h MARIUS_HIP_ABI_VERSION
 
 
 class MariusHipError(RuntimeError):
@@ -46,7 +46,7 @@ class LpLayout(C.Structure):
         ("rowloss", C.c_size_t * 2), ("loss", C.c_size_t), ("dadj", C.c_size_t * 2), ("gocc", C.c_size_t),
         ("grel", C.c_size_t * 2), ("aux", C.c_size_t), ("lsepart", C.c_size_t), 
         ("dpos", C.c_size_t * 2), ("vlog", C.c_size_t), ("adjrec", C.c_size_t), ("negrec", C.c_size_t), ("fpart", C.c_size_t),
-        ("flash", C.c_int32), ("reserved_", C.c_int32),
+        ("flash", C.c_int32), ("flash_cfg", C.c_int32),
     ]
 
 
@@ -102,6 +102,12 @@ SIGNATURES = {
     "marius_layer_post_hook_backward": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "marius_prepare_maps_supported": (C.c_int, [C.POINTER(MapJob), _i32]),
     "marius_prepare_maps_preferred": (C.c_int, []),
+    "marius_nbr_workspace_bytes": (_sz, [_i64]),
+    "marius_nbr_degrees": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "marius_nbr_gather": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "marius_nbr_delta_ids": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "marius_nbr_positions": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i64, _vp, _vp, _vp]),
+    "marius_segment_gather_sum": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp]),
     "marius_prepare_maps": (C.c_int, [C.POINTER(MapJob), _i32, _vp]),
     "marius_owner_offsets_counts": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "marius_a2a_record_words": (_i32, [_i32]),

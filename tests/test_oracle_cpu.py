@@ -390,3 +390,85 @@ def test_only_the_checker_legs_touch_the_oracle():
     for m in re.finditer(r"^\s*(from|import)\s+oracle\b", src, re.M):
         owner = legs[max(s for s in starts if s <= m.start())]
         assert owner in ("cpu_baseline_leg", "arith_check_leg"), owner
+
+
+# ------------------------------------------------------------------------------------------------ cfg4 slice: neighbour sampling / GraphSage oracle
+def _nbr_graph(num_nodes, E, cols, seed, hubs=True):
+    from oracle import neighbor_oracle as NO
+
+    g = torch.Generator().manual_seed(seed)
+    src, dst = torch.randint(num_nodes, (E,), generator=g), torch.randint(num_nodes, (E,), generator=g)
+    if hubs:
+        dst[torch.rand(E, generator=g) < 0.2] = 3          # one node with a fifth of all edges coming in
+        src[torch.rand(E, generator=g) < 0.1] = 5
+    lonely = num_nodes - 1                                  # a node without any edge
+    src[src == lonely] = 0
+    dst[dst == lonely] = 1
+    edges = torch.stack([src, torch.randint(7, (E,), generator=g), dst], 1) if cols == 3 else torch.stack([src, dst], 1)
+    return NO.MariusGraph.from_edges(edges, num_nodes), edges
+
+
+def test_neighbor_oracle_properties():
+    """oracle/neighbor_oracle.py is the reference's ATen op sequence (neighbor.cpp:9-105, 402-582, graph.cpp:16-44, 128-236, 290-398); the reference holds
+    no known answers for it, so it is pinned by what the algorithm implies: ALL returns exactly the node's neighbour slice, in list order; UNIFORM
+    returns min(degree, k) edges per node, each one an edge OF that node; the layered batch has unique ids, hop by hop, every hop's ids ascending and
+    absent from the later hops; the mappings point at the right ids; the aggregation equals a dense float64 mean."""
+    from oracle import neighbor_oracle as NO
+
+    for cols in (2, 3):
+        graph, edges = _nbr_graph(200, 3000, cols, seed=cols)
+        ids = torch.tensor([3, 199, 5, 17, 17, 0])  # hub, lonely node, repeated id
+        got, offs = NO.neighbors_for_node_ids(graph, ids, True)
+        for i, v in enumerate(ids.tolist()):
+            want = graph.dst_sorted_edges[graph.dst_sorted_edges[:, -1] == v]
+            end = offs[i + 1] if i + 1 < len(ids) else got.size(0)
+            assert torch.equal(got[offs[i]:end], want)
+        k = 4
+        num = graph.out_num_neighbors.index_select(0, ids)
+        total = NO.uniform_total(num, k)
+        rs = torch.randint(graph.max_out_num_neighbors, (total,), generator=torch.Generator().manual_seed(9))
+        got, offs = NO.neighbors_for_node_ids(graph, ids, False, k, rs)
+        assert got.size(0) == total == int(num.clamp(max=k).sum())
+        for i, v in enumerate(ids.tolist()):
+            end = offs[i + 1] if i + 1 < len(ids) else got.size(0)
+            mine = got[offs[i]:end]
+            assert mine.size(0) == min(int(num[i]), k) and bool((mine[:, 0] == v).all())
+            allowed = {tuple(r) for r in graph.src_sorted_edges[graph.src_sorted_edges[:, 0] == v].tolist()}
+            assert all(tuple(r) in allowed for r in mine.tolist())
+            if int(num[i]) <= k:  # not capped: every neighbour, in list order
+                assert torch.equal(mine, graph.src_sorted_edges[graph.src_sorted_edges[:, 0] == v])
+        # layered, incoming + outgoing, three hops
+        rg = torch.Generator().manual_seed(4)
+        seeds = torch.tensor([7, 3, 150, 199])
+        dg = NO.layered_neighbors(graph, seeds, [5, -1, 2], True, True, rand=lambda i, inc, t: torch.randint(1 << 30, (t,), generator=rg))
+        assert dg.node_ids.unique().numel() == dg.node_ids.numel() and torch.equal(dg.node_ids[-4:], seeds)
+        ho = dg.hop_offsets.tolist()
+        assert ho[0] == 0 and ho[-1] == dg.node_ids.numel() and ho == sorted(ho) and len(ho) == 3 + 2
+        for a, b in zip(ho[:-2], ho[1:-1]):  # every hop's new ids ascend (nonzero() of a bitmap)
+            assert bool((dg.node_ids[a:b][1:] > dg.node_ids[a:b][:-1]).all())
+        NO.perform_map(dg)
+        assert torch.equal(dg.node_ids[dg.in_neighbors_mapping], dg.dst_sorted_edges[:, 0]) and torch.equal(dg.node_ids[dg.out_neighbors_mapping], dg.src_sorted_edges[:, -1])
+        # the rows of in_offsets / out_offsets are the nodes of node_ids from hop 1 on, and each segment holds edges of exactly that node
+        owners = dg.node_ids[ho[1]:]
+        assert dg.in_offsets.numel() == owners.numel() == dg.out_offsets.numel()
+        seg = NO.segment_ids_from_offsets(dg.in_offsets, dg.dst_sorted_edges.size(0))
+        assert torch.equal(owners[seg], dg.dst_sorted_edges[:, -1])
+        seg = NO.segment_ids_from_offsets(dg.out_offsets, dg.src_sorted_edges.size(0))
+        assert torch.equal(owners[seg], dg.src_sorted_edges[:, 0])
+        # aggregation against a dense float64 mean
+        x = torch.randn(dg.node_ids.numel(), 12, generator=rg)
+        a_i, self_rows = NO.graph_sage_aggregate(x, dg, "MEAN")
+        n = owners.numel()
+        want = torch.zeros(n, 12, dtype=torch.float64)
+        cnt = torch.zeros(n, dtype=torch.float64)
+        for m, offs_, T in ((dg.out_neighbors_mapping, dg.out_offsets, dg.src_sorted_edges.size(0)), (dg.in_neighbors_mapping, dg.in_offsets, dg.dst_sorted_edges.size(0))):
+            s = NO.segment_ids_from_offsets(offs_, T)
+            want.index_add_(0, s, x[m].double())
+            cnt.index_add_(0, s, torch.ones(T, dtype=torch.float64))
+        want = want / cnt.clamp(min=1).unsqueeze(-1)
+        assert torch.allclose(a_i.double(), want, rtol=1e-5, atol=1e-6) and torch.equal(self_rows, x[ho[1]:])
+        # next layer: the finished hop's nodes and their neighbour segments are dropped, ids shift
+        before = dg.node_ids.clone()
+        NO.prepare_for_next_layer(dg)
+        assert torch.equal(dg.node_ids, before[ho[1]:]) and int(dg.hop_offsets[0]) == 0
+        assert torch.equal(dg.node_ids[dg.in_neighbors_mapping], dg.dst_sorted_edges[:, 0])
