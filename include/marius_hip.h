@@ -252,6 +252,9 @@ int marius_owner_offsets(const int64_t* uniq, const int64_t* num_unique_dev, int
  * src/cpp/src/data/batch.cpp:21-60,81-103).  The transport between the two halves is ONE equal-split all-to-all per payload, issued by the
  * host on its communicator (ncclAllToAll(send, recv, cap * width, type, comm, stream) / c10d alltoall_base with empty split vectors): every
  * (requester, owner) pair owns `cap` slots, so no split size — and no device -> host read-back — is needed.  See INTEGRATION.md.
+ * Neither half takes a communicator (SURVEY.md 8(b) sketched `a2a_rows_{post,wait}(comm, ...)`): by design this library issues no
+ * collective and does not link RCCL — the communicator belongs to whoever hosts the training loop (c10d's ProcessGroupNCCL here, an
+ * ncclComm_t per device in a binding of the reference), and the same two halves then serve any transport.
  *
  * marius_a2a_capacity: the planned maximum of rows one requester asks of one owner — max_rows (the batch's id capacity 2 B + 2 C N) for
  * world 1, else ceil(slack * max_rows / world) rounded up to 256 (slack >= 1; ids are spread evenly over the owners when node ids are
