@@ -19,7 +19,10 @@ def build(force=False):
         return lib
     shutil.copyfile(src, os.path.join(out_dir, "neighbor.hip.inc"))
     shutil.copyfile(os.path.join(HERE, "neighbor_emul.cpp"), os.path.join(out_dir, "neighbor_emul.cpp"))
-    cmd = ["g++", "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wno-unknown-pragmas", "-I" + HERE, "-I" + os.path.join(ROOT, "include"),
+    cmd = ["g++", "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wno-unknown-pragmas",
+           # -Bsymbolic: the emulated library defines the SAME symbols as libmarius_hip.so (entry points, and the kernels' names, which are host-side launch
+           # stubs there); a process that has the HIP library loaded globally (marius_amd.host() does) must not get them interposed into this one
+           "-Wl,-Bsymbolic", "-I" + HERE, "-I" + os.path.join(ROOT, "include"),
            os.path.join(out_dir, "neighbor_emul.cpp"), "-o", lib]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
