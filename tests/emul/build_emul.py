@@ -9,11 +9,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 
 
-def build(force=False):
+def build(force=False, sanitize=False):
+    """sanitize: -fsanitize=address,undefined (load it into a python started with LD_PRELOAD=libasan.so: tests/test_neighbor_emul_cpu.py does)"""
     out_dir = os.path.join(HERE, "_build")
     os.makedirs(out_dir, exist_ok=True)
     src = os.path.join(ROOT, "marius_amd", "csrc", "kernels", "neighbor.hip")
-    lib = os.path.join(out_dir, "libneighbor_emul.so")
+    lib = os.path.join(out_dir, "libneighbor_emul_asan.so" if sanitize else "libneighbor_emul.so")
     deps = [src, os.path.join(HERE, "common.h"), os.path.join(HERE, "neighbor_emul.cpp"), os.path.join(ROOT, "include", "marius_hip.h")]
     if not force and os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
         return lib
@@ -23,7 +24,7 @@ def build(force=False):
            # -Bsymbolic: the emulated library defines the SAME symbols as libmarius_hip.so (entry points, and the kernels' names, which are host-side launch
            # stubs there); a process that has the HIP library loaded globally (marius_amd.host() does) must not get them interposed into this one
            "-Wl,-Bsymbolic", "-I" + HERE, "-I" + os.path.join(ROOT, "include"),
-           os.path.join(out_dir, "neighbor_emul.cpp"), "-o", lib]
+           os.path.join(out_dir, "neighbor_emul.cpp"), "-o", lib] + (["-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else [])
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("emulation build failed:\n" + r.stdout)
@@ -32,3 +33,4 @@ def build(force=False):
 
 if __name__ == "__main__":
     print(build(force=True))
+    print(build(force=True, sanitize=True))
