@@ -235,12 +235,30 @@ class _Aggregate(torch.autograd.Function):
         return grad_in, None, None, None, None
 
 
-class GraphSageLayer(torch.nn.Module):
-    """graph_sage_layer.cpp:10-96.  aggregator: "MEAN" (w1 self + w2 mean(neighbours)) or "GCN" (w1 mean(neighbours + self)); bias: Layer::post_hook's"""
+class _PostHook(torch.autograd.Function):
+    """Layer::post_hook (layer.cpp:9-16) on the HIP kernels of encoder.hip: act(x + bias) and its backward (deterministic column sums for bias.grad)"""
 
-    def __init__(self, input_dim, output_dim, aggregator="MEAN", bias=False, device="cuda:0"):
+    @staticmethod
+    def forward(ctx, x, bias, activation):
+        y = H.layer_post_hook(x.contiguous(), bias, activation)
+        ctx.activation, ctx.with_bias = activation, bias is not None
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gx, bg = H.layer_post_hook_backward(gy.contiguous(), y, ctx.activation, with_bias=ctx.with_bias)
+        return gx, bg, None
+
+
+class GraphSageLayer(torch.nn.Module):
+    """graph_sage_layer.cpp:10-96.  aggregator: "MEAN" (w1 self + w2 mean(neighbours)) or "GCN" (w1 mean(neighbours + self)); bias / activation:
+    the layer's post-hook (layer.cpp:9-16; GeneralEncoder::forward applies it right after the layer, encoder.cpp:236-238)"""
+
+    def __init__(self, input_dim, output_dim, aggregator="MEAN", bias=False, device="cuda:0", activation="NONE"):
         super().__init__()
-        self.aggregator = aggregator
+        self.aggregator, self.activation = aggregator, activation
         glorot = lambda: torch.nn.init.xavier_uniform_(torch.empty(output_dim, input_dim, device=device))  # noqa: E731
         self.w1 = torch.nn.Parameter(glorot())
         self.w2 = torch.nn.Parameter(glorot()) if aggregator == "MEAN" else None
@@ -267,6 +285,45 @@ class GraphSageLayer(torch.nn.Module):
             out = (torch.matmul(self.w1, self_embs.transpose(0, -1)) + torch.matmul(self.w2, a_i.transpose(0, -1))).transpose(0, -1)
         else:
             out = torch.matmul(self.w1, self_embs.transpose(0, -1)).transpose(0, -1)
-        if self.bias is not None:
-            out = out + self.bias
+        if self.bias is not None or self.activation != "NONE":
+            out = _PostHook.apply(out, self.bias, self.activation)
         return out
+
+
+class GraphSageEncoder(torch.nn.Module):
+    """GeneralEncoder::forward (src/cpp/src/nn/encoders/encoder.cpp:195-257) for cfg4's shape: a FEATURE stage (the batch's feature rows as they are)
+    followed by GraphSage stages; performMap first, prepareForNextLayer between GNN stages.  dims: [feature_dim, hidden ..., num_classes]."""
+
+    def __init__(self, dims, aggregator="MEAN", activation="RELU", bias=True, device="cuda:0"):
+        super().__init__()
+        n = len(dims) - 1
+        self.layers = torch.nn.ModuleList([GraphSageLayer(dims[i], dims[i + 1], aggregator, bias=bias, device=device, activation=activation if i < n - 1 else "NONE")
+                                           for i in range(n)])
+
+    def forward(self, features, dense_graph, train=True):
+        dense_graph.performMap()
+        out = features
+        for i, layer in enumerate(self.layers):
+            out = layer(out, dense_graph, train)
+            if i < len(self.layers) - 1:
+                dense_graph.prepareForNextLayer()
+        return out
+
+
+def node_classification_step(encoder, features, dense_graph, labels, lr, reduction="sum"):
+    """Model::train_batch, NODE_CLASSIFICATION branch (src/cpp/src/nn/model.cpp:317-328): y_pred for the batch's target nodes, CrossEntropyLoss
+    (src/cpp/src/nn/loss.cpp:88-102), backward, the dense Adagrad step of every layer parameter (marius_dense_adagrad_step: optim.cpp:114-145;
+    the sums live in `.adagrad_sum` of the parameters).  Returns (loss, y_pred)."""
+    for p in encoder.parameters():
+        p.grad = None
+    y = encoder(features, dense_graph, True)
+    loss = torch.nn.functional.cross_entropy(y, labels.to(torch.int64), reduction=reduction)
+    loss.backward()
+    with torch.no_grad():
+        for p in encoder.parameters():
+            if p.grad is None:
+                continue
+            if not hasattr(p, "adagrad_sum"):
+                p.adagrad_sum = torch.zeros_like(p)
+            H.dense_adagrad_step(p.data, p.adagrad_sum, p.grad.contiguous(), lr)
+    return loss.detach(), y.detach()

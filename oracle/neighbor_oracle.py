@@ -260,3 +260,47 @@ def graph_sage_forward(inputs, g, w1, w2=None, bias=None, aggregator="MEAN"):
     if bias is not None:
         out = out + bias
     return out
+
+
+def post_hook(x, bias, activation):
+    """Layer::post_hook (src/cpp/src/nn/layers/layer.cpp:9-16): x + bias, then apply_activation (src/cpp/src/nn/activation.cpp:7-21)"""
+    if bias is not None:
+        x = x + bias
+    if activation == "RELU":
+        x = torch.relu(x)
+    elif activation == "SIGMOID":
+        x = torch.sigmoid(x)
+    return x
+
+
+def encoder_forward(features, g, layers):
+    """GeneralEncoder::forward (src/cpp/src/nn/encoders/encoder.cpp:195-257) for the cfg4 shape: a FEATURE stage followed by GraphSage stages —
+    layers: [(w1, w2, bias, aggregator, activation)]; performMap first, prepareForNextLayer between GNN stages (not after the last)."""
+    perform_map(g)
+    out = features.narrow(0, 0, features.size(0))  # FeatureLayer::forward is the identity on the batch's feature rows
+    for i, (w1, w2, bias, aggregator, activation) in enumerate(layers):
+        out = graph_sage_forward(out, g, w1, w2, None, aggregator)
+        out = post_hook(out, bias, activation)
+        if i < len(layers) - 1:
+            prepare_for_next_layer(g)
+    return out
+
+
+def node_classification_step(features, g, layers, labels, lr):
+    """Model::train_batch, NODE_CLASSIFICATION branch (src/cpp/src/nn/model.cpp:317-328): y_pred = encoder output of the batch's target nodes,
+    loss = cross_entropy(y_pred, labels) (CrossEntropyLoss, src/cpp/src/nn/loss.cpp:88-102, reduction sum), backward, dense Adagrad step of every
+    layer parameter (optim.cpp:59-110: sum += g^2; w -= lr g / (sqrt(sum) + 1e-10)).  Returns (loss, y_pred); parameters are updated in place,
+    their Adagrad sums live in `.adagrad_sum` attributes."""
+    params = [p for layer in layers for p in layer[:3] if p is not None]
+    for p in params:
+        p.grad = None
+    y = encoder_forward(features, g, layers)
+    loss = torch.nn.functional.cross_entropy(y, labels, reduction="sum")
+    loss.backward()
+    with torch.no_grad():
+        for p in params:
+            if not hasattr(p, "adagrad_sum"):
+                p.adagrad_sum = torch.zeros_like(p)
+            p.adagrad_sum.addcmul_(p.grad, p.grad, value=1.0)
+            p.addcdiv_(p.grad, p.adagrad_sum.sqrt().add_(1e-10), value=-lr)
+    return loss.detach(), y.detach()

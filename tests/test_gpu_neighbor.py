@@ -200,3 +200,46 @@ def test_papers100m_shaped_hop_properties(G, dev):
     a_i, _ = layer.aggregate(x, dg)
     has = (dg.in_num_neighbors_ > 0).float().unsqueeze(-1)
     assert torch.equal(a_i, has.expand_as(a_i))
+
+
+@pytest.mark.parametrize("aggregator,inc,out", [("MEAN", True, False), ("GCN", True, True)])
+def test_three_layer_encoder_and_node_classification_steps(G, dev, aggregator, inc, out):
+    """cfg4's shape end to end: DENSE sample -> three GraphSage stages (aggregation: neighbor.hip; bias + RELU: encoder.hip's post-hook kernels) ->
+    cross-entropy over the target nodes -> backward -> marius_dense_adagrad_step, three consecutive steps, against the oracle's restatement of
+    GeneralEncoder::forward (encoder.cpp:195-257) and Model::train_batch's NODE_CLASSIFICATION branch (model.cpp:317-328)."""
+    dims, classes = [100, 64, 32, 7], 7
+    og = make_graph(4000, 60000, 2, seed=13)
+    dgraph = to_device(G, og, dev)
+    gen = torch.Generator().manual_seed(3)
+    feats = torch.randn(4000, dims[0], generator=gen)
+    labels_all = torch.randint(classes, (4000,), generator=gen)
+    enc = G.GraphSageEncoder(dims, aggregator, "RELU", bias=True, device=dev)
+    ref_layers = []
+    for layer in enc.layers:
+        with torch.no_grad():
+            layer.bias.copy_(0.1 * torch.randn(layer.bias.shape, generator=gen))
+        ref_layers.append((layer.w1.detach().cpu().clone().requires_grad_(True), None if layer.w2 is None else layer.w2.detach().cpu().clone().requires_grad_(True),
+                           layer.bias.detach().cpu().clone().requires_grad_(True), aggregator, layer.activation))
+    fan = [8, 5, 3]
+    for step in range(3):
+        seeds = torch.randperm(4000, generator=gen)[:100]
+        draws = {}
+
+        def rand_cpu(i, incoming, t):
+            draws[(i, incoming)] = torch.randint(1 << 40, (t,), generator=torch.Generator().manual_seed(50 * step + 2 * i + int(incoming)))
+            return draws[(i, incoming)]
+
+        want_g = NO.layered_neighbors(og, seeds, fan, inc, out, rand=rand_cpu)
+        got_g = G.LayeredNeighborSampler(dgraph, fan, inc, out).getNeighbors(seeds.to(dev), rand=lambda i, incoming, t: draws[(i, incoming)].to(dev))
+        assert torch.equal(got_g.node_ids_.cpu(), want_g.node_ids)
+        x = feats[want_g.node_ids]
+        labels = labels_all[seeds]
+        want_loss, want_y = NO.node_classification_step(x, want_g, ref_layers, labels, 0.1)
+        got_loss, got_y = G.node_classification_step(enc, x.to(dev), got_g, labels.to(dev), 0.1)
+        scale = float(want_y.abs().max())
+        assert float((got_y.cpu() - want_y).abs().max()) <= 1e-4 * scale and abs(float(got_loss) - float(want_loss)) <= 1e-4 * abs(float(want_loss))
+        for layer, (w1, w2, b, _a, _act) in zip(enc.layers, ref_layers):
+            # (Adagrad from a zero sum moves a weight by lr sign(g): compare where the reference's accumulated g^2 is not rounding noise — tests/tolerance.py)
+            ok = w1.adagrad_sum > 1e-10
+            assert float((layer.w1.detach().cpu() - w1.detach())[ok].abs().max()) <= 2e-3
+            assert float((layer.bias.detach().cpu() - b.detach()).abs().max()) <= 2e-3

@@ -172,6 +172,22 @@ def G_emul(E, monkeypatch):
     monkeypatch.setattr(hip, "lib", lambda: E)
     monkeypatch.setattr(hip, "_dev", lambda t: t)
     monkeypatch.setattr(hip, "stream_ptr", lambda stream=None: None)
+    # the post-hook and the dense optimizer live in other kernel files (encoder.hip, rows.hip: verified on hardware in their own GPU tests): torch
+    # stand-ins with the same contracts for this CPU run
+    act = {"NONE": lambda t: t, "RELU": torch.relu, "SIGMOID": torch.sigmoid}
+    monkeypatch.setattr(hip, "layer_post_hook", lambda x, bias=None, activation="NONE", out=None: act[activation](x if bias is None else x + bias))
+
+    def hook_bwd(gy, y, activation="NONE", with_bias=True):
+        gx = gy if activation == "NONE" else gy * ((y > 0).float() if activation == "RELU" else y * (1 - y))
+        return gx, (gx.sum(0) if with_bias else None)
+
+    monkeypatch.setattr(hip, "layer_post_hook_backward", hook_bwd)
+
+    def adagrad(param, state_sum, grad, lr, eps=1e-10, weight_decay=0.0):
+        state_sum.addcmul_(grad, grad, value=1.0)
+        param.addcdiv_(grad, state_sum.sqrt().add_(eps), value=-lr)
+
+    monkeypatch.setattr(hip, "dense_adagrad_step", adagrad)
     return gnn
 
 
@@ -239,6 +255,47 @@ def test_emulated_host_mirror_graph_sage_layer_forward_backward(G_emul, aggregat
     assert torch.allclose(xd.grad, xc.grad, rtol=1e-5, atol=1e-6) and torch.allclose(layer.w1.grad, w1.grad, rtol=1e-5, atol=1e-6)
     if w2 is not None:
         assert torch.allclose(layer.w2.grad, w2.grad, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("aggregator,inc,out", [("MEAN", True, False), ("GCN", True, True)])
+def test_emulated_three_layer_encoder_and_node_classification_steps(G_emul, aggregator, inc, out):
+    """cfg4's shape end to end on the emulated kernels: DENSE sample (15-10-5 style fan-outs) -> three GraphSage stages with bias + RELU hooks ->
+    cross-entropy over the target nodes -> backward -> dense Adagrad, three consecutive steps, against the oracle's restatement of
+    GeneralEncoder::forward (encoder.cpp:195-257) and Model::train_batch's NODE_CLASSIFICATION branch (model.cpp:317-328)."""
+    dims, classes = [12, 16, 8, 5], 5
+    og = graph(500, 6000, 2, seed=13)
+    dgraph = G_emul.MariusGraph(og.src_sorted_edges, og.dst_sorted_edges, og.num_nodes_in_memory)
+    gen = torch.Generator().manual_seed(3)
+    feats = torch.randn(500, dims[0], generator=gen)
+    labels_all = torch.randint(classes, (500,), generator=gen)
+    enc = G_emul.GraphSageEncoder(dims, aggregator, "RELU", bias=True, device="cpu")
+    ref_layers = []
+    for layer in enc.layers:
+        with torch.no_grad():
+            layer.bias.copy_(0.1 * torch.randn(layer.bias.shape, generator=gen))
+        ref_layers.append((layer.w1.detach().clone().requires_grad_(True), None if layer.w2 is None else layer.w2.detach().clone().requires_grad_(True),
+                           layer.bias.detach().clone().requires_grad_(True), aggregator, layer.activation))
+    fan = [4, 3, 2]
+    for step in range(3):
+        seeds = torch.randperm(500, generator=gen)[:12]
+        draws = {}
+
+        def rand_cpu(i, incoming, t):
+            draws[(i, incoming)] = torch.randint(1 << 40, (t,), generator=torch.Generator().manual_seed(50 * step + 2 * i + int(incoming)))
+            return draws[(i, incoming)]
+
+        want_g = NO.layered_neighbors(og, seeds, fan, inc, out, rand=rand_cpu)
+        got_g = G_emul.LayeredNeighborSampler(dgraph, fan, inc, out).getNeighbors(seeds, rand=lambda i, incoming, t: draws[(i, incoming)])
+        assert torch.equal(got_g.node_ids_, want_g.node_ids)
+        x = feats[want_g.node_ids]
+        labels = labels_all[seeds]
+        want_loss, want_y = NO.node_classification_step(x, want_g, ref_layers, labels, 0.1)
+        got_loss, got_y = G_emul.node_classification_step(enc, x.clone(), got_g, labels, 0.1)
+        assert got_y.shape == (12, classes) and torch.allclose(got_y, want_y, rtol=1e-5, atol=1e-6) and torch.allclose(got_loss, want_loss, rtol=1e-5)
+        for layer, (w1, w2, b, _a, _act) in zip(enc.layers, ref_layers):
+            assert torch.allclose(layer.w1, w1, rtol=1e-4, atol=1e-6) and torch.allclose(layer.bias, b, rtol=1e-4, atol=1e-6)
+            if w2 is not None:
+                assert torch.allclose(layer.w2, w2, rtol=1e-4, atol=1e-6)
 
 
 def test_emulated_library_under_address_and_undefined_behaviour_sanitizers():
