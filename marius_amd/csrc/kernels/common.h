@@ -60,11 +60,6 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(marius_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
-// One spelling for a kernel launch that a CPU build can redirect: tests/emul/ compiles a kernel file with g++ against a shim of this header in
-// which MARIUS_LAUNCH runs the grid block by block on host threads (barriers and wave shuffles emulated) — the sanitizer / no-GPU build of a
-// kernel file, test infrastructure only (tests/test_neighbor_emul_cpu.py).  Here it is the plain HIP launch.
-#define MARIUS_LAUNCH(kernel, grid, block, stream, ...) kernel<<<dim3(grid), dim3(block), 0, stream>>>(__VA_ARGS__)
-
 constexpr int WAVE = 64;
 
 // optional HIP-event profiler (see error.hip): PROF_SCOPE(id, stream) { launch; }

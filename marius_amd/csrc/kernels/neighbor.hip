@@ -264,10 +264,10 @@ extern "C" int marius_nbr_degrees(const int64_t* node_ids, int64_t n, const int6
     const int64_t ntiles = n > 0 ? cdiv(n, NB_TILE) : 0;
     if (n > 0) {
         MARIUS_REQUIRE(node_ids && num_neighbors_tbl && offsets_tbl && num && global_offsets && capped && local_offsets, "nbr_degrees: null pointer");
-        MARIUS_LAUNCH(nbr_degrees_kernel, (unsigned)ntiles, NB_T, st, node_ids, n, num_neighbors_tbl, offsets_tbl, max_neighbors, num, global_offsets, capped, tiles);
+        nbr_degrees_kernel<<<dim3((unsigned)ntiles), dim3(NB_T), 0, st>>>(node_ids, n, num_neighbors_tbl, offsets_tbl, max_neighbors, num, global_offsets, capped, tiles);
     }
-    MARIUS_LAUNCH(nbr_scan_tiles_kernel, 1, NB_T, st, tiles, ntiles, total_dev);
-    if (n > 0) MARIUS_LAUNCH(nbr_local_offsets_kernel, (unsigned)ntiles, NB_T, st, capped, n, tiles, local_offsets);
+    nbr_scan_tiles_kernel<<<dim3(1), dim3(NB_T), 0, st>>>(tiles, ntiles, total_dev);
+    if (n > 0) nbr_local_offsets_kernel<<<dim3((unsigned)ntiles), dim3(NB_T), 0, st>>>(capped, n, tiles, local_offsets);
     return check_launch("nbr_degrees");
 }
 
@@ -276,8 +276,7 @@ extern "C" int marius_nbr_gather(const int64_t* sorted_edges, int32_t cols, cons
     MARIUS_REQUIRE((cols == 2 || cols == 3) && n >= 0 && total >= 0, "nbr_gather: bad arguments");
     if (total == 0) return MARIUS_OK;
     MARIUS_REQUIRE(sorted_edges && num && global_offsets && local_offsets && capped && out_edges && n > 0, "nbr_gather: null pointer");
-    MARIUS_LAUNCH(nbr_gather_kernel, nb_blocks(total, 256), 256, as_stream(stream), sorted_edges, cols, num, global_offsets, local_offsets, capped, n, rand_samples,
-                                                                                         total, out_edges);
+    nbr_gather_kernel<<<dim3(nb_blocks(total, 256)), dim3(256), 0, as_stream(stream)>>>(sorted_edges, cols, num, global_offsets, local_offsets, capped, n, rand_samples, total, out_edges);
     return check_launch("nbr_gather");
 }
 
@@ -288,14 +287,14 @@ extern "C" int marius_nbr_delta_ids(const int64_t* in_edges, int64_t n_in, const
     hipStream_t st = as_stream(stream);
     const int64_t n = n_in + n_out;
     MARIUS_REQUIRE(n == 0 || keys, "nbr_delta_ids: null key buffer");
-    if (n_node_ids > 0) MARIUS_LAUNCH(nbr_mark_kernel, nb_blocks(n_node_ids, 256), 256, st, node_ids, n_node_ids, marks, (uint8_t)1);
-    if (n > 0) MARIUS_LAUNCH(nbr_keys_kernel, nb_blocks(n, 256), 256, st, in_edges, n_in, out_edges, n_out, cols, marks, num_nodes, keys);
+    if (n_node_ids > 0) nbr_mark_kernel<<<dim3(nb_blocks(n_node_ids, 256)), dim3(256), 0, st>>>(node_ids, n_node_ids, marks, (uint8_t)1);
+    if (n > 0) nbr_keys_kernel<<<dim3(nb_blocks(n, 256)), dim3(256), 0, st>>>(in_edges, n_in, out_edges, n_out, cols, marks, num_nodes, keys);
     int bits = 1;
     while (bits < 63 && (1ll << bits) <= num_nodes) ++bits;  // the sentinel key num_nodes must fit
     int rc = marius_sort_unique(keys, n, bits, uniq, inverse, perm, seg_offsets, num_unique_dev, sort_workspace, sort_workspace_bytes, stream);
     if (rc) return rc;
-    if (n > 0) MARIUS_LAUNCH(nbr_drop_sentinel_kernel, 1, 1, st, uniq, num_unique_dev, num_nodes);
-    if (n_node_ids > 0) MARIUS_LAUNCH(nbr_mark_kernel, nb_blocks(n_node_ids, 256), 256, st, node_ids, n_node_ids, marks, (uint8_t)0);  // the mark array is all zero again
+    if (n > 0) nbr_drop_sentinel_kernel<<<dim3(1), dim3(1), 0, st>>>(uniq, num_unique_dev, num_nodes);
+    if (n_node_ids > 0) nbr_mark_kernel<<<dim3(nb_blocks(n_node_ids, 256)), dim3(256), 0, st>>>(node_ids, n_node_ids, marks, (uint8_t)0);  // the mark array is all zero again
     return check_launch("nbr_delta_ids");
 }
 
@@ -303,10 +302,10 @@ extern "C" int marius_nbr_positions(const int64_t* node_ids, int64_t n, const in
                                     marius_stream_t stream) {
     MARIUS_REQUIRE(n >= 0 && T >= 0 && (cols == 2 || cols == 3) && col >= 0 && col < cols && table, "nbr_positions: bad arguments");
     hipStream_t st = as_stream(stream);
-    if (n > 0) MARIUS_LAUNCH(nbr_scatter_positions_kernel, nb_blocks(n, 256), 256, st, node_ids, n, table);
+    if (n > 0) nbr_scatter_positions_kernel<<<dim3(nb_blocks(n, 256)), dim3(256), 0, st>>>(node_ids, n, table);
     if (T > 0) {
         MARIUS_REQUIRE(edges && out, "nbr_positions: null pointer");
-        MARIUS_LAUNCH(nbr_gather_positions_kernel, nb_blocks(T, 256), 256, st, edges, cols, col, T, table, out);
+        nbr_gather_positions_kernel<<<dim3(nb_blocks(T, 256)), dim3(256), 0, st>>>(edges, cols, col, T, table, out);
     }
     return check_launch("nbr_positions");
 }
@@ -335,6 +334,6 @@ extern "C" int marius_segment_gather_sum(const float* rows, int64_t rows_ld, int
     A.self_ld = self_ld;
     A.out = out;
     A.out_ld = out_ld;
-    MARIUS_LAUNCH(segment_gather_sum_kernel, (unsigned)cdiv(n, 4), 256, as_stream(stream), A);
+    segment_gather_sum_kernel<<<dim3((unsigned)cdiv(n, 4)), dim3(256), 0, as_stream(stream)>>>(A);
     return check_launch("segment_gather_sum");
 }

@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE: a shim of marius_amd/csrc/kernels/common.h for the CPU build of a kernel file (tests/emul/README in build_emul.py).
-// `g++ -I tests/emul -I include -x c++ marius_amd/csrc/kernels/neighbor.hip` finds THIS common.h first: HIP's execution model emulated on host
+// the transformed copies of the kernel files (build_emul.py) include THIS common.h: HIP's execution model emulated on host
 // threads — one workgroup at a time, one std::thread per work-item, __syncthreads = a barrier over the workgroup, __shfl_* = an exchange through
 // a per-wave buffer between two wave barriers, __shared__ = static storage (one workgroup runs at a time).  Nothing under marius_amd/ includes
 // this; the product is the hipcc build.
@@ -9,6 +9,7 @@
 #include <barrier>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -30,42 +31,63 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 typedef void* hipStream_t;
+struct alignas(8) float2 {
+    float x, y;
+};
+struct alignas(16) float4 {
+    float x, y, z, w;
+};
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
 namespace emul {
 inline thread_local dim3 t_threadIdx, t_blockIdx;
+inline thread_local unsigned t_linear = 0;
 inline dim3 g_blockDim, g_gridDim;
 inline std::barrier<>* g_block_barrier = nullptr;
 inline std::vector<std::unique_ptr<std::barrier<>>> g_wave_barriers;
 inline uint64_t g_slots[64][64];  // [wave][lane]
 
+// One set of host threads per LAUNCH (creating 256 threads per workgroup dominated the run time, ten-fold under ASan): the threads walk the grid
+// together, workgroup by workgroup; between two workgroups they meet at `sync` twice — once so that everybody has left the previous workgroup,
+// once after thread 0 has rebuilt the workgroup's barriers (a work-item that returns early DROPS out of them, so they are per workgroup).
 template <typename F>
 void launch(dim3 grid, dim3 block, F&& body) {
     g_blockDim = block;
     g_gridDim = grid;
-    const unsigned nt = block.x, nwaves = (nt + 63) / 64;
-    for (unsigned b = 0; b < grid.x; ++b) {
-        std::barrier<> bb((std::ptrdiff_t)nt);
-        g_block_barrier = &bb;
-        g_wave_barriers.clear();
-        for (unsigned w = 0; w < nwaves; ++w) g_wave_barriers.emplace_back(new std::barrier<>((std::ptrdiff_t)std::min(64u, nt - 64 * w)));
-        std::vector<std::thread> th;
-        th.reserve(nt);
-        for (unsigned t = 0; t < nt; ++t)
-            th.emplace_back([&, t, b] {
-                t_threadIdx = dim3(t);
-                t_blockIdx = dim3(b);
+    const unsigned nt = block.x * block.y * block.z, nwaves = (nt + 63) / 64;  // work-items are numbered x fastest, as the hardware packs them into waves
+    const uint64_t nblocks = (uint64_t)grid.x * grid.y * grid.z;
+    if (nt == 0 || nblocks == 0) return;
+    std::barrier<> sync((std::ptrdiff_t)nt);
+    std::unique_ptr<std::barrier<>> block_barrier;
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+            t_linear = t;
+            t_threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            for (uint64_t b = 0; b < nblocks; ++b) {
+                sync.arrive_and_wait();
+                if (t == 0) {
+                    block_barrier.reset(new std::barrier<>((std::ptrdiff_t)nt));
+                    g_block_barrier = block_barrier.get();
+                    g_wave_barriers.clear();
+                    for (unsigned w = 0; w < nwaves; ++w) g_wave_barriers.emplace_back(new std::barrier<>((std::ptrdiff_t)std::min(64u, nt - 64 * w)));
+                }
+                sync.arrive_and_wait();
+                t_blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((uint64_t)grid.x * grid.y)));
                 body();
                 // a work-item that returned early must not leave the others of its workgroup / wave waiting for ever
                 g_block_barrier->arrive_and_drop();
                 g_wave_barriers[t >> 6]->arrive_and_drop();
-            });
-        for (auto& x : th) x.join();
-    }
+            }
+        });
+    for (auto& x : th) x.join();
 }
 template <typename T>
 T exchange(T v, int src_lane_of_me(int lane, int arg), int arg) {
     static_assert(sizeof(T) <= 8, "shuffle of at most 64 bits");
-    const int lane = t_threadIdx.x & 63, wave = t_threadIdx.x >> 6;
+    const int lane = t_linear & 63, wave = t_linear >> 6;
     uint64_t bits = 0;
     memcpy(&bits, &v, sizeof(T));
     g_slots[wave][lane] = bits;
@@ -91,17 +113,47 @@ T __shfl_up(T v, int delta, int = 64) { return emul::exchange<T>(v, [](int lane,
 template <typename T>
 T __shfl_down(T v, int delta, int = 64) { return emul::exchange<T>(v, [](int lane, int d) { return lane + d < 64 ? lane + d : lane; }, delta); }
 
-#define MARIUS_LAUNCH(kernel, grid, block, stream, ...) emul::launch(dim3(grid), dim3(block), [&] { kernel(__VA_ARGS__); })
+// the few runtime calls kernel files make outside launches
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+    memset(p, v, n);
+    return hipSuccess;
+}
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "emulation"; }
 
 namespace marius {
+inline thread_local char g_last_error[512] = "";
 inline void set_last_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
-    vfprintf(stderr, fmt, ap);
-    fputc('\n', stderr);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
     va_end(ap);
 }
 inline int check_launch(const char*) { return MARIUS_OK; }
+// the switches the emulated files read (the hipcc build: error.hip)
+struct KernelEnv {
+    int mt_threads;
+};
+inline KernelEnv read_env() {
+    const char* e = getenv("MARIUS_MT_THREADS");
+    return KernelEnv{e ? atoi(e) : 0};
+}
+inline KernelEnv g_env = read_env();
+inline const KernelEnv& kernel_env() { return g_env; }
+enum ProfId { PROF_LP_SCORES = 0, PROF_LP_GRAD_ADJ, PROF_LP_GRAD_NEG, PROF_LP_PREP, PROF_LP_LSE, PROF_LP_EDGE_BWD, PROF_GATHER, PROF_SEG_ADAGRAD, PROF_SORT_UNIQUE, PROF_MT_FILL,
+              PROF_LP_PACK, PROF_COUNT };
+struct ProfScope {
+    ProfScope(int, hipStream_t) {}
+};
+constexpr int WAVE = 64;
+inline int row_vec_width(const void* base, int64_t ld, int d) {
+    uintptr_t p = reinterpret_cast<uintptr_t>(base);
+    if ((d % 4 == 0) && (ld % 4 == 0) && (p % 16 == 0)) return 4;
+    if ((d % 2 == 0) && (ld % 2 == 0) && (p % 8 == 0)) return 2;
+    return 1;
+}
 #define MARIUS_REQUIRE(cond, ...)                \
     do {                                         \
         if (!(cond)) {                           \

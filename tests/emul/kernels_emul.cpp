@@ -1,11 +1,19 @@
-// TEST INFRASTRUCTURE: the CPU build of marius_amd/csrc/kernels/neighbor.hip (tests/emul/common.h emulates the HIP execution model on host
-// threads).  marius_nbr_delta_ids calls marius_sort_unique, which lives in another kernel file: a plain C++ stand-in with the SAME contract
-// (include/marius_hip.h) is defined here — it is a dependency of the code under test, not the code under test.
+// TEST INFRASTRUCTURE: harness of the CPU build (tests/emul/build_emul.py appends one #include per transformed kernel file).  Entry points that live
+// in kernel files NOT part of this build but are called by ones that are get plain C++ stand-ins with the SAME contract (include/marius_hip.h):
+// they are dependencies of the code under test, not the code under test.
 #include <algorithm>
 #include <numeric>
 
 #include "common.h"
 
+extern "C" const char* marius_hip_last_error(void) { return marius::g_last_error; }
+extern "C" int marius_hip_abi_version(void) { return MARIUS_HIP_ABI_VERSION; }
+extern "C" int marius_config_reload(void) {
+    marius::g_env = marius::read_env();
+    return MARIUS_OK;
+}
+
+extern "C" size_t marius_sort_unique_workspace_bytes(int64_t) { return 256; }
 extern "C" int marius_sort_unique(const int64_t* ids, int64_t n, int32_t, int64_t* uniq, int64_t* inverse, int32_t* perm, int32_t* seg_offsets,
                                   int64_t* num_unique_dev, void*, size_t, marius_stream_t) {
     std::vector<int32_t> p((size_t)n);
@@ -27,6 +35,3 @@ extern "C" int marius_sort_unique(const int64_t* ids, int64_t n, int32_t, int64_
     return MARIUS_OK;
 }
 
-extern "C" size_t marius_sort_unique_workspace_bytes(int64_t) { return 256; }
-
-#include "neighbor.hip.inc"

@@ -1,0 +1,104 @@
+"""The GPU parity tests of the kernel files that have a CPU build (tests/emul/build_emul.py: rows.hip, rng.hip, encoder.hip, neighbor.hip compiled by
+g++ against a shim that emulates HIP's execution model on host threads), run AS THEY ARE — the same test functions, imported from
+tests/test_gpu_parity.py / tests/test_gpu_host.py — with the ctypes layer pointed at the emulated library for the duration of a test and "the device"
+being the host.  What this adds to the `-m gpu` runs: the kernels' logic is checked in the CPU suite of every round, and once more under
+AddressSanitizer + UBSan (the GPU pool has no sanitizer builds).  What it does not replace: the hipcc build, the hardware, the timing.
+Test infrastructure: marius_amd/ has no switch to reach the emulated library; the redirection is a monkeypatch that lives in this file."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "emul"))
+sys.path.insert(0, HERE)
+
+CPU = torch.device("cpu")
+SAN = os.environ.get("MARIUS_EMUL_SANITIZE") == "1"   # inside the sanitizer run: fewer and smaller cases (every emulated work-item is a thread with a shadow stack)
+
+
+@pytest.fixture(scope="module")
+def emulated_library():
+    import build_emul
+    from marius_amd import hip
+
+    lib = C.CDLL(build_emul.build(sanitize=os.environ.get("MARIUS_EMUL_SANITIZE") == "1"))
+    bound = []
+    for name, (res, args) in hip.SIGNATURES.items():
+        if hasattr(lib, name):
+            getattr(lib, name).restype, getattr(lib, name).argtypes = res, args
+            bound.append(name)
+    assert {"marius_gather_rows", "marius_scatter_add_rows", "marius_mt19937_fill", "marius_sample_negatives", "marius_layer_post_hook", "marius_nbr_gather"} <= set(bound)
+    return lib
+
+
+@pytest.fixture()
+def HE(emulated_library, monkeypatch):
+    """marius_amd.hip with lib() -> the emulated library, host tensors accepted, no stream; Tensor.to always copies (a parity test's `x.to(dev)` must not
+    alias its reference copy when the device IS the host)"""
+    from marius_amd import hip
+
+    monkeypatch.setattr(hip, "lib", lambda: emulated_library)
+    monkeypatch.setattr(hip, "_dev", lambda t: t)
+    monkeypatch.setattr(hip, "stream_ptr", lambda stream=None: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    orig_to = torch.Tensor.to
+
+    def to_copy(self, *a, **k):
+        k.setdefault("copy", True)
+        return orig_to(self, *a, **k)
+
+    monkeypatch.setattr(torch.Tensor, "to", to_copy)
+    return hip
+
+
+def test_rows_kernels_on_the_cpu_build(HE):
+    """rows.hip: InMemory::indexRead / indexAdd (storage.cpp:606-673), Batch::accumulateGradients' rule (batch.cpp:62-79), dense Adagrad / Adam (optim.cpp)"""
+    import test_gpu_parity as TP
+
+    for d in ((2, 100) if SAN else (2, 50, 100, 128, 400)):
+        TP.test_gather_scatter_rows(HE, CPU, d)
+    TP.test_gather_empty_and_errors(HE, CPU)
+    TP.test_adagrad_rule_bit_exact(HE, CPU)
+    TP.test_dense_adagrad_step(HE, CPU)
+    for amsgrad, wd in ((False, 0.0), (True, 0.0), (False, 0.01)):
+        TP.test_dense_adam_step_matches_reference_ops(HE, CPU, amsgrad, wd)
+
+
+def test_sampler_kernels_on_the_cpu_build(HE):
+    """rng.hip: ATen's MT19937 stream, CorruptNodeNegativeSampler::getNegatives (negative.cpp:328-366), RandomEdgeSampler::getEdges (edge.cpp:12-14)"""
+    import test_gpu_parity as TP
+
+    for n in ((1, 625, 3000) if SAN else (1, 623, 624, 625, 5000, 20000)):
+        TP.test_mt19937_device_stream_bit_exact(HE, CPU, n)
+    shapes = ((6, 1, 5, 0.0, 6), (6, 3, 5, 0.5, 6), (1000, 10, 500, 0.0, 14541), (1000, 10, 500, 0.5, 14541), (64, 2, 16, 0.25, 2 ** 28 + 5))
+    for B, Cn, N, f, num_nodes in (shapes[:2] + shapes[4:] if SAN else shapes):
+        TP.test_negative_sampler_bit_exact(HE, CPU, B, Cn, N, f, num_nodes)
+    TP.test_select_edges(HE, CPU)
+
+
+def test_post_hook_kernels_on_the_cpu_build(HE):
+    """encoder.hip: Layer::post_hook (layer.cpp:9-16) and its backward"""
+    import test_gpu_host as TH
+
+    for activation in ("NONE", "RELU", "SIGMOID"):
+        for with_bias in (True, False):
+            for n, d, pad in (((1, 2, 0), (901, 100, 28), (64, 7, 3)) if SAN else ((1, 2, 0), (777, 50, 0), (333, 400, 0), (901, 100, 28), (64, 7, 3))):
+                TH.test_layer_post_hook_kernels_match_the_reference_ops(CPU, activation, with_bias, n, d, pad)
+
+
+def test_cpu_build_under_address_and_undefined_behaviour_sanitizers():
+    """every test of this file and of tests/test_neighbor_emul_cpu.py again, in a python started under libasan with the kernel files built with
+    -fsanitize=address,undefined: an out-of-bounds index, a misaligned or overflowing access in any emulated work-item aborts the run"""
+    if os.environ.get("MARIUS_EMUL_SANITIZE") == "1":
+        pytest.skip("already inside the sanitizer run")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan.so next to gcc")
+    env = dict(os.environ, MARIUS_EMUL_SANITIZE="1", LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(HERE, "test_neighbor_emul_cpu.py"), "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "not sanitizers and not (one_hop and 1000) and not (aggregation and 130) and not (aggregation and 64)"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=2400, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-4000:]
