@@ -10,7 +10,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 KDIR = os.path.join(ROOT, "marius_amd", "csrc", "kernels")
-FILES = ["neighbor.hip", "rows.hip", "rng.hip", "encoder.hip"]
+FILES = ["neighbor.hip", "rows.hip", "rng.hip", "encoder.hip", "segreduce.hip"]
+HEADERS = ["seg_plan.h"]  # kernel-side headers the files include by name: copied next to them (their own `#include "common.h"` then finds the shim)
 
 
 def _match(s, i, open_ch, close_ch):
@@ -80,10 +81,13 @@ def build(force=False, sanitize=False):
     out_dir = os.path.join(HERE, "_build")
     os.makedirs(out_dir, exist_ok=True)
     lib = os.path.join(out_dir, "libkernels_emul_asan.so" if sanitize else "libkernels_emul.so")
-    deps = [os.path.join(KDIR, f) for f in FILES] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "kernels_emul.cpp"), os.path.join(ROOT, "include", "marius_hip.h"),
+    deps = [os.path.join(KDIR, f) for f in FILES + HEADERS] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "kernels_emul.cpp"), os.path.join(ROOT, "include", "marius_hip.h"),
                                                     os.path.abspath(__file__)]
     if not force and os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
         return lib
+    for h in HEADERS:
+        with open(os.path.join(KDIR, h)) as fh, open(os.path.join(out_dir, h), "w") as oh:
+            oh.write(fh.read())
     for f in FILES:
         with open(os.path.join(KDIR, f)) as fh:
             text = transform(fh.read())

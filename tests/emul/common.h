@@ -9,6 +9,7 @@
 #include <barrier>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -37,6 +38,10 @@ struct alignas(8) float2 {
 struct alignas(16) float4 {
     float x, y, z, w;
 };
+struct alignas(16) int4 {
+    int x, y, z, w;
+};
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
@@ -111,6 +116,46 @@ T __shfl_xor(T v, int mask, int = 64) { return emul::exchange<T>(v, [](int lane,
 template <typename T>
 T __shfl_up(T v, int delta, int = 64) { return emul::exchange<T>(v, [](int lane, int d) { return lane >= d ? lane - d : lane; }, delta); }
 template <typename T>
+T __shfl(T v, int src, int = 64) { return emul::exchange<T>(v, [](int, int sl) { return sl & 63; }, src); }
+inline unsigned long long __ballot(int pred) {
+    const int lane = emul::t_linear & 63, wave = emul::t_linear >> 6;
+    emul::g_slots[wave][lane] = pred ? 1ull : 0ull;
+    emul::g_wave_barriers[wave]->arrive_and_wait();
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) m |= (emul::g_slots[wave][l] & 1ull) << l;   // (lanes that do not exist in a short last wave never wrote: their slots are stale)
+    emul::g_wave_barriers[wave]->arrive_and_wait();
+    return m;
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline unsigned __float_as_uint(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+template <typename T>
+T atomicMax(T* p, T v) {
+    T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+    return old;
+}
+template <typename T>
+T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+template <typename T>
+T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+#define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __hip_atomic_load(p, order, scope) __atomic_load_n(p, order)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, order)
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, order)
+using std::max;
+using std::min;
+template <typename T>
 T __shfl_down(T v, int delta, int = 64) { return emul::exchange<T>(v, [](int lane, int d) { return lane + d < 64 ? lane + d : lane; }, delta); }
 
 // the few runtime calls kernel files make outside launches
@@ -135,10 +180,12 @@ inline int check_launch(const char*) { return MARIUS_OK; }
 // the switches the emulated files read (the hipcc build: error.hip)
 struct KernelEnv {
     int mt_threads;
+    bool seg_fused_fixup_off, seg_group_off;
 };
 inline KernelEnv read_env() {
+    auto first = [](const char* name) -> char { const char* e = getenv(name); return e ? e[0] : (char)0; };
     const char* e = getenv("MARIUS_MT_THREADS");
-    return KernelEnv{e ? atoi(e) : 0};
+    return KernelEnv{e ? atoi(e) : 0, first("MARIUS_SEG_FUSED_FIXUP") == '0', first("MARIUS_SEG_GROUP") == '0'};
 }
 inline KernelEnv g_env = read_env();
 inline const KernelEnv& kernel_env() { return g_env; }
@@ -148,6 +195,14 @@ struct ProfScope {
     ProfScope(int, hipStream_t) {}
 };
 constexpr int WAVE = 64;
+inline float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+inline float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
 inline int row_vec_width(const void* base, int64_t ld, int d) {
     uintptr_t p = reinterpret_cast<uintptr_t>(base);
     if ((d % 4 == 0) && (ld % 4 == 0) && (p % 16 == 0)) return 4;

@@ -1,5 +1,5 @@
 """The GPU parity tests of the kernel files that have a CPU build (tests/emul/build_emul.py: rows.hip, rng.hip, encoder.hip, neighbor.hip compiled by
-g++ against a shim that emulates HIP's execution model on host threads), run AS THEY ARE — the same test functions, imported from
+g++ against a shim that emulates HIP's execution model on host threads; segreduce.hip since), run AS THEY ARE — the same test functions, imported from
 tests/test_gpu_parity.py / tests/test_gpu_host.py — with the ctypes layer pointed at the emulated library for the duration of a test and "the device"
 being the host.  What this adds to the `-m gpu` runs: the kernels' logic is checked in the CPU suite of every round, and once more under
 AddressSanitizer + UBSan (the GPU pool has no sanitizer builds).  What it does not replace: the hipcc build, the hardware, the timing.
@@ -102,3 +102,19 @@ def test_cpu_build_under_address_and_undefined_behaviour_sanitizers():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(HERE, "test_neighbor_emul_cpu.py"), "-x", "-q", "-p", "no:cacheprovider",
                         "-k", "not sanitizers and not (one_hop and 1000) and not (aggregation and 130) and not (aggregation and 64)"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=2400, cwd=os.path.dirname(HERE))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-4000:]
+
+
+def test_segmented_update_kernels_on_the_cpu_build(HE):
+    """segreduce.hip: the sorted-unique, atomics-free sparse update — per-unique-row sums of the occurrence gradients, Batch::accumulateGradients' rule and
+    InMemory::indexAdd on the unique rows (batch.cpp:62-79, storage.cpp:651-673), planned / tracked / grouped forms, the table magnitude scan"""
+    import test_gpu_parity as TP
+
+    for n, U, d in (((1, 1, 4),) if SAN else ((1, 1, 4), (1000, 900, 100))):   # (every emulated work-item is a host thread: the larger shapes stay with the GPU suite)
+        TP.test_segment_sum_rows(HE, CPU, n, U, d)
+    for n, num_nodes, power, d in ((33, 5, 1, 20), (1, 9, 1, 8), (700, 90, 2, 36)):
+        TP.test_planned_segment_adagrad_scatter_is_bit_identical(HE, CPU, n, num_nodes, power, d)
+    for n, rows, d, planned in ((33, 5, 20, False), (600, 200, 100, True)):
+        TP.test_tracked_update_keeps_the_magnitude_bound(HE, CPU, n, rows, d, planned)
+    for rows, d, ld in ((1000, 100, 100), (777, 50, 50), (513, 33, 33), (3, 7, 7)):
+        TP.test_table_absmax_flat_strided_and_counted(HE, CPU, rows, d, ld)
+    # (the grouped-launch tests run at the bench's shape only — 200,000 occurrences x 100 columns — which is hours of host threads: GPU suite only)
