@@ -12,7 +12,7 @@
 //   marius_segment_gather_sum  GraphSage's a_i: rows gathered by index and summed per segment IN INDEX ORDER (the order of the reference's CPU
 //                          index_add_, layer_helpers.cpp:19-30: bit-identical sums, no atomics), optional second list (outgoing + incoming),
 //                          MEAN / GCN normalisation (graph_sage_layer.cpp:78-90); with a per-row pre-divisor it is also the backward of the gather
-// All integer outputs are bit-exact restatements; the float sums are bit-exact against the CPU op sequence (tests/test_gpu_neighbor.py).
+// All integer outputs are bit-exact restatements; the float sums are bit-exact against the CPU op sequence (tests/test_gpu_zz_unverified_cfg4.py).
 #include "common.h"
 
 namespace marius {

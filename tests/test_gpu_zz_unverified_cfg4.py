@@ -1,4 +1,7 @@
-"""cfg4 slice (round 6): the HIP neighbour-sampling / GraphSage-aggregation path (neighbor.hip through marius_amd/gnn.py) against the oracle
+"""(File name: sorts LAST among the GPU test files on purpose.  Everything in here was written after the pool closed GPU use for this repository and
+has never run on hardware — DESIGN.md §10 — so that `pytest -x -m gpu` reaches it only after every test that HAS been verified on an MI355X.)
+
+cfg4 slice (round 6): the HIP neighbour-sampling / GraphSage-aggregation path (neighbor.hip through marius_amd/gnn.py) against the oracle
 (oracle/neighbor_oracle.py: the reference's own ATen op sequence — neighbor.cpp:9-105, 402-582; graph.cpp:16-44, 128-236, 290-398;
 graph_sage_layer.cpp:37-96).  Integer outputs bit-exact; the aggregation's float sums bit-exact against the CPU op sequence (rows are added in
 index order, as the CPU index_add_ does); the layer's output (two library GEMMs) and the backward within 1e-5 / 1e-6 relative."""
@@ -6,6 +9,8 @@ import math
 
 import pytest
 import torch
+
+from test_gpu_flash import DEC as _FLASH_DEC, make_batch as _flash_make_batch
 
 from oracle import neighbor_oracle as NO
 
@@ -243,3 +248,37 @@ def test_three_layer_encoder_and_node_classification_steps(G, dev, aggregator, i
             ok = w1.adagrad_sum > 1e-10
             assert float((layer.w1.detach().cpu() - w1.detach())[ok].abs().max()) <= 2e-3
             assert float((layer.bias.detach().cpu() - b.detach()).abs().max()) <= 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ also unverified on hardware: the layout's record-layout check
+@pytest.fixture(scope="module")
+def H():
+    from marius_amd import hip
+
+    hip.lib()
+    return hip
+
+
+def test_layout_refuses_a_record_layout_changed_after_the_plan(H, dev, monkeypatch):
+    """the record pitch (folded column tail: d = 36 / 68 / 100) and the column chunking follow MARIUS_FLASH_* switches that
+    marius_config_reload() can change between marius_lp_plan and a launch that reuses its layout — the pack kernels would then write 464-byte
+    records into buffers planned for 432-byte ones.  The plan records what it sized for (marius_lp_layout.flash_cfg) and every launch checks it."""
+    decoder, B, C, N, d = "COMPLEX", 256, 4, 64, 100
+    emb, edges, dst_neg, src_neg, rel, inv = _flash_make_batch(decoder, B, C, N, d, 1000, 7, seed=3)
+    relop, cmp = _FLASH_DEC[decoder]
+    W = H.LpWorkspace(relop, cmp, d, B, C, N, True, H.REDUCE_SUM, 3, True, dev, flags=H.LP_TRAIN_ONLY)
+    assert W.layout.flash == 1 and W.layout.flash_cfg != 0
+    t = lambda x: x.to(dev)  # noqa: E731
+    W.bind(t(emb), t(edges), t(dst_neg), t(src_neg), t(rel), t(inv))
+    W.forward()
+    torch.cuda.synchronize()
+    monkeypatch.setenv("MARIUS_FLASH_TAIL4", "0")
+    H.reload_env()
+    try:
+        with pytest.raises(H.MariusHipError, match="record layout changed"):
+            W.forward()
+    finally:
+        monkeypatch.delenv("MARIUS_FLASH_TAIL4")
+        H.reload_env()
+    W.forward()  # the planned layout is valid again
+    torch.cuda.synchronize()

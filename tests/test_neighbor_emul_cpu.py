@@ -1,7 +1,7 @@
 """CPU build of the cfg4 kernel file: marius_amd/csrc/kernels/neighbor.hip compiled by g++ against tests/emul/common.h (HIP's execution model on
 host threads: a std::thread per work-item, barriers, wave shuffles through a per-wave buffer) and run through the SAME C-ABI entry points against
 the oracle (oracle/neighbor_oracle.py).  This is test infrastructure — nothing under marius_amd/ can reach it, and it proves the kernels' logic
-(indexing, scans, ordering), not their performance or the hipcc build; the `-m gpu` tests (tests/test_gpu_neighbor.py) are the parity tests proper.
+(indexing, scans, ordering), not their performance or the hipcc build; the `-m gpu` tests (tests/test_gpu_zz_unverified_cfg4.py) are the parity tests proper.
 It exists because the round's GPU access ended before the cfg4 slice could run on hardware."""
 import ctypes as C
 import os
