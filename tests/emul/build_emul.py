@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 KDIR = os.path.join(ROOT, "marius_amd", "csrc", "kernels")
-FILES = ["neighbor.hip", "rows.hip", "rng.hip", "encoder.hip", "segreduce.hip"]
+FILES = ["neighbor.hip", "rows.hip", "rng.hip", "encoder.hip", "segreduce.hip", "sort_unique.hip", "exchange.hip"]
 HEADERS = ["seg_plan.h"]  # kernel-side headers the files include by name: copied next to them (their own `#include "common.h"` then finds the shim)
 
 
@@ -72,7 +72,9 @@ def transform(src):
         assert src[a0] == "(", src[j - 40:j + 80]
         a1 = _match(src, a0, "(", ")")
         assert src[a1] == ";", src[a1 - 60:a1 + 5]
-        out += src[i:m.start()] + "emul::launch(dim3(%s), dim3(%s), [&] { %s%s; });" % (grid, block, name, src[a0:a1])
+        # the arguments are evaluated ONCE, by the launching thread, and copied — as a kernel launch does (a `tickets.fetch_add(1)` among them must not run per work-item)
+        out += src[i:m.start()] + ("{ auto emul_args_ = std::make_tuple%s; emul::launch(dim3(%s), dim3(%s), [&] { std::apply([](auto&... a) { %s(a...); }, emul_args_); }); }"
+                                   % (src[a0:a1], grid, block, name))
         i = a1 + 1
 
 

@@ -6,7 +6,9 @@
 #pragma once
 #include <stdint.h>
 
+#include <atomic>
 #include <barrier>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -15,6 +17,7 @@
 #include <functional>
 #include <memory>
 #include <thread>
+#include <tuple>
 #include <type_traits>
 #include <vector>
 
@@ -143,6 +146,15 @@ template <typename T>
 T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 template <typename T>
 T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned long long __builtin_amdgcn_ballot_w64(bool pred) { return __ballot(pred ? 1 : 0); }
+inline void __builtin_amdgcn_wave_barrier() { emul::g_wave_barriers[emul::t_linear >> 6]->arrive_and_wait(); }
+inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
+template <typename T>
+T __builtin_amdgcn_readfirstlane(T v) { return emul::exchange<T>(v, [](int, int) { return 0; }, 0); }   // (lane 0 of every wave that calls it is active in the emulated files)
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+inline unsigned long long wall_clock64() {   // 100 MHz, like the device's constant clock
+    return (unsigned long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
+}
 inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
@@ -181,11 +193,14 @@ inline int check_launch(const char*) { return MARIUS_OK; }
 struct KernelEnv {
     int mt_threads;
     bool seg_fused_fixup_off, seg_group_off;
+    bool sort_rocprim, maps_fused;
+    int pm_nwg;
 };
 inline KernelEnv read_env() {
     auto first = [](const char* name) -> char { const char* e = getenv(name); return e ? e[0] : (char)0; };
     const char* e = getenv("MARIUS_MT_THREADS");
-    return KernelEnv{e ? atoi(e) : 0, first("MARIUS_SEG_FUSED_FIXUP") == '0', first("MARIUS_SEG_GROUP") == '0'};
+    const char* w = getenv("MARIUS_PM_NWG");
+    return KernelEnv{e ? atoi(e) : 0, first("MARIUS_SEG_FUSED_FIXUP") == '0', first("MARIUS_SEG_GROUP") == '0', first("MARIUS_SORT") == 'r', first("MARIUS_MAPS") == 'f', w ? atoi(w) : 0};
 }
 inline KernelEnv g_env = read_env();
 inline const KernelEnv& kernel_env() { return g_env; }

@@ -1,5 +1,5 @@
 """The GPU parity tests of the kernel files that have a CPU build (tests/emul/build_emul.py: rows.hip, rng.hip, encoder.hip, neighbor.hip compiled by
-g++ against a shim that emulates HIP's execution model on host threads; segreduce.hip since), run AS THEY ARE — the same test functions, imported from
+g++ against a shim that emulates HIP's execution model on host threads; since: segreduce.hip, sort_unique.hip, exchange.hip), run AS THEY ARE — the same test functions, imported from
 tests/test_gpu_parity.py / tests/test_gpu_host.py — with the ctypes layer pointed at the emulated library for the duration of a test and "the device"
 being the host.  What this adds to the `-m gpu` runs: the kernels' logic is checked in the CPU suite of every round, and once more under
 AddressSanitizer + UBSan (the GPU pool has no sanitizer builds).  What it does not replace: the hipcc build, the hardware, the timing.
@@ -45,6 +45,8 @@ def HE(emulated_library, monkeypatch):
     monkeypatch.setattr(hip, "_dev", lambda t: t)
     monkeypatch.setattr(hip, "stream_ptr", lambda stream=None: None)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.Tensor, "pin_memory", lambda self, *a, **k: self)
+    monkeypatch.setattr(torch.Tensor, "is_pinned", lambda self, *a, **k: True)
     orig_to = torch.Tensor.to
 
     def to_copy(self, *a, **k):
@@ -90,8 +92,34 @@ def test_post_hook_kernels_on_the_cpu_build(HE):
                 TH.test_layer_post_hook_kernels_match_the_reference_ops(CPU, activation, with_bias, n, d, pad)
 
 
+def test_unique_map_kernels_on_the_cpu_build(HE):
+    """sort_unique.hip: map_tensors (util.cpp:180-205) — the hand-written radix sort and run-head scan, the merge of ascending runs, and the whole map
+    chain of a batch as ONE persistent launch (marius_prepare_maps: the work-item queue is drained by the emulated workgroups one after another, which
+    is the single-workgroup case its design promises to complete) — against torch.unique / the separate launches, bit for bit"""
+    import test_gpu_parity as TP
+
+    sizes = ((1, 5), (12, 6), (4097, 1 << 20), (5001, (1 << 36) - 5)) if SAN else ((1, 5), (12, 6), (4095, 1 << 20), (4096, 1 << 20), (4097, 1 << 20), (16385, 1),
+                                                                                 (5001, (1 << 36) - 5), (9001, (1 << 40) + 3))
+    for n, hi in sizes:
+        TP.test_sort_unique_matches_map_tensors(HE, CPU, n, hi)
+    TP.test_sort_unique_empty(HE, CPU)
+    shapes = ((250, 5, 40, 4000, 11, 3, False), (7, 1, 3, 50, 2, 3, False), (1, 1, 1, 2, 1, 3, False), (2049, 3, 683, 99999, 5, 3, True))
+    for B, Cn, N, num_nodes, R, cols, hubs in (shapes[:3] if SAN else shapes):   # (the bench batch and FB15k-237's shape: GPU suite)
+        TP.test_prepare_maps_one_launch_equals_the_separate_launches(HE, CPU, B, Cn, N, num_nodes, R, cols, hubs)
+    for runs in (([1], [0, 7, 0], [1000, 0, 0, 3]) if SAN else ([1], [5000], [0, 7, 0], [3000, 2500, 4000, 1], [1000, 0, 0, 3], [17] * 64)):
+        TP.test_merge_unique_runs_equals_sort_unique(HE, CPU, runs)
+
+
+def test_exchange_kernels_on_the_cpu_build(HE):
+    """exchange.hip: the fixed-capacity halves of the sharded row exchange and the header record against the numpy restatement (oracle/exchange_oracle.py)"""
+    import test_gpu_parity as TP
+
+    TP.test_fixed_capacity_exchange_halves_against_numpy(HE, CPU, 2, 1.5)   # (worlds 1 / 4 / 8: GPU suite — every emulated work-item is a host thread)
+
+
 def test_cpu_build_under_address_and_undefined_behaviour_sanitizers():
-    """the tests of this file (reduced shapes) and a cross-section of tests/test_neighbor_emul_cpu.py again, in a python started under libasan with the kernel files built with
+    """the storage-row, sampler and post-hook groups of this file (reduced shapes) and a cross-section of tests/test_neighbor_emul_cpu.py again (all of
+    both files with MARIUS_EMUL_SANITIZE_ALL=1: 4-6 minutes; last run clean on the round's final tree), in a python started under libasan with the kernel files built with
     -fsanitize=address,undefined: an out-of-bounds index, a misaligned or overflowing access in any emulated work-item aborts the run"""
     if os.environ.get("MARIUS_EMUL_SANITIZE") == "1":
         pytest.skip("already inside the sanitizer run")
@@ -99,8 +127,11 @@ def test_cpu_build_under_address_and_undefined_behaviour_sanitizers():
     if not os.path.isabs(asan) or not os.path.exists(asan):
         pytest.skip("no libasan.so next to gcc")
     env = dict(os.environ, MARIUS_EMUL_SANITIZE="1", LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    # default: the cheaper groups (a barrier of 512 host threads under ASan costs milliseconds); MARIUS_EMUL_SANITIZE_ALL=1: every emulated test
+    select = ("not sanitizers" if os.environ.get("MARIUS_EMUL_SANITIZE_ALL") == "1" else
+              "rows_kernels or sampler_kernels or post_hook_kernels or delta_ids or (one_hop and 3-2) or (aggregation and GCN and 7) or (layered and fanouts1)")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(HERE, "test_neighbor_emul_cpu.py"), "-x", "-q", "-p", "no:cacheprovider",
-                        "-k", "(cpu_build and not sanitizers) or delta_ids or (one_hop and 3-2) or (aggregation and GCN and 7) or (three_layer and MEAN) or (layered and fanouts1)"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=2400, cwd=os.path.dirname(HERE))
+                        "-k", select], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=2400, cwd=os.path.dirname(HERE))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-4000:]
 
 

@@ -21,7 +21,8 @@ def E():
     from marius_amd import hip
 
     lib = C.CDLL(build_emul.build(sanitize=os.environ.get("MARIUS_EMUL_SANITIZE") == "1"))
-    for name in ("marius_nbr_workspace_bytes", "marius_nbr_degrees", "marius_nbr_gather", "marius_nbr_delta_ids", "marius_nbr_positions", "marius_segment_gather_sum"):
+    for name in ("marius_nbr_workspace_bytes", "marius_nbr_degrees", "marius_nbr_gather", "marius_nbr_delta_ids", "marius_nbr_positions", "marius_segment_gather_sum",
+                 "marius_sort_unique_workspace_bytes"):
         res, args = hip.SIGNATURES[name]  # the same signature table the HIP library is bound with
         getattr(lib, name).restype, getattr(lib, name).argtypes = res, args
     return lib
@@ -98,8 +99,10 @@ def test_emulated_delta_ids_and_positions_equal_the_oracle(E):
         keys, uniq, inverse = (torch.empty(max(n, 1), dtype=torch.int64) for _ in range(3))
         perm, seg = torch.empty(max(n, 1), dtype=torch.int32), torch.empty(max(n, 1) + 1, dtype=torch.int32)
         count = torch.zeros(1, dtype=torch.int64)
+        wsb = E.marius_sort_unique_workspace_bytes(max(n, 1))
+        ws = torch.zeros(wsb, dtype=torch.uint8)  # (zero-filled: the sort's control block — include/marius_hip.h)
         assert E.marius_nbr_delta_ids(P(d_in), n_in, P(d_out), n_out, 2, P(node_ids), node_ids.numel(), 500, P(marks), P(keys), P(uniq), P(inverse), P(perm), P(seg), P(count),
-                                      None, 0, None) == 0
+                                      P(ws), wsb, None) == 0
         assert int(marks.max()) == 0
         delta = uniq[:int(count)].clone()
         if delta.numel():
