@@ -44,7 +44,10 @@ def _split_top(s):
 
 
 def transform(src):
-    """rewrite every kernel launch of a .hip source for the emulation build"""
+    """rewrite every kernel launch of a .hip source for the emulation build; dynamic LDS (`extern __shared__ T name[];`) becomes a pointer into the
+    launch's buffer; clang's ext_vector_type becomes GCC's vector_size"""
+    src = re.sub(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];", r"\1* \2 = reinterpret_cast<\1*>(emul::g_dyn_smem);", src)
+    src = re.sub(r"typedef\s+float\s+(\w+)\s+__attribute__\(\(ext_vector_type\((\d+)\)\)\);", lambda m: "typedef float %s __attribute__((vector_size(%d)));" % (m.group(1), 4 * int(m.group(2))), src)
     out, i = "", 0
     while True:
         j = src.find("<<<", i)
@@ -65,7 +68,8 @@ def transform(src):
         m = re.search(r"[A-Za-z_]\w*$", src[:k])
         name = src[m.start():j]
         e = src.index(">>>", j)
-        grid, block = _split_top(src[j + 3:e])[:2]
+        cfg = _split_top(src[j + 3:e])
+        grid, block, shmem = cfg[0], cfg[1], (cfg[2] if len(cfg) > 2 else "0")
         a0 = e + 3
         while src[a0] in " \n":
             a0 += 1
@@ -73,8 +77,8 @@ def transform(src):
         a1 = _match(src, a0, "(", ")")
         assert src[a1] == ";", src[a1 - 60:a1 + 5]
         # the arguments are evaluated ONCE, by the launching thread, and copied — as a kernel launch does (a `tickets.fetch_add(1)` among them must not run per work-item)
-        out += src[i:m.start()] + ("{ auto emul_args_ = std::make_tuple%s; emul::launch(dim3(%s), dim3(%s), [&] { std::apply([](auto&... a) { %s(a...); }, emul_args_); }); }"
-                                   % (src[a0:a1], grid, block, name))
+        out += src[i:m.start()] + ("{ auto emul_args_ = std::make_tuple%s; emul::launch(dim3(%s), dim3(%s), [&] { std::apply([](auto&... a) { %s(a...); }, emul_args_); }, (size_t)(%s)); }"
+                                   % (src[a0:a1], grid, block, name, shmem))
         i = a1 + 1
 
 
@@ -89,7 +93,7 @@ def build(force=False, sanitize=False):
         return lib
     for h in HEADERS:
         with open(os.path.join(KDIR, h)) as fh, open(os.path.join(out_dir, h), "w") as oh:
-            oh.write(fh.read())
+            oh.write(transform(fh.read()))
     for f in FILES:
         with open(os.path.join(KDIR, f)) as fh:
             text = transform(fh.read())

@@ -59,10 +59,13 @@ inline uint64_t g_slots[64][64];  // [wave][lane]
 // One set of host threads per LAUNCH (creating 256 threads per workgroup dominated the run time, ten-fold under ASan): the threads walk the grid
 // together, workgroup by workgroup; between two workgroups they meet at `sync` twice — once so that everybody has left the previous workgroup,
 // once after thread 0 has rebuilt the workgroup's barriers (a work-item that returns early DROPS out of them, so they are per workgroup).
+inline unsigned char* g_dyn_smem = nullptr;  // the launch's dynamic LDS (one workgroup runs at a time)
 template <typename F>
-void launch(dim3 grid, dim3 block, F&& body) {
+void launch(dim3 grid, dim3 block, F&& body, size_t dyn_smem_bytes = 0) {
     g_blockDim = block;
     g_gridDim = grid;
+    std::unique_ptr<unsigned char[]> dyn(new unsigned char[dyn_smem_bytes + 64]);
+    g_dyn_smem = (unsigned char*)(((uintptr_t)dyn.get() + 63) & ~(uintptr_t)63);
     const unsigned nt = block.x * block.y * block.z, nwaves = (nt + 63) / 64;  // work-items are numbered x fastest, as the hardware packs them into waves
     const uint64_t nblocks = (uint64_t)grid.x * grid.y * grid.z;
     if (nt == 0 || nblocks == 0) return;
@@ -146,6 +149,8 @@ template <typename T>
 T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 template <typename T>
 T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline float __expf(float x) { return expf(x); }
+inline float __logf(float x) { return logf(x); }
 inline unsigned long long __builtin_amdgcn_ballot_w64(bool pred) { return __ballot(pred ? 1 : 0); }
 inline void __builtin_amdgcn_wave_barrier() { emul::g_wave_barriers[emul::t_linear >> 6]->arrive_and_wait(); }
 inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
