@@ -1,13 +1,12 @@
 // TEST INFRASTRUCTURE: a shim of marius_amd/csrc/kernels/common.h for the CPU build of a kernel file (tests/emul/README in build_emul.py).
-// the transformed copies of the kernel files (build_emul.py) include THIS common.h: HIP's execution model emulated on host
-// threads — one workgroup at a time, one std::thread per work-item, __syncthreads = a barrier over the workgroup, __shfl_* = an exchange through
-// a per-wave buffer between two wave barriers, __shared__ = static storage (one workgroup runs at a time).  Nothing under marius_amd/ includes
-// this; the product is the hipcc build.
+// the transformed copies of the kernel files (build_emul.py) include THIS common.h: HIP's execution model emulated on the host —
+// one workgroup at a time, one fiber per work-item, __syncthreads = a barrier over the workgroup's live work-items, __shfl_* / ballot = an exchange
+// through a per-wave buffer between two wave barriers, __shared__ = static storage (one workgroup runs at a time), atomics = the compiler's.
+// Nothing under marius_amd/ includes this; the product is the hipcc build.
 #pragma once
 #include <stdint.h>
 
 #include <atomic>
-#include <barrier>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -16,7 +15,8 @@
 #include <cstring>
 #include <functional>
 #include <memory>
-#include <thread>
+#include <sys/mman.h>
+#include <ucontext.h>
 #include <tuple>
 #include <type_traits>
 #include <vector>
@@ -49,52 +49,152 @@ inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
 namespace emul {
-inline thread_local dim3 t_threadIdx, t_blockIdx;
-inline thread_local unsigned t_linear = 0;
-inline dim3 g_blockDim, g_gridDim;
-inline std::barrier<>* g_block_barrier = nullptr;
-inline std::vector<std::unique_ptr<std::barrier<>>> g_wave_barriers;
+// ---- one workgroup at a time, its work-items as FIBERS of the calling thread (ucontext): a work-item runs until it reaches a barrier, a wave
+// collective or its end, then the scheduler runs the next one.  (The first version gave every work-item a std::thread: a barrier of 512 kernel
+// threads costs milliseconds, ten times that under ASan; a fiber switch costs well under a microsecond, so the parity tests run at their own shapes.)
+// A barrier is released when every work-item of the workgroup (wave) that has not finished is waiting at it — a work-item that returned early
+// drops out, as the hardware's barrier counts only live waves.  If nothing can run and not everything has finished, the launch ABORTS with the
+// state of every work-item: a barrier under divergent control flow shows up as a message, not as a hang.
+struct Fiber {
+    ucontext_t ctx;
+    int state;  // 0 runnable, 1 waiting at the workgroup barrier, 2 waiting at its wave's barrier, 3 finished
+};
+inline dim3 g_blockDim, g_gridDim, g_threadIdx, g_blockIdx;
+inline unsigned t_linear = 0;  // the running work-item (x fastest, as the hardware packs work-items into waves)
+inline std::vector<Fiber> g_fibers;
+inline ucontext_t g_sched;
+inline std::function<void()>* g_body = nullptr;
+inline unsigned g_nt = 0;
 inline uint64_t g_slots[64][64];  // [wave][lane]
+inline unsigned char* g_dyn_smem = nullptr;  // the launch's dynamic LDS
+// (ASan's swapcontext interceptor clears the shadow of the WHOLE target stack on every switch: the stack size is the cost of a switch there)
+#if defined(__SANITIZE_ADDRESS__)
+constexpr size_t FIBER_STACK = 96 * 1024;
+#else
+constexpr size_t FIBER_STACK = 256 * 1024;
+#endif
+#if defined(__SANITIZE_ADDRESS__)
+extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+inline const void* g_sched_stack_bottom = nullptr;
+inline size_t g_sched_stack_size = 0;
+inline std::vector<void*> g_fake(1024, nullptr);
+inline void* g_sched_fake = nullptr;
+#endif
+inline unsigned char* g_stacks = nullptr;
+inline size_t g_stacks_for = 0;
 
-// One set of host threads per LAUNCH (creating 256 threads per workgroup dominated the run time, ten-fold under ASan): the threads walk the grid
-// together, workgroup by workgroup; between two workgroups they meet at `sync` twice — once so that everybody has left the previous workgroup,
-// once after thread 0 has rebuilt the workgroup's barriers (a work-item that returns early DROPS out of them, so they are per workgroup).
-inline unsigned char* g_dyn_smem = nullptr;  // the launch's dynamic LDS (one workgroup runs at a time)
+inline void to_scheduler() {  // called on a fiber
+#if defined(__SANITIZE_ADDRESS__)
+    __sanitizer_start_switch_fiber(&g_fake[t_linear], g_sched_stack_bottom, g_sched_stack_size);
+#endif
+    const unsigned me = t_linear;
+    swapcontext(&g_fibers[me].ctx, &g_sched);
+#if defined(__SANITIZE_ADDRESS__)
+    __sanitizer_finish_switch_fiber(g_fake[me], nullptr, nullptr);
+#endif
+}
+inline void trampoline() {
+#if defined(__SANITIZE_ADDRESS__)
+    __sanitizer_finish_switch_fiber(nullptr, &g_sched_stack_bottom, &g_sched_stack_size);
+#endif
+    (*g_body)();
+    g_fibers[t_linear].state = 3;
+#if defined(__SANITIZE_ADDRESS__)
+    __sanitizer_start_switch_fiber(nullptr, g_sched_stack_bottom, g_sched_stack_size);  // (nullptr: this fiber's fake stack is destroyed)
+#endif
+    // returning resumes uc_link = the scheduler
+}
+inline void wait_at(int what) {
+    g_fibers[t_linear].state = what;
+    to_scheduler();
+}
+
 template <typename F>
 void launch(dim3 grid, dim3 block, F&& body, size_t dyn_smem_bytes = 0) {
     g_blockDim = block;
     g_gridDim = grid;
-    std::unique_ptr<unsigned char[]> dyn(new unsigned char[dyn_smem_bytes + 64]);
-    g_dyn_smem = (unsigned char*)(((uintptr_t)dyn.get() + 63) & ~(uintptr_t)63);
-    const unsigned nt = block.x * block.y * block.z, nwaves = (nt + 63) / 64;  // work-items are numbered x fastest, as the hardware packs them into waves
+    const unsigned nt = block.x * block.y * block.z, nwaves = (nt + 63) / 64;
     const uint64_t nblocks = (uint64_t)grid.x * grid.y * grid.z;
     if (nt == 0 || nblocks == 0) return;
-    std::barrier<> sync((std::ptrdiff_t)nt);
-    std::unique_ptr<std::barrier<>> block_barrier;
-    std::vector<std::thread> th;
-    th.reserve(nt);
-    for (unsigned t = 0; t < nt; ++t)
-        th.emplace_back([&, t] {
-            t_linear = t;
-            t_threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-            for (uint64_t b = 0; b < nblocks; ++b) {
-                sync.arrive_and_wait();
-                if (t == 0) {
-                    block_barrier.reset(new std::barrier<>((std::ptrdiff_t)nt));
-                    g_block_barrier = block_barrier.get();
-                    g_wave_barriers.clear();
-                    for (unsigned w = 0; w < nwaves; ++w) g_wave_barriers.emplace_back(new std::barrier<>((std::ptrdiff_t)std::min(64u, nt - 64 * w)));
-                }
-                sync.arrive_and_wait();
-                t_blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((uint64_t)grid.x * grid.y)));
-                body();
-                // a work-item that returned early must not leave the others of its workgroup / wave waiting for ever
-                g_block_barrier->arrive_and_drop();
-                g_wave_barriers[t >> 6]->arrive_and_drop();
+    std::unique_ptr<unsigned char[]> dyn(new unsigned char[dyn_smem_bytes + 64]);
+    g_dyn_smem = (unsigned char*)(((uintptr_t)dyn.get() + 63) & ~(uintptr_t)63);
+    std::function<void()> fn = [&] { body(); };
+    g_body = &fn;
+    g_nt = nt;
+    g_fibers.assign(nt, Fiber{});
+    // the fibers' stacks: mapped once for the largest workgroup seen and kept (under ASan a fresh 256 MB allocation per launch was most of the run time)
+    if (nt > g_stacks_for) {  // (a namespace-scope counter: a static local here would be one per call site — launch is a template over the kernel's lambda)
+        if (g_stacks) munmap(g_stacks, g_stacks_for * FIBER_STACK);
+        g_stacks = (unsigned char*)mmap(nullptr, (size_t)nt * FIBER_STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (g_stacks == (unsigned char*)MAP_FAILED) abort();
+        g_stacks_for = nt;
+    }
+    for (uint64_t b = 0; b < nblocks; ++b) {
+        g_blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((uint64_t)grid.x * grid.y)));
+        for (unsigned t = 0; t < nt; ++t) {
+            Fiber& f = g_fibers[t];
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = g_stacks + (size_t)t * FIBER_STACK;
+            f.ctx.uc_stack.ss_size = FIBER_STACK;
+            f.ctx.uc_link = &g_sched;
+            makecontext(&f.ctx, (void (*)())trampoline, 0);
+            f.state = 0;
+        }
+        unsigned done = 0;
+        while (done < nt) {
+            bool ran = false;
+            for (unsigned t = 0; t < nt; ++t) {
+                if (g_fibers[t].state != 0) continue;
+                ran = true;
+                t_linear = t;
+                g_threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+#if defined(__SANITIZE_ADDRESS__)
+                __sanitizer_start_switch_fiber(&g_sched_fake, g_stacks + (size_t)t * FIBER_STACK, FIBER_STACK);
+#endif
+                swapcontext(&g_sched, &g_fibers[t].ctx);
+#if defined(__SANITIZE_ADDRESS__)
+                __sanitizer_finish_switch_fiber(g_sched_fake, nullptr, nullptr);
+#endif
+                if (g_fibers[t].state == 3) ++done;
             }
-        });
-    for (auto& x : th) x.join();
+            // release the barriers everybody alive has reached
+            unsigned at_block = 0, alive = 0;
+            for (unsigned t = 0; t < nt; ++t) {
+                alive += g_fibers[t].state != 3;
+                at_block += g_fibers[t].state == 1;
+            }
+            bool released = false;
+            if (alive && at_block == alive) {
+                for (unsigned t = 0; t < nt; ++t)
+                    if (g_fibers[t].state == 1) g_fibers[t].state = 0;
+                released = true;
+            }
+            for (unsigned w = 0; w < nwaves; ++w) {
+                unsigned wa = 0, ww = 0;
+                for (unsigned t = 64 * w; t < nt && t < 64 * (w + 1); ++t) {
+                    wa += g_fibers[t].state != 3;
+                    ww += g_fibers[t].state == 2;
+                }
+                if (wa && ww == wa) {
+                    for (unsigned t = 64 * w; t < nt && t < 64 * (w + 1); ++t)
+                        if (g_fibers[t].state == 2) g_fibers[t].state = 0;
+                    released = true;
+                }
+            }
+            if (!ran && !released && done < nt) {
+                fprintf(stderr, "emulated launch is stuck (workgroup %u %u %u): work-items waiting at the workgroup barrier / a wave collective / finished:", g_blockIdx.x, g_blockIdx.y,
+                        g_blockIdx.z);
+                for (unsigned t = 0; t < nt; ++t) fprintf(stderr, " %u:%d", t, g_fibers[t].state);
+                fprintf(stderr, "\n");
+                abort();
+            }
+        }
+    }
+    g_body = nullptr;
 }
+inline void block_barrier() { wait_at(1); }
+inline void wave_barrier() { wait_at(2); }
 template <typename T>
 T exchange(T v, int src_lane_of_me(int lane, int arg), int arg) {
     static_assert(sizeof(T) <= 8, "shuffle of at most 64 bits");
@@ -102,21 +202,21 @@ T exchange(T v, int src_lane_of_me(int lane, int arg), int arg) {
     uint64_t bits = 0;
     memcpy(&bits, &v, sizeof(T));
     g_slots[wave][lane] = bits;
-    g_wave_barriers[wave]->arrive_and_wait();
+    wave_barrier();
     const int src = src_lane_of_me(lane, arg);
     uint64_t got = (src >= 0 && src < 64) ? g_slots[wave][src] : bits;
-    g_wave_barriers[wave]->arrive_and_wait();
+    wave_barrier();
     T out;
     memcpy(&out, &got, sizeof(T));
     return out;
 }
 }  // namespace emul
 
-#define threadIdx emul::t_threadIdx
-#define blockIdx emul::t_blockIdx
+#define threadIdx emul::g_threadIdx
+#define blockIdx emul::g_blockIdx
 #define blockDim emul::g_blockDim
 #define gridDim emul::g_gridDim
-inline void __syncthreads() { emul::g_block_barrier->arrive_and_wait(); }
+inline void __syncthreads() { emul::block_barrier(); }
 template <typename T>
 T __shfl_xor(T v, int mask, int = 64) { return emul::exchange<T>(v, [](int lane, int m) { return lane ^ m; }, mask); }
 template <typename T>
@@ -126,10 +226,11 @@ T __shfl(T v, int src, int = 64) { return emul::exchange<T>(v, [](int, int sl) {
 inline unsigned long long __ballot(int pred) {
     const int lane = emul::t_linear & 63, wave = emul::t_linear >> 6;
     emul::g_slots[wave][lane] = pred ? 1ull : 0ull;
-    emul::g_wave_barriers[wave]->arrive_and_wait();
+    emul::wave_barrier();
     unsigned long long m = 0;
-    for (int l = 0; l < 64; ++l) m |= (emul::g_slots[wave][l] & 1ull) << l;   // (lanes that do not exist in a short last wave never wrote: their slots are stale)
-    emul::g_wave_barriers[wave]->arrive_and_wait();
+    const int lanes = (int)std::min(64u, emul::g_nt - 64u * (unsigned)wave);
+    for (int l = 0; l < lanes; ++l) m |= (emul::g_slots[wave][l] & 1ull) << l;
+    emul::wave_barrier();
     return m;
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
@@ -152,8 +253,8 @@ T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline float __expf(float x) { return expf(x); }
 inline float __logf(float x) { return logf(x); }
 inline unsigned long long __builtin_amdgcn_ballot_w64(bool pred) { return __ballot(pred ? 1 : 0); }
-inline void __builtin_amdgcn_wave_barrier() { emul::g_wave_barriers[emul::t_linear >> 6]->arrive_and_wait(); }
-inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
+inline void __builtin_amdgcn_wave_barrier() { emul::wave_barrier(); }
+inline void __builtin_amdgcn_s_sleep(int) {}  // (workgroups run one after another: what a spin waits for has already happened)
 template <typename T>
 T __builtin_amdgcn_readfirstlane(T v) { return emul::exchange<T>(v, [](int, int) { return 0; }, 0); }   // (lane 0 of every wave that calls it is active in the emulated files)
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)

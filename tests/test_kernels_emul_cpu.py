@@ -1,7 +1,8 @@
 """The GPU parity tests of the kernel files that have a CPU build (tests/emul/build_emul.py: rows.hip, rng.hip, encoder.hip, neighbor.hip compiled by
 g++ against a shim that emulates HIP's execution model on host threads; since: segreduce.hip, sort_unique.hip, exchange.hip), run AS THEY ARE — the same test functions, imported from
 tests/test_gpu_parity.py / tests/test_gpu_host.py — with the ctypes layer pointed at the emulated library for the duration of a test and "the device"
-being the host.  What this adds to the `-m gpu` runs: the kernels' logic is checked in the CPU suite of every round, and once more under
+being the host.  Work-items are fibers of one thread (tests/emul/common.h), so most tests keep the shapes they have on the GPU; the few that exist only at
+the bench's shape take minutes each and run with MARIUS_EMUL_FULL=1.  What this adds to the `-m gpu` runs: the kernels' logic is checked in the CPU suite of every round, and once more under
 AddressSanitizer + UBSan (the GPU pool has no sanitizer builds).  What it does not replace: the hipcc build, the hardware, the timing.
 Test infrastructure: marius_amd/ has no switch to reach the emulated library; the redirection is a monkeypatch that lives in this file."""
 import ctypes as C
@@ -17,7 +18,8 @@ sys.path.insert(0, os.path.join(HERE, "emul"))
 sys.path.insert(0, HERE)
 
 CPU = torch.device("cpu")
-SAN = os.environ.get("MARIUS_EMUL_SANITIZE") == "1"   # inside the sanitizer run: fewer and smaller cases (every emulated work-item is a thread with a shadow stack)
+SAN = os.environ.get("MARIUS_EMUL_SANITIZE") == "1"   # inside the sanitizer run: fewer and smaller cases
+FULL = os.environ.get("MARIUS_EMUL_FULL") == "1"      # the bench-shape cases too (minutes each: profiles/r6_emulated_full_shapes.txt)
 
 
 @pytest.fixture(scope="module")
@@ -74,10 +76,11 @@ def test_sampler_kernels_on_the_cpu_build(HE):
     """rng.hip: ATen's MT19937 stream, CorruptNodeNegativeSampler::getNegatives (negative.cpp:328-366), RandomEdgeSampler::getEdges (edge.cpp:12-14)"""
     import test_gpu_parity as TP
 
-    for n in ((1, 625, 3000) if SAN else (1, 623, 624, 625, 5000, 20000)):
+    for n in ((1, 625, 3000) if SAN else (1, 623, 624, 625, 5000, 100000)):
         TP.test_mt19937_device_stream_bit_exact(HE, CPU, n)
     shapes = ((6, 1, 5, 0.0, 6), (6, 3, 5, 0.5, 6), (1000, 10, 500, 0.0, 14541), (1000, 10, 500, 0.5, 14541), (64, 2, 16, 0.25, 2 ** 28 + 5))
-    for B, Cn, N, f, num_nodes in (shapes[:2] + shapes[4:] if SAN else shapes):
+    shapes += ((5000, 50, 1000, 0.0, 86054151),)
+    for B, Cn, N, f, num_nodes in (shapes[:2] + shapes[4:5] if SAN else shapes):
         TP.test_negative_sampler_bit_exact(HE, CPU, B, Cn, N, f, num_nodes)
     TP.test_select_edges(HE, CPU)
 
@@ -98,15 +101,18 @@ def test_unique_map_kernels_on_the_cpu_build(HE):
     is the single-workgroup case its design promises to complete) — against torch.unique / the separate launches, bit for bit"""
     import test_gpu_parity as TP
 
-    sizes = ((1, 5), (12, 6), (4097, 1 << 20), (5001, (1 << 36) - 5)) if SAN else ((1, 5), (12, 6), (4095, 1 << 20), (4096, 1 << 20), (4097, 1 << 20), (16385, 1),
-                                                                                 (5001, (1 << 36) - 5), (9001, (1 << 40) + 3))
+    sizes = ((1, 5), (12, 6), (4097, 1 << 20), (5001, (1 << 36) - 5)) if SAN else ((1, 5), (12, 6), (12000, 14541), (4095, 1 << 20), (4096, 1 << 20), (4097, 1 << 20), (16385, 1),
+                                                                                 (70001, (1 << 36) - 5), (70001, (1 << 40) + 3), (200000, 86054151))
     for n, hi in sizes:
         TP.test_sort_unique_matches_map_tensors(HE, CPU, n, hi)
     TP.test_sort_unique_empty(HE, CPU)
+    if not SAN:
+        TP.test_sort_unique_reuses_its_workspace_across_calls_and_sizes(HE, CPU)
     shapes = ((250, 5, 40, 4000, 11, 3, False), (7, 1, 3, 50, 2, 3, False), (1, 1, 1, 2, 1, 3, False), (2049, 3, 683, 99999, 5, 3, True))
-    for B, Cn, N, num_nodes, R, cols, hubs in (shapes[:3] if SAN else shapes):   # (the bench batch and FB15k-237's shape: GPU suite)
+    big = ((1000, 10, 500, 14541, 237, 3, False), (4096, 1, 4096, 1 << 20, 1, 2, False)) + (((50000, 50, 1000, 86054151, 14824, 3, True),) if FULL else ())
+    for B, Cn, N, num_nodes, R, cols, hubs in (shapes[:3] if SAN else shapes + big):
         TP.test_prepare_maps_one_launch_equals_the_separate_launches(HE, CPU, B, Cn, N, num_nodes, R, cols, hubs)
-    for runs in (([1], [0, 7, 0], [1000, 0, 0, 3]) if SAN else ([1], [5000], [0, 7, 0], [3000, 2500, 4000, 1], [1000, 0, 0, 3], [17] * 64)):
+    for runs in (([1], [0, 7, 0], [1000, 0, 0, 3]) if SAN else ([1], [5000], [0, 7, 0], [3000, 2500, 4000, 1], [25000] * 8, [1000, 0, 0, 3], [17] * 64)):
         TP.test_merge_unique_runs_equals_sort_unique(HE, CPU, runs)
 
 
@@ -114,12 +120,12 @@ def test_exchange_kernels_on_the_cpu_build(HE):
     """exchange.hip: the fixed-capacity halves of the sharded row exchange and the header record against the numpy restatement (oracle/exchange_oracle.py)"""
     import test_gpu_parity as TP
 
-    TP.test_fixed_capacity_exchange_halves_against_numpy(HE, CPU, 2, 1.5)   # (worlds 1 / 4 / 8: GPU suite — every emulated work-item is a host thread)
+    for world, slack in (((2, 1.5),) if SAN else ((1, 1.0), (2, 1.5), (8, 1.5), (4, 1.0))):
+        TP.test_fixed_capacity_exchange_halves_against_numpy(HE, CPU, world, slack)
 
 
 def test_cpu_build_under_address_and_undefined_behaviour_sanitizers():
-    """the storage-row, sampler and post-hook groups of this file (reduced shapes) and a cross-section of tests/test_neighbor_emul_cpu.py again (all of
-    both files with MARIUS_EMUL_SANITIZE_ALL=1: 4-6 minutes; last run clean on the round's final tree), in a python started under libasan with the kernel files built with
+    """every emulated test of this file (reduced shapes) and of tests/test_neighbor_emul_cpu.py again, in a python started under libasan with the kernel files built with
     -fsanitize=address,undefined: an out-of-bounds index, a misaligned or overflowing access in any emulated work-item aborts the run"""
     if os.environ.get("MARIUS_EMUL_SANITIZE") == "1":
         pytest.skip("already inside the sanitizer run")
@@ -127,9 +133,7 @@ def test_cpu_build_under_address_and_undefined_behaviour_sanitizers():
     if not os.path.isabs(asan) or not os.path.exists(asan):
         pytest.skip("no libasan.so next to gcc")
     env = dict(os.environ, MARIUS_EMUL_SANITIZE="1", LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
-    # default: the cheaper groups (a barrier of 512 host threads under ASan costs milliseconds); MARIUS_EMUL_SANITIZE_ALL=1: every emulated test
-    select = ("not sanitizers" if os.environ.get("MARIUS_EMUL_SANITIZE_ALL") == "1" else
-              "rows_kernels or sampler_kernels or post_hook_kernels or delta_ids or (one_hop and 3-2) or (aggregation and GCN and 7) or (layered and fanouts1)")
+    select = "not sanitizers"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(HERE, "test_neighbor_emul_cpu.py"), "-x", "-q", "-p", "no:cacheprovider",
                         "-k", select], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=2400, cwd=os.path.dirname(HERE))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-4000:]
@@ -140,12 +144,16 @@ def test_segmented_update_kernels_on_the_cpu_build(HE):
     InMemory::indexAdd on the unique rows (batch.cpp:62-79, storage.cpp:651-673), planned / tracked / grouped forms, the table magnitude scan"""
     import test_gpu_parity as TP
 
-    for n, U, d in (((1, 1, 4),) if SAN else ((1, 1, 4), (1000, 900, 100))):   # (every emulated work-item is a host thread: the larger shapes stay with the GPU suite)
+    for n, U, d in (((1, 1, 4), (1000, 900, 100)) if SAN else ((1, 1, 4), (1000, 900, 100), (5000, 37, 50), (4096, 3, 7), (3000, 2500, 400)) + (((20000, 19000, 100),) if FULL else ())):
         TP.test_segment_sum_rows(HE, CPU, n, U, d)
-    for n, num_nodes, power, d in ((33, 5, 1, 20), (1, 9, 1, 8), (700, 90, 2, 36)):
+    TP.test_segment_adagrad_scatter_matches_reference_update(HE, CPU)
+    for n, num_nodes, power, d in ((33, 5, 1, 20), (1, 9, 1, 8), (700, 90, 2, 36)) + (() if SAN else ((8000, 3000, 3, 100),)) + (((200000, 86054151, 1, 100),) if FULL else ()):
         TP.test_planned_segment_adagrad_scatter_is_bit_identical(HE, CPU, n, num_nodes, power, d)
-    for n, rows, d, planned in ((33, 5, 20, False), (600, 200, 100, True)):
+    for n, rows, d, planned in ((33, 5, 20, False), (600, 200, 100, True)) + (() if SAN else ((8000, 3000, 100, True),)):
         TP.test_tracked_update_keeps_the_magnitude_bound(HE, CPU, n, rows, d, planned)
-    for rows, d, ld in ((1000, 100, 100), (777, 50, 50), (513, 33, 33), (3, 7, 7)):
+    for rows, d, ld in ((1000, 100, 100), (777, 50, 50), (513, 33, 33), (3, 7, 7), (4096, 100, 112)):
         TP.test_table_absmax_flat_strided_and_counted(HE, CPU, rows, d, ld)
-    # (the grouped-launch tests run at the bench's shape only — 200,000 occurrences x 100 columns — which is hours of host threads: GPU suite only)
+    if FULL:  # the grouped-launch tests exist at the bench's shape only (200,000 occurrences x 100 columns): four minutes each on the emulator
+        for planned in (True, False):
+            TP.test_grouped_update_of_three_tables_equals_the_separate_updates(HE, CPU, planned)
+        TP.test_group_with_a_reduce_only_job_equals_the_separate_calls(HE, CPU, True)

@@ -61,7 +61,7 @@ def one_hop(E, og, ids, incoming, max_neighbors, rs):
 def test_emulated_one_hop_sampler_equals_the_oracle(E, cols, max_neighbors):
     og = graph(300, 2500, cols, seed=cols)
     g = torch.Generator().manual_seed(5 + max_neighbors)
-    for n in ((6, 1025) if os.environ.get("MARIUS_EMUL_SANITIZE") == "1" else (1, 6, 1025, 2300)):  # 1025 / 2300: more than one scan tile
+    for n in ((6, 1025) if os.environ.get("MARIUS_EMUL_SANITIZE") == "1" else (1, 6, 1025, 5000)):  # 1025 / 5000: more than one scan tile
         ids = torch.randint(300, (n,), generator=g)
         ids[0], ids[-1] = 3, 299
         for incoming in (True, False):
