@@ -10,8 +10,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 KDIR = os.path.join(ROOT, "marius_amd", "csrc", "kernels")
-FILES = ["neighbor.hip", "rows.hip", "rng.hip", "encoder.hip", "segreduce.hip", "sort_unique.hip", "exchange.hip"]
-HEADERS = ["seg_plan.h"]  # kernel-side headers the files include by name: copied next to them (their own `#include "common.h"` then finds the shim)
+FILES = ["neighbor.hip", "rows.hip", "rng.hip", "encoder.hip", "segreduce.hip", "sort_unique.hip", "exchange.hip", "lp_decoder.hip"]
+HEADERS = ["seg_plan.h", "lp_common.h"]  # kernel-side headers the files include by name: copied next to them (their own `#include "common.h"` then finds the shim)
 
 
 def _match(s, i, open_ch, close_ch):
@@ -45,9 +45,9 @@ def _split_top(s):
 
 def transform(src):
     """rewrite every kernel launch of a .hip source for the emulation build; dynamic LDS (`extern __shared__ T name[];`) becomes a pointer into the
-    launch's buffer; clang's ext_vector_type becomes GCC's vector_size"""
+    launch's buffer; clang's ext_vector_type becomes the shim's emul::vec"""
     src = re.sub(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];", r"\1* \2 = reinterpret_cast<\1*>(emul::g_dyn_smem);", src)
-    src = re.sub(r"typedef\s+float\s+(\w+)\s+__attribute__\(\(ext_vector_type\((\d+)\)\)\);", lambda m: "typedef float %s __attribute__((vector_size(%d)));" % (m.group(1), 4 * int(m.group(2))), src)
+    src = re.sub(r"typedef\s+(\w+)\s+(\w+)\s+__attribute__\(\(ext_vector_type\((\d+)\)\)\);", r"typedef emul::vec<\1, \3> \2;", src)
     out, i = "", 0
     while True:
         j = src.find("<<<", i)

@@ -41,6 +41,98 @@ struct alignas(8) float2 {
 struct alignas(16) float4 {
     float x, y, z, w;
 };
+// fp16 / bf16 scalars g++ 11 does not have on x86-64: conversion from float rounds to nearest even (v_cvt_f16_f32 / v_cvt_pk_bf16_f32), back is exact
+struct _Float16 {
+    uint16_t b;
+    _Float16() = default;
+    _Float16(float f) {
+        uint32_t x;
+        memcpy(&x, &f, 4);
+        const uint32_t sign = (x >> 16) & 0x8000u;
+        const int32_t e = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+        uint32_t m = x & 0x7fffffu;
+        if (((x >> 23) & 0xff) == 0xff) {
+            b = (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0));
+        } else if (e >= 31) {
+            b = (uint16_t)(sign | 0x7c00u);
+        } else if (e <= 0) {
+            if (e < -10) {
+                b = (uint16_t)sign;
+            } else {
+                m |= 0x800000u;
+                const int shift = 14 - e;  // 13 + (1 - e)
+                uint32_t h = m >> shift;
+                const uint32_t rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+                if (rem > half || (rem == half && (h & 1))) ++h;
+                b = (uint16_t)(sign | h);
+            }
+        } else {
+            uint32_t h = ((uint32_t)e << 10) | (m >> 13);
+            const uint32_t rem = m & 0x1fffu;
+            if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;
+            b = (uint16_t)(sign | h);
+        }
+    }
+    operator float() const {
+        const uint32_t sign = (uint32_t)(b & 0x8000u) << 16, e = (b >> 10) & 0x1f, m = b & 0x3ffu;
+        uint32_t x;
+        if (e == 0) {
+            if (m == 0) {
+                x = sign;
+            } else {
+                int k = 0;
+                uint32_t mm = m;
+                while (!(mm & 0x400u)) {
+                    mm <<= 1;
+                    ++k;
+                }
+                x = sign | ((uint32_t)(127 - 15 + 1 - k) << 23) | ((mm & 0x3ffu) << 13);
+            }
+        } else if (e == 31) {
+            x = sign | 0x7f800000u | (m << 13);
+        } else {
+            x = sign | ((e + 127 - 15) << 23) | (m << 13);
+        }
+        float f;
+        memcpy(&f, &x, 4);
+        return f;
+    }
+};
+struct __bf16 {
+    uint16_t b;
+    __bf16() = default;
+    __bf16(float f) {
+        uint32_t x;
+        memcpy(&x, &f, 4);
+        if ((x & 0x7fffffffu) > 0x7f800000u) {
+            b = (uint16_t)((x >> 16) | 0x40u);
+        } else {
+            x += 0x7fffu + ((x >> 16) & 1u);
+            b = (uint16_t)(x >> 16);
+        }
+    }
+    operator float() const {
+        const uint32_t x = (uint32_t)b << 16;
+        float f;
+        memcpy(&f, &x, 4);
+        return f;
+    }
+};
+namespace emul {
+template <typename T, int N>
+struct vec {  // clang's ext_vector_type for the emulation build: element access, brace initialisation, elementwise conversion
+    T v[N];
+    T& operator[](int i) { return v[i]; }
+    const T& operator[](int i) const { return v[i]; }
+};
+template <typename To, typename S, int N>
+To convert(const vec<S, N>& a) {
+    To r;
+    for (int i = 0; i < N; ++i) r[i] = static_cast<std::remove_reference_t<decltype(r[0])>>(a[i]);
+    return r;
+}
+}  // namespace emul
+#define __builtin_convertvector(v, T) emul::convert<T>(v)
 struct alignas(16) int4 {
     int x, y, z, w;
 };
@@ -252,6 +344,30 @@ template <typename T>
 T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline float __expf(float x) { return expf(x); }
 inline float __logf(float x) { return logf(x); }
+// v_mfma_f32_32x32x2_f32 as a wave collective (lp_common.h: lane l supplies A[m = l & 31][k = l >> 5] and B[k = l >> 5][n = l & 31] and holds
+// D[m = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][n = l & 31] in register r): every lane publishes (a, b), then computes its 16 outputs in fp32, k = 0 then k = 1
+inline emul::vec<float, 16> __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emul::vec<float, 16> c, int, int, int) {
+    const int lane = emul::t_linear & 63, wave = emul::t_linear >> 6;
+    uint64_t bits;
+    const float ab[2] = {a, b};
+    memcpy(&bits, ab, 8);
+    emul::g_slots[wave][lane] = bits;
+    emul::wave_barrier();
+    const int n = lane & 31, h = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float am[2], bn[2];
+            memcpy(am, &emul::g_slots[wave][m + 32 * k], 8);
+            memcpy(bn, &emul::g_slots[wave][n + 32 * k], 8);
+            acc = acc + am[0] * bn[1];
+        }
+        c[r] = acc;
+    }
+    emul::wave_barrier();
+    return c;
+}
 inline unsigned long long __builtin_amdgcn_ballot_w64(bool pred) { return __ballot(pred ? 1 : 0); }
 inline void __builtin_amdgcn_wave_barrier() { emul::wave_barrier(); }
 inline void __builtin_amdgcn_s_sleep(int) {}  // (workgroups run one after another: what a spin waits for has already happened)
@@ -301,6 +417,9 @@ struct KernelEnv {
     bool seg_fused_fixup_off, seg_group_off;
     bool sort_rocprim, maps_fused;
     int pm_nwg;
+    // lp_decoder.hip: the CPU build is the generic level (the tuned levels live in lp_fast / lp_res / lp_flash .hip, which are not part of it)
+    char scores = 0, kernels = 'g';
+    bool no_fast = true, no_vlog = false, timeline_grads = false, flash_f16_off = false;
 };
 inline KernelEnv read_env() {
     auto first = [](const char* name) -> char { const char* e = getenv(name); return e ? e[0] : (char)0; };

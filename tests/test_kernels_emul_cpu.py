@@ -1,5 +1,5 @@
 """The GPU parity tests of the kernel files that have a CPU build (tests/emul/build_emul.py: rows.hip, rng.hip, encoder.hip, neighbor.hip compiled by
-g++ against a shim that emulates HIP's execution model on host threads; since: segreduce.hip, sort_unique.hip, exchange.hip), run AS THEY ARE — the same test functions, imported from
+g++ against a shim that emulates HIP's execution model on host threads; since: segreduce.hip, sort_unique.hip, exchange.hip, lp_decoder.hip's generic level), run AS THEY ARE — the same test functions, imported from
 tests/test_gpu_parity.py / tests/test_gpu_host.py — with the ctypes layer pointed at the emulated library for the duration of a test and "the device"
 being the host.  Work-items are fibers of one thread (tests/emul/common.h), so most tests keep the shapes they have on the GPU; the few that exist only at
 the bench's shape take minutes each and run with MARIUS_EMUL_FULL=1.  What this adds to the `-m gpu` runs: the kernels' logic is checked in the CPU suite of every round, and once more under
@@ -102,11 +102,11 @@ def test_unique_map_kernels_on_the_cpu_build(HE):
     import test_gpu_parity as TP
 
     sizes = ((1, 5), (12, 6), (4097, 1 << 20), (5001, (1 << 36) - 5)) if SAN else ((1, 5), (12, 6), (12000, 14541), (4095, 1 << 20), (4096, 1 << 20), (4097, 1 << 20), (16385, 1),
-                                                                                 (70001, (1 << 36) - 5), (70001, (1 << 40) + 3), (200000, 86054151))
+                                                                                 (70001, (1 << 36) - 5), (70001, (1 << 40) + 3)) + (((200000, 86054151),) if FULL else ())
     for n, hi in sizes:
         TP.test_sort_unique_matches_map_tensors(HE, CPU, n, hi)
     TP.test_sort_unique_empty(HE, CPU)
-    if not SAN:
+    if FULL:
         TP.test_sort_unique_reuses_its_workspace_across_calls_and_sizes(HE, CPU)
     shapes = ((250, 5, 40, 4000, 11, 3, False), (7, 1, 3, 50, 2, 3, False), (1, 1, 1, 2, 1, 3, False), (2049, 3, 683, 99999, 5, 3, True))
     big = ((1000, 10, 500, 14541, 237, 3, False), (4096, 1, 4096, 1 << 20, 1, 2, False)) + (((50000, 50, 1000, 86054151, 14824, 3, True),) if FULL else ())
@@ -122,6 +122,33 @@ def test_exchange_kernels_on_the_cpu_build(HE):
 
     for world, slack in (((2, 1.5),) if SAN else ((1, 1.0), (2, 1.5), (8, 1.5), (4, 1.0))):
         TP.test_fixed_capacity_exchange_halves_against_numpy(HE, CPU, world, slack)
+
+
+def test_decoder_generic_kernels_on_the_cpu_build(HE, monkeypatch):
+    """lp_decoder.hip at its generic level (the tuned levels live in lp_fast / lp_res / lp_flash .hip, which have no CPU build): select_relations,
+    the relation operators, Dot / L2 scores on the emulated v_mfma_f32_32x32x2_f32 (a wave collective in the shim), pad_and_reshape, node_corrupt_forward,
+    SoftmaxCE and the six other losses, the hand-derived backward, ranks — decoder_methods.cpp:57-114, relation_operators.cpp:7-47, comparators.cpp:7-73,
+    loss.cpp:50-187, reporting.cpp:55-57 — through marius_lp_plan / _forward / _loss / _backward against the oracle, as the GPU suite does"""
+    import test_gpu_parity as TP
+
+    shapes = ((6, 3, 5, 2), (5, 4, 6, 8)) if SAN else ((6, 3, 5, 2), (100, 10, 50, 50), (5, 4, 6, 8), (2, 4, 64, 100), (1, 3, 33, 100))
+    for decoder in ("DISTMULT", "COMPLEX", "TRANSE"):
+        for use_inverse in (True, False):
+            for B, Cn, N, d in shapes:
+                TP.test_lp_forward_loss_backward(HE, CPU, decoder, use_inverse, B, Cn, N, d, "sum")
+    if not SAN:
+        TP.test_lp_forward_loss_backward(HE, CPU, "COMPLEX", True, 250, 7, 130, 100, "sum")   # B % C != 0, N not a multiple of the tile
+        TP.test_lp_forward_loss_backward(HE, CPU, "TRANSE", False, 250, 7, 130, 100, "sum")
+        TP.test_lp_forward_loss_backward(HE, CPU, "DISTMULT", True, 300, 4, 260, 200, "sum")  # rows wider than 128 columns
+    for decoder in ("DISTMULT", "TRANSE"):
+        TP.test_lp_mean_reduction_and_filter(HE, CPU, decoder)
+    TP.test_lp_two_column_edges(HE, CPU)
+    TP.test_lp_bad_edge_columns_raises(HE, CPU)
+    TP.test_compute_ranks(HE, CPU)
+    for loss in (TP.LOSSES[:2] if SAN else TP.LOSSES):   # (novlog: the generic backward with the loss-specific dL/dS — the form this build has)
+        for cfg in ((("DISTMULT", False, 5, 4, 6, 8, "mean"),) if SAN else (("DISTMULT", True, 100, 10, 50, 50, "sum"), ("DISTMULT", False, 5, 4, 6, 8, "mean")) +
+                    ((("COMPLEX", True, 250, 7, 130, 100, "mean"),) if loss in ("RANKING", "SOFTPLUS") else ())):
+            TP.test_lp_other_losses_forward_backward(HE, CPU, monkeypatch, True, loss, *cfg)
 
 
 def test_cpu_build_under_address_and_undefined_behaviour_sanitizers():
@@ -147,7 +174,7 @@ def test_segmented_update_kernels_on_the_cpu_build(HE):
     for n, U, d in (((1, 1, 4), (1000, 900, 100)) if SAN else ((1, 1, 4), (1000, 900, 100), (5000, 37, 50), (4096, 3, 7), (3000, 2500, 400)) + (((20000, 19000, 100),) if FULL else ())):
         TP.test_segment_sum_rows(HE, CPU, n, U, d)
     TP.test_segment_adagrad_scatter_matches_reference_update(HE, CPU)
-    for n, num_nodes, power, d in ((33, 5, 1, 20), (1, 9, 1, 8), (700, 90, 2, 36)) + (() if SAN else ((8000, 3000, 3, 100),)) + (((200000, 86054151, 1, 100),) if FULL else ()):
+    for n, num_nodes, power, d in ((33, 5, 1, 20), (1, 9, 1, 8), (700, 90, 2, 36)) + (((8000, 3000, 3, 100), (200000, 86054151, 1, 100)) if FULL else ()):
         TP.test_planned_segment_adagrad_scatter_is_bit_identical(HE, CPU, n, num_nodes, power, d)
     for n, rows, d, planned in ((33, 5, 20, False), (600, 200, 100, True)) + (() if SAN else ((8000, 3000, 100, True),)):
         TP.test_tracked_update_keeps_the_magnitude_bound(HE, CPU, n, rows, d, planned)
