@@ -27,7 +27,8 @@ stats() {  # name, bench args...
 timeout 600 python bench.py > $out/bench_freebase86m.json 2> $out/bench_freebase86m.err; tail -c 300 $out/bench_freebase86m.json; echo
 stats freebase86m
 pmc freebase86m
-bash tools/sessions/gpu_session_timeline.sh ${tag}_tl > /dev/null 2>&1; cp gpurun_out/${tag}_tl/timeline.txt $out/timeline_one_step.txt; head -3 $out/timeline_one_step.txt
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace -d /tmp/tl_${tag} -o kt --output-format csv -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-fp32-pass --no-profile --no-arith-check > $out/kt_timeline.log 2>&1 )
+f=$(find /tmp/tl_${tag} -name "*kernel_trace.csv" | head -1); python tools/trace_gaps.py $f lp_prep2 -12 > $out/timeline_one_step.txt; head -3 $out/timeline_one_step.txt
 # ---- twitter (cfg5 shape)
 timeout 400 python bench.py --workload twitter --no-arith-check --no-cpu-baseline > $out/bench_twitter_d400.json 2> $out/bench_twitter_d400.err
 stats twitter_d400 --workload twitter
