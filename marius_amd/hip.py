@@ -411,6 +411,23 @@ def layer_post_hook_backward(gy, y, activation="NONE", with_bias=True):
     return gx, bg
 
 
+def true_edge_filter(sorted_edges, edges, inverse):
+    """compute_filter_corruption, global filter (src/data/samplers/negative.cpp:50-293): [F, 2] = (batch edge id, node whose score is masked) for every known
+    edge that shares a batch edge's uncorrupted endpoint and relation.  sorted_edges: all known edges sorted by source (inverse False) / destination (True).
+    One host read (F) between the two launches, as the reference sizes its output."""
+    _dev(edges)
+    B, cols = edges.shape
+    counts = torch.empty(B, dtype=torch.int64, device=edges.device)
+    offsets = torch.empty(B + 1, dtype=torch.int64, device=edges.device)
+    check(lib().marius_true_edge_filter_offsets(ptr(sorted_edges), sorted_edges.size(0), cols, 1 if inverse else 0, ptr(edges), B, ptr(counts), ptr(offsets), stream_ptr()),
+          "true_edge_filter_offsets")
+    F = int(offsets[B].item())
+    out = torch.empty((F, 2), dtype=torch.int64, device=edges.device)
+    check(lib().marius_true_edge_filter_emit(ptr(sorted_edges), sorted_edges.size(0), cols, 1 if inverse else 0, ptr(edges), B, ptr(offsets), ptr(out), stream_ptr()),
+          "true_edge_filter_emit")
+    return out
+
+
 def owner_offsets_counts(um, shard_rows, world):
     """marius_owner_offsets_counts: (offs [world + 1], send counts [world]) of a sorted unique map, one launch"""
     offs = torch.empty(world + 1, dtype=torch.int64, device=um.uniq.device)

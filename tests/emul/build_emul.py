@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 KDIR = os.path.join(ROOT, "marius_amd", "csrc", "kernels")
-FILES = ["neighbor.hip", "rows.hip", "rng.hip", "encoder.hip", "segreduce.hip", "sort_unique.hip", "exchange.hip", "lp_decoder.hip"]
+FILES = ["neighbor.hip", "rows.hip", "rng.hip", "encoder.hip", "segreduce.hip", "sort_unique.hip", "exchange.hip", "lp_decoder.hip", "eval_filter.hip"]
 HEADERS = ["seg_plan.h", "lp_common.h"]  # kernel-side headers the files include by name: copied next to them (their own `#include "common.h"` then finds the shim)
 
 

@@ -282,3 +282,23 @@ def test_layout_refuses_a_record_layout_changed_after_the_plan(H, dev, monkeypat
         H.reload_env()
     W.forward()  # the planned layout is valid again
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------ also new: the true-edge filter through the C-ABI directly
+@pytest.mark.parametrize("cols", [2, 3])
+@pytest.mark.parametrize("num_nodes,E,B", [(50, 400, 64), (1000, 20000, 500), (7, 30, 9)])
+def test_true_edge_filter_equals_the_reference_loop(H, dev, cols, num_nodes, E, B):
+    """marius_true_edge_filter_offsets / _emit against compute_filter_corruption's global branch (negative.cpp:50-205, oracle/lp_oracle.py: loop for loop),
+    both corruption sides, duplicate edges in the known list and in the batch, batch edges that are not known edges.  (Until round 6 these entry
+    points were only exercised through the C++ host's filtered evaluation.)"""
+    from oracle import lp_oracle as O
+
+    g = torch.Generator().manual_seed(num_nodes + cols)
+    known = torch.stack([torch.randint(num_nodes, (E,), generator=g)] + ([torch.randint(3, (E,), generator=g)] if cols == 3 else []) + [torch.randint(num_nodes, (E,), generator=g)], 1)
+    src_sorted = known[known[:, 0].argsort(stable=True)]
+    dst_sorted = known[known[:, -1].argsort(stable=True)]
+    batch = torch.cat([known[torch.randint(E, (B - 3,), generator=g)], torch.stack([torch.randint(num_nodes, (3,), generator=g) for _ in range(cols)], 1)])
+    for inverse in (False, True):
+        want = O.compute_filter_corruption_global(src_sorted, dst_sorted, batch, inverse)
+        got = H.true_edge_filter((dst_sorted if inverse else src_sorted).to(dev), batch.to(dev), inverse)
+        assert torch.equal(got.cpu(), want)

@@ -151,6 +151,15 @@ def test_decoder_generic_kernels_on_the_cpu_build(HE, monkeypatch):
             TP.test_lp_other_losses_forward_backward(HE, CPU, monkeypatch, True, loss, *cfg)
 
 
+def test_true_edge_filter_kernels_on_the_cpu_build(HE):
+    """eval_filter.hip: compute_filter_corruption's global branch (negative.cpp:50-293) through the C-ABI"""
+    import test_gpu_zz_unverified_cfg4 as TZ
+
+    for cols in (2, 3):
+        for num_nodes, E, B in (((50, 400, 64), (7, 30, 9)) if SAN else ((50, 400, 64), (1000, 20000, 500), (7, 30, 9))):
+            TZ.test_true_edge_filter_equals_the_reference_loop(HE, CPU, cols, num_nodes, E, B)
+
+
 def test_cpu_build_under_address_and_undefined_behaviour_sanitizers():
     """every emulated test of this file (reduced shapes) and of tests/test_neighbor_emul_cpu.py again, in a python started under libasan with the kernel files built with
     -fsanitize=address,undefined: an out-of-bounds index, a misaligned or overflowing access in any emulated work-item aborts the run"""
