@@ -541,6 +541,14 @@ int marius_nbr_degrees(const int64_t* node_ids, int64_t n, const int64_t* num_ne
                        marius_stream_t stream);
 int marius_nbr_gather(const int64_t* sorted_edges, int32_t cols, const int64_t* num, const int64_t* global_offsets, const int64_t* local_offsets,
                       const int64_t* capped, int64_t n, const int64_t* rand_samples, int64_t total, int64_t* out_edges, marius_stream_t stream);
+/* NeighborSamplingLayer::DROPOUT: sample_dropout_gpu (src/cpp/src/data/samplers/neighbor.cpp:236-253).  After marius_nbr_degrees with max_neighbors < 0 (num,
+ * global_offsets, local_offsets, total): keep_rand [total] = the reference's torch::rand draw, neighbour p survives iff keep_rand[p] >= rate.
+ * _offsets: keep [total] / scan [total] int64 scratch (flags and their exclusive scan), new_local_offsets [n], *total_kept_dev; workspace:
+ * marius_nbr_workspace_bytes(total).  _emit: out_edges [total_kept, cols] in the reference's (masked_select) order. */
+int marius_nbr_dropout_offsets(const int64_t* local_offsets, int64_t n, int64_t total, const float* keep_rand, float rate, int64_t* keep, int64_t* scan,
+                               int64_t* new_local_offsets, int64_t* total_kept_dev, void* workspace, size_t workspace_bytes, marius_stream_t stream);
+int marius_nbr_dropout_emit(const int64_t* sorted_edges, int32_t cols, const int64_t* global_offsets, const int64_t* local_offsets, int64_t n, const int64_t* keep,
+                            const int64_t* scan, int64_t total, int64_t* out_edges, marius_stream_t stream);
 int marius_nbr_delta_ids(const int64_t* in_edges, int64_t n_in, const int64_t* out_edges, int64_t n_out, int32_t cols, const int64_t* node_ids,
                          int64_t n_node_ids, int64_t num_nodes, uint8_t* marks, int64_t* keys, int64_t* uniq, int64_t* inverse, int32_t* perm,
                          int32_t* seg_offsets, int64_t* num_unique_dev, void* sort_workspace, size_t sort_workspace_bytes, marius_stream_t stream);

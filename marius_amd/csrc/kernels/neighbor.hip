@@ -6,6 +6,8 @@
 // batch-local mapping (graph.cpp:361-398).  Here:
 //   marius_nbr_degrees     degrees / CSR offsets of the requested nodes, capped degrees, their exclusive scan and total      (3 launches)
 //   marius_nbr_gather      every sampled edge in one launch: owner by binary search in the scan, ALL: k-th neighbour, UNIFORM: start + rand % degree
+//   marius_nbr_dropout_*   NeighborSamplingLayer::DROPOUT (neighbor.cpp:236-253): keep flags from the caller's torch::rand draw, ONE scan of the flags gives both
+//                          the kept neighbours' output positions (masked_select's order) and the nodes' new local offsets
 //   marius_nbr_delta_ids   next hop's ids = ascending unique neighbour ids not yet in the batch: O(batch) — a persistent mark array tested per
 //                          candidate, marked candidates mapped to a sentinel key, marius_sort_unique, sentinel dropped — instead of O(num_nodes)
 //   marius_nbr_positions   batch-local position of every neighbour through a persistent position table (written for the batch's ids only)
@@ -127,6 +129,57 @@ __global__ __launch_bounds__(256) void nbr_gather_kernel(const int64_t* __restri
         const int64_t idx = global_offsets[i] + ((rand_samples && deg > capped[i]) ? (rand_samples[p] % deg) : k);
         const int64_t* e = sorted_edges + idx * cols;
         int64_t* o = out + p * cols;
+        o[0] = e[0];
+        o[1] = e[1];
+        if (cols == 3) o[2] = e[2];
+    }
+}
+
+// ---- dropout sampler: keep flags + their tile sums; after the scan of the flags S: output position of a kept neighbour p is S[p] (masked_select's
+// order is the global order) and a node's new local offset is S at its first neighbour
+__global__ __launch_bounds__(NB_T) void nbr_keep_flags_kernel(const float* __restrict__ keep_rand, int64_t total, float rate, int64_t* __restrict__ keep,
+                                                              int64_t* __restrict__ tile_sums) {
+    __shared__ int64_t red[NB_T / 64];
+    const int64_t base = (int64_t)blockIdx.x * NB_TILE;
+    int64_t mine = 0;
+#pragma unroll
+    for (int r = 0; r < NB_ITEMS; ++r) {
+        const int64_t p = base + r * NB_T + threadIdx.x;
+        if (p < total) {
+            const int64_t k = keep_rand[p] >= rate ? 1 : 0;  // torch::ge(keep_mask, rate): neighbor.cpp:243-244
+            keep[p] = k;
+            mine += k;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t s = 0;
+        for (int w = 0; w < NB_T / 64; ++w) s += red[w];
+        tile_sums[blockIdx.x] = s;
+    }
+}
+__global__ __launch_bounds__(256) void nbr_dropout_offsets_kernel(const int64_t* __restrict__ local_offsets, int64_t n, const int64_t* __restrict__ scan, int64_t total,
+                                                                  const int64_t* __restrict__ total_kept, int64_t* __restrict__ new_local_offsets) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t lo = local_offsets[i];
+        new_local_offsets[i] = lo < total ? scan[lo] : *total_kept;
+    }
+}
+__global__ __launch_bounds__(256) void nbr_dropout_emit_kernel(const int64_t* __restrict__ sorted_edges, int cols, const int64_t* __restrict__ global_offsets,
+                                                               const int64_t* __restrict__ local_offsets, int64_t n, const int64_t* __restrict__ keep,
+                                                               const int64_t* __restrict__ scan, int64_t total, int64_t* __restrict__ out) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        if (!keep[p]) continue;
+        int64_t lo = 0, hi = n;
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (local_offsets[mid] <= p) lo = mid; else hi = mid;
+        }
+        const int64_t* e = sorted_edges + (global_offsets[lo] + (p - local_offsets[lo])) * cols;
+        int64_t* o = out + scan[p] * cols;
         o[0] = e[0];
         o[1] = e[1];
         if (cols == 3) o[2] = e[2];
@@ -278,6 +331,35 @@ extern "C" int marius_nbr_gather(const int64_t* sorted_edges, int32_t cols, cons
     MARIUS_REQUIRE(sorted_edges && num && global_offsets && local_offsets && capped && out_edges && n > 0, "nbr_gather: null pointer");
     nbr_gather_kernel<<<dim3(nb_blocks(total, 256)), dim3(256), 0, as_stream(stream)>>>(sorted_edges, cols, num, global_offsets, local_offsets, capped, n, rand_samples, total, out_edges);
     return check_launch("nbr_gather");
+}
+
+extern "C" int marius_nbr_dropout_offsets(const int64_t* local_offsets, int64_t n, int64_t total, const float* keep_rand, float rate, int64_t* keep, int64_t* scan,
+                                          int64_t* new_local_offsets, int64_t* total_kept_dev, void* workspace, size_t workspace_bytes, marius_stream_t stream) {
+    MARIUS_REQUIRE(n >= 0 && total >= 0 && total_kept_dev && workspace, "nbr_dropout_offsets: bad arguments");
+    MARIUS_REQUIRE(workspace_bytes >= marius_nbr_workspace_bytes(total), "nbr_dropout_offsets: workspace too small (marius_nbr_workspace_bytes(total))");
+    hipStream_t st = as_stream(stream);
+    int64_t* tiles = (int64_t*)workspace;
+    const int64_t ntiles = total > 0 ? cdiv(total, NB_TILE) : 0;
+    if (total > 0) {
+        MARIUS_REQUIRE(keep_rand && keep && scan, "nbr_dropout_offsets: null pointer");
+        nbr_keep_flags_kernel<<<dim3((unsigned)ntiles), dim3(NB_T), 0, st>>>(keep_rand, total, rate, keep, tiles);
+    }
+    nbr_scan_tiles_kernel<<<dim3(1), dim3(NB_T), 0, st>>>(tiles, ntiles, total_kept_dev);
+    if (total > 0) nbr_local_offsets_kernel<<<dim3((unsigned)ntiles), dim3(NB_T), 0, st>>>(keep, total, tiles, scan);
+    if (n > 0) {
+        MARIUS_REQUIRE(local_offsets && new_local_offsets, "nbr_dropout_offsets: null pointer");
+        nbr_dropout_offsets_kernel<<<dim3(nb_blocks(n, 256)), dim3(256), 0, st>>>(local_offsets, n, scan, total, total_kept_dev, new_local_offsets);
+    }
+    return check_launch("nbr_dropout_offsets");
+}
+
+extern "C" int marius_nbr_dropout_emit(const int64_t* sorted_edges, int32_t cols, const int64_t* global_offsets, const int64_t* local_offsets, int64_t n,
+                                       const int64_t* keep, const int64_t* scan, int64_t total, int64_t* out_edges, marius_stream_t stream) {
+    MARIUS_REQUIRE((cols == 2 || cols == 3) && n >= 0 && total >= 0, "nbr_dropout_emit: bad arguments");
+    if (total == 0) return MARIUS_OK;
+    MARIUS_REQUIRE(sorted_edges && global_offsets && local_offsets && keep && scan && out_edges && n > 0, "nbr_dropout_emit: null pointer");
+    nbr_dropout_emit_kernel<<<dim3(nb_blocks(total, 256)), dim3(256), 0, as_stream(stream)>>>(sorted_edges, cols, global_offsets, local_offsets, n, keep, scan, total, out_edges);
+    return check_launch("nbr_dropout_emit");
 }
 
 extern "C" int marius_nbr_delta_ids(const int64_t* in_edges, int64_t n_in, const int64_t* out_edges, int64_t n_out, int32_t cols, const int64_t* node_ids,

@@ -37,7 +37,7 @@ class MariusGraph:
         self.marks_ = torch.zeros(num_nodes_in_memory, dtype=torch.uint8, device=dev)
         self.positions_ = torch.empty(num_nodes_in_memory, **_i64(dev))
 
-    def getNeighborsForNodeIds(self, node_ids, incoming, max_neighbors=-1, rand=None):
+    def getNeighborsForNodeIds(self, node_ids, incoming, max_neighbors=-1, rand=None, dropout_rate=None, keep_rand=None):
         """graph.cpp:128-236 (ALL: max_neighbors < 0; UNIFORM otherwise).  rand(total) -> int64 [total] in [0, max degree): the draw of
         sample_uniform_gpu (neighbor.cpp:91); default: torch.randint on the device generator, as the reference.  Returns (edges, local_offsets)."""
         dev = node_ids.device
@@ -51,6 +51,21 @@ class MariusGraph:
         H.check(H.lib().marius_nbr_degrees(H.ptr(node_ids), n, H.ptr(tbl_num), H.ptr(tbl_off), max_neighbors, H.ptr(num), H.ptr(goff), H.ptr(capped), H.ptr(loff),
                                            H.ptr(total_dev), H.ptr(ws), wsb, H.stream_ptr()), "nbr_degrees")
         total = int(total_dev.item())  # (the reference: summed_num_neighbors[-1].item())
+        if dropout_rate is not None:  # NeighborSamplingLayer::DROPOUT (neighbor.cpp:236-253); keep_rand(total) -> float32 [total]: the reference's torch::rand
+            assert max_neighbors < 0
+            kr = keep_rand(total) if keep_rand is not None else torch.rand(total, device=dev)
+            keep, scan, new_loff = torch.empty(max(total, 1), **_i64(dev)), torch.empty(max(total, 1), **_i64(dev)), torch.empty(n, **_i64(dev))
+            kept_dev = torch.empty(1, **_i64(dev))
+            wsb2 = H.lib().marius_nbr_workspace_bytes(total)
+            ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
+            H.check(H.lib().marius_nbr_dropout_offsets(H.ptr(loff), n, total, H.ptr(kr), float(dropout_rate), H.ptr(keep), H.ptr(scan), H.ptr(new_loff), H.ptr(kept_dev), H.ptr(ws2),
+                                                       wsb2, H.stream_ptr()), "nbr_dropout_offsets")
+            kept = int(kept_dev.item())
+            out = torch.empty((kept, edges.size(1)), **_i64(dev))
+            if kept > 0:
+                H.check(H.lib().marius_nbr_dropout_emit(H.ptr(edges), edges.size(1), H.ptr(goff), H.ptr(loff), n, H.ptr(keep), H.ptr(scan), total, H.ptr(out), H.stream_ptr()),
+                        "nbr_dropout_emit")
+            return out, new_loff
         rs = None
         if max_neighbors >= 0 and total > 0:
             rs = rand(total) if rand is not None else torch.randint(max(max_id, 1), (total,), **_i64(dev))
@@ -133,7 +148,8 @@ class DENSEGraph:
 
 
 class LayeredNeighborSampler:
-    """neighbor.cpp:354-582.  num_neighbors: one entry per layer, -1 = all neighbours (NeighborSamplingLayer::ALL), k >= 0 = UNIFORM with max_neighbors k"""
+    """neighbor.cpp:354-582.  num_neighbors: one entry per layer, -1 = all neighbours (NeighborSamplingLayer::ALL), k >= 0 = UNIFORM with max_neighbors k,
+    ("dropout", rate) = DROPOUT"""
 
     def __init__(self, graph, num_neighbors, use_incoming_nbrs=True, use_outgoing_nbrs=False):
         self.graph_, self.num_neighbors_ = graph, list(num_neighbors)
@@ -152,10 +168,16 @@ class LayeredNeighborSampler:
         for i, fan in enumerate(self.num_neighbors_):
             d_in = d_in_offs = d_out = d_out_offs = None
             if delta_ids.size(0) > 0:
+                def hop(incoming):
+                    draw = None if rand is None else (lambda t, i=i: rand(i, incoming, t))
+                    if isinstance(fan, tuple):  # ("dropout", rate): NeighborSamplingLayer::DROPOUT
+                        return g.getNeighborsForNodeIds(delta_ids, incoming, -1, None, fan[1], draw)
+                    return g.getNeighborsForNodeIds(delta_ids, incoming, fan, draw)
+
                 if self.use_incoming_nbrs_:
-                    d_in, d_in_offs = g.getNeighborsForNodeIds(delta_ids, True, fan, None if rand is None else (lambda t, i=i: rand(i, True, t)))
+                    d_in, d_in_offs = hop(True)
                 if self.use_outgoing_nbrs_:
-                    d_out, d_out_offs = g.getNeighborsForNodeIds(delta_ids, False, fan, None if rand is None else (lambda t, i=i: rand(i, False, t)))
+                    d_out, d_out_offs = hop(False)
             if in_offs is not None:
                 if d_in_offs is not None and d_in_offs.size(0) > 0:
                     in_offs = torch.cat([d_in_offs, in_offs + d_in.size(0)], 0)

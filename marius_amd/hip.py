@@ -105,6 +105,8 @@ SIGNATURES = {
     "marius_nbr_workspace_bytes": (_sz, [_i64]),
     "marius_nbr_degrees": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "marius_nbr_gather": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "marius_nbr_dropout_offsets": (C.c_int, [_vp, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "marius_nbr_dropout_emit": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
     "marius_nbr_delta_ids": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "marius_nbr_positions": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i64, _vp, _vp, _vp]),
     "marius_segment_gather_sum": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp]),

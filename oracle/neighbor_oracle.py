@@ -78,8 +78,22 @@ def sample_uniform(edges, global_offsets, local_offsets, num_neighbors, max_neig
     return edges.index_select(0, idx), local_offsets
 
 
-def neighbors_for_node_ids(graph, node_ids, incoming, max_neighbors=-1, rand_samples=None):
-    """graph.cpp:128-236, device branch; max_neighbors < 0: NeighborSamplingLayer::ALL, else UNIFORM"""
+def sample_dropout(edges, global_offsets, local_offsets, num_neighbors, rate, keep_rand):
+    """neighbor.cpp:236-253; keep_rand: the reference's torch::rand(total)"""
+    repeated_starts = global_offsets.repeat_interleave(num_neighbors)
+    repeated_offsets = local_offsets.repeat_interleave(num_neighbors)
+    arange = torch.arange(repeated_offsets.size(0))
+    sorted_list_idx = repeated_starts + arange - repeated_offsets
+    keep_mask = torch.ge(keep_rand, rate)
+    sorted_list_idx = sorted_list_idx.masked_select(keep_mask)
+    capped = segmented_sum_with_offsets(keep_mask.to(torch.int64), local_offsets)
+    summed = capped.cumsum(0)
+    local_offsets = summed - capped
+    return edges.index_select(0, sorted_list_idx), local_offsets
+
+
+def neighbors_for_node_ids(graph, node_ids, incoming, max_neighbors=-1, rand_samples=None, dropout_rate=None, keep_rand=None):
+    """graph.cpp:128-236, device branch; max_neighbors < 0: NeighborSamplingLayer::ALL, else UNIFORM; dropout_rate: DROPOUT"""
     if incoming:
         num_neighbors = graph.in_num_neighbors.index_select(0, node_ids)
         global_offsets = graph.in_offsets.index_select(0, node_ids)
@@ -90,6 +104,8 @@ def neighbors_for_node_ids(graph, node_ids, incoming, max_neighbors=-1, rand_sam
         edges = graph.src_sorted_edges
     summed = num_neighbors.cumsum(0)
     local_offsets = summed - num_neighbors
+    if dropout_rate is not None:
+        return sample_dropout(edges, global_offsets, local_offsets, num_neighbors, dropout_rate, keep_rand)
     if max_neighbors < 0:
         return sample_all(edges, global_offsets, local_offsets, num_neighbors)
     return sample_uniform(edges, global_offsets, local_offsets, num_neighbors, max_neighbors, rand_samples)
@@ -100,7 +116,7 @@ class DENSEGraph:
 
 
 def layered_neighbors(graph, node_ids, fanouts, use_incoming=True, use_outgoing=False, rand=None):
-    """LayeredNeighborSampler::getNeighbors (neighbor.cpp:402-582), device branch.  fanouts: one entry per layer, -1 = ALL.
+    """LayeredNeighborSampler::getNeighbors (neighbor.cpp:402-582), device branch.  fanouts: one entry per layer, -1 = ALL, k >= 0 = UNIFORM, ("dropout", rate).
     rand(layer, incoming: bool, total) -> int64 [total] in [0, max degree): the randint of sample_uniform_gpu."""
     hop_offsets = torch.zeros(1, dtype=torch.int64)
     delta_ids = node_ids
@@ -110,16 +126,18 @@ def layered_neighbors(graph, node_ids, fanouts, use_incoming=True, use_outgoing=
     for i, fan in enumerate(fanouts):
         d_in_edges = d_in_offs = d_out_edges = d_out_offs = None
         if delta_ids.size(0) > 0:
-            if use_incoming:
-                rs = None
-                if fan >= 0:
-                    rs = rand(i, True, uniform_total(graph.in_num_neighbors.index_select(0, delta_ids), fan))
-                d_in_edges, d_in_offs = neighbors_for_node_ids(graph, delta_ids, True, fan, rs)
-            if use_outgoing:
-                rs = None
-                if fan >= 0:
-                    rs = rand(i, False, uniform_total(graph.out_num_neighbors.index_select(0, delta_ids), fan))
-                d_out_edges, d_out_offs = neighbors_for_node_ids(graph, delta_ids, False, fan, rs)
+            for incoming in ((True,) if use_incoming else ()) + ((False,) if use_outgoing else ()):
+                tbl = graph.in_num_neighbors if incoming else graph.out_num_neighbors
+                if isinstance(fan, tuple):  # ("dropout", rate): NeighborSamplingLayer::DROPOUT; rand(...) -> the torch::rand draw, float32 [total degree]
+                    kr = rand(i, incoming, int(tbl.index_select(0, delta_ids).sum()))
+                    res = neighbors_for_node_ids(graph, delta_ids, incoming, -1, None, fan[1], kr)
+                else:
+                    rs = rand(i, incoming, uniform_total(tbl.index_select(0, delta_ids), fan)) if fan >= 0 else None
+                    res = neighbors_for_node_ids(graph, delta_ids, incoming, fan, rs)
+                if incoming:
+                    d_in_edges, d_in_offs = res
+                else:
+                    d_out_edges, d_out_offs = res
         if incoming_offsets is not None:
             if d_in_offs is not None and d_in_offs.size(0) > 0:
                 incoming_offsets = incoming_offsets + d_in_edges.size(0)

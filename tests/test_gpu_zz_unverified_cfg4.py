@@ -69,6 +69,24 @@ def test_one_hop_sampler_bit_exact(G, dev, num_nodes, E, cols, max_neighbors):
             assert torch.equal(got.cpu(), want) and torch.equal(got_offs.cpu(), want_offs)
 
 
+@pytest.mark.parametrize("cols", [2, 3])
+@pytest.mark.parametrize("rate", [0.0, 0.3, 0.9, 1.5])
+def test_one_hop_dropout_sampler_bit_exact(G, dev, cols, rate):
+    """sample_dropout_gpu (neighbor.cpp:236-253): the kept neighbours in masked_select's order and the nodes' new offsets, from the same torch::rand draw"""
+    og = make_graph(800, 12000, cols, seed=31 + cols)
+    dg = to_device(G, og, dev)
+    g = torch.Generator().manual_seed(int(rate * 10) + 3)
+    for n in (1, 7, 1500):
+        ids = torch.randint(800, (n,), generator=g)
+        ids[0], ids[-1] = 3, 799
+        for incoming in (True, False):
+            tbl = og.in_num_neighbors if incoming else og.out_num_neighbors
+            kr = torch.rand(int(tbl.index_select(0, ids).sum()), generator=g)
+            want, want_offs = NO.neighbors_for_node_ids(og, ids, incoming, -1, None, rate, kr)
+            got, got_offs = dg.getNeighborsForNodeIds(ids.to(dev), incoming, -1, None, rate, lambda t, kr=kr: kr.to(dev))
+            assert torch.equal(got.cpu(), want) and torch.equal(got_offs.cpu(), want_offs)
+
+
 def test_one_hop_sampler_empty_request(G, dev):
     og = make_graph(50, 300, 2, seed=1)
     dg = to_device(G, og, dev)

@@ -22,7 +22,7 @@ def E():
 
     lib = C.CDLL(build_emul.build(sanitize=os.environ.get("MARIUS_EMUL_SANITIZE") == "1"))
     for name in ("marius_nbr_workspace_bytes", "marius_nbr_degrees", "marius_nbr_gather", "marius_nbr_delta_ids", "marius_nbr_positions", "marius_segment_gather_sum",
-                 "marius_sort_unique_workspace_bytes"):
+                 "marius_sort_unique_workspace_bytes", "marius_nbr_dropout_offsets", "marius_nbr_dropout_emit"):
         res, args = hip.SIGNATURES[name]  # the same signature table the HIP library is bound with
         getattr(lib, name).restype, getattr(lib, name).argtypes = res, args
     return lib
@@ -163,6 +163,14 @@ def test_emulated_aggregation_is_bit_identical_to_the_cpu_op_sequence(E, d, aggr
     assert torch.allclose(grad, xr.grad, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("rate", [0.0, 0.3, 0.9, 1.5])
+def test_emulated_dropout_sampler_equals_the_oracle(G_emul, rate):
+    import test_gpu_zz_unverified_cfg4 as TZ
+
+    for cols in (2, 3):
+        TZ.test_one_hop_dropout_sampler_bit_exact(G_emul, torch.device("cpu"), cols, rate)
+
+
 @pytest.fixture()
 def G_emul(E, monkeypatch):
     """marius_amd/gnn.py — the host-side mirror of MariusGraph / LayeredNeighborSampler / DENSEGraph / GraphSageLayer — driven on CPU tensors with the
@@ -194,7 +202,7 @@ def G_emul(E, monkeypatch):
     return gnn
 
 
-@pytest.mark.parametrize("fanouts,inc,out", [([-1], True, False), ([5, 3], True, True), ([4, 0, 2], True, False), ([2, -1], False, True)])
+@pytest.mark.parametrize("fanouts,inc,out", [([-1], True, False), ([5, 3], True, True), ([4, 0, 2], True, False), ([2, -1], False, True), ([("dropout", 0.5), 3], True, True)])
 def test_emulated_host_mirror_layered_sampler_equals_the_oracle(G_emul, fanouts, inc, out):
     og = graph(600, 5000, 3, seed=21)
     dgraph = G_emul.MariusGraph(og.src_sorted_edges, og.dst_sorted_edges, og.num_nodes_in_memory)
@@ -203,7 +211,8 @@ def test_emulated_host_mirror_layered_sampler_equals_the_oracle(G_emul, fanouts,
     draws = {}
 
     def rand_cpu(i, incoming, t):
-        draws[(i, incoming)] = torch.randint(1 << 40, (t,), generator=torch.Generator().manual_seed(100 + 2 * i + int(incoming)))
+        gen = torch.Generator().manual_seed(100 + 2 * i + int(incoming))
+        draws[(i, incoming)] = torch.rand(t, generator=gen) if isinstance(fanouts[i], tuple) else torch.randint(1 << 40, (t,), generator=gen)
         return draws[(i, incoming)]
 
     want = NO.layered_neighbors(og, seeds, fanouts, inc, out, rand=rand_cpu)
